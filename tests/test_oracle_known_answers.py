@@ -1,0 +1,185 @@
+"""Known-answer tests that pin the oracle to identities derivable from the reference's own
+formulas; the reference ships no tests or golden vectors."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import sqair_oracle as O
+from sqair_amd.flags import make_flags
+from sqair_amd.params import count_params, init_params, param_spec
+
+D = torch.float64
+
+
+def test_param_count_matches_reference_listing():
+    # reference: notebooks/play.ipynb:362 (2 951 522 at N=3, 50x50) and per-scope :249,296,301,349,357
+    F = make_flags(n_steps_per_image=3)
+    assert count_params(F, (50, 50)) == 2951522
+    spec = param_spec(F, (50, 50))
+    scope = {}
+    for name, shape, _, tf in spec:
+        scope[tf.split("/")[0]] = scope.get(tf.split("/")[0], 0) + int(np.prod(shape))
+    assert scope == {"decoder": 184149, "discovery": 1403398, "model": 8, "propagation": 1283583,
+                     "sequence": 80384}
+    # N-dependence: only the [N+1] vectors and the [10, N+1] layer
+    F4 = make_flags(n_steps_per_image=4)
+    assert count_params(F4, (50, 50)) - 2951522 == 2 + 10 + 1
+
+
+def test_st_crop_identity():
+    # (sx,sy,tx,ty) = (1,1,0,0) with G=H=W returns the image (modules.py:170-218)
+    img = torch.rand(2, 9, 9, dtype=D)
+    big = 40.0  # sigmoid(40) == 1.0 in fp64
+    where = torch.tensor([[big, big, 0.0, 0.0]] * 2, dtype=D)
+    assert torch.allclose(O.st_crop(img, where, 9), img, atol=1e-12)
+
+
+def test_st_crop_matches_grid_sample():
+    # resampler == grid_sample(bilinear, zeros, align_corners=True) on (sx xn + tx, sy yn + ty)
+    torch.manual_seed(0)
+    img = torch.rand(5, 13, 17, dtype=D)
+    where = torch.randn(5, 4, dtype=D) * 1.5
+    G = 6
+    sx, sy, tx, ty = O.to_coords(where)
+    g = torch.linspace(-1, 1, G, dtype=D)
+    gx = (sx[:, None] * g[None] + tx[:, None])[:, None, :].expand(-1, G, -1)
+    gy = (sy[:, None] * g[None] + ty[:, None])[:, :, None].expand(-1, -1, G)
+    ref = torch.nn.functional.grid_sample(img[:, None], torch.stack([gx, gy], -1), mode="bilinear",
+                                          padding_mode="zeros", align_corners=True)[:, 0]
+    assert torch.allclose(O.st_crop(img, where, G), ref, atol=1e-12)
+
+
+def test_insert_after_crop_is_identity_on_support():
+    # a glimpse that covers the whole image at the same resolution: insert(crop(x)) == x
+    img = torch.rand(1, 7, 7, dtype=D)
+    where = torch.tensor([[40.0, 40.0, 0.0, 0.0]], dtype=D)
+    g = O.st_crop(img, where, 7)
+    assert torch.allclose(O.st_insert(g, where, 7, 7), img, atol=1e-10)
+
+
+def test_insert_zero_outside_glimpse():
+    ones = torch.ones(1, 20, 20, dtype=D)
+    where = torch.tensor(O.to_logits([[0.3, 0.3, 0.2, -0.1]]), dtype=D)
+    m = O.st_insert(ones, where, 50, 50)[0]
+    y, x, h, w = O.stn_to_pixel_coords(np.array([0.3, 0.3, 0.2, -0.1]), (50, 50))
+    assert m.max() <= 1 + 1e-12 and m.min() >= 0
+    inside = m[int(y + 3):int(y + 10), int(x + 3):int(x + 10)]
+    assert torch.allclose(inside, torch.ones_like(inside), atol=1e-9)
+    assert float(m[0, 0]) == 0.0 and float(m[-1, -1]) == 0.0
+
+
+def test_stn_pixel_round_trip_and_logits():
+    # modules.py:246-280 and :221-243
+    stn = np.array([[0.4, 0.25, -0.3, 0.55]])
+    px = O.stn_to_pixel_coords(stn, (50, 40))
+    assert np.allclose(O.pixel_to_stn_coords(px, (50, 40)), stn)
+    lg = O.to_logits(stn)
+    sx, sy, tx, ty = O.to_coords(torch.tensor(lg, dtype=D))
+    assert np.allclose(torch.stack([sx, sy, tx, ty], -1).numpy(), stn, atol=1e-12)
+
+
+def test_modified_geometric():
+    # prior.py:61-67
+    j = O.bernoulli_to_modified_geometric(torch.tensor([[0.5, 0.5, 0.5]], dtype=D))
+    assert torch.allclose(j, torch.tensor([[0.5, 0.25, 0.125, 0.125]], dtype=D))
+    lp = O.num_steps_log_prob(j, torch.tensor([2.0], dtype=D))
+    assert abs(float(lp) - math.log(0.125)) < 1e-12
+    # zero probability is clipped at 1e-16 (prior.py:98)
+    j0 = O.bernoulli_to_modified_geometric(torch.tensor([[0.0, 0.3]], dtype=D))
+    assert abs(float(O.num_steps_log_prob(j0, torch.tensor([2.0], dtype=D))) - math.log(1e-16)) < 1e-9
+
+
+def test_iwae_and_vimco_control_variate():
+    # targets.py:38-59
+    w = torch.full((3, 5), -7.25, dtype=D)
+    assert torch.allclose(O.iwae(w), torch.full((3,), -7.25, dtype=D))
+    w2 = torch.tensor([[1.0, -2.0]], dtype=D)
+    cv = O.vimco_control_variate(w2)  # K=2: replacing w_j by the other one -> logmeanexp = other
+    assert torch.allclose(cv, torch.tensor([[-2.0, 1.0]], dtype=D))
+
+
+def test_vimco_gradient_structure():
+    # targets.py:62-75: d loss / d log_probs = -signal / (B K), signal = stopgrad(log_w - cv)
+    torch.manual_seed(1)
+    lw = torch.randn(4, 3, dtype=D, requires_grad=True)
+    lp = torch.randn(4, 3, dtype=D, requires_grad=True)
+    loss = O.vimco(lw, lp)
+    loss.backward()
+    sig = (lw - O.vimco_control_variate(lw)).detach()
+    assert torch.allclose(lp.grad, -sig / 12.0)
+    assert torch.allclose(lw.grad, -torch.softmax(lw.detach(), -1) / 4.0)
+
+
+def test_select_present_and_ids():
+    # index.py:132-165, :198-221
+    x = torch.tensor([[[1.0], [2.0], [3.0], [4.0]]], dtype=D)
+    pres = torch.tensor([[0.0, 1.0, 0.0, 1.0]], dtype=D)
+    assert O.select_present(x, pres).flatten().tolist() == [2.0, 4.0, 1.0, 3.0]
+    last, ids = O.compute_object_ids(torch.tensor([[2.0]], dtype=D), torch.tensor([[[5.0], [7.0]]], dtype=D),
+                                     torch.tensor([[[1.0], [0.0]]], dtype=D), torch.tensor([[[1.0], [1.0]]], dtype=D))
+    assert last.flatten().tolist() == [4.0]
+    assert ids.flatten().tolist() == [5.0, -1.0, 3.0, 4.0]
+
+
+def test_tile_input_ordering():
+    # index.py:106-129: b' = b*K + k
+    x = torch.arange(6, dtype=D).reshape(1, 3, 2)
+    t = O.tile_input_for_iwae(x, 2)
+    assert t[0, :, 0].tolist() == [0, 0, 2, 2, 4, 4]
+
+
+def test_fill_triangular_convention():
+    t = O.fill_triangular(torch.arange(1.0, 7.0, dtype=D), 3)
+    assert t.tolist() == [[4, 0, 0], [6, 5, 0], [3, 2, 1]]
+
+
+def test_bernoulli_and_absent_slots_stay_absent():
+    # modules.py:513, propagate.py:86: absent slot -> logit -88 -> presence 0, log-prob ~ 0
+    lp = O.bernoulli_log_prob(torch.tensor(0.0, dtype=D), torch.tensor(-88.0, dtype=D))
+    assert abs(float(lp)) < 1e-30
+    F = make_flags(n_steps_per_image=2, k_particles=1)
+    cfg = O.make_cfg(F, (12, 12))
+    P = init_params(F, (12, 12), seed=3, jitter=0.1)
+    orc = O.SqairOracle(P, cfg)
+    rng = np.random.default_rng(0)
+    obs = rng.uniform(size=(2, 3, 12, 12))
+    nz = rng.standard_normal((2, 3, 2, 2, O.noise_width(cfg)))
+    nz[..., -1] = 0.0  # u = 0: every live Bernoulli fires, dead ones (logit -88) must not
+    m = orc.model(obs, nz)
+    assert float(m.prop_pres[0].abs().sum()) == 0.0  # nothing to propagate at t=0
+    assert torch.all(m.disc_pres[0] == 1.0)
+    assert torch.all(m.obj_id[0] == torch.tensor([0.0, 1.0], dtype=D))
+    # at t=1 both slots are propagated (u=0), discoveries are all present but truncated away
+    assert torch.all(m.prop_pres[1] == 1.0) and torch.all(m.presence[1] == 1.0)
+    assert torch.all(m.obj_id[1] == torch.tensor([0.0, 1.0], dtype=D))
+    assert torch.all(m.num_steps_per_sample == 2.0)
+
+
+def test_every_parameter_receives_gradient():
+    # reference asserts the same at model.py:163-166
+    F = make_flags(n_steps_per_image=2, k_particles=2)
+    cfg = O.make_cfg(F, (16, 16))
+    orc = O.SqairOracle(init_params(F, (16, 16), seed=0, jitter=0.05), cfg, requires_grad=True)
+    rng = np.random.default_rng(1)
+    obs = rng.uniform(size=(3, 2, 16, 16))
+    nz = rng.standard_normal((3, 4, 2, 2, O.noise_width(cfg)))
+    nz[..., -1] = rng.uniform(size=nz.shape[:-1])
+    m = orc.model(obs, nz)
+    orc.make_target(m).backward()
+    assert [k for k, v in orc.P.items() if v.grad is None] == []
+    assert all(torch.isfinite(v.grad).all() for v in orc.P.values())
+
+
+def test_fp32_mode_close_to_fp64():
+    F = make_flags(n_steps_per_image=2, k_particles=2)
+    cfg = O.make_cfg(F, (16, 16))
+    P = init_params(F, (16, 16), seed=0, jitter=0.05)
+    rng = np.random.default_rng(1)
+    obs = rng.uniform(size=(3, 2, 16, 16))
+    nz = rng.standard_normal((3, 4, 2, 2, O.noise_width(cfg)))
+    nz[..., -1] = rng.uniform(size=nz.shape[:-1])
+    a = O.SqairOracle(P, cfg, torch.float64).model(obs, nz)
+    b = O.SqairOracle(P, cfg, torch.float32).model(obs, nz)
+    if torch.equal(a.presence, b.presence.double()):
+        assert abs(float(a.elbo_iwae) - float(b.elbo_iwae)) <= 1e-4 * abs(float(a.elbo_iwae))
