@@ -1,0 +1,189 @@
+/*
+ * sqair_hip.h — C-ABI of the MI355X-native SQAIR Discover/Propagate hot path (libsqair_hip.so).
+ *
+ * The reference (akosiorek/sqair) has no native/FFI layer: its operator API for this path is the
+ * Python factory  load(img, coords, num, mean_img, debug) -> Model
+ *   (reference: sqair/configs/mlp_mnist_model.py:74-150, called through
+ *    sqair/experiment_tools.py:147-157 from sqair/scripts/experiment.py:118 and scripts/eval.py:138)
+ * and the Model object it returns (reference: sqair/model.py:33-214).  This header is the boundary a
+ * maintainer would bind from that Python side (ctypes stub in INTEGRATION.md); sqair_amd/ mirrors
+ * load()/Model on top of it.
+ *
+ * Conventions
+ *   - plain C symbols, no C++/torch types; every tensor is caller-owned DEVICE memory, contiguous
+ *     row-major float32 (HBM-resident torch tensors' data_ptr() in practice);
+ *   - the library allocates no device memory: parameters are re-laid-out into a caller-provided
+ *     "packed" buffer, all intermediates live in a caller-provided workspace;
+ *   - every launch function takes a hipStream_t (passed as void*) and is asynchronous on it;
+ *   - return value 0 = ok, negative = error (message via sqair_last_error); one handle per
+ *     (device, stream), not thread-safe across threads sharing a handle.
+ *
+ * Row convention: B' = B*K rows, particle-contiguous (b' = b*K + k), the layout
+ * index.tile_input_for_iwae produces (reference: sqair/index.py:106-129) — the tiled observation is
+ * never materialised, kernels index obs[t, b'/K].
+ */
+#ifndef SQAIR_HIP_H
+#define SQAIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQAIR_ABI_VERSION 1
+
+/* Hyper-parameters of the path.  Field names follow the reference flags
+ * (reference: sqair/common_model_flags.py:32-56, sqair/configs/mlp_mnist_model.py:42-52). */
+typedef struct SqairConfig {
+  int32_t img_h, img_w;          /* H, W of a (grayscale) frame                                  */
+  int32_t glimpse_size;          /* G, flag glimpse_size                                         */
+  int32_t n_steps_per_image;     /* N object slots, flag n_steps_per_image                       */
+  int32_t n_what;                /* flag n_what                                                  */
+  int32_t n_hidden;              /* 32 * n_units (get_params, common_model_flags.py:59-71)       */
+  int32_t k_particles;           /* K, flag k_particles                                          */
+  int32_t prop_prior_type;       /* 0 = rnn, 1 = rw, 2 = guided (propagate.py:36-40)             */
+  int32_t disc_prior_type;       /* 0 = cat, 1 = geom (sqair_modules.py:204-224)                 */
+  int32_t masked_glimpse;        /* flag masked_glimpse                                          */
+  int32_t rec_where_prior;       /* flag rec_where_prior                                         */
+  float prop_prior_step_bias;    /* flag prop_prior_step_bias                                    */
+  float step_success_prob;       /* flag step_success_prob (geom prior only)                     */
+  float output_std;              /* effective p(x|z) std: fl32(fl32(sqrt(flag))^2), modules.py:419-422 */
+  float background_std;          /* same for background pixels (bg_std=None -> output_std)       */
+  float where_prior_mean[4];     /* scale_prior x2, 0, 0 (non-recurrent where prior only)        */
+} SqairConfig;
+
+typedef struct SqairHandle SqairHandle;
+
+/* ---- lifetime / introspection (host only: usable without a GPU) -------------------------------- */
+int sqair_abi_version(void);
+int sqair_create(const SqairConfig* cfg, SqairHandle** out);
+int sqair_destroy(SqairHandle* h);
+const char* sqair_last_error(const SqairHandle* h);
+
+/* Flat parameter buffer = the reference's trainable variables in the order of SURVEY.md Appendix C
+ * (reference listing: notebooks/play.ipynb:239-362), each row-major fp32, no padding.
+ * sqair_param_entry enumerates (name, offset, numel) so the Python side can cross-check its spec. */
+int64_t sqair_param_count(const SqairHandle* h);
+int sqair_param_entries(const SqairHandle* h);
+int sqair_param_entry(const SqairHandle* h, int i, const char** name, int64_t* offset, int64_t* numel);
+
+/* Sizes (bytes) of the caller-provided buffers. */
+int64_t sqair_packed_bytes(const SqairHandle* h);
+int64_t sqair_workspace_bytes(const SqairHandle* h, int T, int B);
+int sqair_noise_width(const SqairHandle* h); /* 4 + n_what + 1 */
+
+/* ---- parameters ------------------------------------------------------------------------------- */
+/* Re-lays the flat parameters out for the MFMA kernels (16x16x4-fp32 fragment order, K padded per
+ * input segment, loop-invariant sub-matrices grouped) into `packed`.  Call after every parameter
+ * update.  Replaces variable creation inside load() (mlp_mnist_model.py:99-148). */
+int sqair_pack_params(SqairHandle* h, const float* flat_params, void* packed, void* stream);
+
+/* ---- the forward pass --------------------------------------------------------------------------
+ * Per-frame outputs, every pointer optional (NULL = not written); shapes are [T, B', ...] exactly
+ * as the TensorArrays of SequentialAIR (reference: sqair/seq.py:121-177).  */
+typedef struct SqairOutputs {
+  float* what;                       /* [T,B',N,n_what] */
+  float* what_loc;                   /* [T,B',N,n_what] */
+  float* what_scale;                 /* [T,B',N,n_what] */
+  float* where;                      /* [T,B',N,4] */
+  float* where_loc;                  /* [T,B',N,4] */
+  float* where_scale;                /* [T,B',N,4] */
+  float* presence_prob;              /* [T,B',N] */
+  float* presence;                   /* [T,B',N] */
+  float* presence_logit;             /* [T,B',N] */
+  float* obj_id;                     /* [T,B',N] */
+  float* step_log_prob;              /* [T,B'] */
+  float* canvas;                     /* [T,B',H,W] */
+  float* glimpse;                    /* [T,B',N,G,G] */
+  float* disc_what_log_prob;         /* [T,B',N] */
+  float* disc_where_log_prob;        /* [T,B',N] */
+  float* disc_what_prior_log_prob;   /* [T,B',N] */
+  float* disc_where_prior_log_prob;  /* [T,B',N] */
+  float* disc_log_prob;              /* [T,B'] */
+  float* disc_prior_log_prob;        /* [T,B'] */
+  float* disc_prob;                  /* [T,B',N+1] */
+  float* prop_what_log_prob;         /* [T,B',N] */
+  float* prop_where_log_prob;        /* [T,B',N] */
+  float* prop_what_prior_log_prob;   /* [T,B',N] */
+  float* prop_where_prior_log_prob;  /* [T,B',N] */
+  float* prop_log_prob;              /* [T,B'] */
+  float* prop_prior_log_prob;        /* [T,B'] */
+  float* prop_prob;                  /* [T,B',N] */
+  float* discrete_log_prob;          /* [T,B'] */
+  float* num_prop_steps_per_sample;  /* [T,B'] */
+  float* num_disc_steps_per_sample;  /* [T,B'] */
+  float* num_steps_per_sample;       /* [T,B'] */
+  float* prop_pres;                  /* [T,B',N] */
+  float* disc_pres;                  /* [T,B',N] */
+  float* data_ll_per_sample;         /* [T,B'] */
+  float* kl_per_sample;              /* [T,B'] */
+  float* log_q_z_given_x_per_sample; /* [T,B'] */
+  float* log_p_z_per_sample;         /* [T,B'] */
+  float* log_weights_per_timestep;   /* [T,B']  (required by sqair_elbo) */
+  /* not reference outputs: final recurrent state, for state-level parity checks */
+  float* final_temporal_state;       /* [B',N,n_hidden] */
+  float* final_prior_state;          /* [B',N,n_hidden] */
+  float* final_last_used_id;         /* [B'] */
+} SqairOutputs;
+
+/* Unrolls the model over T frames: replaces SequentialAIR.__call__ on the tiled observation
+ * (reference: sqair/seq.py:69-84 -> _loop_body :179-269 -> SQAIRTimestep sqair_modules.py:446-582 ->
+ * Propagate/Discover -> PropagationCore/DiscoveryCore sqair/core.py:164-359 -> AIRDecoder
+ * sqair/modules.py:435-467 -> _compute_log_weights seq.py:271-276).
+ *   obs    [T,B,H,W] in [0,1]
+ *   noise  [T,B',2,N,noise_width]: s=0 propagation slot k, s=1 discovery step k; entries 0:4 eps of
+ *          `where`, 4:4+n_what eps of `what`, last = uniform u of the presence Bernoulli
+ *   t_offset: index of obs[0] in the full sequence (the categorical step prior is time dependent,
+ *          sqair_modules.py:212-215); 0 for a whole sequence. */
+int sqair_forward(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
+                  const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Same launch sequence recorded once into a HIP graph and replayed (the T x 2N sequential steps
+ * are launch-latency bound).  Pointers are frozen at capture time: the caller keeps the same
+ * buffers and refreshes their contents before each sqair_graph_launch. */
+int sqair_graph_capture(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
+                        const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+int sqair_graph_launch(SqairHandle* h, void* stream);
+int sqair_graph_nodes(const SqairHandle* h); /* kernel nodes in the captured graph */
+
+/* ---- objective ---------------------------------------------------------------------------------
+ * Fused IWAE / VIMCO reductions over [T,B,K] (reference: Model._build sqair/model.py:88-103,
+ * targets.iwae / vimco_control_variate / vimco sqair/targets.py:38-75, make_target model.py:150-158,
+ * ops.ess ops.py:52-59, _imp_weighted_mean model.py:202-205).
+ *   log_w_t, disc_lp_t: [T,B*K]; scalars_out[16]:
+ *     0 elbo_vae  1 elbo_iwae  2 vimco_target (already / T)  3 ess
+ *   iw_means_in/out: optional n_means x [T,B*K] tensors -> n_means importance-weighted per-frame means */
+int sqair_elbo(SqairHandle* h, const float* log_w_t, const float* disc_lp_t, int T, int B,
+               float* log_weights /*[B,K]*/, float* elbo_iwae_per_example /*[B]*/,
+               float* importance_weights /*[B,K]*/, float* vimco_signal /*[B,K]*/, float* scalars_out /*[16]*/,
+               const float* const* iw_means_in, int n_means, float* iw_means_out, void* stream);
+
+/* ---- per-kernel entry points (unit parity tests; same kernels sqair_forward launches) ----------- */
+/* SpatialTransformer forward crop (reference: sqair/modules.py:170-218): img [B,H,W] shared by K
+ * consecutive rows, where_logits [R,4] (R = B*K), optional mask [R,G*G]; out [R,G*G]. */
+int sqair_st_crop(SqairHandle* h, const float* img, const float* where_logits, const float* mask,
+                  float* out, int B, void* stream);
+/* AIRDecoder canvas + Gaussian log-likelihood (reference: sqair/modules.py:435-467, seq.py:271-274):
+ * glimpse [R,N,G*G], where [R,N,4], presence [R,N], img [B,H,W], mean_img [H,W];
+ * canvas [R,H,W] (optional), data_ll [R]. */
+int sqair_st_insert_loglik(SqairHandle* h, const float* glimpse, const float* where_logits,
+                           const float* presence, const float* img, const float* mean_img,
+                           float* canvas, float* data_ll, int B, void* stream);
+/* y = act(x W + b) on the packed MFMA path with an ad-hoc pack of W [K,N] (test helper):
+ * act 0 none, 1 elu, 2 tanh, 3 sigmoid, 4 softplus+0.01. */
+int sqair_linear_test(SqairHandle* h, const float* x, const float* w, const float* b, float* y, int M,
+                      int Kdim, int Ndim, int act, void* scratch, int64_t scratch_bytes, void* stream);
+/* snt.GRU step through the two fused MFMA launches the forward pass uses:
+ * x [M,Kx], hstate [M,n_hidden]; gru_flat = for g in (z,r,h): w_g [Kx,nh], u_g [nh,nh], b_g [nh]
+ * (the order of the reference's GRU variables inside the flat parameter buffer). */
+int sqair_gru_test(SqairHandle* h, const float* x, const float* hstate, const float* gru_flat, float* h_out,
+                   int M, int Kx, void* scratch, int64_t scratch_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQAIR_HIP_H */

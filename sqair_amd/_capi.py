@@ -1,0 +1,106 @@
+"""ctypes binding of libsqair_hip.so (C-ABI declared in include/sqair_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``sqair_amd/csrc/build.py``.  There is
+no CPU fallback: if the shared object is missing the import of the HIP path fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsqair_hip.so")
+
+OUTPUT_FIELDS = [
+    "what", "what_loc", "what_scale", "where", "where_loc", "where_scale", "presence_prob", "presence",
+    "presence_logit", "obj_id", "step_log_prob", "canvas", "glimpse", "disc_what_log_prob",
+    "disc_where_log_prob", "disc_what_prior_log_prob", "disc_where_prior_log_prob", "disc_log_prob",
+    "disc_prior_log_prob", "disc_prob", "prop_what_log_prob", "prop_where_log_prob",
+    "prop_what_prior_log_prob", "prop_where_prior_log_prob", "prop_log_prob", "prop_prior_log_prob",
+    "prop_prob", "discrete_log_prob", "num_prop_steps_per_sample", "num_disc_steps_per_sample",
+    "num_steps_per_sample", "prop_pres", "disc_pres", "data_ll_per_sample", "kl_per_sample",
+    "log_q_z_given_x_per_sample", "log_p_z_per_sample", "log_weights_per_timestep",
+    "final_temporal_state", "final_prior_state", "final_last_used_id",
+]
+N_REFERENCE_OUTPUTS = 38  # the TensorArrays of reference sqair/seq.py:121-177
+
+
+class SqairConfig(C.Structure):
+    _fields_ = [
+        ("img_h", C.c_int32), ("img_w", C.c_int32), ("glimpse_size", C.c_int32),
+        ("n_steps_per_image", C.c_int32), ("n_what", C.c_int32), ("n_hidden", C.c_int32),
+        ("k_particles", C.c_int32), ("prop_prior_type", C.c_int32), ("disc_prior_type", C.c_int32),
+        ("masked_glimpse", C.c_int32), ("rec_where_prior", C.c_int32),
+        ("prop_prior_step_bias", C.c_float), ("step_success_prob", C.c_float), ("output_std", C.c_float),
+        ("background_std", C.c_float), ("where_prior_mean", C.c_float * 4),
+    ]
+
+
+class SqairOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in OUTPUT_FIELDS]
+
+
+_PROTOS = {
+    "sqair_abi_version": (C.c_int, []),
+    "sqair_create": (C.c_int, [C.POINTER(SqairConfig), C.POINTER(C.c_void_p)]),
+    "sqair_destroy": (C.c_int, [C.c_void_p]),
+    "sqair_last_error": (C.c_char_p, [C.c_void_p]),
+    "sqair_param_count": (C.c_int64, [C.c_void_p]),
+    "sqair_param_entries": (C.c_int, [C.c_void_p]),
+    "sqair_param_entry": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int64)]),
+    "sqair_packed_bytes": (C.c_int64, [C.c_void_p]),
+    "sqair_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    "sqair_noise_width": (C.c_int, [C.c_void_p]),
+    "sqair_pack_params": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sqair_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                C.c_int, C.POINTER(SqairOutputs), C.c_void_p, C.c_int64, C.c_void_p]),
+    "sqair_graph_capture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_int, C.POINTER(SqairOutputs), C.c_void_p, C.c_int64,
+                                      C.c_void_p]),
+    "sqair_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sqair_graph_nodes": (C.c_int, [C.c_void_p]),
+    "sqair_elbo": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
+                             C.c_void_p]),
+    "sqair_st_crop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "sqair_st_insert_loglik": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_void_p]),
+    "sqair_linear_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "sqair_gru_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_int64, C.c_void_p]),
+    "sqair_debug_layers": (C.c_int, [C.c_void_p]),
+    "sqair_debug_layer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sqair_debug_plan": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]),
+}
+
+EXPORTED_SYMBOLS = [n for n in _PROTOS if not n.startswith("sqair_debug")]
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library (once).  Raises ImportError with the build hint if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libsqair_hip.so is missing ({}): build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `python sqair_amd/csrc/build.py`; sqair_amd has no CPU fallback".format(LIB_PATH))
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.sqair_abi_version() != 1:
+            raise ImportError("libsqair_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(handle, rc, what):
+    if rc != 0:
+        msg = lib().sqair_last_error(handle)
+        raise RuntimeError("{} failed (rc={}): {}".format(what, rc, msg.decode() if msg else ""))

@@ -1,0 +1,1046 @@
+// libsqair_hip.so — handle, parameter inventory, weight packing plan, and the launch sequence of the
+// SQAIR forward pass.  Host code only; kernels live in sqair_linear.hip / sqair_glue.hip.
+//
+// The launch sequence of one frame restates SQAIRTimestep + AIRDecoder (reference:
+// sqair/sqair_modules.py:446-582, sqair/core.py:164-359, sqair/propagate.py:68-184,
+// sqair/modules.py:326-467, sqair/seq.py:179-276) with the loop-invariant work hoisted out of the
+// N-slot recurrences:
+//   * the input-encoder MLP (re-evaluated N times per frame by the reference, core.py:165) runs once
+//     per sequence for all T*B frames as one [T*B, H*W] GEMM, already multiplied by its slice of the
+//     discovery RNN's in_to_hidden matrix;
+//   * everything in a propagation slot that depends only on t-1 quantities (where-bias MLP, mask MLP —
+//     evaluated twice per slot on identical input by the reference, core.py:292,336 —, crop #1 and
+//     its encoder, the temporal-state slices of the RNN / transform / steps-predictor / GRU-gate
+//     pre-activations, the prior GRU) is batched over the N slots up front (M = B'*N rows);
+//   * only the truly sequential part (explaining away: slot k needs slot k-1's sample) remains in
+//     the per-slot chain.
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+#include "sqair_glue.h"
+
+struct ParamEntry {
+  std::string name;
+  int64_t off, numel;
+  int rows, cols;
+};
+
+enum LayerId {
+  L_IENC0, L_IENC1, L_PREDISC, L_PRIOR_GRU1, L_PRIOR_GRU2, L_PRIOR_LIN, L_TAU1, L_WB2, L_MASK2, L_GENC0, L_GENC1,
+  L_WHAT_LOC, L_WHAT_HEAD, L_PRE, L_PROP_RNN, L_PROP_T1, L_PROP_T2, L_PROP_T3, L_PROP_GRU1, L_PROP_GRU2,
+  L_PROP_HEADS, L_PROP_S1, L_LAT0, L_LAT1, L_PRED, L_RNCOND, L_DISC_RNN, L_DISC_T1, L_DISC_T2, L_DISC_T3,
+  L_DISC_S1, L_DEC0, L_DEC1, L_DEC2, L_COUNT
+};
+
+struct SqairHandle {
+  SqairConfig cfg;
+  std::string err;
+  std::vector<ParamEntry> params;
+  std::map<std::string, int> pidx;
+  int64_t n_params = 0;
+  POff po;
+  // packing plan
+  PackedLayer layers[L_COUNT];
+  std::vector<int> widx;            // per packed weight element: index into flat params or -1
+  std::vector<int> bidx_a, bidx_b;  // per packed bias element
+  int64_t packed_w = 0, packed_b = 0;
+  bool plan_uploaded_to = false;
+  const void* plan_uploaded_ptr = nullptr;
+  // graph
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_nodes = 0;
+};
+
+void sq_set_error(SqairHandle* h, const std::string& msg) {
+  if (h) h->err = msg;
+}
+
+// ------------------------------------------------------------------------------------------------
+// parameter inventory — order of SURVEY.md Appendix C (reference: notebooks/play.ipynb:239-362)
+// ------------------------------------------------------------------------------------------------
+static void add_param(SqairHandle* h, const std::string& name, int rows, int cols) {
+  ParamEntry e;
+  e.name = name;
+  e.off = h->n_params;
+  e.rows = rows;
+  e.cols = cols;
+  e.numel = (int64_t)rows * cols;
+  h->pidx[name] = (int)h->params.size();
+  h->params.push_back(e);
+  h->n_params += e.numel;
+}
+static void add_lin(SqairHandle* h, const std::string& name, int fin, int fout) {
+  add_param(h, name + ".w", fin, fout);
+  add_param(h, name + ".b", 1, fout);
+}
+static void add_gru(SqairHandle* h, const std::string& name, int fin, int nh) {
+  const char* g[3] = {"z", "r", "h"};
+  for (int i = 0; i < 3; ++i) {
+    add_param(h, name + ".w" + g[i], fin, nh);
+    add_param(h, name + ".u" + g[i], nh, nh);
+    add_param(h, name + ".b" + g[i], 1, nh);
+  }
+}
+static int64_t P(const SqairHandle* h, const std::string& name) {
+  auto it = h->pidx.find(name);
+  if (it == h->pidx.end()) {
+    fprintf(stderr, "sqair: unknown parameter %s\n", name.c_str());
+    abort();
+  }
+  return h->params[it->second].off;
+}
+static int PC(const SqairHandle* h, const std::string& name) { return h->params[h->pidx.at(name)].cols; }
+
+static void build_inventory(SqairHandle* h) {
+  const SqairConfig& c = h->cfg;
+  const int P_ = c.img_h * c.img_w, nh = c.n_hidden, nw = c.n_what, N = c.n_steps_per_image;
+  const int G2 = c.glimpse_size * c.glimpse_size, nsp = nh / 2;
+  add_param(h, "dec.mean_img", c.img_h, c.img_w);
+  add_lin(h, "dec.l0", nw, nh);
+  add_lin(h, "dec.l1", nh, nh);
+  add_lin(h, "dec.l2", nh, G2);
+  add_param(h, "dec.output_scale", 1, 1);
+  add_param(h, "disc.rnn_init", 1, nh);
+  add_lin(h, "disc.steps_prior.l0", 1, 10);
+  add_lin(h, "disc.steps_prior.l1", 10, N + 1);
+  add_param(h, "disc.rn.init_state", 1, 4);
+  add_param(h, "disc.rn.init_sample", 1, 4);
+  add_lin(h, "disc.rn.readout", 4, 8);
+  add_lin(h, "disc.rn.cond", 4 + nh + 1, 128);
+  add_lin(h, "disc.rn.h2h", 128, 4);
+  add_lin(h, "disc.rn.i2h", 4, 4);
+  add_lin(h, "enc.what_head", nh, 2 * nw);
+  add_lin(h, "enc.mask.l0", nh, 128);
+  add_lin(h, "enc.mask.l1", 128, G2);
+  add_lin(h, "enc.input.l0", P_, nh);
+  add_lin(h, "enc.input.l1", nh, nh);
+  add_lin(h, "enc.glimpse.l0", G2, nh);
+  add_lin(h, "enc.glimpse.l1", nh, nh);
+  add_lin(h, "disc.steps.l0", nh + nw, nsp);
+  add_lin(h, "disc.steps.l1", nsp, 1);
+  add_lin(h, "disc.transform.l0", nh, nh);
+  add_lin(h, "disc.transform.l1", nh, nh);
+  add_lin(h, "disc.transform.l2", nh, 8);
+  add_param(h, "disc.transform.scale_offset", 1, 1);
+  add_lin(h, "disc.rnn.h2h", nh, nh);
+  add_lin(h, "disc.rnn.i2h", nh + nh + nw + 4 + 1, nh);
+  add_param(h, "disc.step_prior_bias", 1, N + 1);
+  add_param(h, "disc.step_prior_timestep_bias", 1, N + 1);
+  add_gru(h, "prop.temporal_gru", nh + 4 + 2 * nw, nh);
+  add_gru(h, "prop.prior_gru", nw + 4, nh);
+  add_lin(h, "prop.prior_linear", nh, 2 * (4 + nw) + 1);
+  add_param(h, "prop.cholesky_scale", 1, 10);
+  add_lin(h, "prop.where_bias.l0", nh, 128);
+  add_lin(h, "prop.where_bias.l1", 128, 4);
+  add_lin(h, "prop.steps.l0", 2 * nh + nw, nsp);
+  add_lin(h, "prop.steps.l1", nsp, 1);
+  add_lin(h, "prop.transform.l0", 2 * nh + 4, nh);
+  add_lin(h, "prop.transform.l1", nh, nh);
+  add_lin(h, "prop.transform.l2", nh, 8);
+  add_param(h, "prop.transform.scale_offset", 1, 1);
+  add_lin(h, "prop.what_head", nh, 2 * nw);
+  add_lin(h, "prop.gates", nh, 3 * nw);
+  add_param(h, "prop.rnn_init", 1, nh);
+  add_lin(h, "prop.rnn.h2h", nh, nh);
+  add_lin(h, "prop.rnn.i2h", nw + (nw + 5) + (nw + 5) + nh, nh);
+  add_param(h, "seq.prior_init", 1, nh);
+  add_param(h, "seq.temporal_init", 1, nh);
+  add_lin(h, "seq.latent_enc.l0", nw + 4, nh);
+  add_lin(h, "seq.latent_enc.l1", nh, nh);
+
+  POff& o = h->po;
+  o.dec_mean_img = (int)P(h, "dec.mean_img");
+  o.dec_output_scale = (int)P(h, "dec.output_scale");
+  o.rn_init_state = (int)P(h, "disc.rn.init_state");
+  o.rn_init_sample = (int)P(h, "disc.rn.init_sample");
+  o.rn_readout_w = (int)P(h, "disc.rn.readout.w");
+  o.rn_readout_b = (int)P(h, "disc.rn.readout.b");
+  o.rn_cond_w = (int)P(h, "disc.rn.cond.w");
+  o.rn_cond_b = (int)P(h, "disc.rn.cond.b");
+  o.rn_h2h_w = (int)P(h, "disc.rn.h2h.w");
+  o.rn_h2h_b = (int)P(h, "disc.rn.h2h.b");
+  o.rn_i2h_w = (int)P(h, "disc.rn.i2h.w");
+  o.rn_i2h_b = (int)P(h, "disc.rn.i2h.b");
+  o.sp_l0_w = (int)P(h, "disc.steps_prior.l0.w");
+  o.sp_l0_b = (int)P(h, "disc.steps_prior.l0.b");
+  o.sp_l1_w = (int)P(h, "disc.steps_prior.l1.w");
+  o.sp_l1_b = (int)P(h, "disc.steps_prior.l1.b");
+  o.step_prior_bias = (int)P(h, "disc.step_prior_bias");
+  o.step_prior_tbias = (int)P(h, "disc.step_prior_timestep_bias");
+  o.disc_steps_l1_w = (int)P(h, "disc.steps.l1.w");
+  o.disc_steps_l1_b = (int)P(h, "disc.steps.l1.b");
+  o.prop_steps_l1_w = (int)P(h, "prop.steps.l1.w");
+  o.prop_steps_l1_b = (int)P(h, "prop.steps.l1.b");
+  o.disc_scale_offset = (int)P(h, "disc.transform.scale_offset");
+  o.prop_scale_offset = (int)P(h, "prop.transform.scale_offset");
+  o.cholesky = (int)P(h, "prop.cholesky_scale");
+  o.disc_rnn_init = (int)P(h, "disc.rnn_init");
+  o.prop_rnn_init = (int)P(h, "prop.rnn_init");
+  o.prior_init = (int)P(h, "seq.prior_init");
+  o.temporal_init = (int)P(h, "seq.temporal_init");
+}
+
+// ------------------------------------------------------------------------------------------------
+// packing plan: for every packed weight element the index of its source in the flat buffer
+// ------------------------------------------------------------------------------------------------
+typedef std::vector<int> RowMap;  // per segment position: source row or -1
+static RowMap rm_range(int start, int n) {
+  RowMap r(n);
+  for (int i = 0; i < n; ++i) r[i] = start + i;
+  return r;
+}
+static RowMap rm_none(int n) { return RowMap(n, -1); }
+// z-record segment (rec::ZW wide): where rows, what rows, presence row (-1 = unused)
+static RowMap rm_zrec(int nw, int where0, int what0, int pres_row) {
+  RowMap r(rec::ZW, -1);
+  for (int i = 0; i < 4; ++i) r[rec::WHERE + i] = where0 >= 0 ? where0 + i : -1;
+  for (int i = 0; i < nw; ++i) r[rec::WHAT + i] = what0 >= 0 ? what0 + i : -1;
+  r[rec::PRES] = pres_row;
+  return r;
+}
+
+struct SegSrc {
+  std::string w;  // source weight matrix name ("" = none)
+  RowMap rows;
+};
+struct ColBlock {
+  int ncols;
+  int col0;  // first source column
+  std::vector<SegSrc> seg;
+  std::string bias_a, bias_b;  // bias vector names ("" = none); element col0 + j
+};
+
+static void build_layer(SqairHandle* h, LayerId id, const std::vector<int>& seg_width, const std::vector<ColBlock>& blocks) {
+  PackedLayer& L = h->layers[id];
+  L.seg_width = seg_width;
+  L.kc = 0;
+  for (int w : seg_width) L.kc += (w + 15) / 16;
+  L.N = 0;
+  for (const ColBlock& b : blocks) L.N += b.ncols;
+  L.nt = (L.N + 15) / 16;
+  L.w_off = h->packed_w;
+  L.b_off = h->packed_b;
+  const int64_t nel = (int64_t)L.nt * L.kc * 256;
+  h->widx.resize(h->packed_w + nel, -1);
+  h->bidx_a.resize(h->packed_b + L.nt * 16, -1);
+  h->bidx_b.resize(h->packed_b + L.nt * 16, -1);
+  int n0 = 0;
+  for (const ColBlock& b : blocks) {
+    if ((int)b.seg.size() != (int)seg_width.size()) {
+      fprintf(stderr, "sqair: layer %d: segment count mismatch\n", (int)id);
+      abort();
+    }
+    for (int j = 0; j < b.ncols; ++j) {
+      const int n = n0 + j;
+      const int tile = n / 16, ln = n % 16;
+      if (!b.bias_a.empty()) h->bidx_a[L.b_off + n] = (int)(P(h, b.bias_a) + b.col0 + j);
+      if (!b.bias_b.empty()) h->bidx_b[L.b_off + n] = (int)(P(h, b.bias_b) + b.col0 + j);
+      int cbase = 0;
+      for (size_t s = 0; s < seg_width.size(); ++s) {
+        const SegSrc& src = b.seg[s];
+        const int nch = (seg_width[s] + 15) / 16;
+        if (!src.w.empty()) {
+          if ((int)src.rows.size() != seg_width[s]) {
+            fprintf(stderr, "sqair: layer %d seg %zu: rowmap %zu != width %d\n", (int)id, s, src.rows.size(), seg_width[s]);
+            abort();
+          }
+          const int64_t woff = P(h, src.w);
+          const int ldw = PC(h, src.w);
+          for (int k = 0; k < seg_width[s]; ++k) {
+            if (src.rows[k] < 0) continue;
+            const int c = cbase + k / 16, kin = k % 16;
+            const int lane = (kin / 4) * 16 + ln, comp = kin % 4;
+            h->widx[L.w_off + (((int64_t)tile * L.kc + c) * 64 + lane) * 4 + comp] =
+                (int)(woff + (int64_t)src.rows[k] * ldw + b.col0 + j);
+          }
+        }
+        cbase += nch;
+      }
+    }
+    n0 += b.ncols;
+  }
+  h->packed_w += nel;
+  h->packed_b += L.nt * 16;
+}
+
+static ColBlock cb1(int ncols, int col0, const std::string& w, const RowMap& rows, const std::string& ba = "",
+                    const std::string& bb = "") {
+  ColBlock b;
+  b.ncols = ncols;
+  b.col0 = col0;
+  b.seg.push_back({w, rows});
+  b.bias_a = ba;
+  b.bias_b = bb;
+  return b;
+}
+
+static void build_plan(SqairHandle* h) {
+  const SqairConfig& c = h->cfg;
+  const int P_ = c.img_h * c.img_w, nh = c.n_hidden, nw = c.n_what;
+  const int G2 = c.glimpse_size * c.glimpse_size, nsp = nh / 2;
+  auto simple = [&](LayerId id, const std::string& name, int fin, int fout, int row0 = 0, bool bias = true) {
+    build_layer(h, id, {fin}, {cb1(fout, 0, name + ".w", rm_range(row0, fin), bias ? name + ".b" : "")});
+  };
+  simple(L_IENC0, "enc.input.l0", P_, nh);
+  simple(L_IENC1, "enc.input.l1", nh, nh);
+  // discovery RNN in_to_hidden = [input enc nh | conditioning nh | what nw | where 4 | presence 1] (core.py:164-177)
+  build_layer(h, L_PREDISC, {nh}, {cb1(nh, 0, "disc.rnn.i2h.w", rm_range(0, nh), "disc.rnn.i2h.b", "disc.rnn.h2h.b")});
+  // prior GRU on [what, where]_{t-1} (propagate.py:78-81)
+  {
+    const RowMap zx = rm_zrec(nw, nw, 0, -1);
+    std::vector<ColBlock> bl;
+    const char* g[3] = {"z", "r", "h"};
+    for (int i = 0; i < 3; ++i) {
+      ColBlock b;
+      b.ncols = nh;
+      b.col0 = 0;
+      b.seg.push_back({std::string("prop.prior_gru.w") + g[i], zx});
+      if (i < 2) b.seg.push_back({std::string("prop.prior_gru.u") + g[i], rm_range(0, nh)});
+      else b.seg.push_back({"", RowMap()});
+      b.bias_a = std::string("prop.prior_gru.b") + g[i];
+      bl.push_back(b);
+    }
+    build_layer(h, L_PRIOR_GRU1, {rec::ZW, nh}, bl);
+  }
+  simple(L_PRIOR_GRU2, "prop.prior_gru.uh", nh, nh, 0, false);
+  // fix-up: uh is a bare matrix (no ".w" suffix) -> handled by simple() through name + ".w"; see alias below
+  simple(L_PRIOR_LIN, "prop.prior_linear", nh, 2 * (4 + nw) + 1);
+  build_layer(h, L_TAU1, {nh},
+              {cb1(128, 0, "prop.where_bias.l0.w", rm_range(0, nh), "prop.where_bias.l0.b"),
+               cb1(128, 0, "enc.mask.l0.w", rm_range(0, nh), "enc.mask.l0.b")});
+  simple(L_WB2, "prop.where_bias.l1", 128, 4);
+  simple(L_MASK2, "enc.mask.l1", 128, G2);
+  simple(L_GENC0, "enc.glimpse.l0", G2, nh);
+  simple(L_GENC1, "enc.glimpse.l1", nh, nh);
+  build_layer(h, L_WHAT_LOC, {nh}, {cb1(nw, 0, "enc.what_head.w", rm_range(0, nh), "enc.what_head.b")});
+  simple(L_WHAT_HEAD, "enc.what_head", nh, 2 * nw);
+  // loop-invariant pre-activations of a propagation slot, segments [m1 (nw) | z_{t-1} record | temporal state]
+  {
+    const int tm1 = nw + (nw + 5);  // rnn input: [loc1 nw | what,where,pres (k-1) | what,where,pres (t-1) | temporal]
+    std::vector<ColBlock> bl;
+    ColBlock rnn;
+    rnn.ncols = nh; rnn.col0 = 0;
+    rnn.seg = {{"prop.rnn.i2h.w", rm_range(0, nw)},
+               {"prop.rnn.i2h.w", rm_zrec(nw, tm1 + nw, tm1, tm1 + nw + 4)},
+               {"prop.rnn.i2h.w", rm_range(tm1 + nw + 5, nh)}};
+    rnn.bias_a = "prop.rnn.i2h.b"; rnn.bias_b = "prop.rnn.h2h.b";
+    bl.push_back(rnn);
+    ColBlock t1;  // transform input [hidden nh | where_{t-1} 4 | temporal nh] (core.py:325-326)
+    t1.ncols = nh; t1.col0 = 0;
+    t1.seg = {{"", RowMap()}, {"prop.transform.l0.w", rm_zrec(nw, nh, -1, -1)}, {"prop.transform.l0.w", rm_range(nh + 4, nh)}};
+    t1.bias_a = "prop.transform.l0.b";
+    bl.push_back(t1);
+    ColBlock s1;  // steps predictor input [hidden nh | temporal nh | what nw] (core.py:312-314)
+    s1.ncols = nsp; s1.col0 = 0;
+    s1.seg = {{"", RowMap()}, {"", RowMap()}, {"prop.steps.l0.w", rm_range(nh, nh)}};
+    s1.bias_a = "prop.steps.l0.b";
+    bl.push_back(s1);
+    for (const char* g : {"z", "r"}) {
+      ColBlock u;
+      u.ncols = nh; u.col0 = 0;
+      u.seg = {{"", RowMap()}, {"", RowMap()}, {std::string("prop.temporal_gru.u") + g, rm_range(0, nh)}};
+      u.bias_a = std::string("prop.temporal_gru.b") + g;
+      bl.push_back(u);
+    }
+    build_layer(h, L_PRE, {nw, rec::ZW, nh}, bl);
+  }
+  {
+    ColBlock b;  // explaining-away + recurrent part of the propagation RNN
+    b.ncols = nh; b.col0 = 0;
+    b.seg = {{"prop.rnn.i2h.w", rm_zrec(nw, nw + nw, nw, nw + nw + 4)}, {"prop.rnn.h2h.w", rm_range(0, nh)}};
+    build_layer(h, L_PROP_RNN, {rec::ZW, nh}, {b});
+  }
+  simple(L_PROP_T1, "prop.transform.l0", nh, nh, 0, false);
+  simple(L_PROP_T2, "prop.transform.l1", nh, nh);
+  simple(L_PROP_T3, "prop.transform.l2", nh, 8);
+  {
+    // temporal GRU input [hidden nh | where 4 | loc nw | scale nw] (core.py:340-341)
+    std::vector<ColBlock> bl;
+    const char* g[3] = {"z", "r", "h"};
+    for (int i = 0; i < 3; ++i) {
+      ColBlock b;
+      b.ncols = nh; b.col0 = 0;
+      const std::string w = std::string("prop.temporal_gru.w") + g[i];
+      b.seg = {{w, rm_range(0, nh)}, {w, rm_range(nh, 4)}, {w, rm_range(nh + 4, 2 * nw)}};
+      if (i == 2) b.bias_a = "prop.temporal_gru.bh";
+      bl.push_back(b);
+    }
+    build_layer(h, L_PROP_GRU1, {nh, 4, 2 * nw}, bl);
+  }
+  simple(L_PROP_GRU2, "prop.temporal_gru.uh", nh, nh, 0, false);
+  build_layer(h, L_PROP_HEADS, {nh},
+              {cb1(2 * nw, 0, "prop.what_head.w", rm_range(0, nh), "prop.what_head.b"),
+               cb1(3 * nw, 0, "prop.gates.w", rm_range(0, nh), "prop.gates.b")});
+  {
+    ColBlock b;
+    b.ncols = nsp; b.col0 = 0;
+    b.seg = {{"prop.steps.l0.w", rm_range(0, nh)}, {"prop.steps.l0.w", rm_zrec(nw, -1, 2 * nh, -1)}};
+    build_layer(h, L_PROP_S1, {nh, rec::ZW}, {b});
+  }
+  build_layer(h, L_LAT0, {rec::ZW}, {cb1(nh, 0, "seq.latent_enc.l0.w", rm_zrec(nw, nw, 0, -1), "seq.latent_enc.l0.b")});
+  simple(L_LAT1, "seq.latent_enc.l1", nh, nh);
+  build_layer(h, L_PRED, {nh}, {cb1(nh, 0, "disc.rnn.i2h.w", rm_range(nh, nh))});
+  {
+    ColBlock b;  // conditioning state of the recurrent where prior: [init_state 4 | cond nh | e 1] (modules.py:573-576)
+    b.ncols = 128; b.col0 = 0;
+    b.seg = {{"disc.rn.cond.w", rm_range(0, 4)}, {"disc.rn.cond.w", rm_range(4, nh)}};
+    b.bias_a = "disc.rn.cond.b";
+    build_layer(h, L_RNCOND, {4, nh}, {b});
+  }
+  {
+    ColBlock b;
+    b.ncols = nh; b.col0 = 0;
+    b.seg = {{"disc.rnn.i2h.w", rm_zrec(nw, 2 * nh + nw, 2 * nh, 2 * nh + nw + 4)}, {"disc.rnn.h2h.w", rm_range(0, nh)}};
+    build_layer(h, L_DISC_RNN, {rec::ZW, nh}, {b});
+  }
+  simple(L_DISC_T1, "disc.transform.l0", nh, nh);
+  simple(L_DISC_T2, "disc.transform.l1", nh, nh);
+  simple(L_DISC_T3, "disc.transform.l2", nh, 8);
+  {
+    ColBlock b;
+    b.ncols = nsp; b.col0 = 0;
+    b.seg = {{"disc.steps.l0.w", rm_range(0, nh)}, {"disc.steps.l0.w", rm_zrec(nw, -1, nh, -1)}};
+    b.bias_a = "disc.steps.l0.b";
+    build_layer(h, L_DISC_S1, {nh, rec::ZW}, {b});
+  }
+  build_layer(h, L_DEC0, {rec::ZW}, {cb1(nh, 0, "dec.l0.w", rm_zrec(nw, -1, 0, -1), "dec.l0.b")});
+  simple(L_DEC1, "dec.l1", nh, nh);
+  simple(L_DEC2, "dec.l2", nh, G2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI: lifetime / introspection
+// ------------------------------------------------------------------------------------------------
+extern "C" int sqair_abi_version(void) { return SQAIR_ABI_VERSION; }
+
+extern "C" int sqair_create(const SqairConfig* cfg, SqairHandle** out) {
+  if (cfg == nullptr || out == nullptr) return -1;
+  *out = nullptr;
+  if (cfg->n_what < 1 || cfg->n_what > 50 || cfg->n_steps_per_image < 1 || cfg->n_steps_per_image > SQ_MAXN ||
+      cfg->n_hidden < 16 || (cfg->n_hidden % 16) != 0 || cfg->glimpse_size < 2 || cfg->img_h < 2 || cfg->img_w < 2 ||
+      cfg->k_particles < 1 || cfg->k_particles > 64)
+    return -1;
+  SqairHandle* h = new SqairHandle();
+  h->cfg = *cfg;
+  build_inventory(h);
+  // GRU candidate matrices are bare [nh, nh] parameters: give build_plan's simple() a ".w" alias
+  h->pidx["prop.prior_gru.uh.w"] = h->pidx["prop.prior_gru.uh"];
+  h->pidx["prop.temporal_gru.uh.w"] = h->pidx["prop.temporal_gru.uh"];
+  build_plan(h);
+  *out = h;
+  return 0;
+}
+
+extern "C" int sqair_destroy(SqairHandle* h) {
+  if (h == nullptr) return 0;
+  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+  if (h->graph) hipGraphDestroy(h->graph);
+  delete h;
+  return 0;
+}
+
+extern "C" const char* sqair_last_error(const SqairHandle* h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" int64_t sqair_param_count(const SqairHandle* h) { return h ? h->n_params : -1; }
+extern "C" int sqair_param_entries(const SqairHandle* h) { return h ? (int)h->params.size() : -1; }
+extern "C" int sqair_param_entry(const SqairHandle* h, int i, const char** name, int64_t* offset, int64_t* numel) {
+  if (!h || i < 0 || i >= (int)h->params.size()) return -1;
+  if (name) *name = h->params[i].name.c_str();
+  if (offset) *offset = h->params[i].off;
+  if (numel) *numel = h->params[i].numel;
+  return 0;
+}
+extern "C" int sqair_noise_width(const SqairHandle* h) { return h ? 4 + h->cfg.n_what + 1 : -1; }
+
+static int64_t align64(int64_t x) { return (x + 63) / 64 * 64; }
+
+// packed buffer = [weights fp32 | biases fp32 | widx int32 | bidx_a | bidx_b], each 256-byte aligned
+struct PackedLayout {
+  int64_t w, b, wi, ba, bb, total;  // offsets in 4-byte words
+};
+static PackedLayout packed_layout(const SqairHandle* h) {
+  PackedLayout p;
+  p.w = 0;
+  p.b = align64(p.w + h->packed_w);
+  p.wi = align64(p.b + h->packed_b);
+  p.ba = align64(p.wi + h->packed_w);
+  p.bb = align64(p.ba + h->packed_b);
+  p.total = align64(p.bb + h->packed_b);
+  return p;
+}
+extern "C" int64_t sqair_packed_bytes(const SqairHandle* h) { return h ? packed_layout(h).total * 4 : -1; }
+
+extern "C" int sqair_pack_params(SqairHandle* h, const float* flat, void* packed, void* stream) {
+  if (!h || !flat || !packed) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const PackedLayout pl = packed_layout(h);
+  float* base = (float*)packed;
+  int* ibase = (int*)packed;
+  if (h->plan_uploaded_ptr != packed) {
+    SQ_CHECK_HIP(hipMemcpyAsync(ibase + pl.wi, h->widx.data(), h->packed_w * 4, hipMemcpyHostToDevice, s));
+    SQ_CHECK_HIP(hipMemcpyAsync(ibase + pl.ba, h->bidx_a.data(), h->packed_b * 4, hipMemcpyHostToDevice, s));
+    SQ_CHECK_HIP(hipMemcpyAsync(ibase + pl.bb, h->bidx_b.data(), h->packed_b * 4, hipMemcpyHostToDevice, s));
+    SQ_CHECK_HIP(hipStreamSynchronize(s));
+    h->plan_uploaded_ptr = packed;
+  }
+  sq_launch_pack(flat, base + pl.w, ibase + pl.wi, h->packed_w, s);
+  sq_launch_pack_bias(flat, base + pl.b, ibase + pl.ba, ibase + pl.bb, h->packed_b, s);
+  SQ_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+struct Workspace {
+  float *ienc_a, *ienc_b, *pre_disc;
+  float *rec_m[2], *temporal_m[2], *prior_m[2], *last_id[2];
+  float *rec_p, *rec_d, *zero_rec, *disc_init_rec;
+  float *temporal_p, *prior_p;
+  float *gz, *grh, *gxh;
+  float *pstats, *hid1, *wb, *mask, *g1, *ea, *eb, *m1, *pre;
+  float *rbuf[2], *t1, *t2, *tp, *g2, *enc, *hraw, *s1;
+  float *c, *pre_d, *spre, *qz, *pz, *dlp, *dll, *glimpse;
+  int64_t total;  // floats
+};
+constexpr int PS_LD = 112, ENC_LD = 112, M1_LD = 64, HRAW_LD = 256, WB_LD = 4, TP_LD = 8;
+
+static Workspace carve(const SqairHandle* h, int T, int B, float* base) {
+  const SqairConfig& c = h->cfg;
+  const int64_t nh = c.n_hidden, N = c.n_steps_per_image, R = (int64_t)B * c.k_particles, M = R * N;
+  const int64_t G2 = c.glimpse_size * c.glimpse_size;
+  const int64_t pre_ld = h->layers[L_PRE].nt * 16;
+  Workspace w;
+  int64_t o = 0;
+  auto take = [&](int64_t n) {
+    float* p = base ? base + o : nullptr;
+    o += align64(n);
+    return p;
+  };
+  w.ienc_a = take((int64_t)T * B * nh);
+  w.ienc_b = take((int64_t)T * B * nh);
+  w.pre_disc = take((int64_t)T * B * nh);
+  for (int i = 0; i < 2; ++i) {
+    w.rec_m[i] = take(M * rec::W);
+    w.temporal_m[i] = take(M * nh);
+    w.prior_m[i] = take(M * nh);
+    w.last_id[i] = take(R);
+  }
+  w.rec_p = take(M * rec::W);
+  w.rec_d = take(M * rec::W);
+  w.zero_rec = take(rec::W);
+  w.disc_init_rec = take(rec::W);
+  w.temporal_p = take(M * nh);
+  w.prior_p = take(M * nh);
+  w.gz = take(M * nh);
+  w.grh = take(M * nh);
+  w.gxh = take(M * nh);
+  w.pstats = take(M * PS_LD);
+  w.hid1 = take(M * 256);
+  w.wb = take(M * WB_LD);
+  w.mask = take(M * G2);
+  w.g1 = take(M * G2);
+  w.ea = take(M * nh);
+  w.eb = take(M * nh);
+  w.m1 = take(M * M1_LD);
+  w.pre = take(M * pre_ld);
+  w.rbuf[0] = take(R * nh);
+  w.rbuf[1] = take(R * nh);
+  w.t1 = take(R * nh);
+  w.t2 = take(R * nh);
+  w.tp = take(R * TP_LD);
+  w.g2 = take(R * G2);
+  w.enc = take(R * ENC_LD);
+  w.hraw = take(R * HRAW_LD);
+  w.s1 = take(R * 128);
+  w.c = take(R * nh);
+  w.pre_d = take(R * nh);
+  w.spre = take(R * 128);
+  w.qz = take(R);
+  w.pz = take(R);
+  w.dlp = take(R);
+  w.dll = take(R);
+  w.glimpse = take(M * G2);
+  w.total = o;
+  return w;
+}
+
+extern "C" int64_t sqair_workspace_bytes(const SqairHandle* h, int T, int B) {
+  if (!h || T < 1 || B < 1) return -1;
+  return carve(h, T, B, nullptr).total * 4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the launch sequence
+// ------------------------------------------------------------------------------------------------
+struct Lin {
+  LinArgs a;
+  Lin() {
+    memset(&a, 0, sizeof(a));
+    a.epi = EPI_ACT;
+    a.act_split = 1 << 30;
+    a.add_rdiv = 1;
+    a.scale = 1.0f;
+  }
+  Lin& seg(const float* p, int ld, int width, int rdiv = 1) {
+    a.seg[a.nseg++] = LinSeg{p, ld, width, rdiv};
+    return *this;
+  }
+  Lin& out(float* p, int ld) { a.out = p; a.out_ld = ld; return *this; }
+  Lin& act(int act) { a.act_a = act; return *this; }
+  Lin& act2(int a0, int a1, int split) { a.act_a = a0; a.act_b = a1; a.act_split = split; return *this; }
+  Lin& add(const float* p, int ld, int n, int rdiv = 1) { a.add = p; a.add_ld = ld; a.add_n = n; a.add_rdiv = rdiv; return *this; }
+  Lin& gru1(const float* hprev, int h_ld, float* rh, int rh_ld, float* xh, int xh_ld, int nh) {
+    a.epi = EPI_GRU1; a.e0 = hprev; a.e0_ld = h_ld; a.o1 = rh; a.o1_ld = rh_ld; a.o2 = xh; a.o2_ld = xh_ld; a.nh = nh;
+    return *this;
+  }
+  Lin& gru2(const float* hprev, int h_ld, const float* z, int z_ld, int nh) {
+    a.epi = EPI_GRU2; a.e0 = hprev; a.e0_ld = h_ld; a.e1 = z; a.e1_ld = z_ld; a.nh = nh;
+    return *this;
+  }
+};
+
+static int run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipStream_t s) {
+  const PackedLayer& L = h->layers[id];
+  const PackedLayout pl = packed_layout(h);
+  if (l.a.nseg != (int)L.seg_width.size()) {
+    sq_set_error(h, "internal: segment count mismatch in layer " + std::to_string((int)id));
+    return -3;
+  }
+  for (int i = 0; i < l.a.nseg; ++i)
+    if (l.a.seg[i].width != L.seg_width[i]) {
+      sq_set_error(h, "internal: segment width mismatch in layer " + std::to_string((int)id));
+      return -3;
+    }
+  l.a.wp = packed + pl.w + L.w_off;
+  l.a.bias = packed + pl.b + L.b_off;
+  l.a.M = M;
+  l.a.N = L.N;
+  return sq_launch_linear(l.a, L, s);
+}
+
+#define RUN(l, id, M)                                   \
+  do {                                                  \
+    int _rc = run(h, (l), (id), (M), packed, s);        \
+    if (_rc != 0) return _rc;                           \
+  } while (0)
+
+static int forward_impl(SqairHandle* h, const float* flat, const float* packed, const float* obs, const float* noise,
+                        int T, int B, int t_offset, const SqairOutputs* outp, float* wsbase, int64_t ws_bytes,
+                        hipStream_t s) {
+  const SqairConfig& c = h->cfg;
+  if (!flat || !packed || !obs || !noise || !outp || !wsbase || T < 1 || B < 1) {
+    sq_set_error(h, "sqair_forward: null argument or bad T/B");
+    return -1;
+  }
+  if (ws_bytes < sqair_workspace_bytes(h, T, B)) {
+    sq_set_error(h, "sqair_forward: workspace too small");
+    return -1;
+  }
+  const SqairOutputs out = *outp;
+  const int nh = c.n_hidden, nw = c.n_what, N = c.n_steps_per_image, K = c.k_particles;
+  const int R = B * K, M = R * N, G2 = c.glimpse_size * c.glimpse_size, P_ = c.img_h * c.img_w;
+  const int nzw = 4 + nw + 1;
+  Dims d{c.img_h, c.img_w, c.glimpse_size, N, nw, nh, K, R, B, nzw};
+  const POff po = h->po;
+  Workspace w = carve(h, T, B, wsbase);
+  const int pre_ld = h->layers[L_PRE].nt * 16;
+  const int RW = rec::W;
+
+  // ---- sequence prologue -----------------------------------------------------------------------
+  // slot records are read as 56-wide GEMM segments before every field has been written in a frame (the
+  // unwritten fields meet zero weight rows, but 0 * NaN = NaN): clear them, the caller's workspace is garbage
+  SQ_CHECK_HIP(hipMemsetAsync(w.rec_p, 0, (size_t)(w.temporal_p - w.rec_p) * 4, s));
+  // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
+  sq_launch_init_state(w.rec_m[0], w.temporal_m[0], w.prior_m[0], w.last_id[0], w.disc_init_rec, flat, po, d, s);
+  {  // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
+    Lin a; a.seg(obs, P_, P_).out(w.ienc_a, nh).act(ACT_ELU); RUN(a, L_IENC0, T * B);
+    Lin b; b.seg(w.ienc_a, nh, nh).out(w.ienc_b, nh).act(ACT_ELU); RUN(b, L_IENC1, T * B);
+    Lin p; p.seg(w.ienc_b, nh, nh).out(w.pre_disc, nh); RUN(p, L_PREDISC, T * B);
+  }
+
+  for (int t = 0; t < T; ++t) {
+    const int pp = t & 1, pn = pp ^ 1;
+    const float* img = obs + (size_t)t * B * P_;
+    const float* nz = noise + (size_t)t * R * 2 * N * nzw;
+    const float* rec_prev = w.rec_m[pp];
+    const float* temporal_prev = w.temporal_m[pp];
+    const float* prior_prev = w.prior_m[pp];
+
+    // ---- A. propagation prior (propagate.py:68-98): GRU over [what, where]_{t-1}, all slots ----
+    {
+      Lin g1; g1.seg(rec_prev, RW, rec::ZW).seg(prior_prev, nh, nh).out(w.gz, nh)
+                .gru1(prior_prev, nh, w.grh, nh, w.gxh, nh, nh);
+      RUN(g1, L_PRIOR_GRU1, M);
+      Lin g2; g2.seg(w.grh, nh, nh).add(w.gxh, nh, nh).out(w.prior_p, nh).gru2(prior_prev, nh, w.gz, nh, nh);
+      RUN(g2, L_PRIOR_GRU2, M);
+      Lin pl; pl.seg(w.prior_p, nh, nh).out(w.pstats, PS_LD); RUN(pl, L_PRIOR_LIN, M);
+    }
+    // ---- B. where-bias MLP and glimpse-mask MLP of every slot (core.py:292, modules.py:350-356) ----
+    {
+      Lin a; a.seg(temporal_prev, nh, nh).out(w.hid1, 256).act(ACT_ELU); RUN(a, L_TAU1, M);
+      Lin b; b.seg(w.hid1, 256, 128).out(w.wb, WB_LD); RUN(b, L_WB2, M);
+      Lin m; m.seg(w.hid1 + 128, 256, 128).out(w.mask, G2).act(ACT_SIGMOID); RUN(m, L_MASK2, M);
+    }
+    // ---- C. crop #1 at where_{t-1} + bias, masked, encoded -> loc1 (core.py:293-294) ----
+    {
+      CropArgs ca; memset(&ca, 0, sizeof(ca));
+      ca.mode = CROP_PROP1; ca.img = img; ca.mask = c.masked_glimpse ? w.mask : nullptr; ca.mask_row_mul = N;
+      ca.out = w.g1; ca.out_row_mul = N; ca.rec_prev = rec_prev; ca.wb = w.wb; ca.wb_ld = WB_LD; ca.flat = flat;
+      sq_launch_crop(ca, po, d, N, s);
+      Lin a; a.seg(w.g1, G2, G2).out(w.ea, nh).act(ACT_ELU); RUN(a, L_GENC0, M);
+      Lin b; b.seg(w.ea, nh, nh).out(w.eb, nh).act(ACT_ELU); RUN(b, L_GENC1, M);
+      Lin l; l.seg(w.eb, nh, nh).out(w.m1, M1_LD); RUN(l, L_WHAT_LOC, M);
+    }
+    // ---- D. loop-invariant pre-activations of all slots ----
+    {
+      Lin p; p.seg(w.m1, M1_LD, nw).seg(rec_prev, RW, rec::ZW).seg(temporal_prev, nh, nh).out(w.pre, pre_ld);
+      RUN(p, L_PRE, M);
+    }
+    // ---- E. propagation slots (propagate.py:168-184 static_rnn over PropagationCore) ----
+    for (int k = 0; k < N; ++k) {
+      const float* pre_k = w.pre + (size_t)k * pre_ld;
+      const int pre_rld = N * pre_ld;
+      float* r_k = w.rbuf[k & 1];
+      {
+        Lin a;
+        if (k == 0) a.seg(w.zero_rec, 0, rec::ZW).seg(flat + po.prop_rnn_init, 0, nh);
+        else a.seg(w.rec_p + (size_t)(k - 1) * RW, N * RW, rec::ZW).seg(w.rbuf[(k - 1) & 1], nh, nh);
+        a.add(pre_k, pre_rld, nh).out(r_k, nh).act(ACT_TANH);
+        RUN(a, L_PROP_RNN, R);
+      }
+      {
+        Lin a; a.seg(r_k, nh, nh).add(pre_k + nh, pre_rld, nh).out(w.t1, nh).act(ACT_ELU); RUN(a, L_PROP_T1, R);
+        Lin b; b.seg(w.t1, nh, nh).out(w.t2, nh).act(ACT_ELU); RUN(b, L_PROP_T2, R);
+        Lin t3; t3.seg(w.t2, nh, nh).out(w.tp, TP_LD); RUN(t3, L_PROP_T3, R);
+      }
+      {
+        CropArgs ca; memset(&ca, 0, sizeof(ca));
+        ca.mode = CROP_PROP2; ca.img = img; ca.mask = c.masked_glimpse ? w.mask : nullptr; ca.mask_row_mul = N;
+        ca.mask_row_add = k; ca.out = w.g2; ca.out_row_mul = 1; ca.rec_prev = rec_prev; ca.rec_new = w.rec_p;
+        ca.tp = w.tp; ca.tp_ld = TP_LD; ca.noise = nz; ca.flat = flat; ca.slot = k;
+        sq_launch_crop(ca, po, d, 1, s);
+      }
+      {
+        Lin a; a.seg(w.g2, G2, G2).out(w.t1, nh).act(ACT_ELU); RUN(a, L_GENC0, R);
+        Lin b; b.seg(w.t1, nh, nh).out(w.t2, nh).act(ACT_ELU); RUN(b, L_GENC1, R);
+        Lin e; e.seg(w.t2, nh, nh).out(w.enc, ENC_LD).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
+      }
+      {
+        const float* tau_k = temporal_prev + (size_t)k * nh;
+        Lin g1; g1.seg(r_k, nh, nh).seg(w.rec_p + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(w.enc, ENC_LD, 2 * nw)
+                  .add(pre_k + 2 * nh + nh / 2, pre_rld, 2 * nh).out(w.gz, nh)
+                  .gru1(tau_k, N * nh, w.grh, nh, w.gxh, nh, nh);
+        RUN(g1, L_PROP_GRU1, R);
+        Lin g2; g2.seg(w.grh, nh, nh).add(w.gxh, nh, nh).out(w.temporal_p + (size_t)k * nh, N * nh)
+                  .gru2(tau_k, N * nh, w.gz, nh, nh);
+        RUN(g2, L_PROP_GRU2, R);
+        Lin hd; hd.seg(w.temporal_p + (size_t)k * nh, N * nh, nh).out(w.hraw, HRAW_LD); RUN(hd, L_PROP_HEADS, R);
+        sq_launch_what_prop(w.hraw, HRAW_LD, w.enc, ENC_LD, rec_prev, nz, w.rec_p, k, d, s);
+      }
+      {
+        Lin a; a.seg(r_k, nh, nh).seg(w.rec_p + (size_t)k * RW, N * RW, rec::ZW).add(pre_k + 2 * nh, pre_rld, nh / 2)
+                 .out(w.s1, 128).act(ACT_ELU);
+        RUN(a, L_PROP_S1, R);
+        sq_launch_steps(w.s1, 128, flat, po.prop_steps_l1_w, po.prop_steps_l1_b, rec_prev, w.rec_p, nz, k, 0, d, s);
+      }
+    }
+    // ---- F. summary of propagated latents -> discovery conditioning (sqair_modules.py:368-385, :501) ----
+    {
+      Lin a; a.seg(w.rec_p, RW, rec::ZW).out(w.ea, nh).act(ACT_ELU); RUN(a, L_LAT0, M);
+      Lin b; b.seg(w.ea, nh, nh).out(w.eb, nh).act(ACT_ELU); RUN(b, L_LAT1, M);
+      sq_launch_latent_sum(w.eb, w.rec_p, w.c, d, s);
+      Lin p; p.seg(w.c, nh, nh).add(w.pre_disc + (size_t)t * B * nh, nh, nh, K).out(w.pre_d, nh); RUN(p, L_PRED, R);
+      if (c.rec_where_prior) {
+        Lin q; q.seg(flat + po.rn_init_state, 0, 4).seg(w.c, nh, nh).out(w.spre, 128); RUN(q, L_RNCOND, R);
+      }
+    }
+    // ---- G. discovery steps (sqair_modules.py:129-147 static_rnn over DiscoveryCore) ----
+    for (int j = 0; j < N; ++j) {
+      float* r_j = w.rbuf[j & 1];
+      {
+        Lin a;
+        if (j == 0) a.seg(w.disc_init_rec, 0, rec::ZW).seg(flat + po.disc_rnn_init, 0, nh);
+        else a.seg(w.rec_d + (size_t)(j - 1) * RW, N * RW, rec::ZW).seg(w.rbuf[(j - 1) & 1], nh, nh);
+        a.add(w.pre_d, nh, nh).out(r_j, nh).act(ACT_TANH);
+        RUN(a, L_DISC_RNN, R);
+        Lin b; b.seg(r_j, nh, nh).out(w.t1, nh).act(ACT_ELU); RUN(b, L_DISC_T1, R);
+        Lin cc; cc.seg(w.t1, nh, nh).out(w.t2, nh).act(ACT_ELU); RUN(cc, L_DISC_T2, R);
+        Lin t3; t3.seg(w.t2, nh, nh).out(w.tp, TP_LD); RUN(t3, L_DISC_T3, R);
+      }
+      {
+        CropArgs ca; memset(&ca, 0, sizeof(ca));
+        ca.mode = CROP_DISC; ca.img = img; ca.out = w.g2; ca.out_row_mul = 1; ca.rec_new = w.rec_d; ca.tp = w.tp;
+        ca.tp_ld = TP_LD; ca.noise = nz; ca.flat = flat; ca.slot = j;
+        sq_launch_crop(ca, po, d, 1, s);
+        Lin a; a.seg(w.g2, G2, G2).out(w.t1, nh).act(ACT_ELU); RUN(a, L_GENC0, R);
+        Lin b; b.seg(w.t1, nh, nh).out(w.t2, nh).act(ACT_ELU); RUN(b, L_GENC1, R);
+        Lin e; e.seg(w.t2, nh, nh).out(w.enc, ENC_LD).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
+        sq_launch_what_disc(w.enc, ENC_LD, nz, w.rec_d, j, d, s);
+      }
+      {
+        Lin a; a.seg(r_j, nh, nh).seg(w.rec_d + (size_t)j * RW, N * RW, rec::ZW).out(w.s1, 128).act(ACT_ELU);
+        RUN(a, L_DISC_S1, R);
+        sq_launch_steps(w.s1, 128, flat, po.disc_steps_l1_w, po.disc_steps_l1_b, rec_prev, w.rec_d, nz, j, 1, d, s);
+      }
+    }
+    // ---- H. log-probabilities, I. merge / compaction ----
+    {
+      LogprobArgs la; memset(&la, 0, sizeof(la));
+      la.rec_p = w.rec_p; la.rec_d = w.rec_d; la.rec_prev = rec_prev; la.pstats = w.pstats; la.ps_ld = PS_LD;
+      la.spre = w.spre; la.flat = flat; la.t_global = t + t_offset; la.t = t; la.qz = w.qz; la.pz = w.pz;
+      la.disc_lp = w.dlp; la.out = out; la.cfg = c;
+      sq_launch_logprob(la, po, d, s);
+      CompactArgs ka; memset(&ka, 0, sizeof(ka));
+      ka.rec_p = w.rec_p; ka.rec_d = w.rec_d; ka.rec_prev = rec_prev; ka.temporal_p = w.temporal_p;
+      ka.prior_p = w.prior_p; ka.last_id_prev = w.last_id[pp]; ka.last_id_next = w.last_id[pn];
+      ka.rec_next = w.rec_m[pn]; ka.temporal_next = w.temporal_m[pn]; ka.prior_next = w.prior_m[pn];
+      ka.flat = flat; ka.t = t; ka.out = out;
+      sq_launch_compact(ka, po, d, s);
+    }
+    // ---- J. decoder + log-weight (modules.py:435-467, seq.py:271-276) ----
+    {
+      float* gl = out.glimpse ? out.glimpse + (size_t)t * M * G2 : w.glimpse;
+      Lin a; a.seg(w.rec_m[pn], RW, rec::ZW).out(w.ea, nh).act(ACT_ELU); RUN(a, L_DEC0, M);
+      Lin b; b.seg(w.ea, nh, nh).out(w.eb, nh).act(ACT_ELU); RUN(b, L_DEC1, M);
+      Lin g; g.seg(w.eb, nh, nh).out(gl, G2); g.a.scale_ptr = flat + po.dec_output_scale; RUN(g, L_DEC2, M);
+      InsertArgs ia; memset(&ia, 0, sizeof(ia));
+      ia.glimpse = gl; ia.rec = w.rec_m[pn]; ia.rec_ld = RW; ia.img = img; ia.mean_img = flat + po.dec_mean_img;
+      ia.canvas = out.canvas ? out.canvas + (size_t)t * R * P_ : nullptr; ia.data_ll = w.dll; ia.qz = w.qz; ia.pz = w.pz;
+      ia.t = t; ia.out = out; ia.std_fg = c.output_std; ia.std_bg = c.background_std;
+      sq_launch_insert_loglik(ia, d, s);
+    }
+  }
+  // final recurrent state (for state-level parity checks)
+  const int pf = T & 1;
+  if (out.final_temporal_state)
+    SQ_CHECK_HIP(hipMemcpyAsync(out.final_temporal_state, w.temporal_m[pf], (size_t)M * nh * 4, hipMemcpyDeviceToDevice, s));
+  if (out.final_prior_state)
+    SQ_CHECK_HIP(hipMemcpyAsync(out.final_prior_state, w.prior_m[pf], (size_t)M * nh * 4, hipMemcpyDeviceToDevice, s));
+  if (out.final_last_used_id)
+    SQ_CHECK_HIP(hipMemcpyAsync(out.final_last_used_id, w.last_id[pf], (size_t)R * 4, hipMemcpyDeviceToDevice, s));
+  SQ_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sqair_forward(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
+                             const float* noise, int T, int B, int t_offset, const SqairOutputs* out, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+  if (!h) return -1;
+  return forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
+                      workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int sqair_graph_capture(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
+                                   const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!h) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+  SQ_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  int rc = forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
+                        workspace_bytes, s);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(s, &g);
+  if (rc != 0) {
+    if (g) hipGraphDestroy(g);
+    return rc;
+  }
+  if (e != hipSuccess) {
+    sq_set_error(h, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    return -2;
+  }
+  h->graph = g;
+  size_t nn = 0;
+  SQ_CHECK_HIP(hipGraphGetNodes(g, nullptr, &nn));
+  h->graph_nodes = (int)nn;
+  SQ_CHECK_HIP(hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0));
+  return 0;
+}
+
+extern "C" int sqair_graph_launch(SqairHandle* h, void* stream) {
+  if (!h || !h->graph_exec) {
+    sq_set_error(h, "sqair_graph_launch: no captured graph");
+    return -1;
+  }
+  SQ_CHECK_HIP(hipGraphLaunch(h->graph_exec, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int sqair_graph_nodes(const SqairHandle* h) { return h ? h->graph_nodes : -1; }
+
+extern "C" int sqair_elbo(SqairHandle* h, const float* log_w_t, const float* disc_lp_t, int T, int B, float* log_weights,
+                          float* elbo_iwae_per_example, float* importance_weights, float* vimco_signal,
+                          float* scalars_out, const float* const* iw_means_in, int n_means, float* iw_means_out,
+                          void* stream) {
+  if (!h || !log_w_t || T < 1 || B < 1 || n_means < 0 || n_means > 8) return -1;
+  sq_launch_elbo(log_w_t, disc_lp_t, T, B, h->cfg.k_particles, log_weights, elbo_iwae_per_example, importance_weights,
+                 vimco_signal, scalars_out, iw_means_in, n_means, iw_means_out, (hipStream_t)stream);
+  SQ_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-kernel entry points for unit parity tests
+// ------------------------------------------------------------------------------------------------
+extern "C" int sqair_st_crop(SqairHandle* h, const float* img, const float* where_logits, const float* mask, float* out,
+                             int B, void* stream) {
+  if (!h || !img || !where_logits || !out || B < 1) return -1;
+  const SqairConfig& c = h->cfg;
+  Dims d{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles,
+         B * c.k_particles, B, 4 + c.n_what + 1};
+  CropArgs ca; memset(&ca, 0, sizeof(ca));
+  ca.mode = CROP_PLAIN; ca.img = img; ca.logits = where_logits; ca.mask = mask; ca.mask_row_mul = 1; ca.out = out;
+  ca.out_row_mul = 1;
+  sq_launch_crop(ca, h->po, d, 1, (hipStream_t)stream);
+  SQ_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sqair_st_insert_loglik(SqairHandle* h, const float* glimpse, const float* where_logits,
+                                      const float* presence, const float* img, const float* mean_img, float* canvas,
+                                      float* data_ll, int B, void* stream) {
+  if (!h || !glimpse || !where_logits || !presence || !img || !mean_img || !data_ll || B < 1) return -1;
+  const SqairConfig& c = h->cfg;
+  Dims d{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles,
+         B * c.k_particles, B, 4 + c.n_what + 1};
+  InsertArgs ia; memset(&ia, 0, sizeof(ia));
+  ia.glimpse = glimpse; ia.where_plain = where_logits; ia.pres_plain = presence; ia.img = img; ia.mean_img = mean_img;
+  ia.canvas = canvas; ia.data_ll = data_ll; ia.std_fg = c.output_std; ia.std_bg = c.background_std;
+  sq_launch_insert_loglik(ia, d, (hipStream_t)stream);
+  SQ_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ad-hoc pack of a dense [K,N] matrix on the host plan path: scratch = [idx int32 | packed w | packed b | bidx]
+static int adhoc_layer(SqairHandle* h, int Kdim, int Ndim, PackedLayer* L) {
+  L->seg_width = {Kdim};
+  L->kc = (Kdim + 15) / 16;
+  L->nt = (Ndim + 15) / 16;
+  L->N = Ndim;
+  L->w_off = 0;
+  L->b_off = 0;
+  (void)h;
+  return 0;
+}
+
+// fills idx for a dense [K, N] row-major matrix located at flat offset `woff`, columns col0..col0+ncols of a
+// matrix with leading dimension ldw, into packed columns n0.. of a layer with `kc` chunks, segment chunk base cbase
+static void adhoc_fill(std::vector<int>& idx, int kc, int cbase, int n0, int ncols, int Kdim, int64_t woff, int ldw, int col0) {
+  for (int j = 0; j < ncols; ++j) {
+    const int n = n0 + j, tile = n / 16, ln = n % 16;
+    for (int k = 0; k < Kdim; ++k) {
+      const int cch = cbase + k / 16, kin = k % 16;
+      const int lane = (kin / 4) * 16 + ln, comp = kin % 4;
+      idx[(((int64_t)tile * kc + cch) * 64 + lane) * 4 + comp] = (int)(woff + (int64_t)k * ldw + col0 + j);
+    }
+  }
+}
+
+extern "C" int sqair_linear_test(SqairHandle* h, const float* x, const float* wmat, const float* b, float* y, int M,
+                                 int Kdim, int Ndim, int act, void* scratch, int64_t scratch_bytes, void* stream) {
+  if (!h || !x || !wmat || !y || !scratch) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  PackedLayer L;
+  adhoc_layer(h, Kdim, Ndim, &L);
+  const int64_t nel = (int64_t)L.nt * L.kc * 256, nb = L.nt * 16;
+  if (scratch_bytes < (2 * nel + 2 * nb) * 4) { sq_set_error(h, "sqair_linear_test: scratch too small"); return -1; }
+  std::vector<int> idx(nel, -1), bidx(nb, -1), bnone(nb, -1);
+  adhoc_fill(idx, L.kc, 0, 0, Ndim, Kdim, 0, Ndim, 0);
+  for (int n = 0; n < Ndim; ++n) bidx[n] = b ? n : -1;
+  int* d_idx = (int*)scratch;
+  float* d_w = (float*)scratch + nel;
+  float* d_b = d_w + nel;
+  int* d_bidx = (int*)(d_b + nb);
+  SQ_CHECK_HIP(hipMemcpyAsync(d_idx, idx.data(), nel * 4, hipMemcpyHostToDevice, s));
+  SQ_CHECK_HIP(hipMemcpyAsync(d_bidx, bidx.data(), nb * 4, hipMemcpyHostToDevice, s));
+  SQ_CHECK_HIP(hipStreamSynchronize(s));
+  sq_launch_pack(wmat, d_w, d_idx, nel, s);
+  if (b) sq_launch_pack(b, d_b, d_bidx, nb, s);
+  else SQ_CHECK_HIP(hipMemsetAsync(d_b, 0, nb * 4, s));
+  Lin l;
+  l.seg(x, Kdim, Kdim).out(y, Ndim).act(act);
+  l.a.wp = d_w; l.a.bias = d_b; l.a.M = M; l.a.N = Ndim;
+  sq_launch_linear(l.a, L, s);
+  SQ_CHECK_HIP(hipGetLastError());
+  SQ_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+extern "C" int sqair_gru_test(SqairHandle* h, const float* x, const float* hstate, const float* gru_flat, float* h_out,
+                              int M, int Kx, void* scratch, int64_t scratch_bytes, void* stream) {
+  if (!h || !x || !hstate || !gru_flat || !h_out || !scratch) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const int nh = h->cfg.n_hidden;
+  // gru_flat: for g in (z, r, h): w_g [Kx,nh], u_g [nh,nh], b_g [nh]  (the order add_gru() lays them out)
+  const int64_t gs = (int64_t)Kx * nh + (int64_t)nh * nh + nh;
+  PackedLayer L1, L2;
+  L1.seg_width = {Kx, nh};
+  L1.kc = (Kx + 15) / 16 + (nh + 15) / 16;
+  L1.nt = 3 * nh / 16; L1.N = 3 * nh; L1.w_off = 0; L1.b_off = 0;
+  adhoc_layer(h, nh, nh, &L2);
+  const int64_t n1 = (int64_t)L1.nt * L1.kc * 256, n2 = (int64_t)L2.nt * L2.kc * 256, nb1 = L1.nt * 16, nb2 = L2.nt * 16;
+  const int64_t need = (2 * n1 + 2 * n2 + 2 * nb1 + nb2 + 3 * (int64_t)M * nh) * 4;
+  if (scratch_bytes < need) { sq_set_error(h, "sqair_gru_test: scratch too small"); return -1; }
+  std::vector<int> i1(n1, -1), i2(n2, -1), b1(nb1, -1);
+  const int xc = (Kx + 15) / 16;
+  for (int g = 0; g < 3; ++g) {
+    adhoc_fill(i1, L1.kc, 0, g * nh, nh, Kx, g * gs, nh, 0);
+    if (g < 2) adhoc_fill(i1, L1.kc, xc, g * nh, nh, nh, g * gs + (int64_t)Kx * nh, nh, 0);
+    for (int n = 0; n < nh; ++n) b1[g * nh + n] = (int)(g * gs + (int64_t)Kx * nh + (int64_t)nh * nh + n);
+  }
+  adhoc_fill(i2, L2.kc, 0, 0, nh, nh, 2 * gs + (int64_t)Kx * nh, nh, 0);
+  float* f = (float*)scratch;
+  int* d_i1 = (int*)f; f += n1;
+  float* d_w1 = f; f += n1;
+  int* d_i2 = (int*)f; f += n2;
+  float* d_w2 = f; f += n2;
+  int* d_b1i = (int*)f; f += nb1;
+  float* d_b1 = f; f += nb1;
+  float* d_b2 = f; f += nb2;
+  float* d_z = f; f += (int64_t)M * nh;
+  float* d_rh = f; f += (int64_t)M * nh;
+  float* d_xh = f; f += (int64_t)M * nh;
+  SQ_CHECK_HIP(hipMemcpyAsync(d_i1, i1.data(), n1 * 4, hipMemcpyHostToDevice, s));
+  SQ_CHECK_HIP(hipMemcpyAsync(d_i2, i2.data(), n2 * 4, hipMemcpyHostToDevice, s));
+  SQ_CHECK_HIP(hipMemcpyAsync(d_b1i, b1.data(), nb1 * 4, hipMemcpyHostToDevice, s));
+  SQ_CHECK_HIP(hipStreamSynchronize(s));
+  sq_launch_pack(gru_flat, d_w1, d_i1, n1, s);
+  sq_launch_pack(gru_flat, d_w2, d_i2, n2, s);
+  sq_launch_pack(gru_flat, d_b1, d_b1i, nb1, s);
+  SQ_CHECK_HIP(hipMemsetAsync(d_b2, 0, nb2 * 4, s));
+  Lin g1;
+  g1.seg(x, Kx, Kx).seg(hstate, nh, nh).out(d_z, nh).gru1(hstate, nh, d_rh, nh, d_xh, nh, nh);
+  g1.a.wp = d_w1; g1.a.bias = d_b1; g1.a.M = M; g1.a.N = 3 * nh;
+  sq_launch_linear(g1.a, L1, s);
+  Lin g2;
+  g2.seg(d_rh, nh, nh).add(d_xh, nh, nh).out(h_out, nh).gru2(hstate, nh, d_z, nh, nh);
+  g2.a.wp = d_w2; g2.a.bias = d_b2; g2.a.M = M; g2.a.N = nh;
+  sq_launch_linear(g2.a, L2, s);
+  SQ_CHECK_HIP(hipGetLastError());
+  SQ_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-only introspection of the packing plan (tests/test_pack_plan.py emulates the packed GEMMs on
+// the CPU from these tables to check the row / column maps without a GPU)
+// ------------------------------------------------------------------------------------------------
+extern "C" int sqair_debug_layers(const SqairHandle* h) { return h ? (int)L_COUNT : -1; }
+extern "C" int sqair_debug_layer(const SqairHandle* h, int id, int* kc, int* nt, int* n, int* nseg, int* seg_widths) {
+  if (!h || id < 0 || id >= L_COUNT) return -1;
+  const PackedLayer& L = h->layers[id];
+  *kc = L.kc; *nt = L.nt; *n = L.N; *nseg = (int)L.seg_width.size();
+  for (size_t i = 0; i < L.seg_width.size() && i < 4; ++i) seg_widths[i] = L.seg_width[i];
+  return 0;
+}
+// widx: [nt*kc*256] flat-parameter index per packed weight element; bidx_a/b: [nt*16]
+extern "C" int sqair_debug_plan(const SqairHandle* h, int id, int* widx, int* bidx_a, int* bidx_b) {
+  if (!h || id < 0 || id >= L_COUNT) return -1;
+  const PackedLayer& L = h->layers[id];
+  memcpy(widx, h->widx.data() + L.w_off, (size_t)L.nt * L.kc * 256 * sizeof(int));
+  memcpy(bidx_a, h->bidx_a.data() + L.b_off, (size_t)L.nt * 16 * sizeof(int));
+  memcpy(bidx_b, h->bidx_b.data() + L.b_off, (size_t)L.nt * 16 * sizeof(int));
+  return 0;
+}

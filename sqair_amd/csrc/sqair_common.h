@@ -1,0 +1,119 @@
+// Internal declarations shared by the translation units of libsqair_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/sqair_hip.h"
+
+#define SQ_CHECK_HIP(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      sq_set_error(h, std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+      return -2;                                                                             \
+    }                                                                                        \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Slot record: everything one object slot carries inside a frame, 168 floats (16-byte multiple).
+// The first 56 floats (where | what | presence | logit) are the z-record the recurrences consume;
+// weight rows are permuted at pack time so this memory order never has to match the reference's
+// concat order.
+// ---------------------------------------------------------------------------------------------
+namespace rec {
+constexpr int WHERE = 0;        // 4
+constexpr int WHAT = 4;         // n_what (<= 50 in this layout)
+constexpr int PRES = 54;
+constexpr int LOGIT = 55;
+constexpr int ZW = 56;          // width of the z-record segment
+constexpr int WHERE_LOC = 56;   // 4
+constexpr int WHERE_SCALE = 60; // 4
+constexpr int WHAT_LOC = 64;    // 50
+constexpr int WHAT_SCALE = 114; // 50
+constexpr int PROB = 164;
+constexpr int ID = 165;
+constexpr int W = 168;
+}  // namespace rec
+
+enum Act { ACT_NONE = 0, ACT_ELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3, ACT_SOFTPLUS_MIN = 4 };
+enum Epi { EPI_ACT = 0, EPI_GRU1 = 1, EPI_GRU2 = 2 };
+
+struct LinSeg {
+  const float* p;  // base; row r reads p + (r / rdiv) * ld
+  int ld;          // floats between consecutive (r / rdiv); 0 = broadcast one row
+  int width;       // true number of inputs taken from this segment (K padded to 16 in the pack)
+  int rdiv;
+};
+
+struct LinArgs {
+  LinSeg seg[4];
+  int nseg;
+  const float* wp;    // packed weights of this layer: [n_tiles][k_chunks][64 lanes][4]
+  const float* bias;  // packed bias [n_tiles*16]
+  const float* add;   // optional pre-activation addend, applied for n < add_n
+  int add_ld, add_rdiv, add_n;
+  float* out;
+  int out_ld;
+  int M, N;
+  int epi;
+  int act_a, act_b, act_split;  // act_a for n < act_split, act_b otherwise
+  const float* scale_ptr;       // optional device scalar multiplied after the activation
+  float scale;                  // host scalar multiplied after the activation (1 = none)
+  // GRU epilogues
+  const float* e0; int e0_ld;   // h  (previous state)
+  const float* e1; int e1_ld;   // z  (GRU2)
+  float* o1; int o1_ld;         // r*h (GRU1)
+  float* o2; int o2_ld;         // x W_h + b_h (GRU1)
+  int nh;
+};
+
+// One packed layer (host-side description)
+struct PackedLayer {
+  int64_t w_off;   // float offset into the packed buffer
+  int64_t b_off;   // float offset of the packed bias
+  int kc;          // number of 16-wide K chunks (sum over segments)
+  int nt;          // number of 16-wide N tiles
+  int N;           // true number of output columns
+  std::vector<int> seg_width;  // true widths per segment
+};
+
+struct SqairHandle;
+void sq_set_error(SqairHandle* h, const std::string& msg);
+
+// launchers (sqair_linear.hip)
+int sq_launch_linear(const LinArgs& a, const PackedLayer& L, hipStream_t s);
+int sq_launch_pack(const float* flat, float* packed_w, const int* idx, int64_t n, hipStream_t s);
+int sq_launch_pack_bias(const float* flat, float* packed_b, const int* idxa, const int* idxb, int64_t n,
+                        hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// device math (exact-ish fp32; no fast-math so that parity with the fp64 oracle holds to ~1e-6)
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float sq_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sq_softplus(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sq_elu(float x) { return x > 0.0f ? x : expm1f(x); }
+__device__ __forceinline__ float sq_act(float v, int act) {
+  switch (act) {
+    case ACT_ELU: return sq_elu(v);
+    case ACT_TANH: return tanhf(v);
+    case ACT_SIGMOID: return sq_sigmoid(v);
+    case ACT_SOFTPLUS_MIN: return sq_softplus(v) + 1e-2f;
+    default: return v;
+  }
+}
+__device__ __forceinline__ float sq_normal_lp(float x, float loc, float scale) {
+  const float d = (x - loc) / scale;
+  return -0.5f * d * d - logf(scale) - 0.91893853320467274178f;
+}
+__device__ __forceinline__ float sq_bernoulli_lp(float x, float logit) {
+  return -(fmaxf(logit, 0.0f) - logit * x + log1pf(expf(-fabsf(logit))));
+}
+__device__ __forceinline__ float sq_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+#endif

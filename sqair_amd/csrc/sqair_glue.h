@@ -1,0 +1,99 @@
+// Launchers of the non-GEMM kernels (sqair_glue.hip).
+#pragma once
+#include "sqair_common.h"
+
+constexpr int SQ_MAXN = 8;  // max object slots supported by the small per-row kernels
+
+// Offsets (in floats) into the flat parameter buffer of the small layers the per-row kernels read
+// straight from the unpacked parameters.
+struct POff {
+  int dec_mean_img, dec_output_scale;
+  int rn_init_state, rn_init_sample, rn_readout_w, rn_readout_b, rn_cond_w, rn_cond_b, rn_h2h_w, rn_h2h_b,
+      rn_i2h_w, rn_i2h_b;
+  int sp_l0_w, sp_l0_b, sp_l1_w, sp_l1_b, step_prior_bias, step_prior_tbias;
+  int disc_steps_l1_w, disc_steps_l1_b, prop_steps_l1_w, prop_steps_l1_b;
+  int disc_scale_offset, prop_scale_offset, cholesky;
+  int disc_rnn_init, prop_rnn_init, prior_init, temporal_init;
+};
+
+struct Dims {
+  int H, W, G, N, nw, nh, K, R, B;  // R = B*K rows
+  int nzw;                          // noise width = 4 + nw + 1
+};
+
+enum CropMode { CROP_PLAIN = 0, CROP_PROP1 = 1, CROP_PROP2 = 2, CROP_DISC = 3 };
+
+struct CropArgs {
+  int mode;
+  const float* img;        // [B,H,W] frame t
+  const float* logits;     // PLAIN: [R,4]
+  const float* mask;       // optional [rows, G*G]
+  int mask_row_mul, mask_row_add;  // mask row = r*mul + add
+  float* out;              // [rows, G*G]
+  int out_row_mul, out_row_add;
+  const float* rec_prev;   // merged records of t-1 [R,N,168]
+  float* rec_new;          // prop / disc records of this frame [R,N,168]
+  const float* wb;         // PROP1: raw where-bias MLP output [(R*N), wb_ld]
+  int wb_ld;
+  const float* tp;         // PROP2 / DISC: transform MLP output [R, tp_ld] (loc 0:4, raw scale 4:8)
+  int tp_ld;
+  const float* noise;      // noise of frame t, [R,2,N,nzw]
+  const float* flat;       // flat parameters
+  int slot;                // PROP2 / DISC slot; PROP1 uses blockIdx.y
+};
+
+int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float* last_id, float* disc_init_rec,
+                         const float* flat,
+                         POff po, Dims d, hipStream_t s);
+int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s);
+int sq_launch_what_disc(const float* enc, int enc_ld, const float* noise, float* rec_d, int slot, Dims d,
+                        hipStream_t s);
+int sq_launch_what_prop(const float* hraw, int h_ld, const float* enc, int enc_ld, const float* rec_prev,
+                        const float* noise, float* rec_p, int slot, Dims d, hipStream_t s);
+int sq_launch_steps(const float* s1, int s1_ld, const float* flat, int w_off, int b_off, const float* rec_prev,
+                    float* rec_new, const float* noise, int slot, int is_disc, Dims d, hipStream_t s);
+int sq_launch_latent_sum(const float* f, const float* rec_p, float* c, Dims d, hipStream_t s);
+
+struct LogprobArgs {
+  const float* rec_p; const float* rec_d; const float* rec_prev;
+  const float* pstats; int ps_ld;     // raw prior linear output [(R*N), ps_ld]
+  const float* spre;                  // [R,128] pre-activation of the where-prior conditioning state (without e)
+  const float* flat;
+  int t_global;                       // absolute frame index (categorical prior is time dependent)
+  int t;                              // frame index inside the output tensors
+  float* qz; float* pz; float* disc_lp;  // frame scalars [R]
+  SqairOutputs out;
+  SqairConfig cfg;
+};
+int sq_launch_logprob(const LogprobArgs& a, POff po, Dims d, hipStream_t s);
+
+struct CompactArgs {
+  const float* rec_p; const float* rec_d; const float* rec_prev;
+  const float* temporal_p; const float* prior_p;
+  const float* last_id_prev; float* last_id_next;
+  float* rec_next; float* temporal_next; float* prior_next;
+  const float* flat;
+  int t;
+  SqairOutputs out;
+};
+int sq_launch_compact(const CompactArgs& a, POff po, Dims d, hipStream_t s);
+
+struct InsertArgs {
+  const float* glimpse;    // [R,N,G*G]
+  const float* rec;        // merged records of this frame [R,N,rec_ld] (where at +0, presence at +54) or
+  int rec_ld;              // plain mode: where [R,N,4] / presence [R,N] given separately
+  const float* where_plain; const float* pres_plain;
+  const float* img;        // [B,H,W]
+  const float* mean_img;   // [H,W]
+  float* canvas;           // optional [R,H,W]
+  float* data_ll;          // [R]
+  const float* qz; const float* pz;  // optional frame scalars -> log weight outputs
+  int t;
+  SqairOutputs out;        // only the scalar log-weight outputs are used (may be all NULL)
+  float std_fg, std_bg;
+};
+int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s);
+
+int sq_launch_elbo(const float* log_w_t, const float* disc_lp_t, int T, int B, int K, float* log_weights,
+                   float* elbo_per_ex, float* iw, float* signal, float* scalars, const float* const* means_in,
+                   int n_means, float* means_out, hipStream_t s);

@@ -1,0 +1,735 @@
+// Non-GEMM kernels of the SQAIR hot path: spatial-transformer crop / insert, sampling, presence,
+// log-probabilities with the presence mask applied in-kernel, slot compaction and the IWAE / VIMCO
+// reductions.  All HBM-bound gather / scatter / reduce work (class 2).
+#include "sqair_glue.h"
+
+// ------------------------------------------------------------------------------------------------
+// initial recurrent state (reference: sqair/seq.py:86-100, sqair_modules.py:352-366, core.py:156-162)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_init_state(float* __restrict__ rec_m, float* __restrict__ temporal_m, float* __restrict__ prior_m,
+                             float* __restrict__ last_id, float* __restrict__ disc_init_rec,
+                             const float* __restrict__ flat, POff po, Dims d) {
+  const int rs = blockIdx.x;  // row*N + slot
+  const int tid = threadIdx.x;
+  for (int i = tid; i < rec::W; i += blockDim.x) rec_m[(size_t)rs * rec::W + i] = (i == rec::ID) ? -1.0f : 0.0f;
+  for (int i = tid; i < d.nh; i += blockDim.x) {
+    temporal_m[(size_t)rs * d.nh + i] = flat[po.temporal_init + i];
+    prior_m[(size_t)rs * d.nh + i] = flat[po.prior_init + i];
+  }
+  if (tid == 0 && (rs % d.N) == 0) last_id[rs / d.N] = -1.0f;
+  if (tid == 0 && rs == 0) disc_init_rec[rec::PRES] = 1.0f;
+}
+
+int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float* last_id, float* disc_init_rec,
+                         const float* flat, POff po, Dims d, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_state, dim3(d.R * d.N), dim3(256), 0, s, rec_m, temporal_m, prior_m, last_id, disc_init_rec,
+                     flat, po, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Spatial-transformer crop (reference: sqair/modules.py:170-227; Sonnet AffineGridWarper +
+// tf.contrib.resampler).  One workgroup per sequence b stages the frame in LDS
+// once and cuts the glimpses of all K particles of that sequence from it.  The `where` sample of
+// the propagation / discovery core is drawn in the same launch (core.py:323-334, :217-227).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tril4(const float* __restrict__ v, int i, int j) {
+  // tfd.fill_triangular for n = 4: reshape(concat(v[4:], reverse(v)), [4,4]), lower band
+  const int q = i * 4 + j;
+  return q < 6 ? v[4 + q] : v[15 - q];
+}
+
+__global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, const Dims d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* img_s = smem;                       // H*W
+  float* coord_s = smem + d.H * d.W;         // K * 4 (sx, sy, tx, ty)
+  float* tab_s = coord_s + d.K * 4;          // K * 2G * 2 : per particle x0f,wx per column ; y0f,wy per row
+  const int b = blockIdx.x;
+  const int slot = (a.mode == CROP_PROP1) ? (int)blockIdx.y : a.slot;
+  const int tid = threadIdx.x;
+  const int P = d.H * d.W;
+  const int G = d.G, G2 = d.G * d.G;
+  const float* __restrict__ img = a.img + (size_t)b * P;
+  for (int i = tid; i < P; i += 256) img_s[i] = img[i];
+
+  if (tid < d.K) {
+    const int r = b * d.K + tid;
+    float wl[4];
+    if (a.mode == CROP_PLAIN) {
+      for (int i = 0; i < 4; ++i) wl[i] = a.logits[(size_t)r * 4 + i];
+    } else if (a.mode == CROP_PROP1) {
+      const float* zp = a.rec_prev + ((size_t)r * d.N + slot) * rec::W + rec::WHERE;
+      const float* wb = a.wb + ((size_t)r * d.N + slot) * a.wb_ld;
+      for (int i = 0; i < 4; ++i) wl[i] = zp[i] + wb[i] * 0.1f;
+    } else {
+      const float* tp = a.tp + (size_t)r * a.tp_ld;
+      const float* eps = a.noise + (((size_t)r * 2 + (a.mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
+      float* rn = a.rec_new + ((size_t)r * d.N + slot) * rec::W;
+      float loc[4], sc[4];
+      if (a.mode == CROP_DISC) {
+        const float off = a.flat[po.disc_scale_offset];
+        for (int i = 0; i < 4; ++i) {
+          loc[i] = tp[i];
+          sc[i] = sq_softplus(tp[4 + i] + off) + 1e-2f;
+          wl[i] = loc[i] + sc[i] * eps[i];
+        }
+      } else {
+        const float* zp = a.rec_prev + ((size_t)r * d.N + slot) * rec::W + rec::WHERE;
+        const float off = a.flat[po.prop_scale_offset];
+        const float* ch = a.flat + po.cholesky;
+        for (int i = 0; i < 4; ++i) {
+          loc[i] = zp[i] + 1.0f * tp[i];
+          sc[i] = sq_softplus(tp[4 + i] + off - 1.0f) + 1e-2f;
+        }
+        for (int i = 0; i < 4; ++i) {  // where = loc + L eps, L = T * sc[:,None] + diag(sc)
+          float acc = 0.0f;
+          for (int j = 0; j <= i; ++j) {
+            const float lij = tril4(ch, i, j) * sc[i] + (i == j ? sc[i] : 0.0f);
+            acc += lij * eps[j];
+          }
+          wl[i] = loc[i] + acc;
+        }
+      }
+      for (int i = 0; i < 4; ++i) {
+        rn[rec::WHERE + i] = wl[i];
+        rn[rec::WHERE_LOC + i] = loc[i];
+        rn[rec::WHERE_SCALE + i] = sc[i];
+      }
+    }
+    coord_s[tid * 4 + 0] = fmaxf(sq_sigmoid(wl[0]), 1e-4f);
+    coord_s[tid * 4 + 1] = fmaxf(sq_sigmoid(wl[1]), 1e-4f);
+    coord_s[tid * 4 + 2] = tanhf(wl[2]);
+    coord_s[tid * 4 + 3] = tanhf(wl[3]);
+  }
+  __syncthreads();
+  // per particle: source coordinates of the G columns and G rows
+  for (int i = tid; i < d.K * 2 * G; i += 256) {
+    const int kp = i / (2 * G), q = i % (2 * G);
+    const bool is_y = q >= G;
+    const int j = is_y ? q - G : q;
+    const float gn = -1.0f + 2.0f * (float)j / (float)(G - 1);
+    const float sc = coord_s[kp * 4 + (is_y ? 1 : 0)], tr = coord_s[kp * 4 + (is_y ? 3 : 2)];
+    const float L = (float)((is_y ? d.H : d.W) - 1);
+    const float x = 0.5f * L * (sc * gn + tr + 1.0f);
+    const float x0 = floorf(x);
+    tab_s[(kp * 2 * G + q) * 2 + 0] = x0;
+    tab_s[(kp * 2 * G + q) * 2 + 1] = x - x0;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < d.K * G2; idx += 256) {
+    const int kp = idx / G2, pix = idx % G2;
+    const int i = pix / G, j = pix % G;
+    const float* tb = tab_s + (size_t)kp * 2 * G * 2;
+    const float x0f = tb[j * 2], wx1 = tb[j * 2 + 1];
+    const float y0f = tb[(G + i) * 2], wy1 = tb[(G + i) * 2 + 1];
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    float v = 0.0f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int yy = y0 + dy;
+      const float wy = dy ? wy1 : 1.0f - wy1;
+      if (yy < 0 || yy >= d.H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int xx = x0 + dx;
+        const float wx = dx ? wx1 : 1.0f - wx1;
+        if (xx < 0 || xx >= d.W) continue;
+        v += wy * wx * img_s[yy * d.W + xx];
+      }
+    }
+    const int r = b * d.K + kp;
+    if (a.mask != nullptr) v *= a.mask[((size_t)r * a.mask_row_mul + a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0)) * G2 + pix];
+    a.out[((size_t)r * a.out_row_mul + a.out_row_add + (a.mode == CROP_PROP1 ? slot : 0)) * G2 + pix] = v;
+  }
+}
+
+int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
+  const size_t shm = ((size_t)d.H * d.W + d.K * 4 + (size_t)d.K * 2 * d.G * 2) * sizeof(float);
+  static bool big_lds = false;
+  if (shm > 48 * 1024 && !big_lds) {  // 128x128 frames: 64 KiB + tables, CDNA4 has 160 KiB of LDS per CU
+    hipFuncSetAttribute((const void*)k_crop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    big_lds = true;
+  }
+  hipLaunchKernelGGL(k_crop, dim3(d.B, nslots), dim3(256), shm, s, a, po, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// what ~ N(loc, scale) for discovery (reference: sqair/core.py:213-215)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_what_disc(const float* __restrict__ enc, int enc_ld, const float* __restrict__ noise,
+                            float* __restrict__ rec_d, int slot, Dims d) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int c = threadIdx.x & 63;
+  if (r >= d.R || c >= d.nw) return;
+  const float loc = enc[(size_t)r * enc_ld + c];
+  const float sc = enc[(size_t)r * enc_ld + d.nw + c];
+  const float eps = noise[(((size_t)r * 2 + 1) * d.N + slot) * d.nzw + 4 + c];
+  float* rn = rec_d + ((size_t)r * d.N + slot) * rec::W;
+  rn[rec::WHAT + c] = loc + sc * eps;
+  rn[rec::WHAT_LOC + c] = loc;
+  rn[rec::WHAT_SCALE + c] = sc;
+}
+int sq_launch_what_disc(const float* enc, int enc_ld, const float* noise, float* rec_d, int slot, Dims d,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(k_what_disc, dim3((d.R + 3) / 4), dim3(256), 0, s, enc, enc_ld, noise, rec_d, slot, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gated what update of propagation (reference: sqair/core.py:336-359)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_what_prop(const float* __restrict__ hraw, int h_ld, const float* __restrict__ enc, int enc_ld,
+                            const float* __restrict__ rec_prev, const float* __restrict__ noise,
+                            float* __restrict__ rec_p, int slot, Dims d) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int c = threadIdx.x & 63;
+  if (r >= d.R || c >= d.nw) return;
+  const int nw = d.nw;
+  const float* hr = hraw + (size_t)r * h_ld;
+  const float t_loc = hr[c];
+  const float t_scale = sq_softplus(hr[nw + c]) + 1e-2f;
+  const float fg = sq_sigmoid(hr[2 * nw + c]) * 0.9999f;
+  const float ig = sq_sigmoid(hr[3 * nw + c]) * 0.9999f;
+  const float tg = sq_sigmoid(hr[4 * nw + c]) * 0.9999f;
+  const float loc2 = enc[(size_t)r * enc_ld + c];
+  const float sc2 = enc[(size_t)r * enc_ld + nw + c];
+  const float what_tm1 = rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHAT + c];
+  const float loc = fg * what_tm1 + (1.0f - ig) * loc2 + (1.0f - tg) * t_loc;
+  const float sc = (1.0f - ig) * sc2 + (1.0f - tg) * t_scale;
+  const float eps = noise[(((size_t)r * 2 + 0) * d.N + slot) * d.nzw + 4 + c];
+  float* rn = rec_p + ((size_t)r * d.N + slot) * rec::W;
+  rn[rec::WHAT + c] = loc + sc * eps;
+  rn[rec::WHAT_LOC + c] = loc;
+  rn[rec::WHAT_SCALE + c] = sc;
+}
+int sq_launch_what_prop(const float* hraw, int h_ld, const float* enc, int enc_ld, const float* rec_prev,
+                        const float* noise, float* rec_p, int slot, Dims d, hipStream_t s) {
+  hipLaunchKernelGGL(k_what_prop, dim3((d.R + 3) / 4), dim3(256), 0, s, hraw, h_ld, enc, enc_ld, rec_prev, noise,
+                     rec_p, slot, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// StepsPredictor output layer + presence Bernoulli (reference: sqair/modules.py:506-524,
+// sqair/core.py:141-144).  One wavefront per row: 128-long dot product, wave reduction.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_steps(const float* __restrict__ s1, int s1_ld, const float* __restrict__ flat, int w_off, int b_off,
+                        const float* __restrict__ rec_prev, float* __restrict__ rec_new,
+                        const float* __restrict__ noise, int slot, int is_disc, Dims d) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= d.R) return;
+  const int nsp = d.nh / 2;
+  float acc = 0.0f;
+  for (int i = lane; i < nsp; i += 64) acc += s1[(size_t)r * s1_ld + i] * flat[w_off + i];
+  acc = sq_wave_sum(acc);
+  if (lane == 0) {
+    const float raw = acc + flat[b_off];
+    float prev;
+    if (is_disc) prev = slot == 0 ? 1.0f : rec_new[((size_t)r * d.N + slot - 1) * rec::W + rec::PRES];
+    else prev = rec_prev[((size_t)r * d.N + slot) * rec::W + rec::PRES];
+    const float logit = prev * raw + (prev - 1.0f) * 88.0f;
+    const float prob = sq_sigmoid(logit);
+    const float u = noise[(((size_t)r * 2 + (is_disc ? 1 : 0)) * d.N + slot) * d.nzw + 4 + d.nw];
+    float* rn = rec_new + ((size_t)r * d.N + slot) * rec::W;
+    rn[rec::PRES] = (u < prob ? 1.0f : 0.0f) * prev;
+    rn[rec::LOGIT] = logit;
+    rn[rec::PROB] = prob;
+  }
+}
+int sq_launch_steps(const float* s1, int s1_ld, const float* flat, int w_off, int b_off, const float* rec_prev,
+                    float* rec_new, const float* noise, int slot, int is_disc, Dims d, hipStream_t s) {
+  hipLaunchKernelGGL(k_steps, dim3((d.R + 3) / 4), dim3(256), 0, s, s1, s1_ld, flat, w_off, b_off, rec_prev, rec_new,
+                     noise, slot, is_disc, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DeepSets summary of the propagated latents (reference: sqair/sqair_modules.py:368-385)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_latent_sum(const float* __restrict__ f, const float* __restrict__ rec_p, float* __restrict__ c, Dims d) {
+  const int r = blockIdx.x;
+  for (int n = threadIdx.x; n < d.nh; n += blockDim.x) {
+    float acc = 0.0f;
+    for (int k = 0; k < d.N; ++k)
+      acc += f[((size_t)r * d.N + k) * d.nh + n] * rec_p[((size_t)r * d.N + k) * rec::W + rec::PRES];
+    c[(size_t)r * d.nh + n] = acc;
+  }
+}
+int sq_launch_latent_sum(const float* f, const float* rec_p, float* c, Dims d, hipStream_t s) {
+  hipLaunchKernelGGL(k_latent_sum, dim3(d.R), dim3(256), 0, s, f, rec_p, c, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// All log-probabilities of one frame, presence masks applied in-kernel.
+// reference: Propagate._compute_log_probs sqair/sqair_modules.py:281-329 (+ PropagatePrior
+// propagate.py:68-158, AffineDiagNormal modules.py:535-545), Discover._compute_log_probs /
+// _make_priors sqair_modules.py:149-229, NumStepsDistribution prior.py:61-105 (float64),
+// RecurrentNormalImpl modules.py:548-611, SQAIRTimestep sums :483-485, :505-507.
+// One wavefront per row b'.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_logprob(const LogprobArgs a, const POff po, const Dims d) {
+  const int r = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int N = d.N, nw = d.nw;
+  const float* __restrict__ flat = a.flat;
+  const size_t tr = (size_t)a.t * d.R + r;
+  const float LOG2PI = 1.83787706640934548356f;
+
+  float e_sum = 0.0f, q_prop = 0.0f, p_prop = 0.0f, q_pres_sum = 0.0f, p_pres_sum = 0.0f, n_prop = 0.0f;
+  for (int k = 0; k < N; ++k) {
+    const float* rp = a.rec_p + ((size_t)r * N + k) * rec::W;
+    const float* rm = a.rec_prev + ((size_t)r * N + k) * rec::W;
+    const float* ps = a.pstats + ((size_t)r * N + k) * a.ps_ld;
+    const float pres = rp[rec::PRES], pres_tm1 = rm[rec::PRES];
+    const float logit = rp[rec::LOGIT], logit_tm1 = rm[rec::LOGIT];
+    float pl = ps[0] + a.cfg.prop_prior_step_bias;
+    pl = pres_tm1 * pl + (pres_tm1 - 1.0f) * 88.0f;
+    if (a.cfg.prop_prior_type != 0) pl = logit_tm1 + 0.1f * pl;
+    float qw = 0.0f, pw = 0.0f;
+    if (lane < nw) {
+      const float x = rp[rec::WHAT + lane];
+      qw = sq_normal_lp(x, rp[rec::WHAT_LOC + lane], rp[rec::WHAT_SCALE + lane]);
+      float ploc = ps[5 + lane];
+      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHAT + lane];
+      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHAT + lane] + 0.1f * ploc;
+      pw = sq_normal_lp(x, ploc, sq_softplus(ps[9 + nw + lane]) + 1e-2f);
+    }
+    const float q_what = sq_wave_sum(qw), p_what = sq_wave_sum(pw);
+    float pwh = 0.0f;
+    if (lane < 4) {
+      float ploc = ps[1 + lane];
+      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHERE + lane];
+      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHERE + lane] + 0.1f * ploc;
+      pwh = sq_normal_lp(rp[rec::WHERE + lane], ploc, sq_softplus(ps[5 + nw + lane]) + 1e-2f);
+    }
+    const float p_where = sq_wave_sum(pwh);
+    // MultivariateNormalTriL log-prob: forward substitution with L = T * sc[:,None] + diag(sc)
+    float q_where;
+    {
+      const float* ch = flat + po.cholesky;
+      float y[4];
+      float sq = 0.0f, logdet = 0.0f;
+      for (int i = 0; i < 4; ++i) {
+        const float sci = rp[rec::WHERE_SCALE + i];
+        float acc = rp[rec::WHERE + i] - rp[rec::WHERE_LOC + i];
+        for (int j = 0; j < i; ++j) acc -= tril4(ch, i, j) * sci * y[j];
+        const float lii = tril4(ch, i, i) * sci + sci;
+        y[i] = acc / lii;
+        sq += y[i] * y[i];
+        logdet += logf(fabsf(lii));
+      }
+      q_where = -0.5f * sq - logdet - 2.0f * LOG2PI;
+    }
+    const float q_pres = sq_bernoulli_lp(pres, logit);
+    const float p_pres = sq_bernoulli_lp(pres, pl);
+    const float m = pres_tm1 * pres;
+    if (lane == 0) {
+      const size_t o = tr * N + k;
+      if (a.out.prop_what_log_prob) a.out.prop_what_log_prob[o] = q_what * m;
+      if (a.out.prop_where_log_prob) a.out.prop_where_log_prob[o] = q_where * m;
+      if (a.out.prop_what_prior_log_prob) a.out.prop_what_prior_log_prob[o] = p_what * m;
+      if (a.out.prop_where_prior_log_prob) a.out.prop_where_prior_log_prob[o] = p_where * m;
+      if (a.out.prop_prob) a.out.prop_prob[o] = expf(q_pres) * pres_tm1;
+      if (a.out.prop_pres) a.out.prop_pres[o] = pres;
+    }
+    q_prop += (q_what + q_where) * m;
+    p_prop += (p_what + p_where) * m;
+    q_pres_sum += q_pres * pres_tm1;
+    p_pres_sum += p_pres * pres_tm1;
+    e_sum += (sq_sigmoid(pl) - 0.5f) / (float)N;
+    n_prop += pres;
+  }
+
+  // ---- discovery
+  float hs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (a.cfg.rec_where_prior) {
+    float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = lane; i < 128; i += 64) {
+      const float sv = sq_elu(a.spre[(size_t)r * 128 + i] + e_sum * flat[po.rn_cond_w + (4 + d.nh) * 128 + i]);
+      for (int j = 0; j < 4; ++j) part[j] += sv * flat[po.rn_h2h_w + i * 4 + j];
+    }
+    for (int j = 0; j < 4; ++j) hs[j] = sq_wave_sum(part[j]) + flat[po.rn_h2h_b + j] + flat[po.rn_i2h_b + j];
+  }
+  float q_disc = 0.0f, p_disc = 0.0f, n_disc = 0.0f;
+  double probs[SQ_MAXN];
+  for (int j = 0; j < N; ++j) {
+    const float* rd = a.rec_d + ((size_t)r * N + j) * rec::W;
+    const float pres = rd[rec::PRES];
+    probs[j] = (double)rd[rec::PROB];
+    float qw = 0.0f, pw = 0.0f;
+    if (lane < nw) {
+      const float x = rd[rec::WHAT + lane];
+      qw = sq_normal_lp(x, rd[rec::WHAT_LOC + lane], rd[rec::WHAT_SCALE + lane]);
+      pw = sq_normal_lp(x, 0.0f, 1.0f);
+    }
+    const float q_what = sq_wave_sum(qw), p_what = sq_wave_sum(pw);
+    float qwh = 0.0f, pwh = 0.0f;
+    if (lane < 4) {
+      const float x = rd[rec::WHERE + lane];
+      qwh = sq_normal_lp(x, rd[rec::WHERE_LOC + lane], rd[rec::WHERE_SCALE + lane]);
+      if (a.cfg.rec_where_prior) {
+        const float* xp = j == 0 ? flat + po.rn_init_sample : a.rec_d + ((size_t)r * N + j - 1) * rec::W + rec::WHERE;
+        float o[4];
+        for (int mm = 0; mm < 4; ++mm) {
+          float acc = hs[mm];
+          for (int i = 0; i < 4; ++i) acc += xp[i] * flat[po.rn_i2h_w + i * 4 + mm];
+          o[mm] = tanhf(acc);
+        }
+        float loc = flat[po.rn_readout_b + lane], raw = flat[po.rn_readout_b + 4 + lane];
+        for (int mm = 0; mm < 4; ++mm) {
+          loc += o[mm] * flat[po.rn_readout_w + mm * 8 + lane];
+          raw += o[mm] * flat[po.rn_readout_w + mm * 8 + 4 + lane];
+        }
+        pwh = sq_normal_lp(x, loc, sq_softplus(raw) + 1e-2f);
+      } else {
+        pwh = sq_normal_lp(x, a.cfg.where_prior_mean[lane], 1.0f);
+      }
+    }
+    const float q_where = sq_wave_sum(qwh), p_where = sq_wave_sum(pwh);
+    if (lane == 0) {
+      const size_t o = tr * N + j;
+      if (a.out.disc_what_log_prob) a.out.disc_what_log_prob[o] = q_what * pres;
+      if (a.out.disc_where_log_prob) a.out.disc_where_log_prob[o] = q_where * pres;
+      if (a.out.disc_what_prior_log_prob) a.out.disc_what_prior_log_prob[o] = p_what * pres;
+      if (a.out.disc_where_prior_log_prob) a.out.disc_where_prior_log_prob[o] = p_where * pres;
+      if (a.out.disc_pres) a.out.disc_pres[o] = pres;
+    }
+    q_disc += (q_what + q_where) * pres;
+    p_disc += (p_what + p_where) * pres;
+    n_disc += pres;
+  }
+  if (lane != 0) return;
+  // NumStepsDistribution (float64 inside, prior.py:61-67)
+  const int n = (int)(n_disc + 0.5f);
+  double joint[SQ_MAXN + 1];
+  {
+    double cum = 1.0, tot = 0.0;
+    for (int j = 0; j < N; ++j) {
+      joint[j] = (1.0 - probs[j]) * cum;
+      cum *= probs[j];
+      tot += joint[j];
+    }
+    joint[N] = cum;
+    tot += cum;
+    for (int j = 0; j <= N; ++j) joint[j] /= tot;
+  }
+  const float jn = (float)joint[n];
+  const float q_num = logf(fminf(fmaxf(jn, 1e-16f), 1.0f));
+  float p_num;
+  if (a.cfg.disc_prior_type == 1) {
+    const float pr = 1.0f - a.cfg.step_success_prob;
+    p_num = (float)n * log1pf(-pr) + logf(pr);
+  } else {
+    float hid[10];
+    for (int i = 0; i < 10; ++i) hid[i] = sq_elu(e_sum * flat[po.sp_l0_w + i] + flat[po.sp_l0_b + i]);
+    float lg[SQ_MAXN + 1];
+    float mx = -1e30f;
+    for (int c = 0; c <= N; ++c) {
+      float v = flat[po.step_prior_bias + c] + (a.t_global > 0 ? flat[po.step_prior_tbias + c] : 0.0f) + flat[po.sp_l1_b + c];
+      for (int i = 0; i < 10; ++i) v += hid[i] * flat[po.sp_l1_w + i * (N + 1) + c];
+      lg[c] = sq_elu(v);
+      mx = fmaxf(mx, lg[c]);
+    }
+    float se = 0.0f;
+    for (int c = 0; c <= N; ++c) se += expf(lg[c] - mx);
+    p_num = lg[n] - (mx + logf(se));
+  }
+  const float q_prop_tot = q_prop + q_pres_sum, p_prop_tot = p_prop + p_pres_sum;
+  const float q_disc_tot = q_disc + q_num, p_disc_tot = p_disc + p_num;
+  a.qz[r] = q_disc_tot + q_prop_tot;
+  a.pz[r] = p_disc_tot + p_prop_tot;
+  a.disc_lp[r] = q_pres_sum + q_num;
+  if (a.out.prop_log_prob) a.out.prop_log_prob[tr] = q_pres_sum;
+  if (a.out.prop_prior_log_prob) a.out.prop_prior_log_prob[tr] = p_pres_sum;
+  if (a.out.disc_log_prob) a.out.disc_log_prob[tr] = q_num;
+  if (a.out.disc_prior_log_prob) a.out.disc_prior_log_prob[tr] = p_num;
+  if (a.out.step_log_prob) a.out.step_log_prob[tr] = q_pres_sum + q_num;
+  if (a.out.discrete_log_prob) a.out.discrete_log_prob[tr] = q_pres_sum + q_num;
+  if (a.out.num_prop_steps_per_sample) a.out.num_prop_steps_per_sample[tr] = n_prop;
+  if (a.out.num_disc_steps_per_sample) a.out.num_disc_steps_per_sample[tr] = n_disc;
+  if (a.out.disc_prob)
+    for (int c = 0; c <= N; ++c) a.out.disc_prob[tr * (N + 1) + c] = (float)joint[c];
+}
+int sq_launch_logprob(const LogprobArgs& a, POff po, Dims d, hipStream_t s) {
+  hipLaunchKernelGGL(k_logprob, dim3(d.R), dim3(64), 0, s, a, po, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Slot compaction (reference: SQAIRTimestep._choose_latents sqair/sqair_modules.py:514-582,
+// index.compute_object_ids index.py:198-221, index.select_present index.py:132-165).
+// One workgroup per row: 2N presence bits -> stable present-first permutation -> copy the N
+// survivors (record + prior state + temporal state) into the next frame's state.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff po, const Dims d) {
+  __shared__ int src_s[SQ_MAXN];
+  __shared__ float id_s[SQ_MAXN];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int N = d.N, nh = d.nh;
+  if (tid == 0) {
+    float pres[2 * SQ_MAXN], ids[2 * SQ_MAXN];
+    const float last = a.last_id_prev[r];
+    float cum = 0.0f;
+    for (int k = 0; k < N; ++k) {
+      const float p = a.rec_p[((size_t)r * N + k) * rec::W + rec::PRES];
+      const float pid = a.rec_prev[((size_t)r * N + k) * rec::W + rec::ID];
+      pres[k] = p;
+      ids[k] = pid * p - (1.0f - p);
+    }
+    for (int j = 0; j < N; ++j) {
+      const float p = a.rec_d[((size_t)r * N + j) * rec::W + rec::PRES];
+      cum += p;
+      pres[N + j] = p;
+      ids[N + j] = (cum + last) * p - (1.0f - p);
+    }
+    a.last_id_next[r] = last + cum;
+    int dst = 0;
+    for (int s = 0; s < 2 * N && dst < N; ++s)
+      if (pres[s] != 0.0f) { src_s[dst] = s; id_s[dst] = ids[s]; ++dst; }
+    for (int s = 0; s < 2 * N && dst < N; ++s)
+      if (pres[s] == 0.0f) { src_s[dst] = s; id_s[dst] = ids[s]; ++dst; }
+  }
+  __syncthreads();
+  const size_t tr = (size_t)a.t * d.R + r;
+  for (int dst = 0; dst < N; ++dst) {
+    const int s = src_s[dst];
+    const float* rs = s < N ? a.rec_p + ((size_t)r * N + s) * rec::W : a.rec_d + ((size_t)r * N + (s - N)) * rec::W;
+    float* rn = a.rec_next + ((size_t)r * N + dst) * rec::W;
+    for (int i = tid; i < rec::W; i += 256) rn[i] = (i == rec::ID) ? id_s[dst] : rs[i];
+    const float* ts = s < N ? a.temporal_p + ((size_t)r * N + s) * nh : a.flat + po.temporal_init;
+    const float* qs = s < N ? a.prior_p + ((size_t)r * N + s) * nh : a.flat + po.prior_init;
+    for (int i = tid; i < nh; i += 256) {
+      a.temporal_next[((size_t)r * N + dst) * nh + i] = ts[i];
+      a.prior_next[((size_t)r * N + dst) * nh + i] = qs[i];
+    }
+    // the 9 hidden outputs + object id (seq.py:121-134)
+    const size_t o = tr * N + dst;
+    for (int c = tid; c < d.nw; c += 256) {
+      if (a.out.what) a.out.what[o * d.nw + c] = rs[rec::WHAT + c];
+      if (a.out.what_loc) a.out.what_loc[o * d.nw + c] = rs[rec::WHAT_LOC + c];
+      if (a.out.what_scale) a.out.what_scale[o * d.nw + c] = rs[rec::WHAT_SCALE + c];
+    }
+    if (tid < 4) {
+      if (a.out.where) a.out.where[o * 4 + tid] = rs[rec::WHERE + tid];
+      if (a.out.where_loc) a.out.where_loc[o * 4 + tid] = rs[rec::WHERE_LOC + tid];
+      if (a.out.where_scale) a.out.where_scale[o * 4 + tid] = rs[rec::WHERE_SCALE + tid];
+    }
+    if (tid == 0) {
+      if (a.out.presence_prob) a.out.presence_prob[o] = rs[rec::PROB];
+      if (a.out.presence) a.out.presence[o] = rs[rec::PRES];
+      if (a.out.presence_logit) a.out.presence_logit[o] = rs[rec::LOGIT];
+      if (a.out.obj_id) a.out.obj_id[o] = id_s[dst];
+    }
+  }
+  if (tid == 0 && a.out.num_steps_per_sample) {
+    float ns = 0.0f;
+    for (int dst = 0; dst < N; ++dst) {
+      const int s = src_s[dst];
+      ns += s < N ? a.rec_p[((size_t)r * N + s) * rec::W + rec::PRES] : a.rec_d[((size_t)r * N + (s - N)) * rec::W + rec::PRES];
+    }
+    a.out.num_steps_per_sample[tr] = ns;
+  }
+}
+int sq_launch_compact(const CompactArgs& a, POff po, Dims d, hipStream_t s) {
+  hipLaunchKernelGGL(k_compact, dim3(d.R), dim3(256), 0, s, a, po, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder back end: inverse spatial transformer of the N decoded glimpses onto the canvas, the
+// written-to mask, mean image, Gaussian log-likelihood and the frame log-weight, fused.
+// reference: AIRDecoder._decode/_add_mean_image/_build sqair/modules.py:435-467,
+// SequentialAIR._compute_log_weights sqair/seq.py:271-276.  One workgroup per row b'; the N
+// glimpses sit in LDS, every thread owns canvas pixels and gathers (inverse map) from them, so the
+// canvas is written at most once and the frame is read once.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const Dims d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = d.N, G = d.G, G2 = d.G * d.G, H = d.H, W = d.W, P = d.H * d.W;
+  float* gl_s = smem;                 // N * G2
+  float* xt_s = gl_s + N * G2;        // N * W  glimpse x coordinate per canvas column
+  float* yt_s = xt_s + N * W;         // N * H
+  float* pres_s = yt_s + N * H;       // N
+  __shared__ float red_s[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int b = r / d.K;
+  for (int i = tid; i < N * G2; i += 256) gl_s[i] = a.glimpse[(size_t)r * N * G2 + i];
+  for (int i = tid; i < N * (W + H); i += 256) {
+    const int k = i / (W + H), q = i % (W + H);
+    const bool is_y = q >= W;
+    const int j = is_y ? q - W : q;
+    const float* wl = a.rec ? a.rec + ((size_t)r * N + k) * a.rec_ld + rec::WHERE : a.where_plain + ((size_t)r * N + k) * 4;
+    const float sc = fmaxf(sq_sigmoid(wl[is_y ? 1 : 0]), 1e-4f);
+    const float tr = tanhf(wl[is_y ? 3 : 2]);
+    const float L = (float)((is_y ? H : W) - 1);
+    const float cn = -1.0f + 2.0f * (float)j / L;
+    const float g = 0.5f * (float)(G - 1) * ((cn - tr) / sc + 1.0f);
+    if (is_y) yt_s[k * H + j] = g; else xt_s[k * W + j] = g;
+  }
+  if (tid < N) pres_s[tid] = a.rec ? a.rec[((size_t)r * N + tid) * a.rec_ld + rec::PRES] : a.pres_plain[(size_t)r * N + tid];
+  __syncthreads();
+  const float* __restrict__ img = a.img + (size_t)b * P;
+  float ll = 0.0f;
+  for (int pix = tid; pix < P; pix += 256) {
+    const int Y = pix / W, X = pix % W;
+    float cv = 0.0f, ms = 0.0f;
+    for (int k = 0; k < N; ++k) {
+      const float pk = pres_s[k];
+      if (pk == 0.0f) continue;
+      const float xg = xt_s[k * W + X], yg = yt_s[k * H + Y];
+      const float x0f = floorf(xg), y0f = floorf(yg);
+      // fully outside the glimpse: both taps invalid on one axis
+      if (!(xg > -1.0f && xg < (float)G && yg > -1.0f && yg < (float)G)) continue;
+      const int x0 = (int)x0f, y0 = (int)y0f;
+      const float wx1 = xg - x0f, wy1 = yg - y0f;
+      const float* gk = gl_s + k * G2;
+      float v = 0.0f, on = 0.0f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int yy = y0 + dy;
+        if (yy < 0 || yy >= G) continue;
+        const float wy = dy ? wy1 : 1.0f - wy1;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int xx = x0 + dx;
+          if (xx < 0 || xx >= G) continue;
+          const float w = wy * (dx ? wx1 : 1.0f - wx1);
+          v += w * gk[yy * G + xx];
+          on += w;
+        }
+      }
+      cv += v * pk;
+      ms += on * pk;
+    }
+    const float m = sq_sigmoid(-10.0f + ms * 20.0f);
+    cv += a.mean_img[pix] * m;
+    const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
+    ll += sq_normal_lp(img[pix], cv, sd);
+    if (a.canvas) a.canvas[(size_t)r * P + pix] = cv;
+  }
+  ll = sq_wave_sum(ll);
+  if ((tid & 63) == 0) red_s[tid >> 6] = ll;
+  __syncthreads();
+  if (tid == 0) {
+    const float dll = red_s[0] + red_s[1] + red_s[2] + red_s[3];
+    a.data_ll[r] = dll;
+    if (a.qz != nullptr) {
+      const size_t tr = (size_t)a.t * d.R + r;
+      const float q = a.qz[r], p = a.pz[r];
+      const float kl = q - p;
+      if (a.out.data_ll_per_sample) a.out.data_ll_per_sample[tr] = dll;
+      if (a.out.kl_per_sample) a.out.kl_per_sample[tr] = kl;
+      if (a.out.log_q_z_given_x_per_sample) a.out.log_q_z_given_x_per_sample[tr] = q;
+      if (a.out.log_p_z_per_sample) a.out.log_p_z_per_sample[tr] = p;
+      if (a.out.log_weights_per_timestep) a.out.log_weights_per_timestep[tr] = dll - kl;
+    }
+  }
+}
+int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s) {
+  const size_t shm = ((size_t)d.N * d.G * d.G + (size_t)d.N * (d.W + d.H) + d.N) * sizeof(float);
+  hipLaunchKernelGGL(k_insert_loglik, dim3(d.R), dim3(256), shm, s, a, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// IWAE / VIMCO reductions over [T, B, K] in one launch (reference: sqair/model.py:88-103,:150-158,
+// :202-205, sqair/targets.py:38-75, sqair/ops.py:52-59).  K particles of a sequence sit on the lanes
+// of a wavefront; sums over T are serial, logsumexp / leave-one-out terms are wave reductions.
+// ------------------------------------------------------------------------------------------------
+struct ElboMeans { const float* p[8]; };
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_elbo(const float* __restrict__ log_w_t, const float* __restrict__ disc_lp_t,
+                                              int T, int B, int K, float* log_weights, float* elbo_per_ex, float* iw_out,
+                                              float* signal_out, float* scalars, ElboMeans means, int n_means,
+                                              float* means_out) {
+  __shared__ float acc_s[4][4 + 8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int R = B * K;
+  float a_vae = 0.0f, a_iwae = 0.0f, a_vimco = 0.0f, a_ess = 0.0f;
+  float a_means[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = wave; b < B; b += 4) {
+    const bool act = lane < K;
+    float lw = 0.0f, dl = 0.0f;
+    if (act) {
+      for (int t = 0; t < T; ++t) {
+        lw += log_w_t[(size_t)t * R + b * K + lane];
+        dl += disc_lp_t ? disc_lp_t[(size_t)t * R + b * K + lane] : 0.0f;
+      }
+    }
+    const float mx = wave_max(act ? lw : -3.0e38f);
+    const float ex = act ? expf(lw - mx) : 0.0f;
+    const float se = sq_wave_sum(ex);
+    const float lse = mx + logf(se);
+    const float elbo = lse - logf((float)K);
+    const float w = act ? ex / se : 0.0f;
+    // VIMCO control variate (targets.py:46-59): replace w_k by the mean of the others, logmeanexp
+    const float sum_lw = sq_wave_sum(act ? lw : 0.0f);
+    float cv = 0.0f;
+    {  // K == 1 gives 0/0 = NaN exactly like the reference's (k_particles - 1.) division (targets.py:55)
+      const float abo = (sum_lw - lw) / ((float)K - 1.0f);
+      const float m2 = fmaxf(mx, act ? abo : mx);
+      float rest = 0.0f;  // sum_{j != k} exp(lw_j - m2), exact (no cancellation)
+      for (int j = 0; j < K; ++j) {
+        const float lj = __shfl(lw, j, 64);
+        if (j != lane) rest += expf(lj - m2);
+      }
+      cv = m2 + logf(rest + expf(abo - m2)) - logf((float)K);
+    }
+    const float sig = act ? lw - cv : 0.0f;
+    const float loss = act ? (-elbo - sig * dl) : 0.0f;
+    a_vae += sq_wave_sum(act ? lw : 0.0f);
+    a_vimco += sq_wave_sum(loss);
+    const float sw = sq_wave_sum(w), sw2 = sq_wave_sum(w * w);
+    a_iwae += elbo;
+    a_ess += sw * sw / sw2;
+    if (act) {
+      if (log_weights) log_weights[b * K + lane] = lw;
+      if (iw_out) iw_out[b * K + lane] = w;
+      if (signal_out) signal_out[b * K + lane] = sig;
+    }
+    if (lane == 0 && elbo_per_ex) elbo_per_ex[b] = elbo;
+    for (int q = 0; q < n_means; ++q) {
+      float xm = 0.0f;
+      if (act) {
+        for (int t = 0; t < T; ++t) xm += means.p[q][(size_t)t * R + b * K + lane];
+        xm /= (float)T;
+      }
+      a_means[q] += sq_wave_sum(w * xm);  // mean over (B,K) of iw * x * K == mean_b sum_k iw x
+    }
+  }
+  if (lane == 0) {
+    acc_s[wave][0] = a_vae; acc_s[wave][1] = a_iwae; acc_s[wave][2] = a_vimco; acc_s[wave][3] = a_ess;
+    for (int q = 0; q < 8; ++q) acc_s[wave][4 + q] = a_means[q];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s[12];
+    for (int i = 0; i < 12; ++i) s[i] = acc_s[0][i] + acc_s[1][i] + acc_s[2][i] + acc_s[3][i];
+    if (scalars) {
+      scalars[0] = s[0] / (float)(B * K);
+      scalars[1] = s[1] / (float)B;
+      scalars[2] = s[2] / (float)(B * K) / (float)T;
+      scalars[3] = s[3] / (float)B;
+    }
+    for (int q = 0; q < n_means; ++q) means_out[q] = s[4 + q] / (float)B;
+  }
+}
+
+int sq_launch_elbo(const float* log_w_t, const float* disc_lp_t, int T, int B, int K, float* log_weights,
+                   float* elbo_per_ex, float* iw, float* signal, float* scalars, const float* const* means_in,
+                   int n_means, float* means_out, hipStream_t s) {
+  ElboMeans m;
+  for (int i = 0; i < 8; ++i) m.p[i] = (means_in != nullptr && i < n_means) ? means_in[i] : nullptr;
+  hipLaunchKernelGGL(k_elbo, dim3(1), dim3(256), 0, s, log_w_t, disc_lp_t, T, B, K, log_weights, elbo_per_ex, iw,
+                     signal, scalars, m, n_means, means_out);
+  return 0;
+}

@@ -1,0 +1,344 @@
+"""Host-side mirror of the reference's operator API for the SQAIR hot path.
+
+``load(img, coords, num, mean_img=None, debug=False)`` and the ``Model`` it returns keep the call
+surface of reference sqair/configs/mlp_mnist_model.py:74-150 and sqair/model.py:33-214 (attribute
+names, shapes, the ``make_target`` / ``resample`` methods, flag names) while every quantity is
+computed by libsqair_hip.so on the MI355X.  PyTorch is plumbing only: device memory, the current
+HIP stream, the noise draw.  There is no CPU fallback; without the library or a GPU the
+constructor raises.
+
+Differences a TF1 user will notice (TF builds a graph, ``sess.run`` evaluates it): here
+``model.run()`` plays the role of ``sess.run`` — it executes the forward pass once and refreshes
+every attribute (``model.elbo_iwae`` ...).  The first attribute access runs it implicitly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _capi
+from .flags import FLAGS, get_params, parse_string_flag
+from .params import flatten_params, init_params, param_offsets, param_spec, unflatten_params
+
+_PRIOR_TYPES = {"rnn": 0, "rw": 1, "guided": 2}
+_DISC_PRIOR_TYPES = {"cat": 0, "geom": 1}
+
+
+def make_config(F, img_hw):
+    """Flags -> SqairConfig.  Raises the reference's errors for invalid choices
+    (reference: sqair/propagate.py:42-43, sqair/sqair_modules.py:224)."""
+    if F.prop_prior_type not in _PRIOR_TYPES:
+        raise ValueError('Invalid prior type: "{}". Choose from {}.'.format(F.prop_prior_type, list(_PRIOR_TYPES)))
+    if F.disc_prior_type not in _DISC_PRIOR_TYPES:
+        raise ValueError("Invalid prior type: {}".format(F.disc_prior_type))
+    if (F.transition, F.time_transition, F.prior_transition) != ("VanillaRNN", "GRU", "GRU"):
+        raise NotImplementedError(
+            "HIP path implements the shipped cells (transition=VanillaRNN, time_transition=GRU, "
+            "prior_transition=GRU); got {}/{}/{}".format(F.transition, F.time_transition, F.prior_transition))
+    if F.sample_from_prior:
+        raise NotImplementedError("sample_from_prior / generation modes are outside the hot path (SURVEY 8(f))")
+    p = get_params(F)
+    sp = parse_string_flag(F.scale_prior, num_elements=2)
+    std = float(np.float32(np.float32(np.sqrt(F.output_std)) ** np.float32(2.0)))  # modules.py:419-422
+    return _capi.SqairConfig(
+        int(img_hw[0]), int(img_hw[1]), int(F.glimpse_size), int(F.n_steps_per_image), int(F.n_what),
+        int(p.n_hidden), int(F.k_particles), _PRIOR_TYPES[F.prop_prior_type], _DISC_PRIOR_TYPES[F.disc_prior_type],
+        int(bool(F.masked_glimpse)), int(bool(F.rec_where_prior)), float(F.prop_prior_step_bias),
+        float(F.step_success_prob), std, std, (C.c_float * 4)(sp[0], sp[1], 0.0, 0.0))
+
+
+class SqairCore(object):
+    """Thin owner of a library handle + the device buffers it needs (parameters, packed parameters,
+    workspace, noise, outputs) for one (T, B) shape on one device / stream."""
+
+    def __init__(self, F, img_hw, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sqair_amd needs a HIP device (no CPU fallback)")
+        self.F = F
+        self.lib = _capi.lib()
+        self.device = torch.device(device)
+        self.cfg = make_config(F, img_hw)
+        self.handle = C.c_void_p()
+        rc = self.lib.sqair_create(C.byref(self.cfg), C.byref(self.handle))
+        if rc != 0:
+            raise ValueError("sqair_create rejected the configuration (rc={})".format(rc))
+        self.spec = param_spec(F, img_hw)
+        self.offsets, self.n_params = param_offsets(self.spec)
+        assert self.n_params == self.lib.sqair_param_count(self.handle), "parameter inventory mismatch"
+        self.N = int(F.n_steps_per_image)
+        self.K = int(F.k_particles)
+        self.nw = int(F.n_what)
+        self.nh = get_params(F).n_hidden
+        self.G = int(F.glimpse_size)
+        self.H, self.W = int(img_hw[0]), int(img_hw[1])
+        self.nzw = self.lib.sqair_noise_width(self.handle)
+        with torch.cuda.device(self.device):
+            self.flat = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.packed = torch.zeros(self.lib.sqair_packed_bytes(self.handle) // 4, dtype=torch.float32,
+                                      device=self.device)
+        self._shape = None
+        self._graph_ready = False
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.sqair_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- parameters ------------------------------------------------------------------------------
+    def set_params(self, params):
+        """params: dict name -> array (sqair_amd.params naming) or a flat float32 vector."""
+        if isinstance(params, dict):
+            flat = flatten_params(params, self.spec)
+        else:
+            flat = np.asarray(params, dtype=np.float32)
+        assert flat.shape == (self.n_params,)
+        self.flat.copy_(torch.from_numpy(flat))
+        self.pack()
+
+    def get_params(self):
+        return unflatten_params(self.flat.cpu().numpy(), self.spec)
+
+    def pack(self):
+        with torch.cuda.device(self.device):
+            _capi.check(self.handle, self.lib.sqair_pack_params(self.handle, self.flat.data_ptr(),
+                                                                self.packed.data_ptr(), self._stream()),
+                        "sqair_pack_params")
+        self._graph_ready = False
+
+    # ---- buffers for a (T, B) shape ----------------------------------------------------------------
+    def bind(self, T, B, outputs="all"):
+        if self._shape == (T, B, outputs if isinstance(outputs, str) else tuple(outputs)):
+            return
+        N, K, nw, G, H, W, nh = self.N, self.K, self.nw, self.G, self.H, self.W, self.nh
+        R = B * K
+        shapes = dict(
+            what=(T, R, N, nw), what_loc=(T, R, N, nw), what_scale=(T, R, N, nw), where=(T, R, N, 4),
+            where_loc=(T, R, N, 4), where_scale=(T, R, N, 4), presence_prob=(T, R, N), presence=(T, R, N),
+            presence_logit=(T, R, N), obj_id=(T, R, N), step_log_prob=(T, R), canvas=(T, R, H, W),
+            glimpse=(T, R, N, G, G), disc_what_log_prob=(T, R, N), disc_where_log_prob=(T, R, N),
+            disc_what_prior_log_prob=(T, R, N), disc_where_prior_log_prob=(T, R, N), disc_log_prob=(T, R),
+            disc_prior_log_prob=(T, R), disc_prob=(T, R, N + 1), prop_what_log_prob=(T, R, N),
+            prop_where_log_prob=(T, R, N), prop_what_prior_log_prob=(T, R, N), prop_where_prior_log_prob=(T, R, N),
+            prop_log_prob=(T, R), prop_prior_log_prob=(T, R), prop_prob=(T, R, N), discrete_log_prob=(T, R),
+            num_prop_steps_per_sample=(T, R), num_disc_steps_per_sample=(T, R), num_steps_per_sample=(T, R),
+            prop_pres=(T, R, N), disc_pres=(T, R, N), data_ll_per_sample=(T, R), kl_per_sample=(T, R),
+            log_q_z_given_x_per_sample=(T, R), log_p_z_per_sample=(T, R), log_weights_per_timestep=(T, R),
+            final_temporal_state=(R, N, nh), final_prior_state=(R, N, nh), final_last_used_id=(R,),
+        )
+        if outputs == "all":
+            wanted = list(_capi.OUTPUT_FIELDS)
+        elif outputs == "minimal":  # what the ELBO, the VIMCO target and the scalar metrics need
+            wanted = ["log_weights_per_timestep", "discrete_log_prob", "data_ll_per_sample", "kl_per_sample",
+                      "log_q_z_given_x_per_sample", "log_p_z_per_sample", "num_steps_per_sample",
+                      "num_disc_steps_per_sample", "num_prop_steps_per_sample"]
+        else:
+            wanted = list(outputs)
+        with torch.cuda.device(self.device):
+            self.out = {n: torch.zeros(shapes[n], dtype=torch.float32, device=self.device) for n in wanted}
+            self.obs = torch.zeros(T, B, H, W, dtype=torch.float32, device=self.device)
+            self.noise = torch.zeros(T, R, 2, N, self.nzw, dtype=torch.float32, device=self.device)
+            self.ws_bytes = self.lib.sqair_workspace_bytes(self.handle, T, B)
+            self.workspace = torch.empty(self.ws_bytes // 4, dtype=torch.float32, device=self.device)
+            # ELBO outputs
+            self.log_weights = torch.zeros(B, K, dtype=torch.float32, device=self.device)
+            self.elbo_iwae_per_example = torch.zeros(B, dtype=torch.float32, device=self.device)
+            self.importance_weights = torch.zeros(B, K, dtype=torch.float32, device=self.device)
+            self.vimco_signal = torch.zeros(B, K, dtype=torch.float32, device=self.device)
+            self.scalars = torch.zeros(16, dtype=torch.float32, device=self.device)
+            self.iw_means = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.c_out = _capi.SqairOutputs(**{n: (self.out[n].data_ptr() if n in self.out else None)
+                                          for n in _capi.OUTPUT_FIELDS})
+        self.mean_names = [n for n in ("data_ll_per_sample", "log_p_z_per_sample", "log_q_z_given_x_per_sample",
+                                       "kl_per_sample", "num_steps_per_sample", "num_disc_steps_per_sample",
+                                       "num_prop_steps_per_sample") if n in self.out]
+        self.c_means = (C.c_void_p * 8)(*([self.out[n].data_ptr() for n in self.mean_names] +
+                                         [None] * (8 - len(self.mean_names))))
+        self.T, self.B = T, B
+        self._shape = (T, B, outputs if isinstance(outputs, str) else tuple(outputs))
+        self._graph_ready = False
+
+    def draw_noise(self, generator=None):
+        """eps ~ N(0,1) for the Normals, u ~ U[0,1) for the presence Bernoullis, on device."""
+        self.noise.normal_(generator=generator)
+        self.noise[..., -1].uniform_(generator=generator)
+
+    # ---- execution ---------------------------------------------------------------------------------
+    def _args(self, t_offset):
+        return (self.handle, self.flat.data_ptr(), self.packed.data_ptr(), self.obs.data_ptr(),
+                self.noise.data_ptr(), self.T, self.B, int(t_offset), C.byref(self.c_out),
+                self.workspace.data_ptr(), self.ws_bytes, self._stream())
+
+    def forward(self, t_offset=0, use_graph=False):
+        """Launches the whole T-frame forward pass + the ELBO reductions on the current stream."""
+        with torch.cuda.device(self.device):
+            if use_graph:
+                if not self._graph_ready:
+                    torch.cuda.synchronize(self.device)
+                    _capi.check(self.handle, self.lib.sqair_graph_capture(*self._args(t_offset)), "sqair_graph_capture")
+                    self._graph_ready = True
+                _capi.check(self.handle, self.lib.sqair_graph_launch(self.handle, self._stream()), "sqair_graph_launch")
+            else:
+                _capi.check(self.handle, self.lib.sqair_forward(*self._args(t_offset)), "sqair_forward")
+            dlp = self.out["discrete_log_prob"].data_ptr() if "discrete_log_prob" in self.out else None
+            _capi.check(self.handle, self.lib.sqair_elbo(
+                self.handle, self.out["log_weights_per_timestep"].data_ptr(), dlp, self.T, self.B,
+                self.log_weights.data_ptr(), self.elbo_iwae_per_example.data_ptr(),
+                self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.scalars.data_ptr(),
+                self.c_means, len(self.mean_names), self.iw_means.data_ptr(), self._stream()), "sqair_elbo")
+
+    def graph_nodes(self):
+        return self.lib.sqair_graph_nodes(self.handle)
+
+
+class Model(object):
+    """Mirror of reference sqair/model.py:33-214 on top of ``SqairCore``."""
+    VI_TARGETS = "iwae reinforce".split()
+    TARGETS = VI_TARGETS
+
+    def __init__(self, obs, coords, core, k_particles, presence=None, is_training=None, debug=False,
+                 outputs="all"):
+        self.core = core
+        self.sequence = core
+        self.k_particles = int(k_particles)
+        assert self.k_particles == core.K
+        obs = torch.as_tensor(obs, dtype=torch.float32)
+        if obs.dim() == 5:  # [T,B,H,W,1]
+            obs = obs[..., 0]
+        self.obs = obs.to(core.device)
+        self.coords = coords
+        self.gt_presence = None if presence is None else torch.as_tensor(presence, dtype=torch.float32).to(core.device)
+        self.debug = debug
+        self.n_timesteps, self.batch_size = int(obs.shape[0]), int(obs.shape[1])
+        self.img_size = list(obs.shape[2:])
+        self.tiled_batch_size = self.batch_size * self.k_particles
+        core.bind(self.n_timesteps, self.batch_size, outputs)
+        core.obs.copy_(self.obs)
+        self._ran = False
+        self._use_graph = False
+
+    # `sess.run` --------------------------------------------------------------------------------------
+    def run(self, noise=None, generator=None, resample_u=None, use_graph=None):
+        core = self.core
+        if use_graph is not None:
+            self._use_graph = bool(use_graph)
+        if noise is not None:
+            core.noise.copy_(torch.as_tensor(noise, dtype=torch.float32).reshape(core.noise.shape))
+        else:
+            core.draw_noise(generator)
+        core.forward(use_graph=self._use_graph)
+        self._collect(resample_u)
+        self._ran = True
+        return self
+
+    def _collect(self, resample_u=None):
+        core = self.core
+        T, B, K = self.n_timesteps, self.batch_size, self.k_particles
+        self.outputs = core.out
+        for k, v in core.out.items():
+            setattr(self, k, v)
+        sc = core.scalars
+        self.log_weights = core.log_weights
+        self.elbo_vae = sc[0]
+        self.elbo_iwae_per_example = core.elbo_iwae_per_example
+        self.elbo_iwae = sc[1]
+        self.normalised_elbo_vae = self.elbo_vae / float(T)
+        self.normalised_elbo_iwae = self.elbo_iwae / float(T)
+        self.importance_weights = core.importance_weights
+        self.ess = sc[3]
+        self.vimco_target = sc[2]
+        self.vimco_signal = core.vimco_signal
+        names = dict(data_ll_per_sample="data_ll", log_p_z_per_sample="log_p_z",
+                     log_q_z_given_x_per_sample="log_q_z_given_x", kl_per_sample="kl",
+                     num_steps_per_sample="num_steps", num_disc_steps_per_sample="num_disc_steps",
+                     num_prop_steps_per_sample="num_prop_steps")
+        for i, n in enumerate(core.mean_names):
+            setattr(self, names[n], core.iw_means[i])
+        # importance resampling index (reference draws it with tf Categorical; here inverse-CDF on u)
+        if resample_u is None:
+            u = torch.rand(B, 1, device=core.device)
+        else:
+            u = torch.as_tensor(resample_u, dtype=torch.float32, device=core.device).reshape(B, 1)
+        cdf = torch.cumsum(self.importance_weights, -1)
+        self.iw_resampling_idx = (cdf <= u).sum(-1).clamp(max=K - 1)
+        if "canvas" in core.out:
+            tiled = self.obs.repeat_interleave(K, dim=1)
+            self.mse_per_sample = ((tiled - core.out["canvas"]) ** 2).mean((0, 2, 3))
+            self.mse = self._imp_weighted_mean(self.mse_per_sample)
+            self.raw_mse = self.mse_per_sample.mean()
+        if self.gt_presence is not None and "num_steps_per_sample" in core.out:
+            gt = self.gt_presence.sum(-1)
+            ns = core.out["num_steps_per_sample"].reshape(-1, B, K)
+            self.num_step_accuracy_per_example = (gt[..., None] == ns).float()
+            self.raw_num_step_accuracy = self.num_step_accuracy_per_example.mean()
+            self.num_step_accuracy = self._imp_weighted_mean(self.num_step_accuracy_per_example)
+        for name in "obj_id canvas glimpse presence_prob presence presence_logit where".split():
+            if name in core.out:
+                setattr(self, "resampled_" + name, self.resample(core.out[name], axis=1))
+
+    def __getattr__(self, name):
+        # attribute access before the first run triggers it (graph-mode users expect attributes to exist)
+        if name.startswith("_") or name in ("core", "outputs"):
+            raise AttributeError(name)
+        if not self.__dict__.get("_ran", False):
+            self.run()
+            return getattr(self, name)
+        raise AttributeError(name)
+
+    def _imp_weighted_mean(self, tensor):
+        """reference: sqair/model.py:202-205."""
+        B, K = self.batch_size, self.k_particles
+        tensor = tensor.reshape(-1, B, K).mean(0)
+        return (self.importance_weights * tensor * K).mean()
+
+    def resample(self, *args, **kwargs):
+        """reference: sqair/model.py:170-192 (gather along `axis` at b*K + iw_resampling_idx)."""
+        axis = kwargs.pop("axis", -1)
+        idx = self.iw_resampling_idx + torch.arange(self.batch_size, device=self.core.device) * self.k_particles
+        res = [a.index_select(axis if axis >= 0 else a.dim() + axis, idx) if self.k_particles > 1 else a
+               for a in args]
+        return res[0] if len(res) == 1 else res
+
+    def make_target(self, opt=None, n_train_itr=None, l2_reg=0.0):
+        """reference: sqair/model.py:150-168.  Returns (target, grads_and_vars).  The VIMCO target
+        (already divided by T) is evaluated by the fused ELBO kernel; gradients are the `next` row of
+        the scope table and not part of this round."""
+        if not self._ran:
+            self.run()
+        target = self.vimco_target
+        if l2_reg != 0.0:
+            target = target + l2_reg * 0.5 * (self.core.flat ** 2).sum()
+        if opt is not None:
+            raise NotImplementedError("backward pass of the HIP path is not implemented yet (SURVEY.md 8(f) rank 1)")
+        return target, None
+
+    def img_summaries(self):
+        """reference: sqair/model.py:207-214 -> uint8 reconstructions / inputs of the first frame."""
+        recs = (self.resampled_canvas.clamp(0.0, 1.0) * 255.0).round().to(torch.uint8)
+        return dict(reconstructions=recs[0], inputs=(self.obs[0] * 255.0).round().to(torch.uint8))
+
+
+def load(img, coords=None, num=None, mean_img=None, debug=False, F=None, params=None, seed=0, device="cuda:0",
+         outputs="all"):
+    """Model factory with the reference's signature (sqair/configs/mlp_mnist_model.py:74):
+    ``img`` float32 [T,B,H,W] in [0,1]; ``coords`` [T,B,n_obj,4] (carried, unused by the maths);
+    ``num`` [T,B,n_max+1] prefix-ones presence for the step accuracy; ``mean_img`` [H,W].
+    Hyper-parameters come from the flags (``F`` defaults to the global ``sqair_amd.flags.FLAGS``)."""
+    F = F if F is not None else FLAGS
+    img = torch.as_tensor(img, dtype=torch.float32)
+    if img.dim() == 5:
+        img = img[..., 0]
+    hw = (int(img.shape[2]), int(img.shape[3]))
+    core = SqairCore(F, hw, device=device)
+    if params is None:
+        params = init_params(F, hw, seed=seed, mean_img=mean_img)
+    core.set_params(params)
+    return Model(img, coords, core, int(F.k_particles), presence=num, debug=debug, outputs=outputs)

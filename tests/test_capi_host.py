@@ -1,0 +1,74 @@
+"""Host-side checks that need no GPU: the C-ABI library loads, exports every symbol include/sqair_hip.h
+declares, and its parameter table agrees with the Python inventory."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from sqair_amd import _capi
+from sqair_amd.flags import make_flags
+from sqair_amd.model import make_config
+from sqair_amd.params import param_offsets, param_spec
+
+
+def _header_functions(repo_root):
+    txt = open(os.path.join(repo_root, "include", "sqair_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sqair_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_loads_and_exports_header_symbols(repo_root):
+    lib = _capi.lib()
+    names = _header_functions(repo_root)
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "missing export " + n
+    assert set(names) == set(_capi.EXPORTED_SYMBOLS), "ctypes prototypes and header disagree"
+    assert lib.sqair_abi_version() == 1
+
+
+@pytest.mark.parametrize("N,hw", [(3, (50, 50)), (4, (50, 50)), (6, (50, 50)), (4, (128, 128))])
+def test_param_table_matches_python_spec(N, hw):
+    lib = _capi.lib()
+    F = make_flags(n_steps_per_image=N)
+    cfg = make_config(F, hw)
+    h = C.c_void_p()
+    assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
+    try:
+        spec = param_spec(F, hw)
+        off, total = param_offsets(spec)
+        assert lib.sqair_param_count(h) == total
+        assert lib.sqair_param_entries(h) == len(spec)
+        for i, (name, shape, _, _) in enumerate(spec):
+            cname, coff, cnum = C.c_char_p(), C.c_int64(), C.c_int64()
+            assert lib.sqair_param_entry(h, i, C.byref(cname), C.byref(coff), C.byref(cnum)) == 0
+            assert cname.value.decode() == name
+            assert coff.value == off[name][0]
+            assert cnum.value == (int(np.prod(shape)) if len(shape) else 1)
+        if N == 3 and hw == (50, 50):
+            assert total == 2951522  # reference notebooks/play.ipynb:362
+        assert lib.sqair_packed_bytes(h) > total * 4
+        assert lib.sqair_workspace_bytes(h, 10, 32) > 0
+        assert lib.sqair_noise_width(h) == 55
+    finally:
+        lib.sqair_destroy(h)
+
+
+def test_create_rejects_bad_config():
+    lib = _capi.lib()
+    F = make_flags()
+    cfg = make_config(F, (50, 50))
+    cfg.n_steps_per_image = 0
+    h = C.c_void_p()
+    assert lib.sqair_create(C.byref(cfg), C.byref(h)) != 0
+
+
+def test_flag_errors_mirror_reference():
+    with pytest.raises(ValueError):
+        make_config(make_flags(prop_prior_type="bogus"), (50, 50))   # propagate.py:42-43
+    with pytest.raises(ValueError):
+        make_config(make_flags(disc_prior_type="bogus"), (50, 50))   # sqair_modules.py:224
+    with pytest.raises(ValueError):
+        make_flags(not_a_flag=1)

@@ -1,0 +1,193 @@
+"""-m gpu: unit parity of the individual HIP kernels against the oracle, through the C-ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sqair_oracle as O
+from sqair_amd import _capi
+from sqair_amd.flags import make_flags
+from sqair_amd.model import make_config
+from tests.hip_util import dev, rel_err, stream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def handle():
+    lib = _capi.lib()
+    F = make_flags(k_particles=3, n_steps_per_image=4)
+    cfg = make_config(F, (50, 50))
+    h = C.c_void_p()
+    assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
+    yield lib, h, F
+    lib.sqair_destroy(h)
+
+
+@pytest.mark.parametrize("M,K,N,act", [(160, 256, 256, 1), (37, 54, 109, 0), (640, 400, 256, 1), (5, 2500, 256, 1),
+                                       (160, 311, 256, 2), (160, 256, 8, 0), (33, 128, 400, 3), (160, 256, 100, 4),
+                                       (16, 16, 16, 0), (1, 3, 1, 0)])
+def test_linear_mfma_matches_fp64(handle, M, K, N, act):
+    lib, h, _ = handle
+    rng = np.random.default_rng(M * 7 + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    y = torch.zeros(M, N, device="cuda")
+    scratch = torch.empty(4 * ((K + 15) // 16) * ((N + 15) // 16) * 256 + 4096, dtype=torch.float32, device="cuda")
+    rc = lib.sqair_linear_test(h, dev(x).data_ptr(), dev(w).data_ptr(), dev(b).data_ptr(), y.data_ptr(), M, K, N, act,
+                               scratch.data_ptr(), scratch.numel() * 4, stream())
+    assert rc == 0, lib.sqair_last_error(h)
+    ref = torch.tensor(x, dtype=torch.float64) @ torch.tensor(w, dtype=torch.float64) + torch.tensor(b, dtype=torch.float64)
+    ref = [lambda v: v, O.elu, torch.tanh, torch.sigmoid, lambda v: O.softplus(v) + 1e-2][act](ref)
+    # fp32 fma chain of length K: ~1e-7 * sum|a b| (guide: 0.75-1.5e-7 at K <= 1024)
+    assert np.abs(y.cpu().numpy() - ref.numpy()).max() < 2e-5 * max(1.0, np.sqrt(K / 256.0))
+
+
+def test_linear_identity_asymmetric(handle):
+    """A = I against an asymmetric B catches a row<->col swap in the C-write (guide section 3)."""
+    lib, h, _ = handle
+    n = 48
+    w = (np.arange(n * n, dtype=np.float32).reshape(n, n) * 0.01)
+    y = torch.zeros(n, n, device="cuda")
+    scratch = torch.empty(1 << 18, dtype=torch.float32, device="cuda")
+    assert lib.sqair_linear_test(h, dev(np.eye(n, dtype=np.float32)).data_ptr(), dev(w).data_ptr(), None, y.data_ptr(),
+                                 n, n, n, 0, scratch.data_ptr(), scratch.numel() * 4, stream()) == 0
+    assert np.array_equal(y.cpu().numpy(), w)
+
+
+@pytest.mark.parametrize("M,Kx", [(160, 360), (640, 54), (7, 17)])
+def test_gru_step(handle, M, Kx):
+    lib, h, _ = handle
+    nh = 256
+    rng = np.random.default_rng(Kx)
+    P = {}
+    flat = []
+    for g in "zrh":
+        P["g.w" + g] = (rng.standard_normal((Kx, nh)) / np.sqrt(Kx)).astype(np.float32)
+        P["g.u" + g] = (rng.standard_normal((nh, nh)) / np.sqrt(nh)).astype(np.float32)
+        P["g.b" + g] = rng.standard_normal(nh).astype(np.float32) * 0.1
+        flat += [P["g.w" + g].ravel(), P["g.u" + g].ravel(), P["g.b" + g].ravel()]
+    x = rng.standard_normal((M, Kx)).astype(np.float32)
+    hs = rng.standard_normal((M, nh)).astype(np.float32)
+    out = torch.zeros(M, nh, device="cuda")
+    scratch = torch.empty(1 << 22, dtype=torch.float32, device="cuda")
+    rc = lib.sqair_gru_test(h, dev(x).data_ptr(), dev(hs).data_ptr(), dev(np.concatenate(flat)).data_ptr(),
+                            out.data_ptr(), M, Kx, scratch.data_ptr(), scratch.numel() * 4, stream())
+    assert rc == 0, lib.sqair_last_error(h)
+    P64 = {k: torch.tensor(v, dtype=torch.float64) for k, v in P.items()}
+    ref = O.gru(P64, "g", torch.tensor(x, dtype=torch.float64), torch.tensor(hs, dtype=torch.float64))
+    assert np.abs(out.cpu().numpy() - ref.numpy()).max() < 2e-5
+
+
+@pytest.mark.parametrize("hw", [(50, 50), (128, 128), (37, 61)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_st_crop(hw, masked):
+    lib = _capi.lib()
+    F = make_flags(k_particles=3, n_steps_per_image=4)
+    cfg = make_config(F, hw)
+    h = C.c_void_p()
+    assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
+    try:
+        B, K, G = 5, 3, 20
+        rng = np.random.default_rng(hw[0])
+        img = rng.uniform(size=(B,) + hw).astype(np.float32)
+        where = (rng.standard_normal((B * K, 4)) * 1.5).astype(np.float32)
+        where[0] = [30.0, 30.0, 0.0, 0.0]      # full-frame glimpse
+        where[1] = [-30.0, -30.0, 3.0, -3.0]   # scale clipped at 1e-4, far corner
+        where[2] = [0.0, 0.0, 5.0, 5.0]        # mostly outside the frame
+        mask = rng.uniform(size=(B * K, G * G)).astype(np.float32) if masked else None
+        out = torch.zeros(B * K, G * G, device="cuda")
+        rc = lib.sqair_st_crop(h, dev(img).data_ptr(), dev(where).data_ptr(), dev(mask).data_ptr() if masked else None,
+                               out.data_ptr(), B, stream())
+        assert rc == 0
+        ref = O.st_crop(torch.tensor(np.repeat(img, K, 0), dtype=torch.float64), torch.tensor(where, dtype=torch.float64), G)
+        ref = ref.reshape(B * K, -1)
+        if masked:
+            ref = ref * torch.tensor(mask, dtype=torch.float64)
+        assert np.abs(out.cpu().numpy() - ref.numpy()).max() < 1e-5   # fwd 1e-6-class (SURVEY build plan step 3)
+    finally:
+        lib.sqair_destroy(h)
+
+
+@pytest.mark.parametrize("hw", [(50, 50), (128, 128)])
+def test_st_insert_loglik(hw):
+    lib = _capi.lib()
+    F = make_flags(k_particles=2, n_steps_per_image=4)
+    cfg = make_config(F, hw)
+    h = C.c_void_p()
+    assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
+    try:
+        B, K, N, G = 3, 2, 4, 20
+        R = B * K
+        H, W = hw
+        rng = np.random.default_rng(3)
+        gl = (rng.standard_normal((R, N, G * G)) * 0.3).astype(np.float32)
+        where = (rng.standard_normal((R, N, 4))).astype(np.float32)
+        pres = (rng.uniform(size=(R, N)) > 0.4).astype(np.float32)
+        pres[0] = 0.0
+        img = rng.uniform(size=(B, H, W)).astype(np.float32)
+        mean_img = rng.uniform(size=(H, W)).astype(np.float32)
+        canvas = torch.zeros(R, H, W, device="cuda")
+        dll = torch.zeros(R, device="cuda")
+        rc = lib.sqair_st_insert_loglik(h, dev(gl).data_ptr(), dev(where).data_ptr(), dev(pres).data_ptr(),
+                                        dev(img).data_ptr(), dev(mean_img).data_ptr(), canvas.data_ptr(),
+                                        dll.data_ptr(), B, stream())
+        assert rc == 0
+        D = torch.float64
+        ocfg = O.make_cfg(F, hw)
+        g64 = torch.tensor(gl, dtype=D).reshape(R * N, G, G)
+        w64 = torch.tensor(where, dtype=D).reshape(R * N, 4)
+        p64 = torch.tensor(pres, dtype=D)
+        inv = O.st_insert(g64, w64, H, W).reshape(R, N, H, W) * p64[..., None, None]
+        nz = (O.st_insert(torch.ones_like(g64), w64, H, W).reshape(R, N, H, W) * p64[..., None, None]).sum(1)
+        nz = torch.sigmoid(-10.0 + 20.0 * nz)
+        cv = inv.sum(1) + torch.tensor(mean_img, dtype=D)[None] * nz
+        std = nz * ocfg.output_std + (1 - nz) * ocfg.background_std
+        ll = O.normal_log_prob(torch.tensor(np.repeat(img, K, 0), dtype=D), cv, std).sum((1, 2))
+        assert np.abs(canvas.cpu().numpy() - cv.numpy()).max() < 2e-5
+        assert rel_err(dll.cpu().numpy(), ll.numpy()) < 1e-5
+    finally:
+        lib.sqair_destroy(h)
+
+
+@pytest.mark.parametrize("B,K,T", [(32, 5, 10), (3, 2, 4), (7, 64, 3), (256, 5, 10)])
+def test_elbo_iwae_vimco(B, K, T):
+    lib = _capi.lib()
+    F = make_flags(k_particles=K)
+    cfg = make_config(F, (50, 50))
+    h = C.c_void_p()
+    assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
+    try:
+        rng = np.random.default_rng(B + K)
+        lw_t = (rng.standard_normal((T, B * K)) * 30.0 + 500.0).astype(np.float32)
+        dl_t = (rng.standard_normal((T, B * K)) * 2.0 - 3.0).astype(np.float32)
+        x_t = rng.standard_normal((T, B * K)).astype(np.float32)
+        d_lw, d_dl, d_x = dev(lw_t), dev(dl_t), dev(x_t)
+        lw = torch.zeros(B, K, device="cuda"); el = torch.zeros(B, device="cuda"); iw = torch.zeros(B, K, device="cuda")
+        sig = torch.zeros(B, K, device="cuda"); sc = torch.zeros(16, device="cuda"); mo = torch.zeros(8, device="cuda")
+        means = (C.c_void_p * 8)(d_x.data_ptr(), *([None] * 7))
+        rc = lib.sqair_elbo(h, d_lw.data_ptr(), d_dl.data_ptr(), T, B, lw.data_ptr(), el.data_ptr(), iw.data_ptr(),
+                            sig.data_ptr(), sc.data_ptr(), means, 1, mo.data_ptr(), stream())
+        assert rc == 0
+        D = torch.float64
+        LW = torch.tensor(lw_t, dtype=D).sum(0).reshape(B, K)
+        DL = torch.tensor(dl_t, dtype=D).sum(0).reshape(B, K)
+        el_ref = O.iwae(LW)
+        tgt = O.vimco(LW, DL, el_ref) / T
+        w_ref = torch.softmax(LW, -1)
+        assert rel_err(lw.cpu().numpy(), LW.numpy()) < 1e-6
+        assert rel_err(el.cpu().numpy(), el_ref.numpy()) < 1e-6
+        assert np.abs(iw.cpu().numpy() - w_ref.numpy()).max() < 1e-4
+        s = sc.cpu().numpy()
+        assert abs(s[0] - float(LW.mean())) < 1e-6 * abs(float(LW.mean()))
+        assert abs(s[1] - float(el_ref.mean())) < 1e-6 * abs(float(el_ref.mean()))
+        assert abs(s[2] - float(tgt)) < 1e-4 * abs(float(tgt))
+        assert abs(s[3] - float(O.ess(w_ref))) < 1e-3
+        xm = torch.tensor(x_t, dtype=D).reshape(T, B, K).mean(0)
+        assert abs(mo.cpu().numpy()[0] - float((w_ref * xm * K).mean())) < 1e-4
+        sig_ref = LW - O.vimco_control_variate(LW)
+        assert np.abs(sig.cpu().numpy() - sig_ref.numpy()).max() < 2e-3
+    finally:
+        lib.sqair_destroy(h)
