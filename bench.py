@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""bench.py — frames/sec of the SQAIR Discover/Propagate hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic input: noise draw on device, the
+T-frame forward unroll (HIP-graph replay of the launch sequence), IWAE / VIMCO reductions.  Inputs
+(frames, parameters) are resident in HBM before the timed region starts.  Workload at every N:
+BASELINE.json configs[1] per GPU — multi-MNIST-like 2-glyph sequences, seq_len 10, 50x50, batch 32,
+K=5 IWAE particles, 4 object slots ("cfg2"); with N > 1 every rank processes its own 32-sequence
+shard (weak scaling, the sharding of configs[2]; no collective on the data path of the forward pass).
+frames/step = B * T per rank (all K particles of a frame count as one frame).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     — dominant kernel k_linear (fp32 MFMA dense layers): achieved = algorithmic FLOPs of
+                 the step as the reference graph computes them (135.4 MFLOP/frame
+                 at cfg-2) / summed k_linear time of the step, measured live with HIP events around
+                 every launch on the launch stream; peak = 157.3 TFLOP/s dense fp32 matrix.
+  cpu_baseline — the oracle (PyTorch-CPU fp32 restatement at the reference's op granularity,
+                 kind "port": the TF1 reference cannot run here) timed on the host cores on a bounded
+                 sample of the same workload; only this leg imports oracle/.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense f32-in matrix peak (= vector peak)
+FLOP_PER_FRAME_CFG2 = 2 * 5 * 13543744  # 2 * K * MACs per frame-particle (SURVEY.md 8(d), Appendix D, N=4)
+
+
+def cpu_baseline(F, hw, P, obs, noise, hip_ref, budget_s=25.0):
+    """Times the oracle (fp32 PyTorch-CPU at the reference's op granularity) on the SAME batch, parameters and noise.
+    The ops are tiny (M = B*K = 160-row GEMMs), so more threads is not faster: the thread count is calibrated on a
+    2-frame slice among a few candidates and `cores` reports the one actually used."""
+    from oracle import sqair_oracle as O
+    T, B = obs.shape[:2]
+    ncpu = os.cpu_count() or 1
+    orc = O.SqairOracle(P, O.make_cfg(F, hw), torch.float32)
+    best_thr, best_t = 1, float("inf")
+    with torch.no_grad():
+        for thr in [t for t in (1, 4, 8, 16, 32, 64) if t <= ncpu]:
+            torch.set_num_threads(thr)
+            orc.model(obs[:2], noise[:2])
+            t0 = time.perf_counter()
+            orc.model(obs[:2], noise[:2])
+            dt = time.perf_counter() - t0
+            if dt < best_t:
+                best_thr, best_t = thr, dt
+        torch.set_num_threads(best_thr)
+        times, m = [], None
+        t_start = time.perf_counter()
+        for it in range(1 + 7):
+            t0 = time.perf_counter()
+            m = orc.model(obs, noise)
+            dt = time.perf_counter() - t0
+            if it > 0:
+                times.append(dt)
+            if time.perf_counter() - t_start > budget_s and len(times) >= 1:
+                break
+    med = float(np.median(times))
+    lw_cpu = m.log_weights.numpy().astype(np.float64)
+    pres_cpu = m.presence.numpy()
+    same_rows = (pres_cpu == hip_ref["presence"]).all((0, 2)).reshape(lw_cpu.shape)
+    rel = float(np.abs(lw_cpu - hip_ref["log_weights"])[same_rows].max() / np.abs(lw_cpu).max())
+    cpu_name = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    cpu_name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(value=B * T / med, unit="frames/s", cores=best_thr, kind="port",
+                sample="the full step workload ({} sequences x T={} x K={}, same frames / parameters / noise as one GPU step), "
+                       "fp32 PyTorch-CPU oracle at reference op granularity, median of {} passes after 1 warm-up, "
+                       "{} threads (best of 1/4/8/16/32/64 on a 2-frame slice) of {} logical CPUs; host CPU: {}".format(
+                           B, T, int(F.k_particles), len(times), best_thr, ncpu, cpu_name),
+                ms_per_pass=med * 1e3,
+                parity=dict(rows_with_identical_presence=float(same_rows.mean()), log_weights_max_rel_err=rel,
+                            elbo_iwae_oracle=float(m.elbo_iwae), elbo_iwae_hip=hip_ref["elbo_iwae"]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--cfg", type=int, default=2, help="BASELINE.json config id used as the workload (default 2)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")  # RCCL on ROCm
+    assert args.gpus == world, "--gpus {} but WORLD_SIZE {}".format(args.gpus, world)
+
+    from sqair_amd.data import config_inputs
+    from sqair_amd.flags import make_flags
+    from sqair_amd.model import Model, SqairCore
+    from sqair_amd.params import init_params
+
+    # every rank synthesises its own shard of the global batch (seeded by rank), weights are replicated
+    ov, obs, nums, _ = config_inputs(args.cfg)
+    if rank > 0:
+        from sqair_amd.data import make_sequences, to_float
+        d = make_sequences(obs.shape[1], T=obs.shape[0], canvas=obs.shape[2:], n_objects=(0, nums.shape[-1] - 1),
+                           obj_size=28 if obs.shape[2] <= 64 else 72, seed=1234 + args.cfg + 1000 * rank)
+        obs, nums = to_float(d["imgs"]), d["nums"]
+    F = make_flags(**ov)
+    hw = tuple(int(v) for v in obs.shape[2:])
+    T, B = int(obs.shape[0]), int(obs.shape[1])
+    K, N = int(F.k_particles), int(F.n_steps_per_image)
+    P = {k: np.asarray(v, dtype=np.float32) for k, v in
+         init_params(F, hw, seed=0, mean_img=obs.mean((0, 1)), jitter=0.02).items()}
+    device = "cuda:{}".format(local_rank)
+    core = SqairCore(F, hw, device=device)
+    core.set_params(P)
+    model = Model(obs, None, core, K, presence=nums, outputs="minimal")
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1000 + rank)
+    use_graph = not args.no_graph
+
+    def step():
+        model.core.draw_noise(gen)
+        model.core.forward(use_graph=use_graph)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    frames_per_step = B * T * world
+    value = frames_per_step / (elapsed / args.steps)
+
+    model._collect()
+    elbo = float(model.elbo_iwae)
+    elbo_vae = float(model.elbo_vae)
+    if dist is not None:
+        e = torch.tensor([elbo, elbo_vae], dtype=torch.float64, device=device)
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)  # the only collective: scalar metrics, outside the timed region
+        elbo, elbo_vae = float(e[0] / world), float(e[1] / world)
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel: HIP events around every k_linear launch of one step ----
+    prof = None
+    for _ in range(3):
+        prof = core.profile_linear()
+    torch.cuda.synchronize()
+    lin_ms = prof["linear_ms"]
+    algo_flops_step = float(B * T) * (FLOP_PER_FRAME_CFG2 if (args.cfg in (2, 3)) else
+                                     2.0 * K * {1: 10166288, 4: 20298656, 5: 27760960}[args.cfg])
+    achieved = algo_flops_step / (lin_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_linear_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = dict(
+        kernel="k_linear (fp32 MFMA 16x16x4 dense layers, {} launches/step)".format(prof["launches"]),
+        bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP32_MFMA_TFLOPS,
+        traffic=traffic,
+        algorithmic_flops_per_launch=algo_flops_step / prof["launches"],
+        avg_launch_us=lin_ms * 1e3 / prof["launches"],
+        timer="per launch: first-workgroup-start to last-workgroup-end on the 100 MHz device wall clock (s_memrealtime), "
+              "summed over the launches of one eager step; per-launch HIP events cannot resolve ~2-5 us kernels "
+              "(an empty event pair costs ~7.8 us here), one HIP-event pair brackets the whole pass instead",
+        step_ms_hip_events_eager=prof["forward_ms_events"],
+        executed_flops_per_step=prof["executed_flops"],
+        executed_tflops=prof["executed_flops"] / (lin_ms * 1e-3) / 1e12,
+        k_linear_share_of_step=lin_ms / ms_per_step,
+        note="achieved = as-reference algorithmic FLOPs of the step (input encoder counted N times, mask MLP twice, as the "
+             "reference graph computes them) / summed k_linear time; executed_* counts what the hoisted launch sequence runs",
+    )
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        # parity + timing on the same frames / parameters / noise as one GPU step
+        full = Model(obs, None, core, K, presence=nums, outputs=["log_weights_per_timestep", "discrete_log_prob", "presence"])
+        gen.manual_seed(4242)
+        full.core.draw_noise(gen)
+        noise = full.core.noise.cpu().numpy().copy()
+        full.core.forward(use_graph=False)
+        torch.cuda.synchronize()
+        hip_ref = dict(presence=full.core.out["presence"].cpu().numpy(),
+                       log_weights=full.core.log_weights.cpu().numpy().astype(np.float64),
+                       elbo_iwae=float(full.core.scalars[1]))
+        cpu = cpu_baseline(F, hw, P, obs, noise, hip_ref)
+
+    line = {
+        "metric": "frames/sec (forward IWAE ELBO, 10-step 50x50 moving glyphs, K=5)",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg{}: T={} HxW={}x{} B={}/GPU K={} N={} forward (elbo_iwae), HIP-graph replay={}".format(
+            args.cfg, T, hw[0], hw[1], B, K, N, use_graph), "global_batch": B * world, "seq_len": T,
+            "parallelism": "dp{}".format(world), "graph_nodes": core.graph_nodes()},
+        "elbo_iwae_nats_per_seq": elbo, "elbo_vae_nats_per_seq": elbo_vae,
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    if cpu is not None:
+        line["speedup_vs_cpu_baseline"] = value / world / cpu["value"]
+    print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,11 @@ struct SqairHandle {
   int64_t packed_w = 0, packed_b = 0;
   bool plan_uploaded_to = false;
   const void* plan_uploaded_ptr = nullptr;
+  // live profiling of the dominant kernel (sqair_profile_forward)
+  bool prof = false;
+  unsigned long long* prof_ts = nullptr;
+  int prof_n = 0;
+  double prof_flops = 0.0;
   // graph
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -502,8 +507,10 @@ struct Workspace {
   float *pstats, *hid1, *wb, *mask, *g1, *ea, *eb, *m1, *pre;
   float *rbuf[2], *t1, *t2, *tp, *g2, *enc, *hraw, *s1;
   float *c, *pre_d, *spre, *qz, *pz, *dlp, *dll, *glimpse;
+  unsigned long long* prof_ts;  // [2][PROF_MAX] start / end ticks of profiled k_linear launches
   int64_t total;  // floats
 };
+constexpr int PROF_MAX = 4096;
 constexpr int PS_LD = 112, ENC_LD = 112, M1_LD = 64, HRAW_LD = 256, WB_LD = 4, TP_LD = 8;
 
 static Workspace carve(const SqairHandle* h, int T, int B, float* base) {
@@ -562,6 +569,7 @@ static Workspace carve(const SqairHandle* h, int T, int B, float* base) {
   w.dlp = take(R);
   w.dll = take(R);
   w.glimpse = take(M * G2);
+  w.prof_ts = (unsigned long long*)take(2 * PROF_MAX * 2);
   w.total = o;
   return w;
 }
@@ -617,6 +625,12 @@ static int run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, h
   l.a.bias = packed + pl.b + L.b_off;
   l.a.M = M;
   l.a.N = L.N;
+  if (h->prof && h->prof_n < PROF_MAX) {
+    int ksum = 0;
+    for (int w : L.seg_width) ksum += w;
+    h->prof_flops += 2.0 * (double)M * (double)ksum * (double)L.N;
+    return sq_launch_linear(l.a, L, s, h->prof_ts + h->prof_n++);
+  }
   return sq_launch_linear(l.a, L, s);
 }
 
@@ -830,6 +844,49 @@ extern "C" int sqair_forward(SqairHandle* h, const float* flat_params, const voi
   if (!h) return -1;
   return forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
                       workspace_bytes, (hipStream_t)stream);
+}
+
+// Eager forward in which every dense-layer launch (k_linear, the dominant kernel) stamps {first workgroup start,
+// last workgroup end} with the 100 MHz device wall clock (s_memrealtime) into its own slot; one HIP-event pair
+// brackets the whole pass on the launch stream.  Per-launch HIP events cannot resolve these kernels: an empty event
+// pair costs ~7.8 us on this stack, more than the kernels themselves (measured, profiles/README.md).
+extern "C" int sqair_profile_forward(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
+                                     const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
+                                     void* workspace, int64_t workspace_bytes, void* stream, double* linear_ms,
+                                     int* linear_launches, double* linear_flops, double* forward_ms_events) {
+  if (!h) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  if (workspace_bytes < sqair_workspace_bytes(h, T, B)) { sq_set_error(h, "workspace too small"); return -1; }
+  Workspace w = carve(h, T, B, (float*)workspace);
+  SQ_CHECK_HIP(hipMemsetAsync(w.prof_ts, 0xFF, PROF_MAX * 8, s));
+  SQ_CHECK_HIP(hipMemsetAsync(w.prof_ts + PROF_MAX, 0, PROF_MAX * 8, s));
+  hipEvent_t ea, eb;
+  SQ_CHECK_HIP(hipEventCreate(&ea));
+  SQ_CHECK_HIP(hipEventCreate(&eb));
+  h->prof = true;
+  h->prof_ts = w.prof_ts;
+  h->prof_n = 0;
+  h->prof_flops = 0.0;
+  hipEventRecord(ea, s);
+  int rc = forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
+                        workspace_bytes, s);
+  hipEventRecord(eb, s);
+  h->prof = false;
+  if (rc != 0) return rc;
+  SQ_CHECK_HIP(hipStreamSynchronize(s));
+  float fms = 0.0f;
+  SQ_CHECK_HIP(hipEventElapsedTime(&fms, ea, eb));
+  hipEventDestroy(ea);
+  hipEventDestroy(eb);
+  std::vector<unsigned long long> ts(2 * PROF_MAX);
+  SQ_CHECK_HIP(hipMemcpy(ts.data(), w.prof_ts, 2 * PROF_MAX * 8, hipMemcpyDeviceToHost));
+  double ticks = 0.0;
+  for (int i = 0; i < h->prof_n; ++i) ticks += (double)(ts[PROF_MAX + i] - ts[i]);
+  if (linear_ms) *linear_ms = ticks * 1e-5;  // 100 MHz ticks -> ms
+  if (linear_launches) *linear_launches = h->prof_n;
+  if (linear_flops) *linear_flops = h->prof_flops;
+  if (forward_ms_events) *forward_ms_events = fms;
+  return 0;
 }
 
 extern "C" int sqair_graph_capture(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,

@@ -83,7 +83,8 @@ struct SqairHandle;
 void sq_set_error(SqairHandle* h, const std::string& msg);
 
 // launchers (sqair_linear.hip)
-int sq_launch_linear(const LinArgs& a, const PackedLayer& L, hipStream_t s);
+// prof_ts (optional): device slot {min start, max end} of the launch in 100 MHz wall-clock ticks
+int sq_launch_linear(const LinArgs& a, const PackedLayer& L, hipStream_t s, unsigned long long* prof_ts = nullptr);
 int sq_launch_pack(const float* flat, float* packed_w, const int* idx, int64_t n, hipStream_t s);
 int sq_launch_pack_bias(const float* flat, float* packed_b, const int* idxa, const int* idxb, int64_t n,
                         hipStream_t s);

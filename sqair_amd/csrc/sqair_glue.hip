@@ -49,58 +49,56 @@ __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, c
   const int tid = threadIdx.x;
   const int P = d.H * d.W;
   const int G = d.G, G2 = d.G * d.G;
-  const float* __restrict__ img = a.img + (size_t)b * P;
-  for (int i = tid; i < P; i += 256) img_s[i] = img[i];
+  const int mrow_add = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
+  const int orow_add = a.out_row_add + (a.mode == CROP_PROP1 ? slot : 0);
 
-  if (tid < d.K) {
-    const int r = b * d.K + tid;
-    float wl[4];
+  // ---- the `where` logits: one thread per (particle, component), all operands requested at once
+  float wl = 0.0f;
+  if (tid < 4 * d.K) {
+    const int kp = tid >> 2, i = tid & 3;
+    const int r = b * d.K + kp;
     if (a.mode == CROP_PLAIN) {
-      for (int i = 0; i < 4; ++i) wl[i] = a.logits[(size_t)r * 4 + i];
+      wl = a.logits[(size_t)r * 4 + i];
     } else if (a.mode == CROP_PROP1) {
-      const float* zp = a.rec_prev + ((size_t)r * d.N + slot) * rec::W + rec::WHERE;
-      const float* wb = a.wb + ((size_t)r * d.N + slot) * a.wb_ld;
-      for (int i = 0; i < 4; ++i) wl[i] = zp[i] + wb[i] * 0.1f;
+      wl = a.rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHERE + i] +
+           a.wb[((size_t)r * d.N + slot) * a.wb_ld + i] * 0.1f;
     } else {
       const float* tp = a.tp + (size_t)r * a.tp_ld;
       const float* eps = a.noise + (((size_t)r * 2 + (a.mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
       float* rn = a.rec_new + ((size_t)r * d.N + slot) * rec::W;
-      float loc[4], sc[4];
+      float loc, sc;
       if (a.mode == CROP_DISC) {
-        const float off = a.flat[po.disc_scale_offset];
-        for (int i = 0; i < 4; ++i) {
-          loc[i] = tp[i];
-          sc[i] = sq_softplus(tp[4 + i] + off) + 1e-2f;
-          wl[i] = loc[i] + sc[i] * eps[i];
-        }
+        const float tl = tp[i], tr = tp[4 + i], e = eps[i], off = a.flat[po.disc_scale_offset];
+        loc = tl;
+        sc = sq_softplus(tr + off) + 1e-2f;
+        wl = loc + sc * e;
       } else {
-        const float* zp = a.rec_prev + ((size_t)r * d.N + slot) * rec::W + rec::WHERE;
-        const float off = a.flat[po.prop_scale_offset];
+        const float tl = tp[i], tr = tp[4 + i], off = a.flat[po.prop_scale_offset];
+        const float zp = a.rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHERE + i];
         const float* ch = a.flat + po.cholesky;
-        for (int i = 0; i < 4; ++i) {
-          loc[i] = zp[i] + 1.0f * tp[i];
-          sc[i] = sq_softplus(tp[4 + i] + off - 1.0f) + 1e-2f;
+        float e[4], t[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          e[jj] = eps[jj];
+          t[jj] = (jj <= i) ? tril4(ch, i, jj) : 0.0f;
         }
-        for (int i = 0; i < 4; ++i) {  // where = loc + L eps, L = T * sc[:,None] + diag(sc)
-          float acc = 0.0f;
-          for (int j = 0; j <= i; ++j) {
-            const float lij = tril4(ch, i, j) * sc[i] + (i == j ? sc[i] : 0.0f);
-            acc += lij * eps[j];
-          }
-          wl[i] = loc[i] + acc;
-        }
+        loc = zp + 1.0f * tl;
+        sc = sq_softplus(tr + off - 1.0f) + 1e-2f;
+        float acc = 0.0f;  // row i of L = T * sc[:,None] + diag(sc), times eps
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          if (jj <= i) acc += (t[jj] * sc + (jj == i ? sc : 0.0f)) * e[jj];
+        wl = loc + acc;
       }
-      for (int i = 0; i < 4; ++i) {
-        rn[rec::WHERE + i] = wl[i];
-        rn[rec::WHERE_LOC + i] = loc[i];
-        rn[rec::WHERE_SCALE + i] = sc[i];
-      }
+      rn[rec::WHERE + i] = wl;
+      rn[rec::WHERE_LOC + i] = loc;
+      rn[rec::WHERE_SCALE + i] = sc;
     }
-    coord_s[tid * 4 + 0] = fmaxf(sq_sigmoid(wl[0]), 1e-4f);
-    coord_s[tid * 4 + 1] = fmaxf(sq_sigmoid(wl[1]), 1e-4f);
-    coord_s[tid * 4 + 2] = tanhf(wl[2]);
-    coord_s[tid * 4 + 3] = tanhf(wl[3]);
   }
+  // ---- stage the frame in LDS (one HBM read of the frame for all K particles)
+  const float* __restrict__ img = a.img + (size_t)b * P;
+  for (int i = tid; i < P; i += 256) img_s[i] = img[i];
+  if (tid < 4 * d.K) coord_s[tid] = (tid & 2) ? tanhf(wl) : fmaxf(sq_sigmoid(wl), 1e-4f);
   __syncthreads();
   // per particle: source coordinates of the G columns and G rows
   for (int i = tid; i < d.K * 2 * G; i += 256) {
@@ -118,6 +116,9 @@ __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, c
   __syncthreads();
   for (int idx = tid; idx < d.K * G2; idx += 256) {
     const int kp = idx / G2, pix = idx % G2;
+    const int r = b * d.K + kp;
+    float mk = 1.0f;
+    if (a.mask != nullptr) mk = a.mask[((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix];
     const int i = pix / G, j = pix % G;
     const float* tb = tab_s + (size_t)kp * 2 * G * 2;
     const float x0f = tb[j * 2], wx1 = tb[j * 2 + 1];
@@ -137,9 +138,7 @@ __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, c
         v += wy * wx * img_s[yy * d.W + xx];
       }
     }
-    const int r = b * d.K + kp;
-    if (a.mask != nullptr) v *= a.mask[((size_t)r * a.mask_row_mul + a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0)) * G2 + pix];
-    a.out[((size_t)r * a.out_row_mul + a.out_row_add + (a.mode == CROP_PROP1 ? slot : 0)) * G2 + pix] = v;
+    a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + pix] = v * mk;
   }
 }
 
@@ -221,17 +220,19 @@ __global__ void k_steps(const float* __restrict__ s1, int s1_ld, const float* __
   const int lane = threadIdx.x & 63;
   if (r >= d.R) return;
   const int nsp = d.nh / 2;
+  // every operand is requested before the reduction (one memory round trip)
+  const float bias = flat[b_off];
+  const float u = noise[(((size_t)r * 2 + (is_disc ? 1 : 0)) * d.N + slot) * d.nzw + 4 + d.nw];
+  float prev;
+  if (is_disc) prev = slot == 0 ? 1.0f : rec_new[((size_t)r * d.N + slot - 1) * rec::W + rec::PRES];
+  else prev = rec_prev[((size_t)r * d.N + slot) * rec::W + rec::PRES];
   float acc = 0.0f;
   for (int i = lane; i < nsp; i += 64) acc += s1[(size_t)r * s1_ld + i] * flat[w_off + i];
   acc = sq_wave_sum(acc);
   if (lane == 0) {
-    const float raw = acc + flat[b_off];
-    float prev;
-    if (is_disc) prev = slot == 0 ? 1.0f : rec_new[((size_t)r * d.N + slot - 1) * rec::W + rec::PRES];
-    else prev = rec_prev[((size_t)r * d.N + slot) * rec::W + rec::PRES];
+    const float raw = acc + bias;
     const float logit = prev * raw + (prev - 1.0f) * 88.0f;
     const float prob = sq_sigmoid(logit);
-    const float u = noise[(((size_t)r * 2 + (is_disc ? 1 : 0)) * d.N + slot) * d.nzw + 4 + d.nw];
     float* rn = rec_new + ((size_t)r * d.N + slot) * rec::W;
     rn[rec::PRES] = (u < prob ? 1.0f : 0.0f) * prev;
     rn[rec::LOGIT] = logit;
@@ -270,19 +271,65 @@ int sq_launch_latent_sum(const float* f, const float* rec_p, float* c, Dims d, h
 // RecurrentNormalImpl modules.py:548-611, SQAIRTimestep sums :483-485, :505-507.
 // One wavefront per row b'.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_logprob(const LogprobArgs a, const POff po, const Dims d) {
+__global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff po, const Dims d) {
+  // Everything a row needs (3N slot records, N prior-stat rows, the conditioning state and ~1k small-layer
+  // parameters) is pulled into LDS by all 256 threads in one burst of independent loads; wavefront 0 then
+  // evaluates the densities from LDS.  (A direct global-memory walk was ~20 dependent round trips = 27 us.)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int r = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   const int N = d.N, nw = d.nw;
+  const int RW = rec::W;
+  float* recp_s = smem;                    // N * RW
+  float* recd_s = recp_s + N * RW;         // N * RW
+  float* recm_s = recd_s + N * RW;         // N * RW
+  float* ps_s = recm_s + N * RW;           // N * ps_ld
+  float* spre_s = ps_s + N * a.ps_ld;      // 128
+  float* ce_s = spre_s + 128;              // 128  rn.cond.w row of e
+  float* h2h_s = ce_s + 128;               // 512 + 4
+  float* i2h_s = h2h_s + 516;              // 16 + 4
+  float* ro_s = i2h_s + 20;                // 32 + 8
+  float* isamp_s = ro_s + 40;              // 4
+  float* sp0_s = isamp_s + 4;              // 10 + 10
+  float* sp1_s = sp0_s + 20;               // 10*(N+1) + (N+1)
+  float* spb_s = sp1_s + 11 * (N + 1);     // 2*(N+1)
+  float* ch_s = spb_s + 2 * (N + 1);       // 10
   const float* __restrict__ flat = a.flat;
+  for (int i = tid; i < N * RW; i += 256) {
+    recp_s[i] = a.rec_p[(size_t)r * N * RW + i];
+    recd_s[i] = a.rec_d[(size_t)r * N * RW + i];
+    recm_s[i] = a.rec_prev[(size_t)r * N * RW + i];
+  }
+  for (int i = tid; i < N * a.ps_ld; i += 256) ps_s[i] = a.pstats[(size_t)r * N * a.ps_ld + i];
+  if (a.cfg.rec_where_prior) {
+    if (tid < 128) {
+      spre_s[tid] = a.spre[(size_t)r * 128 + tid];
+      ce_s[tid] = flat[po.rn_cond_w + (4 + d.nh) * 128 + tid];
+    }
+    for (int i = tid; i < 512; i += 256) h2h_s[i] = flat[po.rn_h2h_w + i];
+    if (tid < 4) { h2h_s[512 + tid] = flat[po.rn_h2h_b + tid]; i2h_s[16 + tid] = flat[po.rn_i2h_b + tid]; isamp_s[tid] = flat[po.rn_init_sample + tid]; }
+    if (tid < 16) i2h_s[tid] = flat[po.rn_i2h_w + tid];
+    if (tid < 32) ro_s[tid] = flat[po.rn_readout_w + tid];
+    if (tid < 8) ro_s[32 + tid] = flat[po.rn_readout_b + tid];
+  }
+  if (tid < 10) { sp0_s[tid] = flat[po.sp_l0_w + tid]; sp0_s[10 + tid] = flat[po.sp_l0_b + tid]; ch_s[tid] = flat[po.cholesky + tid]; }
+  if (tid < 10 * (N + 1)) sp1_s[tid] = flat[po.sp_l1_w + tid];
+  if (tid <= N) {
+    sp1_s[10 * (N + 1) + tid] = flat[po.sp_l1_b + tid];
+    spb_s[tid] = flat[po.step_prior_bias + tid];
+    spb_s[N + 1 + tid] = flat[po.step_prior_tbias + tid];
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  const int lane = tid;
   const size_t tr = (size_t)a.t * d.R + r;
   const float LOG2PI = 1.83787706640934548356f;
 
   float e_sum = 0.0f, q_prop = 0.0f, p_prop = 0.0f, q_pres_sum = 0.0f, p_pres_sum = 0.0f, n_prop = 0.0f;
   for (int k = 0; k < N; ++k) {
-    const float* rp = a.rec_p + ((size_t)r * N + k) * rec::W;
-    const float* rm = a.rec_prev + ((size_t)r * N + k) * rec::W;
-    const float* ps = a.pstats + ((size_t)r * N + k) * a.ps_ld;
+    const float* rp = recp_s + k * RW;
+    const float* rm = recm_s + k * RW;
+    const float* ps = ps_s + k * a.ps_ld;
     const float pres = rp[rec::PRES], pres_tm1 = rm[rec::PRES];
     const float logit = rp[rec::LOGIT], logit_tm1 = rm[rec::LOGIT];
     float pl = ps[0] + a.cfg.prop_prior_step_bias;
@@ -309,14 +356,13 @@ __global__ __launch_bounds__(64) void k_logprob(const LogprobArgs a, const POff 
     // MultivariateNormalTriL log-prob: forward substitution with L = T * sc[:,None] + diag(sc)
     float q_where;
     {
-      const float* ch = flat + po.cholesky;
       float y[4];
       float sq = 0.0f, logdet = 0.0f;
       for (int i = 0; i < 4; ++i) {
         const float sci = rp[rec::WHERE_SCALE + i];
         float acc = rp[rec::WHERE + i] - rp[rec::WHERE_LOC + i];
-        for (int j = 0; j < i; ++j) acc -= tril4(ch, i, j) * sci * y[j];
-        const float lii = tril4(ch, i, i) * sci + sci;
+        for (int jj = 0; jj < i; ++jj) acc -= tril4(ch_s, i, jj) * sci * y[jj];
+        const float lii = tril4(ch_s, i, i) * sci + sci;
         y[i] = acc / lii;
         sq += y[i] * y[i];
         logdet += logf(fabsf(lii));
@@ -348,15 +394,15 @@ __global__ __launch_bounds__(64) void k_logprob(const LogprobArgs a, const POff 
   if (a.cfg.rec_where_prior) {
     float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int i = lane; i < 128; i += 64) {
-      const float sv = sq_elu(a.spre[(size_t)r * 128 + i] + e_sum * flat[po.rn_cond_w + (4 + d.nh) * 128 + i]);
-      for (int j = 0; j < 4; ++j) part[j] += sv * flat[po.rn_h2h_w + i * 4 + j];
+      const float sv = sq_elu(spre_s[i] + e_sum * ce_s[i]);
+      for (int jj = 0; jj < 4; ++jj) part[jj] += sv * h2h_s[i * 4 + jj];
     }
-    for (int j = 0; j < 4; ++j) hs[j] = sq_wave_sum(part[j]) + flat[po.rn_h2h_b + j] + flat[po.rn_i2h_b + j];
+    for (int jj = 0; jj < 4; ++jj) hs[jj] = sq_wave_sum(part[jj]) + h2h_s[512 + jj] + i2h_s[16 + jj];
   }
   float q_disc = 0.0f, p_disc = 0.0f, n_disc = 0.0f;
   double probs[SQ_MAXN];
   for (int j = 0; j < N; ++j) {
-    const float* rd = a.rec_d + ((size_t)r * N + j) * rec::W;
+    const float* rd = recd_s + j * RW;
     const float pres = rd[rec::PRES];
     probs[j] = (double)rd[rec::PROB];
     float qw = 0.0f, pw = 0.0f;
@@ -371,17 +417,17 @@ __global__ __launch_bounds__(64) void k_logprob(const LogprobArgs a, const POff 
       const float x = rd[rec::WHERE + lane];
       qwh = sq_normal_lp(x, rd[rec::WHERE_LOC + lane], rd[rec::WHERE_SCALE + lane]);
       if (a.cfg.rec_where_prior) {
-        const float* xp = j == 0 ? flat + po.rn_init_sample : a.rec_d + ((size_t)r * N + j - 1) * rec::W + rec::WHERE;
+        const float* xp = j == 0 ? isamp_s : recd_s + (j - 1) * RW + rec::WHERE;
         float o[4];
         for (int mm = 0; mm < 4; ++mm) {
           float acc = hs[mm];
-          for (int i = 0; i < 4; ++i) acc += xp[i] * flat[po.rn_i2h_w + i * 4 + mm];
+          for (int i = 0; i < 4; ++i) acc += xp[i] * i2h_s[i * 4 + mm];
           o[mm] = tanhf(acc);
         }
-        float loc = flat[po.rn_readout_b + lane], raw = flat[po.rn_readout_b + 4 + lane];
+        float loc = ro_s[32 + lane], raw = ro_s[32 + 4 + lane];
         for (int mm = 0; mm < 4; ++mm) {
-          loc += o[mm] * flat[po.rn_readout_w + mm * 8 + lane];
-          raw += o[mm] * flat[po.rn_readout_w + mm * 8 + 4 + lane];
+          loc += o[mm] * ro_s[mm * 8 + lane];
+          raw += o[mm] * ro_s[mm * 8 + 4 + lane];
         }
         pwh = sq_normal_lp(x, loc, sq_softplus(raw) + 1e-2f);
       } else {
@@ -424,12 +470,12 @@ __global__ __launch_bounds__(64) void k_logprob(const LogprobArgs a, const POff 
     p_num = (float)n * log1pf(-pr) + logf(pr);
   } else {
     float hid[10];
-    for (int i = 0; i < 10; ++i) hid[i] = sq_elu(e_sum * flat[po.sp_l0_w + i] + flat[po.sp_l0_b + i]);
+    for (int i = 0; i < 10; ++i) hid[i] = sq_elu(e_sum * sp0_s[i] + sp0_s[10 + i]);
     float lg[SQ_MAXN + 1];
     float mx = -1e30f;
     for (int c = 0; c <= N; ++c) {
-      float v = flat[po.step_prior_bias + c] + (a.t_global > 0 ? flat[po.step_prior_tbias + c] : 0.0f) + flat[po.sp_l1_b + c];
-      for (int i = 0; i < 10; ++i) v += hid[i] * flat[po.sp_l1_w + i * (N + 1) + c];
+      float v = spb_s[c] + (a.t_global > 0 ? spb_s[N + 1 + c] : 0.0f) + sp1_s[10 * (N + 1) + c];
+      for (int i = 0; i < 10; ++i) v += hid[i] * sp1_s[i * (N + 1) + c];
       lg[c] = sq_elu(v);
       mx = fmaxf(mx, lg[c]);
     }
@@ -454,7 +500,9 @@ __global__ __launch_bounds__(64) void k_logprob(const LogprobArgs a, const POff 
     for (int c = 0; c <= N; ++c) a.out.disc_prob[tr * (N + 1) + c] = (float)joint[c];
 }
 int sq_launch_logprob(const LogprobArgs& a, POff po, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_logprob, dim3(d.R), dim3(64), 0, s, a, po, d);
+  const size_t shm = ((size_t)3 * d.N * rec::W + (size_t)d.N * a.ps_ld + 128 + 128 + 516 + 20 + 40 + 4 + 20 +
+                      11 * (d.N + 1) + 2 * (d.N + 1) + 16) * sizeof(float);
+  hipLaunchKernelGGL(k_logprob, dim3(d.R), dim3(256), shm, s, a, po, d);
   return 0;
 }
 
@@ -469,55 +517,73 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff
   __shared__ float id_s[SQ_MAXN];
   const int r = blockIdx.x, tid = threadIdx.x;
   const int N = d.N, nh = d.nh;
-  if (tid == 0) {
-    float pres[2 * SQ_MAXN], ids[2 * SQ_MAXN];
+  if (tid < 64) {
+    // one lane per candidate slot (N propagated ++ N discovered): ballot + popcount give the stable
+    // present-first permutation and the running discovery count that numbers new objects
+    const int sl = tid;
+    const bool in = sl < 2 * N;
     const float last = a.last_id_prev[r];
-    float cum = 0.0f;
-    for (int k = 0; k < N; ++k) {
-      const float p = a.rec_p[((size_t)r * N + k) * rec::W + rec::PRES];
-      const float pid = a.rec_prev[((size_t)r * N + k) * rec::W + rec::ID];
-      pres[k] = p;
-      ids[k] = pid * p - (1.0f - p);
+    float p = 0.0f, pid = -1.0f;
+    if (in) {
+      p = sl < N ? a.rec_p[((size_t)r * N + sl) * rec::W + rec::PRES] : a.rec_d[((size_t)r * N + (sl - N)) * rec::W + rec::PRES];
+      if (sl < N) pid = a.rec_prev[((size_t)r * N + sl) * rec::W + rec::ID];
     }
-    for (int j = 0; j < N; ++j) {
-      const float p = a.rec_d[((size_t)r * N + j) * rec::W + rec::PRES];
-      cum += p;
-      pres[N + j] = p;
-      ids[N + j] = (cum + last) * p - (1.0f - p);
+    const unsigned long long all = (2 * N >= 64) ? ~0ull : ((1ull << (2 * N)) - 1ull);
+    const unsigned long long present = __ballot(in && p != 0.0f) & all;
+    const unsigned long long below = (1ull << sl) - 1ull;
+    const int n_present = __popcll(present);
+    const unsigned long long disc_bits = present >> N;  // bit j = discovery step j present
+    float id;
+    if (sl < N) id = pid * p - (1.0f - p);
+    else {
+      const int cum = __popcll(disc_bits & ((2ull << (sl - N)) - 1ull));  // inclusive cumsum of disc presence
+      id = ((float)cum + last) * p - (1.0f - p);
     }
-    a.last_id_next[r] = last + cum;
-    int dst = 0;
-    for (int s = 0; s < 2 * N && dst < N; ++s)
-      if (pres[s] != 0.0f) { src_s[dst] = s; id_s[dst] = ids[s]; ++dst; }
-    for (int s = 0; s < 2 * N && dst < N; ++s)
-      if (pres[s] == 0.0f) { src_s[dst] = s; id_s[dst] = ids[s]; ++dst; }
+    if (in) {
+      const int dst = (p != 0.0f) ? __popcll(present & below) : n_present + __popcll(~present & all & below);
+      if (dst < N) { src_s[dst] = sl; id_s[dst] = id; }
+    }
+    if (sl == 0) a.last_id_next[r] = last + (float)__popcll(disc_bits);
   }
   __syncthreads();
   const size_t tr = (size_t)a.t * d.R + r;
-  for (int dst = 0; dst < N; ++dst) {
-    const int s = src_s[dst];
-    const float* rs = s < N ? a.rec_p + ((size_t)r * N + s) * rec::W : a.rec_d + ((size_t)r * N + (s - N)) * rec::W;
-    float* rn = a.rec_next + ((size_t)r * N + dst) * rec::W;
-    for (int i = tid; i < rec::W; i += 256) rn[i] = (i == rec::ID) ? id_s[dst] : rs[i];
-    const float* ts = s < N ? a.temporal_p + ((size_t)r * N + s) * nh : a.flat + po.temporal_init;
-    const float* qs = s < N ? a.prior_p + ((size_t)r * N + s) * nh : a.flat + po.prior_init;
-    for (int i = tid; i < nh; i += 256) {
-      a.temporal_next[((size_t)r * N + dst) * nh + i] = ts[i];
-      a.prior_next[((size_t)r * N + dst) * nh + i] = qs[i];
+  // copy the N survivors: record (168) + temporal state + prior state, one flat loop of independent loads
+  const int per = rec::W + 2 * nh;
+#pragma unroll 4
+  for (int e = tid; e < N * per; e += 256) {
+    const int dst = e / per, i = e - dst * per;
+    const int sidx = src_s[dst];
+    const bool prop = sidx < N;
+    const int ss = prop ? sidx : sidx - N;
+    if (i < rec::W) {
+      const float* rs = (prop ? a.rec_p : a.rec_d) + ((size_t)r * N + ss) * rec::W;
+      a.rec_next[((size_t)r * N + dst) * rec::W + i] = (i == rec::ID) ? id_s[dst] : rs[i];
+    } else if (i < rec::W + nh) {
+      const int q = i - rec::W;
+      a.temporal_next[((size_t)r * N + dst) * nh + q] =
+          prop ? a.temporal_p[((size_t)r * N + ss) * nh + q] : a.flat[po.temporal_init + q];
+    } else {
+      const int q = i - rec::W - nh;
+      a.prior_next[((size_t)r * N + dst) * nh + q] = prop ? a.prior_p[((size_t)r * N + ss) * nh + q] : a.flat[po.prior_init + q];
     }
-    // the 9 hidden outputs + object id (seq.py:121-134)
+  }
+  // the 9 hidden outputs + object id (seq.py:121-134)
+  for (int e = tid; e < N * 64; e += 256) {
+    const int dst = e >> 6, c = e & 63;
+    const int sidx = src_s[dst];
+    const float* rs = sidx < N ? a.rec_p + ((size_t)r * N + sidx) * rec::W : a.rec_d + ((size_t)r * N + (sidx - N)) * rec::W;
     const size_t o = tr * N + dst;
-    for (int c = tid; c < d.nw; c += 256) {
+    if (c < d.nw) {
       if (a.out.what) a.out.what[o * d.nw + c] = rs[rec::WHAT + c];
       if (a.out.what_loc) a.out.what_loc[o * d.nw + c] = rs[rec::WHAT_LOC + c];
       if (a.out.what_scale) a.out.what_scale[o * d.nw + c] = rs[rec::WHAT_SCALE + c];
     }
-    if (tid < 4) {
-      if (a.out.where) a.out.where[o * 4 + tid] = rs[rec::WHERE + tid];
-      if (a.out.where_loc) a.out.where_loc[o * 4 + tid] = rs[rec::WHERE_LOC + tid];
-      if (a.out.where_scale) a.out.where_scale[o * 4 + tid] = rs[rec::WHERE_SCALE + tid];
+    if (c < 4) {
+      if (a.out.where) a.out.where[o * 4 + c] = rs[rec::WHERE + c];
+      if (a.out.where_loc) a.out.where_loc[o * 4 + c] = rs[rec::WHERE_LOC + c];
+      if (a.out.where_scale) a.out.where_scale[o * 4 + c] = rs[rec::WHERE_SCALE + c];
     }
-    if (tid == 0) {
+    if (c == 0) {
       if (a.out.presence_prob) a.out.presence_prob[o] = rs[rec::PROB];
       if (a.out.presence) a.out.presence[o] = rs[rec::PRES];
       if (a.out.presence_logit) a.out.presence_logit[o] = rs[rec::LOGIT];
@@ -527,8 +593,8 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff
   if (tid == 0 && a.out.num_steps_per_sample) {
     float ns = 0.0f;
     for (int dst = 0; dst < N; ++dst) {
-      const int s = src_s[dst];
-      ns += s < N ? a.rec_p[((size_t)r * N + s) * rec::W + rec::PRES] : a.rec_d[((size_t)r * N + (s - N)) * rec::W + rec::PRES];
+      const int sidx = src_s[dst];
+      ns += sidx < N ? a.rec_p[((size_t)r * N + sidx) * rec::W + rec::PRES] : a.rec_d[((size_t)r * N + (sidx - N)) * rec::W + rec::PRES];
     }
     a.out.num_steps_per_sample[tr] = ns;
   }
@@ -572,43 +638,57 @@ __global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const
   if (tid < N) pres_s[tid] = a.rec ? a.rec[((size_t)r * N + tid) * a.rec_ld + rec::PRES] : a.pres_plain[(size_t)r * N + tid];
   __syncthreads();
   const float* __restrict__ img = a.img + (size_t)b * P;
+  const float qv = a.qz != nullptr ? a.qz[r] : 0.0f, pv = a.qz != nullptr ? a.pz[r] : 0.0f;  // requested early
   float ll = 0.0f;
-  for (int pix = tid; pix < P; pix += 256) {
-    const int Y = pix / W, X = pix % W;
-    float cv = 0.0f, ms = 0.0f;
-    for (int k = 0; k < N; ++k) {
-      const float pk = pres_s[k];
-      if (pk == 0.0f) continue;
-      const float xg = xt_s[k * W + X], yg = yt_s[k * H + Y];
-      const float x0f = floorf(xg), y0f = floorf(yg);
-      // fully outside the glimpse: both taps invalid on one axis
-      if (!(xg > -1.0f && xg < (float)G && yg > -1.0f && yg < (float)G)) continue;
-      const int x0 = (int)x0f, y0 = (int)y0f;
-      const float wx1 = xg - x0f, wy1 = yg - y0f;
-      const float* gk = gl_s + k * G2;
-      float v = 0.0f, on = 0.0f;
+  constexpr int PF = 10;  // pixels per thread whose frame / mean-image values are requested together
+  for (int pix0 = tid; pix0 < P; pix0 += 256 * PF) {
+    float xv[PF], mv[PF];
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {
-        const int yy = y0 + dy;
-        if (yy < 0 || yy >= G) continue;
-        const float wy = dy ? wy1 : 1.0f - wy1;
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          const int xx = x0 + dx;
-          if (xx < 0 || xx >= G) continue;
-          const float w = wy * (dx ? wx1 : 1.0f - wx1);
-          v += w * gk[yy * G + xx];
-          on += w;
-        }
-      }
-      cv += v * pk;
-      ms += on * pk;
+    for (int q = 0; q < PF; ++q) {
+      const int pix = pix0 + q * 256;
+      xv[q] = pix < P ? img[pix] : 0.0f;
+      mv[q] = pix < P ? a.mean_img[pix] : 0.0f;
     }
-    const float m = sq_sigmoid(-10.0f + ms * 20.0f);
-    cv += a.mean_img[pix] * m;
-    const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
-    ll += sq_normal_lp(img[pix], cv, sd);
-    if (a.canvas) a.canvas[(size_t)r * P + pix] = cv;
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int pix = pix0 + q * 256;
+      if (pix >= P) break;
+      const int Y = pix / W, X = pix % W;
+      float cv = 0.0f, ms = 0.0f;
+      for (int k = 0; k < N; ++k) {
+        const float pk = pres_s[k];
+        if (pk == 0.0f) continue;
+        const float xg = xt_s[k * W + X], yg = yt_s[k * H + Y];
+        // fully outside the glimpse: both taps invalid on one axis
+        if (!(xg > -1.0f && xg < (float)G && yg > -1.0f && yg < (float)G)) continue;
+        const float x0f = floorf(xg), y0f = floorf(yg);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float wx1 = xg - x0f, wy1 = yg - y0f;
+        const float* gk = gl_s + k * G2;
+        float v = 0.0f, on = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const int yy = y0 + dy;
+          if (yy < 0 || yy >= G) continue;
+          const float wy = dy ? wy1 : 1.0f - wy1;
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int xx = x0 + dx;
+            if (xx < 0 || xx >= G) continue;
+            const float w = wy * (dx ? wx1 : 1.0f - wx1);
+            v += w * gk[yy * G + xx];
+            on += w;
+          }
+        }
+        cv += v * pk;
+        ms += on * pk;
+      }
+      const float m = sq_sigmoid(-10.0f + ms * 20.0f);
+      cv += mv[q] * m;
+      const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
+      ll += sq_normal_lp(xv[q], cv, sd);
+      if (a.canvas) a.canvas[(size_t)r * P + pix] = cv;
+    }
   }
   ll = sq_wave_sum(ll);
   if ((tid & 63) == 0) red_s[tid >> 6] = ll;
@@ -618,7 +698,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const
     a.data_ll[r] = dll;
     if (a.qz != nullptr) {
       const size_t tr = (size_t)a.t * d.R + r;
-      const float q = a.qz[r], p = a.pz[r];
+      const float q = qv, p = pv;
       const float kl = q - p;
       if (a.out.data_ll_per_sample) a.out.data_ll_per_sample[tr] = dll;
       if (a.out.kl_per_sample) a.out.kl_per_sample[tr] = kl;
@@ -647,22 +727,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void k_elbo(const float* __restrict__ log_w_t, const float* __restrict__ disc_lp_t,
+__global__ __launch_bounds__(1024) void k_elbo(const float* __restrict__ log_w_t, const float* __restrict__ disc_lp_t,
                                               int T, int B, int K, float* log_weights, float* elbo_per_ex, float* iw_out,
                                               float* signal_out, float* scalars, ElboMeans means, int n_means,
                                               float* means_out) {
-  __shared__ float acc_s[4][4 + 8];
+  __shared__ float acc_s[16][4 + 8];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int R = B * K;
   float a_vae = 0.0f, a_iwae = 0.0f, a_vimco = 0.0f, a_ess = 0.0f;
   float a_means[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int b = wave; b < B; b += 4) {
+  for (int b = wave; b < B; b += 16) {
     const bool act = lane < K;
     float lw = 0.0f, dl = 0.0f;
     if (act) {
-      for (int t = 0; t < T; ++t) {
-        lw += log_w_t[(size_t)t * R + b * K + lane];
-        dl += disc_lp_t ? disc_lp_t[(size_t)t * R + b * K + lane] : 0.0f;
+#pragma unroll 10
+      for (int t = 0; t < T; ++t) lw += log_w_t[(size_t)t * R + b * K + lane];
+      if (disc_lp_t != nullptr) {
+#pragma unroll 10
+        for (int t = 0; t < T; ++t) dl += disc_lp_t[(size_t)t * R + b * K + lane];
       }
     }
     const float mx = wave_max(act ? lw : -3.0e38f);
@@ -676,7 +758,11 @@ __global__ __launch_bounds__(256) void k_elbo(const float* __restrict__ log_w_t,
     float cv = 0.0f;
     {  // K == 1 gives 0/0 = NaN exactly like the reference's (k_particles - 1.) division (targets.py:55)
       const float abo = (sum_lw - lw) / ((float)K - 1.0f);
-      const float m2 = fmaxf(mx, act ? abo : mx);
+      float m2 = abo;  // max over the K terms of the leave-one-out sum (own weight replaced by abo)
+      for (int j = 0; j < K; ++j) {
+        const float lj = __shfl(lw, j, 64);
+        if (j != lane) m2 = fmaxf(m2, lj);
+      }
       float rest = 0.0f;  // sum_{j != k} exp(lw_j - m2), exact (no cancellation)
       for (int j = 0; j < K; ++j) {
         const float lj = __shfl(lw, j, 64);
@@ -700,6 +786,7 @@ __global__ __launch_bounds__(256) void k_elbo(const float* __restrict__ log_w_t,
     for (int q = 0; q < n_means; ++q) {
       float xm = 0.0f;
       if (act) {
+#pragma unroll 10
         for (int t = 0; t < T; ++t) xm += means.p[q][(size_t)t * R + b * K + lane];
         xm /= (float)T;
       }
@@ -713,7 +800,10 @@ __global__ __launch_bounds__(256) void k_elbo(const float* __restrict__ log_w_t,
   __syncthreads();
   if (threadIdx.x == 0) {
     float s[12];
-    for (int i = 0; i < 12; ++i) s[i] = acc_s[0][i] + acc_s[1][i] + acc_s[2][i] + acc_s[3][i];
+    for (int i = 0; i < 12; ++i) {
+      s[i] = 0.0f;
+      for (int wv = 0; wv < 16; ++wv) s[i] += acc_s[wv][i];
+    }
     if (scalars) {
       scalars[0] = s[0] / (float)(B * K);
       scalars[1] = s[1] / (float)B;
@@ -729,7 +819,7 @@ int sq_launch_elbo(const float* log_w_t, const float* disc_lp_t, int T, int B, i
                    int n_means, float* means_out, hipStream_t s) {
   ElboMeans m;
   for (int i = 0; i < 8; ++i) m.p[i] = (means_in != nullptr && i < n_means) ? means_in[i] : nullptr;
-  hipLaunchKernelGGL(k_elbo, dim3(1), dim3(256), 0, s, log_w_t, disc_lp_t, T, B, K, log_weights, elbo_per_ex, iw,
+  hipLaunchKernelGGL(k_elbo, dim3(1), dim3(1024), 0, s, log_w_t, disc_lp_t, T, B, K, log_weights, elbo_per_ex, iw,
                      signal, scalars, m, n_means, means_out);
   return 0;
 }

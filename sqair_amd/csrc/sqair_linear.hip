@@ -69,7 +69,14 @@ __device__ __forceinline__ f32x4 load_a4(const float* __restrict__ rowp, int kk,
   return a;
 }
 
-__global__ __launch_bounds__(256) void k_linear(const LinArgs a, const int kc_total, const int n_tiles) {
+// D = K-chunks per wave whose operand loads are issued before the first MFMA.  The layers of this model are
+// latency-bound (measured: ~1 us per dependent global access, activations come from another XCD's writes), so the
+// kernel is organised as ONE memory round trip: epilogue operands (bias, partial sums, GRU state) and every A / B
+// fragment of the wave are requested up front, then the MFMAs drain them in order.
+constexpr int LIN_D = 10;
+
+__global__ __launch_bounds__(256) void k_linear(const LinArgs a, const int kc_total, const int n_tiles,
+                                                unsigned long long* __restrict__ prof_ts) {
   __shared__ float red[4 * 256];
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
@@ -78,75 +85,111 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a, const int kc_to
   const int tile_m = blockIdx.x / n_tiles;
   const int arow = min(tile_m * 16 + (lane & 15), a.M - 1);
   const int kq = lane >> 4;
+  unsigned long long t_start = 0;
+  if (prof_ts != nullptr && tid == 0) t_start = wall_clock64();
 
-  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-  const f32x4* __restrict__ wp =
-      reinterpret_cast<const f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
-
-  int cbase = 0;
-#pragma unroll 1
-  for (int s = 0; s < a.nseg; ++s) {
-    const LinSeg sg = a.seg[s];
-    const int nch = (sg.width + 15) >> 4;
-    const float* __restrict__ rowp = sg.p + (size_t)(arow / sg.rdiv) * sg.ld;
-    const bool vec = ((reinterpret_cast<uintptr_t>(sg.p) & 15) == 0) && ((sg.ld & 3) == 0);
-    // chunks of this segment owned by this wave: global chunk index == wave (mod 4)
-    int c = (wave - (cbase & 3)) & 3;
-#pragma unroll 2
-    for (; c < nch; c += 4) {
-      const f32x4 av = load_a4(rowp, c * 16 + kq * 4, sg.width, vec);
-      const f32x4 bv = wp[(size_t)(cbase + c) * 64];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+  // ---- epilogue operands, requested first
+  const int m = tile_m * 16 + (tid >> 4);
+  const int n = tile_n * 16 + (tid & 15);
+  const bool live = m < a.M && n < a.N;
+  float p_bias = 0.0f, p_add = 0.0f, p_e0 = 0.0f, p_e1 = 0.0f, p_scale = 1.0f;
+  if (live) {
+    p_bias = a.bias[n];
+    if (a.add != nullptr && n < a.add_n) p_add = a.add[(size_t)(m / a.add_rdiv) * a.add_ld + n];
+    if (a.epi == EPI_GRU1) {
+      if (n >= a.nh && n < 2 * a.nh) p_e0 = a.e0[(size_t)m * a.e0_ld + (n - a.nh)];
+    } else if (a.epi == EPI_GRU2) {
+      p_e0 = a.e0[(size_t)m * a.e0_ld + n];
+      p_e1 = a.e1[(size_t)m * a.e1_ld + n];
+    } else if (a.scale_ptr != nullptr) {
+      p_scale = a.scale_ptr[0];
     }
-    cbase += nch;
+  }
+
+  // ---- segment table (chunk ranges are wave-uniform)
+  int cum[5];
+  const float* rowp[4];
+  int width[4];
+  bool vec[4];
+  cum[0] = 0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s < a.nseg) {
+      const LinSeg sg = a.seg[s];
+      cum[s + 1] = cum[s] + ((sg.width + 15) >> 4);
+      rowp[s] = sg.p + (size_t)(arow / sg.rdiv) * sg.ld;
+      width[s] = sg.width;
+      vec[s] = ((reinterpret_cast<uintptr_t>(sg.p) & 15) == 0) && ((sg.ld & 3) == 0);
+    } else {
+      cum[s + 1] = 0x7fffffff;
+      rowp[s] = a.seg[0].p;
+      width[s] = 0;
+      vec[s] = false;
+    }
+  }
+
+  f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
+  const int nmine = (kc_total - wave + 3) >> 2;  // this wave owns global chunks g = wave + 4 i
+#pragma unroll 1
+  for (int base = 0; base < nmine; base += LIN_D) {
+    f32x4 av[LIN_D], bv[LIN_D];
+#pragma unroll
+    for (int j = 0; j < LIN_D; ++j) {
+      if (base + j < nmine) {
+        const int g = wave + 4 * (base + j);
+        const int s = (g >= cum[1] ? 1 : 0) + (g >= cum[2] ? 1 : 0) + (g >= cum[3] ? 1 : 0);
+        const int c = g - cum[s];
+        av[j] = load_a4(rowp[s], c * 16 + kq * 4, width[s], vec[s]);
+        bv[j] = wp[(size_t)g * 64];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < LIN_D; ++j) {
+      if (base + j < nmine) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
+      }
+    }
   }
 
   // split-K reduction: acc[i] of lane l is C[row = 4*(l>>4) + i][col = l & 15]
   float* r = red + wave * 256;
-  r[(4 * kq + 0) * 16 + (lane & 15)] = acc.x;
-  r[(4 * kq + 1) * 16 + (lane & 15)] = acc.y;
-  r[(4 * kq + 2) * 16 + (lane & 15)] = acc.z;
-  r[(4 * kq + 3) * 16 + (lane & 15)] = acc.w;
+  r[(4 * kq + 0) * 16 + (lane & 15)] = acc0.x + acc1.x;
+  r[(4 * kq + 1) * 16 + (lane & 15)] = acc0.y + acc1.y;
+  r[(4 * kq + 2) * 16 + (lane & 15)] = acc0.z + acc1.z;
+  r[(4 * kq + 3) * 16 + (lane & 15)] = acc0.w + acc1.w;
   __syncthreads();
-  float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
-
-  const int m = tile_m * 16 + (tid >> 4);
-  const int n = tile_n * 16 + (tid & 15);
-  if (m >= a.M || n >= a.N) return;
-  v += a.bias[n];
-  if (a.add != nullptr && n < a.add_n) v += a.add[(size_t)(m / a.add_rdiv) * a.add_ld + n];
-
-  if (a.epi == EPI_ACT) {
-    v = sq_act(v, n < a.act_split ? a.act_a : a.act_b);
-    v *= a.scale;
-    if (a.scale_ptr != nullptr) v *= a.scale_ptr[0];
-    a.out[(size_t)m * a.out_ld + n] = v;
-  } else if (a.epi == EPI_GRU1) {
-    // columns [z | r | x W_h + b_h]   (snt.GRU)
-    const int nh = a.nh;
-    if (n < nh) {
-      a.out[(size_t)m * a.out_ld + n] = sq_sigmoid(v);
-    } else if (n < 2 * nh) {
-      const int j = n - nh;
-      a.o1[(size_t)m * a.o1_ld + j] = sq_sigmoid(v) * a.e0[(size_t)m * a.e0_ld + j];
-    } else {
-      a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
+  if (live) {
+    float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + p_bias + p_add;
+    if (a.epi == EPI_ACT) {
+      v = sq_act(v, n < a.act_split ? a.act_a : a.act_b);
+      a.out[(size_t)m * a.out_ld + n] = v * a.scale * p_scale;
+    } else if (a.epi == EPI_GRU1) {
+      // columns [z | r | x W_h + b_h]   (snt.GRU)
+      const int nh = a.nh;
+      if (n < nh) a.out[(size_t)m * a.out_ld + n] = sq_sigmoid(v);
+      else if (n < 2 * nh) a.o1[(size_t)m * a.o1_ld + (n - nh)] = sq_sigmoid(v) * p_e0;
+      else a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
+    } else {  // EPI_GRU2: h' = (1 - z) h + z tanh(x W_h + (r h) U_h + b_h)
+      a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1) * p_e0 + p_e1 * tanhf(v);
     }
-  } else {  // EPI_GRU2: h' = (1 - z) h + z tanh(x W_h + (r h) U_h + b_h)
-    const float hc = tanhf(v);
-    const float z = a.e1[(size_t)m * a.e1_ld + n];
-    const float hprev = a.e0[(size_t)m * a.e0_ld + n];
-    a.out[(size_t)m * a.out_ld + n] = (1.0f - z) * hprev + z * hc;
+  }
+  if (prof_ts != nullptr) {
+    __syncthreads();
+    if (tid == 0) {
+      atomicMin(prof_ts, t_start);
+      atomicMax(prof_ts + 4096, wall_clock64());  // end slots follow the PROF_MAX start slots
+    }
   }
 }
 
-int sq_launch_linear(const LinArgs& a, const PackedLayer& L, hipStream_t s) {
+int sq_launch_linear(const LinArgs& a, const PackedLayer& L, hipStream_t s, unsigned long long* prof_ts) {
   const int mt = (a.M + 15) / 16;
   const int grid = mt * L.nt;
   if (grid <= 0) return 0;
-  hipLaunchKernelGGL(k_linear, dim3(grid), dim3(256), 0, s, a, L.kc, L.nt);
+  hipLaunchKernelGGL(k_linear, dim3(grid), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
   return 0;
 }

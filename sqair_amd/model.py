@@ -79,6 +79,8 @@ class SqairCore(object):
             self.flat = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
             self.packed = torch.zeros(self.lib.sqair_packed_bytes(self.handle) // 4, dtype=torch.float32,
                                       device=self.device)
+            # all launches go to one dedicated non-default stream (HIP refuses to capture the legacy stream)
+            self.stream = torch.cuda.Stream(device=self.device)
         self._shape = None
         self._graph_ready = False
 
@@ -91,7 +93,7 @@ class SqairCore(object):
             pass
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(self.stream.cuda_stream)
 
     # ---- parameters ------------------------------------------------------------------------------
     def set_params(self, params):
@@ -109,9 +111,11 @@ class SqairCore(object):
 
     def pack(self):
         with torch.cuda.device(self.device):
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             _capi.check(self.handle, self.lib.sqair_pack_params(self.handle, self.flat.data_ptr(),
                                                                 self.packed.data_ptr(), self._stream()),
                         "sqair_pack_params")
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
         self._graph_ready = False
 
     # ---- buffers for a (T, B) shape ----------------------------------------------------------------
@@ -180,6 +184,7 @@ class SqairCore(object):
     def forward(self, t_offset=0, use_graph=False):
         """Launches the whole T-frame forward pass + the ELBO reductions on the current stream."""
         with torch.cuda.device(self.device):
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             if use_graph:
                 if not self._graph_ready:
                     torch.cuda.synchronize(self.device)
@@ -194,6 +199,18 @@ class SqairCore(object):
                 self.log_weights.data_ptr(), self.elbo_iwae_per_example.data_ptr(),
                 self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.scalars.data_ptr(),
                 self.c_means, len(self.mean_names), self.iw_means.data_ptr(), self._stream()), "sqair_elbo")
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def profile_linear(self, t_offset=0):
+        """Eager forward with HIP events around every dense-layer launch; returns a dict (see
+        sqair_profile_forward in include/sqair_hip.h)."""
+        ms, n, fl, empty = C.c_double(), C.c_int(), C.c_double(), C.c_double()
+        with torch.cuda.device(self.device):
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            _capi.check(self.handle, self.lib.sqair_profile_forward(*(self._args(t_offset) + (
+                C.byref(ms), C.byref(n), C.byref(fl), C.byref(empty)))), "sqair_profile_forward")
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return dict(linear_ms=ms.value, launches=n.value, executed_flops=fl.value, forward_ms_events=empty.value)
 
     def graph_nodes(self):
         return self.lib.sqair_graph_nodes(self.handle)
