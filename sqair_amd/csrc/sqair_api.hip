@@ -52,6 +52,7 @@ struct SqairHandle {
   unsigned long long* prof_ts = nullptr;
   int prof_n = 0;
   double prof_flops = 0.0;
+  std::vector<int> prof_layer, prof_m;
   // graph
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -283,6 +284,8 @@ static ColBlock cb1(int ncols, int col0, const std::string& w, const RowMap& row
 
 static void build_plan(SqairHandle* h) {
   const SqairConfig& c = h->cfg;
+  h->packed_w = 256;  // leading zero block: one K-chunk of zero weights for the ragged tail of the chunk loop
+  h->widx.assign(256, -1);
   const int P_ = c.img_h * c.img_w, nh = c.n_hidden, nw = c.n_what;
   const int G2 = c.glimpse_size * c.glimpse_size, nsp = nh / 2;
   auto simple = [&](LayerId id, const std::string& name, int fin, int fout, int row0 = 0, bool bias = true) {
@@ -357,7 +360,9 @@ static void build_plan(SqairHandle* h) {
     b.seg = {{"prop.rnn.i2h.w", rm_zrec(nw, nw + nw, nw, nw + nw + 4)}, {"prop.rnn.h2h.w", rm_range(0, nh)}};
     build_layer(h, L_PROP_RNN, {rec::ZW, nh}, {b});
   }
-  simple(L_PROP_T1, "prop.transform.l0", nh, nh, 0, false);
+  // transform hidden layer 1 + (extra columns) the r_k rows of the steps predictor's hidden layer: both consume r_k
+  build_layer(h, L_PROP_T1, {nh},
+              {cb1(nh, 0, "prop.transform.l0.w", rm_range(0, nh)), cb1(nsp, 0, "prop.steps.l0.w", rm_range(0, nh))});
   simple(L_PROP_T2, "prop.transform.l1", nh, nh);
   simple(L_PROP_T3, "prop.transform.l2", nh, 8);
   {
@@ -381,8 +386,8 @@ static void build_plan(SqairHandle* h) {
   {
     ColBlock b;
     b.ncols = nsp; b.col0 = 0;
-    b.seg = {{"prop.steps.l0.w", rm_range(0, nh)}, {"prop.steps.l0.w", rm_zrec(nw, -1, 2 * nh, -1)}};
-    build_layer(h, L_PROP_S1, {nh, rec::ZW}, {b});
+    b.seg = {{"prop.steps.l0.w", rm_zrec(nw, -1, 2 * nh, -1)}};  // `what` rows only; consumed by k_slot_tail
+    build_layer(h, L_PROP_S1, {rec::ZW}, {b});
   }
   build_layer(h, L_LAT0, {rec::ZW}, {cb1(nh, 0, "seq.latent_enc.l0.w", rm_zrec(nw, nw, 0, -1), "seq.latent_enc.l0.b")});
   simple(L_LAT1, "seq.latent_enc.l1", nh, nh);
@@ -400,15 +405,16 @@ static void build_plan(SqairHandle* h) {
     b.seg = {{"disc.rnn.i2h.w", rm_zrec(nw, 2 * nh + nw, 2 * nh, 2 * nh + nw + 4)}, {"disc.rnn.h2h.w", rm_range(0, nh)}};
     build_layer(h, L_DISC_RNN, {rec::ZW, nh}, {b});
   }
-  simple(L_DISC_T1, "disc.transform.l0", nh, nh);
+  build_layer(h, L_DISC_T1, {nh},
+              {cb1(nh, 0, "disc.transform.l0.w", rm_range(0, nh), "disc.transform.l0.b"),
+               cb1(nsp, 0, "disc.steps.l0.w", rm_range(0, nh), "disc.steps.l0.b")});
   simple(L_DISC_T2, "disc.transform.l1", nh, nh);
   simple(L_DISC_T3, "disc.transform.l2", nh, 8);
   {
     ColBlock b;
     b.ncols = nsp; b.col0 = 0;
-    b.seg = {{"disc.steps.l0.w", rm_range(0, nh)}, {"disc.steps.l0.w", rm_zrec(nw, -1, nh, -1)}};
-    b.bias_a = "disc.steps.l0.b";
-    build_layer(h, L_DISC_S1, {nh, rec::ZW}, {b});
+    b.seg = {{"disc.steps.l0.w", rm_zrec(nw, -1, nh, -1)}};  // `what` rows only; consumed by k_slot_tail
+    build_layer(h, L_DISC_S1, {rec::ZW}, {b});
   }
   build_layer(h, L_DEC0, {rec::ZW}, {cb1(nh, 0, "dec.l0.w", rm_zrec(nw, -1, 0, -1), "dec.l0.b")});
   simple(L_DEC1, "dec.l1", nh, nh);
@@ -502,10 +508,11 @@ struct Workspace {
   float *ienc_a, *ienc_b, *pre_disc;
   float *rec_m[2], *temporal_m[2], *prior_m[2], *last_id[2];
   float *rec_p, *rec_d, *zero_rec, *disc_init_rec;
+  float *prop_rnn_init, *disc_rnn_init, *rn_init_state;  // 16-byte aligned copies of small parameter vectors
   float *temporal_p, *prior_p;
   float *gz, *grh, *gxh;
   float *pstats, *hid1, *wb, *mask, *g1, *ea, *eb, *m1, *pre;
-  float *rbuf[2], *t1, *t2, *tp, *g2, *enc, *hraw, *s1;
+  float *rbuf[2], *t1, *t2, *tp, *g2, *enc, *hraw, *s1, *e1, *e2, *w3_prop, *w3_disc;
   float *c, *pre_d, *spre, *qz, *pz, *dlp, *dll, *glimpse;
   unsigned long long* prof_ts;  // [2][PROF_MAX] start / end ticks of profiled k_linear launches
   int64_t total;  // floats
@@ -538,6 +545,9 @@ static Workspace carve(const SqairHandle* h, int T, int B, float* base) {
   w.rec_d = take(M * rec::W);
   w.zero_rec = take(rec::W);
   w.disc_init_rec = take(rec::W);
+  w.prop_rnn_init = take(nh);
+  w.disc_rnn_init = take(nh);
+  w.rn_init_state = take(4);
   w.temporal_p = take(M * nh);
   w.prior_p = take(M * nh);
   w.gz = take(M * nh);
@@ -554,7 +564,11 @@ static Workspace carve(const SqairHandle* h, int T, int B, float* base) {
   w.pre = take(M * pre_ld);
   w.rbuf[0] = take(R * nh);
   w.rbuf[1] = take(R * nh);
-  w.t1 = take(R * nh);
+  w.t1 = take(R * (nh + nh / 2));  // [transform hidden 1 | steps-predictor partial pre-activation]
+  w.e1 = take(R * nh);
+  w.e2 = take(R * nh);
+  w.w3_prop = take(nh * 8 + 8);
+  w.w3_disc = take(nh * 8 + 8);
   w.t2 = take(R * nh);
   w.tp = take(R * TP_LD);
   w.g2 = take(R * G2);
@@ -622,6 +636,7 @@ static int run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, h
       return -3;
     }
   l.a.wp = packed + pl.w + L.w_off;
+  l.a.wzero = packed + pl.w;
   l.a.bias = packed + pl.b + L.b_off;
   l.a.M = M;
   l.a.N = L.N;
@@ -629,9 +644,13 @@ static int run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, h
     int ksum = 0;
     for (int w : L.seg_width) ksum += w;
     h->prof_flops += 2.0 * (double)M * (double)ksum * (double)L.N;
+    h->prof_layer.push_back((int)id);
+    h->prof_m.push_back(M);
     return sq_launch_linear(l.a, L, s, h->prof_ts + h->prof_n++);
   }
-  return sq_launch_linear(l.a, L, s);
+  const int rc = sq_launch_linear(l.a, L, s);
+  if (rc != 0) sq_set_error(h, "internal: A-operand contract (16-byte aligned, ld % 4 == 0) violated in layer " + std::to_string((int)id));
+  return rc;
 }
 
 #define RUN(l, id, M)                                   \
@@ -663,11 +682,14 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
   const int RW = rec::W;
 
   // ---- sequence prologue -----------------------------------------------------------------------
-  // slot records are read as 56-wide GEMM segments before every field has been written in a frame (the
-  // unwritten fields meet zero weight rows, but 0 * NaN = NaN): clear them, the caller's workspace is garbage
-  SQ_CHECK_HIP(hipMemsetAsync(w.rec_p, 0, (size_t)(w.temporal_p - w.rec_p) * 4, s));
+  // The GEMM A-operand contract wants every float it may touch to be finite (padding meets zero weights, but
+  // 0 * NaN = NaN) and slot records are read as 56-wide segments before all their fields are written in a frame:
+  // clear the caller's (garbage) workspace once per pass, ~15 MB = a few microseconds
+  SQ_CHECK_HIP(hipMemsetAsync(wsbase, 0, (size_t)((float*)w.prof_ts - wsbase) * 4, s));
   // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
-  sq_launch_init_state(w.rec_m[0], w.temporal_m[0], w.prior_m[0], w.last_id[0], w.disc_init_rec, flat, po, d, s);
+  sq_launch_init_state(w.rec_m[0], w.temporal_m[0], w.prior_m[0], w.last_id[0], w.disc_init_rec, w.prop_rnn_init,
+                       w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc, (int)P(h, "prop.transform.l2.w"),
+                       (int)P(h, "disc.transform.l2.w"), flat, po, d, s);
   {  // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
     Lin a; a.seg(obs, P_, P_).out(w.ienc_a, nh).act(ACT_ELU); RUN(a, L_IENC0, T * B);
     Lin b; b.seg(w.ienc_a, nh, nh).out(w.ienc_b, nh).act(ACT_ELU); RUN(b, L_IENC1, T * B);
@@ -719,27 +741,29 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
       float* r_k = w.rbuf[k & 1];
       {
         Lin a;
-        if (k == 0) a.seg(w.zero_rec, 0, rec::ZW).seg(flat + po.prop_rnn_init, 0, nh);
+        if (k == 0) a.seg(w.zero_rec, 0, rec::ZW).seg(w.prop_rnn_init, 0, nh);
         else a.seg(w.rec_p + (size_t)(k - 1) * RW, N * RW, rec::ZW).seg(w.rbuf[(k - 1) & 1], nh, nh);
         a.add(pre_k, pre_rld, nh).out(r_k, nh).act(ACT_TANH);
         RUN(a, L_PROP_RNN, R);
       }
+      const int t1ld = nh + nh / 2;
       {
-        Lin a; a.seg(r_k, nh, nh).add(pre_k + nh, pre_rld, nh).out(w.t1, nh).act(ACT_ELU); RUN(a, L_PROP_T1, R);
-        Lin b; b.seg(w.t1, nh, nh).out(w.t2, nh).act(ACT_ELU); RUN(b, L_PROP_T2, R);
-        Lin t3; t3.seg(w.t2, nh, nh).out(w.tp, TP_LD); RUN(t3, L_PROP_T3, R);
+        // T1 columns [transform hidden 1 (ELU) | steps-predictor hidden pre-activation without `what` (linear)]
+        Lin a; a.seg(r_k, nh, nh).add(pre_k + nh, pre_rld, nh + nh / 2).out(w.t1, t1ld).act2(ACT_ELU, ACT_NONE, nh);
+        RUN(a, L_PROP_T1, R);
+        Lin b; b.seg(w.t1, t1ld, nh).out(w.t2, nh).act(ACT_ELU); RUN(b, L_PROP_T2, R);
       }
       {
         CropArgs ca; memset(&ca, 0, sizeof(ca));
         ca.mode = CROP_PROP2; ca.img = img; ca.mask = c.masked_glimpse ? w.mask : nullptr; ca.mask_row_mul = N;
         ca.mask_row_add = k; ca.out = w.g2; ca.out_row_mul = 1; ca.rec_prev = rec_prev; ca.rec_new = w.rec_p;
-        ca.tp = w.tp; ca.tp_ld = TP_LD; ca.noise = nz; ca.flat = flat; ca.slot = k;
+        ca.t2 = w.t2; ca.t2_ld = nh; ca.w3 = w.w3_prop; ca.noise = nz; ca.flat = flat; ca.slot = k;
         sq_launch_crop(ca, po, d, 1, s);
       }
       {
-        Lin a; a.seg(w.g2, G2, G2).out(w.t1, nh).act(ACT_ELU); RUN(a, L_GENC0, R);
-        Lin b; b.seg(w.t1, nh, nh).out(w.t2, nh).act(ACT_ELU); RUN(b, L_GENC1, R);
-        Lin e; e.seg(w.t2, nh, nh).out(w.enc, ENC_LD).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
+        Lin a; a.seg(w.g2, G2, G2).out(w.e1, nh).act(ACT_ELU); RUN(a, L_GENC0, R);
+        Lin b; b.seg(w.e1, nh, nh).out(w.e2, nh).act(ACT_ELU); RUN(b, L_GENC1, R);
+        Lin e; e.seg(w.e2, nh, nh).out(w.enc, ENC_LD).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
       }
       {
         const float* tau_k = temporal_prev + (size_t)k * nh;
@@ -751,13 +775,14 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
                   .gru2(tau_k, N * nh, w.gz, nh, nh);
         RUN(g2, L_PROP_GRU2, R);
         Lin hd; hd.seg(w.temporal_p + (size_t)k * nh, N * nh, nh).out(w.hraw, HRAW_LD); RUN(hd, L_PROP_HEADS, R);
-        sq_launch_what_prop(w.hraw, HRAW_LD, w.enc, ENC_LD, rec_prev, nz, w.rec_p, k, d, s);
       }
       {
-        Lin a; a.seg(r_k, nh, nh).seg(w.rec_p + (size_t)k * RW, N * RW, rec::ZW).add(pre_k + 2 * nh, pre_rld, nh / 2)
-                 .out(w.s1, 128).act(ACT_ELU);
-        RUN(a, L_PROP_S1, R);
-        sq_launch_steps(w.s1, 128, flat, po.prop_steps_l1_w, po.prop_steps_l1_b, rec_prev, w.rec_p, nz, k, 0, d, s);
+        TailArgs ta; memset(&ta, 0, sizeof(ta));
+        ta.is_disc = 0; ta.slot = k; ta.hraw = w.hraw; ta.h_ld = HRAW_LD; ta.enc = w.enc; ta.enc_ld = ENC_LD;
+        ta.rec_prev = rec_prev; ta.rec_new = w.rec_p; ta.noise = nz; ta.s1p = w.t1 + nh; ta.s1p_ld = t1ld;
+        ta.wp = packed + packed_layout(h).w + h->layers[L_PROP_S1].w_off; ta.flat = flat;
+        ta.w2_off = po.prop_steps_l1_w; ta.b2_off = po.prop_steps_l1_b;
+        sq_launch_slot_tail(ta, d, s);
       }
     }
     // ---- F. summary of propagated latents -> discovery conditioning (sqair_modules.py:368-385, :501) ----
@@ -767,7 +792,7 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
       sq_launch_latent_sum(w.eb, w.rec_p, w.c, d, s);
       Lin p; p.seg(w.c, nh, nh).add(w.pre_disc + (size_t)t * B * nh, nh, nh, K).out(w.pre_d, nh); RUN(p, L_PRED, R);
       if (c.rec_where_prior) {
-        Lin q; q.seg(flat + po.rn_init_state, 0, 4).seg(w.c, nh, nh).out(w.spre, 128); RUN(q, L_RNCOND, R);
+        Lin q; q.seg(w.rn_init_state, 0, 4).seg(w.c, nh, nh).out(w.spre, 128); RUN(q, L_RNCOND, R);
       }
     }
     // ---- G. discovery steps (sqair_modules.py:129-147 static_rnn over DiscoveryCore) ----
@@ -775,28 +800,30 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
       float* r_j = w.rbuf[j & 1];
       {
         Lin a;
-        if (j == 0) a.seg(w.disc_init_rec, 0, rec::ZW).seg(flat + po.disc_rnn_init, 0, nh);
+        if (j == 0) a.seg(w.disc_init_rec, 0, rec::ZW).seg(w.disc_rnn_init, 0, nh);
         else a.seg(w.rec_d + (size_t)(j - 1) * RW, N * RW, rec::ZW).seg(w.rbuf[(j - 1) & 1], nh, nh);
         a.add(w.pre_d, nh, nh).out(r_j, nh).act(ACT_TANH);
         RUN(a, L_DISC_RNN, R);
-        Lin b; b.seg(r_j, nh, nh).out(w.t1, nh).act(ACT_ELU); RUN(b, L_DISC_T1, R);
-        Lin cc; cc.seg(w.t1, nh, nh).out(w.t2, nh).act(ACT_ELU); RUN(cc, L_DISC_T2, R);
-        Lin t3; t3.seg(w.t2, nh, nh).out(w.tp, TP_LD); RUN(t3, L_DISC_T3, R);
+        const int t1ld = nh + nh / 2;
+        Lin b; b.seg(r_j, nh, nh).out(w.t1, t1ld).act2(ACT_ELU, ACT_NONE, nh); RUN(b, L_DISC_T1, R);
+        Lin cc; cc.seg(w.t1, t1ld, nh).out(w.t2, nh).act(ACT_ELU); RUN(cc, L_DISC_T2, R);
       }
       {
         CropArgs ca; memset(&ca, 0, sizeof(ca));
-        ca.mode = CROP_DISC; ca.img = img; ca.out = w.g2; ca.out_row_mul = 1; ca.rec_new = w.rec_d; ca.tp = w.tp;
-        ca.tp_ld = TP_LD; ca.noise = nz; ca.flat = flat; ca.slot = j;
+        ca.mode = CROP_DISC; ca.img = img; ca.out = w.g2; ca.out_row_mul = 1; ca.rec_new = w.rec_d; ca.t2 = w.t2;
+        ca.t2_ld = nh; ca.w3 = w.w3_disc; ca.noise = nz; ca.flat = flat; ca.slot = j;
         sq_launch_crop(ca, po, d, 1, s);
-        Lin a; a.seg(w.g2, G2, G2).out(w.t1, nh).act(ACT_ELU); RUN(a, L_GENC0, R);
-        Lin b; b.seg(w.t1, nh, nh).out(w.t2, nh).act(ACT_ELU); RUN(b, L_GENC1, R);
-        Lin e; e.seg(w.t2, nh, nh).out(w.enc, ENC_LD).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
-        sq_launch_what_disc(w.enc, ENC_LD, nz, w.rec_d, j, d, s);
+        Lin a; a.seg(w.g2, G2, G2).out(w.e1, nh).act(ACT_ELU); RUN(a, L_GENC0, R);
+        Lin b; b.seg(w.e1, nh, nh).out(w.e2, nh).act(ACT_ELU); RUN(b, L_GENC1, R);
+        Lin e; e.seg(w.e2, nh, nh).out(w.enc, ENC_LD).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
       }
       {
-        Lin a; a.seg(r_j, nh, nh).seg(w.rec_d + (size_t)j * RW, N * RW, rec::ZW).out(w.s1, 128).act(ACT_ELU);
-        RUN(a, L_DISC_S1, R);
-        sq_launch_steps(w.s1, 128, flat, po.disc_steps_l1_w, po.disc_steps_l1_b, rec_prev, w.rec_d, nz, j, 1, d, s);
+        TailArgs ta; memset(&ta, 0, sizeof(ta));
+        ta.is_disc = 1; ta.slot = j; ta.enc = w.enc; ta.enc_ld = ENC_LD; ta.rec_prev = rec_prev; ta.rec_new = w.rec_d;
+        ta.noise = nz; ta.s1p = w.t1 + nh; ta.s1p_ld = nh + nh / 2;
+        ta.wp = packed + packed_layout(h).w + h->layers[L_DISC_S1].w_off; ta.flat = flat;
+        ta.w2_off = po.disc_steps_l1_w; ta.b2_off = po.disc_steps_l1_b;
+        sq_launch_slot_tail(ta, d, s);
       }
     }
     // ---- H. log-probabilities, I. merge / compaction ----
@@ -867,6 +894,8 @@ extern "C" int sqair_profile_forward(SqairHandle* h, const float* flat_params, c
   h->prof_ts = w.prof_ts;
   h->prof_n = 0;
   h->prof_flops = 0.0;
+  h->prof_layer.clear();
+  h->prof_m.clear();
   hipEventRecord(ea, s);
   int rc = forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
                         workspace_bytes, s);
@@ -882,6 +911,14 @@ extern "C" int sqair_profile_forward(SqairHandle* h, const float* flat_params, c
   SQ_CHECK_HIP(hipMemcpy(ts.data(), w.prof_ts, 2 * PROF_MAX * 8, hipMemcpyDeviceToHost));
   double ticks = 0.0;
   for (int i = 0; i < h->prof_n; ++i) ticks += (double)(ts[PROF_MAX + i] - ts[i]);
+  if (const char* dump = getenv("SQAIR_PROF_DUMP")) {  // per-launch CSV: layer id, rows, start tick, end tick (10 ns ticks)
+    if (FILE* f = fopen(dump, "w")) {
+      fprintf(f, "layer,M,start,end\n");
+      for (int i = 0; i < h->prof_n; ++i)
+        fprintf(f, "%d,%d,%llu,%llu\n", h->prof_layer[i], h->prof_m[i], ts[i] - ts[0], ts[PROF_MAX + i] - ts[0]);
+      fclose(f);
+    }
+  }
   if (linear_ms) *linear_ms = ticks * 1e-5;  // 100 MHz ticks -> ms
   if (linear_launches) *linear_launches = h->prof_n;
   if (linear_flops) *linear_flops = h->prof_flops;
@@ -1002,24 +1039,29 @@ extern "C" int sqair_linear_test(SqairHandle* h, const float* x, const float* wm
   PackedLayer L;
   adhoc_layer(h, Kdim, Ndim, &L);
   const int64_t nel = (int64_t)L.nt * L.kc * 256, nb = L.nt * 16;
-  if (scratch_bytes < (2 * nel + 2 * nb) * 4) { sq_set_error(h, "sqair_linear_test: scratch too small"); return -1; }
-  std::vector<int> idx(nel, -1), bidx(nb, -1), bnone(nb, -1);
+  const int kpad = (Kdim + 3) & ~3;
+  if (scratch_bytes < (2 * nel + 2 * nb + 256 + (int64_t)M * kpad) * 4) { sq_set_error(h, "sqair_linear_test: scratch too small"); return -1; }
+  std::vector<int> idx(nel, -1), bidx(nb, -1);
   adhoc_fill(idx, L.kc, 0, 0, Ndim, Kdim, 0, Ndim, 0);
   for (int n = 0; n < Ndim; ++n) bidx[n] = b ? n : -1;
   int* d_idx = (int*)scratch;
   float* d_w = (float*)scratch + nel;
   float* d_b = d_w + nel;
   int* d_bidx = (int*)(d_b + nb);
+  float* d_zero = (float*)(d_bidx + nb);
+  float* d_x = d_zero + 256;  // A-operand contract: rows padded to a multiple of 4 floats, finite
   SQ_CHECK_HIP(hipMemcpyAsync(d_idx, idx.data(), nel * 4, hipMemcpyHostToDevice, s));
   SQ_CHECK_HIP(hipMemcpyAsync(d_bidx, bidx.data(), nb * 4, hipMemcpyHostToDevice, s));
+  SQ_CHECK_HIP(hipMemsetAsync(d_zero, 0, (256 + (size_t)M * kpad) * 4, s));
+  SQ_CHECK_HIP(hipMemcpy2DAsync(d_x, (size_t)kpad * 4, x, (size_t)Kdim * 4, (size_t)Kdim * 4, M, hipMemcpyDeviceToDevice, s));
   SQ_CHECK_HIP(hipStreamSynchronize(s));
   sq_launch_pack(wmat, d_w, d_idx, nel, s);
   if (b) sq_launch_pack(b, d_b, d_bidx, nb, s);
   else SQ_CHECK_HIP(hipMemsetAsync(d_b, 0, nb * 4, s));
   Lin l;
-  l.seg(x, Kdim, Kdim).out(y, Ndim).act(act);
-  l.a.wp = d_w; l.a.bias = d_b; l.a.M = M; l.a.N = Ndim;
-  sq_launch_linear(l.a, L, s);
+  l.seg(d_x, kpad, Kdim).out(y, Ndim).act(act);
+  l.a.wp = d_w; l.a.wzero = d_zero; l.a.bias = d_b; l.a.M = M; l.a.N = Ndim;
+  if (sq_launch_linear(l.a, L, s) != 0) { sq_set_error(h, "sqair_linear_test: A-operand contract violated"); return -5; }
   SQ_CHECK_HIP(hipGetLastError());
   SQ_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
@@ -1038,7 +1080,8 @@ extern "C" int sqair_gru_test(SqairHandle* h, const float* x, const float* hstat
   L1.nt = 3 * nh / 16; L1.N = 3 * nh; L1.w_off = 0; L1.b_off = 0;
   adhoc_layer(h, nh, nh, &L2);
   const int64_t n1 = (int64_t)L1.nt * L1.kc * 256, n2 = (int64_t)L2.nt * L2.kc * 256, nb1 = L1.nt * 16, nb2 = L2.nt * 16;
-  const int64_t need = (2 * n1 + 2 * n2 + 2 * nb1 + nb2 + 3 * (int64_t)M * nh) * 4;
+  const int kpad = (Kx + 3) & ~3;
+  const int64_t need = (2 * n1 + 2 * n2 + 2 * nb1 + nb2 + 3 * (int64_t)M * nh + 256 + (int64_t)M * kpad) * 4;
   if (scratch_bytes < need) { sq_set_error(h, "sqair_gru_test: scratch too small"); return -1; }
   std::vector<int> i1(n1, -1), i2(n2, -1), b1(nb1, -1);
   const int xc = (Kx + 15) / 16;
@@ -1059,6 +1102,10 @@ extern "C" int sqair_gru_test(SqairHandle* h, const float* x, const float* hstat
   float* d_z = f; f += (int64_t)M * nh;
   float* d_rh = f; f += (int64_t)M * nh;
   float* d_xh = f; f += (int64_t)M * nh;
+  float* d_zero = f; f += 256;
+  float* d_x = f; f += (int64_t)M * kpad;
+  SQ_CHECK_HIP(hipMemsetAsync(d_zero, 0, (256 + (size_t)M * kpad) * 4, s));
+  SQ_CHECK_HIP(hipMemcpy2DAsync(d_x, (size_t)kpad * 4, x, (size_t)Kx * 4, (size_t)Kx * 4, M, hipMemcpyDeviceToDevice, s));
   SQ_CHECK_HIP(hipMemcpyAsync(d_i1, i1.data(), n1 * 4, hipMemcpyHostToDevice, s));
   SQ_CHECK_HIP(hipMemcpyAsync(d_i2, i2.data(), n2 * 4, hipMemcpyHostToDevice, s));
   SQ_CHECK_HIP(hipMemcpyAsync(d_b1i, b1.data(), nb1 * 4, hipMemcpyHostToDevice, s));
@@ -1068,12 +1115,12 @@ extern "C" int sqair_gru_test(SqairHandle* h, const float* x, const float* hstat
   sq_launch_pack(gru_flat, d_b1, d_b1i, nb1, s);
   SQ_CHECK_HIP(hipMemsetAsync(d_b2, 0, nb2 * 4, s));
   Lin g1;
-  g1.seg(x, Kx, Kx).seg(hstate, nh, nh).out(d_z, nh).gru1(hstate, nh, d_rh, nh, d_xh, nh, nh);
-  g1.a.wp = d_w1; g1.a.bias = d_b1; g1.a.M = M; g1.a.N = 3 * nh;
-  sq_launch_linear(g1.a, L1, s);
+  g1.seg(d_x, kpad, Kx).seg(hstate, nh, nh).out(d_z, nh).gru1(hstate, nh, d_rh, nh, d_xh, nh, nh);
+  g1.a.wp = d_w1; g1.a.wzero = d_zero; g1.a.bias = d_b1; g1.a.M = M; g1.a.N = 3 * nh;
+  if (sq_launch_linear(g1.a, L1, s) != 0) { sq_set_error(h, "sqair_gru_test: A-operand contract violated"); return -5; }
   Lin g2;
   g2.seg(d_rh, nh, nh).add(d_xh, nh, nh).out(h_out, nh).gru2(hstate, nh, d_z, nh, nh);
-  g2.a.wp = d_w2; g2.a.bias = d_b2; g2.a.M = M; g2.a.N = nh;
+  g2.a.wp = d_w2; g2.a.wzero = d_zero; g2.a.bias = d_b2; g2.a.M = M; g2.a.N = nh;
   sq_launch_linear(g2.a, L2, s);
   SQ_CHECK_HIP(hipGetLastError());
   SQ_CHECK_HIP(hipStreamSynchronize(s));

@@ -52,6 +52,7 @@ struct LinArgs {
   int nseg;
   const float* wp;    // packed weights of this layer: [n_tiles][k_chunks][64 lanes][4]
   const float* bias;  // packed bias [n_tiles*16]
+  const float* wzero; // 256 zero floats (one chunk of zero weights) inside the packed buffer
   const float* add;   // optional pre-activation addend, applied for n < add_n
   int add_ld, add_rdiv, add_n;
   float* out;

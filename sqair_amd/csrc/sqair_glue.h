@@ -35,15 +35,19 @@ struct CropArgs {
   float* rec_new;          // prop / disc records of this frame [R,N,168]
   const float* wb;         // PROP1: raw where-bias MLP output [(R*N), wb_ld]
   int wb_ld;
-  const float* tp;         // PROP2 / DISC: transform MLP output [R, tp_ld] (loc 0:4, raw scale 4:8)
+  const float* tp;         // PROP2 / DISC: transform MLP output [R, tp_ld] (loc 0:4, raw scale 4:8), or
   int tp_ld;
+  const float* t2;         // ... its input [R, t2_ld]: the 256 -> 8 output layer is then evaluated in this launch
+  int t2_ld;
+  const float* w3;         // 16-byte aligned copy of transform.l2 {w [nh,8], b [8]} (workspace, see k_init_state)
   const float* noise;      // noise of frame t, [R,2,N,nzw]
   const float* flat;       // flat parameters
   int slot;                // PROP2 / DISC slot; PROP1 uses blockIdx.y
 };
 
 int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float* last_id, float* disc_init_rec,
-                         const float* flat,
+                         float* prop_rnn_init, float* disc_rnn_init, float* rn_init_state, float* w3_prop, float* w3_disc,
+                         int w3p_off, int w3d_off, const float* flat,
                          POff po, Dims d, hipStream_t s);
 int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s);
 int sq_launch_what_disc(const float* enc, int enc_ld, const float* noise, float* rec_d, int slot, Dims d,
@@ -52,6 +56,20 @@ int sq_launch_what_prop(const float* hraw, int h_ld, const float* enc, int enc_l
                         const float* noise, float* rec_p, int slot, Dims d, hipStream_t s);
 int sq_launch_steps(const float* s1, int s1_ld, const float* flat, int w_off, int b_off, const float* rec_prev,
                     float* rec_new, const float* noise, int slot, int is_disc, Dims d, hipStream_t s);
+// Tail of a propagation / discovery slot in one launch: what-sample, the what-dependent part of the steps
+// predictor's hidden layer (small MFMA, K = 56), its output layer (dot with w2) and the presence Bernoulli.
+struct TailArgs {
+  int is_disc, slot;
+  const float* hraw; int h_ld;      // prop: raw what-head (2 nw) + gate (3 nw) pre-activations
+  const float* enc; int enc_ld;     // glimpse-encoder Gaussian (loc nw | scale nw)
+  const float* rec_prev;            // merged records of t-1
+  float* rec_new;                   // rec_p / rec_d
+  const float* noise;               // noise of frame t
+  const float* s1p; int s1p_ld;     // [R, nh/2] hidden pre-activation without the `what` term
+  const float* wp;                  // packed [nh/32 ... ] weights of the `what` rows of steps.l0 (layer *_S1)
+  const float* flat; int w2_off, b2_off;
+};
+int sq_launch_slot_tail(const TailArgs& a, Dims d, hipStream_t s);
 int sq_launch_latent_sum(const float* f, const float* rec_p, float* c, Dims d, hipStream_t s);
 
 struct LogprobArgs {

@@ -8,6 +8,9 @@
 // ------------------------------------------------------------------------------------------------
 __global__ void k_init_state(float* __restrict__ rec_m, float* __restrict__ temporal_m, float* __restrict__ prior_m,
                              float* __restrict__ last_id, float* __restrict__ disc_init_rec,
+                             float* __restrict__ prop_rnn_init, float* __restrict__ disc_rnn_init,
+                             float* __restrict__ rn_init_state, float* __restrict__ w3_prop,
+                             float* __restrict__ w3_disc, int w3p_off, int w3d_off,
                              const float* __restrict__ flat, POff po, Dims d) {
   const int rs = blockIdx.x;  // row*N + slot
   const int tid = threadIdx.x;
@@ -17,13 +20,27 @@ __global__ void k_init_state(float* __restrict__ rec_m, float* __restrict__ temp
     prior_m[(size_t)rs * d.nh + i] = flat[po.prior_init + i];
   }
   if (tid == 0 && (rs % d.N) == 0) last_id[rs / d.N] = -1.0f;
-  if (tid == 0 && rs == 0) disc_init_rec[rec::PRES] = 1.0f;
+  if (rs == 0) {  // aligned copies of the small trainable initial states (GEMM A-operand contract)
+    if (tid == 0) disc_init_rec[rec::PRES] = 1.0f;
+    for (int i = tid; i < d.nh; i += blockDim.x) {
+      prop_rnn_init[i] = flat[po.prop_rnn_init + i];
+      disc_rnn_init[i] = flat[po.disc_rnn_init + i];
+    }
+    if (tid < 4) rn_init_state[tid] = flat[po.rn_init_state + tid];
+  }
+  if (rs == 1 || (rs == 0 && d.R * d.N == 1)) {  // transform.l2 {w [nh,8], b [8]} are adjacent in the flat buffer
+    for (int i = tid; i < d.nh * 8 + 8; i += blockDim.x) {
+      w3_prop[i] = flat[w3p_off + i];
+      w3_disc[i] = flat[w3d_off + i];
+    }
+  }
 }
 
 int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float* last_id, float* disc_init_rec,
-                         const float* flat, POff po, Dims d, hipStream_t s) {
+                         float* prop_rnn_init, float* disc_rnn_init, float* rn_init_state, float* w3_prop, float* w3_disc,
+                         int w3p_off, int w3d_off, const float* flat, POff po, Dims d, hipStream_t s) {
   hipLaunchKernelGGL(k_init_state, dim3(d.R * d.N), dim3(256), 0, s, rec_m, temporal_m, prior_m, last_id, disc_init_rec,
-                     flat, po, d);
+                     prop_rnn_init, disc_rnn_init, rn_init_state, w3_prop, w3_disc, w3p_off, w3d_off, flat, po, d);
   return 0;
 }
 
@@ -52,6 +69,32 @@ __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, c
   const int mrow_add = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
   const int orow_add = a.out_row_add + (a.mode == CROP_PROP1 ? slot : 0);
 
+  // ---- transform MLP output layer (nh -> 8) evaluated here when its input is given: one wavefront per particle
+  // row, each lane owning 4 of the nh inputs, 8 wave reductions (replaces a whole dependent launch)
+  float* tp_s = tab_s + d.K * 2 * G * 2;     // K * 8
+  const bool fused_tp = a.t2 != nullptr && (a.mode == CROP_PROP2 || a.mode == CROP_DISC);
+  if (fused_tp) {
+    const int wave = tid >> 6, lane = tid & 63;
+    float wl3[32];
+    const float4* w4 = reinterpret_cast<const float4*>(a.w3) + (size_t)lane * 8;  // rows 4*lane .. 4*lane+3, 8 outputs each
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 t = (4 * lane < d.nh) ? w4[q] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+      wl3[q * 4 + 0] = t.x; wl3[q * 4 + 1] = t.y; wl3[q * 4 + 2] = t.z; wl3[q * 4 + 3] = t.w;
+    }
+    for (int kp = wave; kp < d.K; kp += 4) {
+      const int r = b * d.K + kp;
+      const float4 x = (4 * lane < d.nh) ? *reinterpret_cast<const float4*>(a.t2 + (size_t)r * a.t2_ld + 4 * lane)
+                                         : float4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        float part = x.x * wl3[o] + x.y * wl3[8 + o] + x.z * wl3[16 + o] + x.w * wl3[24 + o];
+        part = sq_wave_sum(part);
+        if (lane == 0) tp_s[kp * 8 + o] = part + a.w3[d.nh * 8 + o];
+      }
+    }
+    __syncthreads();
+  }
   // ---- the `where` logits: one thread per (particle, component), all operands requested at once
   float wl = 0.0f;
   if (tid < 4 * d.K) {
@@ -63,7 +106,7 @@ __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, c
       wl = a.rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHERE + i] +
            a.wb[((size_t)r * d.N + slot) * a.wb_ld + i] * 0.1f;
     } else {
-      const float* tp = a.tp + (size_t)r * a.tp_ld;
+      const float* tp = fused_tp ? tp_s + kp * 8 : a.tp + (size_t)r * a.tp_ld;
       const float* eps = a.noise + (((size_t)r * 2 + (a.mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
       float* rn = a.rec_new + ((size_t)r * d.N + slot) * rec::W;
       float loc, sc;
@@ -95,9 +138,32 @@ __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, c
       rn[rec::WHERE_SCALE + i] = sc;
     }
   }
-  // ---- stage the frame in LDS (one HBM read of the frame for all K particles)
+  // ---- stage the frame in LDS (one HBM read of the frame for all K particles); the mask values of this
+  // thread's pixels are requested in the same burst (unconditional, clamped loads: a guarded load makes hipcc
+  // drain vmcnt at every branch and the kernel degenerates into one memory round trip per pixel)
   const float* __restrict__ img = a.img + (size_t)b * P;
-  for (int i = tid; i < P; i += 256) img_s[i] = img[i];
+  constexpr int IPT = 10, MPT = 8;
+  const int npix = d.K * G2;
+  const bool has_mask = a.mask != nullptr;
+  const float* mbase = has_mask ? a.mask : img;
+  float mk[MPT];
+#pragma unroll
+  for (int q = 0; q < MPT; ++q) {
+    const int idx = min(tid + q * 256, npix - 1);
+    const int kp = idx / G2, pix = idx - kp * G2;
+    const size_t off = has_mask ? ((size_t)(b * d.K + kp) * a.mask_row_mul + mrow_add) * G2 + pix : 0;
+    mk[q] = mbase[off];
+  }
+  for (int base = 0; base < P; base += 256 * IPT) {
+    float v[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) v[q] = img[min(base + q * 256 + tid, P - 1)];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      const int idx = base + q * 256 + tid;
+      if (idx < P) img_s[idx] = v[q];
+    }
+  }
   if (tid < 4 * d.K) coord_s[tid] = (tid & 2) ? tanhf(wl) : fmaxf(sq_sigmoid(wl), 1e-4f);
   __syncthreads();
   // per particle: source coordinates of the G columns and G rows
@@ -114,36 +180,47 @@ __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, c
     tab_s[(kp * 2 * G + q) * 2 + 1] = x - x0;
   }
   __syncthreads();
-  for (int idx = tid; idx < d.K * G2; idx += 256) {
-    const int kp = idx / G2, pix = idx % G2;
-    const int r = b * d.K + kp;
-    float mk = 1.0f;
-    if (a.mask != nullptr) mk = a.mask[((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix];
-    const int i = pix / G, j = pix % G;
-    const float* tb = tab_s + (size_t)kp * 2 * G * 2;
-    const float x0f = tb[j * 2], wx1 = tb[j * 2 + 1];
-    const float y0f = tb[(G + i) * 2], wy1 = tb[(G + i) * 2 + 1];
-    const int x0 = (int)x0f, y0 = (int)y0f;
-    float v = 0.0f;
+  for (int base = 0; base < npix; base += 256 * MPT) {
+    if (base > 0 && has_mask) {  // more than MPT pixels per thread (K*G*G > 2048): fetch the next batch of mask values
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-      const int yy = y0 + dy;
-      const float wy = dy ? wy1 : 1.0f - wy1;
-      if (yy < 0 || yy >= d.H) continue;
-#pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        const int xx = x0 + dx;
-        const float wx = dx ? wx1 : 1.0f - wx1;
-        if (xx < 0 || xx >= d.W) continue;
-        v += wy * wx * img_s[yy * d.W + xx];
+      for (int q = 0; q < MPT; ++q) {
+        const int idx = min(base + tid + q * 256, npix - 1);
+        const int kp = idx / G2, pix = idx - kp * G2;
+        mk[q] = a.mask[((size_t)(b * d.K + kp) * a.mask_row_mul + mrow_add) * G2 + pix];
       }
     }
-    a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + pix] = v * mk;
+#pragma unroll
+    for (int q = 0; q < MPT; ++q) {
+      const int idx = base + tid + q * 256;
+      if (idx >= npix) break;
+      const int kp = idx / G2, pix = idx - kp * G2;
+      const int r = b * d.K + kp;
+      const int i = pix / G, j = pix - i * G;
+      const float* tb = tab_s + (size_t)kp * 2 * G * 2;
+      const float x0f = tb[j * 2], wx1 = tb[j * 2 + 1];
+      const float y0f = tb[(G + i) * 2], wy1 = tb[(G + i) * 2 + 1];
+      const int x0 = (int)x0f, y0 = (int)y0f;
+      float v = 0.0f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int yy = y0 + dy;
+        const float wy = dy ? wy1 : 1.0f - wy1;
+        if (yy < 0 || yy >= d.H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int xx = x0 + dx;
+          const float wx = dx ? wx1 : 1.0f - wx1;
+          if (xx < 0 || xx >= d.W) continue;
+          v += wy * wx * img_s[yy * d.W + xx];
+        }
+      }
+      a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + pix] = has_mask ? v * mk[q] : v;
+    }
   }
 }
 
 int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
-  const size_t shm = ((size_t)d.H * d.W + d.K * 4 + (size_t)d.K * 2 * d.G * 2) * sizeof(float);
+  const size_t shm = ((size_t)d.H * d.W + d.K * 4 + (size_t)d.K * 2 * d.G * 2 + d.K * 8) * sizeof(float);
   static bool big_lds = false;
   if (shm > 48 * 1024 && !big_lds) {  // 128x128 frames: 64 KiB + tables, CDNA4 has 160 KiB of LDS per CU
     hipFuncSetAttribute((const void*)k_crop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -243,6 +320,149 @@ int sq_launch_steps(const float* s1, int s1_ld, const float* flat, int w_off, in
                     float* rec_new, const float* noise, int slot, int is_disc, Dims d, hipStream_t s) {
   hipLaunchKernelGGL(k_steps, dim3((d.R + 3) / 4), dim3(256), 0, s, s1, s1_ld, flat, w_off, b_off, rec_prev, rec_new,
                      noise, slot, is_disc, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tail of one propagation / discovery slot, fused (was: what-sample kernel, a dense launch, presence kernel):
+//   what ~ N(.)           reference: sqair/core.py:336-359 (propagation, gated), :213-215 (discovery)
+//   hidden = elu(s1p + what W_what)   StepsPredictor hidden layer; the r_k / temporal-state terms of its
+//                         pre-activation (s1p) were produced by earlier launches (sqair/modules.py:506-524)
+//   logit, presence       sqair/core.py:141-144
+// One workgroup = 16 rows; 4 waves x 2 column tiles x 4 K-chunks of v_mfma_f32_16x16x4_f32 with the A operand
+// read from an LDS tile of the freshly sampled `what`.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims d) {
+  constexpr int ZLD = 68;
+  __shared__ __attribute__((aligned(16))) float zt[16 * ZLD];
+  __shared__ float rs[4][16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
+  const int row0 = blockIdx.x * 16;
+  const int nw = d.nw, nsp = d.nh / 2;
+  const int n_tiles = nsp / 16;  // 8 for nh = 256; wave w owns tiles w, w + 4, ...
+  // ---- requests that do not depend on the sample: weights, partial pre-activations, w2, Bernoulli operands
+  const f32x4_t* wp4 = reinterpret_cast<const f32x4_t*>(a.wp);
+  f32x4_t bv[2][4];
+  float sp[2][4], w2v[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int tile = min(wave + 4 * t, n_tiles - 1);
+    const int col = tile * 16 + (lane & 15);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bv[t][c] = wp4[(size_t)(tile * 4 + c) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sp[t][i] = a.s1p[(size_t)min(row0 + 4 * kq + i, d.R - 1) * a.s1p_ld + col];
+    w2v[t] = a.flat[a.w2_off + col];
+  }
+  const int pr = min(row0 + (tid & 15), d.R - 1);
+  const float b2 = a.flat[a.b2_off];
+  const float u = a.noise[(((size_t)pr * 2 + (a.is_disc ? 1 : 0)) * d.N + a.slot) * d.nzw + 4 + nw];
+  const float* prevp = a.is_disc ? (a.slot == 0 ? &a.flat[a.b2_off] : a.rec_new + ((size_t)pr * d.N + a.slot - 1) * rec::W + rec::PRES)
+                                 : a.rec_prev + ((size_t)pr * d.N + a.slot) * rec::W + rec::PRES;
+  float prev = *prevp;
+  if (a.is_disc && a.slot == 0) prev = 1.0f;
+  // ---- what sample for the 16 rows (nw elements each), operands requested in one burst
+  constexpr int EPT = 4;
+  const int nel = 16 * nw;
+  float v_loc[EPT], v_sc[EPT], v_eps[EPT], v_h[EPT][5], v_tm1[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int e = min(tid + 256 * q, nel - 1);
+    const int rr = e / nw, c = e - rr * nw;
+    const int r = min(row0 + rr, d.R - 1);
+    v_loc[q] = a.enc[(size_t)r * a.enc_ld + c];
+    v_sc[q] = a.enc[(size_t)r * a.enc_ld + nw + c];
+    v_eps[q] = a.noise[(((size_t)r * 2 + (a.is_disc ? 1 : 0)) * d.N + a.slot) * d.nzw + 4 + c];
+    if (!a.is_disc) {
+      const float* hr = a.hraw + (size_t)r * a.h_ld;
+#pragma unroll
+      for (int g = 0; g < 5; ++g) v_h[q][g] = hr[g * nw + c];
+      v_tm1[q] = a.rec_prev[((size_t)r * d.N + a.slot) * rec::W + rec::WHAT + c];
+    } else {
+#pragma unroll
+      for (int g = 0; g < 5; ++g) v_h[q][g] = 0.0f;
+      v_tm1[q] = 0.0f;
+    }
+  }
+  for (int i = tid; i < 16 * ZLD; i += 256) {  // everything but the `what` columns of the tile is zero
+    const int c = i % ZLD;
+    if (c < rec::WHAT || c >= rec::WHAT + nw) zt[i] = 0.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int e = tid + 256 * q;
+    if (e < nel) {
+      const int rr = e / nw, c = e - rr * nw;
+      float loc, sc;
+      if (a.is_disc) {
+        loc = v_loc[q];
+        sc = v_sc[q];
+      } else {
+        const float t_loc = v_h[q][0];
+        const float t_scale = sq_softplus(v_h[q][1]) + 1e-2f;
+        const float fg = sq_sigmoid(v_h[q][2]) * 0.9999f;
+        const float ig = sq_sigmoid(v_h[q][3]) * 0.9999f;
+        const float tg = sq_sigmoid(v_h[q][4]) * 0.9999f;
+        loc = fg * v_tm1[q] + (1.0f - ig) * v_loc[q] + (1.0f - tg) * t_loc;
+        sc = (1.0f - ig) * v_sc[q] + (1.0f - tg) * t_scale;
+      }
+      const float what = loc + sc * v_eps[q];
+      zt[rr * ZLD + rec::WHAT + c] = what;
+      if (row0 + rr < d.R) {
+        float* rn = a.rec_new + ((size_t)(row0 + rr) * d.N + a.slot) * rec::W;
+        rn[rec::WHAT + c] = what;
+        rn[rec::WHAT_LOC + c] = loc;
+        rn[rec::WHAT_SCALE + c] = sc;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- hidden layer: acc = what W_what  (K = 56 padded to 64)
+  f32x4_t acc[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const f32x4_t av = *reinterpret_cast<const f32x4_t*>(&zt[(lane & 15) * ZLD + 16 * c + 4 * kq]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[t][c].x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[t][c].y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[t][c].z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[t][c].w, acc[t], 0, 0, 0);
+    }
+  }
+  // ---- output layer: sum over the nh/2 hidden units of elu(.) * w2; lane holds rows 4 kq + i, one column per tile
+  float part[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float v = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (wave + 4 * t < n_tiles) v += sq_elu(acc[t][i] + sp[t][i]) * w2v[t];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    part[i] = v;
+  }
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rs[wave][4 * kq + i] = part[i];
+  }
+  __syncthreads();
+  if (tid < 16 && row0 + tid < d.R) {
+    const float raw = rs[0][tid] + rs[1][tid] + rs[2][tid] + rs[3][tid] + b2;
+    const float logit = prev * raw + (prev - 1.0f) * 88.0f;
+    const float prob = sq_sigmoid(logit);
+    float* rn = a.rec_new + ((size_t)(row0 + tid) * d.N + a.slot) * rec::W;
+    rn[rec::PRES] = (u < prob ? 1.0f : 0.0f) * prev;
+    rn[rec::LOGIT] = logit;
+    rn[rec::PROB] = prob;
+  }
+}
+int sq_launch_slot_tail(const TailArgs& a, Dims d, hipStream_t s) {
+  hipLaunchKernelGGL(k_slot_tail, dim3((d.R + 15) / 16), dim3(256), 0, s, a, d);
   return 0;
 }
 

@@ -56,140 +56,158 @@ int sq_launch_pack_bias(const float* flat, float* packed_b, const int* idxa, con
   return 0;
 }
 
-__device__ __forceinline__ f32x4 load_a4(const float* __restrict__ rowp, int kk, int width, bool vec) {
-  f32x4 a;
-  if (vec && kk + 4 <= width) {
-    a = *reinterpret_cast<const f32x4*>(rowp + kk);
-  } else {
-    a.x = kk + 0 < width ? rowp[kk + 0] : 0.0f;
-    a.y = kk + 1 < width ? rowp[kk + 1] : 0.0f;
-    a.z = kk + 2 < width ? rowp[kk + 2] : 0.0f;
-    a.w = kk + 3 < width ? rowp[kk + 3] : 0.0f;
-  }
-  return a;
-}
+// ---------------------------------------------------------------------------------------------------
+// A-operand contract (checked on the host in sq_launch_linear): every segment base is 16-byte aligned,
+// its row stride a multiple of 4 floats, and round_up(width, 4) floats of each row are readable and
+// FINITE.  The kernel then needs no guards at all: a lane whose 4 k-positions fall beyond the segment
+// width re-reads the last valid float4 of the row (address clamp) and the packed weights there are
+// zero.  Guarded / scalar tail loads made hipcc fence every chunk with s_waitcnt vmcnt(0), turning one
+// memory round trip into one per chunk (measured 5.5 us per launch, all of it latency).
+// ---------------------------------------------------------------------------------------------------
 
-// D = K-chunks per wave whose operand loads are issued before the first MFMA.  The layers of this model are
-// latency-bound (measured: ~1 us per dependent global access, activations come from another XCD's writes), so the
-// kernel is organised as ONE memory round trip: epilogue operands (bias, partial sums, GRU state) and every A / B
-// fragment of the wave are requested up front, then the MFMAs drain them in order.
-constexpr int LIN_D = 10;
+// (SQ_ROWTILE_XCD_AFFINITY was measured: -0.3 us with L2-resident weights, +0.4 us once the weights of a whole
+// frame rotate through L2; left off.  tools/linear_floor.hip reproduces both numbers.)
+#define SQ_KLINEAR_NAME k_linear
+#include "sqair_linear_kernel.inc"
+#undef SQ_KLINEAR_NAME
 
-__global__ __launch_bounds__(256) void k_linear(const LinArgs a, const int kc_total, const int n_tiles,
-                                                unsigned long long* __restrict__ prof_ts) {
-  __shared__ float red[4 * 256];
+// ---------------------------------------------------------------------------------------------------
+// Throughput variant for the batched (M = B'*N = 640-row) layers that run once per frame: the 4 waves of a
+// workgroup take 4 consecutive 16-row tiles against the SAME 16-column weight slab (one fetch of the slab
+// per workgroup through L1 instead of four, no split-K, no LDS), each wave walking all K-chunks in blocks
+// of NCH with every load of a block in flight at once.
+// ---------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int kc_total, const int n_tiles,
+                                                     unsigned long long* __restrict__ prof_ts) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
   const int tile_n = blockIdx.x % n_tiles;
-  const int tile_m = blockIdx.x / n_tiles;
+  const int tile_m = (blockIdx.x / n_tiles) * 4 + wave;
   const int arow = min(tile_m * 16 + (lane & 15), a.M - 1);
   const int kq = lane >> 4;
   unsigned long long t_start = 0;
   if (prof_ts != nullptr && tid == 0) t_start = wall_clock64();
 
-  // ---- epilogue operands, requested first
-  const int m = tile_m * 16 + (tid >> 4);
-  const int n = tile_n * 16 + (tid & 15);
-  const bool live = m < a.M && n < a.N;
-  float p_bias = 0.0f, p_add = 0.0f, p_e0 = 0.0f, p_e1 = 0.0f, p_scale = 1.0f;
-  if (live) {
-    p_bias = a.bias[n];
-    if (a.add != nullptr && n < a.add_n) p_add = a.add[(size_t)(m / a.add_rdiv) * a.add_ld + n];
-    if (a.epi == EPI_GRU1) {
-      if (n >= a.nh && n < 2 * a.nh) p_e0 = a.e0[(size_t)m * a.e0_ld + (n - a.nh)];
-    } else if (a.epi == EPI_GRU2) {
-      p_e0 = a.e0[(size_t)m * a.e0_ld + n];
-      p_e1 = a.e1[(size_t)m * a.e1_ld + n];
-    } else if (a.scale_ptr != nullptr) {
-      p_scale = a.scale_ptr[0];
-    }
-  }
-
-  // ---- segment table (chunk ranges are wave-uniform)
-  int cum[5];
-  const float* rowp[4];
-  int width[4];
-  bool vec[4];
-  cum[0] = 0;
+  // epilogue operands of the 4 outputs of this lane: rows 4*kq + i, column lane & 15
+  const int n = tile_n * 16 + (lane & 15);
+  const int nc = min(n, a.N - 1);
+  const float* pb = a.bias + nc;
+  const bool use_add = a.add != nullptr && nc < a.add_n;
+  const bool g1 = a.epi == EPI_GRU1 && nc >= a.nh && nc < 2 * a.nh;
+  const bool g2 = a.epi == EPI_GRU2;
+  const float p_bias = *pb;
+  float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : pb);
+  p_scale = a.scale_ptr != nullptr ? p_scale : 1.0f;
+  float p_add[4], p_e0[4], p_e1[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    if (s < a.nseg) {
-      const LinSeg sg = a.seg[s];
-      cum[s + 1] = cum[s] + ((sg.width + 15) >> 4);
-      rowp[s] = sg.p + (size_t)(arow / sg.rdiv) * sg.ld;
-      width[s] = sg.width;
-      vec[s] = ((reinterpret_cast<uintptr_t>(sg.p) & 15) == 0) && ((sg.ld & 3) == 0);
-    } else {
-      cum[s + 1] = 0x7fffffff;
-      rowp[s] = a.seg[0].p;
-      width[s] = 0;
-      vec[s] = false;
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int mc = min(tile_m * 16 + 4 * kq + i, a.M - 1);
+    const float* pa = use_add ? a.add + (size_t)(mc / a.add_rdiv) * a.add_ld + nc : pb;
+    const float* pe0 = g1 ? a.e0 + (size_t)mc * a.e0_ld + (nc - a.nh) : (g2 ? a.e0 + (size_t)mc * a.e0_ld + nc : pb);
+    const float* pe1 = g2 ? a.e1 + (size_t)mc * a.e1_ld + nc : pb;
+    p_add[i] = *pa;
+    p_e0[i] = *pe0;
+    p_e1[i] = *pe1;
   }
 
+  int cum1 = 0x7fffffff, cum2 = 0x7fffffff, cum3 = 0x7fffffff;
+  const float* rp0 = a.seg[0].p + (size_t)(arow / a.seg[0].rdiv) * a.seg[0].ld;
+  const float* rp1 = rp0; const float* rp2 = rp0; const float* rp3 = rp0;
+  int lim0 = ((a.seg[0].width + 3) & ~3) - 4, lim1 = 0, lim2 = 0, lim3 = 0;
+  {
+    int c = (a.seg[0].width + 15) >> 4;
+    if (a.nseg > 1) { cum1 = c; c += (a.seg[1].width + 15) >> 4; rp1 = a.seg[1].p + (size_t)(arow / a.seg[1].rdiv) * a.seg[1].ld; lim1 = ((a.seg[1].width + 3) & ~3) - 4; }
+    if (a.nseg > 2) { cum2 = c; c += (a.seg[2].width + 15) >> 4; rp2 = a.seg[2].p + (size_t)(arow / a.seg[2].rdiv) * a.seg[2].ld; lim2 = ((a.seg[2].width + 3) & ~3) - 4; }
+    if (a.nseg > 3) { cum3 = c; rp3 = a.seg[3].p + (size_t)(arow / a.seg[3].rdiv) * a.seg[3].ld; lim3 = ((a.seg[3].width + 3) & ~3) - 4; }
+  }
   f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
   const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
-  const int nmine = (kc_total - wave + 3) >> 2;  // this wave owns global chunks g = wave + 4 i
+  const f32x4* __restrict__ wz = reinterpret_cast<const f32x4*>(a.wzero) + lane;
 #pragma unroll 1
-  for (int base = 0; base < nmine; base += LIN_D) {
-    f32x4 av[LIN_D], bv[LIN_D];
+  for (int base = 0; base < kc_total; base += NCH) {
+    f32x4 av[NCH], bv[NCH];
 #pragma unroll
-    for (int j = 0; j < LIN_D; ++j) {
-      if (base + j < nmine) {
-        const int g = wave + 4 * (base + j);
-        const int s = (g >= cum[1] ? 1 : 0) + (g >= cum[2] ? 1 : 0) + (g >= cum[3] ? 1 : 0);
-        const int c = g - cum[s];
-        av[j] = load_a4(rowp[s], c * 16 + kq * 4, width[s], vec[s]);
-        bv[j] = wp[(size_t)g * 64];
-      }
+    for (int j = 0; j < NCH; ++j) {
+      const bool valid = base + j < kc_total;
+      const int g = valid ? base + j : 0;
+      const bool s1 = g >= cum1, s2 = g >= cum2, s3 = g >= cum3;
+      const float* rp = s3 ? rp3 : (s2 ? rp2 : (s1 ? rp1 : rp0));
+      const int cb = s3 ? cum3 : (s2 ? cum2 : (s1 ? cum1 : 0));
+      const int lim = s3 ? lim3 : (s2 ? lim2 : (s1 ? lim1 : lim0));
+      av[j] = *reinterpret_cast<const f32x4*>(rp + min((g - cb) * 16 + kq * 4, lim));
+      bv[j] = *(valid ? wp + (size_t)g * 64 : wz);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < LIN_D; ++j) {
-      if (base + j < nmine) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
-      }
+    for (int j = 0; j < NCH; ++j) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
     }
   }
-
-  // split-K reduction: acc[i] of lane l is C[row = 4*(l>>4) + i][col = l & 15]
-  float* r = red + wave * 256;
-  r[(4 * kq + 0) * 16 + (lane & 15)] = acc0.x + acc1.x;
-  r[(4 * kq + 1) * 16 + (lane & 15)] = acc0.y + acc1.y;
-  r[(4 * kq + 2) * 16 + (lane & 15)] = acc0.z + acc1.z;
-  r[(4 * kq + 3) * 16 + (lane & 15)] = acc0.w + acc1.w;
-  __syncthreads();
-  if (live) {
-    float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + p_bias + p_add;
-    if (a.epi == EPI_ACT) {
-      v = sq_act(v, n < a.act_split ? a.act_a : a.act_b);
-      a.out[(size_t)m * a.out_ld + n] = v * a.scale * p_scale;
-    } else if (a.epi == EPI_GRU1) {
-      // columns [z | r | x W_h + b_h]   (snt.GRU)
-      const int nh = a.nh;
-      if (n < nh) a.out[(size_t)m * a.out_ld + n] = sq_sigmoid(v);
-      else if (n < 2 * nh) a.o1[(size_t)m * a.o1_ld + (n - nh)] = sq_sigmoid(v) * p_e0;
-      else a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
-    } else {  // EPI_GRU2: h' = (1 - z) h + z tanh(x W_h + (r h) U_h + b_h)
-      a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1) * p_e0 + p_e1 * tanhf(v);
+  const float accv[4] = {acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = tile_m * 16 + 4 * kq + i;
+    if (m < a.M && n < a.N) {
+      float v = accv[i] + p_bias + (use_add ? p_add[i] : 0.0f);
+      if (a.epi == EPI_ACT) {
+        v = sq_act(v, n < a.act_split ? a.act_a : a.act_b);
+        a.out[(size_t)m * a.out_ld + n] = v * a.scale * p_scale;
+      } else if (a.epi == EPI_GRU1) {
+        const int nh = a.nh;
+        if (n < nh) a.out[(size_t)m * a.out_ld + n] = sq_sigmoid(v);
+        else if (n < 2 * nh) a.o1[(size_t)m * a.o1_ld + (n - nh)] = sq_sigmoid(v) * p_e0[i];
+        else a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
+      } else {
+        a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1[i]) * p_e0[i] + p_e1[i] * tanhf(v);
+      }
     }
   }
   if (prof_ts != nullptr) {
     __syncthreads();
     if (tid == 0) {
       atomicMin(prof_ts, t_start);
-      atomicMax(prof_ts + 4096, wall_clock64());  // end slots follow the PROF_MAX start slots
+      atomicMax(prof_ts + 4096, wall_clock64());
     }
   }
+}
+
+template <int NCH>
+static void launch_nch(const LinArgs& a, const PackedLayer& L, int grid, hipStream_t s, unsigned long long* prof_ts) {
+  hipLaunchKernelGGL(k_linear<NCH>, dim3(grid), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
 }
 
 int sq_launch_linear(const LinArgs& a, const PackedLayer& L, hipStream_t s, unsigned long long* prof_ts) {
   const int mt = (a.M + 15) / 16;
   const int grid = mt * L.nt;
   if (grid <= 0) return 0;
-  hipLaunchKernelGGL(k_linear, dim3(grid), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+  for (int i = 0; i < a.nseg; ++i) {  // A-operand contract
+    const LinSeg& sg = a.seg[i];
+    if ((reinterpret_cast<uintptr_t>(sg.p) & 15) != 0 || (sg.ld & 3) != 0 || sg.width < 1 || sg.rdiv < 1) return -5;
+  }
+  if (a.M >= 256 && L.kc * L.nt >= 400 && L.kc <= 32) {  // big batched once-per-frame layers: throughput variant
+    const int grid_r = ((mt + 3) / 4) * L.nt;
+    if (L.kc <= 4) hipLaunchKernelGGL(k_linear_rows<4>, dim3(grid_r), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+    else if (L.kc <= 8) hipLaunchKernelGGL(k_linear_rows<8>, dim3(grid_r), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+    else hipLaunchKernelGGL(k_linear_rows<12>, dim3(grid_r), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+    return 0;
+  }
+  const int per_wave = (L.kc + 3) / 4;
+  switch (per_wave) {
+    case 1: launch_nch<1>(a, L, grid, s, prof_ts); break;
+    case 2: launch_nch<2>(a, L, grid, s, prof_ts); break;
+    case 3: launch_nch<3>(a, L, grid, s, prof_ts); break;
+    case 4: launch_nch<4>(a, L, grid, s, prof_ts); break;
+    case 5: launch_nch<5>(a, L, grid, s, prof_ts); break;
+    case 6: launch_nch<6>(a, L, grid, s, prof_ts); break;
+    case 7: launch_nch<7>(a, L, grid, s, prof_ts); break;
+    case 8: launch_nch<8>(a, L, grid, s, prof_ts); break;
+    case 9: launch_nch<9>(a, L, grid, s, prof_ts); break;
+    default: launch_nch<10>(a, L, grid, s, prof_ts); break;  // deeper K: blocks of 10 chunks per wave
+  }
   return 0;
 }

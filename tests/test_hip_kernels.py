@@ -35,7 +35,7 @@ def test_linear_mfma_matches_fp64(handle, M, K, N, act):
     w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(N).astype(np.float32)
     y = torch.zeros(M, N, device="cuda")
-    scratch = torch.empty(4 * ((K + 15) // 16) * ((N + 15) // 16) * 256 + 4096, dtype=torch.float32, device="cuda")
+    scratch = torch.empty(4 * ((K + 15) // 16) * ((N + 15) // 16) * 256 + 8192 + M * (K + 4), dtype=torch.float32, device="cuda")
     dx, dw, db = dev(x), dev(w), dev(b)  # keep alive: a temporary's block is recycled by the caching allocator
     rc = lib.sqair_linear_test(h, dx.data_ptr(), dw.data_ptr(), db.data_ptr(), y.data_ptr(), M, K, N, act,
                                scratch.data_ptr(), scratch.numel() * 4, stream())
