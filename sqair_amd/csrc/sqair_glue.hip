@@ -69,6 +69,25 @@ __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, c
   const int mrow_add = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
   const int orow_add = a.out_row_add + (a.mode == CROP_PROP1 ? slot : 0);
 
+  // ---- stage the frame in LDS (one HBM read of the frame for all K particles); the mask values of this
+  // thread's pixels are requested in the same burst (unconditional, clamped loads: a guarded load makes hipcc
+  // drain vmcnt at every branch and the kernel degenerates into one memory round trip per pixel)
+  const float* __restrict__ img = a.img + (size_t)b * P;
+  constexpr int IPT = 10, MPT = 8;
+  const int npix = d.K * G2;
+  const bool has_mask = a.mask != nullptr;
+  const float* mbase = has_mask ? a.mask : img;
+  float mk[MPT];
+#pragma unroll
+  for (int q = 0; q < MPT; ++q) {
+    const int idx = min(tid + q * 256, npix - 1);
+    const int kp = idx / G2, pix = idx - kp * G2;
+    const size_t off = has_mask ? ((size_t)(b * d.K + kp) * a.mask_row_mul + mrow_add) * G2 + pix : 0;
+    mk[q] = mbase[off];
+  }
+  float v0[IPT];  // first (for 50x50: only) batch of frame pixels of this thread, requested before anything else
+#pragma unroll
+  for (int q = 0; q < IPT; ++q) v0[q] = img[min(q * 256 + tid, P - 1)];
   // ---- transform MLP output layer (nh -> 8) evaluated here when its input is given: one wavefront per particle
   // row, each lane owning 4 of the nh inputs, 8 wave reductions (replaces a whole dependent launch)
   float* tp_s = tab_s + d.K * 2 * G * 2;     // K * 8
@@ -138,23 +157,12 @@ __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, c
       rn[rec::WHERE_SCALE + i] = sc;
     }
   }
-  // ---- stage the frame in LDS (one HBM read of the frame for all K particles); the mask values of this
-  // thread's pixels are requested in the same burst (unconditional, clamped loads: a guarded load makes hipcc
-  // drain vmcnt at every branch and the kernel degenerates into one memory round trip per pixel)
-  const float* __restrict__ img = a.img + (size_t)b * P;
-  constexpr int IPT = 10, MPT = 8;
-  const int npix = d.K * G2;
-  const bool has_mask = a.mask != nullptr;
-  const float* mbase = has_mask ? a.mask : img;
-  float mk[MPT];
 #pragma unroll
-  for (int q = 0; q < MPT; ++q) {
-    const int idx = min(tid + q * 256, npix - 1);
-    const int kp = idx / G2, pix = idx - kp * G2;
-    const size_t off = has_mask ? ((size_t)(b * d.K + kp) * a.mask_row_mul + mrow_add) * G2 + pix : 0;
-    mk[q] = mbase[off];
+  for (int q = 0; q < IPT; ++q) {
+    const int idx = q * 256 + tid;
+    if (idx < P) img_s[idx] = v0[q];
   }
-  for (int base = 0; base < P; base += 256 * IPT) {
+  for (int base = 256 * IPT; base < P; base += 256 * IPT) {  // frames larger than 2560 pixels
     float v[IPT];
 #pragma unroll
     for (int q = 0; q < IPT; ++q) v[q] = img[min(base + q * 256 + tid, P - 1)];

@@ -92,6 +92,18 @@ int main() {
   RUN("full, 40 WG (M=160, N=64)", k_full, 160, 4, false);
   RUN("full, 16 WG (M=16, N=256)", k_full, 16, 16, false);
   RUN("full, 640 WG (M=640)", k_full, 640, 16, true);
+  // instruction-cache pressure: rotate through differently-instantiated copies of the same kernel
+  {
+    typedef void (*KF)(const LinArgs, const int, const int, unsigned long long*);
+    KF ks[] = {k_full<4>, k_full<5>, k_full<6>, k_full<7>, k_full<8>, k_full<9>, k_full<10>, k_noepi<4>, k_noepi<5>, k_noepi<6>,
+               k_noepi<7>, k_noepi<8>, k_nob<4>, k_nob<5>, k_nob<6>, k_nob<7>, k_aff<4>, k_aff<5>, k_aff<6>, k_aff<7>};
+    for (int nk : {1, 4, 8, 12, 20}) {
+      char nm[64]; snprintf(nm, 64, "rotating %d kernel instantiations", nk);
+      printf("%-34s %.2f us/node\n", nm, time_graph(s, NODES, REPS, [&](int i) {
+        LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);
+        hipLaunchKernelGGL(ks[i % nk], dim3(160), dim3(256), 0, s, a, kc, 16, (unsigned long long*)nullptr); }));
+    }
+  }
   for (int L : {1, 16, 64}) {
     char nm[64]; snprintf(nm, 64, "row-tile XCD affinity, %d w mats", L);
     printf("%-34s %.2f us/node\n", nm, time_graph(s, NODES, REPS, [&](int i) {
