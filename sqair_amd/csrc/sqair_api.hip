@@ -506,14 +506,14 @@ extern "C" int sqair_pack_params(SqairHandle* h, const float* flat, void* packed
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
   float *ienc_a, *ienc_b, *pre_disc;
-  float *rec_m[2], *temporal_m[2], *prior_m[2], *last_id[2];
-  float *rec_p, *rec_d, *zero_rec, *disc_init_rec;
+  float *rec_m_all, *temporal_m[2], *prior_m[2], *last_id[2];  // rec_m_all: [T+1][M][168] merged records per frame
+  float *rec_p_all, *rec_d_all, *zero_rec, *disc_init_rec;      // [T][M][168] propagation / discovery records
   float *prop_rnn_init, *disc_rnn_init, *rn_init_state;  // 16-byte aligned copies of small parameter vectors
   float *temporal_p, *prior_p;
   float *gz, *grh, *gxh;
   float *pstats, *hid1, *wb, *mask, *g1, *ea, *eb, *m1, *pre;
   float *rbuf[2], *t1, *t2, *tp, *g2, *enc, *hraw, *s1, *e1, *e2, *w3_prop, *w3_disc;
-  float *c, *pre_d, *spre, *qz, *pz, *dlp, *dll, *glimpse;
+  float *c, *pre_d, *spre, *qz, *pz, *dlp, *dll, *glimpse, *dec_a, *dec_b;
   unsigned long long* prof_ts;  // [2][PROF_MAX] start / end ticks of profiled k_linear launches
   int64_t total;  // floats
 };
@@ -535,14 +535,14 @@ static Workspace carve(const SqairHandle* h, int T, int B, float* base) {
   w.ienc_a = take((int64_t)T * B * nh);
   w.ienc_b = take((int64_t)T * B * nh);
   w.pre_disc = take((int64_t)T * B * nh);
+  w.rec_m_all = take((int64_t)(T + 1) * M * rec::W);
   for (int i = 0; i < 2; ++i) {
-    w.rec_m[i] = take(M * rec::W);
     w.temporal_m[i] = take(M * nh);
     w.prior_m[i] = take(M * nh);
     w.last_id[i] = take(R);
   }
-  w.rec_p = take(M * rec::W);
-  w.rec_d = take(M * rec::W);
+  w.rec_p_all = take((int64_t)T * M * rec::W);
+  w.rec_d_all = take((int64_t)T * M * rec::W);
   w.zero_rec = take(rec::W);
   w.disc_init_rec = take(rec::W);
   w.prop_rnn_init = take(nh);
@@ -553,7 +553,7 @@ static Workspace carve(const SqairHandle* h, int T, int B, float* base) {
   w.gz = take(M * nh);
   w.grh = take(M * nh);
   w.gxh = take(M * nh);
-  w.pstats = take(M * PS_LD);
+  w.pstats = take((int64_t)T * M * PS_LD);
   w.hid1 = take(M * 256);
   w.wb = take(M * WB_LD);
   w.mask = take(M * G2);
@@ -577,12 +577,14 @@ static Workspace carve(const SqairHandle* h, int T, int B, float* base) {
   w.s1 = take(R * 128);
   w.c = take(R * nh);
   w.pre_d = take(R * nh);
-  w.spre = take(R * 128);
-  w.qz = take(R);
-  w.pz = take(R);
-  w.dlp = take(R);
-  w.dll = take(R);
-  w.glimpse = take(M * G2);
+  w.spre = take((int64_t)T * R * 128);
+  w.qz = take((int64_t)T * R);
+  w.pz = take((int64_t)T * R);
+  w.dlp = take((int64_t)T * R);
+  w.dll = take((int64_t)T * R);
+  w.glimpse = take((int64_t)T * M * G2);
+  w.dec_a = take((int64_t)T * M * nh);
+  w.dec_b = take((int64_t)T * M * nh);
   w.prof_ts = (unsigned long long*)take(2 * PROF_MAX * 2);
   w.total = o;
   return w;
@@ -687,7 +689,7 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
   // clear the caller's (garbage) workspace once per pass, ~15 MB = a few microseconds
   SQ_CHECK_HIP(hipMemsetAsync(wsbase, 0, (size_t)((float*)w.prof_ts - wsbase) * 4, s));
   // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
-  sq_launch_init_state(w.rec_m[0], w.temporal_m[0], w.prior_m[0], w.last_id[0], w.disc_init_rec, w.prop_rnn_init,
+  sq_launch_init_state(w.rec_m_all, w.temporal_m[0], w.prior_m[0], w.last_id[0], w.disc_init_rec, w.prop_rnn_init,
                        w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc, (int)P(h, "prop.transform.l2.w"),
                        (int)P(h, "disc.transform.l2.w"), flat, po, d, s);
   {  // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
@@ -700,7 +702,12 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
     const int pp = t & 1, pn = pp ^ 1;
     const float* img = obs + (size_t)t * B * P_;
     const float* nz = noise + (size_t)t * R * 2 * N * nzw;
-    const float* rec_prev = w.rec_m[pp];
+    const float* rec_prev = w.rec_m_all + (size_t)t * M * RW;
+    float* rec_next = w.rec_m_all + (size_t)(t + 1) * M * RW;
+    float* rec_p_t = w.rec_p_all + (size_t)t * M * RW;
+    float* rec_d_t = w.rec_d_all + (size_t)t * M * RW;
+    float* pstats_t = w.pstats + (size_t)t * M * PS_LD;
+    float* spre_t = w.spre + (size_t)t * R * 128;
     const float* temporal_prev = w.temporal_m[pp];
     const float* prior_prev = w.prior_m[pp];
 
@@ -711,7 +718,7 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
       RUN(g1, L_PRIOR_GRU1, M);
       Lin g2; g2.seg(w.grh, nh, nh).add(w.gxh, nh, nh).out(w.prior_p, nh).gru2(prior_prev, nh, w.gz, nh, nh);
       RUN(g2, L_PRIOR_GRU2, M);
-      Lin pl; pl.seg(w.prior_p, nh, nh).out(w.pstats, PS_LD); RUN(pl, L_PRIOR_LIN, M);
+      Lin pl; pl.seg(w.prior_p, nh, nh).out(pstats_t, PS_LD); RUN(pl, L_PRIOR_LIN, M);
     }
     // ---- B. where-bias MLP and glimpse-mask MLP of every slot (core.py:292, modules.py:350-356) ----
     {
@@ -742,7 +749,7 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
       {
         Lin a;
         if (k == 0) a.seg(w.zero_rec, 0, rec::ZW).seg(w.prop_rnn_init, 0, nh);
-        else a.seg(w.rec_p + (size_t)(k - 1) * RW, N * RW, rec::ZW).seg(w.rbuf[(k - 1) & 1], nh, nh);
+        else a.seg(rec_p_t + (size_t)(k - 1) * RW, N * RW, rec::ZW).seg(w.rbuf[(k - 1) & 1], nh, nh);
         a.add(pre_k, pre_rld, nh).out(r_k, nh).act(ACT_TANH);
         RUN(a, L_PROP_RNN, R);
       }
@@ -756,7 +763,7 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
       {
         CropArgs ca; memset(&ca, 0, sizeof(ca));
         ca.mode = CROP_PROP2; ca.img = img; ca.mask = c.masked_glimpse ? w.mask : nullptr; ca.mask_row_mul = N;
-        ca.mask_row_add = k; ca.out = w.g2; ca.out_row_mul = 1; ca.rec_prev = rec_prev; ca.rec_new = w.rec_p;
+        ca.mask_row_add = k; ca.out = w.g2; ca.out_row_mul = 1; ca.rec_prev = rec_prev; ca.rec_new = rec_p_t;
         ca.t2 = w.t2; ca.t2_ld = nh; ca.w3 = w.w3_prop; ca.noise = nz; ca.flat = flat; ca.slot = k;
         sq_launch_crop(ca, po, d, 1, s);
       }
@@ -767,7 +774,7 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
       }
       {
         const float* tau_k = temporal_prev + (size_t)k * nh;
-        Lin g1; g1.seg(r_k, nh, nh).seg(w.rec_p + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(w.enc, ENC_LD, 2 * nw)
+        Lin g1; g1.seg(r_k, nh, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(w.enc, ENC_LD, 2 * nw)
                   .add(pre_k + 2 * nh + nh / 2, pre_rld, 2 * nh).out(w.gz, nh)
                   .gru1(tau_k, N * nh, w.grh, nh, w.gxh, nh, nh);
         RUN(g1, L_PROP_GRU1, R);
@@ -779,7 +786,7 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
       {
         TailArgs ta; memset(&ta, 0, sizeof(ta));
         ta.is_disc = 0; ta.slot = k; ta.hraw = w.hraw; ta.h_ld = HRAW_LD; ta.enc = w.enc; ta.enc_ld = ENC_LD;
-        ta.rec_prev = rec_prev; ta.rec_new = w.rec_p; ta.noise = nz; ta.s1p = w.t1 + nh; ta.s1p_ld = t1ld;
+        ta.rec_prev = rec_prev; ta.rec_new = rec_p_t; ta.noise = nz; ta.s1p = w.t1 + nh; ta.s1p_ld = t1ld;
         ta.wp = packed + packed_layout(h).w + h->layers[L_PROP_S1].w_off; ta.flat = flat;
         ta.w2_off = po.prop_steps_l1_w; ta.b2_off = po.prop_steps_l1_b;
         sq_launch_slot_tail(ta, d, s);
@@ -787,12 +794,12 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
     }
     // ---- F. summary of propagated latents -> discovery conditioning (sqair_modules.py:368-385, :501) ----
     {
-      Lin a; a.seg(w.rec_p, RW, rec::ZW).out(w.ea, nh).act(ACT_ELU); RUN(a, L_LAT0, M);
+      Lin a; a.seg(rec_p_t, RW, rec::ZW).out(w.ea, nh).act(ACT_ELU); RUN(a, L_LAT0, M);
       Lin b; b.seg(w.ea, nh, nh).out(w.eb, nh).act(ACT_ELU); RUN(b, L_LAT1, M);
-      sq_launch_latent_sum(w.eb, w.rec_p, w.c, d, s);
+      sq_launch_latent_sum(w.eb, rec_p_t, w.c, d, s);
       Lin p; p.seg(w.c, nh, nh).add(w.pre_disc + (size_t)t * B * nh, nh, nh, K).out(w.pre_d, nh); RUN(p, L_PRED, R);
       if (c.rec_where_prior) {
-        Lin q; q.seg(w.rn_init_state, 0, 4).seg(w.c, nh, nh).out(w.spre, 128); RUN(q, L_RNCOND, R);
+        Lin q; q.seg(w.rn_init_state, 0, 4).seg(w.c, nh, nh).out(spre_t, 128); RUN(q, L_RNCOND, R);
       }
     }
     // ---- G. discovery steps (sqair_modules.py:129-147 static_rnn over DiscoveryCore) ----
@@ -801,7 +808,7 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
       {
         Lin a;
         if (j == 0) a.seg(w.disc_init_rec, 0, rec::ZW).seg(w.disc_rnn_init, 0, nh);
-        else a.seg(w.rec_d + (size_t)(j - 1) * RW, N * RW, rec::ZW).seg(w.rbuf[(j - 1) & 1], nh, nh);
+        else a.seg(rec_d_t + (size_t)(j - 1) * RW, N * RW, rec::ZW).seg(w.rbuf[(j - 1) & 1], nh, nh);
         a.add(w.pre_d, nh, nh).out(r_j, nh).act(ACT_TANH);
         RUN(a, L_DISC_RNN, R);
         const int t1ld = nh + nh / 2;
@@ -810,7 +817,7 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
       }
       {
         CropArgs ca; memset(&ca, 0, sizeof(ca));
-        ca.mode = CROP_DISC; ca.img = img; ca.out = w.g2; ca.out_row_mul = 1; ca.rec_new = w.rec_d; ca.t2 = w.t2;
+        ca.mode = CROP_DISC; ca.img = img; ca.out = w.g2; ca.out_row_mul = 1; ca.rec_new = rec_d_t; ca.t2 = w.t2;
         ca.t2_ld = nh; ca.w3 = w.w3_disc; ca.noise = nz; ca.flat = flat; ca.slot = j;
         sq_launch_crop(ca, po, d, 1, s);
         Lin a; a.seg(w.g2, G2, G2).out(w.e1, nh).act(ACT_ELU); RUN(a, L_GENC0, R);
@@ -819,39 +826,46 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
       }
       {
         TailArgs ta; memset(&ta, 0, sizeof(ta));
-        ta.is_disc = 1; ta.slot = j; ta.enc = w.enc; ta.enc_ld = ENC_LD; ta.rec_prev = rec_prev; ta.rec_new = w.rec_d;
+        ta.is_disc = 1; ta.slot = j; ta.enc = w.enc; ta.enc_ld = ENC_LD; ta.rec_prev = rec_prev; ta.rec_new = rec_d_t;
         ta.noise = nz; ta.s1p = w.t1 + nh; ta.s1p_ld = nh + nh / 2;
         ta.wp = packed + packed_layout(h).w + h->layers[L_DISC_S1].w_off; ta.flat = flat;
         ta.w2_off = po.disc_steps_l1_w; ta.b2_off = po.disc_steps_l1_b;
         sq_launch_slot_tail(ta, d, s);
       }
     }
-    // ---- H. log-probabilities, I. merge / compaction ----
+    // ---- I. merge / compaction (the log-probabilities H and the decoder J are off the recurrence's critical path:
+    //      they run once for all T frames after the loop)
     {
-      LogprobArgs la; memset(&la, 0, sizeof(la));
-      la.rec_p = w.rec_p; la.rec_d = w.rec_d; la.rec_prev = rec_prev; la.pstats = w.pstats; la.ps_ld = PS_LD;
-      la.spre = w.spre; la.flat = flat; la.t_global = t + t_offset; la.t = t; la.qz = w.qz; la.pz = w.pz;
-      la.disc_lp = w.dlp; la.out = out; la.cfg = c;
-      sq_launch_logprob(la, po, d, s);
       CompactArgs ka; memset(&ka, 0, sizeof(ka));
-      ka.rec_p = w.rec_p; ka.rec_d = w.rec_d; ka.rec_prev = rec_prev; ka.temporal_p = w.temporal_p;
+      ka.rec_p = rec_p_t; ka.rec_d = rec_d_t; ka.rec_prev = rec_prev; ka.temporal_p = w.temporal_p;
       ka.prior_p = w.prior_p; ka.last_id_prev = w.last_id[pp]; ka.last_id_next = w.last_id[pn];
-      ka.rec_next = w.rec_m[pn]; ka.temporal_next = w.temporal_m[pn]; ka.prior_next = w.prior_m[pn];
+      ka.rec_next = rec_next; ka.temporal_next = w.temporal_m[pn]; ka.prior_next = w.prior_m[pn];
       ka.flat = flat; ka.t = t; ka.out = out;
       sq_launch_compact(ka, po, d, s);
     }
-    // ---- J. decoder + log-weight (modules.py:435-467, seq.py:271-276) ----
-    {
-      float* gl = out.glimpse ? out.glimpse + (size_t)t * M * G2 : w.glimpse;
-      Lin a; a.seg(w.rec_m[pn], RW, rec::ZW).out(w.ea, nh).act(ACT_ELU); RUN(a, L_DEC0, M);
-      Lin b; b.seg(w.ea, nh, nh).out(w.eb, nh).act(ACT_ELU); RUN(b, L_DEC1, M);
-      Lin g; g.seg(w.eb, nh, nh).out(gl, G2); g.a.scale_ptr = flat + po.dec_output_scale; RUN(g, L_DEC2, M);
-      InsertArgs ia; memset(&ia, 0, sizeof(ia));
-      ia.glimpse = gl; ia.rec = w.rec_m[pn]; ia.rec_ld = RW; ia.img = img; ia.mean_img = flat + po.dec_mean_img;
-      ia.canvas = out.canvas ? out.canvas + (size_t)t * R * P_ : nullptr; ia.data_ll = w.dll; ia.qz = w.qz; ia.pz = w.pz;
-      ia.t = t; ia.out = out; ia.std_fg = c.output_std; ia.std_bg = c.background_std;
-      sq_launch_insert_loglik(ia, d, s);
-    }
+  }
+  // ---- H. log-probabilities of all T frames in one launch (grid R x T) ----
+  {
+    LogprobArgs la; memset(&la, 0, sizeof(la));
+    la.rec_p = w.rec_p_all; la.rec_d = w.rec_d_all; la.rec_prev = w.rec_m_all; la.pstats = w.pstats; la.ps_ld = PS_LD;
+    la.spre = w.spre; la.flat = flat; la.t_global = t_offset; la.t = 0; la.n_frames = T; la.qz = w.qz; la.pz = w.pz;
+    la.disc_lp = w.dlp; la.out = out; la.cfg = c;
+    sq_launch_logprob(la, po, d, s);
+  }
+  // ---- J. decoder of all T frames as three M = T*B'*N row GEMMs + one insert / log-likelihood launch
+  //      (modules.py:435-467, seq.py:271-276) ----
+  {
+    const int MT = T * M;
+    const float* rec_all = w.rec_m_all + (size_t)M * RW;  // merged records of frames 0..T-1
+    float* gl = out.glimpse ? out.glimpse : w.glimpse;
+    Lin a; a.seg(rec_all, RW, rec::ZW).out(w.dec_a, nh).act(ACT_ELU); RUN(a, L_DEC0, MT);
+    Lin b; b.seg(w.dec_a, nh, nh).out(w.dec_b, nh).act(ACT_ELU); RUN(b, L_DEC1, MT);
+    Lin g; g.seg(w.dec_b, nh, nh).out(gl, G2); g.a.scale_ptr = flat + po.dec_output_scale; RUN(g, L_DEC2, MT);
+    InsertArgs ia; memset(&ia, 0, sizeof(ia));
+    ia.glimpse = gl; ia.rec = rec_all; ia.rec_ld = RW; ia.img = obs; ia.mean_img = flat + po.dec_mean_img;
+    ia.canvas = out.canvas; ia.data_ll = w.dll; ia.qz = w.qz; ia.pz = w.pz; ia.t = 0; ia.n_frames = T; ia.out = out;
+    ia.std_fg = c.output_std; ia.std_bg = c.background_std;
+    sq_launch_insert_loglik(ia, d, s);
   }
   // final recurrent state (for state-level parity checks)
   const int pf = T & 1;

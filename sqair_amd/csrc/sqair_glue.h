@@ -78,7 +78,8 @@ struct LogprobArgs {
   const float* spre;                  // [R,128] pre-activation of the where-prior conditioning state (without e)
   const float* flat;
   int t_global;                       // absolute frame index (categorical prior is time dependent)
-  int t;                              // frame index inside the output tensors
+  int t;                              // index of the first frame inside the output tensors
+  int n_frames;                       // frames covered by the launch (inputs are [n_frames][...] contiguous)
   float* qz; float* pz; float* disc_lp;  // frame scalars [R]
   SqairOutputs out;
   SqairConfig cfg;
@@ -106,7 +107,8 @@ struct InsertArgs {
   float* canvas;           // optional [R,H,W]
   float* data_ll;          // [R]
   const float* qz; const float* pz;  // optional frame scalars -> log weight outputs
-  int t;
+  int t;                   // first frame in the output tensors
+  int n_frames;            // frames covered by the launch (0/1 = single)
   SqairOutputs out;        // only the scalar log-weight outputs are used (may be all NULL)
   float std_fg, std_bg;
 };

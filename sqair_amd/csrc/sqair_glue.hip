@@ -505,9 +505,11 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
   // evaluates the densities from LDS.  (A direct global-memory walk was ~20 dependent round trips = 27 us.)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int r = blockIdx.x;
+  const int fr = blockIdx.y;               // frame (the launch covers all T frames of the pass)
   const int tid = threadIdx.x;
   const int N = d.N, nw = d.nw;
   const int RW = rec::W;
+  const size_t fs = (size_t)fr * d.R * N;  // slot-rows per frame
   float* recp_s = smem;                    // N * RW
   float* recd_s = recp_s + N * RW;         // N * RW
   float* recm_s = recd_s + N * RW;         // N * RW
@@ -524,14 +526,14 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
   float* ch_s = spb_s + 2 * (N + 1);       // 10
   const float* __restrict__ flat = a.flat;
   for (int i = tid; i < N * RW; i += 256) {
-    recp_s[i] = a.rec_p[(size_t)r * N * RW + i];
-    recd_s[i] = a.rec_d[(size_t)r * N * RW + i];
-    recm_s[i] = a.rec_prev[(size_t)r * N * RW + i];
+    recp_s[i] = a.rec_p[(fs + (size_t)r * N) * RW + i];
+    recd_s[i] = a.rec_d[(fs + (size_t)r * N) * RW + i];
+    recm_s[i] = a.rec_prev[(fs + (size_t)r * N) * RW + i];
   }
-  for (int i = tid; i < N * a.ps_ld; i += 256) ps_s[i] = a.pstats[(size_t)r * N * a.ps_ld + i];
+  for (int i = tid; i < N * a.ps_ld; i += 256) ps_s[i] = a.pstats[(fs + (size_t)r * N) * a.ps_ld + i];
   if (a.cfg.rec_where_prior) {
     if (tid < 128) {
-      spre_s[tid] = a.spre[(size_t)r * 128 + tid];
+      spre_s[tid] = a.spre[((size_t)fr * d.R + r) * 128 + tid];
       ce_s[tid] = flat[po.rn_cond_w + (4 + d.nh) * 128 + tid];
     }
     for (int i = tid; i < 512; i += 256) h2h_s[i] = flat[po.rn_h2h_w + i];
@@ -550,7 +552,8 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
   __syncthreads();
   if (tid >= 64) return;
   const int lane = tid;
-  const size_t tr = (size_t)a.t * d.R + r;
+  const size_t tr = (size_t)(a.t + fr) * d.R + r;
+  const int t_global = a.t_global + fr;
   const float LOG2PI = 1.83787706640934548356f;
 
   float e_sum = 0.0f, q_prop = 0.0f, p_prop = 0.0f, q_pres_sum = 0.0f, p_pres_sum = 0.0f, n_prop = 0.0f;
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
     float lg[SQ_MAXN + 1];
     float mx = -1e30f;
     for (int c = 0; c <= N; ++c) {
-      float v = spb_s[c] + (a.t_global > 0 ? spb_s[N + 1 + c] : 0.0f) + sp1_s[10 * (N + 1) + c];
+      float v = spb_s[c] + (t_global > 0 ? spb_s[N + 1 + c] : 0.0f) + sp1_s[10 * (N + 1) + c];
       for (int i = 0; i < 10; ++i) v += hid[i] * sp1_s[i * (N + 1) + c];
       lg[c] = sq_elu(v);
       mx = fmaxf(mx, lg[c]);
@@ -713,9 +716,9 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
   }
   const float q_prop_tot = q_prop + q_pres_sum, p_prop_tot = p_prop + p_pres_sum;
   const float q_disc_tot = q_disc + q_num, p_disc_tot = p_disc + p_num;
-  a.qz[r] = q_disc_tot + q_prop_tot;
-  a.pz[r] = p_disc_tot + p_prop_tot;
-  a.disc_lp[r] = q_pres_sum + q_num;
+  a.qz[(size_t)fr * d.R + r] = q_disc_tot + q_prop_tot;
+  a.pz[(size_t)fr * d.R + r] = p_disc_tot + p_prop_tot;
+  a.disc_lp[(size_t)fr * d.R + r] = q_pres_sum + q_num;
   if (a.out.prop_log_prob) a.out.prop_log_prob[tr] = q_pres_sum;
   if (a.out.prop_prior_log_prob) a.out.prop_prior_log_prob[tr] = p_pres_sum;
   if (a.out.disc_log_prob) a.out.disc_log_prob[tr] = q_num;
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
 int sq_launch_logprob(const LogprobArgs& a, POff po, Dims d, hipStream_t s) {
   const size_t shm = ((size_t)3 * d.N * rec::W + (size_t)d.N * a.ps_ld + 128 + 128 + 516 + 20 + 40 + 4 + 20 +
                       11 * (d.N + 1) + 2 * (d.N + 1) + 16) * sizeof(float);
-  hipLaunchKernelGGL(k_logprob, dim3(d.R), dim3(256), shm, s, a, po, d);
+  hipLaunchKernelGGL(k_logprob, dim3(d.R, a.n_frames), dim3(256), shm, s, a, po, d);
   return 0;
 }
 
@@ -849,13 +852,15 @@ __global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const
   float* pres_s = yt_s + N * H;       // N
   __shared__ float red_s[4];
   const int r = blockIdx.x, tid = threadIdx.x;
+  const int fr = blockIdx.y;  // frame
   const int b = r / d.K;
-  for (int i = tid; i < N * G2; i += 256) gl_s[i] = a.glimpse[(size_t)r * N * G2 + i];
+  const size_t fs = (size_t)fr * d.R * N;
+  for (int i = tid; i < N * G2; i += 256) gl_s[i] = a.glimpse[(fs + (size_t)r * N) * G2 + i];
   for (int i = tid; i < N * (W + H); i += 256) {
     const int k = i / (W + H), q = i % (W + H);
     const bool is_y = q >= W;
     const int j = is_y ? q - W : q;
-    const float* wl = a.rec ? a.rec + ((size_t)r * N + k) * a.rec_ld + rec::WHERE : a.where_plain + ((size_t)r * N + k) * 4;
+    const float* wl = a.rec ? a.rec + (fs + (size_t)r * N + k) * a.rec_ld + rec::WHERE : a.where_plain + ((size_t)r * N + k) * 4;
     const float sc = fmaxf(sq_sigmoid(wl[is_y ? 1 : 0]), 1e-4f);
     const float tr = tanhf(wl[is_y ? 3 : 2]);
     const float L = (float)((is_y ? H : W) - 1);
@@ -863,10 +868,11 @@ __global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const
     const float g = 0.5f * (float)(G - 1) * ((cn - tr) / sc + 1.0f);
     if (is_y) yt_s[k * H + j] = g; else xt_s[k * W + j] = g;
   }
-  if (tid < N) pres_s[tid] = a.rec ? a.rec[((size_t)r * N + tid) * a.rec_ld + rec::PRES] : a.pres_plain[(size_t)r * N + tid];
+  if (tid < N) pres_s[tid] = a.rec ? a.rec[(fs + (size_t)r * N + tid) * a.rec_ld + rec::PRES] : a.pres_plain[(size_t)r * N + tid];
   __syncthreads();
-  const float* __restrict__ img = a.img + (size_t)b * P;
-  const float qv = a.qz != nullptr ? a.qz[r] : 0.0f, pv = a.qz != nullptr ? a.pz[r] : 0.0f;  // requested early
+  const float* __restrict__ img = a.img + ((size_t)fr * d.B + b) * P;
+  const size_t frr = (size_t)fr * d.R + r;
+  const float qv = a.qz != nullptr ? a.qz[frr] : 0.0f, pv = a.qz != nullptr ? a.pz[frr] : 0.0f;  // requested early
   float ll = 0.0f;
   constexpr int PF = 10;  // pixels per thread whose frame / mean-image values are requested together
   for (int pix0 = tid; pix0 < P; pix0 += 256 * PF) {
@@ -915,7 +921,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const
       cv += mv[q] * m;
       const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
       ll += sq_normal_lp(xv[q], cv, sd);
-      if (a.canvas) a.canvas[(size_t)r * P + pix] = cv;
+      if (a.canvas) a.canvas[frr * P + pix] = cv;
     }
   }
   ll = sq_wave_sum(ll);
@@ -923,9 +929,9 @@ __global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const
   __syncthreads();
   if (tid == 0) {
     const float dll = red_s[0] + red_s[1] + red_s[2] + red_s[3];
-    a.data_ll[r] = dll;
+    a.data_ll[frr] = dll;
     if (a.qz != nullptr) {
-      const size_t tr = (size_t)a.t * d.R + r;
+      const size_t tr = (size_t)a.t * d.R + frr;
       const float q = qv, p = pv;
       const float kl = q - p;
       if (a.out.data_ll_per_sample) a.out.data_ll_per_sample[tr] = dll;
@@ -938,7 +944,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const
 }
 int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s) {
   const size_t shm = ((size_t)d.N * d.G * d.G + (size_t)d.N * (d.W + d.H) + d.N) * sizeof(float);
-  hipLaunchKernelGGL(k_insert_loglik, dim3(d.R), dim3(256), shm, s, a, d);
+  hipLaunchKernelGGL(k_insert_loglik, dim3(d.R, a.n_frames > 0 ? a.n_frames : 1), dim3(256), shm, s, a, d);
   return 0;
 }
 
