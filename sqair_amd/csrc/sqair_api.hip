@@ -585,7 +585,7 @@ static Workspace carve(const SqairHandle* h, int T, int B, float* base) {
   w.glimpse = take((int64_t)T * M * G2);
   w.dec_a = take((int64_t)T * M * nh);
   w.dec_b = take((int64_t)T * M * nh);
-  w.prof_ts = (unsigned long long*)take(2 * PROF_MAX * 2);
+  w.prof_ts = (unsigned long long*)take(5 * PROF_MAX * 2);
   w.total = o;
   return w;
 }
@@ -921,15 +921,16 @@ extern "C" int sqair_profile_forward(SqairHandle* h, const float* flat_params, c
   SQ_CHECK_HIP(hipEventElapsedTime(&fms, ea, eb));
   hipEventDestroy(ea);
   hipEventDestroy(eb);
-  std::vector<unsigned long long> ts(2 * PROF_MAX);
-  SQ_CHECK_HIP(hipMemcpy(ts.data(), w.prof_ts, 2 * PROF_MAX * 8, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> ts(5 * PROF_MAX);
+  SQ_CHECK_HIP(hipMemcpy(ts.data(), w.prof_ts, 5 * PROF_MAX * 8, hipMemcpyDeviceToHost));
   double ticks = 0.0;
   for (int i = 0; i < h->prof_n; ++i) ticks += (double)(ts[PROF_MAX + i] - ts[i]);
   if (const char* dump = getenv("SQAIR_PROF_DUMP")) {  // per-launch CSV: layer id, rows, start tick, end tick (10 ns ticks)
     if (FILE* f = fopen(dump, "w")) {
-      fprintf(f, "layer,M,start,end\n");
+      fprintf(f, "layer,M,start,end,wg0_setup,wg0_mfma,wg0_end\n");
       for (int i = 0; i < h->prof_n; ++i)
-        fprintf(f, "%d,%d,%llu,%llu\n", h->prof_layer[i], h->prof_m[i], ts[i] - ts[0], ts[PROF_MAX + i] - ts[0]);
+        fprintf(f, "%d,%d,%llu,%llu,%llu,%llu,%llu\n", h->prof_layer[i], h->prof_m[i], ts[i] - ts[0], ts[PROF_MAX + i] - ts[0],
+                ts[2 * PROF_MAX + i], ts[3 * PROF_MAX + i], ts[4 * PROF_MAX + i]);
       fclose(f);
     }
   }

@@ -45,6 +45,7 @@ struct LinSeg {
   int ld;          // floats between consecutive (r / rdiv); 0 = broadcast one row
   int width;       // true number of inputs taken from this segment (K padded to 16 in the pack)
   int rdiv;
+  unsigned rmul;   // filled by the launcher: 0 = rdiv 1, else floor(2^32 / rdiv) + 1 (row / rdiv == umulhi(row, rmul))
 };
 
 struct LinArgs {
@@ -55,6 +56,7 @@ struct LinArgs {
   const float* wzero; // 256 zero floats (one chunk of zero weights) inside the packed buffer
   const float* add;   // optional pre-activation addend, applied for n < add_n
   int add_ld, add_rdiv, add_n;
+  unsigned add_rmul;
   float* out;
   int out_ld;
   int M, N;

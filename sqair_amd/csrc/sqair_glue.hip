@@ -88,74 +88,93 @@ __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, c
   float v0[IPT];  // first (for 50x50: only) batch of frame pixels of this thread, requested before anything else
 #pragma unroll
   for (int q = 0; q < IPT; ++q) v0[q] = img[min(q * 256 + tid, P - 1)];
-  // ---- transform MLP output layer (nh -> 8) evaluated here when its input is given: one wavefront per particle
-  // row, each lane owning 4 of the nh inputs, 8 wave reductions (replaces a whole dependent launch)
-  float* tp_s = tab_s + d.K * 2 * G * 2;     // K * 8
+  // ---- `where` of every particle row: one HALF-wavefront (32 lanes) per row.  When the transform MLP's input is
+  // given, its output layer (nh -> 8) is evaluated right here — each lane owns nh/32 inputs, 8 half-wave
+  // reductions — and lanes 0..3 go straight on to the sample (no extra launch, no LDS round trip).  All operands
+  // (weights, eps, previous where, scale offset, Cholesky factor) are requested before the first reduction.
   const bool fused_tp = a.t2 != nullptr && (a.mode == CROP_PROP2 || a.mode == CROP_DISC);
-  if (fused_tp) {
-    const int wave = tid >> 6, lane = tid & 63;
-    float wl3[32];
-    const float4* w4 = reinterpret_cast<const float4*>(a.w3) + (size_t)lane * 8;  // rows 4*lane .. 4*lane+3, 8 outputs each
+  const int hw = tid >> 5, hl = tid & 31;
+  const int per = d.nh / 32;  // inputs per lane (8 for nh = 256); nh % 128 == 0 assumed for the float4 path
+  for (int kp = hw; kp < d.K; kp += 8) {
+    const int r = b * d.K + kp;
+    const int ci = hl & 3;  // component handled by lanes 0..3 (other lanes compute a harmless duplicate)
+    float tp_loc = 0.0f, tp_raw = 0.0f;
+    // operands of the sample
+    float e[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zp = 0.0f, off = 0.0f, chv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wbv = 0.0f, lg = 0.0f;
+    if (a.mode == CROP_PLAIN) {
+      lg = a.logits[(size_t)r * 4 + ci];
+    } else if (a.mode == CROP_PROP1) {
+      zp = a.rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHERE + ci];
+      wbv = a.wb[((size_t)r * d.N + slot) * a.wb_ld + ci];
+    } else {
+      const float* eps = a.noise + (((size_t)r * 2 + (a.mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float4 t = (4 * lane < d.nh) ? w4[q] : float4{0.0f, 0.0f, 0.0f, 0.0f};
-      wl3[q * 4 + 0] = t.x; wl3[q * 4 + 1] = t.y; wl3[q * 4 + 2] = t.z; wl3[q * 4 + 3] = t.w;
+      for (int jj = 0; jj < 4; ++jj) e[jj] = eps[jj];
+      if (a.mode == CROP_DISC) {
+        off = a.flat[po.disc_scale_offset];
+      } else {
+        off = a.flat[po.prop_scale_offset];
+        zp = a.rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHERE + ci];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) chv[jj] = tril4(a.flat + po.cholesky, ci, min(jj, ci));
+      }
+      if (!fused_tp) {
+        tp_loc = a.tp[(size_t)r * a.tp_ld + ci];
+        tp_raw = a.tp[(size_t)r * a.tp_ld + 4 + ci];
+      }
     }
-    for (int kp = wave; kp < d.K; kp += 4) {
-      const int r = b * d.K + kp;
-      const float4 x = (4 * lane < d.nh) ? *reinterpret_cast<const float4*>(a.t2 + (size_t)r * a.t2_ld + 4 * lane)
-                                         : float4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (fused_tp) {
+      float part[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      const float4* x4 = reinterpret_cast<const float4*>(a.t2 + (size_t)r * a.t2_ld + per * hl);
+      const float4* w4 = reinterpret_cast<const float4*>(a.w3) + (size_t)per * hl * 2;  // rows per*hl.., 8 outputs each
+      for (int q = 0; q < per / 4; ++q) {
+        const float4 x = x4[q];
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const float4 wa = w4[(q * 4 + ii) * 2], wb2 = w4[(q * 4 + ii) * 2 + 1];
+          part[0] += xs[ii] * wa.x; part[1] += xs[ii] * wa.y; part[2] += xs[ii] * wa.z; part[3] += xs[ii] * wa.w;
+          part[4] += xs[ii] * wb2.x; part[5] += xs[ii] * wb2.y; part[6] += xs[ii] * wb2.z; part[7] += xs[ii] * wb2.w;
+        }
+      }
 #pragma unroll
       for (int o = 0; o < 8; ++o) {
-        float part = x.x * wl3[o] + x.y * wl3[8 + o] + x.z * wl3[16 + o] + x.w * wl3[24 + o];
-        part = sq_wave_sum(part);
-        if (lane == 0) tp_s[kp * 8 + o] = part + a.w3[d.nh * 8 + o];
+        float v = part[o];
+        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+        part[o] = v + a.w3[d.nh * 8 + o];
       }
+      tp_loc = ci == 0 ? part[0] : (ci == 1 ? part[1] : (ci == 2 ? part[2] : part[3]));
+      tp_raw = ci == 0 ? part[4] : (ci == 1 ? part[5] : (ci == 2 ? part[6] : part[7]));
     }
-    __syncthreads();
-  }
-  // ---- the `where` logits: one thread per (particle, component), all operands requested at once
-  float wl = 0.0f;
-  if (tid < 4 * d.K) {
-    const int kp = tid >> 2, i = tid & 3;
-    const int r = b * d.K + kp;
+    float wl;
     if (a.mode == CROP_PLAIN) {
-      wl = a.logits[(size_t)r * 4 + i];
+      wl = lg;
     } else if (a.mode == CROP_PROP1) {
-      wl = a.rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHERE + i] +
-           a.wb[((size_t)r * d.N + slot) * a.wb_ld + i] * 0.1f;
+      wl = zp + wbv * 0.1f;
     } else {
-      const float* tp = fused_tp ? tp_s + kp * 8 : a.tp + (size_t)r * a.tp_ld;
-      const float* eps = a.noise + (((size_t)r * 2 + (a.mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
-      float* rn = a.rec_new + ((size_t)r * d.N + slot) * rec::W;
       float loc, sc;
       if (a.mode == CROP_DISC) {
-        const float tl = tp[i], tr = tp[4 + i], e = eps[i], off = a.flat[po.disc_scale_offset];
-        loc = tl;
-        sc = sq_softplus(tr + off) + 1e-2f;
-        wl = loc + sc * e;
+        loc = tp_loc;
+        sc = sq_softplus(tp_raw + off) + 1e-2f;
+        wl = loc + sc * (ci == 0 ? e[0] : (ci == 1 ? e[1] : (ci == 2 ? e[2] : e[3])));
       } else {
-        const float tl = tp[i], tr = tp[4 + i], off = a.flat[po.prop_scale_offset];
-        const float zp = a.rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHERE + i];
-        const float* ch = a.flat + po.cholesky;
-        float e[4], t[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          e[jj] = eps[jj];
-          t[jj] = (jj <= i) ? tril4(ch, i, jj) : 0.0f;
-        }
-        loc = zp + 1.0f * tl;
-        sc = sq_softplus(tr + off - 1.0f) + 1e-2f;
-        float acc = 0.0f;  // row i of L = T * sc[:,None] + diag(sc), times eps
+        loc = zp + 1.0f * tp_loc;
+        sc = sq_softplus(tp_raw + off - 1.0f) + 1e-2f;
+        float acc = 0.0f;  // row ci of L = T * sc[:,None] + diag(sc), times eps
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
-          if (jj <= i) acc += (t[jj] * sc + (jj == i ? sc : 0.0f)) * e[jj];
+          if (jj <= ci) acc += (chv[jj] * sc + (jj == ci ? sc : 0.0f)) * e[jj];
         wl = loc + acc;
       }
-      rn[rec::WHERE + i] = wl;
-      rn[rec::WHERE_LOC + i] = loc;
-      rn[rec::WHERE_SCALE + i] = sc;
+      if (hl < 4) {
+        float* rn = a.rec_new + ((size_t)r * d.N + slot) * rec::W;
+        rn[rec::WHERE + ci] = wl;
+        rn[rec::WHERE_LOC + ci] = loc;
+        rn[rec::WHERE_SCALE + ci] = sc;
+      }
     }
+    if (hl < 4) coord_s[kp * 4 + ci] = (ci & 2) ? tanhf(wl) : fmaxf(sq_sigmoid(wl), 1e-4f);
   }
 #pragma unroll
   for (int q = 0; q < IPT; ++q) {
@@ -172,7 +191,6 @@ __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, c
       if (idx < P) img_s[idx] = v[q];
     }
   }
-  if (tid < 4 * d.K) coord_s[tid] = (tid & 2) ? tanhf(wl) : fmaxf(sq_sigmoid(wl), 1e-4f);
   __syncthreads();
   // per particle: source coordinates of the G columns and G rows
   for (int i = tid; i < d.K * 2 * G; i += 256) {

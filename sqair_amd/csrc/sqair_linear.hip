@@ -83,8 +83,9 @@ __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int 
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
-  const int tile_n = blockIdx.x % n_tiles;
-  const int tile_m = (blockIdx.x / n_tiles) * 4 + wave;
+  const int tile_n = blockIdx.x;
+  const int tile_m = blockIdx.y * 4 + wave;
+  (void)n_tiles;
   const int arow = min(tile_m * 16 + (lane & 15), a.M - 1);
   const int kq = lane >> 4;
   unsigned long long t_start = 0;
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int mc = min(tile_m * 16 + 4 * kq + i, a.M - 1);
-    const float* pa = use_add ? a.add + (size_t)(mc / a.add_rdiv) * a.add_ld + nc : pb;
+    const int mcd = a.add_rmul ? (int)__umulhi((unsigned)mc, a.add_rmul) : mc;
+    const float* pa = use_add ? a.add + (size_t)mcd * a.add_ld + nc : pb;
     const float* pe0 = g1 ? a.e0 + (size_t)mc * a.e0_ld + (nc - a.nh) : (g2 ? a.e0 + (size_t)mc * a.e0_ld + nc : pb);
     const float* pe1 = g2 ? a.e1 + (size_t)mc * a.e1_ld + nc : pb;
     p_add[i] = *pa;
@@ -113,14 +115,15 @@ __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int 
   }
 
   int cum1 = 0x7fffffff, cum2 = 0x7fffffff, cum3 = 0x7fffffff;
-  const float* rp0 = a.seg[0].p + (size_t)(arow / a.seg[0].rdiv) * a.seg[0].ld;
+#define SQ_ROWOF(sg) ((sg).rmul ? (int)__umulhi((unsigned)arow, (sg).rmul) : arow)
+  const float* rp0 = a.seg[0].p + (size_t)SQ_ROWOF(a.seg[0]) * a.seg[0].ld;
   const float* rp1 = rp0; const float* rp2 = rp0; const float* rp3 = rp0;
   int lim0 = ((a.seg[0].width + 3) & ~3) - 4, lim1 = 0, lim2 = 0, lim3 = 0;
   {
     int c = (a.seg[0].width + 15) >> 4;
-    if (a.nseg > 1) { cum1 = c; c += (a.seg[1].width + 15) >> 4; rp1 = a.seg[1].p + (size_t)(arow / a.seg[1].rdiv) * a.seg[1].ld; lim1 = ((a.seg[1].width + 3) & ~3) - 4; }
-    if (a.nseg > 2) { cum2 = c; c += (a.seg[2].width + 15) >> 4; rp2 = a.seg[2].p + (size_t)(arow / a.seg[2].rdiv) * a.seg[2].ld; lim2 = ((a.seg[2].width + 3) & ~3) - 4; }
-    if (a.nseg > 3) { cum3 = c; rp3 = a.seg[3].p + (size_t)(arow / a.seg[3].rdiv) * a.seg[3].ld; lim3 = ((a.seg[3].width + 3) & ~3) - 4; }
+    if (a.nseg > 1) { cum1 = c; c += (a.seg[1].width + 15) >> 4; rp1 = a.seg[1].p + (size_t)SQ_ROWOF(a.seg[1]) * a.seg[1].ld; lim1 = ((a.seg[1].width + 3) & ~3) - 4; }
+    if (a.nseg > 2) { cum2 = c; c += (a.seg[2].width + 15) >> 4; rp2 = a.seg[2].p + (size_t)SQ_ROWOF(a.seg[2]) * a.seg[2].ld; lim2 = ((a.seg[2].width + 3) & ~3) - 4; }
+    if (a.nseg > 3) { cum3 = c; rp3 = a.seg[3].p + (size_t)SQ_ROWOF(a.seg[3]) * a.seg[3].ld; lim3 = ((a.seg[3].width + 3) & ~3) - 4; }
   }
   f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
   const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
@@ -178,10 +181,22 @@ __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int 
 
 template <int NCH>
 static void launch_nch(const LinArgs& a, const PackedLayer& L, int grid, hipStream_t s, unsigned long long* prof_ts) {
-  hipLaunchKernelGGL(k_linear<NCH>, dim3(grid), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+  (void)grid;
+  const dim3 g(L.nt, (a.M + 15) / 16);
+  switch (a.nseg) {  // the segment count is a template parameter: dead segment-selection code disappears
+    case 1: hipLaunchKernelGGL((k_linear<NCH, 1>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts); break;
+    case 2: hipLaunchKernelGGL((k_linear<NCH, 2>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts); break;
+    case 3: hipLaunchKernelGGL((k_linear<NCH, 3>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts); break;
+    default: hipLaunchKernelGGL((k_linear<NCH, 4>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts); break;
+  }
 }
 
-int sq_launch_linear(const LinArgs& a, const PackedLayer& L, hipStream_t s, unsigned long long* prof_ts) {
+static unsigned rmul_of(int rdiv) { return rdiv <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)rdiv) + 1u; }
+
+int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, unsigned long long* prof_ts) {
+  LinArgs a = a_in;
+  for (int i = 0; i < a.nseg; ++i) a.seg[i].rmul = rmul_of(a.seg[i].rdiv);
+  a.add_rmul = rmul_of(a.add_rdiv);
   const int mt = (a.M + 15) / 16;
   const int grid = mt * L.nt;
   if (grid <= 0) return 0;
@@ -189,11 +204,11 @@ int sq_launch_linear(const LinArgs& a, const PackedLayer& L, hipStream_t s, unsi
     const LinSeg& sg = a.seg[i];
     if ((reinterpret_cast<uintptr_t>(sg.p) & 15) != 0 || (sg.ld & 3) != 0 || sg.width < 1 || sg.rdiv < 1) return -5;
   }
-  if (a.M >= 256 && L.kc * L.nt >= 400 && L.kc <= 32) {  // big batched once-per-frame layers: throughput variant
-    const int grid_r = ((mt + 3) / 4) * L.nt;
-    if (L.kc <= 4) hipLaunchKernelGGL(k_linear_rows<4>, dim3(grid_r), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
-    else if (L.kc <= 8) hipLaunchKernelGGL(k_linear_rows<8>, dim3(grid_r), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
-    else hipLaunchKernelGGL(k_linear_rows<12>, dim3(grid_r), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+  if (a.M >= 2048 || (a.M >= 256 && L.kc * L.nt >= 400 && L.kc <= 32)) {  // big batched once-per-frame layers: throughput variant
+    const dim3 grid_r(L.nt, (mt + 3) / 4);
+    if (L.kc <= 4) hipLaunchKernelGGL(k_linear_rows<4>, grid_r, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+    else if (L.kc <= 8) hipLaunchKernelGGL(k_linear_rows<8>, grid_r, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+    else hipLaunchKernelGGL(k_linear_rows<12>, grid_r, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
     return 0;
   }
   const int per_wave = (L.kc + 3) / 4;

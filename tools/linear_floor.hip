@@ -68,8 +68,8 @@ int main() {
   hipStream_t s; hipStreamCreate(&s);
   const int M = 160, K = 256, N = 256, kc = K / 16, nt = N / 16;
   float *x, *y, *w, *b;
-  hipMalloc(&x, M * K * 4); hipMalloc(&y, M * K * 4); hipMalloc(&w, (256 + 64 * nt * kc * 256) * 4); hipMalloc(&b, N * 4);
-  hipMemset(x, 0, M * K * 4); hipMemset(y, 0, M * K * 4); hipMemset(w, 0, (256 + 64 * nt * kc * 256) * 4); hipMemset(b, 0, N * 4);
+  hipMalloc(&x, 640 * K * 4); hipMalloc(&y, 640 * K * 4); hipMalloc(&w, (256 + 64 * nt * kc * 256) * 4); hipMalloc(&b, N * 4);
+  hipMemset(x, 0, 640 * K * 4); hipMemset(y, 0, 640 * K * 4); hipMemset(w, 0, (256 + 64 * nt * kc * 256) * 4); hipMemset(b, 0, N * 4);
   auto mk = [&](const float* in, float* out, int m, int n_tiles_used) {
     LinArgs a = LinArgs();
     a.seg[0] = LinSeg{in, K, K, 1}; a.nseg = 1; a.wp = w + 256; a.wzero = w; a.bias = b; a.out = out; a.out_ld = N;
@@ -80,7 +80,7 @@ int main() {
 #define RUN(name, kern, m, ntu, statin)                                                                         \
   printf("%-34s %.2f us/node\n", name, time_graph(s, NODES, REPS, [&](int i) {                                    \
     LinArgs a = mk((statin) ? x : ((i & 1) ? y : x), (statin) ? y : ((i & 1) ? x : y), m, ntu);                   \
-    hipLaunchKernelGGL(kern<4>, dim3(((m) + 15) / 16 * (ntu)), dim3(256), 0, s, a, kc, ntu, (unsigned long long*)nullptr); }));
+    hipLaunchKernelGGL(kern<4>, dim3((ntu), ((m) + 15) / 16), dim3(256), 0, s, a, kc, ntu, (unsigned long long*)nullptr); }));
   RUN("full 160x256x256 (160 WG)", k_full, 160, 16, false);
   RUN("full, static input", k_full, 160, 16, true);
   RUN("no MFMA (VALU fma instead)", k_nomfma, 160, 16, false);
@@ -101,7 +101,7 @@ int main() {
       char nm[64]; snprintf(nm, 64, "rotating %d kernel instantiations", nk);
       printf("%-34s %.2f us/node\n", nm, time_graph(s, NODES, REPS, [&](int i) {
         LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);
-        hipLaunchKernelGGL(ks[i % nk], dim3(160), dim3(256), 0, s, a, kc, 16, (unsigned long long*)nullptr); }));
+        hipLaunchKernelGGL(ks[i % nk], dim3(16, 10), dim3(256), 0, s, a, kc, 16, (unsigned long long*)nullptr); }));
     }
   }
   for (int L : {1, 16, 64}) {
@@ -120,7 +120,7 @@ int main() {
     printf("%-34s %.2f us/node\n", nm, time_graph(s, NODES, REPS, [&](int i) {
       LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);
       a.wp = w + 256 + (size_t)(i % L) * nt * kc * 256;
-      hipLaunchKernelGGL(k_full<4>, dim3(160), dim3(256), 0, s, a, kc, 16, (unsigned long long*)nullptr); }));
+      hipLaunchKernelGGL(k_full<4>, dim3(16, 10), dim3(256), 0, s, a, kc, 16, (unsigned long long*)nullptr); }));
   }
   return 0;
 }
