@@ -73,6 +73,7 @@ int sqair_param_entry(const SqairHandle* h, int i, const char** name, int64_t* o
 int64_t sqair_packed_bytes(const SqairHandle* h);
 int64_t sqair_workspace_bytes(const SqairHandle* h, int T, int B);
 int sqair_noise_width(const SqairHandle* h); /* 4 + n_what + 1 */
+int sqair_get_config(const SqairHandle* h, SqairConfig* out);
 
 /* ---- parameters ------------------------------------------------------------------------------- */
 /* Re-lays the flat parameters out for the MFMA kernels (16x16x4-fp32 fragment order, K padded per
@@ -191,6 +192,27 @@ int sqair_linear_test(SqairHandle* h, const float* x, const float* w, const floa
  * (the order of the reference's GRU variables inside the flat parameter buffer). */
 int sqair_gru_test(SqairHandle* h, const float* x, const float* hstate, const float* gru_flat, float* h_out,
                    int M, int Kx, void* scratch, int64_t scratch_bytes, void* stream);
+
+/* ---- adjoint (backward) building blocks of the training step (sqair_st_crop_bwd,
+ * sqair_st_insert_ll_bwd, ...; the reference gets them from TF autodiff, sqair/model.py:160) ---------- */
+/* d/d(where logits) [R,4] and optionally d/d(mask) [R,G*G] of the (masked) crop, given d/d(out) [R,G*G]. */
+int sqair_st_crop_bwd(SqairHandle* h, const float* img, const float* where_logits, const float* mask,
+                      const float* g_out, float* d_where_logits, float* d_mask, int B, void* stream);
+/* Adjoint of sqair_st_insert_loglik for an upstream gradient g_data_ll [R]: d_glimpse [R,N,G*G],
+ * d_where_logits [R,N,4], d_mean_img [H,W] (summed over rows); scratch >= R*H*W*4 bytes. */
+int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, const float* where_logits,
+                               const float* presence, const float* img, const float* mean_img,
+                               const float* g_data_ll, float* d_glimpse, float* d_where_logits,
+                               float* d_mean_img, void* scratch, int64_t scratch_bytes, int B, void* stream);
+/* Gradient of the VIMCO target (already / T) w.r.t. the per-frame log weights and discrete log-probs [T,B*K],
+ * from the importance weights and the learning signal sqair_elbo returned. */
+int sqair_elbo_bwd(SqairHandle* h, const float* importance_weights, const float* vimco_signal, int T, int B,
+                   float* g_log_w_t, float* g_disc_lp_t, void* stream);
+/* Dense layer backward on the MFMA path (test helper): y = act(x W + b) forward; given dy returns dx [M,K],
+ * dw [K,N] (reference [in,out] layout) and db [N]. */
+int sqair_linear_bwd_test(SqairHandle* h, const float* x, const float* w, const float* y, const float* dy, float* dx,
+                          float* dw, float* db, int M, int Kdim, int Ndim, int act, void* scratch,
+                          int64_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

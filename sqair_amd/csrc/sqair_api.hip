@@ -462,6 +462,11 @@ extern "C" int sqair_param_entry(const SqairHandle* h, int i, const char** name,
   if (numel) *numel = h->params[i].numel;
   return 0;
 }
+extern "C" int sqair_get_config(const SqairHandle* h, SqairConfig* out) {
+  if (!h || !out) return -1;
+  *out = h->cfg;
+  return 0;
+}
 extern "C" int sqair_noise_width(const SqairHandle* h) { return h ? 4 + h->cfg.n_what + 1 : -1; }
 
 static int64_t align64(int64_t x) { return (x + 63) / 64 * 64; }
@@ -1161,5 +1166,59 @@ extern "C" int sqair_debug_plan(const SqairHandle* h, int id, int* widx, int* bi
   memcpy(widx, h->widx.data() + L.w_off, (size_t)L.nt * L.kc * 256 * sizeof(int));
   memcpy(bidx_a, h->bidx_a.data() + L.b_off, (size_t)L.nt * 16 * sizeof(int));
   memcpy(bidx_b, h->bidx_b.data() + L.b_off, (size_t)L.nt * 16 * sizeof(int));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense-layer backward through the MFMA kernels (unit-test entry): y = act(x W + b) was computed forward;
+// given dL/dy returns dL/dx (k_linear on the transposed pack), dL/dW and dL/db (k_wgrad).
+// ------------------------------------------------------------------------------------------------
+int sq_launch_wgrad(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int Kdim,
+                    int Ndim, int accumulate, hipStream_t s);
+int sq_launch_dact(const float* d_out, const float* out, float* d_pre, int64_t n, int act, hipStream_t s);
+
+extern "C" int sqair_linear_bwd_test(SqairHandle* h, const float* x, const float* wmat, const float* y, const float* dy,
+                                     float* dx, float* dw, float* db, int M, int Kdim, int Ndim, int act, void* scratch,
+                                     int64_t scratch_bytes, void* stream) {
+  if (!h || !x || !wmat || !y || !dy || !dx || !dw || !db || !scratch) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  // transposed layer: K' = Ndim inputs (dpre), N' = Kdim outputs (dx)
+  PackedLayer L;
+  adhoc_layer(h, Ndim, Kdim, &L);
+  const int64_t nel = (int64_t)L.nt * L.kc * 256, nb = L.nt * 16;
+  const int npad = (Ndim + 3) & ~3;
+  if (scratch_bytes < (2 * nel + nb + 256 + (int64_t)M * npad + (int64_t)M * Ndim) * 4) {
+    sq_set_error(h, "sqair_linear_bwd_test: scratch too small");
+    return -1;
+  }
+  std::vector<int> idx(nel, -1);
+  for (int j = 0; j < Kdim; ++j) {       // output column j of the transposed layer = input k of the forward layer
+    const int tile = j / 16, ln = j % 16;
+    for (int kk = 0; kk < Ndim; ++kk) {  // reduction index = forward output n
+      const int cch = kk / 16, kin = kk % 16;
+      const int lane = (kin / 4) * 16 + ln, comp = kin % 4;
+      idx[(((int64_t)tile * L.kc + cch) * 64 + lane) * 4 + comp] = j * Ndim + kk;  // W[j][kk]
+    }
+  }
+  int* d_idx = (int*)scratch;
+  float* d_w = (float*)scratch + nel;
+  float* d_b = d_w + nel;
+  float* d_zero = d_b + nb;
+  float* d_dpre_pad = d_zero + 256;
+  float* d_dpre = d_dpre_pad + (int64_t)M * npad;
+  SQ_CHECK_HIP(hipMemcpyAsync(d_idx, idx.data(), nel * 4, hipMemcpyHostToDevice, s));
+  SQ_CHECK_HIP(hipMemsetAsync(d_b, 0, (nb + 256 + (size_t)M * npad) * 4, s));
+  SQ_CHECK_HIP(hipStreamSynchronize(s));
+  sq_launch_pack(wmat, d_w, d_idx, nel, s);
+  sq_launch_dact(dy, y, d_dpre, (int64_t)M * Ndim, act, s);
+  sq_launch_wgrad(x, Kdim, d_dpre, Ndim, dw, Ndim, db, M, Kdim, Ndim, 0, s);
+  SQ_CHECK_HIP(hipMemcpy2DAsync(d_dpre_pad, (size_t)npad * 4, d_dpre, (size_t)Ndim * 4, (size_t)Ndim * 4, M,
+                                hipMemcpyDeviceToDevice, s));
+  Lin l;
+  l.seg(d_dpre_pad, npad, Ndim).out(dx, Kdim).act(ACT_NONE);
+  l.a.wp = d_w; l.a.wzero = d_zero; l.a.bias = d_b; l.a.M = M; l.a.N = Kdim;
+  if (sq_launch_linear(l.a, L, s) != 0) { sq_set_error(h, "sqair_linear_bwd_test: A-operand contract violated"); return -5; }
+  SQ_CHECK_HIP(hipGetLastError());
+  SQ_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }

@@ -249,7 +249,8 @@ int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s
   const size_t shm = ((size_t)d.H * d.W + d.K * 4 + (size_t)d.K * 2 * d.G * 2 + d.K * 8) * sizeof(float);
   static bool big_lds = false;
   if (shm > 48 * 1024 && !big_lds) {  // 128x128 frames: 64 KiB + tables, CDNA4 has 160 KiB of LDS per CU
-    hipFuncSetAttribute((const void*)k_crop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_crop, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipGetLastError();
     big_lds = true;
   }
   hipLaunchKernelGGL(k_crop, dim3(d.B, nslots), dim3(256), shm, s, a, po, d);

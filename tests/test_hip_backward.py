@@ -1,0 +1,161 @@
+"""-m gpu: adjoint kernels (building blocks of the training step) against autograd on the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sqair_oracle as O
+from sqair_amd import _capi
+from sqair_amd.flags import make_flags
+from sqair_amd.model import make_config
+from tests.hip_util import dev, rel_err, stream
+
+pytestmark = pytest.mark.gpu
+D = torch.float64
+
+
+def _handle(K, N, hw):
+    lib = _capi.lib()
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    cfg = make_config(F, hw)
+    h = C.c_void_p()
+    assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
+    return lib, h, F
+
+
+@pytest.mark.parametrize("hw", [(50, 50), (128, 128), (33, 47)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_st_crop_backward(hw, masked):
+    lib, h, F = _handle(3, 4, hw)
+    try:
+        B, K, G = 4, 3, 20
+        R = B * K
+        rng = np.random.default_rng(hw[1])
+        img = rng.uniform(size=(B,) + hw).astype(np.float32)
+        where = (rng.standard_normal((R, 4)) * 1.2).astype(np.float32)
+        where[0] = [2.0, 2.5, 0.1, -0.2]
+        mask = rng.uniform(size=(R, G * G)).astype(np.float32) if masked else None
+        g_out = rng.standard_normal((R, G * G)).astype(np.float32)
+        d_where = torch.zeros(R, 4, device="cuda")
+        d_mask = torch.zeros(R, G * G, device="cuda")
+        di, dw, dg = dev(img), dev(where), dev(g_out)
+        dm = dev(mask) if masked else None
+        rc = lib.sqair_st_crop_bwd(h, di.data_ptr(), dw.data_ptr(), dm.data_ptr() if masked else None, dg.data_ptr(),
+                                   d_where.data_ptr(), d_mask.data_ptr() if masked else None, B, stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        w64 = torch.tensor(where, dtype=D, requires_grad=True)
+        m64 = torch.tensor(mask, dtype=D, requires_grad=True) if masked else None
+        out = O.st_crop(torch.tensor(np.repeat(img, K, 0), dtype=D), w64, G).reshape(R, -1)
+        if masked:
+            out = out * m64
+        (out * torch.tensor(g_out, dtype=D)).sum().backward()
+        assert rel_err(d_where.cpu().numpy(), w64.grad.numpy()) < 2e-4
+        if masked:
+            assert rel_err(d_mask.cpu().numpy(), m64.grad.numpy()) < 1e-5
+    finally:
+        lib.sqair_destroy(h)
+
+
+@pytest.mark.parametrize("hw", [(50, 50), (128, 128)])
+def test_st_insert_loglik_backward(hw):
+    lib, h, F = _handle(2, 4, hw)
+    try:
+        B, K, N, G = 3, 2, 4, 20
+        R = B * K
+        H, W = hw
+        rng = np.random.default_rng(5)
+        gl = (rng.standard_normal((R, N, G * G)) * 0.3).astype(np.float32)
+        where = rng.standard_normal((R, N, 4)).astype(np.float32)
+        pres = (rng.uniform(size=(R, N)) > 0.35).astype(np.float32)
+        pres[1] = 0.0
+        img = rng.uniform(size=(B, H, W)).astype(np.float32)
+        mean_img = rng.uniform(size=(H, W)).astype(np.float32)
+        g_ll = rng.standard_normal(R).astype(np.float32)
+        d_gl = torch.zeros(R, N, G * G, device="cuda")
+        d_wh = torch.zeros(R, N, 4, device="cuda")
+        d_mean = torch.zeros(H, W, device="cuda")
+        scratch = torch.empty(R * H * W, device="cuda")
+        ts = [dev(gl), dev(where), dev(pres), dev(img), dev(mean_img), dev(g_ll)]
+        rc = lib.sqair_st_insert_loglik_bwd(h, *[t.data_ptr() for t in ts], d_gl.data_ptr(), d_wh.data_ptr(),
+                                            d_mean.data_ptr(), scratch.data_ptr(), scratch.numel() * 4, B, stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        ocfg = O.make_cfg(F, hw)
+        g64 = torch.tensor(gl, dtype=D, requires_grad=True)
+        w64 = torch.tensor(where, dtype=D, requires_grad=True)
+        mi64 = torch.tensor(mean_img, dtype=D, requires_grad=True)
+        p64 = torch.tensor(pres, dtype=D)
+        gg = g64.reshape(R * N, G, G)
+        ww = w64.reshape(R * N, 4)
+        inv = O.st_insert(gg, ww, H, W).reshape(R, N, H, W) * p64[..., None, None]
+        nz = (O.st_insert(torch.ones_like(gg), ww, H, W).reshape(R, N, H, W) * p64[..., None, None]).sum(1)
+        nz = torch.sigmoid(-10.0 + 20.0 * nz)
+        cv = inv.sum(1) + mi64[None] * nz
+        std = nz * ocfg.output_std + (1 - nz) * ocfg.background_std
+        ll = O.normal_log_prob(torch.tensor(np.repeat(img, K, 0), dtype=D), cv, std).sum((1, 2))
+        (ll * torch.tensor(g_ll, dtype=D)).sum().backward()
+        assert rel_err(d_gl.cpu().numpy(), g64.grad.numpy()) < 1e-4
+        assert rel_err(d_mean.cpu().numpy(), mi64.grad.numpy()) < 1e-4
+        assert rel_err(d_wh.cpu().numpy(), w64.grad.numpy()) < 5e-4
+    finally:
+        lib.sqair_destroy(h)
+
+
+@pytest.mark.parametrize("B,K,T", [(32, 5, 10), (5, 3, 4)])
+def test_elbo_backward(B, K, T):
+    lib, h, F = _handle(K, 3, (50, 50))
+    try:
+        rng = np.random.default_rng(B)
+        lw_t = (rng.standard_normal((T, B * K)) * 20.0 + 300.0).astype(np.float32)
+        dl_t = (rng.standard_normal((T, B * K)) * 2.0 - 3.0).astype(np.float32)
+        d_lw, d_dl = dev(lw_t), dev(dl_t)
+        lw = torch.zeros(B, K, device="cuda"); el = torch.zeros(B, device="cuda"); iw = torch.zeros(B, K, device="cuda")
+        sig = torch.zeros(B, K, device="cuda"); sc = torch.zeros(16, device="cuda"); mo = torch.zeros(8, device="cuda")
+        means = (C.c_void_p * 8)(*([None] * 8))
+        assert lib.sqair_elbo(h, d_lw.data_ptr(), d_dl.data_ptr(), T, B, lw.data_ptr(), el.data_ptr(), iw.data_ptr(),
+                              sig.data_ptr(), sc.data_ptr(), means, 0, mo.data_ptr(), stream()) == 0
+        g_lw = torch.zeros(T, B * K, device="cuda"); g_dl = torch.zeros(T, B * K, device="cuda")
+        assert lib.sqair_elbo_bwd(h, iw.data_ptr(), sig.data_ptr(), T, B, g_lw.data_ptr(), g_dl.data_ptr(), stream()) == 0
+        torch.cuda.synchronize()
+        a = torch.tensor(lw_t, dtype=D, requires_grad=True)
+        b = torch.tensor(dl_t, dtype=D, requires_grad=True)
+        LW = a.sum(0).reshape(B, K)
+        tgt = O.vimco(LW, b.sum(0).reshape(B, K), O.iwae(LW)) / T
+        tgt.backward()
+        assert np.abs(g_lw.cpu().numpy() - a.grad.numpy()).max() < 5e-3 * np.abs(a.grad.numpy()).max()
+        assert np.abs(g_dl.cpu().numpy() - b.grad.numpy()).max() < 5e-3 * np.abs(b.grad.numpy()).max()
+    finally:
+        lib.sqair_destroy(h)
+
+
+@pytest.mark.parametrize("M,K,N,act", [(160, 256, 256, 1), (640, 400, 256, 1), (6400, 56, 256, 1), (160, 311, 128, 2),
+                                       (37, 54, 109, 0), (160, 256, 100, 4), (33, 128, 400, 3)])
+def test_linear_backward_mfma(M, K, N, act):
+    lib, h, F = _handle(2, 3, (50, 50))
+    try:
+        rng = np.random.default_rng(M + K)
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+        b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+        dy = rng.standard_normal((M, N)).astype(np.float32)
+        fn = [lambda v: v, O.elu, torch.tanh, torch.sigmoid, lambda v: O.softplus(v) + 1e-2][act]
+        x64 = torch.tensor(x, dtype=D, requires_grad=True)
+        w64 = torch.tensor(w, dtype=D, requires_grad=True)
+        b64 = torch.tensor(b, dtype=D, requires_grad=True)
+        y64 = fn(x64 @ w64 + b64)
+        (y64 * torch.tensor(dy, dtype=D)).sum().backward()
+        dxx, dww, dyy, dy_out = dev(x), dev(w), dev(dy), dev(y64.detach().numpy())
+        dx = torch.zeros(M, K, device="cuda"); dw = torch.zeros(K, N, device="cuda"); db = torch.zeros(N, device="cuda")
+        nel = ((N + 15) // 16) * ((K + 15) // 16) * 256
+        scratch = torch.empty(2 * nel + 4096 + M * (N + 4) * 2, dtype=torch.float32, device="cuda")
+        rc = lib.sqair_linear_bwd_test(h, dxx.data_ptr(), dww.data_ptr(), dy_out.data_ptr(), dyy.data_ptr(), dx.data_ptr(),
+                                       dw.data_ptr(), db.data_ptr(), M, K, N, act, scratch.data_ptr(), scratch.numel() * 4,
+                                       stream())
+        assert rc == 0, lib.sqair_last_error(h)
+        assert rel_err(dx.cpu().numpy(), x64.grad.numpy()) < 2e-5
+        assert rel_err(dw.cpu().numpy(), w64.grad.numpy()) < 2e-5 * max(1.0, np.sqrt(M / 160.0))
+        assert rel_err(db.cpu().numpy(), b64.grad.numpy()) < 2e-5 * max(1.0, np.sqrt(M / 160.0))
+    finally:
+        lib.sqair_destroy(h)
