@@ -208,6 +208,16 @@ int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, const float
  * from the importance weights and the learning signal sqair_elbo returned. */
 int sqair_elbo_bwd(SqairHandle* h, const float* importance_weights, const float* vimco_signal, int T, int B,
                    float* g_log_w_t, float* g_disc_lp_t, void* stream);
+/* Decoder branch of sqair_backward (first slice of the training step).  Call after sqair_forward (with
+ * SqairOutputs.glimpse == NULL so the decoded glimpses stay in the workspace) and sqair_elbo on the same
+ * workspace.  Writes the gradients of the VIMCO target w.r.t. dec.mean_img, dec.l{0,1,2}.{w,b}, dec.output_scale
+ * into flat_grad (flat-parameter layout; other entries untouched) and, optionally, the seed gradients on the
+ * merged latents d_rec [T, B'*N, 64] (record order: where 0:4, what 4:54). */
+int64_t sqair_backward_scratch_bytes(const SqairHandle* h, int T, int B);
+int sqair_backward_decoder(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
+                           const float* importance_weights, const float* vimco_signal, int T, int B,
+                           void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
+                           float* flat_grad, float* d_rec_out, void* stream);
 /* Dense layer backward on the MFMA path (test helper): y = act(x W + b) forward; given dy returns dx [M,K],
  * dw [K,N] (reference [in,out] layout) and db [N]. */
 int sqair_linear_bwd_test(SqairHandle* h, const float* x, const float* w, const float* y, const float* dy, float* dx,

@@ -78,6 +78,9 @@ _PROTOS = {
     "sqair_st_insert_loglik_bwd": (C.c_int, [C.c_void_p] * 11 + [C.c_int64, C.c_int, C.c_void_p]),
     "sqair_elbo_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
+    "sqair_backward_scratch_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    "sqair_backward_decoder": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "sqair_linear_bwd_test": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_int64, C.c_void_p]),
     "sqair_debug_layers": (C.c_int, [C.c_void_p]),
     "sqair_debug_layer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),

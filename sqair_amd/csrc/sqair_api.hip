@@ -42,6 +42,9 @@ struct SqairHandle {
   POff po;
   // packing plan
   PackedLayer layers[L_COUNT];
+  PackedLayer layersT[L_COUNT];     // transposed packs (dX = dY W^T), K' = padded N, N' = padded concat K
+  std::vector<int> rowmaps;         // per layer: A-position -> reference row of the FIRST column block (wgrad)
+  int64_t rowmap_off[L_COUNT];
   std::vector<int> widx;            // per packed weight element: index into flat params or -1
   std::vector<int> bidx_a, bidx_b;  // per packed bias element
   int64_t packed_w = 0, packed_b = 0;
@@ -421,6 +424,35 @@ static void build_plan(SqairHandle* h) {
   simple(L_DEC2, "dec.l2", nh, G2);
 }
 
+// Transposed packs for the backward pass: dA_cat [M, 16 kc] = dPre [M, N] W^T with the same zero padding, so the
+// gradient of a z-record segment comes out in record order.  Built from the forward plan element by element.
+static void build_plan_T(SqairHandle* h) {
+  for (int id = 0; id < L_COUNT; ++id) {
+    const PackedLayer& L = h->layers[id];
+    PackedLayer& T = h->layersT[id];
+    T.kc = L.nt;            // reduction over the (padded) forward outputs
+    T.nt = L.kc;            // one output tile per forward K-chunk
+    T.N = L.kc * 16;
+    T.seg_width = {L.N};
+    T.w_off = h->packed_w;
+    T.b_off = h->packed_b;
+    const int64_t nel = (int64_t)T.nt * T.kc * 256;
+    h->widx.resize(h->packed_w + nel, -1);
+    h->bidx_a.resize(h->packed_b + T.nt * 16, -1);
+    h->bidx_b.resize(h->packed_b + T.nt * 16, -1);
+    for (int k = 0; k < L.kc * 16; ++k)
+      for (int n = 0; n < L.nt * 16; ++n) {
+        const int64_t f = L.w_off + ((((int64_t)(n / 16) * L.kc + k / 16) * 64) + ((k % 16) / 4) * 16 + n % 16) * 4 + k % 4;
+        const int src = h->widx[f];
+        if (src < 0) continue;
+        const int64_t t = T.w_off + ((((int64_t)(k / 16) * T.kc + n / 16) * 64) + ((n % 16) / 4) * 16 + k % 16) * 4 + n % 4;
+        h->widx[t] = src;
+      }
+    h->packed_w += nel;
+    h->packed_b += T.nt * 16;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C-ABI: lifetime / introspection
 // ------------------------------------------------------------------------------------------------
@@ -440,6 +472,7 @@ extern "C" int sqair_create(const SqairConfig* cfg, SqairHandle** out) {
   h->pidx["prop.prior_gru.uh.w"] = h->pidx["prop.prior_gru.uh"];
   h->pidx["prop.temporal_gru.uh.w"] = h->pidx["prop.temporal_gru.uh"];
   build_plan(h);
+  build_plan_T(h);
   *out = h;
   return 0;
 }
@@ -1174,7 +1207,13 @@ extern "C" int sqair_debug_plan(const SqairHandle* h, int id, int* widx, int* bi
 // given dL/dy returns dL/dx (k_linear on the transposed pack), dL/dW and dL/db (k_wgrad).
 // ------------------------------------------------------------------------------------------------
 int sq_launch_wgrad(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int Kdim,
-                    int Ndim, int accumulate, hipStream_t s);
+                    int Ndim, int accumulate, hipStream_t s, const int* rowmap = nullptr, const float* alpha_ptr = nullptr);
+int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_ld, const float* img, const float* mean_img,
+                                const float* g_ll, float* d_glimpse, float* d_rec, int d_rec_ld, float* d_mean_rows,
+                                float std_fg, float std_bg, int T, Dims d, hipStream_t s);
+int sq_launch_reduce_rows(const float* rows, float* out, int R, int P, int accumulate, hipStream_t s);
+int sq_launch_elbo_bwd(const float* iw, const float* sig, int T, int B, int K, float* g_lw, float* g_dl, hipStream_t s);
+int sq_launch_dot_scale(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s);
 int sq_launch_dact(const float* d_out, const float* out, float* d_pre, int64_t n, int act, hipStream_t s);
 
 extern "C" int sqair_linear_bwd_test(SqairHandle* h, const float* x, const float* wmat, const float* y, const float* dy,
@@ -1220,5 +1259,104 @@ extern "C" int sqair_linear_bwd_test(SqairHandle* h, const float* x, const float
   if (sq_launch_linear(l.a, L, s) != 0) { sq_set_error(h, "sqair_linear_bwd_test: A-operand contract violated"); return -5; }
   SQ_CHECK_HIP(hipGetLastError());
   SQ_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sqair_backward, decoder branch (first slice of the training step).
+// Must follow sqair_forward + sqair_elbo on the same workspace (it reads the merged records, decoder activations
+// and glimpses of all T frames the forward pass left there).  Computes
+//   dL/d(log w_t) from the VIMCO target  ->  insert / log-likelihood adjoint of all T frames  ->  three dense
+//   layers backward (dX through the transposed packs, dW / db through k_wgrad over M = T*B'*N rows)
+// and writes the gradients of every decoder parameter (dec.mean_img, dec.l0-2.{w,b}, dec.output_scale) into
+// flat_grad (other entries untouched) plus the seed gradients on the merged latents d_rec [T, B'*N, 64] (record
+// order: where 0:4, what 4:54) that the recurrent part of the backward pass will consume.
+// ------------------------------------------------------------------------------------------------
+extern "C" int64_t sqair_backward_scratch_bytes(const SqairHandle* h, int T, int B) {
+  if (!h || T < 1 || B < 1) return -1;
+  const SqairConfig& c = h->cfg;
+  const int64_t R = (int64_t)B * c.k_particles, M = R * c.n_steps_per_image, MT = M * T;
+  const int64_t G2 = c.glimpse_size * c.glimpse_size, P_ = c.img_h * c.img_w, nh = c.n_hidden;
+  return (2 * align64(T * R) + align64(MT * G2) + align64(T * R * P_) + 2 * align64(MT * (nh > G2 ? nh : G2)) +
+          align64(MT * 64) + 1024) * 4;
+}
+
+extern "C" int sqair_backward_decoder(SqairHandle* h, const float* flat, const void* packedv, const float* obs,
+                                      const float* importance_weights, const float* vimco_signal, int T, int B,
+                                      void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
+                                      float* flat_grad, float* d_rec_out, void* stream) {
+  if (!h || !flat || !packedv || !obs || !importance_weights || !vimco_signal || !workspace || !scratch || !flat_grad) return -1;
+  if (workspace_bytes < sqair_workspace_bytes(h, T, B) || scratch_bytes < sqair_backward_scratch_bytes(h, T, B)) {
+    sq_set_error(h, "sqair_backward_decoder: workspace / scratch too small");
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const float* packed = (const float*)packedv;
+  const SqairConfig& c = h->cfg;
+  const int nh = c.n_hidden, nw = c.n_what, N = c.n_steps_per_image, K = c.k_particles;
+  const int R = B * K, M = R * N, MT = M * T, G2 = c.glimpse_size * c.glimpse_size, P_ = c.img_h * c.img_w;
+  Dims d{c.img_h, c.img_w, c.glimpse_size, N, nw, nh, K, R, B, 4 + nw + 1};
+  Workspace w = carve(h, T, B, (float*)workspace);
+  const PackedLayout pl = packed_layout(h);
+  const int RW = rec::W;
+  // scratch carve
+  float* sc = (float*)scratch;
+  const int64_t big = (int64_t)MT * (nh > G2 ? nh : G2);
+  float* g_lw = sc; sc += align64((int64_t)T * R);  // every carve 256-byte aligned (GEMM A-operand contract)
+  float* g_dl = sc; sc += align64((int64_t)T * R);
+  float* d_gl = sc; sc += align64((int64_t)MT * G2);
+  float* d_mean_rows = sc; sc += align64((int64_t)T * R * P_);
+  float* bufa = sc; sc += align64(big);
+  float* bufb = sc; sc += align64(big);
+  float* d_rec = sc; sc += align64((int64_t)MT * 64);
+  const float* rec_all = w.rec_m_all + (size_t)M * RW;
+  const float* gl = w.glimpse;  // forward wrote the decoded glimpses here unless the caller asked for the output tensor
+  sq_launch_elbo_bwd(importance_weights, vimco_signal, T, B, K, g_lw, g_dl, s);
+  SQ_CHECK_HIP(hipMemsetAsync(d_rec, 0, (size_t)MT * 64 * 4, s));
+  sq_launch_insert_bwd_frames(gl, rec_all, RW, obs, flat + h->po.dec_mean_img, g_lw, d_gl, d_rec + rec::WHERE, 64, d_mean_rows,
+                              c.output_std, c.background_std, T, d, s);
+  sq_launch_reduce_rows(d_mean_rows, flat_grad + h->po.dec_mean_img, T * R, P_, 0, s);
+  // ---- DEC2: glimpse = scale * (dec_b W2 + b2)
+  const float* scale = flat + h->po.dec_output_scale;
+  sq_launch_dot_scale(d_gl, gl, (int64_t)MT * G2, scale, flat_grad + h->po.dec_output_scale, s);
+  sq_launch_wgrad(w.dec_b, nh, d_gl, G2, flat_grad + P(h, "dec.l2.w"), G2, flat_grad + P(h, "dec.l2.b"), MT, nh, G2, 0, s,
+                  nullptr, scale);
+  auto dx = [&](LayerId id, const float* dpre, int ld, int width, float* outp, int out_ld, const float* scale_ptr) -> int {
+    const PackedLayer& LT = h->layersT[id];
+    Lin l;
+    l.seg(dpre, ld, width).out(outp, out_ld).act(ACT_NONE);
+    l.a.scale_ptr = scale_ptr;
+    l.a.wp = packed + pl.w + LT.w_off; l.a.wzero = packed + pl.w; l.a.bias = packed + pl.b + LT.b_off;
+    l.a.M = MT; l.a.N = LT.N;
+    return sq_launch_linear(l.a, LT, s);
+  };
+  if (dx(L_DEC2, d_gl, G2, G2, bufa, nh, scale) != 0) { sq_set_error(h, "backward: DEC2 dX contract"); return -5; }
+  sq_launch_dact(bufa, w.dec_b, bufb, (int64_t)MT * nh, ACT_ELU, s);            // bufb = dPre of layer 1
+  sq_launch_wgrad(w.dec_a, nh, bufb, nh, flat_grad + P(h, "dec.l1.w"), nh, flat_grad + P(h, "dec.l1.b"), MT, nh, nh, 0, s);
+  if (dx(L_DEC1, bufb, nh, nh, bufa, nh, nullptr) != 0) { sq_set_error(h, "backward: DEC1 dX contract"); return -5; }
+  sq_launch_dact(bufa, w.dec_a, bufb, (int64_t)MT * nh, ACT_ELU, s);            // bufb = dPre of layer 0
+  // layer 0 reads the z-record: positions 4..53 are `what` -> rows 0..nw-1 of dec.l0.w
+  {
+    std::vector<int> rm(rec::ZW, -1);
+    for (int i = 0; i < nw; ++i) rm[rec::WHAT + i] = i;
+    int* d_rm = (int*)sc;  // 1024-float tail of the scratch
+    SQ_CHECK_HIP(hipMemcpyAsync(d_rm, rm.data(), rec::ZW * 4, hipMemcpyHostToDevice, s));
+    SQ_CHECK_HIP(hipStreamSynchronize(s));
+    sq_launch_wgrad(rec_all, RW, bufb, nh, flat_grad + P(h, "dec.l0.w"), nh, flat_grad + P(h, "dec.l0.b"), MT, rec::ZW, nh, 0, s,
+                    d_rm, nullptr);
+  }
+  // d what of the merged records: accumulate onto the d where the insert adjoint already wrote (disjoint columns)
+  {
+    const PackedLayer& LT = h->layersT[L_DEC0];
+    Lin l;
+    l.seg(bufb, nh, nh).out(bufa, 64).act(ACT_NONE);
+    l.a.wp = packed + pl.w + LT.w_off; l.a.wzero = packed + pl.w; l.a.bias = packed + pl.b + LT.b_off;
+    l.a.M = MT; l.a.N = LT.N;
+    l.a.add = d_rec; l.a.add_ld = 64; l.a.add_n = 64;
+    if (sq_launch_linear(l.a, LT, s) != 0) { sq_set_error(h, "backward: DEC0 dX contract"); return -5; }
+    SQ_CHECK_HIP(hipMemcpyAsync(d_rec, bufa, (size_t)MT * 64 * 4, hipMemcpyDeviceToDevice, s));
+  }
+  if (d_rec_out) SQ_CHECK_HIP(hipMemcpyAsync(d_rec_out, d_rec, (size_t)MT * 64 * 4, hipMemcpyDeviceToDevice, s));
+  SQ_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -125,6 +125,9 @@ struct InsertBwdArgs {
   float* d_where;            // [R,N,4]
   float* d_mean_rows;        // [R,H*W] per-row contribution to d mean_img
   float std_fg, std_bg;
+  const float* rec;          // alternatively: merged slot records [.., rec_ld] (where at +0, presence at +54)
+  int rec_ld;
+  int dw_ld;                 // leading dimension of d_where rows (4 = plain, 64 = gradient records)
 };
 
 __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a, const Dims d) {
@@ -138,13 +141,17 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   float* co_s = pres_s + N;           // N * 4  (sx, sy, tx, ty)
   float* acc_s = co_s + N * 4;        // 4 waves * N * 4
   const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int fr = blockIdx.y;  // frame
   const int b = r / d.K;
-  for (int i = tid; i < N * G2; i += 256) { gl_s[i] = a.glimpse[(size_t)r * N * G2 + i]; dg_s[i] = 0.0f; }
+  const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot-row of this (frame, row)
+  const size_t frr = (size_t)fr * d.R + r;
+  for (int i = tid; i < N * G2; i += 256) { gl_s[i] = a.glimpse[fs * G2 + i]; dg_s[i] = 0.0f; }
   if (tid < N * 4) {
-    const float l = a.where[(size_t)r * N * 4 + tid];
+    const int k = tid >> 2, c = tid & 3;
+    const float l = a.rec ? a.rec[(fs + k) * a.rec_ld + rec::WHERE + c] : a.where[fs * 4 + tid];
     co_s[tid] = (tid & 2) ? tanhf(l) : fmaxf(sq_sigmoid(l), 1e-4f);
   }
-  if (tid < N) pres_s[tid] = a.pres[(size_t)r * N + tid];
+  if (tid < N) pres_s[tid] = a.rec ? a.rec[(fs + tid) * a.rec_ld + rec::PRES] : a.pres[fs + tid];
   __syncthreads();
   for (int i = tid; i < N * (W + H); i += 256) {
     const int k = i / (W + H), q = i % (W + H);
@@ -157,8 +164,8 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
     if (is_y) yt_s[k * H + j] = g; else xt_s[k * W + j] = g;
   }
   __syncthreads();
-  const float gll = a.g_ll[r];
-  const float* img = a.img + (size_t)b * P;
+  const float gll = a.g_ll[frr];
+  const float* img = a.img + ((size_t)fr * d.B + b) * P;
   float dco[SQ_MAXN][4];
 #pragma unroll
   for (int k = 0; k < SQ_MAXN; ++k) dco[k][0] = dco[k][1] = dco[k][2] = dco[k][3] = 0.0f;
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
     const float g_sd = gll * (diff * diff / (sd * sd * sd) - 1.0f / sd);
     const float g_m = g_cv * mean + g_sd * (a.std_fg - a.std_bg);
     const float g_ms = g_m * 20.0f * m * (1.0f - m);
-    a.d_mean_rows[(size_t)r * P + pix] = g_cv * m;
+    a.d_mean_rows[frr * P + pix] = g_cv * m;
     for (int k = 0; k < N; ++k) {
       const float pk = pres_s[k];
       if (pk == 0.0f) continue;
@@ -249,13 +256,13 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
       if (lane == 0) acc_s[(wave * N + k) * 4 + c] = v;
     }
   __syncthreads();
-  for (int i = tid; i < N * G2; i += 256) a.d_glimpse[(size_t)r * N * G2 + i] = dg_s[i];
+  for (int i = tid; i < N * G2; i += 256) a.d_glimpse[fs * G2 + i] = dg_s[i];
   if (tid < N * 4) {
     const int k = tid >> 2, c = tid & 3;
     const float tot = acc_s[(0 * N + k) * 4 + c] + acc_s[(1 * N + k) * 4 + c] + acc_s[(2 * N + k) * 4 + c] + acc_s[(3 * N + k) * 4 + c];
-    const float l = a.where[(size_t)r * N * 4 + tid];
+    const float l = a.rec ? a.rec[(fs + k) * a.rec_ld + rec::WHERE + c] : a.where[fs * 4 + tid];
     const float sg = sq_sigmoid(l), th = tanhf(l);
-    a.d_where[(size_t)r * N * 4 + tid] = tot * ((c & 2) ? 1.0f - th * th : sg * (1.0f - sg));
+    a.d_where[(fs + k) * a.dw_ld + c] = tot * ((c & 2) ? 1.0f - th * th : sg * (1.0f - sg));
   }
 }
 
@@ -281,9 +288,9 @@ extern "C" int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, 
   const int P = d.H * d.W;
   if (scratch_bytes < (int64_t)d.R * P * 4) return -1;
   InsertBwdArgs a{glimpse, where_logits, presence, img, mean_img, g_data_ll, d_glimpse, d_where_logits, (float*)scratch,
-                  c.output_std, c.background_std};
+                  c.output_std, c.background_std, nullptr, 0, 4};
   const size_t shm = ((size_t)2 * d.N * d.G * d.G + (size_t)d.N * (d.W + d.H) + d.N + d.N * 4 + 4 * d.N * 4) * sizeof(float);
-  hipLaunchKernelGGL(k_insert_loglik_bwd, dim3(d.R), dim3(256), shm, (hipStream_t)stream, a, d);
+  hipLaunchKernelGGL(k_insert_loglik_bwd, dim3(d.R, 1), dim3(256), shm, (hipStream_t)stream, a, d);
   hipLaunchKernelGGL(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch,
                      d_mean_img, d.R, P, 0);
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -324,7 +331,8 @@ extern "C" int sqair_elbo_bwd(SqairHandle* h, const float* importance_weights, c
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int lda, const float* __restrict__ dY, int ldy,
                                                float* __restrict__ dW, int ldw, float* __restrict__ db, int M, int Kdim,
-                                               int Ndim, int accumulate) {
+                                               int Ndim, int accumulate, const int* __restrict__ rowmap,
+                                               const float* __restrict__ alpha_ptr) {
   __shared__ float red[4 * 256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int k0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
@@ -353,11 +361,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
 #pragma unroll
   for (int i = 0; i < 4; ++i) r[(4 * mq + i) * 16 + (lane & 15)] = acc[i];
   __syncthreads();
-  const float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+  const float alpha = alpha_ptr != nullptr ? alpha_ptr[0] : 1.0f;
+  const float v = (red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid]) * alpha;
   const int k = k0 + (tid >> 4), n = n0 + (tid & 15);
   if (k < Kdim && n < Ndim) {
-    float* p = dW + (size_t)k * ldw + n;
-    *p = accumulate ? *p + v : v;
+    const int row = rowmap != nullptr ? rowmap[k] : k;  // A-segment position -> row of the reference matrix (-1: none)
+    if (row >= 0) {
+      float* p = dW + (size_t)row * ldw + n;
+      *p = accumulate ? *p + v : v;
+    }
   }
   if (db != nullptr && blockIdx.x == 0) {
     // column sums: lanes with the same (l & 15) across mq and waves
@@ -367,16 +379,56 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
     if (lane < 16) red[wave * 16 + lane] = bsum;
     __syncthreads();
     if (tid < 16 && n0 + tid < Ndim) {
-      const float s = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+      const float s = (red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid]) * alpha;
       db[n0 + tid] = accumulate ? db[n0 + tid] + s : s;
     }
   }
 }
 
 int sq_launch_wgrad(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int Kdim,
-                    int Ndim, int accumulate, hipStream_t s) {
+                    int Ndim, int accumulate, hipStream_t s, const int* rowmap, const float* alpha_ptr) {
   hipLaunchKernelGGL(k_wgrad, dim3((Kdim + 15) / 16, (Ndim + 15) / 16), dim3(256), 0, s, A, lda, dY, ldy, dW, ldw, db, M,
-                     Kdim, Ndim, accumulate);
+                     Kdim, Ndim, accumulate, rowmap, alpha_ptr);
+  return 0;
+}
+
+// batched insert/log-likelihood adjoint over T frames on merged slot records (decoder branch of sqair_backward)
+int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_ld, const float* img, const float* mean_img,
+                                const float* g_ll, float* d_glimpse, float* d_rec, int d_rec_ld, float* d_mean_rows,
+                                float std_fg, float std_bg, int T, Dims d, hipStream_t s) {
+  InsertBwdArgs a{glimpse, nullptr, nullptr, img, mean_img, g_ll, d_glimpse, d_rec, d_mean_rows, std_fg, std_bg, rec, rec_ld,
+                  d_rec_ld};
+  const size_t shm = ((size_t)2 * d.N * d.G * d.G + (size_t)d.N * (d.W + d.H) + d.N + d.N * 4 + 4 * d.N * 4) * sizeof(float);
+  hipLaunchKernelGGL(k_insert_loglik_bwd, dim3(d.R, T), dim3(256), shm, s, a, d);
+  return 0;
+}
+int sq_launch_reduce_rows(const float* rows, float* out, int R, int P, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, s, rows, out, R, P, accumulate);
+  return 0;
+}
+int sq_launch_elbo_bwd(const float* iw, const float* sig, int T, int B, int K, float* g_lw, float* g_dl, hipStream_t s) {
+  const int n = T * B * K;
+  hipLaunchKernelGGL(k_elbo_bwd, dim3((n + 255) / 256), dim3(256), 0, s, iw, sig, T, B, K, g_lw, g_dl);
+  return 0;
+}
+
+// d(output_scale) = sum(d_glimpse * glimpse) / scale   (glimpse = scale * raw; modules.py:144-147)
+__global__ void k_dot_scale(const float* __restrict__ a, const float* __restrict__ b, int64_t n, const float* __restrict__ scale,
+                            float* __restrict__ out) {
+  __shared__ float red[16];
+  float acc = 0.0f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) acc += a[i] * b[i];
+  acc = sq_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    out[0] = t / scale[0];
+  }
+}
+int sq_launch_dot_scale(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_dot_scale, dim3(1), dim3(1024), 0, s, a, b, n, scale, out);
   return 0;
 }
 

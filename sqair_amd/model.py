@@ -201,6 +201,32 @@ class SqairCore(object):
                 self.c_means, len(self.mean_names), self.iw_means.data_ptr(), self._stream()), "sqair_elbo")
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
+    def backward_decoder(self):
+        """Decoder branch of the backward pass (first slice of the training step, see include/sqair_hip.h):
+        gradients of the VIMCO target w.r.t. the decoder parameters as a dict name -> tensor, plus the seed
+        gradients on the merged latents.  Requires a preceding forward() whose outputs did not request `glimpse`."""
+        assert "glimpse" not in self.out, "bind(outputs=...) without 'glimpse' so that the glimpses stay in the workspace"
+        R, M = self.B * self.K, self.B * self.K * self.N
+        with torch.cuda.device(self.device):
+            nb = self.lib.sqair_backward_scratch_bytes(self.handle, self.T, self.B)
+            scratch = torch.empty(nb // 4, dtype=torch.float32, device=self.device)
+            flat_grad = torch.zeros_like(self.flat)
+            d_rec = torch.zeros(self.T, M, 64, dtype=torch.float32, device=self.device)
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            _capi.check(self.handle, self.lib.sqair_backward_decoder(
+                self.handle, self.flat.data_ptr(), self.packed.data_ptr(), self.obs.data_ptr(),
+                self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.T, self.B,
+                self.workspace.data_ptr(), self.ws_bytes, scratch.data_ptr(), nb, flat_grad.data_ptr(), d_rec.data_ptr(),
+                self._stream()), "sqair_backward_decoder")
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            torch.cuda.synchronize(self.device)
+        grads = {}
+        for name, (o, shape) in self.offsets.items():
+            if name.startswith("dec."):
+                n = int(np.prod(shape)) if len(shape) else 1
+                grads[name] = flat_grad[o:o + n].reshape(shape).clone()
+        return grads, d_rec
+
     def profile_linear(self, t_offset=0):
         """Eager forward with HIP events around every dense-layer launch; returns a dict (see
         sqair_profile_forward in include/sqair_hip.h)."""

@@ -159,3 +159,36 @@ def test_linear_backward_mfma(M, K, N, act):
         assert rel_err(db.cpu().numpy(), b64.grad.numpy()) < 2e-5 * max(1.0, np.sqrt(M / 160.0))
     finally:
         lib.sqair_destroy(h)
+
+
+@pytest.mark.parametrize("K,N,T,B,hw", [(5, 4, 5, 3, (50, 50)), (2, 3, 3, 4, (32, 40))])
+def test_backward_decoder_branch_matches_autograd(K, N, T, B, hw):
+    """Gradients of the VIMCO target w.r.t. every decoder parameter (they depend on the decoder path only) after a
+    full HIP forward pass, against autograd through the whole oracle model."""
+    from sqair_amd.data import make_sequences, to_float
+    from sqair_amd.model import Model, SqairCore
+    from tests.hip_util import draw_noise, params32
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=min(28, hw[0] // 2), seed=11)
+    obs = to_float(d["imgs"])
+    P = params32(F, hw, 4, 0.05, obs.mean((0, 1)))
+    core = SqairCore(F, hw)
+    core.set_params(P)
+    names = ["log_weights_per_timestep", "discrete_log_prob", "presence", "prop_pres", "disc_pres"]
+    m = Model(obs, None, core, K, outputs=names)
+    for attempt in range(50):
+        noise = draw_noise(np.random.default_rng(100 + attempt), T, B * K, N, 55)
+        orc = O.SqairOracle(P, O.make_cfg(F, hw), torch.float64, requires_grad=True)
+        ref = orc.model(obs, noise)
+        m.run(noise=noise)
+        torch.cuda.synchronize()
+        if np.array_equal(m.prop_pres.cpu().numpy(), ref.prop_pres.detach().numpy()) and \
+                np.array_equal(m.disc_pres.cpu().numpy(), ref.disc_pres.detach().numpy()):
+            break
+    orc.make_target(ref).backward()
+    grads, d_rec = core.backward_decoder()
+    for name, g in grads.items():
+        want = orc.P[name].grad.numpy()
+        got = g.cpu().numpy().reshape(want.shape)
+        assert np.abs(got - want).max() <= 2e-3 * max(np.abs(want).max(), 1e-12), (name, np.abs(got - want).max(), np.abs(want).max())
+    assert np.isfinite(d_rec.cpu().numpy()).all() and float(d_rec.abs().sum()) > 0
