@@ -131,3 +131,48 @@ def test_cfg2_full_size_properties():
         assert agree.mean() > 0.9
         a, b = m3.log_weights.cpu().numpy()[agree], ref.log_weights.numpy()[agree]
         assert np.abs(a - b).max() <= REL * np.abs(b).max()
+
+
+@pytest.mark.parametrize("cfg_id,B", [(4, 8), (5, 4)])
+def test_other_baseline_configs_vs_oracle(cfg_id, B):
+    """BASELINE.json configs[3] (4 digits, max_steps = 6) and configs[4] (128x128 frames) at reduced batch against the
+    fp64 oracle; their full-size shapes run in test_baseline_configs_full_size."""
+    ov, obs, nums, _ = config_inputs(cfg_id, B=B)
+    F = make_flags(**ov)
+    hw = tuple(obs.shape[2:])
+    T, K, N = 4, int(F.k_particles), int(F.n_steps_per_image)
+    obs, nums = obs[:T], nums[:T]
+    P = params32(F, hw, 7, 0.03, obs.mean((0, 1)))
+    for attempt in range(30):
+        noise = draw_noise(np.random.default_rng(50 + attempt), T, B * K, N, 55)
+        ref = run_oracle(F, hw, P, obs, noise, nums=nums)
+        m = run_hip(F, hw, P, obs, noise, nums=nums)
+        if np.array_equal(m.prop_pres.cpu().numpy(), ref.prop_pres.numpy()) and \
+                np.array_equal(m.disc_pres.cpu().numpy(), ref.disc_pres.numpy()):
+            break
+    ref_out = {k: v.numpy() for k, v in ref.outputs.items() if not k.startswith("_")}
+    ref_model = {k: getattr(ref, k).numpy() for k in ("log_weights", "elbo_iwae_per_example", "elbo_vae", "elbo_iwae",
+                                                      "data_ll", "kl", "log_p_z", "log_q_z_given_x")}
+    _check_against(m, ref_out, ref_model, list(ref_out), T)
+
+
+@pytest.mark.parametrize("cfg_id", [4, 5])
+def test_baseline_configs_full_size(cfg_id):
+    """Full-size shapes of configs[3] (B=64, K=5, N=6) and configs[4] (128x128, B=32, K=5, N=4): finite results, graph
+    replay == eager, IWAE >= VAE bound, at most N objects, ids consistent."""
+    ov, obs, nums, _ = config_inputs(cfg_id)
+    F = make_flags(**ov)
+    hw = tuple(obs.shape[2:])
+    T, B, K, N = obs.shape[0], obs.shape[1], int(F.k_particles), int(F.n_steps_per_image)
+    P = params32(F, hw, 0, 0.02, obs.mean((0, 1)))
+    noise = draw_noise(np.random.default_rng(1), T, B * K, N, 55)
+    m1 = run_hip(F, hw, P, obs, noise, nums=nums, outputs=["log_weights_per_timestep", "discrete_log_prob", "presence", "obj_id"])
+    lw = m1.log_weights.cpu().numpy().copy()
+    assert np.isfinite(lw).all()
+    m2 = run_hip(F, hw, P, obs, noise, nums=nums, use_graph=True,
+                 outputs=["log_weights_per_timestep", "discrete_log_prob", "presence", "obj_id"])
+    assert np.array_equal(m2.log_weights.cpu().numpy(), lw)
+    assert float(m1.elbo_iwae) >= float(m1.elbo_vae) - 1e-2
+    pres = m1.presence.cpu().numpy()
+    assert pres.sum(-1).max() <= N
+    assert ((m1.obj_id.cpu().numpy() >= 0) == (pres > 0)).all()
