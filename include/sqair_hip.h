@@ -142,6 +142,14 @@ int sqair_forward(SqairHandle* h, const float* flat_params, const void* packed, 
                   const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
                   void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Training-mode forward pass: same launch sequence and results, but every intermediate the backward pass needs
+ * (per-frame and per-slot activations, GRU gates, compaction permutation) is kept in the larger workspace of
+ * sqair_train_workspace_bytes; sqair_backward consumes it. */
+int64_t sqair_train_workspace_bytes(const SqairHandle* h, int T, int B);
+int sqair_forward_train(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
+                        const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Same launch sequence recorded once into a HIP graph and replayed (the T x 2N sequential steps
  * are launch-latency bound).  Pointers are frozen at capture time: the caller keeps the same
  * buffers and refreshes their contents before each sqair_graph_launch. */
@@ -218,6 +226,12 @@ int sqair_backward_decoder(SqairHandle* h, const float* flat_params, const void*
                            const float* importance_weights, const float* vimco_signal, int T, int B,
                            void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
                            float* flat_grad, float* d_rec_out, void* stream);
+/* Fused optimiser step on the flat buffers: tf.train.RMSPropOptimizer(lr, momentum=0.9) as used by the
+ * reference driver (sqair/scripts/experiment.py:140; TF defaults decay 0.9, epsilon 1e-10, ms initialised to 1):
+ * ms <- decay ms + (1-decay) g^2; mom <- momentum mom + lr g / sqrt(ms + eps); theta <- theta - mom, with
+ * g = grad_scale * flat_grad (grad_scale = 1/world after the data-parallel all-reduce(sum)). */
+int sqair_rmsprop_step(SqairHandle* h, float* flat_params, const float* flat_grad, float* ms, float* mom, int64_t n,
+                       float lr, float decay, float momentum, float epsilon, float grad_scale, void* stream);
 /* Dense layer backward on the MFMA path (test helper): y = act(x W + b) forward; given dy returns dx [M,K],
  * dw [K,N] (reference [in,out] layout) and db [N]. */
 int sqair_linear_bwd_test(SqairHandle* h, const float* x, const float* w, const float* y, const float* dy, float* dx,

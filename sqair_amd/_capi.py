@@ -55,6 +55,9 @@ _PROTOS = {
     "sqair_pack_params": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sqair_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                 C.c_int, C.POINTER(SqairOutputs), C.c_void_p, C.c_int64, C.c_void_p]),
+    "sqair_train_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    "sqair_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_int, C.POINTER(SqairOutputs), C.c_void_p, C.c_int64, C.c_void_p]),
     "sqair_graph_capture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_int, C.c_int, C.POINTER(SqairOutputs), C.c_void_p, C.c_int64,
                                       C.c_void_p]),
@@ -81,6 +84,8 @@ _PROTOS = {
     "sqair_backward_scratch_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
     "sqair_backward_decoder": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sqair_rmsprop_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "sqair_linear_bwd_test": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_int64, C.c_void_p]),
     "sqair_debug_layers": (C.c_int, [C.c_void_p]),
     "sqair_debug_layer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),

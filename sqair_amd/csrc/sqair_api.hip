@@ -14,53 +14,7 @@
 //     pre-activations, the prior GRU) is batched over the N slots up front (M = B'*N rows);
 //   * only the truly sequential part (explaining away: slot k needs slot k-1's sample) remains in
 //     the per-slot chain.
-#include <cstdio>
-#include <cstring>
-#include <map>
-
-#include "sqair_glue.h"
-
-struct ParamEntry {
-  std::string name;
-  int64_t off, numel;
-  int rows, cols;
-};
-
-enum LayerId {
-  L_IENC0, L_IENC1, L_PREDISC, L_PRIOR_GRU1, L_PRIOR_GRU2, L_PRIOR_LIN, L_TAU1, L_WB2, L_MASK2, L_GENC0, L_GENC1,
-  L_WHAT_LOC, L_WHAT_HEAD, L_PRE, L_PROP_RNN, L_PROP_T1, L_PROP_T2, L_PROP_T3, L_PROP_GRU1, L_PROP_GRU2,
-  L_PROP_HEADS, L_PROP_S1, L_LAT0, L_LAT1, L_PRED, L_RNCOND, L_DISC_RNN, L_DISC_T1, L_DISC_T2, L_DISC_T3,
-  L_DISC_S1, L_DEC0, L_DEC1, L_DEC2, L_COUNT
-};
-
-struct SqairHandle {
-  SqairConfig cfg;
-  std::string err;
-  std::vector<ParamEntry> params;
-  std::map<std::string, int> pidx;
-  int64_t n_params = 0;
-  POff po;
-  // packing plan
-  PackedLayer layers[L_COUNT];
-  PackedLayer layersT[L_COUNT];     // transposed packs (dX = dY W^T), K' = padded N, N' = padded concat K
-  std::vector<int> rowmaps;         // per layer: A-position -> reference row of the FIRST column block (wgrad)
-  int64_t rowmap_off[L_COUNT];
-  std::vector<int> widx;            // per packed weight element: index into flat params or -1
-  std::vector<int> bidx_a, bidx_b;  // per packed bias element
-  int64_t packed_w = 0, packed_b = 0;
-  bool plan_uploaded_to = false;
-  const void* plan_uploaded_ptr = nullptr;
-  // live profiling of the dominant kernel (sqair_profile_forward)
-  bool prof = false;
-  unsigned long long* prof_ts = nullptr;
-  int prof_n = 0;
-  double prof_flops = 0.0;
-  std::vector<int> prof_layer, prof_m;
-  // graph
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-  int graph_nodes = 0;
-};
+#include "sqair_internal.h"
 
 void sq_set_error(SqairHandle* h, const std::string& msg) {
   if (h) h->err = msg;
@@ -92,7 +46,7 @@ static void add_gru(SqairHandle* h, const std::string& name, int fin, int nh) {
     add_param(h, name + ".b" + g[i], 1, nh);
   }
 }
-static int64_t P(const SqairHandle* h, const std::string& name) {
+int64_t P(const SqairHandle* h, const std::string& name) {
   auto it = h->pidx.find(name);
   if (it == h->pidx.end()) {
     fprintf(stderr, "sqair: unknown parameter %s\n", name.c_str());
@@ -100,7 +54,7 @@ static int64_t P(const SqairHandle* h, const std::string& name) {
   }
   return h->params[it->second].off;
 }
-static int PC(const SqairHandle* h, const std::string& name) { return h->params[h->pidx.at(name)].cols; }
+int PC(const SqairHandle* h, const std::string& name) { return h->params[h->pidx.at(name)].cols; }
 
 static void build_inventory(SqairHandle* h) {
   const SqairConfig& c = h->cfg;
@@ -502,22 +456,7 @@ extern "C" int sqair_get_config(const SqairHandle* h, SqairConfig* out) {
 }
 extern "C" int sqair_noise_width(const SqairHandle* h) { return h ? 4 + h->cfg.n_what + 1 : -1; }
 
-static int64_t align64(int64_t x) { return (x + 63) / 64 * 64; }
 
-// packed buffer = [weights fp32 | biases fp32 | widx int32 | bidx_a | bidx_b], each 256-byte aligned
-struct PackedLayout {
-  int64_t w, b, wi, ba, bb, total;  // offsets in 4-byte words
-};
-static PackedLayout packed_layout(const SqairHandle* h) {
-  PackedLayout p;
-  p.w = 0;
-  p.b = align64(p.w + h->packed_w);
-  p.wi = align64(p.b + h->packed_b);
-  p.ba = align64(p.wi + h->packed_w);
-  p.bb = align64(p.ba + h->packed_b);
-  p.total = align64(p.bb + h->packed_b);
-  return p;
-}
 extern "C" int64_t sqair_packed_bytes(const SqairHandle* h) { return h ? packed_layout(h).total * 4 : -1; }
 
 extern "C" int sqair_pack_params(SqairHandle* h, const float* flat, void* packed, void* stream) {
@@ -540,45 +479,32 @@ extern "C" int sqair_pack_params(SqairHandle* h, const float* flat, void* packed
 }
 
 // ------------------------------------------------------------------------------------------------
-// workspace
+// workspace carve
 // ------------------------------------------------------------------------------------------------
-struct Workspace {
-  float *ienc_a, *ienc_b, *pre_disc;
-  float *rec_m_all, *temporal_m[2], *prior_m[2], *last_id[2];  // rec_m_all: [T+1][M][168] merged records per frame
-  float *rec_p_all, *rec_d_all, *zero_rec, *disc_init_rec;      // [T][M][168] propagation / discovery records
-  float *prop_rnn_init, *disc_rnn_init, *rn_init_state;  // 16-byte aligned copies of small parameter vectors
-  float *temporal_p, *prior_p;
-  float *gz, *grh, *gxh;
-  float *pstats, *hid1, *wb, *mask, *g1, *ea, *eb, *m1, *pre;
-  float *rbuf[2], *t1, *t2, *tp, *g2, *enc, *hraw, *s1, *e1, *e2, *w3_prop, *w3_disc;
-  float *c, *pre_d, *spre, *qz, *pz, *dlp, *dll, *glimpse, *dec_a, *dec_b;
-  unsigned long long* prof_ts;  // [2][PROF_MAX] start / end ticks of profiled k_linear launches
-  int64_t total;  // floats
-};
-constexpr int PROF_MAX = 4096;
-constexpr int PS_LD = 112, ENC_LD = 112, M1_LD = 64, HRAW_LD = 256, WB_LD = 4, TP_LD = 8;
-
-static Workspace carve(const SqairHandle* h, int T, int B, float* base) {
+Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) {
   const SqairConfig& c = h->cfg;
   const int64_t nh = c.n_hidden, N = c.n_steps_per_image, R = (int64_t)B * c.k_particles, M = R * N;
   const int64_t G2 = c.glimpse_size * c.glimpse_size;
   const int64_t pre_ld = h->layers[L_PRE].nt * 16;
   Workspace w;
+  memset(&w, 0, sizeof(w));
+  w.train = train; w.T = T; w.B = B; w.R = (int)R; w.M = (int)M; w.N = (int)N; w.nh = (int)nh;
   int64_t o = 0;
   auto take = [&](int64_t n) {
     float* p = base ? base + o : nullptr;
     o += align64(n);
     return p;
   };
+  const int64_t F = train ? T : 1;          // per-frame multiplicity
+  const int64_t S = train ? 2 * T * N : 1;  // per-slot multiplicity (x R rows)
   w.ienc_a = take((int64_t)T * B * nh);
   w.ienc_b = take((int64_t)T * B * nh);
   w.pre_disc = take((int64_t)T * B * nh);
   w.rec_m_all = take((int64_t)(T + 1) * M * rec::W);
-  for (int i = 0; i < 2; ++i) {
-    w.temporal_m[i] = take(M * nh);
-    w.prior_m[i] = take(M * nh);
-    w.last_id[i] = take(R);
-  }
+  w.temporal_m = take((train ? T + 1 : 2) * M * nh);
+  w.prior_m = take((train ? T + 1 : 2) * M * nh);
+  w.last_id[0] = take(R);
+  w.last_id[1] = take(R);
   w.rec_p_all = take((int64_t)T * M * rec::W);
   w.rec_d_all = take((int64_t)T * M * rec::W);
   w.zero_rec = take(rec::W);
@@ -586,36 +512,45 @@ static Workspace carve(const SqairHandle* h, int T, int B, float* base) {
   w.prop_rnn_init = take(nh);
   w.disc_rnn_init = take(nh);
   w.rn_init_state = take(4);
-  w.temporal_p = take(M * nh);
-  w.prior_p = take(M * nh);
-  w.gz = take(M * nh);
-  w.grh = take(M * nh);
-  w.gxh = take(M * nh);
-  w.pstats = take((int64_t)T * M * PS_LD);
-  w.hid1 = take(M * 256);
-  w.wb = take(M * WB_LD);
-  w.mask = take(M * G2);
-  w.g1 = take(M * G2);
-  w.ea = take(M * nh);
-  w.eb = take(M * nh);
-  w.m1 = take(M * M1_LD);
-  w.pre = take(M * pre_ld);
-  w.rbuf[0] = take(R * nh);
-  w.rbuf[1] = take(R * nh);
-  w.t1 = take(R * (nh + nh / 2));  // [transform hidden 1 | steps-predictor partial pre-activation]
-  w.e1 = take(R * nh);
-  w.e2 = take(R * nh);
   w.w3_prop = take(nh * 8 + 8);
   w.w3_disc = take(nh * 8 + 8);
-  w.t2 = take(R * nh);
-  w.tp = take(R * TP_LD);
-  w.g2 = take(R * G2);
-  w.enc = take(R * ENC_LD);
-  w.hraw = take(R * HRAW_LD);
-  w.s1 = take(R * 128);
-  w.c = take(R * nh);
-  w.pre_d = take(R * nh);
+  w.temporal_p = take(F * M * nh);
+  w.prior_p = take(F * M * nh);
+  w.pgz = take(F * M * nh);
+  w.pgr = take(F * M * nh);
+  w.pghc = take(F * M * nh);
+  w.pgrh = take(M * nh);
+  w.pgxh = take(M * nh);
+  w.pstats = take((int64_t)T * M * PS_LD);
   w.spre = take((int64_t)T * R * 128);
+  w.hid1 = take(F * M * 256);
+  w.wb = take(F * M * WB_LD);
+  w.mask = take(F * M * G2);
+  w.g1 = take(F * M * G2);
+  w.pea = take(F * M * nh);
+  w.peb = take(F * M * nh);
+  w.m1 = take(F * M * M1_LD);
+  w.pre = take(M * pre_ld);
+  w.lea = take(F * M * nh);
+  w.leb = take(F * M * nh);
+  w.c = take(F * R * nh);
+  w.pre_d = take(R * nh);
+  w.r = take((train ? S : 2) * R * nh);
+  w.t1 = take(S * R * T1_LD);
+  w.t2 = take(S * R * nh);
+  w.tp = take(S * R * TP_LD);
+  w.g2 = take(S * R * G2);
+  w.e1 = take(S * R * nh);
+  w.e2 = take(S * R * nh);
+  w.enc = take(S * R * ENC_LD);
+  w.hraw = take(S * R * HRAW_LD);
+  w.s1h = take(S * R * S1_LD);
+  w.gz = take(S * R * nh);
+  w.gr = take(S * R * nh);
+  w.ghc = take(S * R * nh);
+  w.grh = take(R * nh);
+  w.gxh = take(R * nh);
+  w.src = (int*)take(train ? (int64_t)T * M : 64);
   w.qz = take((int64_t)T * R);
   w.pz = take((int64_t)T * R);
   w.dlp = take((int64_t)T * R);
@@ -627,43 +562,21 @@ static Workspace carve(const SqairHandle* h, int T, int B, float* base) {
   w.total = o;
   return w;
 }
+static Workspace carve(const SqairHandle* h, int T, int B, float* base) { return sq_carve(h, T, B, base, false); }
 
 extern "C" int64_t sqair_workspace_bytes(const SqairHandle* h, int T, int B) {
   if (!h || T < 1 || B < 1) return -1;
-  return carve(h, T, B, nullptr).total * 4;
+  return sq_carve(h, T, B, nullptr, false).total * 4;
+}
+extern "C" int64_t sqair_train_workspace_bytes(const SqairHandle* h, int T, int B) {
+  if (!h || T < 1 || B < 1) return -1;
+  return sq_carve(h, T, B, nullptr, true).total * 4;
 }
 
 // ------------------------------------------------------------------------------------------------
 // the launch sequence
 // ------------------------------------------------------------------------------------------------
-struct Lin {
-  LinArgs a;
-  Lin() {
-    memset(&a, 0, sizeof(a));
-    a.epi = EPI_ACT;
-    a.act_split = 1 << 30;
-    a.add_rdiv = 1;
-    a.scale = 1.0f;
-  }
-  Lin& seg(const float* p, int ld, int width, int rdiv = 1) {
-    a.seg[a.nseg++] = LinSeg{p, ld, width, rdiv};
-    return *this;
-  }
-  Lin& out(float* p, int ld) { a.out = p; a.out_ld = ld; return *this; }
-  Lin& act(int act) { a.act_a = act; return *this; }
-  Lin& act2(int a0, int a1, int split) { a.act_a = a0; a.act_b = a1; a.act_split = split; return *this; }
-  Lin& add(const float* p, int ld, int n, int rdiv = 1) { a.add = p; a.add_ld = ld; a.add_n = n; a.add_rdiv = rdiv; return *this; }
-  Lin& gru1(const float* hprev, int h_ld, float* rh, int rh_ld, float* xh, int xh_ld, int nh) {
-    a.epi = EPI_GRU1; a.e0 = hprev; a.e0_ld = h_ld; a.o1 = rh; a.o1_ld = rh_ld; a.o2 = xh; a.o2_ld = xh_ld; a.nh = nh;
-    return *this;
-  }
-  Lin& gru2(const float* hprev, int h_ld, const float* z, int z_ld, int nh) {
-    a.epi = EPI_GRU2; a.e0 = hprev; a.e0_ld = h_ld; a.e1 = z; a.e1_ld = z_ld; a.nh = nh;
-    return *this;
-  }
-};
-
-static int run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipStream_t s) {
+int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipStream_t s) {
   const PackedLayer& L = h->layers[id];
   const PackedLayout pl = packed_layout(h);
   if (l.a.nseg != (int)L.seg_width.size()) {
@@ -693,21 +606,15 @@ static int run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, h
   return rc;
 }
 
-#define RUN(l, id, M)                                   \
-  do {                                                  \
-    int _rc = run(h, (l), (id), (M), packed, s);        \
-    if (_rc != 0) return _rc;                           \
-  } while (0)
-
-static int forward_impl(SqairHandle* h, const float* flat, const float* packed, const float* obs, const float* noise,
-                        int T, int B, int t_offset, const SqairOutputs* outp, float* wsbase, int64_t ws_bytes,
-                        hipStream_t s) {
+int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, const float* obs, const float* noise,
+                    int T, int B, int t_offset, const SqairOutputs* outp, float* wsbase, int64_t ws_bytes,
+                    hipStream_t s, bool train) {
   const SqairConfig& c = h->cfg;
   if (!flat || !packed || !obs || !noise || !outp || !wsbase || T < 1 || B < 1) {
     sq_set_error(h, "sqair_forward: null argument or bad T/B");
     return -1;
   }
-  if (ws_bytes < sqair_workspace_bytes(h, T, B)) {
+  if (ws_bytes < sq_carve(h, T, B, nullptr, train).total * 4) {
     sq_set_error(h, "sqair_forward: workspace too small");
     return -1;
   }
@@ -717,19 +624,20 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
   const int nzw = 4 + nw + 1;
   Dims d{c.img_h, c.img_w, c.glimpse_size, N, nw, nh, K, R, B, nzw};
   const POff po = h->po;
-  Workspace w = carve(h, T, B, wsbase);
+  const Workspace w = sq_carve(h, T, B, wsbase, train);
   const int pre_ld = h->layers[L_PRE].nt * 16;
   const int RW = rec::W;
+  const PackedLayout pl = packed_layout(h);
 
   // ---- sequence prologue -----------------------------------------------------------------------
   // The GEMM A-operand contract wants every float it may touch to be finite (padding meets zero weights, but
   // 0 * NaN = NaN) and slot records are read as 56-wide segments before all their fields are written in a frame:
-  // clear the caller's (garbage) workspace once per pass, ~15 MB = a few microseconds
+  // clear the caller's (garbage) workspace once per pass
   SQ_CHECK_HIP(hipMemsetAsync(wsbase, 0, (size_t)((float*)w.prof_ts - wsbase) * 4, s));
   // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
-  sq_launch_init_state(w.rec_m_all, w.temporal_m[0], w.prior_m[0], w.last_id[0], w.disc_init_rec, w.prop_rnn_init,
-                       w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc, (int)P(h, "prop.transform.l2.w"),
-                       (int)P(h, "disc.transform.l2.w"), flat, po, d, s);
+  sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0), w.state(w.prior_m, 0), w.last_id[0], w.disc_init_rec,
+                       w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc,
+                       (int)P(h, "prop.transform.l2.w"), (int)P(h, "disc.transform.l2.w"), flat, po, d, s);
   {  // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
     Lin a; a.seg(obs, P_, P_).out(w.ienc_a, nh).act(ACT_ELU); RUN(a, L_IENC0, T * B);
     Lin b; b.seg(w.ienc_a, nh, nh).out(w.ienc_b, nh).act(ACT_ELU); RUN(b, L_IENC1, T * B);
@@ -746,128 +654,163 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
     float* rec_d_t = w.rec_d_all + (size_t)t * M * RW;
     float* pstats_t = w.pstats + (size_t)t * M * PS_LD;
     float* spre_t = w.spre + (size_t)t * R * 128;
-    const float* temporal_prev = w.temporal_m[pp];
-    const float* prior_prev = w.prior_m[pp];
+    const float* temporal_prev = w.state(w.temporal_m, t);
+    const float* prior_prev = w.state(w.prior_m, t);
+    float* temporal_p = w.frame(w.temporal_p, (int64_t)M * nh, t);
+    float* prior_p = w.frame(w.prior_p, (int64_t)M * nh, t);
+    float* hid1 = w.frame(w.hid1, (int64_t)M * 256, t);
+    float* wb = w.frame(w.wb, (int64_t)M * WB_LD, t);
+    float* mask = w.frame(w.mask, (int64_t)M * G2, t);
+    float* g1 = w.frame(w.g1, (int64_t)M * G2, t);
+    float* pea = w.frame(w.pea, (int64_t)M * nh, t);
+    float* peb = w.frame(w.peb, (int64_t)M * nh, t);
+    float* m1 = w.frame(w.m1, (int64_t)M * M1_LD, t);
+    float* lea = w.frame(w.lea, (int64_t)M * nh, t);
+    float* leb = w.frame(w.leb, (int64_t)M * nh, t);
+    float* cvec = w.frame(w.c, (int64_t)R * nh, t);
 
     // ---- A. propagation prior (propagate.py:68-98): GRU over [what, where]_{t-1}, all slots ----
     {
-      Lin g1; g1.seg(rec_prev, RW, rec::ZW).seg(prior_prev, nh, nh).out(w.gz, nh)
-                .gru1(prior_prev, nh, w.grh, nh, w.gxh, nh, nh);
-      RUN(g1, L_PRIOR_GRU1, M);
-      Lin g2; g2.seg(w.grh, nh, nh).add(w.gxh, nh, nh).out(w.prior_p, nh).gru2(prior_prev, nh, w.gz, nh, nh);
-      RUN(g2, L_PRIOR_GRU2, M);
-      Lin pl; pl.seg(w.prior_p, nh, nh).out(pstats_t, PS_LD); RUN(pl, L_PRIOR_LIN, M);
+      float* pgz = w.frame(w.pgz, (int64_t)M * nh, t);
+      Lin g1l; g1l.seg(rec_prev, RW, rec::ZW).seg(prior_prev, nh, nh).out(pgz, nh)
+                 .gru1(prior_prev, nh, w.pgrh, nh, w.pgxh, nh, nh);
+      if (train) { g1l.a.o3 = w.frame(w.pgr, (int64_t)M * nh, t); g1l.a.o3_ld = nh; }
+      RUN(g1l, L_PRIOR_GRU1, M);
+      Lin g2l; g2l.seg(w.pgrh, nh, nh).add(w.pgxh, nh, nh).out(prior_p, nh).gru2(prior_prev, nh, pgz, nh, nh);
+      if (train) { g2l.a.o1 = w.frame(w.pghc, (int64_t)M * nh, t); g2l.a.o1_ld = nh; }
+      RUN(g2l, L_PRIOR_GRU2, M);
+      Lin pll; pll.seg(prior_p, nh, nh).out(pstats_t, PS_LD); RUN(pll, L_PRIOR_LIN, M);
     }
     // ---- B. where-bias MLP and glimpse-mask MLP of every slot (core.py:292, modules.py:350-356) ----
     {
-      Lin a; a.seg(temporal_prev, nh, nh).out(w.hid1, 256).act(ACT_ELU); RUN(a, L_TAU1, M);
-      Lin b; b.seg(w.hid1, 256, 128).out(w.wb, WB_LD); RUN(b, L_WB2, M);
-      Lin m; m.seg(w.hid1 + 128, 256, 128).out(w.mask, G2).act(ACT_SIGMOID); RUN(m, L_MASK2, M);
+      Lin a; a.seg(temporal_prev, nh, nh).out(hid1, 256).act(ACT_ELU); RUN(a, L_TAU1, M);
+      Lin b; b.seg(hid1, 256, 128).out(wb, WB_LD); RUN(b, L_WB2, M);
+      Lin m; m.seg(hid1 + 128, 256, 128).out(mask, G2).act(ACT_SIGMOID); RUN(m, L_MASK2, M);
     }
     // ---- C. crop #1 at where_{t-1} + bias, masked, encoded -> loc1 (core.py:293-294) ----
     {
       CropArgs ca; memset(&ca, 0, sizeof(ca));
-      ca.mode = CROP_PROP1; ca.img = img; ca.mask = c.masked_glimpse ? w.mask : nullptr; ca.mask_row_mul = N;
-      ca.out = w.g1; ca.out_row_mul = N; ca.rec_prev = rec_prev; ca.wb = w.wb; ca.wb_ld = WB_LD; ca.flat = flat;
+      ca.mode = CROP_PROP1; ca.img = img; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N;
+      ca.out = g1; ca.out_row_mul = N; ca.rec_prev = rec_prev; ca.wb = wb; ca.wb_ld = WB_LD; ca.flat = flat;
       sq_launch_crop(ca, po, d, N, s);
-      Lin a; a.seg(w.g1, G2, G2).out(w.ea, nh).act(ACT_ELU); RUN(a, L_GENC0, M);
-      Lin b; b.seg(w.ea, nh, nh).out(w.eb, nh).act(ACT_ELU); RUN(b, L_GENC1, M);
-      Lin l; l.seg(w.eb, nh, nh).out(w.m1, M1_LD); RUN(l, L_WHAT_LOC, M);
+      Lin a; a.seg(g1, G2, G2).out(pea, nh).act(ACT_ELU); RUN(a, L_GENC0, M);
+      Lin b; b.seg(pea, nh, nh).out(peb, nh).act(ACT_ELU); RUN(b, L_GENC1, M);
+      Lin l; l.seg(peb, nh, nh).out(m1, M1_LD); RUN(l, L_WHAT_LOC, M);
     }
     // ---- D. loop-invariant pre-activations of all slots ----
     {
-      Lin p; p.seg(w.m1, M1_LD, nw).seg(rec_prev, RW, rec::ZW).seg(temporal_prev, nh, nh).out(w.pre, pre_ld);
+      Lin p; p.seg(m1, M1_LD, nw).seg(rec_prev, RW, rec::ZW).seg(temporal_prev, nh, nh).out(w.pre, pre_ld);
       RUN(p, L_PRE, M);
     }
     // ---- E. propagation slots (propagate.py:168-184 static_rnn over PropagationCore) ----
     for (int k = 0; k < N; ++k) {
       const float* pre_k = w.pre + (size_t)k * pre_ld;
       const int pre_rld = N * pre_ld;
-      float* r_k = w.rbuf[k & 1];
+      float* r_k = w.rslot(t, 0, k);
+      const int rl = w.sld(nh), t1l = w.sld(T1_LD), gl2 = w.sld(G2), el = w.sld(ENC_LD), hl = w.sld(HRAW_LD);
+      float* t1 = w.slot(w.t1, T1_LD, t, 0, k);
+      float* t2 = w.slot(w.t2, nh, t, 0, k);
+      float* g2 = w.slot(w.g2, G2, t, 0, k);
+      float* e1 = w.slot(w.e1, nh, t, 0, k);
+      float* e2 = w.slot(w.e2, nh, t, 0, k);
+      float* enc = w.slot(w.enc, ENC_LD, t, 0, k);
+      float* hraw = w.slot(w.hraw, HRAW_LD, t, 0, k);
+      float* gz = w.slot(w.gz, nh, t, 0, k);
       {
         Lin a;
         if (k == 0) a.seg(w.zero_rec, 0, rec::ZW).seg(w.prop_rnn_init, 0, nh);
-        else a.seg(rec_p_t + (size_t)(k - 1) * RW, N * RW, rec::ZW).seg(w.rbuf[(k - 1) & 1], nh, nh);
-        a.add(pre_k, pre_rld, nh).out(r_k, nh).act(ACT_TANH);
+        else a.seg(rec_p_t + (size_t)(k - 1) * RW, N * RW, rec::ZW).seg(w.rslot(t, 0, k - 1), rl, nh);
+        a.add(pre_k, pre_rld, nh).out(r_k, rl).act(ACT_TANH);
         RUN(a, L_PROP_RNN, R);
       }
-      const int t1ld = nh + nh / 2;
       {
         // T1 columns [transform hidden 1 (ELU) | steps-predictor hidden pre-activation without `what` (linear)]
-        Lin a; a.seg(r_k, nh, nh).add(pre_k + nh, pre_rld, nh + nh / 2).out(w.t1, t1ld).act2(ACT_ELU, ACT_NONE, nh);
+        Lin a; a.seg(r_k, rl, nh).add(pre_k + nh, pre_rld, nh + nh / 2).out(t1, t1l).act2(ACT_ELU, ACT_NONE, nh);
         RUN(a, L_PROP_T1, R);
-        Lin b; b.seg(w.t1, t1ld, nh).out(w.t2, nh).act(ACT_ELU); RUN(b, L_PROP_T2, R);
+        Lin b; b.seg(t1, t1l, nh).out(t2, rl).act(ACT_ELU); RUN(b, L_PROP_T2, R);
       }
       {
         CropArgs ca; memset(&ca, 0, sizeof(ca));
-        ca.mode = CROP_PROP2; ca.img = img; ca.mask = c.masked_glimpse ? w.mask : nullptr; ca.mask_row_mul = N;
-        ca.mask_row_add = k; ca.out = w.g2; ca.out_row_mul = 1; ca.rec_prev = rec_prev; ca.rec_new = rec_p_t;
-        ca.t2 = w.t2; ca.t2_ld = nh; ca.w3 = w.w3_prop; ca.noise = nz; ca.flat = flat; ca.slot = k;
+        ca.mode = CROP_PROP2; ca.img = img; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N;
+        ca.mask_row_add = k; ca.out = g2; ca.out_row_mul = train ? N : 1; ca.rec_prev = rec_prev; ca.rec_new = rec_p_t;
+        ca.t2 = t2; ca.t2_ld = rl; ca.w3 = w.w3_prop; ca.noise = nz; ca.flat = flat; ca.slot = k;
+        if (train) { ca.tp_out = w.slot(w.tp, TP_LD, t, 0, k); ca.tp_out_ld = w.sld(TP_LD); }
         sq_launch_crop(ca, po, d, 1, s);
       }
       {
-        Lin a; a.seg(w.g2, G2, G2).out(w.e1, nh).act(ACT_ELU); RUN(a, L_GENC0, R);
-        Lin b; b.seg(w.e1, nh, nh).out(w.e2, nh).act(ACT_ELU); RUN(b, L_GENC1, R);
-        Lin e; e.seg(w.e2, nh, nh).out(w.enc, ENC_LD).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
+        Lin a; a.seg(g2, gl2, G2).out(e1, rl).act(ACT_ELU); RUN(a, L_GENC0, R);
+        Lin b; b.seg(e1, rl, nh).out(e2, rl).act(ACT_ELU); RUN(b, L_GENC1, R);
+        Lin e; e.seg(e2, rl, nh).out(enc, el).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
       }
       {
         const float* tau_k = temporal_prev + (size_t)k * nh;
-        Lin g1; g1.seg(r_k, nh, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(w.enc, ENC_LD, 2 * nw)
-                  .add(pre_k + 2 * nh + nh / 2, pre_rld, 2 * nh).out(w.gz, nh)
-                  .gru1(tau_k, N * nh, w.grh, nh, w.gxh, nh, nh);
-        RUN(g1, L_PROP_GRU1, R);
-        Lin g2; g2.seg(w.grh, nh, nh).add(w.gxh, nh, nh).out(w.temporal_p + (size_t)k * nh, N * nh)
-                  .gru2(tau_k, N * nh, w.gz, nh, nh);
-        RUN(g2, L_PROP_GRU2, R);
-        Lin hd; hd.seg(w.temporal_p + (size_t)k * nh, N * nh, nh).out(w.hraw, HRAW_LD); RUN(hd, L_PROP_HEADS, R);
+        Lin g1l; g1l.seg(r_k, rl, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(enc, el, 2 * nw)
+                   .add(pre_k + 2 * nh + nh / 2, pre_rld, 2 * nh).out(gz, rl)
+                   .gru1(tau_k, N * nh, w.grh, nh, w.gxh, nh, nh);
+        if (train) { g1l.a.o3 = w.slot(w.gr, nh, t, 0, k); g1l.a.o3_ld = rl; }
+        RUN(g1l, L_PROP_GRU1, R);
+        Lin g2l; g2l.seg(w.grh, nh, nh).add(w.gxh, nh, nh).out(temporal_p + (size_t)k * nh, N * nh)
+                   .gru2(tau_k, N * nh, gz, rl, nh);
+        if (train) { g2l.a.o1 = w.slot(w.ghc, nh, t, 0, k); g2l.a.o1_ld = rl; }
+        RUN(g2l, L_PROP_GRU2, R);
+        Lin hd; hd.seg(temporal_p + (size_t)k * nh, N * nh, nh).out(hraw, hl); RUN(hd, L_PROP_HEADS, R);
       }
       {
         TailArgs ta; memset(&ta, 0, sizeof(ta));
-        ta.is_disc = 0; ta.slot = k; ta.hraw = w.hraw; ta.h_ld = HRAW_LD; ta.enc = w.enc; ta.enc_ld = ENC_LD;
-        ta.rec_prev = rec_prev; ta.rec_new = rec_p_t; ta.noise = nz; ta.s1p = w.t1 + nh; ta.s1p_ld = t1ld;
-        ta.wp = packed + packed_layout(h).w + h->layers[L_PROP_S1].w_off; ta.flat = flat;
+        ta.is_disc = 0; ta.slot = k; ta.hraw = hraw; ta.h_ld = hl; ta.enc = enc; ta.enc_ld = el;
+        ta.rec_prev = rec_prev; ta.rec_new = rec_p_t; ta.noise = nz; ta.s1p = t1 + nh; ta.s1p_ld = t1l;
+        ta.wp = packed + pl.w + h->layers[L_PROP_S1].w_off; ta.flat = flat;
         ta.w2_off = po.prop_steps_l1_w; ta.b2_off = po.prop_steps_l1_b;
+        if (train) { ta.s1h_out = w.slot(w.s1h, S1_LD, t, 0, k); ta.s1h_ld = w.sld(S1_LD); }
         sq_launch_slot_tail(ta, d, s);
       }
     }
     // ---- F. summary of propagated latents -> discovery conditioning (sqair_modules.py:368-385, :501) ----
     {
-      Lin a; a.seg(rec_p_t, RW, rec::ZW).out(w.ea, nh).act(ACT_ELU); RUN(a, L_LAT0, M);
-      Lin b; b.seg(w.ea, nh, nh).out(w.eb, nh).act(ACT_ELU); RUN(b, L_LAT1, M);
-      sq_launch_latent_sum(w.eb, rec_p_t, w.c, d, s);
-      Lin p; p.seg(w.c, nh, nh).add(w.pre_disc + (size_t)t * B * nh, nh, nh, K).out(w.pre_d, nh); RUN(p, L_PRED, R);
+      Lin a; a.seg(rec_p_t, RW, rec::ZW).out(lea, nh).act(ACT_ELU); RUN(a, L_LAT0, M);
+      Lin b; b.seg(lea, nh, nh).out(leb, nh).act(ACT_ELU); RUN(b, L_LAT1, M);
+      sq_launch_latent_sum(leb, rec_p_t, cvec, d, s);
+      Lin p; p.seg(cvec, nh, nh).add(w.pre_disc + (size_t)t * B * nh, nh, nh, K).out(w.pre_d, nh); RUN(p, L_PRED, R);
       if (c.rec_where_prior) {
-        Lin q; q.seg(w.rn_init_state, 0, 4).seg(w.c, nh, nh).out(spre_t, 128); RUN(q, L_RNCOND, R);
+        Lin q; q.seg(w.rn_init_state, 0, 4).seg(cvec, nh, nh).out(spre_t, 128); RUN(q, L_RNCOND, R);
       }
     }
     // ---- G. discovery steps (sqair_modules.py:129-147 static_rnn over DiscoveryCore) ----
     for (int j = 0; j < N; ++j) {
-      float* r_j = w.rbuf[j & 1];
+      float* r_j = w.rslot(t, 1, j);
+      const int rl = w.sld(nh), t1l = w.sld(T1_LD), gl2 = w.sld(G2), el = w.sld(ENC_LD);
+      float* t1 = w.slot(w.t1, T1_LD, t, 1, j);
+      float* t2 = w.slot(w.t2, nh, t, 1, j);
+      float* g2 = w.slot(w.g2, G2, t, 1, j);
+      float* e1 = w.slot(w.e1, nh, t, 1, j);
+      float* e2 = w.slot(w.e2, nh, t, 1, j);
+      float* enc = w.slot(w.enc, ENC_LD, t, 1, j);
       {
         Lin a;
         if (j == 0) a.seg(w.disc_init_rec, 0, rec::ZW).seg(w.disc_rnn_init, 0, nh);
-        else a.seg(rec_d_t + (size_t)(j - 1) * RW, N * RW, rec::ZW).seg(w.rbuf[(j - 1) & 1], nh, nh);
-        a.add(w.pre_d, nh, nh).out(r_j, nh).act(ACT_TANH);
+        else a.seg(rec_d_t + (size_t)(j - 1) * RW, N * RW, rec::ZW).seg(w.rslot(t, 1, j - 1), rl, nh);
+        a.add(w.pre_d, nh, nh).out(r_j, rl).act(ACT_TANH);
         RUN(a, L_DISC_RNN, R);
-        const int t1ld = nh + nh / 2;
-        Lin b; b.seg(r_j, nh, nh).out(w.t1, t1ld).act2(ACT_ELU, ACT_NONE, nh); RUN(b, L_DISC_T1, R);
-        Lin cc; cc.seg(w.t1, t1ld, nh).out(w.t2, nh).act(ACT_ELU); RUN(cc, L_DISC_T2, R);
+        Lin b; b.seg(r_j, rl, nh).out(t1, t1l).act2(ACT_ELU, ACT_NONE, nh); RUN(b, L_DISC_T1, R);
+        Lin cc; cc.seg(t1, t1l, nh).out(t2, rl).act(ACT_ELU); RUN(cc, L_DISC_T2, R);
       }
       {
         CropArgs ca; memset(&ca, 0, sizeof(ca));
-        ca.mode = CROP_DISC; ca.img = img; ca.out = w.g2; ca.out_row_mul = 1; ca.rec_new = rec_d_t; ca.t2 = w.t2;
-        ca.t2_ld = nh; ca.w3 = w.w3_disc; ca.noise = nz; ca.flat = flat; ca.slot = j;
+        ca.mode = CROP_DISC; ca.img = img; ca.out = g2; ca.out_row_mul = train ? N : 1; ca.rec_new = rec_d_t; ca.t2 = t2;
+        ca.t2_ld = rl; ca.w3 = w.w3_disc; ca.noise = nz; ca.flat = flat; ca.slot = j;
+        if (train) { ca.tp_out = w.slot(w.tp, TP_LD, t, 1, j); ca.tp_out_ld = w.sld(TP_LD); }
         sq_launch_crop(ca, po, d, 1, s);
-        Lin a; a.seg(w.g2, G2, G2).out(w.e1, nh).act(ACT_ELU); RUN(a, L_GENC0, R);
-        Lin b; b.seg(w.e1, nh, nh).out(w.e2, nh).act(ACT_ELU); RUN(b, L_GENC1, R);
-        Lin e; e.seg(w.e2, nh, nh).out(w.enc, ENC_LD).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
+        Lin a; a.seg(g2, gl2, G2).out(e1, rl).act(ACT_ELU); RUN(a, L_GENC0, R);
+        Lin b; b.seg(e1, rl, nh).out(e2, rl).act(ACT_ELU); RUN(b, L_GENC1, R);
+        Lin e; e.seg(e2, rl, nh).out(enc, el).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
       }
       {
         TailArgs ta; memset(&ta, 0, sizeof(ta));
-        ta.is_disc = 1; ta.slot = j; ta.enc = w.enc; ta.enc_ld = ENC_LD; ta.rec_prev = rec_prev; ta.rec_new = rec_d_t;
-        ta.noise = nz; ta.s1p = w.t1 + nh; ta.s1p_ld = nh + nh / 2;
-        ta.wp = packed + packed_layout(h).w + h->layers[L_DISC_S1].w_off; ta.flat = flat;
+        ta.is_disc = 1; ta.slot = j; ta.enc = enc; ta.enc_ld = el; ta.rec_prev = rec_prev; ta.rec_new = rec_d_t;
+        ta.noise = nz; ta.s1p = t1 + nh; ta.s1p_ld = t1l;
+        ta.wp = packed + pl.w + h->layers[L_DISC_S1].w_off; ta.flat = flat;
         ta.w2_off = po.disc_steps_l1_w; ta.b2_off = po.disc_steps_l1_b;
+        if (train) { ta.s1h_out = w.slot(w.s1h, S1_LD, t, 1, j); ta.s1h_ld = w.sld(S1_LD); }
         sq_launch_slot_tail(ta, d, s);
       }
     }
@@ -875,10 +818,11 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
     //      they run once for all T frames after the loop)
     {
       CompactArgs ka; memset(&ka, 0, sizeof(ka));
-      ka.rec_p = rec_p_t; ka.rec_d = rec_d_t; ka.rec_prev = rec_prev; ka.temporal_p = w.temporal_p;
-      ka.prior_p = w.prior_p; ka.last_id_prev = w.last_id[pp]; ka.last_id_next = w.last_id[pn];
-      ka.rec_next = rec_next; ka.temporal_next = w.temporal_m[pn]; ka.prior_next = w.prior_m[pn];
+      ka.rec_p = rec_p_t; ka.rec_d = rec_d_t; ka.rec_prev = rec_prev; ka.temporal_p = temporal_p;
+      ka.prior_p = prior_p; ka.last_id_prev = w.last_id[pp]; ka.last_id_next = w.last_id[pn];
+      ka.rec_next = rec_next; ka.temporal_next = w.state(w.temporal_m, t + 1); ka.prior_next = w.state(w.prior_m, t + 1);
       ka.flat = flat; ka.t = t; ka.out = out;
+      ka.src_out = train ? w.src + (size_t)t * M : nullptr;
       sq_launch_compact(ka, po, d, s);
     }
   }
@@ -895,10 +839,11 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
   {
     const int MT = T * M;
     const float* rec_all = w.rec_m_all + (size_t)M * RW;  // merged records of frames 0..T-1
-    float* gl = out.glimpse ? out.glimpse : w.glimpse;
+    float* gl = (out.glimpse && !train) ? out.glimpse : w.glimpse;
     Lin a; a.seg(rec_all, RW, rec::ZW).out(w.dec_a, nh).act(ACT_ELU); RUN(a, L_DEC0, MT);
     Lin b; b.seg(w.dec_a, nh, nh).out(w.dec_b, nh).act(ACT_ELU); RUN(b, L_DEC1, MT);
     Lin g; g.seg(w.dec_b, nh, nh).out(gl, G2); g.a.scale_ptr = flat + po.dec_output_scale; RUN(g, L_DEC2, MT);
+    if (out.glimpse && train) SQ_CHECK_HIP(hipMemcpyAsync(out.glimpse, gl, (size_t)MT * G2 * 4, hipMemcpyDeviceToDevice, s));
     InsertArgs ia; memset(&ia, 0, sizeof(ia));
     ia.glimpse = gl; ia.rec = rec_all; ia.rec_ld = RW; ia.img = obs; ia.mean_img = flat + po.dec_mean_img;
     ia.canvas = out.canvas; ia.data_ll = w.dll; ia.qz = w.qz; ia.pz = w.pz; ia.t = 0; ia.n_frames = T; ia.out = out;
@@ -906,15 +851,29 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
     sq_launch_insert_loglik(ia, d, s);
   }
   // final recurrent state (for state-level parity checks)
-  const int pf = T & 1;
   if (out.final_temporal_state)
-    SQ_CHECK_HIP(hipMemcpyAsync(out.final_temporal_state, w.temporal_m[pf], (size_t)M * nh * 4, hipMemcpyDeviceToDevice, s));
+    SQ_CHECK_HIP(hipMemcpyAsync(out.final_temporal_state, w.state(w.temporal_m, T), (size_t)M * nh * 4, hipMemcpyDeviceToDevice, s));
   if (out.final_prior_state)
-    SQ_CHECK_HIP(hipMemcpyAsync(out.final_prior_state, w.prior_m[pf], (size_t)M * nh * 4, hipMemcpyDeviceToDevice, s));
+    SQ_CHECK_HIP(hipMemcpyAsync(out.final_prior_state, w.state(w.prior_m, T), (size_t)M * nh * 4, hipMemcpyDeviceToDevice, s));
   if (out.final_last_used_id)
-    SQ_CHECK_HIP(hipMemcpyAsync(out.final_last_used_id, w.last_id[pf], (size_t)R * 4, hipMemcpyDeviceToDevice, s));
+    SQ_CHECK_HIP(hipMemcpyAsync(out.final_last_used_id, w.last_id[T & 1], (size_t)R * 4, hipMemcpyDeviceToDevice, s));
   SQ_CHECK_HIP(hipGetLastError());
   return 0;
+}
+static int forward_impl(SqairHandle* h, const float* flat, const float* packed, const float* obs, const float* noise,
+                        int T, int B, int t_offset, const SqairOutputs* outp, float* wsbase, int64_t ws_bytes,
+                        hipStream_t s) {
+  return sq_forward_impl(h, flat, packed, obs, noise, T, B, t_offset, outp, wsbase, ws_bytes, s, false);
+}
+
+// Training-mode forward pass: identical launch sequence and results, but every intermediate the backward pass needs
+// is kept in the (larger) workspace; sqair_backward consumes it.
+extern "C" int sqair_forward_train(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
+                                   const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!h) return -1;
+  return sq_forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
+                         workspace_bytes, (hipStream_t)stream, true);
 }
 
 extern "C" int sqair_forward(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,

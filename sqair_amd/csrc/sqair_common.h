@@ -69,6 +69,7 @@ struct LinArgs {
   const float* e1; int e1_ld;   // z  (GRU2)
   float* o1; int o1_ld;         // r*h (GRU1)
   float* o2; int o2_ld;         // x W_h + b_h (GRU1)
+  float* o3; int o3_ld;         // optional: r (GRU1) — kept for the backward pass; GRU2 keeps tanh(.) in o1
   int nh;
 };
 

@@ -43,6 +43,8 @@ struct CropArgs {
   const float* noise;      // noise of frame t, [R,2,N,nzw]
   const float* flat;       // flat parameters
   int slot;                // PROP2 / DISC slot; PROP1 uses blockIdx.y
+  float* tp_out;           // optional (training): the transform output [R, tp_out_ld] (loc 0:4, raw scale 4:8)
+  int tp_out_ld;
 };
 
 int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float* last_id, float* disc_init_rec,
@@ -68,6 +70,7 @@ struct TailArgs {
   const float* s1p; int s1p_ld;     // [R, nh/2] hidden pre-activation without the `what` term
   const float* wp;                  // packed [nh/32 ... ] weights of the `what` rows of steps.l0 (layer *_S1)
   const float* flat; int w2_off, b2_off;
+  float* s1h_out; int s1h_ld;       // optional (training): the hidden activations elu(.) [R, nh/2]
 };
 int sq_launch_slot_tail(const TailArgs& a, Dims d, hipStream_t s);
 int sq_launch_latent_sum(const float* f, const float* rec_p, float* c, Dims d, hipStream_t s);
@@ -94,6 +97,7 @@ struct CompactArgs {
   const float* flat;
   int t;
   SqairOutputs out;
+  int* src_out;            // optional (training): source slot (0..2N-1) of every surviving slot [R,N]
 };
 int sq_launch_compact(const CompactArgs& a, POff po, Dims d, hipStream_t s);
 

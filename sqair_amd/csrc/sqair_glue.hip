@@ -146,6 +146,10 @@ __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, c
       }
       tp_loc = ci == 0 ? part[0] : (ci == 1 ? part[1] : (ci == 2 ? part[2] : part[3]));
       tp_raw = ci == 0 ? part[4] : (ci == 1 ? part[5] : (ci == 2 ? part[6] : part[7]));
+      if (a.tp_out != nullptr && hl < 4) {
+        a.tp_out[(size_t)r * a.tp_out_ld + ci] = tp_loc;
+        a.tp_out[(size_t)r * a.tp_out_ld + 4 + ci] = tp_raw;
+      }
     }
     float wl;
     if (a.mode == CROP_PLAIN) {
@@ -466,7 +470,12 @@ __global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims 
     float v = 0.0f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
-      if (wave + 4 * t < n_tiles) v += sq_elu(acc[t][i] + sp[t][i]) * w2v[t];
+      if (wave + 4 * t < n_tiles) {
+        const float hv = sq_elu(acc[t][i] + sp[t][i]);
+        v += hv * w2v[t];
+        if (a.s1h_out != nullptr && row0 + 4 * kq + i < d.R)
+          a.s1h_out[(size_t)(row0 + 4 * kq + i) * a.s1h_ld + (wave + 4 * t) * 16 + (lane & 15)] = hv;
+      }
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
     v += __shfl_xor(v, 4, 64);
@@ -791,7 +800,11 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff
     }
     if (in) {
       const int dst = (p != 0.0f) ? __popcll(present & below) : n_present + __popcll(~present & all & below);
-      if (dst < N) { src_s[dst] = sl; id_s[dst] = id; }
+      if (dst < N) {
+        src_s[dst] = sl;
+        id_s[dst] = id;
+        if (a.src_out != nullptr) a.src_out[(size_t)r * N + dst] = sl;
+      }
     }
     if (sl == 0) a.last_id_next[r] = last + (float)__popcll(disc_bits);
   }

@@ -1,0 +1,145 @@
+// Internal declarations shared by sqair_api.hip (handle, plan, forward pass) and sqair_train.hip (backward pass).
+#pragma once
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+#include "sqair_glue.h"
+
+struct ParamEntry {
+  std::string name;
+  int64_t off, numel;
+  int rows, cols;
+};
+
+enum LayerId {
+  L_IENC0, L_IENC1, L_PREDISC, L_PRIOR_GRU1, L_PRIOR_GRU2, L_PRIOR_LIN, L_TAU1, L_WB2, L_MASK2, L_GENC0, L_GENC1,
+  L_WHAT_LOC, L_WHAT_HEAD, L_PRE, L_PROP_RNN, L_PROP_T1, L_PROP_T2, L_PROP_T3, L_PROP_GRU1, L_PROP_GRU2,
+  L_PROP_HEADS, L_PROP_S1, L_LAT0, L_LAT1, L_PRED, L_RNCOND, L_DISC_RNN, L_DISC_T1, L_DISC_T2, L_DISC_T3,
+  L_DISC_S1, L_DEC0, L_DEC1, L_DEC2, L_COUNT
+};
+
+struct SqairHandle {
+  SqairConfig cfg;
+  std::string err;
+  std::vector<ParamEntry> params;
+  std::map<std::string, int> pidx;
+  int64_t n_params = 0;
+  POff po;
+  // packing plan
+  PackedLayer layers[L_COUNT];
+  PackedLayer layersT[L_COUNT];     // transposed packs (dX = dY W^T), K' = padded N, N' = padded concat K
+  std::vector<int> rowmaps;         // per layer: A-position -> reference row of the FIRST column block (wgrad)
+  int64_t rowmap_off[L_COUNT];
+  std::vector<int> widx;            // per packed weight element: index into flat params or -1
+  std::vector<int> bidx_a, bidx_b;  // per packed bias element
+  int64_t packed_w = 0, packed_b = 0;
+  bool plan_uploaded_to = false;
+  const void* plan_uploaded_ptr = nullptr;
+  // live profiling of the dominant kernel (sqair_profile_forward)
+  bool prof = false;
+  unsigned long long* prof_ts = nullptr;
+  int prof_n = 0;
+  double prof_flops = 0.0;
+  std::vector<int> prof_layer, prof_m;
+  // graph
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_nodes = 0;
+};
+
+
+inline int64_t align64(int64_t x) { return (x + 63) / 64 * 64; }
+int64_t P(const SqairHandle* h, const std::string& name);  // flat offset of a parameter (aborts on unknown names)
+int PC(const SqairHandle* h, const std::string& name);      // its number of columns
+
+// packed buffer = [weights fp32 | biases fp32 | widx int32 | bidx_a | bidx_b], each 256-byte aligned
+struct PackedLayout {
+  int64_t w, b, wi, ba, bb, total;  // offsets in 4-byte words
+};
+inline PackedLayout packed_layout(const SqairHandle* h) {
+  PackedLayout p;
+  p.w = 0;
+  p.b = align64(p.w + h->packed_w);
+  p.wi = align64(p.b + h->packed_b);
+  p.ba = align64(p.wi + h->packed_w);
+  p.bb = align64(p.ba + h->packed_b);
+  p.total = align64(p.bb + h->packed_b);
+  return p;
+}
+
+struct Lin {
+  LinArgs a;
+  Lin() {
+    memset(&a, 0, sizeof(a));
+    a.epi = EPI_ACT;
+    a.act_split = 1 << 30;
+    a.add_rdiv = 1;
+    a.scale = 1.0f;
+  }
+  Lin& seg(const float* p, int ld, int width, int rdiv = 1) {
+    a.seg[a.nseg++] = LinSeg{p, ld, width, rdiv};
+    return *this;
+  }
+  Lin& out(float* p, int ld) { a.out = p; a.out_ld = ld; return *this; }
+  Lin& act(int act) { a.act_a = act; return *this; }
+  Lin& act2(int a0, int a1, int split) { a.act_a = a0; a.act_b = a1; a.act_split = split; return *this; }
+  Lin& add(const float* p, int ld, int n, int rdiv = 1) { a.add = p; a.add_ld = ld; a.add_n = n; a.add_rdiv = rdiv; return *this; }
+  Lin& gru1(const float* hprev, int h_ld, float* rh, int rh_ld, float* xh, int xh_ld, int nh) {
+    a.epi = EPI_GRU1; a.e0 = hprev; a.e0_ld = h_ld; a.o1 = rh; a.o1_ld = rh_ld; a.o2 = xh; a.o2_ld = xh_ld; a.nh = nh;
+    return *this;
+  }
+  Lin& gru2(const float* hprev, int h_ld, const float* z, int z_ld, int nh) {
+    a.epi = EPI_GRU2; a.e0 = hprev; a.e0_ld = h_ld; a.e1 = z; a.e1_ld = z_ld; a.nh = nh;
+    return *this;
+  }
+};
+
+
+
+// ------------------------------------------------------------------------------------------------
+// workspace.  In training mode (train = true) every intermediate the backward pass needs is kept: per-frame
+// buffers become [T][...], per-slot buffers a "tape" [T][2 phases][B'][N slots][width] (slot-inner like the slot
+// records, so a slot launch addresses it with row stride N * width and the batched weight-gradient GEMMs see all
+// uses of a layer as one long row range).
+// ------------------------------------------------------------------------------------------------
+constexpr int PROF_MAX = 4096;
+constexpr int PS_LD = 112, ENC_LD = 112, M1_LD = 64, HRAW_LD = 256, WB_LD = 4, TP_LD = 8, T1_LD = 384, S1_LD = 128;
+
+struct Workspace {
+  bool train;
+  int T, B, R, M, N, nh;
+  float *ienc_a, *ienc_b, *pre_disc;
+  float *rec_m_all, *rec_p_all, *rec_d_all;
+  float *temporal_m, *prior_m;                   // train: [T+1][M][nh], else [2][M][nh]
+  float *last_id[2];
+  float *zero_rec, *disc_init_rec, *prop_rnn_init, *disc_rnn_init, *rn_init_state, *w3_prop, *w3_disc;
+  float *temporal_p, *prior_p;                   // per frame
+  float *pgz, *pgr, *pghc, *pgrh, *pgxh;         // prior GRU internals, per frame
+  float *pstats, *spre;                          // always [T]
+  float *hid1, *wb, *mask, *g1, *pea, *peb, *m1, *pre, *lea, *leb, *c, *pre_d;  // per frame
+  float *r, *t1, *t2, *tp, *g2, *e1, *e2, *enc, *hraw, *s1h, *gz, *gr, *ghc, *grh, *gxh;  // per slot
+  int* src;                                      // train: compaction source slot [T][R][N]
+  float *qz, *pz, *dlp, *dll, *glimpse, *dec_a, *dec_b;
+  unsigned long long* prof_ts;
+  int64_t total;  // floats
+
+  float* frame(float* base, int64_t per_frame, int t) const { return base + (train ? (size_t)t * per_frame : 0); }
+  float* state(float* base, int t) const { return base + (size_t)(train ? t : (t & 1)) * M * nh; }
+  // slot buffer of width W: pointer of (frame t, phase ph, slot k) and its row stride
+  float* slot(float* base, int W, int t, int ph, int k) const {
+    return base + (train ? (((size_t)(t * 2 + ph) * R * N) + k) * W : 0);
+  }
+  int sld(int W) const { return train ? N * W : W; }
+  float* rslot(int t, int ph, int k) const {  // RNN hidden state: ping-pong over slots when no tape is kept
+    return train ? slot(r, nh, t, ph, k) : r + (size_t)(k & 1) * R * nh;
+  }
+};
+Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train);
+
+int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipStream_t s);
+#define RUN(l, id, M)                                   \
+  do {                                                  \
+    int _rc = sq_run(h, (l), (id), (M), packed, s);     \
+    if (_rc != 0) return _rc;                           \
+  } while (0)

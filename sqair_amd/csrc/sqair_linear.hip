@@ -163,10 +163,16 @@ __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int 
       } else if (a.epi == EPI_GRU1) {
         const int nh = a.nh;
         if (n < nh) a.out[(size_t)m * a.out_ld + n] = sq_sigmoid(v);
-        else if (n < 2 * nh) a.o1[(size_t)m * a.o1_ld + (n - nh)] = sq_sigmoid(v) * p_e0[i];
+        else if (n < 2 * nh) {
+          const float rg = sq_sigmoid(v);
+          a.o1[(size_t)m * a.o1_ld + (n - nh)] = rg * p_e0[i];
+          if (a.o3 != nullptr) a.o3[(size_t)m * a.o3_ld + (n - nh)] = rg;
+        }
         else a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
       } else {
-        a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1[i]) * p_e0[i] + p_e1[i] * tanhf(v);
+        const float hc = tanhf(v);
+        a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1[i]) * p_e0[i] + p_e1[i] * hc;
+        if (a.o1 != nullptr) a.o1[(size_t)m * a.o1_ld + n] = hc;
       }
     }
   }

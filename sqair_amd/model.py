@@ -181,11 +181,19 @@ class SqairCore(object):
                 self.noise.data_ptr(), self.T, self.B, int(t_offset), C.byref(self.c_out),
                 self.workspace.data_ptr(), self.ws_bytes, self._stream())
 
-    def forward(self, t_offset=0, use_graph=False):
-        """Launches the whole T-frame forward pass + the ELBO reductions on the current stream."""
+    def forward(self, t_offset=0, use_graph=False, train=False):
+        """Launches the whole T-frame forward pass + the ELBO reductions on the current stream.  ``train`` keeps the
+        tape for the backward pass (larger workspace, allocated on first use)."""
         with torch.cuda.device(self.device):
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
-            if use_graph:
+            if train:
+                nb = self.lib.sqair_train_workspace_bytes(self.handle, self.T, self.B)
+                if getattr(self, "train_ws", None) is None or self.train_ws.numel() * 4 < nb:
+                    self.train_ws = torch.empty(nb // 4, dtype=torch.float32, device=self.device)
+                args = list(self._args(t_offset))
+                args[9], args[10] = self.train_ws.data_ptr(), nb
+                _capi.check(self.handle, self.lib.sqair_forward_train(*args), "sqair_forward_train")
+            elif use_graph:
                 if not self._graph_ready:
                     torch.cuda.synchronize(self.device)
                     _capi.check(self.handle, self.lib.sqair_graph_capture(*self._args(t_offset)), "sqair_graph_capture")

@@ -192,3 +192,27 @@ def test_backward_decoder_branch_matches_autograd(K, N, T, B, hw):
         got = g.cpu().numpy().reshape(want.shape)
         assert np.abs(got - want).max() <= 2e-3 * max(np.abs(want).max(), 1e-12), (name, np.abs(got - want).max(), np.abs(want).max())
     assert np.isfinite(d_rec.cpu().numpy()).all() and float(d_rec.abs().sum()) > 0
+
+
+def test_rmsprop_step_matches_tf_semantics():
+    from sqair_amd.train import rmsprop_reference
+    lib, h, F = _handle(2, 3, (50, 50))
+    try:
+        n = 2951522 + 3  # not a multiple of 4: exercises the scalar tail
+        rng = np.random.default_rng(0)
+        theta = rng.standard_normal(n).astype(np.float32)
+        ms = np.ones(n, dtype=np.float32)
+        mom = np.zeros(n, dtype=np.float32)
+        dt, dms, dmom = dev(theta), dev(ms), dev(mom)
+        t64, s64, m64 = theta.astype(np.float64), ms.astype(np.float64), mom.astype(np.float64)
+        for it in range(3):
+            g = (rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 1)).astype(np.float32)
+            dg = dev(g * 2.0)  # as if summed over 2 ranks; grad_scale = 0.5 undoes it
+            assert lib.sqair_rmsprop_step(h, dt.data_ptr(), dg.data_ptr(), dms.data_ptr(), dmom.data_ptr(), n, 1e-3, 0.9, 0.9,
+                                          1e-10, 0.5, stream()) == 0
+            t64, s64, m64 = rmsprop_reference(t64, g.astype(np.float64), s64, m64, 1e-3)
+        torch.cuda.synchronize()
+        assert np.abs(dt.cpu().numpy() - t64).max() < 1e-5
+        assert rel_err(dms.cpu().numpy(), s64) < 1e-5
+    finally:
+        lib.sqair_destroy(h)

@@ -176,3 +176,26 @@ def test_baseline_configs_full_size(cfg_id):
     pres = m1.presence.cpu().numpy()
     assert pres.sum(-1).max() <= N
     assert ((m1.obj_id.cpu().numpy() >= 0) == (pres > 0)).all()
+
+
+def test_training_mode_forward_is_bitwise_identical():
+    """sqair_forward_train keeps the tape for the backward pass; its results must equal the inference pass exactly."""
+    from sqair_amd.model import Model, SqairCore
+    F = make_flags(k_particles=3, n_steps_per_image=4)
+    hw, T, B = (50, 50), 4, 5
+    d = make_sequences(B, T=T, canvas=hw, seed=21)
+    obs = to_float(d["imgs"])
+    P = params32(F, hw, 9, 0.05, obs.mean((0, 1)))
+    noise = draw_noise(np.random.default_rng(3), T, B * 3, 4, 55)
+    core = SqairCore(F, hw)
+    core.set_params(P)
+    m = Model(obs, None, core, 3, presence=d["nums"])
+    m.run(noise=noise)
+    torch.cuda.synchronize()
+    ref = {k: v.clone() for k, v in core.out.items()}
+    lw = core.log_weights.clone()
+    core.forward(train=True)
+    torch.cuda.synchronize()
+    for k, v in core.out.items():
+        assert torch.equal(v, ref[k]), k
+    assert torch.equal(core.log_weights, lw)

@@ -1,0 +1,28 @@
+"""Host-side train-step semantics (no GPU): LR schedule, curriculum, RMSProp restatement."""
+import numpy as np
+
+from sqair_amd.flags import make_flags
+from sqair_amd.train import curriculum_seq_len, learning_rate, lr_schedule, rmsprop_reference
+
+
+def test_lr_schedule_matches_reference_defaults():
+    # release_models/mnist_mlp/1/flags.json: lr 1e-5, schedule 4,6,10, train_itr 2M (experiment.py:127-138)
+    F = make_flags(learning_rate=1e-5, schedule="4,6,10", train_itr=2000000)
+    bounds, values = lr_schedule(F)
+    assert bounds == [400000, 1000000]
+    assert np.allclose(values, [1e-5, 1e-5 / 3, 1e-5 / 9])
+    assert learning_rate(F, 0) == 1e-5 and learning_rate(F, 399999) == 1e-5
+    assert np.isclose(learning_rate(F, 400000), 1e-5 / 3) and np.isclose(learning_rate(F, 1999999), 1e-5 / 9)
+
+
+def test_curriculum():
+    F = make_flags(seq_len=3, stage_itr=200000)
+    assert curriculum_seq_len(F, 0, 10) == 3 and curriculum_seq_len(F, 200000, 10) == 4
+    assert curriculum_seq_len(F, 5000000, 10) == 10
+    assert curriculum_seq_len(make_flags(), 123, 10) == 10
+
+
+def test_rmsprop_reference_first_step():
+    th, ms, mom = rmsprop_reference(np.array([1.0]), np.array([2.0]), np.array([1.0]), np.array([0.0]), 0.1)
+    assert np.isclose(ms[0], 0.9 + 0.1 * 4.0) and np.isclose(mom[0], 0.1 * 2.0 / np.sqrt(1.3 + 1e-10))
+    assert np.isclose(th[0], 1.0 - mom[0])
