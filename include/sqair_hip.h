@@ -226,6 +226,17 @@ int sqair_backward_decoder(SqairHandle* h, const float* flat_params, const void*
                            const float* importance_weights, const float* vimco_signal, int T, int B,
                            void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
                            float* flat_grad, float* d_rec_out, void* stream);
+/* Full backward pass (replaces TF autodiff of Model.make_target, sqair/model.py:150-168,
+ * through SequentialAIR / SQAIRTimestep, sqair/seq.py:60-150, sqair/sqair_modules.py:388-582): gradient of the VIMCO
+ * target / T w.r.t. EVERY trainable parameter, written to flat_grad (flat-parameter layout, overwritten).
+ * Call order on one stream:  sqair_forward_train(train_workspace)  ->  sqair_elbo  ->  sqair_backward with the same
+ * obs / noise / T / B / t_offset, the importance weights and learning signal sqair_elbo returned.  `scratch` holds the
+ * gradient records and pre-activation gradient tapes (sqair_backward_bytes). */
+int64_t sqair_backward_bytes(const SqairHandle* h, int T, int B);
+int sqair_backward(SqairHandle* h, const float* flat_params, const void* packed, const float* obs, const float* noise,
+                   const float* importance_weights, const float* vimco_signal, int T, int B, int t_offset,
+                   void* train_workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
+                   float* flat_grad, void* stream);
 /* Fused optimiser step on the flat buffers: tf.train.RMSPropOptimizer(lr, momentum=0.9) as used by the
  * reference driver (sqair/scripts/experiment.py:140; TF defaults decay 0.9, epsilon 1e-10, ms initialised to 1):
  * ms <- decay ms + (1-decay) g^2; mom <- momentum mom + lr g / sqrt(ms + eps); theta <- theta - mom, with

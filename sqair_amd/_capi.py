@@ -84,6 +84,9 @@ _PROTOS = {
     "sqair_backward_scratch_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
     "sqair_backward_decoder": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sqair_backward_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    "sqair_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                 C.c_void_p, C.c_void_p]),
     "sqair_rmsprop_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "sqair_linear_bwd_test": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_int64, C.c_void_p]),

@@ -195,6 +195,12 @@ static void build_layer(SqairHandle* h, LayerId id, const std::vector<int>& seg_
       fprintf(stderr, "sqair: layer %d: segment count mismatch\n", (int)id);
       abort();
     }
+    for (size_t sgi = 0; sgi < seg_width.size(); ++sgi)
+      if (!b.seg[sgi].w.empty()) {
+        h->wg[id].push_back({n0, b.ncols, b.col0, (int)sgi, b.seg[sgi].w, (int64_t)h->rm_pool.size()});
+        h->rm_pool.insert(h->rm_pool.end(), b.seg[sgi].rows.begin(), b.seg[sgi].rows.end());
+      }
+    if (!b.bias_a.empty() || !b.bias_b.empty()) h->bg[id].push_back({n0, b.ncols, b.col0, b.bias_a, b.bias_b});
     for (int j = 0; j < b.ncols; ++j) {
       const int n = n0 + j;
       const int tile = n / 16, ln = n % 16;
@@ -469,6 +475,7 @@ extern "C" int sqair_pack_params(SqairHandle* h, const float* flat, void* packed
     SQ_CHECK_HIP(hipMemcpyAsync(ibase + pl.wi, h->widx.data(), h->packed_w * 4, hipMemcpyHostToDevice, s));
     SQ_CHECK_HIP(hipMemcpyAsync(ibase + pl.ba, h->bidx_a.data(), h->packed_b * 4, hipMemcpyHostToDevice, s));
     SQ_CHECK_HIP(hipMemcpyAsync(ibase + pl.bb, h->bidx_b.data(), h->packed_b * 4, hipMemcpyHostToDevice, s));
+    SQ_CHECK_HIP(hipMemcpyAsync(ibase + pl.rm, h->rm_pool.data(), h->rm_pool.size() * 4, hipMemcpyHostToDevice, s));
     SQ_CHECK_HIP(hipStreamSynchronize(s));
     h->plan_uploaded_ptr = packed;
   }

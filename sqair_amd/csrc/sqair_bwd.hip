@@ -502,3 +502,680 @@ extern "C" int sqair_rmsprop_step(SqairHandle* h, float* flat_params, const floa
                      flat_grad, ms, mom, n, lr, decay, momentum, epsilon, grad_scale);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// =================================================================================================
+// Adjoint kernels of the recurrent part.  Gradients w.r.t. slot quantities live in "gradient records" with the
+// layout of the forward slot records (rec::WHERE, WHAT, LOGIT, WHERE_LOC, WHERE_SCALE, WHAT_LOC, WHAT_SCALE), so the
+// dX GEMMs of z-record segments (which come out in record order) accumulate straight into them.  Gradients of the
+// small parameters are accumulated with float atomics into the flat gradient buffer.
+// =================================================================================================
+
+__device__ __forceinline__ float dnormal_dx(float x, float loc, float sc) { return -(x - loc) / (sc * sc); }
+__device__ __forceinline__ float dnormal_dsc(float x, float loc, float sc) {
+  const float dd = x - loc;
+  return dd * dd / (sc * sc * sc) - 1.0f / sc;
+}
+__device__ __forceinline__ float delu_from_out(float o) { return o > 0.0f ? 1.0f : o + 1.0f; }
+
+// ------------------------------------------------------------------------------------------------
+// log-probability adjoint, all T frames in one launch (grid R x T), mirror of k_logprob.
+// ------------------------------------------------------------------------------------------------
+struct LogprobBwdArgs {
+  const float* rec_p; const float* rec_d; const float* rec_m;   // forward records [T][M][168] / merged [T+1][M][168]
+  const float* pstats; int ps_ld; const float* spre;
+  const float* g_lw; const float* g_dl;                          // [T][R]
+  float* d_rec_p; float* d_rec_d; float* d_rec_m;                // gradient records (accumulated)
+  float* d_pstats;                                               // [T][M][ps_ld] (written)
+  float* d_spre;                                                 // [T][R][128] (written)
+  const float* flat; float* flat_grad;
+  int t_global0;
+  SqairConfig cfg;
+};
+
+__global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, const POff po, const Dims d) {
+  const int r = blockIdx.x, fr = blockIdx.y, lane = threadIdx.x;
+  const int N = d.N, nw = d.nw, RW = rec::W;
+  const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;
+  const size_t frr = (size_t)fr * d.R + r;
+  const float* flat = a.flat;
+  float* fg = a.flat_grad;
+  const float gw = a.g_lw[frr], gd = a.g_dl[frr];
+  const int t_global = a.t_global0 + fr;
+  // ---------------- forward quantities needed below: prior logits, e_sum
+  float pl[SQ_MAXN], e_sum = 0.0f;
+  for (int k = 0; k < N; ++k) {
+    const float* rm = a.rec_m + (fs + k) * RW;
+    const float* ps = a.pstats + (fs + k) * a.ps_ld;
+    const float pres_tm1 = rm[rec::PRES];
+    float v = ps[0] + a.cfg.prop_prior_step_bias;
+    v = pres_tm1 * v + (pres_tm1 - 1.0f) * 88.0f;
+    if (a.cfg.prop_prior_type != 0) v = rm[rec::LOGIT] + 0.1f * v;
+    pl[k] = v;
+    e_sum += (sq_sigmoid(v) - 0.5f) / (float)N;
+  }
+  float d_e = 0.0f;
+  // ---------------- discovery: recurrent where prior
+  float n_disc = 0.0f;
+  for (int j = 0; j < N; ++j) n_disc += a.rec_d[(fs + j) * RW + rec::PRES];
+  const int n = (int)(n_disc + 0.5f);
+  if (a.cfg.rec_where_prior) {
+    // s = elu(spre + e ce), hs = s h2h + b_h2h + b_i2h  (lanes own s_i for i = lane, lane + 64)
+    float sv[2], part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = lane + 64 * q;
+      sv[q] = sq_elu(a.spre[frr * 128 + i] + e_sum * flat[po.rn_cond_w + (4 + d.nh) * 128 + i]);
+      for (int jj = 0; jj < 4; ++jj) part[jj] += sv[q] * flat[po.rn_h2h_w + i * 4 + jj];
+    }
+    float hs[4], d_hs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int jj = 0; jj < 4; ++jj) hs[jj] = sq_wave_sum(part[jj]) + flat[po.rn_h2h_b + jj] + flat[po.rn_i2h_b + jj];
+    for (int j = 0; j < N; ++j) {
+      const float* rd = a.rec_d + (fs + j) * RW;
+      const float pres = rd[rec::PRES];
+      const float* xp = j == 0 ? flat + po.rn_init_sample : a.rec_d + (fs + j - 1) * RW + rec::WHERE;
+      float o[4], pre;
+      for (int mm = 0; mm < 4; ++mm) {
+        pre = hs[mm];
+        for (int i = 0; i < 4; ++i) pre += xp[i] * flat[po.rn_i2h_w + i * 4 + mm];
+        o[mm] = tanhf(pre);
+      }
+      // lanes 0..3: component i
+      float g_loc = 0.0f, g_raw = 0.0f;
+      if (lane < 4) {
+        float loc = flat[po.rn_readout_b + lane], raw = flat[po.rn_readout_b + 4 + lane];
+        for (int mm = 0; mm < 4; ++mm) {
+          loc += o[mm] * flat[po.rn_readout_w + mm * 8 + lane];
+          raw += o[mm] * flat[po.rn_readout_w + mm * 8 + 4 + lane];
+        }
+        const float psc = sq_softplus(raw) + 1e-2f;
+        const float x = rd[rec::WHERE + lane];
+        const float coef = gw * pres;
+        g_loc = coef * (-dnormal_dx(x, loc, psc));
+        g_raw = coef * dnormal_dsc(x, loc, psc) * sq_sigmoid(raw);
+        atomicAdd(&a.d_rec_d[(fs + j) * RW + rec::WHERE + lane], coef * dnormal_dx(x, loc, psc));
+        atomicAdd(&fg[po.rn_readout_b + lane], g_loc);
+        atomicAdd(&fg[po.rn_readout_b + 4 + lane], g_raw);
+        for (int mm = 0; mm < 4; ++mm) {
+          atomicAdd(&fg[po.rn_readout_w + mm * 8 + lane], o[mm] * g_loc);
+          atomicAdd(&fg[po.rn_readout_w + mm * 8 + 4 + lane], o[mm] * g_raw);
+        }
+      }
+      // g_o[m] = sum_i ro_w[m][i] g_loc_i + ro_w[m][4+i] g_raw_i  (reduce over lanes 0..3)
+      float g_pre[4];
+      for (int mm = 0; mm < 4; ++mm) {
+        float v = lane < 4 ? flat[po.rn_readout_w + mm * 8 + lane] * g_loc + flat[po.rn_readout_w + mm * 8 + 4 + lane] * g_raw : 0.0f;
+        v = sq_wave_sum(v);
+        g_pre[mm] = v * (1.0f - o[mm] * o[mm]);
+        d_hs[mm] += g_pre[mm];
+      }
+      if (lane < 4) {  // lane = input index i of i2h
+        float dx = 0.0f;
+        for (int mm = 0; mm < 4; ++mm) {
+          atomicAdd(&fg[po.rn_i2h_w + lane * 4 + mm], xp[lane] * g_pre[mm]);
+          dx += flat[po.rn_i2h_w + lane * 4 + mm] * g_pre[mm];
+        }
+        if (j == 0) atomicAdd(&fg[po.rn_init_sample + lane], dx);
+        else atomicAdd(&a.d_rec_d[(fs + j - 1) * RW + rec::WHERE + lane], dx);
+      }
+    }
+    if (lane < 4) {
+      atomicAdd(&fg[po.rn_h2h_b + lane], d_hs[lane]);
+      atomicAdd(&fg[po.rn_i2h_b + lane], d_hs[lane]);
+    }
+    float de_part = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = lane + 64 * q;
+      float g_s = 0.0f;
+      for (int jj = 0; jj < 4; ++jj) {
+        g_s += flat[po.rn_h2h_w + i * 4 + jj] * d_hs[jj];
+        atomicAdd(&fg[po.rn_h2h_w + i * 4 + jj], sv[q] * d_hs[jj]);
+      }
+      const float g_spre = g_s * delu_from_out(sv[q]);
+      a.d_spre[frr * 128 + i] = g_spre;
+      atomicAdd(&fg[po.rn_cond_w + (4 + d.nh) * 128 + i], e_sum * g_spre);
+      de_part += flat[po.rn_cond_w + (4 + d.nh) * 128 + i] * g_spre;
+    }
+    d_e += sq_wave_sum(de_part);
+  } else {
+    a.d_spre[frr * 128 + lane] = 0.0f;
+    a.d_spre[frr * 128 + 64 + lane] = 0.0f;
+    for (int j = 0; j < N; ++j)
+      if (lane < 4) {
+        const float* rd = a.rec_d + (fs + j) * RW;
+        atomicAdd(&a.d_rec_d[(fs + j) * RW + rec::WHERE + lane],
+                  gw * rd[rec::PRES] * dnormal_dx(rd[rec::WHERE + lane], a.cfg.where_prior_mean[lane], 1.0f));
+      }
+  }
+  // ---------------- discovery: q what / where, p what, number of steps
+  for (int j = 0; j < N; ++j) {
+    const float* rd = a.rec_d + (fs + j) * RW;
+    float* dr = a.d_rec_d + (fs + j) * RW;
+    const float pres = rd[rec::PRES];
+    const float cq = -gw * pres, cp = gw * pres;
+    if (lane < nw) {
+      const float x = rd[rec::WHAT + lane], loc = rd[rec::WHAT_LOC + lane], sc = rd[rec::WHAT_SCALE + lane];
+      atomicAdd(&dr[rec::WHAT + lane], cq * dnormal_dx(x, loc, sc) + cp * (-x));
+      atomicAdd(&dr[rec::WHAT_LOC + lane], -cq * dnormal_dx(x, loc, sc));
+      atomicAdd(&dr[rec::WHAT_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
+    }
+    if (lane < 4) {
+      const float x = rd[rec::WHERE + lane], loc = rd[rec::WHERE_LOC + lane], sc = rd[rec::WHERE_SCALE + lane];
+      atomicAdd(&dr[rec::WHERE + lane], cq * dnormal_dx(x, loc, sc));
+      atomicAdd(&dr[rec::WHERE_LOC + lane], -cq * dnormal_dx(x, loc, sc));
+      atomicAdd(&dr[rec::WHERE_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
+    }
+    if (lane == 0) {
+      // q_num = log J_n, J from p_j = sigmoid(logit_j): d log J_n / d logit_j = (1 - p_j) for j < n, -p_n for j = n < N
+      const float coef = -gw + gd;
+      const float pj = rd[rec::PROB];
+      float g = 0.0f;
+      if (j < n) g = coef * (1.0f - pj);
+      else if (j == n) g = coef * (-pj);
+      atomicAdd(&dr[rec::LOGIT], g);
+    }
+  }
+  // categorical / geometric prior of the number of steps
+  if (a.cfg.disc_prior_type == 0 && lane == 0) {
+    float hid[10], lg[SQ_MAXN + 1], gv[SQ_MAXN + 1];
+    for (int i = 0; i < 10; ++i) hid[i] = sq_elu(e_sum * flat[po.sp_l0_w + i] + flat[po.sp_l0_b + i]);
+    float mx = -1e30f;
+    for (int c = 0; c <= N; ++c) {
+      float v = flat[po.step_prior_bias + c] + (t_global > 0 ? flat[po.step_prior_tbias + c] : 0.0f) + flat[po.sp_l1_b + c];
+      for (int i = 0; i < 10; ++i) v += hid[i] * flat[po.sp_l1_w + i * (N + 1) + c];
+      lg[c] = sq_elu(v);
+      mx = fmaxf(mx, lg[c]);
+    }
+    float se = 0.0f;
+    for (int c = 0; c <= N; ++c) se += expf(lg[c] - mx);
+    for (int c = 0; c <= N; ++c) {
+      const float sm = expf(lg[c] - mx) / se;
+      gv[c] = gw * ((c == n ? 1.0f : 0.0f) - sm) * delu_from_out(lg[c]);
+      atomicAdd(&fg[po.step_prior_bias + c], gv[c]);
+      if (t_global > 0) atomicAdd(&fg[po.step_prior_tbias + c], gv[c]);
+      atomicAdd(&fg[po.sp_l1_b + c], gv[c]);
+    }
+    for (int i = 0; i < 10; ++i) {
+      float gh = 0.0f;
+      for (int c = 0; c <= N; ++c) {
+        atomicAdd(&fg[po.sp_l1_w + i * (N + 1) + c], hid[i] * gv[c]);
+        gh += flat[po.sp_l1_w + i * (N + 1) + c] * gv[c];
+      }
+      const float ghp = gh * delu_from_out(hid[i]);
+      atomicAdd(&fg[po.sp_l0_w + i], e_sum * ghp);
+      atomicAdd(&fg[po.sp_l0_b + i], ghp);
+      d_e += flat[po.sp_l0_w + i] * ghp;
+    }
+  }
+  d_e = __shfl(d_e, 0, 64);
+  // ---------------- propagation
+  for (int k = 0; k < N; ++k) {
+    const float* rp = a.rec_p + (fs + k) * RW;
+    const float* rm = a.rec_m + (fs + k) * RW;
+    const float* ps = a.pstats + (fs + k) * a.ps_ld;
+    float* drp = a.d_rec_p + (fs + k) * RW;
+    float* drm = a.d_rec_m + (fs + k) * RW;
+    float* dps = a.d_pstats + (fs + k) * a.ps_ld;
+    const float pres = rp[rec::PRES], pres_tm1 = rm[rec::PRES];
+    const float m = pres_tm1 * pres;
+    const float cq = -gw * m, cp = gw * m;
+    for (int i = lane; i < a.ps_ld; i += 64) dps[i] = 0.0f;
+    __syncthreads();
+    if (lane < nw) {
+      const float x = rp[rec::WHAT + lane];
+      const float loc = rp[rec::WHAT_LOC + lane], sc = rp[rec::WHAT_SCALE + lane];
+      float ploc = ps[5 + lane];
+      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHAT + lane];
+      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHAT + lane] + 0.1f * ploc;
+      const float praw = ps[9 + nw + lane];
+      const float psc = sq_softplus(praw) + 1e-2f;
+      atomicAdd(&drp[rec::WHAT + lane], cq * dnormal_dx(x, loc, sc) + cp * dnormal_dx(x, ploc, psc));
+      atomicAdd(&drp[rec::WHAT_LOC + lane], -cq * dnormal_dx(x, loc, sc));
+      atomicAdd(&drp[rec::WHAT_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
+      const float g_ploc = -cp * dnormal_dx(x, ploc, psc);
+      if (a.cfg.prop_prior_type == 0) dps[5 + lane] = g_ploc;
+      else {
+        atomicAdd(&drm[rec::WHAT + lane], g_ploc);
+        if (a.cfg.prop_prior_type == 2) dps[5 + lane] = 0.1f * g_ploc;
+      }
+      dps[9 + nw + lane] = cp * dnormal_dsc(x, ploc, psc) * sq_sigmoid(praw);
+    }
+    if (lane < 4) {
+      const float x = rp[rec::WHERE + lane];
+      float ploc = ps[1 + lane];
+      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHERE + lane];
+      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHERE + lane] + 0.1f * ploc;
+      const float praw = ps[5 + nw + lane];
+      const float psc = sq_softplus(praw) + 1e-2f;
+      atomicAdd(&drp[rec::WHERE + lane], cp * dnormal_dx(x, ploc, psc));
+      const float g_ploc = -cp * dnormal_dx(x, ploc, psc);
+      if (a.cfg.prop_prior_type == 0) dps[1 + lane] = g_ploc;
+      else {
+        atomicAdd(&drm[rec::WHERE + lane], g_ploc);
+        if (a.cfg.prop_prior_type == 2) dps[1 + lane] = 0.1f * g_ploc;
+      }
+      dps[5 + nw + lane] = cp * dnormal_dsc(x, ploc, psc) * sq_sigmoid(praw);
+    }
+    if (lane == 0) {
+      // MultivariateNormalTriL posterior of where: L = T * sc[:,None] + diag(sc)
+      const float* ch = flat + po.cholesky;
+      float L[4][4], y[4], u[4], dd[4];
+      for (int i = 0; i < 4; ++i) {
+        const float sci = rp[rec::WHERE_SCALE + i];
+        for (int j = 0; j < 4; ++j) L[i][j] = j <= i ? tril4(ch, i, j) * sci + (i == j ? sci : 0.0f) : 0.0f;
+        dd[i] = rp[rec::WHERE + i] - rp[rec::WHERE_LOC + i];
+      }
+      for (int i = 0; i < 4; ++i) {
+        float acc = dd[i];
+        for (int j = 0; j < i; ++j) acc -= L[i][j] * y[j];
+        y[i] = acc / L[i][i];
+      }
+      for (int i = 3; i >= 0; --i) {  // L^T u = y
+        float acc = y[i];
+        for (int j = i + 1; j < 4; ++j) acc -= L[j][i] * u[j];
+        u[i] = acc / L[i][i];
+      }
+      for (int i = 0; i < 4; ++i) {
+        atomicAdd(&drp[rec::WHERE + i], cq * (-u[i]));
+        atomicAdd(&drp[rec::WHERE_LOC + i], cq * u[i]);
+        const float sci = rp[rec::WHERE_SCALE + i];
+        float dsc = 0.0f;
+        for (int j = 0; j <= i; ++j) {
+          const float dL = u[i] * y[j] - (i == j ? 1.0f / L[i][i] : 0.0f);
+          const float tij = tril4(ch, i, j);
+          dsc += dL * (tij + (i == j ? 1.0f : 0.0f));
+          const int q = i * 4 + j;  // fill_triangular index -> cholesky_scale element
+          atomicAdd(&fg[po.cholesky + (q < 6 ? 4 + q : 15 - q)], cq * dL * sci);
+        }
+        atomicAdd(&drp[rec::WHERE_SCALE + i], cq * dsc);
+      }
+      // presence Bernoullis and the prior logit (incl. its path through e_sum)
+      const float logit = rp[rec::LOGIT];
+      atomicAdd(&drp[rec::LOGIT], (-gw + gd) * pres_tm1 * (pres - sq_sigmoid(logit)));
+      const float spl = sq_sigmoid(pl[k]);
+      float g_pl = gw * pres_tm1 * (pres - spl) + d_e * spl * (1.0f - spl) / (float)N;
+      if (a.cfg.prop_prior_type != 0) {
+        atomicAdd(&drm[rec::LOGIT], g_pl);
+        g_pl *= 0.1f;
+      }
+      dps[0] = g_pl * pres_tm1;
+    }
+    __syncthreads();
+  }
+}
+
+int sq_launch_logprob_bwd(const LogprobBwdArgs& a, POff po, Dims d, int T, hipStream_t s) {
+  hipLaunchKernelGGL(k_logprob_bwd, dim3(d.R, T), dim3(64), 0, s, a, po, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// compaction adjoint: route the gradients of the merged slots of frame t+1 back to their source slots
+// ------------------------------------------------------------------------------------------------
+struct CompactBwdArgs {
+  const int* src;                 // [R][N]
+  const float* d_rec_next;        // gradient records of the merged slots [M][168]
+  const float* d_temporal_next; const float* d_prior_next;   // [M][nh]
+  float* d_rec_p; float* d_rec_d; // gradient records of this frame (accumulated)
+  float* d_temporal_p; float* d_prior_p;                     // [M][nh] (written: every propagation slot)
+  float* flat_grad;
+};
+__global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, const POff po, const Dims d) {
+  const int r = blockIdx.x, tid = threadIdx.x, N = d.N, nh = d.nh, RW = rec::W;
+  __shared__ int inv_s[2 * SQ_MAXN];  // source slot -> destination (or -1)
+  if (tid < 2 * N) inv_s[tid] = -1;
+  __syncthreads();
+  if (tid < N) inv_s[a.src[(size_t)r * N + tid]] = tid;
+  __syncthreads();
+  for (int e = tid; e < 2 * N * RW; e += 256) {
+    const int sl = e / RW, i = e - sl * RW;
+    const int dst = inv_s[sl];
+    if (dst < 0) continue;
+    const float g = a.d_rec_next[((size_t)r * N + dst) * RW + i];
+    float* tgt = sl < N ? a.d_rec_p + ((size_t)r * N + sl) * RW : a.d_rec_d + ((size_t)r * N + (sl - N)) * RW;
+    tgt[i] += g;
+  }
+  for (int e = tid; e < 2 * N * nh; e += 256) {
+    const int sl = e / nh, i = e - sl * nh;
+    const int dst = inv_s[sl];
+    const float gt = dst >= 0 ? a.d_temporal_next[((size_t)r * N + dst) * nh + i] : 0.0f;
+    const float gp = dst >= 0 ? a.d_prior_next[((size_t)r * N + dst) * nh + i] : 0.0f;
+    if (sl < N) {
+      a.d_temporal_p[((size_t)r * N + sl) * nh + i] = gt;
+      a.d_prior_p[((size_t)r * N + sl) * nh + i] = gp;
+    } else if (dst >= 0) {  // a newly discovered object starts from the trainable initial states
+      atomicAdd(&a.flat_grad[po.temporal_init + i], gt);
+      atomicAdd(&a.flat_grad[po.prior_init + i], gp);
+    }
+  }
+}
+int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t s) {
+  hipLaunchKernelGGL(k_compact_bwd, dim3(d.R), dim3(256), 0, s, a, po, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// slot-tail adjoint (mirror of k_slot_tail): presence logit -> steps-predictor output / hidden layer -> what,
+// then the what-sample adjoint (gated mixture for propagation).  One workgroup (128 threads) per row.
+// ------------------------------------------------------------------------------------------------
+struct TailBwdArgs {
+  int is_disc, slot;
+  const float* rec_prev; const float* rec_new; float* d_rec_new; float* d_rec_prev;  // records / gradient records
+  const float* s1h; int s1h_ld;         // saved hidden activations [R][nh/2]
+  const float* hraw; int h_ld; const float* enc; int enc_ld; const float* noise;
+  float* d_s1pre; int ds_ld;            // out: gradient of the hidden pre-activation [R][nh/2] (T1's extra columns)
+  float* d_enc; int de_ld;              // out (=): gradient of (loc, scale) of the glimpse encoder
+  float* d_hraw; int dh_ld;             // out (=, prop): gradient of the raw head / gate pre-activations
+  const float* flat; float* flat_grad;
+  int w2_off, b2_off, wwhat_off;        // steps.l1 {w,b}; first `what` row of steps.l0.w ([in, nh/2] layout)
+};
+__global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, const Dims d) {
+  __shared__ float ds_s[128];
+  const int r = blockIdx.x, tid = threadIdx.x, nw = d.nw, nsp = d.nh / 2, RW = rec::W;
+  const float* rn = a.rec_new + ((size_t)r * d.N + a.slot) * RW;
+  float* drn = a.d_rec_new + ((size_t)r * d.N + a.slot) * RW;
+  float prev;
+  if (a.is_disc) prev = a.slot == 0 ? 1.0f : a.rec_new[((size_t)r * d.N + a.slot - 1) * RW + rec::PRES];
+  else prev = a.rec_prev[((size_t)r * d.N + a.slot) * RW + rec::PRES];
+  const float d_raw = prev * drn[rec::LOGIT];
+  if (tid < nsp) {
+    const float hv = a.s1h[(size_t)r * a.s1h_ld + tid];
+    const float w2 = a.flat[a.w2_off + tid];
+    atomicAdd(&a.flat_grad[a.w2_off + tid], hv * d_raw);
+    const float g = d_raw * w2 * delu_from_out(hv);
+    ds_s[tid] = g;
+    a.d_s1pre[(size_t)r * a.ds_ld + tid] = g;
+  }
+  if (tid == 0) atomicAdd(&a.flat_grad[a.b2_off], d_raw);
+  __syncthreads();
+  if (tid < nw) {
+    const int c = tid;
+    float dw = drn[rec::WHAT + c];
+    const float* wrow = a.flat + a.wwhat_off + (size_t)c * nsp;
+    for (int i = 0; i < nsp; ++i) dw += ds_s[i] * wrow[i];
+    drn[rec::WHAT + c] = dw;  // total gradient of the sample (kept for the batched weight gradients' bookkeeping)
+    const float eps = a.noise[(((size_t)r * 2 + (a.is_disc ? 1 : 0)) * d.N + a.slot) * d.nzw + 4 + c];
+    const float d_loc = dw + drn[rec::WHAT_LOC + c];
+    const float d_sc = dw * eps + drn[rec::WHAT_SCALE + c];
+    if (a.is_disc) {
+      a.d_enc[(size_t)r * a.de_ld + c] = d_loc;
+      a.d_enc[(size_t)r * a.de_ld + nw + c] = d_sc;
+    } else {
+      const float* hr = a.hraw + (size_t)r * a.h_ld;
+      const float t_loc = hr[c], h1 = hr[nw + c];
+      const float t_scale = sq_softplus(h1) + 1e-2f;
+      const float s2 = sq_sigmoid(hr[2 * nw + c]), s3 = sq_sigmoid(hr[3 * nw + c]), s4 = sq_sigmoid(hr[4 * nw + c]);
+      const float fg = s2 * 0.9999f, ig = s3 * 0.9999f, tg = s4 * 0.9999f;
+      const float loc2 = a.enc[(size_t)r * a.enc_ld + c], sc2 = a.enc[(size_t)r * a.enc_ld + nw + c];
+      const float wtm1 = a.rec_prev[((size_t)r * d.N + a.slot) * RW + rec::WHAT + c];
+      const float d_fg = d_loc * wtm1;
+      const float d_ig = -d_loc * loc2 - d_sc * sc2;
+      const float d_tg = -d_loc * t_loc - d_sc * t_scale;
+      a.d_rec_prev[((size_t)r * d.N + a.slot) * RW + rec::WHAT + c] += d_loc * fg;
+      a.d_enc[(size_t)r * a.de_ld + c] = d_loc * (1.0f - ig);
+      a.d_enc[(size_t)r * a.de_ld + nw + c] = d_sc * (1.0f - ig);
+      float* dh = a.d_hraw + (size_t)r * a.dh_ld;
+      dh[c] = d_loc * (1.0f - tg);
+      dh[nw + c] = d_sc * (1.0f - tg) * sq_sigmoid(h1);
+      dh[2 * nw + c] = d_fg * 0.9999f * s2 * (1.0f - s2);
+      dh[3 * nw + c] = d_ig * 0.9999f * s3 * (1.0f - s3);
+      dh[4 * nw + c] = d_tg * 0.9999f * s4 * (1.0f - s4);
+    }
+  }
+}
+int sq_launch_slot_tail_bwd(const TailBwdArgs& a, Dims d, hipStream_t s) {
+  hipLaunchKernelGGL(k_slot_tail_bwd, dim3(d.R), dim3(128), 0, s, a, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// crop adjoint inside the recurrence: d glimpse -> d where (all consumers' gradients are already in the gradient
+// record) -> adjoint of the where sample -> d(transform output) [R][8], d(previous where), d(mask).
+// modes as CropMode.  One workgroup per sequence.
+// ------------------------------------------------------------------------------------------------
+struct CropChainBwdArgs {
+  int mode, slot;
+  const float* img;                      // frame [B,H,W]
+  const float* rec_prev; const float* rec_new;   // forward records (where lives in rec_new for PROP2 / DISC)
+  float* d_rec_prev; float* d_rec_new;   // gradient records
+  const float* wb; int wb_ld;            // PROP1: raw where-bias output
+  float* d_wb;                           // PROP1 out: [M][wb_ld]
+  const float* mask; int mask_row_mul, mask_row_add; float* d_mask;  // optional; d_mask accumulated (+=)
+  const float* g_out; int g_row_mul, g_row_add;                       // d glimpse [rows][G2]
+  const float* tp; int tp_ld;            // saved transform output (loc 0:4, raw 4:8)
+  float* d_tp; int dtp_ld;               // out
+  const float* noise; const float* flat; float* flat_grad;
+};
+__global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a, const POff po, const Dims d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* img_s = smem;
+  __shared__ float red_s[4][4];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int slot = a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot;
+  const int P = d.H * d.W, G = d.G, G2 = d.G * d.G, RW = rec::W;
+  const float* img = a.img + (size_t)b * P;
+  for (int i = tid; i < P; i += 256) img_s[i] = img[i];
+  __syncthreads();
+  const int madd = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
+  const int gadd = a.g_row_add + (a.mode == CROP_PROP1 ? slot : 0);
+  for (int kp = 0; kp < d.K; ++kp) {
+    const int r = b * d.K + kp;
+    float wl[4];
+    const float* wsrc = a.mode == CROP_PROP1 ? a.rec_prev + ((size_t)r * d.N + slot) * RW + rec::WHERE
+                                             : a.rec_new + ((size_t)r * d.N + slot) * RW + rec::WHERE;
+    for (int i = 0; i < 4; ++i) wl[i] = wsrc[i] + (a.mode == CROP_PROP1 ? 0.1f * a.wb[((size_t)r * d.N + slot) * a.wb_ld + i] : 0.0f);
+    const float s0 = sq_sigmoid(wl[0]), s1 = sq_sigmoid(wl[1]);
+    const float sx = fmaxf(s0, 1e-4f), sy = fmaxf(s1, 1e-4f), tx = tanhf(wl[2]), ty = tanhf(wl[3]);
+    const float hx = 0.5f * (float)(d.W - 1), hy = 0.5f * (float)(d.H - 1);
+    float dsx = 0.0f, dsy = 0.0f, dtx = 0.0f, dty = 0.0f;
+    for (int pix = tid; pix < G2; pix += 256) {
+      const int i = pix / G, j = pix - i * G;
+      const float gx = -1.0f + 2.0f * (float)j / (float)(G - 1), gy = -1.0f + 2.0f * (float)i / (float)(G - 1);
+      const float x = hx * (sx * gx + tx + 1.0f), y = hy * (sy * gy + ty + 1.0f);
+      const float x0f = floorf(x), y0f = floorf(y);
+      const int x0 = (int)x0f, y0 = (int)y0f;
+      const float wx1 = x - x0f, wy1 = y - y0f;
+      float t[2][2];
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int yy = y0 + dy, xx = x0 + dx;
+          t[dy][dx] = (yy >= 0 && yy < d.H && xx >= 0 && xx < d.W) ? img_s[yy * d.W + xx] : 0.0f;
+        }
+      const float v = (1.0f - wy1) * ((1.0f - wx1) * t[0][0] + wx1 * t[0][1]) + wy1 * ((1.0f - wx1) * t[1][0] + wx1 * t[1][1]);
+      const float dvdx = (1.0f - wy1) * (t[0][1] - t[0][0]) + wy1 * (t[1][1] - t[1][0]);
+      const float dvdy = (1.0f - wx1) * (t[1][0] - t[0][0]) + wx1 * (t[1][1] - t[0][1]);
+      float g = a.g_out[((size_t)r * a.g_row_mul + gadd) * G2 + pix];
+      if (a.mask != nullptr) {
+        const size_t mi = ((size_t)r * a.mask_row_mul + madd) * G2 + pix;
+        a.d_mask[mi] += g * v;
+        g *= a.mask[mi];
+      }
+      dsx += g * dvdx * hx * gx;
+      dtx += g * dvdx * hx;
+      dsy += g * dvdy * hy * gy;
+      dty += g * dvdy * hy;
+    }
+    dsx = sq_wave_sum(dsx); dsy = sq_wave_sum(dsy); dtx = sq_wave_sum(dtx); dty = sq_wave_sum(dty);
+    if (lane == 0) { red_s[wave][0] = dsx; red_s[wave][1] = dsy; red_s[wave][2] = dtx; red_s[wave][3] = dty; }
+    __syncthreads();
+    if (tid < 4) {
+      const int i = tid;
+      const float tot = red_s[0][i] + red_s[1][i] + red_s[2][i] + red_s[3][i];
+      const float dl = i == 0 ? s0 * (1.0f - s0) : (i == 1 ? s1 * (1.0f - s1) : (i == 2 ? 1.0f - tx * tx : 1.0f - ty * ty));
+      const float g_crop = tot * dl;
+      if (a.mode == CROP_PROP1) {
+        a.d_rec_prev[((size_t)r * d.N + slot) * RW + rec::WHERE + i] += g_crop;
+        a.d_wb[((size_t)r * d.N + slot) * a.wb_ld + i] = 0.1f * g_crop;
+      } else {
+        float* drn = a.d_rec_new + ((size_t)r * d.N + slot) * RW;
+        const float dW = drn[rec::WHERE + i] + g_crop;  // every other consumer has already accumulated here
+        const float* eps = a.noise + (((size_t)r * 2 + (a.mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
+        const float* tp = a.tp + (size_t)r * a.tp_ld;
+        const float d_loc = dW + drn[rec::WHERE_LOC + i];
+        float d_sc = drn[rec::WHERE_SCALE + i];
+        float d_raw;
+        if (a.mode == CROP_DISC) {
+          d_sc += dW * eps[i];
+          const float off = a.flat[po.disc_scale_offset];
+          d_raw = d_sc * sq_sigmoid(tp[4 + i] + off);
+          atomicAdd(&a.flat_grad[po.disc_scale_offset], d_raw);
+        } else {
+          const float* ch = a.flat + po.cholesky;
+          const float sci = a.rec_new[((size_t)r * d.N + slot) * RW + rec::WHERE_SCALE + i];
+          float lin = 0.0f;
+          for (int j = 0; j <= i; ++j) {
+            lin += (tril4(ch, i, j) + (i == j ? 1.0f : 0.0f)) * eps[j];
+            const int q = i * 4 + j;
+            atomicAdd(&a.flat_grad[po.cholesky + (q < 6 ? 4 + q : 15 - q)], dW * sci * eps[j]);
+          }
+          d_sc += dW * lin;
+          const float off = a.flat[po.prop_scale_offset];
+          d_raw = d_sc * sq_sigmoid(tp[4 + i] + off - 1.0f);
+          atomicAdd(&a.flat_grad[po.prop_scale_offset], d_raw);
+          a.d_rec_prev[((size_t)r * d.N + slot) * RW + rec::WHERE + i] += d_loc;  // loc = where_{t-1} + transform
+        }
+        a.d_tp[(size_t)r * a.dtp_ld + i] = d_loc;
+        a.d_tp[(size_t)r * a.dtp_ld + 4 + i] = d_raw;
+      }
+    }
+    __syncthreads();
+  }
+}
+int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
+  const size_t shm = (size_t)d.H * d.W * sizeof(float);
+  static bool big = false;
+  if (shm > 48 * 1024 && !big) {
+    (void)hipFuncSetAttribute((const void*)k_crop_chain_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipGetLastError();
+    big = true;
+  }
+  hipLaunchKernelGGL(k_crop_chain_bwd, dim3(d.B, nslots), dim3(256), shm, s, a, po, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GRU gate adjoints (snt.GRU: z, r gates; hc = tanh(x W_h + (r h) U_h + b_h); h' = (1 - z) h + z hc)
+//   stage A: from d h' -> dPre columns [d_az | . | d_ah] and the direct part of d h
+//   stage B: after d(r h) = d_ah U_h^T -> d_ar, d h += d(rh) r
+// dpre1 is [rows][3 nh] (the dPre of the fused gate GEMM); rows addressed with explicit strides.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_gru_bwd_a(const float* __restrict__ d_hn, int dhn_ld, const float* __restrict__ z, int z_ld,
+                            const float* __restrict__ hc, int hc_ld, const float* __restrict__ hprev, int h_ld,
+                            float* __restrict__ dpre1, int dp_ld, float* __restrict__ d_h, int dh_ld, int rows, int nh,
+                            int accumulate_dh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * nh) return;
+  const int m = i / nh, n = i - m * nh;
+  const float g = d_hn[(size_t)m * dhn_ld + n];
+  const float zz = z[(size_t)m * z_ld + n], hh = hc[(size_t)m * hc_ld + n], hp = hprev[(size_t)m * h_ld + n];
+  dpre1[(size_t)m * dp_ld + n] = g * (hh - hp) * zz * (1.0f - zz);
+  dpre1[(size_t)m * dp_ld + 2 * nh + n] = g * zz * (1.0f - hh * hh);
+  float* dh = d_h + (size_t)m * dh_ld + n;
+  *dh = (accumulate_dh ? *dh : 0.0f) + g * (1.0f - zz);
+}
+__global__ void k_gru_bwd_b(const float* __restrict__ d_rh, int drh_ld, const float* __restrict__ rg, int r_ld,
+                            const float* __restrict__ hprev, int h_ld, float* __restrict__ dpre1, int dp_ld,
+                            float* __restrict__ d_h, int dh_ld, int rows, int nh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * nh) return;
+  const int m = i / nh, n = i - m * nh;
+  const float g = d_rh[(size_t)m * drh_ld + n], rr = rg[(size_t)m * r_ld + n], hp = hprev[(size_t)m * h_ld + n];
+  dpre1[(size_t)m * dp_ld + nh + n] = g * hp * rr * (1.0f - rr);
+  d_h[(size_t)m * dh_ld + n] += g * rr;
+}
+int sq_launch_gru_bwd_a(const float* d_hn, int dhn_ld, const float* z, int z_ld, const float* hc, int hc_ld,
+                        const float* hprev, int h_ld, float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh,
+                        int accumulate_dh, hipStream_t s) {
+  hipLaunchKernelGGL(k_gru_bwd_a, dim3((rows * nh + 255) / 256), dim3(256), 0, s, d_hn, dhn_ld, z, z_ld, hc, hc_ld, hprev,
+                     h_ld, dpre1, dp_ld, d_h, dh_ld, rows, nh, accumulate_dh);
+  return 0;
+}
+int sq_launch_gru_bwd_b(const float* d_rh, int drh_ld, const float* rg, int r_ld, const float* hprev, int h_ld,
+                        float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh, hipStream_t s) {
+  hipLaunchKernelGGL(k_gru_bwd_b, dim3((rows * nh + 255) / 256), dim3(256), 0, s, d_rh, drh_ld, rg, r_ld, hprev, h_ld,
+                     dpre1, dp_ld, d_h, dh_ld, rows, nh);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// strided elementwise helpers
+// ------------------------------------------------------------------------------------------------
+// out[m][n] = (acc ? out : 0) + in[m][n] * act'(saved[m][n])   with per-column-range activations (act_a below split)
+__global__ void k_dact2(const float* __restrict__ din, int in_ld, const float* __restrict__ saved, int s_ld,
+                        float* __restrict__ dout, int out_ld, int rows, int cols, int act_a, int act_b, int split, int acc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int m = i / cols, n = i - m * cols;
+  float g = din[(size_t)m * in_ld + n];
+  const int act = n < split ? act_a : act_b;
+  if (act != ACT_NONE) {
+    const float o = saved[(size_t)m * s_ld + n];
+    if (act == ACT_ELU) g *= delu_from_out(o);
+    else if (act == ACT_TANH) g *= 1.0f - o * o;
+    else if (act == ACT_SIGMOID) g *= o * (1.0f - o);
+    else if (act == ACT_SOFTPLUS_MIN) g *= 1.0f - expf(-(o - 1e-2f));
+  }
+  float* p = dout + (size_t)m * out_ld + n;
+  *p = (acc ? *p : 0.0f) + g;
+}
+int sq_launch_dact2(const float* din, int in_ld, const float* saved, int s_ld, float* dout, int out_ld, int rows, int cols,
+                    int act_a, int act_b, int split, int acc, hipStream_t s) {
+  hipLaunchKernelGGL(k_dact2, dim3((rows * cols + 255) / 256), dim3(256), 0, s, din, in_ld, saved, s_ld, dout, out_ld, rows,
+                     cols, act_a, act_b, split, acc);
+  return 0;
+}
+// column sums of dY[rows][cols] (+)= into out[cols] (bias gradients)
+__global__ void k_colsum(const float* __restrict__ dy, int ld, int rows, int cols, float* __restrict__ out, int acc) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;  // 4 row partitions
+  __shared__ float red[4][64];
+  float sacc = 0.0f;
+  if (n < cols)
+    for (int m = part; m < rows; m += 4) sacc += dy[(size_t)m * ld + n];
+  red[part][threadIdx.x & 63] = sacc;
+  __syncthreads();
+  if (part == 0 && n < cols) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    out[n] = (acc ? out[n] : 0.0f) + t;
+  }
+}
+int sq_launch_colsum(const float* dy, int ld, int rows, int cols, float* out, int acc, hipStream_t s) {
+  hipLaunchKernelGGL(k_colsum, dim3((cols + 63) / 64), dim3(256), 0, s, dy, ld, rows, cols, out, acc);
+  return 0;
+}
+// latent-summary adjoint: d f[(r,k)][n] = d c[r][n] * presence_k ; particle sum: d pre_disc[b][n] = sum_kp d pre_d[b K + kp][n]
+__global__ void k_latent_sum_bwd(const float* __restrict__ d_c, const float* __restrict__ rec_p, float* __restrict__ d_f, Dims d) {
+  const int rk = blockIdx.x;  // r * N + k
+  const float pres = rec_p[(size_t)rk * rec::W + rec::PRES];
+  for (int n = threadIdx.x; n < d.nh; n += blockDim.x) d_f[(size_t)rk * d.nh + n] = d_c[(size_t)(rk / d.N) * d.nh + n] * pres;
+}
+int sq_launch_latent_sum_bwd(const float* d_c, const float* rec_p, float* d_f, Dims d, hipStream_t s) {
+  hipLaunchKernelGGL(k_latent_sum_bwd, dim3(d.R * d.N), dim3(256), 0, s, d_c, rec_p, d_f, d);
+  return 0;
+}
+__global__ void k_particle_sum(const float* __restrict__ in, float* __restrict__ out, int B, int K, int nh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nh) return;
+  const int b = i / nh, n = i - b * nh;
+  float acc = 0.0f;
+  for (int kp = 0; kp < K; ++kp) acc += in[(size_t)(b * K + kp) * nh + n];
+  out[i] = acc;
+}
+int sq_launch_particle_sum(const float* in, float* out, int B, int K, int nh, hipStream_t s) {
+  hipLaunchKernelGGL(k_particle_sum, dim3((B * nh + 255) / 256), dim3(256), 0, s, in, out, B, K, nh);
+  return 0;
+}
+// y[m][n] (+)= x[m][n] over a strided sub-block
+__global__ void k_axpy2d(const float* __restrict__ x, int x_ld, float* __restrict__ y, int y_ld, int rows, int cols, int acc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int m = i / cols, n = i - m * cols;
+  float* p = y + (size_t)m * y_ld + n;
+  *p = (acc ? *p : 0.0f) + x[(size_t)m * x_ld + n];
+}
+int sq_launch_axpy2d(const float* x, int x_ld, float* y, int y_ld, int rows, int cols, int acc, hipStream_t s) {
+  hipLaunchKernelGGL(k_axpy2d, dim3((rows * cols + 255) / 256), dim3(256), 0, s, x, x_ld, y, y_ld, rows, cols, acc);
+  return 0;
+}

@@ -116,6 +116,11 @@ __device__ __forceinline__ float sq_normal_lp(float x, float loc, float scale) {
 __device__ __forceinline__ float sq_bernoulli_lp(float x, float logit) {
   return -(fmaxf(logit, 0.0f) - logit * x + log1pf(expf(-fabsf(logit))));
 }
+// tfd.fill_triangular for n = 4: reshape(concat(v[4:], reverse(v)), [4,4]), lower band
+__device__ __forceinline__ float tril4(const float* __restrict__ v, int i, int j) {
+  const int q = i * 4 + j;
+  return q < 6 ? v[4 + q] : v[15 - q];
+}
 __device__ __forceinline__ float sq_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

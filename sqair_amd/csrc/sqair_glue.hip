@@ -50,11 +50,6 @@ int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float*
 // once and cuts the glimpses of all K particles of that sequence from it.  The `where` sample of
 // the propagation / discovery core is drawn in the same launch (core.py:323-334, :217-227).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float tril4(const float* __restrict__ v, int i, int j) {
-  // tfd.fill_triangular for n = 4: reshape(concat(v[4:], reverse(v)), [4,4]), lower band
-  const int q = i * 4 + j;
-  return q < 6 ? v[4 + q] : v[15 - q];
-}
 
 __global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, const Dims d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -29,8 +29,12 @@ struct SqairHandle {
   // packing plan
   PackedLayer layers[L_COUNT];
   PackedLayer layersT[L_COUNT];     // transposed packs (dX = dY W^T), K' = padded N, N' = padded concat K
-  std::vector<int> rowmaps;         // per layer: A-position -> reference row of the FIRST column block (wgrad)
-  int64_t rowmap_off[L_COUNT];
+  // weight-gradient plan: per layer, one entry per (column block, segment) with the A-position -> matrix-row map
+  struct WgEntry { int n0, ncols, col0, seg; std::string w; int64_t rm_off; };
+  struct BgEntry { int n0, ncols, col0; std::string a, b; };
+  std::vector<WgEntry> wg[L_COUNT];
+  std::vector<BgEntry> bg[L_COUNT];
+  std::vector<int> rm_pool;
   std::vector<int> widx;            // per packed weight element: index into flat params or -1
   std::vector<int> bidx_a, bidx_b;  // per packed bias element
   int64_t packed_w = 0, packed_b = 0;
@@ -55,7 +59,7 @@ int PC(const SqairHandle* h, const std::string& name);      // its number of col
 
 // packed buffer = [weights fp32 | biases fp32 | widx int32 | bidx_a | bidx_b], each 256-byte aligned
 struct PackedLayout {
-  int64_t w, b, wi, ba, bb, total;  // offsets in 4-byte words
+  int64_t w, b, wi, ba, bb, rm, total;  // offsets in 4-byte words
 };
 inline PackedLayout packed_layout(const SqairHandle* h) {
   PackedLayout p;
@@ -64,7 +68,8 @@ inline PackedLayout packed_layout(const SqairHandle* h) {
   p.wi = align64(p.b + h->packed_b);
   p.ba = align64(p.wi + h->packed_w);
   p.bb = align64(p.ba + h->packed_b);
-  p.total = align64(p.bb + h->packed_b);
+  p.rm = align64(p.bb + h->packed_b);
+  p.total = align64(p.rm + (int64_t)h->rm_pool.size());
   return p;
 }
 
@@ -99,7 +104,7 @@ struct Lin {
 
 // ------------------------------------------------------------------------------------------------
 // workspace.  In training mode (train = true) every intermediate the backward pass needs is kept: per-frame
-// buffers become [T][...], per-slot buffers a "tape" [T][2 phases][B'][N slots][width] (slot-inner like the slot
+// buffers become [T][...], per-slot buffers a "tape" [2 phases][T][B'][N slots][width] (slot-inner like the slot
 // records, so a slot launch addresses it with row stride N * width and the batched weight-gradient GEMMs see all
 // uses of a layer as one long row range).
 // ------------------------------------------------------------------------------------------------
@@ -128,7 +133,7 @@ struct Workspace {
   float* state(float* base, int t) const { return base + (size_t)(train ? t : (t & 1)) * M * nh; }
   // slot buffer of width W: pointer of (frame t, phase ph, slot k) and its row stride
   float* slot(float* base, int W, int t, int ph, int k) const {
-    return base + (train ? (((size_t)(t * 2 + ph) * R * N) + k) * W : 0);
+    return base + (train ? (((size_t)(ph * T + t) * R * N) + k) * W : 0);  // [phase][T][B'][N][W]
   }
   int sld(int W) const { return train ? N * W : W; }
   float* rslot(int t, int ph, int k) const {  // RNN hidden state: ping-pong over slots when no tape is kept

@@ -1,0 +1,546 @@
+// sqair_backward — reverse sweep of the whole forward pass: gradients of the VIMCO
+// target / T (reference: Model.make_target sqair/model.py:150-168, targets.vimco sqair/targets.py:62-75; the
+// reference obtains them from TF autodiff through tf.while_loop, both static_rnns, the resampler, the
+// dynamic_partition) w.r.t. every trainable parameter, written into the flat gradient buffer.
+//
+// Structure mirrors sqair_forward (sections A..J of sq_forward_impl) in reverse:
+//   ELBO adjoint -> decoder branch + log-probability adjoint for all T frames at once (they are off the recurrence)
+//   -> for t = T-1..0: compaction^T, discovery slots N-1..0, latent summary, propagation slots N-1..0, the
+//      loop-invariant pre-activation GEMM, crop #1 / mask / where-bias MLPs, prior GRU
+//   -> initial states, input encoder -> ONE weight-gradient GEMM per (layer, segment) over all its uses (the tape
+//      keeps activations and pre-activation gradients of every use in slot-inner order, M up to 2*T*B'*N rows).
+// Every dense adjoint is the forward MFMA kernel on the transposed pack; gradients of z-record segments come out in
+// record order and accumulate straight into "gradient records".
+#include "sqair_internal.h"
+
+// launchers from sqair_bwd.hip
+struct LogprobBwdArgs {
+  const float* rec_p; const float* rec_d; const float* rec_m;
+  const float* pstats; int ps_ld; const float* spre;
+  const float* g_lw; const float* g_dl;
+  float* d_rec_p; float* d_rec_d; float* d_rec_m;
+  float* d_pstats;
+  float* d_spre;
+  const float* flat; float* flat_grad;
+  int t_global0;
+  SqairConfig cfg;
+};
+struct CompactBwdArgs {
+  const int* src;
+  const float* d_rec_next;
+  const float* d_temporal_next; const float* d_prior_next;
+  float* d_rec_p; float* d_rec_d;
+  float* d_temporal_p; float* d_prior_p;
+  float* flat_grad;
+};
+struct TailBwdArgs {
+  int is_disc, slot;
+  const float* rec_prev; const float* rec_new; float* d_rec_new; float* d_rec_prev;
+  const float* s1h; int s1h_ld;
+  const float* hraw; int h_ld; const float* enc; int enc_ld; const float* noise;
+  float* d_s1pre; int ds_ld;
+  float* d_enc; int de_ld;
+  float* d_hraw; int dh_ld;
+  const float* flat; float* flat_grad;
+  int w2_off, b2_off, wwhat_off;
+};
+struct CropChainBwdArgs {
+  int mode, slot;
+  const float* img;
+  const float* rec_prev; const float* rec_new;
+  float* d_rec_prev; float* d_rec_new;
+  const float* wb; int wb_ld;
+  float* d_wb;
+  const float* mask; int mask_row_mul, mask_row_add; float* d_mask;
+  const float* g_out; int g_row_mul, g_row_add;
+  const float* tp; int tp_ld;
+  float* d_tp; int dtp_ld;
+  const float* noise; const float* flat; float* flat_grad;
+};
+int sq_launch_logprob_bwd(const LogprobBwdArgs& a, POff po, Dims d, int T, hipStream_t s);
+int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t s);
+int sq_launch_slot_tail_bwd(const TailBwdArgs& a, Dims d, hipStream_t s);
+int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nslots, hipStream_t s);
+int sq_launch_gru_bwd_a(const float* d_hn, int dhn_ld, const float* z, int z_ld, const float* hc, int hc_ld,
+                        const float* hprev, int h_ld, float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh,
+                        int accumulate_dh, hipStream_t s);
+int sq_launch_gru_bwd_b(const float* d_rh, int drh_ld, const float* rg, int r_ld, const float* hprev, int h_ld,
+                        float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh, hipStream_t s);
+int sq_launch_dact2(const float* din, int in_ld, const float* saved, int s_ld, float* dout, int out_ld, int rows, int cols,
+                    int act_a, int act_b, int split, int acc, hipStream_t s);
+int sq_launch_colsum(const float* dy, int ld, int rows, int cols, float* out, int acc, hipStream_t s);
+int sq_launch_latent_sum_bwd(const float* d_c, const float* rec_p, float* d_f, Dims d, hipStream_t s);
+int sq_launch_particle_sum(const float* in, float* out, int B, int K, int nh, hipStream_t s);
+int sq_launch_axpy2d(const float* x, int x_ld, float* y, int y_ld, int rows, int cols, int acc, hipStream_t s);
+int sq_launch_wgrad(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int Kdim,
+                    int Ndim, int accumulate, hipStream_t s, const int* rowmap = nullptr, const float* alpha_ptr = nullptr);
+int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_ld, const float* img, const float* mean_img,
+                                const float* g_ll, float* d_glimpse, float* d_rec, int d_rec_ld, float* d_mean_rows,
+                                float std_fg, float std_bg, int T, Dims d, hipStream_t s);
+int sq_launch_reduce_rows(const float* rows, float* out, int R, int P, int accumulate, hipStream_t s);
+int sq_launch_elbo_bwd(const float* iw, const float* sig, int T, int B, int K, float* g_lw, float* g_dl, hipStream_t s);
+int sq_launch_dot_scale(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s);
+
+// a few elementwise helpers local to the driver
+__global__ void k_mul2d(const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld, float* __restrict__ out,
+                        int o_ld, int rows, int cols) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int m = i / cols, n = i - m * cols;
+  out[(size_t)m * o_ld + n] = a[(size_t)m * a_ld + n] * b[(size_t)m * b_ld + n];
+}
+// shifted z-record / RNN-state inputs of the slot RNNs as dense matrices for the batched weight gradient:
+//   zs[(t,r,k)] = z-record of slot k-1 (k > 0) or `init_rec` (k = 0);  rs[(t,r,k)] = r tape of slot k-1 or rnn_init
+__global__ void k_shift_inputs(const float* __restrict__ rec_all, const float* __restrict__ r_tape, const float* __restrict__ init_rec,
+                               const float* __restrict__ rnn_init, float* __restrict__ zs, float* __restrict__ rs, int rows,
+                               int N, int nh) {
+  const int row = blockIdx.x;  // (t, r, k) flattened
+  if (row >= rows) return;
+  const int k = row % N;
+  for (int i = threadIdx.x; i < 64; i += blockDim.x)
+    zs[(size_t)row * 64 + i] = i < rec::ZW ? (k > 0 ? rec_all[(size_t)(row - 1) * rec::W + i] : init_rec[i]) : 0.0f;
+  for (int i = threadIdx.x; i < nh; i += blockDim.x)
+    rs[(size_t)row * nh + i] = k > 0 ? r_tape[(size_t)(row - 1) * nh + i] : rnn_init[i];
+}
+
+struct BwdSpace {
+  float *g_lw, *g_dl;
+  float *d_rec_m, *d_rec_p, *d_rec_d;          // gradient records
+  float *d_tm[2], *d_pm[2];                    // d temporal / prior merged state, by frame parity
+  float *d_temporal_p, *d_prior_p;
+  float *d_pstats, *d_spre;
+  // per-frame pre-activation gradients (kept for the batched weight gradients)
+  float *d_pgru1, *d_hid1, *d_wb, *d_maskpre, *d_pea, *d_peb, *d_m1, *d_pre, *d_lea, *d_leb, *d_pre_d, *d_pre_disc;
+  // per-slot pre-activation gradients [2][T][R][N][W]
+  float *d_rnn, *d_t1, *d_t2, *d_tp, *d_e1, *d_e2, *d_enc3, *d_gru1, *d_hraw;
+  // scratch
+  float *d_mask, *d_g, *d_g1, *d_c, *dcat, *tmp, *tmp2, *d_r[2], *dhn, *d_rh, *d_enc, *d_hid1out;
+  float *d_gl, *d_mean_rows, *bufa, *bufb, *d_ia, *d_ib, *zs, *rs, *rh;
+  int64_t total;
+};
+
+static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
+  const SqairConfig& c = h->cfg;
+  const int64_t nh = c.n_hidden, N = c.n_steps_per_image, R = (int64_t)B * c.k_particles, M = R * N;
+  const int64_t G2 = c.glimpse_size * c.glimpse_size, P_ = c.img_h * c.img_w, MT = M * T;
+  const int64_t pre_ld = h->layers[L_PRE].nt * 16;
+  BwdSpace b;
+  memset(&b, 0, sizeof(b));
+  int64_t o = 0;
+  auto take = [&](int64_t n) {
+    float* p = base ? base + o : nullptr;
+    o += align64(n);
+    return p;
+  };
+  b.g_lw = take(T * R); b.g_dl = take(T * R);
+  b.d_rec_m = take((T + 1) * M * rec::W); b.d_rec_p = take(MT * rec::W); b.d_rec_d = take(MT * rec::W);
+  for (int i = 0; i < 2; ++i) { b.d_tm[i] = take(M * nh); b.d_pm[i] = take(M * nh); }
+  b.d_temporal_p = take(M * nh); b.d_prior_p = take(M * nh);
+  b.d_pstats = take(MT * PS_LD); b.d_spre = take(T * R * 128);
+  b.d_pgru1 = take(MT * 3 * nh); b.d_hid1 = take(MT * 256); b.d_wb = take(MT * WB_LD); b.d_maskpre = take(MT * G2);
+  b.d_pea = take(MT * nh); b.d_peb = take(MT * nh); b.d_m1 = take(MT * M1_LD); b.d_pre = take(MT * pre_ld);
+  b.d_lea = take(MT * nh); b.d_leb = take(MT * nh); b.d_pre_d = take(T * R * nh); b.d_pre_disc = take((int64_t)T * B * nh);
+  const int64_t S = 2 * MT;
+  b.d_rnn = take(S * nh); b.d_t1 = take(S * T1_LD); b.d_t2 = take(S * nh); b.d_tp = take(S * TP_LD);
+  b.d_e1 = take(S * nh); b.d_e2 = take(S * nh); b.d_enc3 = take(S * ENC_LD); b.d_gru1 = take(MT * 3 * nh);
+  b.d_hraw = take(MT * HRAW_LD);
+  b.d_mask = take(M * G2); b.d_g = take(R * G2); b.d_g1 = take(M * G2); b.d_c = take(R * nh);
+  b.dcat = take(M * 512); b.tmp = take(M * 512); b.tmp2 = take(M * 512);
+  b.d_r[0] = take(R * nh); b.d_r[1] = take(R * nh); b.dhn = take(M * nh); b.d_rh = take(M * nh);
+  b.d_enc = take(R * ENC_LD); b.d_hid1out = take(M * 256);
+  const int64_t big = MT * (nh > G2 ? nh : G2);
+  b.d_gl = take(MT * G2); b.d_mean_rows = take(T * R * P_); b.bufa = take(big); b.bufb = take(big);
+  b.d_ia = take((int64_t)T * B * nh); b.d_ib = take((int64_t)T * B * nh);
+  b.zs = take(MT * 64); b.rs = take(MT * nh); b.rh = take(MT * nh);
+  b.total = o;
+  return b;
+}
+
+extern "C" int64_t sqair_backward_bytes(const SqairHandle* h, int T, int B) {
+  if (!h || T < 1 || B < 1) return -1;
+  return carve_bwd(h, T, B, nullptr).total * 4;
+}
+
+#define CK(x) do { int _r = (x); if (_r != 0) { sq_set_error(h, std::string("sqair_backward: ") + #x); return _r; } } while (0)
+
+extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* packedv, const float* obs, const float* noise,
+                              const float* importance_weights, const float* vimco_signal, int T, int B, int t_offset,
+                              void* train_workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
+                              float* flat_grad, void* stream) {
+  if (!h || !flat || !packedv || !obs || !noise || !importance_weights || !vimco_signal || !train_workspace || !scratch || !flat_grad)
+    return -1;
+  if (workspace_bytes < sqair_train_workspace_bytes(h, T, B) || scratch_bytes < sqair_backward_bytes(h, T, B)) {
+    sq_set_error(h, "sqair_backward: workspace / scratch too small");
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const float* packed = (const float*)packedv;
+  const SqairConfig& c = h->cfg;
+  const int nh = c.n_hidden, nw = c.n_what, N = c.n_steps_per_image, K = c.k_particles;
+  const int R = B * K, M = R * N, MT = M * T, G2 = c.glimpse_size * c.glimpse_size, P_ = c.img_h * c.img_w;
+  const int nzw = 4 + nw + 1, RW = rec::W, nsp = nh / 2;
+  Dims d{c.img_h, c.img_w, c.glimpse_size, N, nw, nh, K, R, B, nzw};
+  const POff po = h->po;
+  const Workspace w = sq_carve(h, T, B, (float*)train_workspace, true);
+  const BwdSpace b = carve_bwd(h, T, B, (float*)scratch);
+  const PackedLayout pl = packed_layout(h);
+  const int pre_ld = h->layers[L_PRE].nt * 16;
+  const int* rm_dev = (const int*)packed + pl.rm;
+
+  SQ_CHECK_HIP(hipMemsetAsync(flat_grad, 0, (size_t)h->n_params * 4, s));
+  SQ_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)b.total * 4, s));
+
+  // dX through the transposed pack: out[M][K of the forward layer] (+)= dpre[M][N] W^T.  Single-segment layers write
+  // exactly their true input width; multi-segment layers write all 16 * kc padded columns (the caller splits them).
+  auto dx = [&](LayerId id, const float* dpre, int ld, int Mrows, float* outp, int out_ld, bool acc,
+                const float* scale_ptr = nullptr) -> int {
+    const PackedLayer& LT = h->layersT[id];
+    const PackedLayer& LF = h->layers[id];
+    Lin l;
+    l.seg(dpre, ld, LF.N).out(outp, out_ld).act(ACT_NONE);
+    l.a.scale_ptr = scale_ptr;
+    l.a.wp = packed + pl.w + LT.w_off; l.a.wzero = packed + pl.w; l.a.bias = packed + pl.b + LT.b_off;
+    l.a.M = Mrows; l.a.N = LF.seg_width.size() == 1 ? LF.seg_width[0] : LT.N;
+    if (acc) { l.a.add = outp; l.a.add_ld = out_ld; l.a.add_n = l.a.N; }
+    const int rc = sq_launch_linear(l.a, LT, s);
+    if (rc != 0) sq_set_error(h, "sqair_backward: A-operand contract violated in dX of layer " + std::to_string((int)id));
+    return rc;
+  };
+  // batched weight + bias gradients of one layer over `rows` uses
+  auto wgrad = [&](LayerId id, std::vector<std::pair<const float*, int>> segs, const float* dY, int ldy, int rows) {
+    for (const auto& e : h->wg[id])
+      sq_launch_wgrad(segs[e.seg].first, segs[e.seg].second, dY + e.n0, ldy, flat_grad + P(h, e.w) + e.col0, PC(h, e.w),
+                      nullptr, rows, h->layers[id].seg_width[e.seg], e.ncols, 1, s, rm_dev + e.rm_off, nullptr);
+    for (const auto& e : h->bg[id]) {
+      if (!e.a.empty()) sq_launch_colsum(dY + e.n0, ldy, rows, e.ncols, flat_grad + P(h, e.a) + e.col0, 1, s);
+      if (!e.b.empty()) sq_launch_colsum(dY + e.n0, ldy, rows, e.ncols, flat_grad + P(h, e.b) + e.col0, 1, s);
+    }
+  };
+  auto slotp = [&](float* base, int W, int t, int ph, int k) { return base + (((size_t)(ph * T + t) * R * N) + k) * W; };
+  auto cslotp = [&](const float* base, int W, int t, int ph, int k) { return base + (((size_t)(ph * T + t) * R * N) + k) * W; };
+
+  // ================= 0. objective =================
+  sq_launch_elbo_bwd(importance_weights, vimco_signal, T, B, K, b.g_lw, b.g_dl, s);
+
+  // ================= J^T. decoder branch, all frames =================
+  {
+    const float* rec_all = w.rec_m_all + (size_t)M * RW;
+    float* d_rec_all = b.d_rec_m + (size_t)M * RW;
+    const float* gl = w.glimpse;
+    sq_launch_insert_bwd_frames(gl, rec_all, RW, obs, flat + po.dec_mean_img, b.g_lw, b.d_gl, d_rec_all + rec::WHERE, RW,
+                                b.d_mean_rows, c.output_std, c.background_std, T, d, s);
+    sq_launch_reduce_rows(b.d_mean_rows, flat_grad + po.dec_mean_img, T * R, P_, 0, s);
+    const float* scale = flat + po.dec_output_scale;
+    sq_launch_dot_scale(b.d_gl, gl, (int64_t)MT * G2, scale, flat_grad + po.dec_output_scale, s);
+    sq_launch_wgrad(w.dec_b, nh, b.d_gl, G2, flat_grad + P(h, "dec.l2.w"), G2, flat_grad + P(h, "dec.l2.b"), MT, nh, G2, 0, s,
+                    nullptr, scale);
+    CK(dx(L_DEC2, b.d_gl, G2, MT, b.bufa, nh, false, scale));
+    sq_launch_dact2(b.bufa, nh, w.dec_b, nh, b.bufb, nh, MT, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+    wgrad(L_DEC1, {{w.dec_a, nh}}, b.bufb, nh, MT);
+    CK(dx(L_DEC1, b.bufb, nh, MT, b.bufa, nh, false));
+    sq_launch_dact2(b.bufa, nh, w.dec_a, nh, b.bufb, nh, MT, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+    wgrad(L_DEC0, {{rec_all, RW}}, b.bufb, nh, MT);
+    CK(dx(L_DEC0, b.bufb, nh, MT, d_rec_all, RW, true));
+  }
+  // ================= H^T. log-probabilities, all frames =================
+  {
+    LogprobBwdArgs la; memset(&la, 0, sizeof(la));
+    la.rec_p = w.rec_p_all; la.rec_d = w.rec_d_all; la.rec_m = w.rec_m_all; la.pstats = w.pstats; la.ps_ld = PS_LD;
+    la.spre = w.spre; la.g_lw = b.g_lw; la.g_dl = b.g_dl; la.d_rec_p = b.d_rec_p; la.d_rec_d = b.d_rec_d;
+    la.d_rec_m = b.d_rec_m; la.d_pstats = b.d_pstats; la.d_spre = b.d_spre; la.flat = flat; la.flat_grad = flat_grad;
+    la.t_global0 = t_offset; la.cfg = c;
+    sq_launch_logprob_bwd(la, po, d, T, s);
+  }
+
+  // ================= reverse sweep over the frames =================
+  for (int t = T - 1; t >= 0; --t) {
+    const float* img = obs + (size_t)t * B * P_;
+    const float* nz = noise + (size_t)t * R * 2 * N * nzw;
+    const float* rec_prev = w.rec_m_all + (size_t)t * M * RW;
+    const float* rec_p_t = w.rec_p_all + (size_t)t * M * RW;
+    const float* rec_d_t = w.rec_d_all + (size_t)t * M * RW;
+    float* d_rec_prev = b.d_rec_m + (size_t)t * M * RW;
+    float* d_rec_next = b.d_rec_m + (size_t)(t + 1) * M * RW;
+    float* d_rec_p_t = b.d_rec_p + (size_t)t * M * RW;
+    float* d_rec_d_t = b.d_rec_d + (size_t)t * M * RW;
+    const float* temporal_prev = w.state(w.temporal_m, t);
+    const float* prior_prev = w.state(w.prior_m, t);
+    float* d_tau = b.d_tm[t & 1];       // d temporal_m[t]
+    float* d_pprev = b.d_pm[t & 1];     // d prior_m[t]
+    const int rl = N * nh, t1l = N * T1_LD, gl2 = N * G2, el = N * ENC_LD, hl = N * HRAW_LD, tpl = N * TP_LD, s1l = N * S1_LD;
+
+    // ---- I^T. compaction
+    {
+      CompactBwdArgs ka; memset(&ka, 0, sizeof(ka));
+      ka.src = w.src + (size_t)t * M; ka.d_rec_next = d_rec_next; ka.d_temporal_next = b.d_tm[(t + 1) & 1];
+      ka.d_prior_next = b.d_pm[(t + 1) & 1]; ka.d_rec_p = d_rec_p_t; ka.d_rec_d = d_rec_d_t;
+      ka.d_temporal_p = b.d_temporal_p; ka.d_prior_p = b.d_prior_p; ka.flat_grad = flat_grad;
+      sq_launch_compact_bwd(ka, po, d, s);
+      SQ_CHECK_HIP(hipMemsetAsync(d_tau, 0, (size_t)M * nh * 4, s));
+      SQ_CHECK_HIP(hipMemsetAsync(d_pprev, 0, (size_t)M * nh * 4, s));
+    }
+    // ---- G^T. discovery steps
+    float* d_pre_d = b.d_pre_d + (size_t)t * R * nh;
+    for (int j = N - 1; j >= 0; --j) {
+      float* d_t1 = slotp(b.d_t1, T1_LD, t, 1, j);
+      float* d_t2 = slotp(b.d_t2, nh, t, 1, j);
+      float* d_tp = slotp(b.d_tp, TP_LD, t, 1, j);
+      float* d_e1 = slotp(b.d_e1, nh, t, 1, j);
+      float* d_e2 = slotp(b.d_e2, nh, t, 1, j);
+      float* d_enc3 = slotp(b.d_enc3, ENC_LD, t, 1, j);
+      float* d_rnn = slotp(b.d_rnn, nh, t, 1, j);
+      const float* r_j = cslotp(w.r, nh, t, 1, j);
+      const float* t1 = cslotp(w.t1, T1_LD, t, 1, j);
+      const float* t2 = cslotp(w.t2, nh, t, 1, j);
+      const float* e1 = cslotp(w.e1, nh, t, 1, j);
+      const float* e2 = cslotp(w.e2, nh, t, 1, j);
+      const float* enc = cslotp(w.enc, ENC_LD, t, 1, j);
+      {
+        TailBwdArgs ta; memset(&ta, 0, sizeof(ta));
+        ta.is_disc = 1; ta.slot = j; ta.rec_prev = rec_prev; ta.rec_new = rec_d_t; ta.d_rec_new = d_rec_d_t;
+        ta.d_rec_prev = d_rec_prev; ta.s1h = cslotp(w.s1h, S1_LD, t, 1, j); ta.s1h_ld = s1l; ta.enc = enc; ta.enc_ld = el;
+        ta.noise = nz; ta.d_s1pre = d_t1 + nh; ta.ds_ld = t1l; ta.d_enc = b.d_enc; ta.de_ld = ENC_LD; ta.flat = flat;
+        ta.flat_grad = flat_grad; ta.w2_off = po.disc_steps_l1_w; ta.b2_off = po.disc_steps_l1_b;
+        ta.wwhat_off = (int)P(h, "disc.steps.l0.w") + nh * nsp;
+        sq_launch_slot_tail_bwd(ta, d, s);
+      }
+      sq_launch_dact2(b.d_enc, ENC_LD, enc, el, d_enc3, el, R, 2 * nw, ACT_NONE, ACT_SOFTPLUS_MIN, nw, 0, s);
+      CK(dx(L_WHAT_HEAD, d_enc3, el, R, b.tmp, nh, false));
+      sq_launch_dact2(b.tmp, nh, e2, rl, d_e2, rl, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      CK(dx(L_GENC1, d_e2, rl, R, b.tmp, nh, false));
+      sq_launch_dact2(b.tmp, nh, e1, rl, d_e1, rl, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      CK(dx(L_GENC0, d_e1, rl, R, b.d_g, G2, false));
+      {
+        CropChainBwdArgs ca; memset(&ca, 0, sizeof(ca));
+        ca.mode = CROP_DISC; ca.slot = j; ca.img = img; ca.rec_prev = rec_prev; ca.rec_new = rec_d_t; ca.d_rec_prev = d_rec_prev;
+        ca.d_rec_new = d_rec_d_t; ca.g_out = b.d_g; ca.g_row_mul = 1; ca.tp = cslotp(w.tp, TP_LD, t, 1, j); ca.tp_ld = tpl;
+        ca.d_tp = d_tp; ca.dtp_ld = tpl; ca.noise = nz; ca.flat = flat; ca.flat_grad = flat_grad;
+        sq_launch_crop_chain_bwd(ca, po, d, 1, s);
+      }
+      CK(dx(L_DISC_T3, d_tp, tpl, R, b.tmp, nh, false));
+      sq_launch_dact2(b.tmp, nh, t2, rl, d_t2, rl, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      CK(dx(L_DISC_T2, d_t2, rl, R, b.tmp, nh, false));
+      sq_launch_dact2(b.tmp, nh, t1, t1l, d_t1, t1l, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      // d r_j = T1^T (incl. the steps-predictor columns) + what the next slot's RNN sent back
+      CK(dx(L_DISC_T1, d_t1, t1l, R, b.tmp, nh, false));
+      if (j < N - 1) sq_launch_axpy2d(b.d_r[(j + 1) & 1], nh, b.tmp, nh, R, nh, 1, s);
+      sq_launch_dact2(b.tmp, nh, r_j, rl, d_rnn, rl, R, nh, ACT_TANH, ACT_TANH, 1 << 30, 0, s);
+      sq_launch_axpy2d(d_rnn, rl, d_pre_d, nh, R, nh, 1, s);
+      CK(dx(L_DISC_RNN, d_rnn, rl, R, b.dcat, 320, false));
+      if (j > 0) {
+        sq_launch_axpy2d(b.dcat, 320, d_rec_d_t + (size_t)(j - 1) * RW, N * RW, R, rec::ZW, 1, s);
+        sq_launch_axpy2d(b.dcat + 64, 320, b.d_r[j & 1], nh, R, nh, 0, s);
+      } else {
+        sq_launch_colsum(b.dcat + 64, 320, R, nh, flat_grad + po.disc_rnn_init, 1, s);
+      }
+    }
+    // ---- F^T. conditioning of discovery on the propagated latents
+    sq_launch_particle_sum(d_pre_d, b.d_pre_disc + (size_t)t * B * nh, B, K, nh, s);
+    CK(dx(L_PRED, d_pre_d, nh, R, b.d_c, nh, false));
+    if (c.rec_where_prior) {
+      CK(dx(L_RNCOND, b.d_spre + (size_t)t * R * 128, 128, R, b.dcat, 272, false));
+      sq_launch_axpy2d(b.dcat + 16, 272, b.d_c, nh, R, nh, 1, s);
+      sq_launch_colsum(b.dcat, 272, R, 4, flat_grad + po.rn_init_state, 1, s);
+    }
+    {
+      float* d_leb = b.d_leb + (size_t)t * M * nh;
+      float* d_lea = b.d_lea + (size_t)t * M * nh;
+      const float* leb = w.frame(w.leb, (int64_t)M * nh, t);
+      const float* lea = w.frame(w.lea, (int64_t)M * nh, t);
+      sq_launch_latent_sum_bwd(b.d_c, rec_p_t, b.tmp, d, s);
+      sq_launch_dact2(b.tmp, nh, leb, nh, d_leb, nh, M, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      CK(dx(L_LAT1, d_leb, nh, M, b.tmp, nh, false));
+      sq_launch_dact2(b.tmp, nh, lea, nh, d_lea, nh, M, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      CK(dx(L_LAT0, d_lea, nh, M, d_rec_p_t, RW, true));
+    }
+    // ---- E^T. propagation slots
+    float* d_pre = b.d_pre + (size_t)t * M * pre_ld;
+    SQ_CHECK_HIP(hipMemsetAsync(b.d_mask, 0, (size_t)M * G2 * 4, s));
+    const float* mask = w.frame(w.mask, (int64_t)M * G2, t);
+    const float* temporal_p = w.frame(w.temporal_p, (int64_t)M * nh, t);
+    for (int k = N - 1; k >= 0; --k) {
+      float* d_t1 = slotp(b.d_t1, T1_LD, t, 0, k);
+      float* d_t2 = slotp(b.d_t2, nh, t, 0, k);
+      float* d_tp = slotp(b.d_tp, TP_LD, t, 0, k);
+      float* d_e1 = slotp(b.d_e1, nh, t, 0, k);
+      float* d_e2 = slotp(b.d_e2, nh, t, 0, k);
+      float* d_enc3 = slotp(b.d_enc3, ENC_LD, t, 0, k);
+      float* d_rnn = slotp(b.d_rnn, nh, t, 0, k);
+      float* d_gru1 = b.d_gru1 + ((size_t)t * M + k) * 3 * nh;   // [T][R][N][3nh], row stride N*3nh
+      float* d_hraw = b.d_hraw + ((size_t)t * M + k) * HRAW_LD;
+      const int g1l = N * 3 * nh;
+      const float* r_k = cslotp(w.r, nh, t, 0, k);
+      const float* t1 = cslotp(w.t1, T1_LD, t, 0, k);
+      const float* t2 = cslotp(w.t2, nh, t, 0, k);
+      const float* e1 = cslotp(w.e1, nh, t, 0, k);
+      const float* e2 = cslotp(w.e2, nh, t, 0, k);
+      const float* enc = cslotp(w.enc, ENC_LD, t, 0, k);
+      const float* tau_k = temporal_prev + (size_t)k * nh;
+      float* d_pre_k = d_pre + (size_t)k * pre_ld;
+      const int pre_rld = N * pre_ld;
+      {
+        TailBwdArgs ta; memset(&ta, 0, sizeof(ta));
+        ta.is_disc = 0; ta.slot = k; ta.rec_prev = rec_prev; ta.rec_new = rec_p_t; ta.d_rec_new = d_rec_p_t;
+        ta.d_rec_prev = d_rec_prev; ta.s1h = cslotp(w.s1h, S1_LD, t, 0, k); ta.s1h_ld = s1l;
+        ta.hraw = cslotp(w.hraw, HRAW_LD, t, 0, k); ta.h_ld = hl; ta.enc = enc; ta.enc_ld = el; ta.noise = nz;
+        ta.d_s1pre = d_t1 + nh; ta.ds_ld = t1l; ta.d_enc = b.d_enc; ta.de_ld = ENC_LD; ta.d_hraw = d_hraw; ta.dh_ld = hl;
+        ta.flat = flat; ta.flat_grad = flat_grad; ta.w2_off = po.prop_steps_l1_w; ta.b2_off = po.prop_steps_l1_b;
+        ta.wwhat_off = (int)P(h, "prop.steps.l0.w") + 2 * nh * nsp;
+        sq_launch_slot_tail_bwd(ta, d, s);
+      }
+      // heads -> d tau'_k ; + what the compaction sent back for this slot's new temporal state
+      CK(dx(L_PROP_HEADS, d_hraw, hl, R, b.dhn, nh, false));
+      sq_launch_axpy2d(b.d_temporal_p + (size_t)k * nh, N * nh, b.dhn, nh, R, nh, 1, s);
+      sq_launch_gru_bwd_a(b.dhn, nh, cslotp(w.gz, nh, t, 0, k), rl, cslotp(w.ghc, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l,
+                          d_tau + (size_t)k * nh, N * nh, R, nh, 1, s);
+      CK(dx(L_PROP_GRU2, d_gru1 + 2 * nh, g1l, R, b.d_rh, nh, false));
+      sq_launch_gru_bwd_b(b.d_rh, nh, cslotp(w.gr, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l, d_tau + (size_t)k * nh, N * nh,
+                          R, nh, s);
+      sq_launch_axpy2d(d_gru1, g1l, d_pre_k + 2 * nh + nsp, pre_rld, R, 2 * nh, 0, s);  // z, r pre-activation parts of PRE
+      CK(dx(L_PROP_GRU1, d_gru1, g1l, R, b.dcat, 384, false));  // [r_k 256 | where 16 | enc 112]
+      sq_launch_axpy2d(b.dcat + nh, 384, d_rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, R, 4, 1, s);
+      sq_launch_axpy2d(b.dcat + nh + 16, 384, b.d_enc, ENC_LD, R, 2 * nw, 1, s);
+      sq_launch_dact2(b.d_enc, ENC_LD, enc, el, d_enc3, el, R, 2 * nw, ACT_NONE, ACT_SOFTPLUS_MIN, nw, 0, s);
+      CK(dx(L_WHAT_HEAD, d_enc3, el, R, b.tmp, nh, false));
+      sq_launch_dact2(b.tmp, nh, e2, rl, d_e2, rl, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      CK(dx(L_GENC1, d_e2, rl, R, b.tmp, nh, false));
+      sq_launch_dact2(b.tmp, nh, e1, rl, d_e1, rl, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      CK(dx(L_GENC0, d_e1, rl, R, b.d_g, G2, false));
+      {
+        CropChainBwdArgs ca; memset(&ca, 0, sizeof(ca));
+        ca.mode = CROP_PROP2; ca.slot = k; ca.img = img; ca.rec_prev = rec_prev; ca.rec_new = rec_p_t; ca.d_rec_prev = d_rec_prev;
+        ca.d_rec_new = d_rec_p_t; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N; ca.mask_row_add = k;
+        ca.d_mask = b.d_mask; ca.g_out = b.d_g; ca.g_row_mul = 1; ca.tp = cslotp(w.tp, TP_LD, t, 0, k); ca.tp_ld = tpl;
+        ca.d_tp = d_tp; ca.dtp_ld = tpl; ca.noise = nz; ca.flat = flat; ca.flat_grad = flat_grad;
+        sq_launch_crop_chain_bwd(ca, po, d, 1, s);
+      }
+      CK(dx(L_PROP_T3, d_tp, tpl, R, b.tmp, nh, false));
+      sq_launch_dact2(b.tmp, nh, t2, rl, d_t2, rl, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      CK(dx(L_PROP_T2, d_t2, rl, R, b.tmp, nh, false));
+      sq_launch_dact2(b.tmp, nh, t1, t1l, d_t1, t1l, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      sq_launch_axpy2d(d_t1, t1l, d_pre_k + nh, pre_rld, R, nh + nsp, 0, s);  // T1 / steps-predictor parts of PRE
+      CK(dx(L_PROP_T1, d_t1, t1l, R, b.tmp, nh, false));
+      sq_launch_axpy2d(b.dcat, 384, b.tmp, nh, R, nh, 1, s);                  // + GRU1's r_k segment
+      if (k < N - 1) sq_launch_axpy2d(b.d_r[(k + 1) & 1], nh, b.tmp, nh, R, nh, 1, s);
+      sq_launch_dact2(b.tmp, nh, r_k, rl, d_rnn, rl, R, nh, ACT_TANH, ACT_TANH, 1 << 30, 0, s);
+      sq_launch_axpy2d(d_rnn, rl, d_pre_k, pre_rld, R, nh, 0, s);
+      CK(dx(L_PROP_RNN, d_rnn, rl, R, b.tmp2, 320, false));
+      if (k > 0) {
+        sq_launch_axpy2d(b.tmp2, 320, d_rec_p_t + (size_t)(k - 1) * RW, N * RW, R, rec::ZW, 1, s);
+        sq_launch_axpy2d(b.tmp2 + 64, 320, b.d_r[k & 1], nh, R, nh, 0, s);
+      } else {
+        sq_launch_colsum(b.tmp2 + 64, 320, R, nh, flat_grad + po.prop_rnn_init, 1, s);
+      }
+    }
+    // ---- D^T. the loop-invariant pre-activation GEMM: segments [m1 64 | z_{t-1} record 64 | temporal nh]
+    float* d_m1 = b.d_m1 + (size_t)t * M * M1_LD;
+    CK(dx(L_PRE, d_pre, pre_ld, M, b.dcat, 384, false));
+    sq_launch_axpy2d(b.dcat, 384, d_m1, M1_LD, M, 64, 0, s);
+    sq_launch_axpy2d(b.dcat + 64, 384, d_rec_prev, RW, M, rec::ZW, 1, s);
+    sq_launch_axpy2d(b.dcat + 128, 384, d_tau, nh, M, nh, 1, s);
+    // ---- C^T. crop #1 and its encoder
+    {
+      float* d_peb = b.d_peb + (size_t)t * M * nh;
+      float* d_pea = b.d_pea + (size_t)t * M * nh;
+      const float* peb = w.frame(w.peb, (int64_t)M * nh, t);
+      const float* pea = w.frame(w.pea, (int64_t)M * nh, t);
+      CK(dx(L_WHAT_LOC, d_m1, M1_LD, M, b.tmp, nh, false));
+      sq_launch_dact2(b.tmp, nh, peb, nh, d_peb, nh, M, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      CK(dx(L_GENC1, d_peb, nh, M, b.tmp, nh, false));
+      sq_launch_dact2(b.tmp, nh, pea, nh, d_pea, nh, M, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      CK(dx(L_GENC0, d_pea, nh, M, b.d_g1, G2, false));
+      CropChainBwdArgs ca; memset(&ca, 0, sizeof(ca));
+      ca.mode = CROP_PROP1; ca.img = img; ca.rec_prev = rec_prev; ca.d_rec_prev = d_rec_prev; ca.wb = w.frame(w.wb, (int64_t)M * WB_LD, t);
+      ca.wb_ld = WB_LD; ca.d_wb = b.d_wb + (size_t)t * M * WB_LD; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N;
+      ca.d_mask = b.d_mask; ca.g_out = b.d_g1; ca.g_row_mul = N; ca.flat = flat; ca.flat_grad = flat_grad;
+      sq_launch_crop_chain_bwd(ca, po, d, N, s);
+    }
+    // ---- B^T. mask MLP and where-bias MLP
+    {
+      float* d_maskpre = b.d_maskpre + (size_t)t * M * G2;
+      float* d_hid1 = b.d_hid1 + (size_t)t * M * 256;
+      const float* hid1 = w.frame(w.hid1, (int64_t)M * 256, t);
+      sq_launch_dact2(b.d_mask, G2, mask, G2, d_maskpre, G2, M, G2, ACT_SIGMOID, ACT_SIGMOID, 1 << 30, 0, s);
+      if (c.masked_glimpse) CK(dx(L_MASK2, d_maskpre, G2, M, b.d_hid1out + 128, 256, false));
+      CK(dx(L_WB2, b.d_wb + (size_t)t * M * WB_LD, WB_LD, M, b.d_hid1out, 256, false));
+      sq_launch_dact2(b.d_hid1out, 256, hid1, 256, d_hid1, 256, M, 256, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+      CK(dx(L_TAU1, d_hid1, 256, M, d_tau, nh, true));
+    }
+    // ---- A^T. prior GRU
+    {
+      float* d_pgru1 = b.d_pgru1 + (size_t)t * M * 3 * nh;
+      CK(dx(L_PRIOR_LIN, b.d_pstats + (size_t)t * M * PS_LD, PS_LD, M, b.dhn, nh, false));
+      sq_launch_axpy2d(b.d_prior_p, nh, b.dhn, nh, M, nh, 1, s);
+      sq_launch_gru_bwd_a(b.dhn, nh, w.frame(w.pgz, (int64_t)M * nh, t), nh, w.frame(w.pghc, (int64_t)M * nh, t), nh, prior_prev, nh,
+                          d_pgru1, 3 * nh, d_pprev, nh, M, nh, 1, s);
+      CK(dx(L_PRIOR_GRU2, d_pgru1 + 2 * nh, 3 * nh, M, b.d_rh, nh, false));
+      sq_launch_gru_bwd_b(b.d_rh, nh, w.frame(w.pgr, (int64_t)M * nh, t), nh, prior_prev, nh, d_pgru1, 3 * nh, d_pprev, nh, M, nh, s);
+      CK(dx(L_PRIOR_GRU1, d_pgru1, 3 * nh, M, b.dcat, 320, false));  // [z_{t-1} record 64 | prior state nh]
+      sq_launch_axpy2d(b.dcat, 320, d_rec_prev, RW, M, rec::ZW, 1, s);
+      sq_launch_axpy2d(b.dcat + 64, 320, d_pprev, nh, M, nh, 1, s);
+    }
+  }
+  // ================= initial states, input encoder =================
+  sq_launch_colsum(b.d_tm[0], nh, M, nh, flat_grad + po.temporal_init, 1, s);
+  sq_launch_colsum(b.d_pm[0], nh, M, nh, flat_grad + po.prior_init, 1, s);
+  {
+    const int TB = T * B;
+    CK(dx(L_PREDISC, b.d_pre_disc, nh, TB, b.tmp, nh, false));
+    sq_launch_dact2(b.tmp, nh, w.ienc_b, nh, b.d_ib, nh, TB, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+    CK(dx(L_IENC1, b.d_ib, nh, TB, b.tmp, nh, false));
+    sq_launch_dact2(b.tmp, nh, w.ienc_a, nh, b.d_ia, nh, TB, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+    wgrad(L_PREDISC, {{w.ienc_b, nh}}, b.d_pre_disc, nh, TB);
+    wgrad(L_IENC1, {{w.ienc_a, nh}}, b.d_ib, nh, TB);
+    wgrad(L_IENC0, {{obs, P_}}, b.d_ia, nh, TB);
+  }
+  // ================= batched weight gradients =================
+  {
+    const float* tm_all = w.temporal_m;  // [T+1][M][nh]; frames 0..T-1 are the inputs
+    const float* pm_all = w.prior_m;
+    // prior GRU
+    wgrad(L_PRIOR_GRU1, {{w.rec_m_all, RW}, {pm_all, nh}}, b.d_pgru1, 3 * nh, MT);
+    hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.pgr, nh, pm_all, nh, b.rh, nh, MT, nh);
+    wgrad(L_PRIOR_GRU2, {{b.rh, nh}}, b.d_pgru1 + 2 * nh, 3 * nh, MT);
+    wgrad(L_PRIOR_LIN, {{w.prior_p, nh}}, b.d_pstats, PS_LD, MT);
+    // where-bias / mask MLPs
+    wgrad(L_TAU1, {{tm_all, nh}}, b.d_hid1, 256, MT);
+    wgrad(L_WB2, {{w.hid1, 256}}, b.d_wb, WB_LD, MT);
+    if (c.masked_glimpse) wgrad(L_MASK2, {{w.hid1 + 128, 256}}, b.d_maskpre, G2, MT);
+    // glimpse encoder: crop #1 (per frame, M rows) + both slot phases (2*T*R*N rows)
+    wgrad(L_GENC0, {{w.g1, G2}}, b.d_pea, nh, MT);
+    wgrad(L_GENC0, {{w.g2, G2}}, b.d_e1, nh, 2 * MT);
+    wgrad(L_GENC1, {{w.pea, nh}}, b.d_peb, nh, MT);
+    wgrad(L_GENC1, {{w.e1, nh}}, b.d_e2, nh, 2 * MT);
+    wgrad(L_WHAT_LOC, {{w.peb, nh}}, b.d_m1, M1_LD, MT);
+    wgrad(L_WHAT_HEAD, {{w.e2, nh}}, b.d_enc3, ENC_LD, 2 * MT);
+    // loop-invariant pre-activations
+    wgrad(L_PRE, {{w.m1, M1_LD}, {w.rec_m_all, RW}, {tm_all, nh}}, b.d_pre, pre_ld, MT);
+    // propagation slot chain (phase 0 of the tapes)
+    hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_p_all, w.r, w.zero_rec, w.prop_rnn_init, b.zs, b.rs, MT, N, nh);
+    wgrad(L_PROP_RNN, {{b.zs, 64}, {b.rs, nh}}, b.d_rnn, nh, MT);
+    wgrad(L_PROP_T1, {{w.r, nh}}, b.d_t1, T1_LD, MT);
+    wgrad(L_PROP_T2, {{w.t1, T1_LD}}, b.d_t2, nh, MT);
+    wgrad(L_PROP_T3, {{w.t2, nh}}, b.d_tp, TP_LD, MT);
+    wgrad(L_PROP_GRU1, {{w.r, nh}, {w.rec_p_all + rec::WHERE, RW}, {w.enc, ENC_LD}}, b.d_gru1, 3 * nh, MT);
+    hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.gr, nh, tm_all, nh, b.rh, nh, MT, nh);
+    wgrad(L_PROP_GRU2, {{b.rh, nh}}, b.d_gru1 + 2 * nh, 3 * nh, MT);
+    wgrad(L_PROP_HEADS, {{w.temporal_p, nh}}, b.d_hraw, HRAW_LD, MT);
+    wgrad(L_PROP_S1, {{w.rec_p_all, RW}}, b.d_t1 + nh, T1_LD, MT);
+    // latent summary, discovery conditioning
+    wgrad(L_LAT0, {{w.rec_p_all, RW}}, b.d_lea, nh, MT);
+    wgrad(L_LAT1, {{w.lea, nh}}, b.d_leb, nh, MT);
+    wgrad(L_PRED, {{w.c, nh}}, b.d_pre_d, nh, T * R);
+    if (c.rec_where_prior) wgrad(L_RNCOND, {{w.rn_init_state, 0}, {w.c, nh}}, b.d_spre, 128, T * R);
+    // discovery slot chain (phase 1 of the tapes)
+    const size_t ph1 = (size_t)MT;
+    hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_d_all, w.r + ph1 * nh, w.disc_init_rec, w.disc_rnn_init, b.zs,
+                       b.rs, MT, N, nh);
+    wgrad(L_DISC_RNN, {{b.zs, 64}, {b.rs, nh}}, b.d_rnn + ph1 * nh, nh, MT);
+    wgrad(L_DISC_T1, {{w.r + ph1 * nh, nh}}, b.d_t1 + ph1 * T1_LD, T1_LD, MT);
+    wgrad(L_DISC_T2, {{w.t1 + ph1 * T1_LD, T1_LD}}, b.d_t2 + ph1 * nh, nh, MT);
+    wgrad(L_DISC_T3, {{w.t2 + ph1 * nh, nh}}, b.d_tp + ph1 * TP_LD, TP_LD, MT);
+    wgrad(L_DISC_S1, {{w.rec_d_all, RW}}, b.d_t1 + ph1 * T1_LD + nh, T1_LD, MT);
+  }
+  SQ_CHECK_HIP(hipGetLastError());
+  return 0;
+}

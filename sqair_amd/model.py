@@ -209,6 +209,33 @@ class SqairCore(object):
                 self.c_means, len(self.mean_names), self.iw_means.data_ptr(), self._stream()), "sqair_elbo")
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
+    def backward(self, t_offset=0):
+        """Full backward pass after forward(train=True): gradient of the VIMCO target / T w.r.t. every parameter.
+        Leaves it in ``self.flat_grad`` (flat layout) on the core's stream; returns that tensor."""
+        assert getattr(self, "train_ws", None) is not None, "backward() needs forward(train=True) first"
+        with torch.cuda.device(self.device):
+            nb = self.lib.sqair_backward_bytes(self.handle, self.T, self.B)
+            if getattr(self, "bwd_scratch", None) is None or self.bwd_scratch.numel() * 4 < nb:
+                self.bwd_scratch = torch.empty(nb // 4, dtype=torch.float32, device=self.device)
+            if getattr(self, "flat_grad", None) is None:
+                self.flat_grad = torch.zeros_like(self.flat)
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            _capi.check(self.handle, self.lib.sqair_backward(
+                self.handle, self.flat.data_ptr(), self.packed.data_ptr(), self.obs.data_ptr(), self.noise.data_ptr(),
+                self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.T, self.B, int(t_offset),
+                self.train_ws.data_ptr(), self.train_ws.numel() * 4, self.bwd_scratch.data_ptr(), nb,
+                self.flat_grad.data_ptr(), self._stream()), "sqair_backward")
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return self.flat_grad
+
+    def grads_by_name(self):
+        """The last backward()'s gradients as a dict name -> tensor (reference variable shapes)."""
+        out = {}
+        for name, (o, shape) in self.offsets.items():
+            n = int(np.prod(shape)) if len(shape) else 1
+            out[name] = self.flat_grad[o:o + n].reshape(shape)
+        return out
+
     def backward_decoder(self):
         """Decoder branch of the backward pass (first slice of the training step, see include/sqair_hip.h):
         gradients of the VIMCO target w.r.t. the decoder parameters as a dict name -> tensor, plus the seed
