@@ -237,6 +237,14 @@ int sqair_backward(SqairHandle* h, const float* flat_params, const void* packed,
                    const float* importance_weights, const float* vimco_signal, int T, int B, int t_offset,
                    void* train_workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
                    float* flat_grad, void* stream);
+/* Graph capture of any sequence of the calls above on one stream (the training step up to the gradient all-reduce
+ * is ~3000 short dependent launches): _begin, issue the calls, _end(slot 0..3) -> node count (>= 0) or error (< 0);
+ * _launch replays the slot.  Captured calls keep the pointers they were given. */
+int sqair_capture_begin(SqairHandle* h, void* stream);
+int sqair_capture_end(SqairHandle* h, void* stream, int slot);
+int sqair_capture_launch(SqairHandle* h, int slot, void* stream);
+/* flat_grad += l2 * flat_params: the l2_reg term of Model.make_target (sqair/targets.py:31-35, sqair/model.py:160). */
+int sqair_add_l2_grad(SqairHandle* h, const float* flat_params, float* flat_grad, int64_t n, float l2, void* stream);
 /* Fused optimiser step on the flat buffers: tf.train.RMSPropOptimizer(lr, momentum=0.9) as used by the
  * reference driver (sqair/scripts/experiment.py:140; TF defaults decay 0.9, epsilon 1e-10, ms initialised to 1):
  * ms <- decay ms + (1-decay) g^2; mom <- momentum mom + lr g / sqrt(ms + eps); theta <- theta - mom, with

@@ -87,6 +87,10 @@ _PROTOS = {
     "sqair_backward_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
     "sqair_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                  C.c_void_p, C.c_void_p]),
+    "sqair_capture_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sqair_capture_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "sqair_capture_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "sqair_add_l2_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "sqair_rmsprop_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "sqair_linear_bwd_test": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_int64, C.c_void_p]),

@@ -441,6 +441,10 @@ extern "C" int sqair_destroy(SqairHandle* h) {
   if (h == nullptr) return 0;
   if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
   if (h->graph) hipGraphDestroy(h->graph);
+  for (int i = 0; i < 4; ++i) {
+    if (h->cap_exec[i]) (void)hipGraphExecDestroy(h->cap_exec[i]);
+    if (h->cap_graph[i]) (void)hipGraphDestroy(h->cap_graph[i]);
+  }
   delete h;
   return 0;
 }
@@ -640,7 +644,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   // The GEMM A-operand contract wants every float it may touch to be finite (padding meets zero weights, but
   // 0 * NaN = NaN) and slot records are read as 56-wide segments before all their fields are written in a frame:
   // clear the caller's (garbage) workspace once per pass
-  SQ_CHECK_HIP(hipMemsetAsync(wsbase, 0, (size_t)((float*)w.prof_ts - wsbase) * 4, s));
+  sq_zero_fill(wsbase, (int64_t)((float*)w.prof_ts - wsbase), s);
   // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
   sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0), w.state(w.prior_m, 0), w.last_id[0], w.disc_init_rec,
                        w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc,
@@ -850,7 +854,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     Lin a; a.seg(rec_all, RW, rec::ZW).out(w.dec_a, nh).act(ACT_ELU); RUN(a, L_DEC0, MT);
     Lin b; b.seg(w.dec_a, nh, nh).out(w.dec_b, nh).act(ACT_ELU); RUN(b, L_DEC1, MT);
     Lin g; g.seg(w.dec_b, nh, nh).out(gl, G2); g.a.scale_ptr = flat + po.dec_output_scale; RUN(g, L_DEC2, MT);
-    if (out.glimpse && train) SQ_CHECK_HIP(hipMemcpyAsync(out.glimpse, gl, (size_t)MT * G2 * 4, hipMemcpyDeviceToDevice, s));
+    if (out.glimpse && train) sq_copy(out.glimpse, gl, (int64_t)MT * G2, s);
     InsertArgs ia; memset(&ia, 0, sizeof(ia));
     ia.glimpse = gl; ia.rec = rec_all; ia.rec_ld = RW; ia.img = obs; ia.mean_img = flat + po.dec_mean_img;
     ia.canvas = out.canvas; ia.data_ll = w.dll; ia.qz = w.qz; ia.pz = w.pz; ia.t = 0; ia.n_frames = T; ia.out = out;
@@ -859,11 +863,11 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   }
   // final recurrent state (for state-level parity checks)
   if (out.final_temporal_state)
-    SQ_CHECK_HIP(hipMemcpyAsync(out.final_temporal_state, w.state(w.temporal_m, T), (size_t)M * nh * 4, hipMemcpyDeviceToDevice, s));
+    sq_copy(out.final_temporal_state, w.state(w.temporal_m, T), (int64_t)M * nh, s);
   if (out.final_prior_state)
-    SQ_CHECK_HIP(hipMemcpyAsync(out.final_prior_state, w.state(w.prior_m, T), (size_t)M * nh * 4, hipMemcpyDeviceToDevice, s));
+    sq_copy(out.final_prior_state, w.state(w.prior_m, T), (int64_t)M * nh, s);
   if (out.final_last_used_id)
-    SQ_CHECK_HIP(hipMemcpyAsync(out.final_last_used_id, w.last_id[T & 1], (size_t)R * 4, hipMemcpyDeviceToDevice, s));
+    sq_copy(out.final_last_used_id, w.last_id[T & 1], (int64_t)R, s);
   SQ_CHECK_HIP(hipGetLastError());
   return 0;
 }

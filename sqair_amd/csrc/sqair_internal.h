@@ -50,6 +50,9 @@ struct SqairHandle {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int graph_nodes = 0;
+  // generic capture slots (sqair_capture_begin / _end / _launch): any sequence of C-ABI calls as one HIP graph
+  hipGraph_t cap_graph[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t cap_exec[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 
@@ -141,6 +144,10 @@ struct Workspace {
   }
 };
 Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train);
+
+// zero fill as a kernel (not a memset node: see sqair_train.hip); p 16-byte aligned
+void sq_zero_fill(float* p, int64_t n, hipStream_t s);
+void sq_copy(float* dst, const float* src, int64_t n, hipStream_t s);
 
 int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipStream_t s);
 #define RUN(l, id, M)                                   \

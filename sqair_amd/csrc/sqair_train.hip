@@ -89,6 +89,29 @@ __global__ void k_mul2d(const float* __restrict__ a, int a_ld, const float* __re
   const int m = i / cols, n = i - m * cols;
   out[(size_t)m * o_ld + n] = a[(size_t)m * a_ld + n] * b[(size_t)m * b_ld + n];
 }
+// zero fill as a kernel node: memset nodes in the middle of a long captured chain proved unreliable on replay
+// (ROCm 7.2: the second replay of the training graph read stale scratch), a plain kernel keeps the chain uniform
+__global__ void k_zero(float* __restrict__ p, int64_t n) {
+  const int64_t n4 = n / 4;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    p4[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = 0.0f;
+}
+void sq_zero_fill(float* p, int64_t n, hipStream_t s) {  // p 16-byte aligned
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (n > 0) hipLaunchKernelGGL(k_zero, dim3((unsigned)blocks), dim3(256), 0, s, p, n);
+}
+__global__ void k_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void sq_copy(float* dst, const float* src, int64_t n, hipStream_t s) {
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (n > 0) hipLaunchKernelGGL(k_copy, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n);
+}
 // shifted z-record / RNN-state inputs of the slot RNNs as dense matrices for the batched weight gradient:
 //   zs[(t,r,k)] = z-record of slot k-1 (k > 0) or `init_rec` (k = 0);  rs[(t,r,k)] = r tape of slot k-1 or rnn_init
 __global__ void k_shift_inputs(const float* __restrict__ rec_all, const float* __restrict__ r_tape, const float* __restrict__ init_rec,
@@ -187,8 +210,12 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   const int pre_ld = h->layers[L_PRE].nt * 16;
   const int* rm_dev = (const int*)packed + pl.rm;
 
-  SQ_CHECK_HIP(hipMemsetAsync(flat_grad, 0, (size_t)h->n_params * 4, s));
-  SQ_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)b.total * 4, s));
+  if ((reinterpret_cast<uintptr_t>(flat_grad) & 15) != 0) {
+    sq_set_error(h, "sqair_backward: flat_grad must be 16-byte aligned");
+    return -1;
+  }
+  sq_zero_fill(flat_grad, h->n_params, s);
+  sq_zero_fill((float*)scratch, b.total, s);
 
   // dX through the transposed pack: out[M][K of the forward layer] (+)= dpre[M][N] W^T.  Single-segment layers write
   // exactly their true input width; multi-segment layers write all 16 * kc padded columns (the caller splits them).
@@ -276,8 +303,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       ka.d_prior_next = b.d_pm[(t + 1) & 1]; ka.d_rec_p = d_rec_p_t; ka.d_rec_d = d_rec_d_t;
       ka.d_temporal_p = b.d_temporal_p; ka.d_prior_p = b.d_prior_p; ka.flat_grad = flat_grad;
       sq_launch_compact_bwd(ka, po, d, s);
-      SQ_CHECK_HIP(hipMemsetAsync(d_tau, 0, (size_t)M * nh * 4, s));
-      SQ_CHECK_HIP(hipMemsetAsync(d_pprev, 0, (size_t)M * nh * 4, s));
+      sq_zero_fill(d_tau, (int64_t)M * nh, s);
+      sq_zero_fill(d_pprev, (int64_t)M * nh, s);
     }
     // ---- G^T. discovery steps
     float* d_pre_d = b.d_pre_d + (size_t)t * R * nh;
@@ -355,7 +382,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     }
     // ---- E^T. propagation slots
     float* d_pre = b.d_pre + (size_t)t * M * pre_ld;
-    SQ_CHECK_HIP(hipMemsetAsync(b.d_mask, 0, (size_t)M * G2 * 4, s));
+    sq_zero_fill(b.d_mask, align64((int64_t)M * G2), s);
     const float* mask = w.frame(w.mask, (int64_t)M * G2, t);
     const float* temporal_p = w.frame(w.temporal_p, (int64_t)M * nh, t);
     for (int k = N - 1; k >= 0; --k) {
@@ -541,6 +568,49 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     wgrad(L_DISC_T3, {{w.t2 + ph1 * nh, nh}}, b.d_tp + ph1 * TP_LD, TP_LD, MT);
     wgrad(L_DISC_S1, {{w.rec_d_all, RW}}, b.d_t1 + ph1 * T1_LD + nh, T1_LD, MT);
   }
+  SQ_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic graph capture: the host brackets any sequence of C-ABI calls on one stream (e.g. sqair_forward_train,
+// sqair_elbo, sqair_backward = one training step up to the gradient all-reduce) and replays it as ONE hipGraphLaunch —
+// the step is ~3000 short dependent launches, so replay removes the host launch cost from the critical path.
+// ------------------------------------------------------------------------------------------------
+extern "C" int sqair_capture_begin(SqairHandle* h, void* stream) {
+  if (!h) return -1;
+  SQ_CHECK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return 0;
+}
+extern "C" int sqair_capture_end(SqairHandle* h, void* stream, int slot) {
+  if (!h || slot < 0 || slot >= 4) return -1;
+  hipGraph_t g = nullptr;
+  SQ_CHECK_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+  if (h->cap_exec[slot]) { (void)hipGraphExecDestroy(h->cap_exec[slot]); h->cap_exec[slot] = nullptr; }
+  if (h->cap_graph[slot]) { (void)hipGraphDestroy(h->cap_graph[slot]); h->cap_graph[slot] = nullptr; }
+  h->cap_graph[slot] = g;
+  size_t nn = 0;
+  SQ_CHECK_HIP(hipGraphGetNodes(g, nullptr, &nn));
+  SQ_CHECK_HIP(hipGraphInstantiate(&h->cap_exec[slot], g, nullptr, nullptr, 0));
+  return (int)nn;
+}
+extern "C" int sqair_capture_launch(SqairHandle* h, int slot, void* stream) {
+  if (!h || slot < 0 || slot >= 4 || !h->cap_exec[slot]) {
+    sq_set_error(h, "sqair_capture_launch: empty slot");
+    return -1;
+  }
+  SQ_CHECK_HIP(hipGraphLaunch(h->cap_exec[slot], (hipStream_t)stream));
+  return 0;
+}
+// grad += l2 * theta  (targets.l2_reg, sqair/targets.py:31-35: weight * sum_v l2_loss(v) over ALL trainable variables)
+__global__ void k_add_l2(const float* __restrict__ theta, float* __restrict__ grad, int64_t n, float l2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) grad[i] += l2 * theta[i];
+}
+extern "C" int sqair_add_l2_grad(SqairHandle* h, const float* flat_params, float* flat_grad, int64_t n, float l2, void* stream) {
+  if (!h || !flat_params || !flat_grad || n < 0) return -1;
+  if (n == 0 || l2 == 0.0f) return 0;
+  hipLaunchKernelGGL(k_add_l2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat_params, flat_grad, n, l2);
   SQ_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -169,6 +169,9 @@ class SqairCore(object):
         self.T, self.B = T, B
         self._shape = (T, B, outputs if isinstance(outputs, str) else tuple(outputs))
         self._graph_ready = False
+        self._train_graph_ready = False
+        self.train_ws = None
+        self.bwd_scratch = None
 
     def draw_noise(self, generator=None):
         """eps ~ N(0,1) for the Normals, u ~ U[0,1) for the presence Bernoullis, on device."""
@@ -227,6 +230,53 @@ class SqairCore(object):
                 self.flat_grad.data_ptr(), self._stream()), "sqair_backward")
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return self.flat_grad
+
+    def grad_step(self, t_offset=0, use_graph=True):
+        """One gradient evaluation = forward(train) + ELBO / VIMCO reductions + backward, replayed as ONE HIP graph
+        (``use_graph``) once captured for the bound (T, B) shape.  The parameters must have been packed (set_params /
+        pack) and obs / noise filled.  Returns the flat gradient buffer (valid on the current stream)."""
+        if not use_graph:
+            self.forward(t_offset=t_offset, train=True)
+            return self.backward(t_offset=t_offset)
+        if not getattr(self, "_train_graph_ready", False) or self._train_graph_key != (self._shape, int(t_offset)):
+            # first call: run eagerly once (allocates tape / scratch, uploads the plan), then capture
+            self.forward(t_offset=t_offset, train=True)
+            self.backward(t_offset=t_offset)
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.device(self.device):
+                _capi.check(self.handle, self.lib.sqair_capture_begin(self.handle, self._stream()), "sqair_capture_begin")
+                try:
+                    self._issue_train(t_offset)
+                finally:
+                    n = self.lib.sqair_capture_end(self.handle, self._stream(), 1)
+                if n < 0:
+                    _capi.check(self.handle, n, "sqair_capture_end")
+            self.train_graph_nodes = n
+            self._train_graph_ready = True
+            self._train_graph_key = (self._shape, int(t_offset))
+        with torch.cuda.device(self.device):
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            _capi.check(self.handle, self.lib.sqair_capture_launch(self.handle, 1, self._stream()), "sqair_capture_launch")
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return self.flat_grad
+
+    def _issue_train(self, t_offset):
+        """The raw call sequence of a gradient evaluation on the core's stream (no stream joins: capturable)."""
+        nb = self.train_ws.numel() * 4
+        args = list(self._args(t_offset))
+        args[9], args[10] = self.train_ws.data_ptr(), nb
+        _capi.check(self.handle, self.lib.sqair_forward_train(*args), "sqair_forward_train")
+        dlp = self.out["discrete_log_prob"].data_ptr() if "discrete_log_prob" in self.out else None
+        _capi.check(self.handle, self.lib.sqair_elbo(
+            self.handle, self.out["log_weights_per_timestep"].data_ptr(), dlp, self.T, self.B,
+            self.log_weights.data_ptr(), self.elbo_iwae_per_example.data_ptr(),
+            self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.scalars.data_ptr(),
+            self.c_means, len(self.mean_names), self.iw_means.data_ptr(), self._stream()), "sqair_elbo")
+        _capi.check(self.handle, self.lib.sqair_backward(
+            self.handle, self.flat.data_ptr(), self.packed.data_ptr(), self.obs.data_ptr(), self.noise.data_ptr(),
+            self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.T, self.B, int(t_offset),
+            self.train_ws.data_ptr(), nb, self.bwd_scratch.data_ptr(), self.bwd_scratch.numel() * 4,
+            self.flat_grad.data_ptr(), self._stream()), "sqair_backward")
 
     def grads_by_name(self):
         """The last backward()'s gradients as a dict name -> tensor (reference variable shapes)."""
@@ -386,17 +436,35 @@ class Model(object):
         return res[0] if len(res) == 1 else res
 
     def make_target(self, opt=None, n_train_itr=None, l2_reg=0.0):
-        """reference: sqair/model.py:150-168.  Returns (target, grads_and_vars).  The VIMCO target
-        (already divided by T) is evaluated by the fused ELBO kernel; gradients are the `next` row of
-        the scope table and not part of this round."""
+        """reference: sqair/model.py:150-168.  Returns (target, grads_and_vars): the VIMCO target (already divided
+        by T, plus the l2 term) from the fused ELBO kernel and, when an optimiser is given, the gradients of every
+        trainable variable from the HIP backward pass as a list of (gradient tensor, variable name) — the
+        reference's ``opt.compute_gradients(target)``.  ``opt.apply_gradients(gvs)`` (sqair_amd.train.Optimizer)
+        performs the update."""
+        core = self.core
+        if opt is None:
+            if not self._ran:
+                self.run()
+            target = self.vimco_target
+            if l2_reg != 0.0:
+                target = target + l2_reg * 0.5 * (core.flat ** 2).sum()
+            return target, None
         if not self._ran:
-            self.run()
+            core.draw_noise()
+        core.grad_step(use_graph=self._use_graph)
+        if l2_reg != 0.0:
+            with torch.cuda.device(core.device):
+                _capi.check(core.handle, core.lib.sqair_add_l2_grad(
+                    core.handle, core.flat.data_ptr(), core.flat_grad.data_ptr(), core.n_params, float(l2_reg),
+                    C.c_void_p(torch.cuda.current_stream(core.device).cuda_stream)), "sqair_add_l2_grad")
+        self._collect()
+        self._ran = True
         target = self.vimco_target
         if l2_reg != 0.0:
-            target = target + l2_reg * 0.5 * (self.core.flat ** 2).sum()
-        if opt is not None:
-            raise NotImplementedError("backward pass of the HIP path is not implemented yet (SURVEY.md 8(f) rank 1)")
-        return target, None
+            target = target + l2_reg * 0.5 * (core.flat ** 2).sum()
+        gvs = [(g, name) for name, g in core.grads_by_name().items()]
+        assert len(gvs) == len(core.spec)
+        return target, gvs
 
     def img_summaries(self):
         """reference: sqair/model.py:207-214 -> uint8 reconstructions / inputs of the first frame."""

@@ -4,9 +4,12 @@ reference: sqair/scripts/experiment.py:126-155 — global step, piecewise-consta
 (``schedule`` = comma-separated relative segment lengths; the rate is divided by 3 at every boundary),
 ``tf.train.RMSPropOptimizer(lr, momentum=.9)``; sqair/data/mnist_tools.py:84-92 — sequence-length
 curriculum (``seq_len`` grows by one every ``stage_itr`` iterations).  The parameter update itself is the
-fused HIP kernel ``sqair_rmsprop_step``; the backward pass that feeds it is built up in sqair_bwd.hip
-(decoder branch done, recurrent part next round)."""
+fused HIP kernel ``sqair_rmsprop_step``; the gradients come from ``sqair_backward`` (csrc/sqair_train.hip).
+``Optimizer`` mirrors the ``opt.compute_gradients`` / ``opt.apply_gradients`` pair the reference's ``make_target``
+and driver use; ``Trainer`` is the driver's inner loop (experiment.py:150-185) for one rank."""
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 
@@ -41,3 +44,83 @@ def rmsprop_reference(theta, grad, ms, mom, lr, decay=0.9, momentum=0.9, eps=1e-
     ms = decay * ms + (1.0 - decay) * grad * grad
     mom = momentum * mom + lr * grad / np.sqrt(ms + eps)
     return theta - mom, ms, mom
+
+
+class Optimizer(object):
+    """The optimisers the reference driver offers (experiment.py:139-147) on the flat fp32 buffers of a ``SqairCore``.
+    ``rmsprop`` (the default and the only one the shipped configs use) is the fused HIP kernel; ``adam`` / ``sgd`` /
+    ``momentum`` are a handful of elementwise torch ops on the same device buffers (TF1 defaults)."""
+
+    def __init__(self, core, kind="rmsprop", momentum=0.9, decay=0.9, epsilon=1e-10):
+        import torch
+        self.core, self.kind = core, str(kind).lower()
+        if self.kind not in ("rmsprop", "adam", "sgd", "momentum"):
+            raise ValueError("unknown optimiser {!r}".format(kind))
+        self.momentum, self.decay, self.epsilon = float(momentum), float(decay), float(epsilon)
+        # TF initialises the RMSProp mean-square slot with ones, Adam's second moment with zeros
+        self.ms = torch.ones_like(core.flat) if self.kind == "rmsprop" else torch.zeros_like(core.flat)
+        self.mom = torch.zeros_like(core.flat)
+        self.t = 0
+
+    def apply_gradients(self, flat_grad, lr, grad_scale=1.0):
+        """theta <- theta - update(grad_scale * flat_grad); re-packs the weights for the next forward pass."""
+        import torch
+        from . import _capi
+        core = self.core
+        self.t += 1
+        if self.kind == "rmsprop":
+            with torch.cuda.device(core.device):
+                _capi.check(core.handle, core.lib.sqair_rmsprop_step(
+                    core.handle, core.flat.data_ptr(), flat_grad.data_ptr(), self.ms.data_ptr(), self.mom.data_ptr(),
+                    core.n_params, float(lr), self.decay, self.momentum, self.epsilon, float(grad_scale),
+                    C.c_void_p(torch.cuda.current_stream(core.device).cuda_stream)), "sqair_rmsprop_step")
+        else:
+            g = flat_grad * float(grad_scale) if grad_scale != 1.0 else flat_grad
+            if self.kind == "sgd":
+                core.flat.add_(g, alpha=-float(lr))
+            elif self.kind == "momentum":      # tf.train.MomentumOptimizer: accum = m accum + g; theta -= lr accum
+                self.mom.mul_(self.momentum).add_(g)
+                core.flat.add_(self.mom, alpha=-float(lr))
+            else:                              # tf.train.AdamOptimizer defaults beta1 .9, beta2 .999, eps 1e-8
+                b1, b2, eps = 0.9, 0.999, 1e-8
+                self.mom.mul_(b1).add_(g, alpha=1.0 - b1)
+                self.ms.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                lr_t = float(lr) * np.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+                core.flat.addcdiv_(self.mom, self.ms.sqrt().add_(eps), value=-lr_t)
+        core.pack()
+
+
+class Trainer(object):
+    """One rank of the reference's training loop (experiment.py:150-185): per step draw noise, evaluate the VIMCO
+    target and its gradients on this rank's shard of sequences (ONE HIP graph replay), all-reduce the flat gradient
+    buffer over the ranks (the single collective of the step, RCCL over xGMI), apply the optimiser.
+    ``model`` is a ``sqair_amd.model.Model`` bound to this rank's shard."""
+
+    def __init__(self, model, F, use_graph=True):
+        self.model, self.core, self.F = model, model.core, F
+        self.opt = Optimizer(self.core, getattr(F, "opt", "rmsprop"))
+        self.step_no = 0
+        self.use_graph = bool(use_graph)
+
+    def step(self, obs=None, noise=None, generator=None):
+        import torch
+        from . import _capi
+        from .dist import allreduce_flat_grads
+        core, F = self.core, self.F
+        if obs is not None:
+            core.obs.copy_(torch.as_tensor(obs, dtype=torch.float32).reshape(core.obs.shape))
+        if noise is not None:
+            core.noise.copy_(torch.as_tensor(noise, dtype=torch.float32).reshape(core.noise.shape))
+        else:
+            core.draw_noise(generator)
+        g = core.grad_step(use_graph=self.use_graph)
+        l2 = float(getattr(F, "l2", 0.0))
+        if l2 != 0.0:
+            with torch.cuda.device(core.device):
+                _capi.check(core.handle, core.lib.sqair_add_l2_grad(
+                    core.handle, core.flat.data_ptr(), g.data_ptr(), core.n_params, l2,
+                    C.c_void_p(torch.cuda.current_stream(core.device).cuda_stream)), "sqair_add_l2_grad")
+        allreduce_flat_grads(g)
+        self.opt.apply_gradients(g, learning_rate(F, self.step_no))
+        self.step_no += 1
+        return g

@@ -278,3 +278,119 @@ def test_full_backward_matches_autograd(K, N, T, B, hw):
     report, ref, _ = _full_backward_case(K, N, T, B, hw, seed=11)
     assert float(ref.prop_pres.sum()) > 0, "case must exercise propagation"
     _check_report(report)
+
+
+def test_grad_step_graph_replay_equals_eager():
+    """forward(train) + ELBO + backward replayed as one HIP graph gives the eager gradients (float atomics in the
+    small-parameter adjoints make the order of additions free: compare to 1e-5 of the largest gradient)."""
+    from sqair_amd.data import make_sequences, to_float
+    from sqair_amd.model import Model, SqairCore
+    from tests.hip_util import draw_noise, params32
+    K, N, T, B, hw = 3, 3, 3, 4, (50, 50)
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    obs = to_float(make_sequences(B, T=T, canvas=hw, seed=3)["imgs"])
+    core = SqairCore(F, hw)
+    core.set_params(params32(F, hw, 4, 0.05, obs.mean((0, 1))))
+    Model(obs, None, core, K, outputs="minimal")
+    core.noise.copy_(torch.as_tensor(draw_noise(np.random.default_rng(0), T, B * K, N, 55)).reshape(core.noise.shape))
+    g0 = core.grad_step(use_graph=False).clone()
+    torch.cuda.synchronize()
+    for _ in range(2):
+        g1 = core.grad_step(use_graph=True).clone()
+        torch.cuda.synchronize()
+        assert core.train_graph_nodes > 100
+        assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max())
+    # new noise through the same graph changes the result (the graph reads the buffers, not a snapshot)
+    core.noise.copy_(torch.as_tensor(draw_noise(np.random.default_rng(1), T, B * K, N, 55)).reshape(core.noise.shape))
+    g2 = core.grad_step(use_graph=True).clone()
+    torch.cuda.synchronize()
+    assert float((g2 - g0).abs().max()) > 1e-3 * float(g0.abs().max())
+
+
+def test_training_steps_track_oracle_rmsprop():
+    """Three optimiser steps (graph replay + fused RMSProp + re-pack) against autograd + the NumPy restatement of the TF
+    update on the fp64 oracle, same noise per step.  Every step starts from the HIP path's own fp32 parameters (the
+    objective is curved enough that an fp32 rounding of the parameters changes the next gradient by ~1 %), while the
+    optimiser slots (ms, mom) are carried independently on both sides."""
+    from sqair_amd.data import make_sequences, to_float
+    from sqair_amd.model import Model, SqairCore
+    from sqair_amd.params import flatten_params, unflatten_params
+    from sqair_amd.train import Trainer, learning_rate, rmsprop_reference
+    from tests.hip_util import draw_noise, params32
+    K, N, T, B, hw = 3, 3, 3, 3, (50, 50)
+    F = make_flags(k_particles=K, n_steps_per_image=N, learning_rate=1e-3, train_itr=100)
+    obs = to_float(make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=24, seed=11)["imgs"])
+    P = params32(F, hw, 4, 0.05, obs.mean((0, 1)))
+    core = SqairCore(F, hw)
+    core.set_params(P)
+    m = Model(obs, None, core, K, outputs=["log_weights_per_timestep", "discrete_log_prob", "prop_pres", "disc_pres"])
+    tr = Trainer(m, F)
+    ms = mom = None
+    for it in range(3):
+        theta = core.flat.cpu().numpy().astype(np.float64)
+        if ms is None:
+            ms, mom = np.ones_like(theta), np.zeros_like(theta)
+        noise = draw_noise(np.random.default_rng(200 + it), T, B * K, N, 55)
+        orc = O.SqairOracle(unflatten_params(theta.astype(np.float32), core.spec), O.make_cfg(F, hw), torch.float64,
+                            requires_grad=True)
+        ref = orc.model(obs, noise)
+        target = orc.make_target(ref)
+        target.backward()
+        tr.step(noise=noise)
+        torch.cuda.synchronize()
+        if not (np.array_equal(core.out["prop_pres"].cpu().numpy(), ref.prop_pres.detach().numpy()) and
+                np.array_equal(core.out["disc_pres"].cpu().numpy(), ref.disc_pres.detach().numpy())):
+            pytest.skip("presence decisions diverged at step %d (measure-zero boundary)" % it)
+        assert abs(float(core.scalars[2]) - float(target)) <= 1e-4 * abs(float(target))
+        g = flatten_params({k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in orc.P.items()},
+                           core.spec).astype(np.float64)
+        new, ms, mom = rmsprop_reference(theta, g, ms, mom, learning_rate(F, it))
+        got = core.flat.cpu().numpy().astype(np.float64)
+        assert np.abs(new - theta).max() > 1e-4
+        assert np.abs((got - theta) - (new - theta)).max() <= 2e-3 * np.abs(new - theta).max(), it
+    assert tr.step_no == 3
+
+
+@pytest.mark.parametrize("kind", ["sgd", "momentum", "adam"])
+def test_other_optimisers_move_parameters(kind):
+    from sqair_amd.data import make_sequences, to_float
+    from sqair_amd.model import Model, SqairCore
+    from sqair_amd.train import Trainer
+    from tests.hip_util import params32
+    K, N, T, B, hw = 2, 3, 2, 2, (50, 50)
+    F = make_flags(k_particles=K, n_steps_per_image=N, learning_rate=1e-4, opt=kind, l2=1e-3)
+    obs = to_float(make_sequences(B, T=T, canvas=hw, seed=2)["imgs"])
+    core = SqairCore(F, hw)
+    core.set_params(params32(F, hw, 4, 0.05, obs.mean((0, 1))))
+    m = Model(obs, None, core, K, outputs="minimal")
+    before = core.flat.clone()
+    tr = Trainer(m, F)
+    tr.step(generator=torch.Generator(device="cuda").manual_seed(0))
+    tr.step(generator=torch.Generator(device="cuda").manual_seed(1))
+    torch.cuda.synchronize()
+    assert torch.isfinite(core.flat).all()
+    assert float((core.flat - before).abs().max()) > 0
+
+
+def test_full_size_cfg2_backward_is_finite_and_times():
+    """BASELINE configs[1] shape (T10, 50x50, B32, K5, N4): a whole gradient evaluation as one graph replay."""
+    import time
+    from sqair_amd.data import config_inputs
+    from sqair_amd.model import Model, SqairCore
+    from tests.hip_util import params32
+    ov, obs, _, _ = config_inputs(2)
+    F = make_flags(**ov)
+    hw = obs.shape[2:4]
+    core = SqairCore(F, hw)
+    core.set_params(params32(F, hw, 1, 0.02, obs.mean((0, 1))))
+    Model(obs, None, core, int(F.k_particles), outputs="minimal")
+    core.draw_noise(torch.Generator(device="cuda").manual_seed(0))
+    g = core.grad_step(use_graph=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    t0 = time.perf_counter()
+    for _ in range(5):
+        core.grad_step(use_graph=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print("cfg2 gradient evaluation: %.2f ms (%d graph nodes)" % (dt * 1e3, core.train_graph_nodes))
