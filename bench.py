@@ -68,6 +68,18 @@ def cpu_baseline(F, hw, P, obs, noise, hip_ref, budget_s=25.0):
                 times.append(dt)
             if time.perf_counter() - t_start > budget_s and len(times) >= 1:
                 break
+    # the same workload as a training step: forward + VIMCO target + autograd backward (no optimiser update)
+    orc_t = O.SqairOracle(P, O.make_cfg(F, hw), torch.float32, requires_grad=True)
+    ttimes = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        mt = orc_t.model(obs, noise)
+        orc_t.make_target(mt).backward()
+        if it > 0:
+            ttimes.append(time.perf_counter() - t0)
+        for v in orc_t.P.values():
+            v.grad = None
+    tmed = float(np.median(ttimes))
     med = float(np.median(times))
     lw_cpu = m.log_weights.numpy().astype(np.float64)
     pres_cpu = m.presence.numpy()
@@ -87,7 +99,7 @@ def cpu_baseline(F, hw, P, obs, noise, hip_ref, budget_s=25.0):
                        "fp32 PyTorch-CPU oracle at reference op granularity, median of {} passes after 1 warm-up, "
                        "{} threads (best of 1/4/8/16/32/64 on a 2-frame slice) of {} logical CPUs; host CPU: {}".format(
                            B, T, int(F.k_particles), len(times), best_thr, ncpu, cpu_name),
-                ms_per_pass=med * 1e3,
+                ms_per_pass=med * 1e3, train_value=B * T / tmed, train_ms_per_pass=tmed * 1e3,
                 parity=dict(rows_with_identical_presence=float(same_rows.mean()), log_weights_max_rel_err=rel,
                             elbo_iwae_oracle=float(m.elbo_iwae), elbo_iwae_hip=hip_ref["elbo_iwae"]))
 
@@ -100,6 +112,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--cfg", type=int, default=2, help="BASELINE.json config id used as the workload (default 2)")
+    ap.add_argument("--train-steps", type=int, default=-1,
+                    help="steps of the extra training-step leg (default min(steps, 20); 0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,6 +189,41 @@ def main():
         dist.all_reduce(e, op=dist.ReduceOp.SUM)  # the only collective: scalar metrics, outside the timed region
         elbo, elbo_vae = float(e[0] / world), float(e[1] / world)
 
+    # ---- training-step leg (extra object "train"): noise draw + gradient evaluation (forward with tape, VIMCO target,
+    # backward; ONE HIP-graph replay) + the step's single collective (all-reduce of the flat fp32 gradient buffer over
+    # RCCL) + fused RMSProp + weight re-pack.  Same workload, same barrier / max-over-ranks timing.
+    train = None
+    n_train = min(args.steps, 20) if args.train_steps < 0 else args.train_steps
+    if n_train > 0:
+        from sqair_amd.train import Trainer
+        Ftr = make_flags(**dict(ov, learning_rate=1e-5, train_itr=1000000))
+        trainer = Trainer(model, Ftr, use_graph=use_graph)
+        for _ in range(max(2, min(args.warmup, 3))):
+            trainer.step(generator=gen)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_train):
+            trainer.step(generator=gen)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        train = dict(value=frames_per_step / (el / n_train), unit="frames/s", ms_per_step=el / n_train * 1e3, steps=n_train,
+                     scaling="weak", graph_nodes=getattr(core, "train_graph_nodes", None),
+                     collective="all-reduce(sum) of {} fp32 gradients ({:.1f} MB) per step over RCCL, / world".format(
+                         core.n_params, core.n_params * 4 / 1e6) if world > 1 else "none (1 rank)",
+                     what="draw noise + forward(train) + VIMCO target + backward (one HIP-graph replay) + all-reduce + "
+                          "RMSProp + re-pack; finite={}".format(bool(torch.isfinite(core.flat).all())))
+        core.set_params(P)  # back to the benchmark parameters for the parity / roofline legs below
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -237,10 +286,12 @@ def main():
             args.cfg, T, hw[0], hw[1], B, K, N, use_graph), "global_batch": B * world, "seq_len": T,
             "parallelism": "dp{}".format(world), "graph_nodes": core.graph_nodes()},
         "elbo_iwae_nats_per_seq": elbo, "elbo_vae_nats_per_seq": elbo_vae,
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "train": train,
     }
     if cpu is not None:
         line["speedup_vs_cpu_baseline"] = value / world / cpu["value"]
+        if train is not None:
+            train["speedup_vs_cpu_baseline"] = train["value"] / world / cpu["train_value"]
     print(json.dumps(line))
     if dist is not None:
         dist.barrier()

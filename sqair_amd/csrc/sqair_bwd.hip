@@ -273,6 +273,15 @@ __global__ void k_reduce_rows(const float* __restrict__ rows, float* __restrict_
   for (int r = 0; r < R; ++r) acc += rows[(size_t)r * P + p];
   out[p] = acc;
 }
+// row-chunked variant for the training step: out[p] += sum over this block's rows (float atomics, out pre-zeroed)
+__global__ void k_reduce_rows_atomic(const float* __restrict__ rows, float* __restrict__ out, int R, int P, int rows_per_block) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  float acc = 0.0f;
+  for (int r = r0; r < r1; ++r) acc += rows[(size_t)r * P + p];
+  unsafeAtomicAdd(out + p, acc);
+}
 
 extern "C" int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, const float* where_logits,
                                           const float* presence, const float* img, const float* mean_img,
@@ -392,6 +401,96 @@ int sq_launch_wgrad(const float* A, int lda, const float* dY, int ldy, float* dW
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient for the training step: dW[rowmap[k]][n] += alpha * sum_m A[m][k] dY[m][n] (float atomics onto a
+// zeroed gradient buffer), db_a[n], db_b[n] += alpha * sum_m dY[m][n].  Grid = (K/32, N/32, M-chunks): every wave
+// owns a 32(k) x 32(n) macro tile (4 accumulators: 2 A + 2 dY fragment loads feed 4 MFMAs), the 4 waves of a
+// workgroup split the rows of the workgroup's M-chunk and reduce through LDS; the M range is split over
+// blockIdx.z so that a layer with few tiles (e.g. 256 x 8) still fills the chip.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wgrad2(const float* __restrict__ A, int lda, const float* __restrict__ dY, int ldy,
+                                                float* __restrict__ dW, int ldw, int M, int Kdim, int Ndim,
+                                                const int* __restrict__ rowmap, const float* __restrict__ alpha_ptr,
+                                                float* __restrict__ db_a, float* __restrict__ db_b, int m_per_wg) {
+  __shared__ float red[4 * 1024];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, mq = lane >> 4;
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int mbeg = blockIdx.z * m_per_wg, mend = min(M, mbeg + m_per_wg);
+  const int ka = min(k0 + l15, Kdim - 1), kb = min(k0 + 16 + l15, Kdim - 1);
+  const int na = min(n0 + l15, Ndim - 1), nb = min(n0 + 16 + l15, Ndim - 1);
+  const bool want_bias = (db_a != nullptr || db_b != nullptr) && blockIdx.x == 0;
+  f32x4_b c00 = {0.0f, 0.0f, 0.0f, 0.0f}, c01 = c00, c10 = c00, c11 = c00;
+  float bs0 = 0.0f, bs1 = 0.0f;
+  for (int mb = mbeg + wave * 16; mb < mend; mb += 64) {
+    float a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = mb + q * 4 + mq;
+      const int mc = min(m, mend - 1);
+      const float* ar = A + (size_t)mc * lda;
+      const float* yr = dY + (size_t)mc * ldy;
+      const float x0 = ar[ka], x1 = ar[kb], y0 = yr[na], y1 = yr[nb];
+      const bool ok = m < mend;
+      a0[q] = ok ? x0 : 0.0f; a1[q] = ok ? x1 : 0.0f; b0[q] = ok ? y0 : 0.0f; b1[q] = ok ? y1 : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], b0[q], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], b1[q], c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], b0[q], c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], b1[q], c11, 0, 0, 0);
+      bs0 += b0[q];
+      bs1 += b1[q];
+    }
+  }
+  // acc[i] of lane l = tile [row k = 4*(l>>4) + i][col n = l & 15]; tiles ordered (kb, nb) = 00, 01, 10, 11
+  float* r = red + wave * 1024;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r[0 * 256 + (4 * mq + i) * 16 + l15] = c00[i];
+    r[1 * 256 + (4 * mq + i) * 16 + l15] = c01[i];
+    r[2 * 256 + (4 * mq + i) * 16 + l15] = c10[i];
+    r[3 * 256 + (4 * mq + i) * 16 + l15] = c11[i];
+  }
+  __syncthreads();
+  const float alpha = alpha_ptr != nullptr ? alpha_ptr[0] : 1.0f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int idx = t * 256 + tid;
+    const float v = (red[idx] + red[1024 + idx] + red[2048 + idx] + red[3072 + idx]) * alpha;
+    const int k = k0 + (t >> 1) * 16 + (tid >> 4), n = n0 + (t & 1) * 16 + (tid & 15);
+    if (k < Kdim && n < Ndim) {
+      const int row = rowmap != nullptr ? rowmap[k] : k;
+      if (row >= 0) unsafeAtomicAdd(dW + (size_t)row * ldw + n, v);
+    }
+  }
+  if (want_bias) {
+    bs0 += __shfl_xor(bs0, 16, 64); bs0 += __shfl_xor(bs0, 32, 64);
+    bs1 += __shfl_xor(bs1, 16, 64); bs1 += __shfl_xor(bs1, 32, 64);
+    __syncthreads();
+    if (lane < 16) { red[wave * 32 + lane] = bs0; red[wave * 32 + 16 + lane] = bs1; }
+    __syncthreads();
+    if (tid < 32 && n0 + tid < Ndim) {
+      const float sb = (red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]) * alpha;
+      if (db_a != nullptr) unsafeAtomicAdd(db_a + n0 + tid, sb);
+      if (db_b != nullptr) unsafeAtomicAdd(db_b + n0 + tid, sb);
+    }
+  }
+}
+int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim,
+                        hipStream_t s, const int* rowmap, const float* alpha_ptr, float* db_a, float* db_b) {
+  const int kt = (Kdim + 31) / 32, nt = (Ndim + 31) / 32;
+  int zc = 2048 / (kt * nt);
+  const int max_z = (M + 63) / 64;
+  if (zc > max_z) zc = max_z;
+  if (zc < 1) zc = 1;
+  int m_per_wg = ((M + zc - 1) / zc + 63) / 64 * 64;
+  zc = (M + m_per_wg - 1) / m_per_wg;
+  hipLaunchKernelGGL(k_wgrad2, dim3(kt, nt, zc), dim3(256), 0, s, A, lda, dY, ldy, dW, ldw, M, Kdim, Ndim, rowmap, alpha_ptr,
+                     db_a, db_b, m_per_wg);
+  return 0;
+}
+
 // batched insert/log-likelihood adjoint over T frames on merged slot records (decoder branch of sqair_backward)
 int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_ld, const float* img, const float* mean_img,
                                 const float* g_ll, float* d_glimpse, float* d_rec, int d_rec_ld, float* d_mean_rows,
@@ -404,6 +503,11 @@ int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_
 }
 int sq_launch_reduce_rows(const float* rows, float* out, int R, int P, int accumulate, hipStream_t s) {
   hipLaunchKernelGGL(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, s, rows, out, R, P, accumulate);
+  return 0;
+}
+int sq_launch_reduce_rows_atomic(const float* rows, float* out, int R, int P, hipStream_t s) {
+  const int rpb = 32;
+  hipLaunchKernelGGL(k_reduce_rows_atomic, dim3((P + 255) / 256, (R + rpb - 1) / rpb), dim3(256), 0, s, rows, out, R, P, rpb);
   return 0;
 }
 int sq_launch_elbo_bwd(const float* iw, const float* sig, int T, int B, int K, float* g_lw, float* g_dl, hipStream_t s) {
@@ -426,6 +530,20 @@ __global__ void k_dot_scale(const float* __restrict__ a, const float* __restrict
     for (int i = 0; i < 16; ++i) t += red[i];
     out[0] = t / scale[0];
   }
+}
+__global__ void k_dot_scale_atomic(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                   const float* __restrict__ scale, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += a[i] * b[i];
+  acc = sq_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1] + red[2] + red[3]) / scale[0]);
+}
+int sq_launch_dot_scale_atomic(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_dot_scale_atomic, dim3(512), dim3(256), 0, s, a, b, n, scale, out);
+  return 0;
 }
 int sq_launch_dot_scale(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s) {
   hipLaunchKernelGGL(k_dot_scale, dim3(1), dim3(1024), 0, s, a, b, n, scale, out);
@@ -592,12 +710,12 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
         const float coef = gw * pres;
         g_loc = coef * (-dnormal_dx(x, loc, psc));
         g_raw = coef * dnormal_dsc(x, loc, psc) * sq_sigmoid(raw);
-        atomicAdd(&a.d_rec_d[(fs + j) * RW + rec::WHERE + lane], coef * dnormal_dx(x, loc, psc));
-        atomicAdd(&fg[po.rn_readout_b + lane], g_loc);
-        atomicAdd(&fg[po.rn_readout_b + 4 + lane], g_raw);
+        unsafeAtomicAdd(&a.d_rec_d[(fs + j) * RW + rec::WHERE + lane], coef * dnormal_dx(x, loc, psc));
+        unsafeAtomicAdd(&fg[po.rn_readout_b + lane], g_loc);
+        unsafeAtomicAdd(&fg[po.rn_readout_b + 4 + lane], g_raw);
         for (int mm = 0; mm < 4; ++mm) {
-          atomicAdd(&fg[po.rn_readout_w + mm * 8 + lane], o[mm] * g_loc);
-          atomicAdd(&fg[po.rn_readout_w + mm * 8 + 4 + lane], o[mm] * g_raw);
+          unsafeAtomicAdd(&fg[po.rn_readout_w + mm * 8 + lane], o[mm] * g_loc);
+          unsafeAtomicAdd(&fg[po.rn_readout_w + mm * 8 + 4 + lane], o[mm] * g_raw);
         }
       }
       // g_o[m] = sum_i ro_w[m][i] g_loc_i + ro_w[m][4+i] g_raw_i  (reduce over lanes 0..3)
@@ -611,16 +729,16 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
       if (lane < 4) {  // lane = input index i of i2h
         float dx = 0.0f;
         for (int mm = 0; mm < 4; ++mm) {
-          atomicAdd(&fg[po.rn_i2h_w + lane * 4 + mm], xp[lane] * g_pre[mm]);
+          unsafeAtomicAdd(&fg[po.rn_i2h_w + lane * 4 + mm], xp[lane] * g_pre[mm]);
           dx += flat[po.rn_i2h_w + lane * 4 + mm] * g_pre[mm];
         }
-        if (j == 0) atomicAdd(&fg[po.rn_init_sample + lane], dx);
-        else atomicAdd(&a.d_rec_d[(fs + j - 1) * RW + rec::WHERE + lane], dx);
+        if (j == 0) unsafeAtomicAdd(&fg[po.rn_init_sample + lane], dx);
+        else unsafeAtomicAdd(&a.d_rec_d[(fs + j - 1) * RW + rec::WHERE + lane], dx);
       }
     }
     if (lane < 4) {
-      atomicAdd(&fg[po.rn_h2h_b + lane], d_hs[lane]);
-      atomicAdd(&fg[po.rn_i2h_b + lane], d_hs[lane]);
+      unsafeAtomicAdd(&fg[po.rn_h2h_b + lane], d_hs[lane]);
+      unsafeAtomicAdd(&fg[po.rn_i2h_b + lane], d_hs[lane]);
     }
     float de_part = 0.0f;
 #pragma unroll
@@ -629,11 +747,11 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
       float g_s = 0.0f;
       for (int jj = 0; jj < 4; ++jj) {
         g_s += flat[po.rn_h2h_w + i * 4 + jj] * d_hs[jj];
-        atomicAdd(&fg[po.rn_h2h_w + i * 4 + jj], sv[q] * d_hs[jj]);
+        unsafeAtomicAdd(&fg[po.rn_h2h_w + i * 4 + jj], sv[q] * d_hs[jj]);
       }
       const float g_spre = g_s * delu_from_out(sv[q]);
       a.d_spre[frr * 128 + i] = g_spre;
-      atomicAdd(&fg[po.rn_cond_w + (4 + d.nh) * 128 + i], e_sum * g_spre);
+      unsafeAtomicAdd(&fg[po.rn_cond_w + (4 + d.nh) * 128 + i], e_sum * g_spre);
       de_part += flat[po.rn_cond_w + (4 + d.nh) * 128 + i] * g_spre;
     }
     d_e += sq_wave_sum(de_part);
@@ -643,7 +761,7 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
     for (int j = 0; j < N; ++j)
       if (lane < 4) {
         const float* rd = a.rec_d + (fs + j) * RW;
-        atomicAdd(&a.d_rec_d[(fs + j) * RW + rec::WHERE + lane],
+        unsafeAtomicAdd(&a.d_rec_d[(fs + j) * RW + rec::WHERE + lane],
                   gw * rd[rec::PRES] * dnormal_dx(rd[rec::WHERE + lane], a.cfg.where_prior_mean[lane], 1.0f));
       }
   }
@@ -655,15 +773,15 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
     const float cq = -gw * pres, cp = gw * pres;
     if (lane < nw) {
       const float x = rd[rec::WHAT + lane], loc = rd[rec::WHAT_LOC + lane], sc = rd[rec::WHAT_SCALE + lane];
-      atomicAdd(&dr[rec::WHAT + lane], cq * dnormal_dx(x, loc, sc) + cp * (-x));
-      atomicAdd(&dr[rec::WHAT_LOC + lane], -cq * dnormal_dx(x, loc, sc));
-      atomicAdd(&dr[rec::WHAT_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
+      unsafeAtomicAdd(&dr[rec::WHAT + lane], cq * dnormal_dx(x, loc, sc) + cp * (-x));
+      unsafeAtomicAdd(&dr[rec::WHAT_LOC + lane], -cq * dnormal_dx(x, loc, sc));
+      unsafeAtomicAdd(&dr[rec::WHAT_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
     }
     if (lane < 4) {
       const float x = rd[rec::WHERE + lane], loc = rd[rec::WHERE_LOC + lane], sc = rd[rec::WHERE_SCALE + lane];
-      atomicAdd(&dr[rec::WHERE + lane], cq * dnormal_dx(x, loc, sc));
-      atomicAdd(&dr[rec::WHERE_LOC + lane], -cq * dnormal_dx(x, loc, sc));
-      atomicAdd(&dr[rec::WHERE_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
+      unsafeAtomicAdd(&dr[rec::WHERE + lane], cq * dnormal_dx(x, loc, sc));
+      unsafeAtomicAdd(&dr[rec::WHERE_LOC + lane], -cq * dnormal_dx(x, loc, sc));
+      unsafeAtomicAdd(&dr[rec::WHERE_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
     }
     if (lane == 0) {
       // q_num = log J_n, J from p_j = sigmoid(logit_j): d log J_n / d logit_j = (1 - p_j) for j < n, -p_n for j = n < N
@@ -672,7 +790,7 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
       float g = 0.0f;
       if (j < n) g = coef * (1.0f - pj);
       else if (j == n) g = coef * (-pj);
-      atomicAdd(&dr[rec::LOGIT], g);
+      unsafeAtomicAdd(&dr[rec::LOGIT], g);
     }
   }
   // categorical / geometric prior of the number of steps
@@ -691,19 +809,19 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
     for (int c = 0; c <= N; ++c) {
       const float sm = expf(lg[c] - mx) / se;
       gv[c] = gw * ((c == n ? 1.0f : 0.0f) - sm) * delu_from_out(lg[c]);
-      atomicAdd(&fg[po.step_prior_bias + c], gv[c]);
-      if (t_global > 0) atomicAdd(&fg[po.step_prior_tbias + c], gv[c]);
-      atomicAdd(&fg[po.sp_l1_b + c], gv[c]);
+      unsafeAtomicAdd(&fg[po.step_prior_bias + c], gv[c]);
+      if (t_global > 0) unsafeAtomicAdd(&fg[po.step_prior_tbias + c], gv[c]);
+      unsafeAtomicAdd(&fg[po.sp_l1_b + c], gv[c]);
     }
     for (int i = 0; i < 10; ++i) {
       float gh = 0.0f;
       for (int c = 0; c <= N; ++c) {
-        atomicAdd(&fg[po.sp_l1_w + i * (N + 1) + c], hid[i] * gv[c]);
+        unsafeAtomicAdd(&fg[po.sp_l1_w + i * (N + 1) + c], hid[i] * gv[c]);
         gh += flat[po.sp_l1_w + i * (N + 1) + c] * gv[c];
       }
       const float ghp = gh * delu_from_out(hid[i]);
-      atomicAdd(&fg[po.sp_l0_w + i], e_sum * ghp);
-      atomicAdd(&fg[po.sp_l0_b + i], ghp);
+      unsafeAtomicAdd(&fg[po.sp_l0_w + i], e_sum * ghp);
+      unsafeAtomicAdd(&fg[po.sp_l0_b + i], ghp);
       d_e += flat[po.sp_l0_w + i] * ghp;
     }
   }
@@ -729,13 +847,13 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
       else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHAT + lane] + 0.1f * ploc;
       const float praw = ps[9 + nw + lane];
       const float psc = sq_softplus(praw) + 1e-2f;
-      atomicAdd(&drp[rec::WHAT + lane], cq * dnormal_dx(x, loc, sc) + cp * dnormal_dx(x, ploc, psc));
-      atomicAdd(&drp[rec::WHAT_LOC + lane], -cq * dnormal_dx(x, loc, sc));
-      atomicAdd(&drp[rec::WHAT_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
+      unsafeAtomicAdd(&drp[rec::WHAT + lane], cq * dnormal_dx(x, loc, sc) + cp * dnormal_dx(x, ploc, psc));
+      unsafeAtomicAdd(&drp[rec::WHAT_LOC + lane], -cq * dnormal_dx(x, loc, sc));
+      unsafeAtomicAdd(&drp[rec::WHAT_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
       const float g_ploc = -cp * dnormal_dx(x, ploc, psc);
       if (a.cfg.prop_prior_type == 0) dps[5 + lane] = g_ploc;
       else {
-        atomicAdd(&drm[rec::WHAT + lane], g_ploc);
+        unsafeAtomicAdd(&drm[rec::WHAT + lane], g_ploc);
         if (a.cfg.prop_prior_type == 2) dps[5 + lane] = 0.1f * g_ploc;
       }
       dps[9 + nw + lane] = cp * dnormal_dsc(x, ploc, psc) * sq_sigmoid(praw);
@@ -747,11 +865,11 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
       else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHERE + lane] + 0.1f * ploc;
       const float praw = ps[5 + nw + lane];
       const float psc = sq_softplus(praw) + 1e-2f;
-      atomicAdd(&drp[rec::WHERE + lane], cp * dnormal_dx(x, ploc, psc));
+      unsafeAtomicAdd(&drp[rec::WHERE + lane], cp * dnormal_dx(x, ploc, psc));
       const float g_ploc = -cp * dnormal_dx(x, ploc, psc);
       if (a.cfg.prop_prior_type == 0) dps[1 + lane] = g_ploc;
       else {
-        atomicAdd(&drm[rec::WHERE + lane], g_ploc);
+        unsafeAtomicAdd(&drm[rec::WHERE + lane], g_ploc);
         if (a.cfg.prop_prior_type == 2) dps[1 + lane] = 0.1f * g_ploc;
       }
       dps[5 + nw + lane] = cp * dnormal_dsc(x, ploc, psc) * sq_sigmoid(praw);
@@ -776,8 +894,8 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
         u[i] = acc / L[i][i];
       }
       for (int i = 0; i < 4; ++i) {
-        atomicAdd(&drp[rec::WHERE + i], cq * (-u[i]));
-        atomicAdd(&drp[rec::WHERE_LOC + i], cq * u[i]);
+        unsafeAtomicAdd(&drp[rec::WHERE + i], cq * (-u[i]));
+        unsafeAtomicAdd(&drp[rec::WHERE_LOC + i], cq * u[i]);
         const float sci = rp[rec::WHERE_SCALE + i];
         float dsc = 0.0f;
         for (int j = 0; j <= i; ++j) {
@@ -785,17 +903,17 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
           const float tij = tril4(ch, i, j);
           dsc += dL * (tij + (i == j ? 1.0f : 0.0f));
           const int q = i * 4 + j;  // fill_triangular index -> cholesky_scale element
-          atomicAdd(&fg[po.cholesky + (q < 6 ? 4 + q : 15 - q)], cq * dL * sci);
+          unsafeAtomicAdd(&fg[po.cholesky + (q < 6 ? 4 + q : 15 - q)], cq * dL * sci);
         }
-        atomicAdd(&drp[rec::WHERE_SCALE + i], cq * dsc);
+        unsafeAtomicAdd(&drp[rec::WHERE_SCALE + i], cq * dsc);
       }
       // presence Bernoullis and the prior logit (incl. its path through e_sum)
       const float logit = rp[rec::LOGIT];
-      atomicAdd(&drp[rec::LOGIT], (-gw + gd) * pres_tm1 * (pres - sq_sigmoid(logit)));
+      unsafeAtomicAdd(&drp[rec::LOGIT], (-gw + gd) * pres_tm1 * (pres - sq_sigmoid(logit)));
       const float spl = sq_sigmoid(pl[k]);
       float g_pl = gw * pres_tm1 * (pres - spl) + d_e * spl * (1.0f - spl) / (float)N;
       if (a.cfg.prop_prior_type != 0) {
-        atomicAdd(&drm[rec::LOGIT], g_pl);
+        unsafeAtomicAdd(&drm[rec::LOGIT], g_pl);
         g_pl *= 0.1f;
       }
       dps[0] = g_pl * pres_tm1;
@@ -844,8 +962,8 @@ __global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, con
       a.d_temporal_p[((size_t)r * N + sl) * nh + i] = gt;
       a.d_prior_p[((size_t)r * N + sl) * nh + i] = gp;
     } else if (dst >= 0) {  // a newly discovered object starts from the trainable initial states
-      atomicAdd(&a.flat_grad[po.temporal_init + i], gt);
-      atomicAdd(&a.flat_grad[po.prior_init + i], gp);
+      unsafeAtomicAdd(&a.flat_grad[po.temporal_init + i], gt);
+      unsafeAtomicAdd(&a.flat_grad[po.prior_init + i], gp);
     }
   }
 }
@@ -881,12 +999,12 @@ __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, cons
   if (tid < nsp) {
     const float hv = a.s1h[(size_t)r * a.s1h_ld + tid];
     const float w2 = a.flat[a.w2_off + tid];
-    atomicAdd(&a.flat_grad[a.w2_off + tid], hv * d_raw);
+    unsafeAtomicAdd(&a.flat_grad[a.w2_off + tid], hv * d_raw);
     const float g = d_raw * w2 * delu_from_out(hv);
     ds_s[tid] = g;
     a.d_s1pre[(size_t)r * a.ds_ld + tid] = g;
   }
-  if (tid == 0) atomicAdd(&a.flat_grad[a.b2_off], d_raw);
+  if (tid == 0) unsafeAtomicAdd(&a.flat_grad[a.b2_off], d_raw);
   __syncthreads();
   if (tid < nw) {
     const int c = tid;
@@ -1020,7 +1138,7 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
           d_sc += dW * eps[i];
           const float off = a.flat[po.disc_scale_offset];
           d_raw = d_sc * sq_sigmoid(tp[4 + i] + off);
-          atomicAdd(&a.flat_grad[po.disc_scale_offset], d_raw);
+          unsafeAtomicAdd(&a.flat_grad[po.disc_scale_offset], d_raw);
         } else {
           const float* ch = a.flat + po.cholesky;
           const float sci = a.rec_new[((size_t)r * d.N + slot) * RW + rec::WHERE_SCALE + i];
@@ -1028,12 +1146,12 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
           for (int j = 0; j <= i; ++j) {
             lin += (tril4(ch, i, j) + (i == j ? 1.0f : 0.0f)) * eps[j];
             const int q = i * 4 + j;
-            atomicAdd(&a.flat_grad[po.cholesky + (q < 6 ? 4 + q : 15 - q)], dW * sci * eps[j]);
+            unsafeAtomicAdd(&a.flat_grad[po.cholesky + (q < 6 ? 4 + q : 15 - q)], dW * sci * eps[j]);
           }
           d_sc += dW * lin;
           const float off = a.flat[po.prop_scale_offset];
           d_raw = d_sc * sq_sigmoid(tp[4 + i] + off - 1.0f);
-          atomicAdd(&a.flat_grad[po.prop_scale_offset], d_raw);
+          unsafeAtomicAdd(&a.flat_grad[po.prop_scale_offset], d_raw);
           a.d_rec_prev[((size_t)r * d.N + slot) * RW + rec::WHERE + i] += d_loc;  // loc = where_{t-1} + transform
         }
         a.d_tp[(size_t)r * a.dtp_ld + i] = d_loc;
@@ -1127,22 +1245,22 @@ int sq_launch_dact2(const float* din, int in_ld, const float* saved, int s_ld, f
   return 0;
 }
 // column sums of dY[rows][cols] (+)= into out[cols] (bias gradients)
-__global__ void k_colsum(const float* __restrict__ dy, int ld, int rows, int cols, float* __restrict__ out, int acc) {
+__global__ void k_colsum(const float* __restrict__ dy, int ld, int rows, int cols, float* __restrict__ out, int rows_per_block) {
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;  // 4 row partitions
   __shared__ float red[4][64];
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   float sacc = 0.0f;
   if (n < cols)
-    for (int m = part; m < rows; m += 4) sacc += dy[(size_t)m * ld + n];
+    for (int m = r0 + part; m < r1; m += 4) sacc += dy[(size_t)m * ld + n];
   red[part][threadIdx.x & 63] = sacc;
   __syncthreads();
-  if (part == 0 && n < cols) {
-    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    out[n] = (acc ? out[n] : 0.0f) + t;
-  }
+  if (part == 0 && n < cols) unsafeAtomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 int sq_launch_colsum(const float* dy, int ld, int rows, int cols, float* out, int acc, hipStream_t s) {
-  hipLaunchKernelGGL(k_colsum, dim3((cols + 63) / 64), dim3(256), 0, s, dy, ld, rows, cols, out, acc);
+  (void)acc;  // always accumulates (float atomics)
+  const int rpb = 64;
+  hipLaunchKernelGGL(k_colsum, dim3((cols + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, s, dy, ld, rows, cols, out, rpb);
   return 0;
 }
 // latent-summary adjoint: d f[(r,k)][n] = d c[r][n] * presence_k ; particle sum: d pre_disc[b][n] = sum_kp d pre_d[b K + kp][n]

@@ -80,6 +80,10 @@ int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_
 int sq_launch_reduce_rows(const float* rows, float* out, int R, int P, int accumulate, hipStream_t s);
 int sq_launch_elbo_bwd(const float* iw, const float* sig, int T, int B, int K, float* g_lw, float* g_dl, hipStream_t s);
 int sq_launch_dot_scale(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s);
+int sq_launch_dot_scale_atomic(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s);
+int sq_launch_reduce_rows_atomic(const float* rows, float* out, int R, int P, hipStream_t s);
+int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim,
+                        hipStream_t s, const int* rowmap, const float* alpha_ptr, float* db_a, float* db_b);
 
 // a few elementwise helpers local to the driver
 __global__ void k_mul2d(const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld, float* __restrict__ out,
@@ -235,13 +239,27 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   };
   // batched weight + bias gradients of one layer over `rows` uses
   auto wgrad = [&](LayerId id, std::vector<std::pair<const float*, int>> segs, const float* dY, int ldy, int rows) {
-    for (const auto& e : h->wg[id])
-      sq_launch_wgrad(segs[e.seg].first, segs[e.seg].second, dY + e.n0, ldy, flat_grad + P(h, e.w) + e.col0, PC(h, e.w),
-                      nullptr, rows, h->layers[id].seg_width[e.seg], e.ncols, 1, s, rm_dev + e.rm_off, nullptr);
-    for (const auto& e : h->bg[id]) {
-      if (!e.a.empty()) sq_launch_colsum(dY + e.n0, ldy, rows, e.ncols, flat_grad + P(h, e.a) + e.col0, 1, s);
-      if (!e.b.empty()) sq_launch_colsum(dY + e.n0, ldy, rows, e.ncols, flat_grad + P(h, e.b) + e.col0, 1, s);
+    // the bias gradient of a column block rides on the first weight-gradient launch of that block
+    std::vector<char> bias_done(h->bg[id].size(), 0);
+    for (const auto& e : h->wg[id]) {
+      float *dba = nullptr, *dbb = nullptr;
+      for (size_t bi = 0; bi < h->bg[id].size(); ++bi) {
+        const auto& be = h->bg[id][bi];
+        if (!bias_done[bi] && be.n0 == e.n0 && be.ncols == e.ncols) {
+          if (!be.a.empty()) dba = flat_grad + P(h, be.a) + be.col0;
+          if (!be.b.empty()) dbb = flat_grad + P(h, be.b) + be.col0;
+          bias_done[bi] = 1;
+        }
+      }
+      sq_launch_wgrad_acc(segs[e.seg].first, segs[e.seg].second, dY + e.n0, ldy, flat_grad + P(h, e.w) + e.col0, PC(h, e.w), rows,
+                          h->layers[id].seg_width[e.seg], e.ncols, s, rm_dev + e.rm_off, nullptr, dba, dbb);
     }
+    for (size_t bi = 0; bi < h->bg[id].size(); ++bi)
+      if (!bias_done[bi]) {  // (no weight block with the same column range: plain column sums)
+        const auto& e = h->bg[id][bi];
+        if (!e.a.empty()) sq_launch_colsum(dY + e.n0, ldy, rows, e.ncols, flat_grad + P(h, e.a) + e.col0, 1, s);
+        if (!e.b.empty()) sq_launch_colsum(dY + e.n0, ldy, rows, e.ncols, flat_grad + P(h, e.b) + e.col0, 1, s);
+      }
   };
   auto slotp = [&](float* base, int W, int t, int ph, int k) { return base + (((size_t)(ph * T + t) * R * N) + k) * W; };
   auto cslotp = [&](const float* base, int W, int t, int ph, int k) { return base + (((size_t)(ph * T + t) * R * N) + k) * W; };
@@ -256,11 +274,11 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     const float* gl = w.glimpse;
     sq_launch_insert_bwd_frames(gl, rec_all, RW, obs, flat + po.dec_mean_img, b.g_lw, b.d_gl, d_rec_all + rec::WHERE, RW,
                                 b.d_mean_rows, c.output_std, c.background_std, T, d, s);
-    sq_launch_reduce_rows(b.d_mean_rows, flat_grad + po.dec_mean_img, T * R, P_, 0, s);
+    sq_launch_reduce_rows_atomic(b.d_mean_rows, flat_grad + po.dec_mean_img, T * R, P_, s);
     const float* scale = flat + po.dec_output_scale;
-    sq_launch_dot_scale(b.d_gl, gl, (int64_t)MT * G2, scale, flat_grad + po.dec_output_scale, s);
-    sq_launch_wgrad(w.dec_b, nh, b.d_gl, G2, flat_grad + P(h, "dec.l2.w"), G2, flat_grad + P(h, "dec.l2.b"), MT, nh, G2, 0, s,
-                    nullptr, scale);
+    sq_launch_dot_scale_atomic(b.d_gl, gl, (int64_t)MT * G2, scale, flat_grad + po.dec_output_scale, s);
+    sq_launch_wgrad_acc(w.dec_b, nh, b.d_gl, G2, flat_grad + P(h, "dec.l2.w"), G2, MT, nh, G2, s, nullptr, scale,
+                        flat_grad + P(h, "dec.l2.b"), nullptr);
     CK(dx(L_DEC2, b.d_gl, G2, MT, b.bufa, nh, false, scale));
     sq_launch_dact2(b.bufa, nh, w.dec_b, nh, b.bufb, nh, MT, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
     wgrad(L_DEC1, {{w.dec_a, nh}}, b.bufb, nh, MT);
