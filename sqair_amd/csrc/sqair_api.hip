@@ -439,8 +439,8 @@ extern "C" int sqair_create(const SqairConfig* cfg, SqairHandle** out) {
 
 extern "C" int sqair_destroy(SqairHandle* h) {
   if (h == nullptr) return 0;
-  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
-  if (h->graph) hipGraphDestroy(h->graph);
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  if (h->graph) (void)hipGraphDestroy(h->graph);
   for (int i = 0; i < 4; ++i) {
     if (h->cap_exec[i]) (void)hipGraphExecDestroy(h->cap_exec[i]);
     if (h->cap_graph[i]) (void)hipGraphDestroy(h->cap_graph[i]);
@@ -918,17 +918,17 @@ extern "C" int sqair_profile_forward(SqairHandle* h, const float* flat_params, c
   h->prof_flops = 0.0;
   h->prof_layer.clear();
   h->prof_m.clear();
-  hipEventRecord(ea, s);
+  (void)hipEventRecord(ea, s);
   int rc = forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
                         workspace_bytes, s);
-  hipEventRecord(eb, s);
+  (void)hipEventRecord(eb, s);
   h->prof = false;
   if (rc != 0) return rc;
   SQ_CHECK_HIP(hipStreamSynchronize(s));
   float fms = 0.0f;
   SQ_CHECK_HIP(hipEventElapsedTime(&fms, ea, eb));
-  hipEventDestroy(ea);
-  hipEventDestroy(eb);
+  (void)hipEventDestroy(ea);
+  (void)hipEventDestroy(eb);
   std::vector<unsigned long long> ts(5 * PROF_MAX);
   SQ_CHECK_HIP(hipMemcpy(ts.data(), w.prof_ts, 5 * PROF_MAX * 8, hipMemcpyDeviceToHost));
   double ticks = 0.0;
@@ -954,15 +954,15 @@ extern "C" int sqair_graph_capture(SqairHandle* h, const float* flat_params, con
                                    void* workspace, int64_t workspace_bytes, void* stream) {
   if (!h) return -1;
   hipStream_t s = (hipStream_t)stream;
-  if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-  if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
   SQ_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   int rc = forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
                         workspace_bytes, s);
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamEndCapture(s, &g);
   if (rc != 0) {
-    if (g) hipGraphDestroy(g);
+    if (g) (void)hipGraphDestroy(g);
     return rc;
   }
   if (e != hipSuccess) {

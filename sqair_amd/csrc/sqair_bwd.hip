@@ -982,6 +982,8 @@ struct TailBwdArgs {
   const float* s1h; int s1h_ld;         // saved hidden activations [R][nh/2]
   const float* hraw; int h_ld; const float* enc; int enc_ld; const float* noise;
   float* d_s1pre; int ds_ld;            // out: gradient of the hidden pre-activation [R][nh/2] (T1's extra columns)
+  float* d_s1pre2; int ds2_ld;          // optional second copy (the S1 columns of the PRE gradient, propagation)
+  int enc_pre;                          // disc: write d_enc as the PRE-activation gradient of the what head (softplus')
   float* d_enc; int de_ld;              // out (=): gradient of (loc, scale) of the glimpse encoder
   float* d_hraw; int dh_ld;             // out (=, prop): gradient of the raw head / gate pre-activations
   const float* flat; float* flat_grad;
@@ -1003,6 +1005,7 @@ __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, cons
     const float g = d_raw * w2 * delu_from_out(hv);
     ds_s[tid] = g;
     a.d_s1pre[(size_t)r * a.ds_ld + tid] = g;
+    if (a.d_s1pre2 != nullptr) a.d_s1pre2[(size_t)r * a.ds2_ld + tid] = g;
   }
   if (tid == 0) unsafeAtomicAdd(&a.flat_grad[a.b2_off], d_raw);
   __syncthreads();
@@ -1017,7 +1020,9 @@ __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, cons
     const float d_sc = dw * eps + drn[rec::WHAT_SCALE + c];
     if (a.is_disc) {
       a.d_enc[(size_t)r * a.de_ld + c] = d_loc;
-      a.d_enc[(size_t)r * a.de_ld + nw + c] = d_sc;
+      // scale = softplus(raw) + 0.01  ->  d raw = d scale * (1 - exp(-(scale - 0.01)))
+      a.d_enc[(size_t)r * a.de_ld + nw + c] =
+          a.enc_pre ? d_sc * (1.0f - expf(-(a.enc[(size_t)r * a.enc_ld + nw + c] - 1e-2f))) : d_sc;
     } else {
       const float* hr = a.hraw + (size_t)r * a.h_ld;
       const float t_loc = hr[c], h1 = hr[nw + c];
@@ -1068,7 +1073,8 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* img_s = smem;
   __shared__ float red_s[4][4];
-  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // one workgroup per particle row (the K particles of a sequence re-stage the same frame from L2: 10 KB at 50x50)
+  const int r = blockIdx.x, b = r / d.K, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int slot = a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot;
   const int P = d.H * d.W, G = d.G, G2 = d.G * d.G, RW = rec::W;
   const float* img = a.img + (size_t)b * P;
@@ -1076,8 +1082,7 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
   __syncthreads();
   const int madd = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
   const int gadd = a.g_row_add + (a.mode == CROP_PROP1 ? slot : 0);
-  for (int kp = 0; kp < d.K; ++kp) {
-    const int r = b * d.K + kp;
+  {
     float wl[4];
     const float* wsrc = a.mode == CROP_PROP1 ? a.rec_prev + ((size_t)r * d.N + slot) * RW + rec::WHERE
                                              : a.rec_new + ((size_t)r * d.N + slot) * RW + rec::WHERE;
@@ -1158,7 +1163,6 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
         a.d_tp[(size_t)r * a.dtp_ld + 4 + i] = d_raw;
       }
     }
-    __syncthreads();
   }
 }
 int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
@@ -1169,7 +1173,7 @@ int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nsl
     (void)hipGetLastError();
     big = true;
   }
-  hipLaunchKernelGGL(k_crop_chain_bwd, dim3(d.B, nslots), dim3(256), shm, s, a, po, d);
+  hipLaunchKernelGGL(k_crop_chain_bwd, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
   return 0;
 }
 
@@ -1182,38 +1186,42 @@ int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nsl
 __global__ void k_gru_bwd_a(const float* __restrict__ d_hn, int dhn_ld, const float* __restrict__ z, int z_ld,
                             const float* __restrict__ hc, int hc_ld, const float* __restrict__ hprev, int h_ld,
                             float* __restrict__ dpre1, int dp_ld, float* __restrict__ d_h, int dh_ld, int rows, int nh,
-                            int accumulate_dh) {
+                            int accumulate_dh, float* __restrict__ dup_z, int dup_ld) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * nh) return;
   const int m = i / nh, n = i - m * nh;
   const float g = d_hn[(size_t)m * dhn_ld + n];
   const float zz = z[(size_t)m * z_ld + n], hh = hc[(size_t)m * hc_ld + n], hp = hprev[(size_t)m * h_ld + n];
-  dpre1[(size_t)m * dp_ld + n] = g * (hh - hp) * zz * (1.0f - zz);
+  const float dz = g * (hh - hp) * zz * (1.0f - zz);
+  dpre1[(size_t)m * dp_ld + n] = dz;
+  if (dup_z != nullptr) dup_z[(size_t)m * dup_ld + n] = dz;
   dpre1[(size_t)m * dp_ld + 2 * nh + n] = g * zz * (1.0f - hh * hh);
   float* dh = d_h + (size_t)m * dh_ld + n;
   *dh = (accumulate_dh ? *dh : 0.0f) + g * (1.0f - zz);
 }
 __global__ void k_gru_bwd_b(const float* __restrict__ d_rh, int drh_ld, const float* __restrict__ rg, int r_ld,
                             const float* __restrict__ hprev, int h_ld, float* __restrict__ dpre1, int dp_ld,
-                            float* __restrict__ d_h, int dh_ld, int rows, int nh) {
+                            float* __restrict__ d_h, int dh_ld, int rows, int nh, float* __restrict__ dup_r, int dup_ld) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * nh) return;
   const int m = i / nh, n = i - m * nh;
   const float g = d_rh[(size_t)m * drh_ld + n], rr = rg[(size_t)m * r_ld + n], hp = hprev[(size_t)m * h_ld + n];
-  dpre1[(size_t)m * dp_ld + nh + n] = g * hp * rr * (1.0f - rr);
+  const float dr = g * hp * rr * (1.0f - rr);
+  dpre1[(size_t)m * dp_ld + nh + n] = dr;
+  if (dup_r != nullptr) dup_r[(size_t)m * dup_ld + n] = dr;
   d_h[(size_t)m * dh_ld + n] += g * rr;
 }
 int sq_launch_gru_bwd_a(const float* d_hn, int dhn_ld, const float* z, int z_ld, const float* hc, int hc_ld,
                         const float* hprev, int h_ld, float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh,
-                        int accumulate_dh, hipStream_t s) {
+                        int accumulate_dh, hipStream_t s, float* dup_z, int dup_ld) {
   hipLaunchKernelGGL(k_gru_bwd_a, dim3((rows * nh + 255) / 256), dim3(256), 0, s, d_hn, dhn_ld, z, z_ld, hc, hc_ld, hprev,
-                     h_ld, dpre1, dp_ld, d_h, dh_ld, rows, nh, accumulate_dh);
+                     h_ld, dpre1, dp_ld, d_h, dh_ld, rows, nh, accumulate_dh, dup_z, dup_ld);
   return 0;
 }
 int sq_launch_gru_bwd_b(const float* d_rh, int drh_ld, const float* rg, int r_ld, const float* hprev, int h_ld,
-                        float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh, hipStream_t s) {
+                        float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh, hipStream_t s, float* dup_r, int dup_ld) {
   hipLaunchKernelGGL(k_gru_bwd_b, dim3((rows * nh + 255) / 256), dim3(256), 0, s, d_rh, drh_ld, rg, r_ld, hprev, h_ld,
-                     dpre1, dp_ld, d_h, dh_ld, rows, nh);
+                     dpre1, dp_ld, d_h, dh_ld, rows, nh, dup_r, dup_ld);
   return 0;
 }
 
@@ -1264,13 +1272,35 @@ int sq_launch_colsum(const float* dy, int ld, int rows, int cols, float* out, in
   return 0;
 }
 // latent-summary adjoint: d f[(r,k)][n] = d c[r][n] * presence_k ; particle sum: d pre_disc[b][n] = sum_kp d pre_d[b K + kp][n]
-__global__ void k_latent_sum_bwd(const float* __restrict__ d_c, const float* __restrict__ rec_p, float* __restrict__ d_f, Dims d) {
-  const int rk = blockIdx.x;  // r * N + k
+__global__ void k_latent_sum_bwd(const float* __restrict__ d_c, const float* __restrict__ rec_p, const float* __restrict__ f_out,
+                                 float* __restrict__ d_f, Dims d) {
+  const int rk = blockIdx.x;  // r * N + k;  f_out = elu(.) output of the summed feature: its derivative is applied here
   const float pres = rec_p[(size_t)rk * rec::W + rec::PRES];
-  for (int n = threadIdx.x; n < d.nh; n += blockDim.x) d_f[(size_t)rk * d.nh + n] = d_c[(size_t)(rk / d.N) * d.nh + n] * pres;
+  for (int n = threadIdx.x; n < d.nh; n += blockDim.x)
+    d_f[(size_t)rk * d.nh + n] = d_c[(size_t)(rk / d.N) * d.nh + n] * pres * delu_from_out(f_out[(size_t)rk * d.nh + n]);
 }
-int sq_launch_latent_sum_bwd(const float* d_c, const float* rec_p, float* d_f, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_latent_sum_bwd, dim3(d.R * d.N), dim3(256), 0, s, d_c, rec_p, d_f, d);
+int sq_launch_latent_sum_bwd(const float* d_c, const float* rec_p, const float* f_out, float* d_f, Dims d, hipStream_t s) {
+  hipLaunchKernelGGL(k_latent_sum_bwd, dim3(d.R * d.N), dim3(256), 0, s, d_c, rec_p, f_out, d_f, d);
+  return 0;
+}
+// d pre_d[r][n] = sum over the N discovery slots of the RNN pre-activation gradients [R][N][nh]; then over particles
+__global__ void k_sum_slots(const float* __restrict__ d_rnn, float* __restrict__ d_pre_d, float* __restrict__ d_pre_disc, int B, int K,
+                            int N, int nh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nh) return;
+  const int b = i / nh, n = i - b * nh;
+  float tot = 0.0f;
+  for (int kp = 0; kp < K; ++kp) {
+    const int r = b * K + kp;
+    float acc = 0.0f;
+    for (int j = 0; j < N; ++j) acc += d_rnn[((size_t)r * N + j) * nh + n];
+    d_pre_d[(size_t)r * nh + n] = acc;
+    tot += acc;
+  }
+  d_pre_disc[i] = tot;
+}
+int sq_launch_sum_slots(const float* d_rnn, float* d_pre_d, float* d_pre_disc, int B, int K, int N, int nh, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum_slots, dim3((B * nh + 255) / 256), dim3(256), 0, s, d_rnn, d_pre_d, d_pre_disc, B, K, N, nh);
   return 0;
 }
 __global__ void k_particle_sum(const float* __restrict__ in, float* __restrict__ out, int B, int K, int nh) {

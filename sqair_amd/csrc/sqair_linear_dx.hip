@@ -1,0 +1,107 @@
+// dX GEMM of the backward pass: out = (dPre W^T [+ addend]) * act'(saved), with the output columns routed to up to
+// three destinations.  Same weight-stationary split-K MFMA structure as k_linear (sqair_linear_kernel.inc) on the
+// TRANSPOSED packs, but the epilogue does what the reverse sweep would otherwise spend separate launches on:
+//   * column ranges of the (virtually concatenated) input gradient go straight to their consumers' gradient
+//     buffers (a z-record segment into the gradient record, the hidden-state segment into the RNN accumulator, ...),
+//     each either overwriting or accumulating (addend pointer = destination);
+//   * the activation derivative of the producing layer is applied from its saved OUTPUT (elu / tanh / sigmoid /
+//     softplus), so the result is the next dPre.
+// At B' = 160 rows every launch costs ~5 us regardless of its size (dependent-launch boundary + latency), so the
+// backward chain is priced in launches: this kernel halves them.
+#include "sqair_common.h"
+#include "sqair_dx.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float dx_dact(float g, float o, int act) {
+  switch (act) {
+    case ACT_ELU: return g * (o > 0.0f ? 1.0f : o + 1.0f);
+    case ACT_TANH: return g * (1.0f - o * o);
+    case ACT_SIGMOID: return g * (o * (1.0f - o));
+    case ACT_SOFTPLUS_MIN: return g * (1.0f - expf(-(o - 1e-2f)));
+    default: return g;
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void k_linear_dx(const DxArgs a, const int kc_total) {
+  __shared__ float red[4 * 256];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tile_n = blockIdx.x, tile_m = blockIdx.y;
+  const int arow = min(tile_m * 16 + (lane & 15), a.M - 1);
+  const int kq = lane >> 4;
+  // ---- epilogue operands (addend, saved activation), requested before the operand loads
+  const int m = tile_m * 16 + (tid >> 4);
+  const int n = tile_n * 16 + (tid & 15);
+  const int mc = min(m, a.M - 1);
+  int ri = 0;
+  if (a.nranges > 1 && n >= a.r[1].n0) ri = 1;
+  if (a.nranges > 2 && n >= a.r[2].n0) ri = 2;
+  const DxRange& rg = a.r[ri];
+  const bool live = m < a.M && n >= rg.n0 && n < rg.n1;
+  const int c = live ? n - rg.n0 : 0;
+  const float* dummy = a.wzero;
+  const float* pa = (live && rg.add != nullptr) ? rg.add + (size_t)mc * rg.add_ld + c : dummy;
+  const float* ps = (live && rg.saved != nullptr) ? rg.saved + (size_t)mc * rg.saved_ld + c : dummy;
+  const float p_add = *pa, p_saved = *ps;
+  const float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : dummy);
+
+  const float* rp = a.dpre + (size_t)arow * a.ld;
+  const int lim = ((a.width + 3) & ~3) - 4;
+  f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
+  const f32x4* __restrict__ wz = reinterpret_cast<const f32x4*>(a.wzero) + lane;
+  const int nmine = (kc_total - wave + 3) >> 2;  // this wave owns chunks g = wave + 4 i
+#pragma unroll 1
+  for (int base = 0; base < nmine; base += NCH) {
+    f32x4 av[NCH], bv[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const bool valid = base + j < nmine;
+      const int g = valid ? wave + 4 * (base + j) : wave;
+      av[j] = *reinterpret_cast<const f32x4*>(rp + min(g * 16 + kq * 4, lim));
+      bv[j] = *(valid ? wp + (size_t)g * 64 : wz);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
+    }
+  }
+  float* r = red + wave * 256;
+  r[(4 * kq + 0) * 16 + (lane & 15)] = acc0.x + acc1.x;
+  r[(4 * kq + 1) * 16 + (lane & 15)] = acc0.y + acc1.y;
+  r[(4 * kq + 2) * 16 + (lane & 15)] = acc0.z + acc1.z;
+  r[(4 * kq + 3) * 16 + (lane & 15)] = acc0.w + acc1.w;
+  __syncthreads();
+  if (live) {
+    float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+    if (a.scale_ptr != nullptr) v *= p_scale;
+    if (rg.add != nullptr) v += p_add;
+    if (rg.saved != nullptr) v = dx_dact(v, p_saved, c < rg.act_split ? rg.act_a : rg.act_b);
+    rg.dst[(size_t)m * rg.dst_ld + c] = v;
+    if (rg.dst2 != nullptr) rg.dst2[(size_t)m * rg.dst2_ld + c] = v;
+  }
+}
+
+int sq_launch_linear_dx(const DxArgs& a, int kc, int nt, hipStream_t s) {
+  if ((reinterpret_cast<uintptr_t>(a.dpre) & 15) != 0 || (a.ld & 3) != 0 || a.width < 1 || a.nranges < 1 || a.nranges > 3) return -5;
+  const dim3 g(nt, (a.M + 15) / 16);
+  if (g.x == 0 || g.y == 0) return 0;
+  const int per_wave = (kc + 3) / 4;
+  switch (per_wave) {
+    case 1: hipLaunchKernelGGL(k_linear_dx<1>, g, dim3(256), 0, s, a, kc); break;
+    case 2: hipLaunchKernelGGL(k_linear_dx<2>, g, dim3(256), 0, s, a, kc); break;
+    case 3: hipLaunchKernelGGL(k_linear_dx<3>, g, dim3(256), 0, s, a, kc); break;
+    case 4: hipLaunchKernelGGL(k_linear_dx<4>, g, dim3(256), 0, s, a, kc); break;
+    case 5: hipLaunchKernelGGL(k_linear_dx<5>, g, dim3(256), 0, s, a, kc); break;
+    case 6: hipLaunchKernelGGL(k_linear_dx<6>, g, dim3(256), 0, s, a, kc); break;
+    case 7: hipLaunchKernelGGL(k_linear_dx<7>, g, dim3(256), 0, s, a, kc); break;
+    case 8: hipLaunchKernelGGL(k_linear_dx<8>, g, dim3(256), 0, s, a, kc); break;
+    default: hipLaunchKernelGGL(k_linear_dx<9>, g, dim3(256), 0, s, a, kc); break;
+  }
+  return 0;
+}

@@ -12,6 +12,7 @@
 // Every dense adjoint is the forward MFMA kernel on the transposed pack; gradients of z-record segments come out in
 // record order and accumulate straight into "gradient records".
 #include "sqair_internal.h"
+#include "sqair_dx.h"
 
 // launchers from sqair_bwd.hip
 struct LogprobBwdArgs {
@@ -39,6 +40,8 @@ struct TailBwdArgs {
   const float* s1h; int s1h_ld;
   const float* hraw; int h_ld; const float* enc; int enc_ld; const float* noise;
   float* d_s1pre; int ds_ld;
+  float* d_s1pre2; int ds2_ld;
+  int enc_pre;
   float* d_enc; int de_ld;
   float* d_hraw; int dh_ld;
   const float* flat; float* flat_grad;
@@ -63,13 +66,15 @@ int sq_launch_slot_tail_bwd(const TailBwdArgs& a, Dims d, hipStream_t s);
 int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nslots, hipStream_t s);
 int sq_launch_gru_bwd_a(const float* d_hn, int dhn_ld, const float* z, int z_ld, const float* hc, int hc_ld,
                         const float* hprev, int h_ld, float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh,
-                        int accumulate_dh, hipStream_t s);
+                        int accumulate_dh, hipStream_t s, float* dup_z = nullptr, int dup_ld = 0);
 int sq_launch_gru_bwd_b(const float* d_rh, int drh_ld, const float* rg, int r_ld, const float* hprev, int h_ld,
-                        float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh, hipStream_t s);
+                        float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh, hipStream_t s, float* dup_r = nullptr,
+                        int dup_ld = 0);
 int sq_launch_dact2(const float* din, int in_ld, const float* saved, int s_ld, float* dout, int out_ld, int rows, int cols,
                     int act_a, int act_b, int split, int acc, hipStream_t s);
 int sq_launch_colsum(const float* dy, int ld, int rows, int cols, float* out, int acc, hipStream_t s);
-int sq_launch_latent_sum_bwd(const float* d_c, const float* rec_p, float* d_f, Dims d, hipStream_t s);
+int sq_launch_latent_sum_bwd(const float* d_c, const float* rec_p, const float* f_out, float* d_f, Dims d, hipStream_t s);
+int sq_launch_sum_slots(const float* d_rnn, float* d_pre_d, float* d_pre_disc, int B, int K, int N, int nh, hipStream_t s);
 int sq_launch_particle_sum(const float* in, float* out, int B, int K, int nh, hipStream_t s);
 int sq_launch_axpy2d(const float* x, int x_ld, float* y, int y_ld, int rows, int cols, int acc, hipStream_t s);
 int sq_launch_wgrad(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int Kdim,
@@ -129,6 +134,28 @@ __global__ void k_shift_inputs(const float* __restrict__ rec_all, const float* _
   for (int i = threadIdx.x; i < nh; i += blockDim.x)
     rs[(size_t)row * nh + i] = k > 0 ? r_tape[(size_t)(row - 1) * nh + i] : rnn_init[i];
 }
+
+// builder for the routed dX GEMM
+struct Dx {
+  DxArgs a;
+  Dx(const float* dpre, int ld) {
+    memset(&a, 0, sizeof(a));
+    a.dpre = dpre; a.ld = ld;
+  }
+  DxRange& last() { return a.r[a.nranges - 1]; }
+  Dx& to(int n0, int n1, float* dst, int dst_ld) {
+    DxRange& r = a.r[a.nranges++];
+    r.n0 = n0; r.n1 = n1; r.dst = dst; r.dst_ld = dst_ld; r.act_split = 1 << 30;
+    return *this;
+  }
+  Dx& acc() { last().add = last().dst; last().add_ld = last().dst_ld; return *this; }
+  Dx& add(const float* p, int ld) { last().add = p; last().add_ld = ld; return *this; }
+  Dx& dact(const float* saved, int ld, int act_a, int act_b = ACT_NONE, int split = 1 << 30) {
+    last().saved = saved; last().saved_ld = ld; last().act_a = act_a; last().act_b = act_b; last().act_split = split;
+    return *this;
+  }
+  Dx& dup(float* p, int ld) { last().dst2 = p; last().dst2_ld = ld; return *this; }
+};
 
 struct BwdSpace {
   float *g_lw, *g_dl;
@@ -234,6 +261,14 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     l.a.M = Mrows; l.a.N = LF.seg_width.size() == 1 ? LF.seg_width[0] : LT.N;
     if (acc) { l.a.add = outp; l.a.add_ld = out_ld; l.a.add_n = l.a.N; }
     const int rc = sq_launch_linear(l.a, LT, s);
+    if (rc != 0) sq_set_error(h, "sqair_backward: A-operand contract violated in dX of layer " + std::to_string((int)id));
+    return rc;
+  };
+  auto rundx = [&](LayerId id, Dx& dxa, int Mrows, const float* scale_ptr = nullptr) -> int {
+    const PackedLayer& LT = h->layersT[id];
+    dxa.a.width = h->layers[id].N; dxa.a.wp = packed + pl.w + LT.w_off; dxa.a.wzero = packed + pl.w;
+    dxa.a.scale_ptr = scale_ptr; dxa.a.M = Mrows;
+    const int rc = sq_launch_linear_dx(dxa.a, LT.kc, LT.nt, s);
     if (rc != 0) sq_set_error(h, "sqair_backward: A-operand contract violated in dX of layer " + std::to_string((int)id));
     return rc;
   };
@@ -344,17 +379,14 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         TailBwdArgs ta; memset(&ta, 0, sizeof(ta));
         ta.is_disc = 1; ta.slot = j; ta.rec_prev = rec_prev; ta.rec_new = rec_d_t; ta.d_rec_new = d_rec_d_t;
         ta.d_rec_prev = d_rec_prev; ta.s1h = cslotp(w.s1h, S1_LD, t, 1, j); ta.s1h_ld = s1l; ta.enc = enc; ta.enc_ld = el;
-        ta.noise = nz; ta.d_s1pre = d_t1 + nh; ta.ds_ld = t1l; ta.d_enc = b.d_enc; ta.de_ld = ENC_LD; ta.flat = flat;
+        ta.noise = nz; ta.d_s1pre = d_t1 + nh; ta.ds_ld = t1l; ta.d_enc = d_enc3; ta.de_ld = el; ta.enc_pre = 1; ta.flat = flat;
         ta.flat_grad = flat_grad; ta.w2_off = po.disc_steps_l1_w; ta.b2_off = po.disc_steps_l1_b;
         ta.wwhat_off = (int)P(h, "disc.steps.l0.w") + nh * nsp;
         sq_launch_slot_tail_bwd(ta, d, s);
       }
-      sq_launch_dact2(b.d_enc, ENC_LD, enc, el, d_enc3, el, R, 2 * nw, ACT_NONE, ACT_SOFTPLUS_MIN, nw, 0, s);
-      CK(dx(L_WHAT_HEAD, d_enc3, el, R, b.tmp, nh, false));
-      sq_launch_dact2(b.tmp, nh, e2, rl, d_e2, rl, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      CK(dx(L_GENC1, d_e2, rl, R, b.tmp, nh, false));
-      sq_launch_dact2(b.tmp, nh, e1, rl, d_e1, rl, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      CK(dx(L_GENC0, d_e1, rl, R, b.d_g, G2, false));
+      { Dx x(d_enc3, el); x.to(0, nh, d_e2, rl).dact(e2, rl, ACT_ELU); CK(rundx(L_WHAT_HEAD, x, R)); }
+      { Dx x(d_e2, rl); x.to(0, nh, d_e1, rl).dact(e1, rl, ACT_ELU); CK(rundx(L_GENC1, x, R)); }
+      { Dx x(d_e1, rl); x.to(0, G2, b.d_g, G2); CK(rundx(L_GENC0, x, R)); }
       {
         CropChainBwdArgs ca; memset(&ca, 0, sizeof(ca));
         ca.mode = CROP_DISC; ca.slot = j; ca.img = img; ca.rec_prev = rec_prev; ca.rec_new = rec_d_t; ca.d_rec_prev = d_rec_prev;
@@ -362,47 +394,47 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         ca.d_tp = d_tp; ca.dtp_ld = tpl; ca.noise = nz; ca.flat = flat; ca.flat_grad = flat_grad;
         sq_launch_crop_chain_bwd(ca, po, d, 1, s);
       }
-      CK(dx(L_DISC_T3, d_tp, tpl, R, b.tmp, nh, false));
-      sq_launch_dact2(b.tmp, nh, t2, rl, d_t2, rl, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      CK(dx(L_DISC_T2, d_t2, rl, R, b.tmp, nh, false));
-      sq_launch_dact2(b.tmp, nh, t1, t1l, d_t1, t1l, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      // d r_j = T1^T (incl. the steps-predictor columns) + what the next slot's RNN sent back
-      CK(dx(L_DISC_T1, d_t1, t1l, R, b.tmp, nh, false));
-      if (j < N - 1) sq_launch_axpy2d(b.d_r[(j + 1) & 1], nh, b.tmp, nh, R, nh, 1, s);
-      sq_launch_dact2(b.tmp, nh, r_j, rl, d_rnn, rl, R, nh, ACT_TANH, ACT_TANH, 1 << 30, 0, s);
-      sq_launch_axpy2d(d_rnn, rl, d_pre_d, nh, R, nh, 1, s);
-      CK(dx(L_DISC_RNN, d_rnn, rl, R, b.dcat, 320, false));
+      { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_DISC_T3, x, R)); }
+      { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU); CK(rundx(L_DISC_T2, x, R)); }
+      {  // d r_j = T1^T (incl. the steps-predictor columns) + what the next slot's RNN sent back; tanh' -> d pre-activation
+        Dx x(d_t1, t1l); x.to(0, nh, d_rnn, rl);
+        if (j < N - 1) x.add(b.d_r[j & 1], nh);
+        x.dact(r_j, rl, ACT_TANH);
+        CK(rundx(L_DISC_T1, x, R));
+      }
       if (j > 0) {
-        sq_launch_axpy2d(b.dcat, 320, d_rec_d_t + (size_t)(j - 1) * RW, N * RW, R, rec::ZW, 1, s);
-        sq_launch_axpy2d(b.dcat + 64, 320, b.d_r[j & 1], nh, R, nh, 0, s);
+        Dx x(d_rnn, rl);
+        x.to(0, rec::ZW, d_rec_d_t + (size_t)(j - 1) * RW, N * RW).acc();
+        x.to(64, 64 + nh, b.d_r[(j - 1) & 1], nh);
+        CK(rundx(L_DISC_RNN, x, R));
       } else {
-        sq_launch_colsum(b.dcat + 64, 320, R, nh, flat_grad + po.disc_rnn_init, 1, s);
+        Dx x(d_rnn, rl); x.to(64, 64 + nh, b.tmp, nh); CK(rundx(L_DISC_RNN, x, R));
+        sq_launch_colsum(b.tmp, nh, R, nh, flat_grad + po.disc_rnn_init, 1, s);
       }
     }
     // ---- F^T. conditioning of discovery on the propagated latents
-    sq_launch_particle_sum(d_pre_d, b.d_pre_disc + (size_t)t * B * nh, B, K, nh, s);
-    CK(dx(L_PRED, d_pre_d, nh, R, b.d_c, nh, false));
+    sq_launch_sum_slots(b.d_rnn + (size_t)(T + t) * M * nh, d_pre_d, b.d_pre_disc + (size_t)t * B * nh, B, K, N, nh, s);
+    { Dx x(d_pre_d, nh); x.to(0, nh, b.d_c, nh); CK(rundx(L_PRED, x, R)); }
     if (c.rec_where_prior) {
-      CK(dx(L_RNCOND, b.d_spre + (size_t)t * R * 128, 128, R, b.dcat, 272, false));
-      sq_launch_axpy2d(b.dcat + 16, 272, b.d_c, nh, R, nh, 1, s);
-      sq_launch_colsum(b.dcat, 272, R, 4, flat_grad + po.rn_init_state, 1, s);
+      Dx x(b.d_spre + (size_t)t * R * 128, 128);
+      x.to(0, 4, b.tmp, 4);
+      x.to(16, 16 + nh, b.d_c, nh).acc();
+      CK(rundx(L_RNCOND, x, R));
+      sq_launch_colsum(b.tmp, 4, R, 4, flat_grad + po.rn_init_state, 1, s);
     }
     {
       float* d_leb = b.d_leb + (size_t)t * M * nh;
       float* d_lea = b.d_lea + (size_t)t * M * nh;
       const float* leb = w.frame(w.leb, (int64_t)M * nh, t);
       const float* lea = w.frame(w.lea, (int64_t)M * nh, t);
-      sq_launch_latent_sum_bwd(b.d_c, rec_p_t, b.tmp, d, s);
-      sq_launch_dact2(b.tmp, nh, leb, nh, d_leb, nh, M, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      CK(dx(L_LAT1, d_leb, nh, M, b.tmp, nh, false));
-      sq_launch_dact2(b.tmp, nh, lea, nh, d_lea, nh, M, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      CK(dx(L_LAT0, d_lea, nh, M, d_rec_p_t, RW, true));
+      sq_launch_latent_sum_bwd(b.d_c, rec_p_t, leb, d_leb, d, s);
+      { Dx x(d_leb, nh); x.to(0, nh, d_lea, nh).dact(lea, nh, ACT_ELU); CK(rundx(L_LAT1, x, M)); }
+      { Dx x(d_lea, nh); x.to(0, rec::ZW, d_rec_p_t, RW).acc(); CK(rundx(L_LAT0, x, M)); }
     }
     // ---- E^T. propagation slots
     float* d_pre = b.d_pre + (size_t)t * M * pre_ld;
     sq_zero_fill(b.d_mask, align64((int64_t)M * G2), s);
     const float* mask = w.frame(w.mask, (int64_t)M * G2, t);
-    const float* temporal_p = w.frame(w.temporal_p, (int64_t)M * nh, t);
     for (int k = N - 1; k >= 0; --k) {
       float* d_t1 = slotp(b.d_t1, T1_LD, t, 0, k);
       float* d_t2 = slotp(b.d_t2, nh, t, 0, k);
@@ -421,36 +453,37 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       const float* e2 = cslotp(w.e2, nh, t, 0, k);
       const float* enc = cslotp(w.enc, ENC_LD, t, 0, k);
       const float* tau_k = temporal_prev + (size_t)k * nh;
-      float* d_pre_k = d_pre + (size_t)k * pre_ld;
+      float* d_pre_k = d_pre + (size_t)k * pre_ld;   // columns: rnn 0:nh | T1 nh:2nh | S1 2nh:2nh+nsp | z, r
       const int pre_rld = N * pre_ld;
       {
         TailBwdArgs ta; memset(&ta, 0, sizeof(ta));
         ta.is_disc = 0; ta.slot = k; ta.rec_prev = rec_prev; ta.rec_new = rec_p_t; ta.d_rec_new = d_rec_p_t;
         ta.d_rec_prev = d_rec_prev; ta.s1h = cslotp(w.s1h, S1_LD, t, 0, k); ta.s1h_ld = s1l;
         ta.hraw = cslotp(w.hraw, HRAW_LD, t, 0, k); ta.h_ld = hl; ta.enc = enc; ta.enc_ld = el; ta.noise = nz;
-        ta.d_s1pre = d_t1 + nh; ta.ds_ld = t1l; ta.d_enc = b.d_enc; ta.de_ld = ENC_LD; ta.d_hraw = d_hraw; ta.dh_ld = hl;
+        ta.d_s1pre = d_t1 + nh; ta.ds_ld = t1l; ta.d_s1pre2 = d_pre_k + 2 * nh; ta.ds2_ld = pre_rld;
+        ta.d_enc = b.d_enc; ta.de_ld = ENC_LD; ta.d_hraw = d_hraw; ta.dh_ld = hl;
         ta.flat = flat; ta.flat_grad = flat_grad; ta.w2_off = po.prop_steps_l1_w; ta.b2_off = po.prop_steps_l1_b;
         ta.wwhat_off = (int)P(h, "prop.steps.l0.w") + 2 * nh * nsp;
         sq_launch_slot_tail_bwd(ta, d, s);
       }
-      // heads -> d tau'_k ; + what the compaction sent back for this slot's new temporal state
-      CK(dx(L_PROP_HEADS, d_hraw, hl, R, b.dhn, nh, false));
-      sq_launch_axpy2d(b.d_temporal_p + (size_t)k * nh, N * nh, b.dhn, nh, R, nh, 1, s);
+      // heads -> d tau'_k, + what the compaction sent back for this slot's new temporal state
+      { Dx x(d_hraw, hl); x.to(0, nh, b.dhn, nh).add(b.d_temporal_p + (size_t)k * nh, N * nh); CK(rundx(L_PROP_HEADS, x, R)); }
       sq_launch_gru_bwd_a(b.dhn, nh, cslotp(w.gz, nh, t, 0, k), rl, cslotp(w.ghc, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l,
-                          d_tau + (size_t)k * nh, N * nh, R, nh, 1, s);
-      CK(dx(L_PROP_GRU2, d_gru1 + 2 * nh, g1l, R, b.d_rh, nh, false));
+                          d_tau + (size_t)k * nh, N * nh, R, nh, 1, s, d_pre_k + 2 * nh + nsp, pre_rld);
+      { Dx x(d_gru1 + 2 * nh, g1l); x.to(0, nh, b.d_rh, nh); CK(rundx(L_PROP_GRU2, x, R)); }
       sq_launch_gru_bwd_b(b.d_rh, nh, cslotp(w.gr, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l, d_tau + (size_t)k * nh, N * nh,
-                          R, nh, s);
-      sq_launch_axpy2d(d_gru1, g1l, d_pre_k + 2 * nh + nsp, pre_rld, R, 2 * nh, 0, s);  // z, r pre-activation parts of PRE
-      CK(dx(L_PROP_GRU1, d_gru1, g1l, R, b.dcat, 384, false));  // [r_k 256 | where 16 | enc 112]
-      sq_launch_axpy2d(b.dcat + nh, 384, d_rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, R, 4, 1, s);
-      sq_launch_axpy2d(b.dcat + nh + 16, 384, b.d_enc, ENC_LD, R, 2 * nw, 1, s);
-      sq_launch_dact2(b.d_enc, ENC_LD, enc, el, d_enc3, el, R, 2 * nw, ACT_NONE, ACT_SOFTPLUS_MIN, nw, 0, s);
-      CK(dx(L_WHAT_HEAD, d_enc3, el, R, b.tmp, nh, false));
-      sq_launch_dact2(b.tmp, nh, e2, rl, d_e2, rl, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      CK(dx(L_GENC1, d_e2, rl, R, b.tmp, nh, false));
-      sq_launch_dact2(b.tmp, nh, e1, rl, d_e1, rl, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      CK(dx(L_GENC0, d_e1, rl, R, b.d_g, G2, false));
+                          R, nh, s, d_pre_k + 3 * nh + nsp, pre_rld);
+      {  // gate GEMM inputs [r_k nh | where 4 (pad 16) | glimpse-encoder (loc, scale) 2 nw]
+        Dx x(d_gru1, g1l);
+        x.to(0, nh, b.d_r[k & 1], nh);
+        if (k < N - 1) x.acc();                                      // slot k+1's RNN already wrote d r_k there
+        x.to(nh, nh + 4, d_rec_p_t + (size_t)k * RW + rec::WHERE, N * RW).acc();
+        x.to(nh + 16, nh + 16 + 2 * nw, d_enc3, el).add(b.d_enc, ENC_LD).dact(enc, el, ACT_NONE, ACT_SOFTPLUS_MIN, nw);
+        CK(rundx(L_PROP_GRU1, x, R));
+      }
+      { Dx x(d_enc3, el); x.to(0, nh, d_e2, rl).dact(e2, rl, ACT_ELU); CK(rundx(L_WHAT_HEAD, x, R)); }
+      { Dx x(d_e2, rl); x.to(0, nh, d_e1, rl).dact(e1, rl, ACT_ELU); CK(rundx(L_GENC1, x, R)); }
+      { Dx x(d_e1, rl); x.to(0, G2, b.d_g, G2); CK(rundx(L_GENC0, x, R)); }
       {
         CropChainBwdArgs ca; memset(&ca, 0, sizeof(ca));
         ca.mode = CROP_PROP2; ca.slot = k; ca.img = img; ca.rec_prev = rec_prev; ca.rec_new = rec_p_t; ca.d_rec_prev = d_rec_prev;
@@ -459,41 +492,41 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         ca.d_tp = d_tp; ca.dtp_ld = tpl; ca.noise = nz; ca.flat = flat; ca.flat_grad = flat_grad;
         sq_launch_crop_chain_bwd(ca, po, d, 1, s);
       }
-      CK(dx(L_PROP_T3, d_tp, tpl, R, b.tmp, nh, false));
-      sq_launch_dact2(b.tmp, nh, t2, rl, d_t2, rl, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      CK(dx(L_PROP_T2, d_t2, rl, R, b.tmp, nh, false));
-      sq_launch_dact2(b.tmp, nh, t1, t1l, d_t1, t1l, R, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      sq_launch_axpy2d(d_t1, t1l, d_pre_k + nh, pre_rld, R, nh + nsp, 0, s);  // T1 / steps-predictor parts of PRE
-      CK(dx(L_PROP_T1, d_t1, t1l, R, b.tmp, nh, false));
-      sq_launch_axpy2d(b.dcat, 384, b.tmp, nh, R, nh, 1, s);                  // + GRU1's r_k segment
-      if (k < N - 1) sq_launch_axpy2d(b.d_r[(k + 1) & 1], nh, b.tmp, nh, R, nh, 1, s);
-      sq_launch_dact2(b.tmp, nh, r_k, rl, d_rnn, rl, R, nh, ACT_TANH, ACT_TANH, 1 << 30, 0, s);
-      sq_launch_axpy2d(d_rnn, rl, d_pre_k, pre_rld, R, nh, 0, s);
-      CK(dx(L_PROP_RNN, d_rnn, rl, R, b.tmp2, 320, false));
+      { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_PROP_T3, x, R)); }
+      { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU).dup(d_pre_k + nh, pre_rld); CK(rundx(L_PROP_T2, x, R)); }
+      {  // d r_k total = T1^T + (gate GEMM + next slot's RNN, accumulated in d_r[k & 1]); tanh' -> RNN pre-activation
+        Dx x(d_t1, t1l);
+        x.to(0, nh, d_rnn, rl).add(b.d_r[k & 1], nh).dact(r_k, rl, ACT_TANH).dup(d_pre_k, pre_rld);
+        CK(rundx(L_PROP_T1, x, R));
+      }
       if (k > 0) {
-        sq_launch_axpy2d(b.tmp2, 320, d_rec_p_t + (size_t)(k - 1) * RW, N * RW, R, rec::ZW, 1, s);
-        sq_launch_axpy2d(b.tmp2 + 64, 320, b.d_r[k & 1], nh, R, nh, 0, s);
+        Dx x(d_rnn, rl);
+        x.to(0, rec::ZW, d_rec_p_t + (size_t)(k - 1) * RW, N * RW).acc();
+        x.to(64, 64 + nh, b.d_r[(k - 1) & 1], nh);
+        CK(rundx(L_PROP_RNN, x, R));
       } else {
-        sq_launch_colsum(b.tmp2 + 64, 320, R, nh, flat_grad + po.prop_rnn_init, 1, s);
+        Dx x(d_rnn, rl); x.to(64, 64 + nh, b.tmp, nh); CK(rundx(L_PROP_RNN, x, R));
+        sq_launch_colsum(b.tmp, nh, R, nh, flat_grad + po.prop_rnn_init, 1, s);
       }
     }
-    // ---- D^T. the loop-invariant pre-activation GEMM: segments [m1 64 | z_{t-1} record 64 | temporal nh]
+    // ---- D^T. the loop-invariant pre-activation GEMM: segments [m1 nw (pad 64) | z_{t-1} record 56 (pad 64) | temporal nh]
     float* d_m1 = b.d_m1 + (size_t)t * M * M1_LD;
-    CK(dx(L_PRE, d_pre, pre_ld, M, b.dcat, 384, false));
-    sq_launch_axpy2d(b.dcat, 384, d_m1, M1_LD, M, 64, 0, s);
-    sq_launch_axpy2d(b.dcat + 64, 384, d_rec_prev, RW, M, rec::ZW, 1, s);
-    sq_launch_axpy2d(b.dcat + 128, 384, d_tau, nh, M, nh, 1, s);
+    {
+      Dx x(d_pre, pre_ld);
+      x.to(0, nw, d_m1, M1_LD);
+      x.to(64, 64 + rec::ZW, d_rec_prev, RW).acc();
+      x.to(128, 128 + nh, d_tau, nh).acc();
+      CK(rundx(L_PRE, x, M));
+    }
     // ---- C^T. crop #1 and its encoder
     {
       float* d_peb = b.d_peb + (size_t)t * M * nh;
       float* d_pea = b.d_pea + (size_t)t * M * nh;
       const float* peb = w.frame(w.peb, (int64_t)M * nh, t);
       const float* pea = w.frame(w.pea, (int64_t)M * nh, t);
-      CK(dx(L_WHAT_LOC, d_m1, M1_LD, M, b.tmp, nh, false));
-      sq_launch_dact2(b.tmp, nh, peb, nh, d_peb, nh, M, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      CK(dx(L_GENC1, d_peb, nh, M, b.tmp, nh, false));
-      sq_launch_dact2(b.tmp, nh, pea, nh, d_pea, nh, M, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      CK(dx(L_GENC0, d_pea, nh, M, b.d_g1, G2, false));
+      { Dx x(d_m1, M1_LD); x.to(0, nh, d_peb, nh).dact(peb, nh, ACT_ELU); CK(rundx(L_WHAT_LOC, x, M)); }
+      { Dx x(d_peb, nh); x.to(0, nh, d_pea, nh).dact(pea, nh, ACT_ELU); CK(rundx(L_GENC1, x, M)); }
+      { Dx x(d_pea, nh); x.to(0, G2, b.d_g1, G2); CK(rundx(L_GENC0, x, M)); }
       CropChainBwdArgs ca; memset(&ca, 0, sizeof(ca));
       ca.mode = CROP_PROP1; ca.img = img; ca.rec_prev = rec_prev; ca.d_rec_prev = d_rec_prev; ca.wb = w.frame(w.wb, (int64_t)M * WB_LD, t);
       ca.wb_ld = WB_LD; ca.d_wb = b.d_wb + (size_t)t * M * WB_LD; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N;
@@ -505,24 +538,27 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       float* d_maskpre = b.d_maskpre + (size_t)t * M * G2;
       float* d_hid1 = b.d_hid1 + (size_t)t * M * 256;
       const float* hid1 = w.frame(w.hid1, (int64_t)M * 256, t);
-      sq_launch_dact2(b.d_mask, G2, mask, G2, d_maskpre, G2, M, G2, ACT_SIGMOID, ACT_SIGMOID, 1 << 30, 0, s);
-      if (c.masked_glimpse) CK(dx(L_MASK2, d_maskpre, G2, M, b.d_hid1out + 128, 256, false));
-      CK(dx(L_WB2, b.d_wb + (size_t)t * M * WB_LD, WB_LD, M, b.d_hid1out, 256, false));
-      sq_launch_dact2(b.d_hid1out, 256, hid1, 256, d_hid1, 256, M, 256, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-      CK(dx(L_TAU1, d_hid1, 256, M, d_tau, nh, true));
+      if (c.masked_glimpse) {
+        sq_launch_dact2(b.d_mask, G2, mask, G2, d_maskpre, G2, M, G2, ACT_SIGMOID, ACT_SIGMOID, 1 << 30, 0, s);
+        Dx x(d_maskpre, G2); x.to(0, 128, d_hid1 + 128, 256).dact(hid1 + 128, 256, ACT_ELU); CK(rundx(L_MASK2, x, M));
+      }
+      { Dx x(b.d_wb + (size_t)t * M * WB_LD, WB_LD); x.to(0, 128, d_hid1, 256).dact(hid1, 256, ACT_ELU); CK(rundx(L_WB2, x, M)); }
+      { Dx x(d_hid1, 256); x.to(0, nh, d_tau, nh).acc(); CK(rundx(L_TAU1, x, M)); }
     }
     // ---- A^T. prior GRU
     {
       float* d_pgru1 = b.d_pgru1 + (size_t)t * M * 3 * nh;
-      CK(dx(L_PRIOR_LIN, b.d_pstats + (size_t)t * M * PS_LD, PS_LD, M, b.dhn, nh, false));
-      sq_launch_axpy2d(b.d_prior_p, nh, b.dhn, nh, M, nh, 1, s);
+      { Dx x(b.d_pstats + (size_t)t * M * PS_LD, PS_LD); x.to(0, nh, b.dhn, nh).add(b.d_prior_p, nh); CK(rundx(L_PRIOR_LIN, x, M)); }
       sq_launch_gru_bwd_a(b.dhn, nh, w.frame(w.pgz, (int64_t)M * nh, t), nh, w.frame(w.pghc, (int64_t)M * nh, t), nh, prior_prev, nh,
                           d_pgru1, 3 * nh, d_pprev, nh, M, nh, 1, s);
-      CK(dx(L_PRIOR_GRU2, d_pgru1 + 2 * nh, 3 * nh, M, b.d_rh, nh, false));
+      { Dx x(d_pgru1 + 2 * nh, 3 * nh); x.to(0, nh, b.d_rh, nh); CK(rundx(L_PRIOR_GRU2, x, M)); }
       sq_launch_gru_bwd_b(b.d_rh, nh, w.frame(w.pgr, (int64_t)M * nh, t), nh, prior_prev, nh, d_pgru1, 3 * nh, d_pprev, nh, M, nh, s);
-      CK(dx(L_PRIOR_GRU1, d_pgru1, 3 * nh, M, b.dcat, 320, false));  // [z_{t-1} record 64 | prior state nh]
-      sq_launch_axpy2d(b.dcat, 320, d_rec_prev, RW, M, rec::ZW, 1, s);
-      sq_launch_axpy2d(b.dcat + 64, 320, d_pprev, nh, M, nh, 1, s);
+      {  // [z_{t-1} record 56 (pad 64) | prior state nh]
+        Dx x(d_pgru1, 3 * nh);
+        x.to(0, rec::ZW, d_rec_prev, RW).acc();
+        x.to(64, 64 + nh, d_pprev, nh).acc();
+        CK(rundx(L_PRIOR_GRU1, x, M));
+      }
     }
   }
   // ================= initial states, input encoder =================
