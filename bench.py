@@ -121,12 +121,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    # (SQAIR_DIST_BACKEND=gloo lets two ranks share one GPU for a functional check of the N > 1 code path on a 1-GPU box)
+    backend = os.environ.get("SQAIR_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")  # RCCL on ROCm
+        dist.init_process_group(backend=backend)  # "nccl" = RCCL on ROCm
     assert args.gpus == world, "--gpus {} but WORLD_SIZE {}".format(args.gpus, world)
 
     from sqair_amd.data import config_inputs

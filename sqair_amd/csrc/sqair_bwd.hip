@@ -650,13 +650,27 @@ struct LogprobBwdArgs {
   SqairConfig cfg;
 };
 
-__global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, const POff po, const Dims d) {
+constexpr int SQ_SMALL_MAX = 1024;
+struct SmallParamTab { int n; int src[16]; int len[16]; int dst[16]; };
+
+__global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, const POff pc, const SmallParamTab tab, const Dims d) {
+  // The ~800 small parameters this kernel reads (where-prior RNN, step-prior MLP, Cholesky factor) are staged in LDS
+  // and their gradients accumulated there (`pc` holds COMPACT offsets into these arrays): reads from the flat buffer
+  // interleaved with atomics on the gradient buffer cannot be hoisted by the compiler and serialised the kernel on
+  // L2 latency (1.1 ms); one coalesced flush of float atomics per workgroup at the end instead.
+  __shared__ float fl[SQ_SMALL_MAX], gl[SQ_SMALL_MAX];
+  for (int sgi = 0; sgi < tab.n; ++sgi)
+    for (int i = threadIdx.x; i < tab.len[sgi]; i += 64) {
+      fl[tab.dst[sgi] + i] = a.flat[tab.src[sgi] + i];
+      gl[tab.dst[sgi] + i] = 0.0f;
+    }
+  __syncthreads();
   const int r = blockIdx.x, fr = blockIdx.y, lane = threadIdx.x;
   const int N = d.N, nw = d.nw, RW = rec::W;
   const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;
   const size_t frr = (size_t)fr * d.R + r;
-  const float* flat = a.flat;
-  float* fg = a.flat_grad;
+  const float* flat = fl;
+  float* fg = gl;
   const float gw = a.g_lw[frr], gd = a.g_dl[frr];
   const int t_global = a.t_global0 + fr;
   // ---------------- forward quantities needed below: prior logits, e_sum
@@ -682,28 +696,28 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int i = lane + 64 * q;
-      sv[q] = sq_elu(a.spre[frr * 128 + i] + e_sum * flat[po.rn_cond_w + (4 + d.nh) * 128 + i]);
-      for (int jj = 0; jj < 4; ++jj) part[jj] += sv[q] * flat[po.rn_h2h_w + i * 4 + jj];
+      sv[q] = sq_elu(a.spre[frr * 128 + i] + e_sum * flat[pc.rn_cond_w + (4 + d.nh) * 128 + i]);
+      for (int jj = 0; jj < 4; ++jj) part[jj] += sv[q] * flat[pc.rn_h2h_w + i * 4 + jj];
     }
     float hs[4], d_hs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int jj = 0; jj < 4; ++jj) hs[jj] = sq_wave_sum(part[jj]) + flat[po.rn_h2h_b + jj] + flat[po.rn_i2h_b + jj];
+    for (int jj = 0; jj < 4; ++jj) hs[jj] = sq_wave_sum(part[jj]) + flat[pc.rn_h2h_b + jj] + flat[pc.rn_i2h_b + jj];
     for (int j = 0; j < N; ++j) {
       const float* rd = a.rec_d + (fs + j) * RW;
       const float pres = rd[rec::PRES];
-      const float* xp = j == 0 ? flat + po.rn_init_sample : a.rec_d + (fs + j - 1) * RW + rec::WHERE;
+      const float* xp = j == 0 ? flat + pc.rn_init_sample : a.rec_d + (fs + j - 1) * RW + rec::WHERE;
       float o[4], pre;
       for (int mm = 0; mm < 4; ++mm) {
         pre = hs[mm];
-        for (int i = 0; i < 4; ++i) pre += xp[i] * flat[po.rn_i2h_w + i * 4 + mm];
+        for (int i = 0; i < 4; ++i) pre += xp[i] * flat[pc.rn_i2h_w + i * 4 + mm];
         o[mm] = tanhf(pre);
       }
       // lanes 0..3: component i
       float g_loc = 0.0f, g_raw = 0.0f;
       if (lane < 4) {
-        float loc = flat[po.rn_readout_b + lane], raw = flat[po.rn_readout_b + 4 + lane];
+        float loc = flat[pc.rn_readout_b + lane], raw = flat[pc.rn_readout_b + 4 + lane];
         for (int mm = 0; mm < 4; ++mm) {
-          loc += o[mm] * flat[po.rn_readout_w + mm * 8 + lane];
-          raw += o[mm] * flat[po.rn_readout_w + mm * 8 + 4 + lane];
+          loc += o[mm] * flat[pc.rn_readout_w + mm * 8 + lane];
+          raw += o[mm] * flat[pc.rn_readout_w + mm * 8 + 4 + lane];
         }
         const float psc = sq_softplus(raw) + 1e-2f;
         const float x = rd[rec::WHERE + lane];
@@ -711,17 +725,17 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
         g_loc = coef * (-dnormal_dx(x, loc, psc));
         g_raw = coef * dnormal_dsc(x, loc, psc) * sq_sigmoid(raw);
         unsafeAtomicAdd(&a.d_rec_d[(fs + j) * RW + rec::WHERE + lane], coef * dnormal_dx(x, loc, psc));
-        unsafeAtomicAdd(&fg[po.rn_readout_b + lane], g_loc);
-        unsafeAtomicAdd(&fg[po.rn_readout_b + 4 + lane], g_raw);
+        atomicAdd(&fg[pc.rn_readout_b + lane], g_loc);
+        atomicAdd(&fg[pc.rn_readout_b + 4 + lane], g_raw);
         for (int mm = 0; mm < 4; ++mm) {
-          unsafeAtomicAdd(&fg[po.rn_readout_w + mm * 8 + lane], o[mm] * g_loc);
-          unsafeAtomicAdd(&fg[po.rn_readout_w + mm * 8 + 4 + lane], o[mm] * g_raw);
+          atomicAdd(&fg[pc.rn_readout_w + mm * 8 + lane], o[mm] * g_loc);
+          atomicAdd(&fg[pc.rn_readout_w + mm * 8 + 4 + lane], o[mm] * g_raw);
         }
       }
       // g_o[m] = sum_i ro_w[m][i] g_loc_i + ro_w[m][4+i] g_raw_i  (reduce over lanes 0..3)
       float g_pre[4];
       for (int mm = 0; mm < 4; ++mm) {
-        float v = lane < 4 ? flat[po.rn_readout_w + mm * 8 + lane] * g_loc + flat[po.rn_readout_w + mm * 8 + 4 + lane] * g_raw : 0.0f;
+        float v = lane < 4 ? flat[pc.rn_readout_w + mm * 8 + lane] * g_loc + flat[pc.rn_readout_w + mm * 8 + 4 + lane] * g_raw : 0.0f;
         v = sq_wave_sum(v);
         g_pre[mm] = v * (1.0f - o[mm] * o[mm]);
         d_hs[mm] += g_pre[mm];
@@ -729,16 +743,16 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
       if (lane < 4) {  // lane = input index i of i2h
         float dx = 0.0f;
         for (int mm = 0; mm < 4; ++mm) {
-          unsafeAtomicAdd(&fg[po.rn_i2h_w + lane * 4 + mm], xp[lane] * g_pre[mm]);
-          dx += flat[po.rn_i2h_w + lane * 4 + mm] * g_pre[mm];
+          atomicAdd(&fg[pc.rn_i2h_w + lane * 4 + mm], xp[lane] * g_pre[mm]);
+          dx += flat[pc.rn_i2h_w + lane * 4 + mm] * g_pre[mm];
         }
-        if (j == 0) unsafeAtomicAdd(&fg[po.rn_init_sample + lane], dx);
+        if (j == 0) atomicAdd(&fg[pc.rn_init_sample + lane], dx);
         else unsafeAtomicAdd(&a.d_rec_d[(fs + j - 1) * RW + rec::WHERE + lane], dx);
       }
     }
     if (lane < 4) {
-      unsafeAtomicAdd(&fg[po.rn_h2h_b + lane], d_hs[lane]);
-      unsafeAtomicAdd(&fg[po.rn_i2h_b + lane], d_hs[lane]);
+      atomicAdd(&fg[pc.rn_h2h_b + lane], d_hs[lane]);
+      atomicAdd(&fg[pc.rn_i2h_b + lane], d_hs[lane]);
     }
     float de_part = 0.0f;
 #pragma unroll
@@ -746,13 +760,13 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
       const int i = lane + 64 * q;
       float g_s = 0.0f;
       for (int jj = 0; jj < 4; ++jj) {
-        g_s += flat[po.rn_h2h_w + i * 4 + jj] * d_hs[jj];
-        unsafeAtomicAdd(&fg[po.rn_h2h_w + i * 4 + jj], sv[q] * d_hs[jj]);
+        g_s += flat[pc.rn_h2h_w + i * 4 + jj] * d_hs[jj];
+        atomicAdd(&fg[pc.rn_h2h_w + i * 4 + jj], sv[q] * d_hs[jj]);
       }
       const float g_spre = g_s * delu_from_out(sv[q]);
       a.d_spre[frr * 128 + i] = g_spre;
-      unsafeAtomicAdd(&fg[po.rn_cond_w + (4 + d.nh) * 128 + i], e_sum * g_spre);
-      de_part += flat[po.rn_cond_w + (4 + d.nh) * 128 + i] * g_spre;
+      atomicAdd(&fg[pc.rn_cond_w + (4 + d.nh) * 128 + i], e_sum * g_spre);
+      de_part += flat[pc.rn_cond_w + (4 + d.nh) * 128 + i] * g_spre;
     }
     d_e += sq_wave_sum(de_part);
   } else {
@@ -796,11 +810,11 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
   // categorical / geometric prior of the number of steps
   if (a.cfg.disc_prior_type == 0 && lane == 0) {
     float hid[10], lg[SQ_MAXN + 1], gv[SQ_MAXN + 1];
-    for (int i = 0; i < 10; ++i) hid[i] = sq_elu(e_sum * flat[po.sp_l0_w + i] + flat[po.sp_l0_b + i]);
+    for (int i = 0; i < 10; ++i) hid[i] = sq_elu(e_sum * flat[pc.sp_l0_w + i] + flat[pc.sp_l0_b + i]);
     float mx = -1e30f;
     for (int c = 0; c <= N; ++c) {
-      float v = flat[po.step_prior_bias + c] + (t_global > 0 ? flat[po.step_prior_tbias + c] : 0.0f) + flat[po.sp_l1_b + c];
-      for (int i = 0; i < 10; ++i) v += hid[i] * flat[po.sp_l1_w + i * (N + 1) + c];
+      float v = flat[pc.step_prior_bias + c] + (t_global > 0 ? flat[pc.step_prior_tbias + c] : 0.0f) + flat[pc.sp_l1_b + c];
+      for (int i = 0; i < 10; ++i) v += hid[i] * flat[pc.sp_l1_w + i * (N + 1) + c];
       lg[c] = sq_elu(v);
       mx = fmaxf(mx, lg[c]);
     }
@@ -809,20 +823,20 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
     for (int c = 0; c <= N; ++c) {
       const float sm = expf(lg[c] - mx) / se;
       gv[c] = gw * ((c == n ? 1.0f : 0.0f) - sm) * delu_from_out(lg[c]);
-      unsafeAtomicAdd(&fg[po.step_prior_bias + c], gv[c]);
-      if (t_global > 0) unsafeAtomicAdd(&fg[po.step_prior_tbias + c], gv[c]);
-      unsafeAtomicAdd(&fg[po.sp_l1_b + c], gv[c]);
+      atomicAdd(&fg[pc.step_prior_bias + c], gv[c]);
+      if (t_global > 0) atomicAdd(&fg[pc.step_prior_tbias + c], gv[c]);
+      atomicAdd(&fg[pc.sp_l1_b + c], gv[c]);
     }
     for (int i = 0; i < 10; ++i) {
       float gh = 0.0f;
       for (int c = 0; c <= N; ++c) {
-        unsafeAtomicAdd(&fg[po.sp_l1_w + i * (N + 1) + c], hid[i] * gv[c]);
-        gh += flat[po.sp_l1_w + i * (N + 1) + c] * gv[c];
+        atomicAdd(&fg[pc.sp_l1_w + i * (N + 1) + c], hid[i] * gv[c]);
+        gh += flat[pc.sp_l1_w + i * (N + 1) + c] * gv[c];
       }
       const float ghp = gh * delu_from_out(hid[i]);
-      unsafeAtomicAdd(&fg[po.sp_l0_w + i], e_sum * ghp);
-      unsafeAtomicAdd(&fg[po.sp_l0_b + i], ghp);
-      d_e += flat[po.sp_l0_w + i] * ghp;
+      atomicAdd(&fg[pc.sp_l0_w + i], e_sum * ghp);
+      atomicAdd(&fg[pc.sp_l0_b + i], ghp);
+      d_e += flat[pc.sp_l0_w + i] * ghp;
     }
   }
   d_e = __shfl(d_e, 0, 64);
@@ -876,7 +890,7 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
     }
     if (lane == 0) {
       // MultivariateNormalTriL posterior of where: L = T * sc[:,None] + diag(sc)
-      const float* ch = flat + po.cholesky;
+      const float* ch = flat + pc.cholesky;
       float L[4][4], y[4], u[4], dd[4];
       for (int i = 0; i < 4; ++i) {
         const float sci = rp[rec::WHERE_SCALE + i];
@@ -903,7 +917,7 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
           const float tij = tril4(ch, i, j);
           dsc += dL * (tij + (i == j ? 1.0f : 0.0f));
           const int q = i * 4 + j;  // fill_triangular index -> cholesky_scale element
-          unsafeAtomicAdd(&fg[po.cholesky + (q < 6 ? 4 + q : 15 - q)], cq * dL * sci);
+          atomicAdd(&fg[pc.cholesky + (q < 6 ? 4 + q : 15 - q)], cq * dL * sci);
         }
         unsafeAtomicAdd(&drp[rec::WHERE_SCALE + i], cq * dsc);
       }
@@ -920,10 +934,44 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
     }
     __syncthreads();
   }
+  __syncthreads();
+  for (int sgi = 0; sgi < tab.n; ++sgi)
+    for (int i = threadIdx.x; i < tab.len[sgi]; i += 64) {
+      const float g = gl[tab.dst[sgi] + i];
+      if (g != 0.0f) unsafeAtomicAdd(a.flat_grad + tab.src[sgi] + i, g);
+    }
 }
 
 int sq_launch_logprob_bwd(const LogprobBwdArgs& a, POff po, Dims d, int T, hipStream_t s) {
-  hipLaunchKernelGGL(k_logprob_bwd, dim3(d.R, T), dim3(64), 0, s, a, po, d);
+  // compact layout of the small parameters (flat offset, length) -> LDS offset
+  SmallParamTab tab = {};
+  POff cp = po;
+  int o = 0;
+  auto seg = [&](int src, int len) {
+    tab.src[tab.n] = src; tab.len[tab.n] = len; tab.dst[tab.n] = o;
+    ++tab.n;
+    const int at = o;
+    o += len;
+    return at;
+  };
+  const int N1 = d.N + 1;
+  cp.rn_readout_w = seg(po.rn_readout_w, 32);
+  cp.rn_readout_b = seg(po.rn_readout_b, 8);
+  cp.rn_i2h_w = seg(po.rn_i2h_w, 16);
+  cp.rn_i2h_b = seg(po.rn_i2h_b, 4);
+  cp.rn_h2h_w = seg(po.rn_h2h_w, 512);
+  cp.rn_h2h_b = seg(po.rn_h2h_b, 4);
+  cp.rn_cond_w = seg(po.rn_cond_w + (4 + d.nh) * 128, 128) - (4 + d.nh) * 128;  // only the e row is touched here
+  cp.rn_init_sample = seg(po.rn_init_sample, 4);
+  cp.sp_l0_w = seg(po.sp_l0_w, 10);
+  cp.sp_l0_b = seg(po.sp_l0_b, 10);
+  cp.sp_l1_w = seg(po.sp_l1_w, 10 * N1);
+  cp.sp_l1_b = seg(po.sp_l1_b, N1);
+  cp.step_prior_bias = seg(po.step_prior_bias, N1);
+  cp.step_prior_tbias = seg(po.step_prior_tbias, N1);
+  cp.cholesky = seg(po.cholesky, 10);
+  if (o > SQ_SMALL_MAX) return -1;
+  hipLaunchKernelGGL(k_logprob_bwd, dim3(d.R, T), dim3(64), 0, s, a, cp, tab, d);
   return 0;
 }
 
@@ -991,7 +1039,12 @@ struct TailBwdArgs {
 };
 __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, const Dims d) {
   __shared__ float ds_s[128];
+  extern __shared__ float wt_s[];  // the `what` rows of steps.l0.w, [nw][nsp + 1] (padded: conflict-free row reads)
   const int r = blockIdx.x, tid = threadIdx.x, nw = d.nw, nsp = d.nh / 2, RW = rec::W;
+  for (int e = tid; e < nw * nsp; e += 128) {  // coalesced, independent loads: one round trip
+    const int c = e / nsp, i = e - c * nsp;
+    wt_s[c * (nsp + 1) + i] = a.flat[a.wwhat_off + e];
+  }
   const float* rn = a.rec_new + ((size_t)r * d.N + a.slot) * RW;
   float* drn = a.d_rec_new + ((size_t)r * d.N + a.slot) * RW;
   float prev;
@@ -1012,7 +1065,7 @@ __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, cons
   if (tid < nw) {
     const int c = tid;
     float dw = drn[rec::WHAT + c];
-    const float* wrow = a.flat + a.wwhat_off + (size_t)c * nsp;
+    const float* wrow = wt_s + c * (nsp + 1);
     for (int i = 0; i < nsp; ++i) dw += ds_s[i] * wrow[i];
     drn[rec::WHAT + c] = dw;  // total gradient of the sample (kept for the batched weight gradients' bookkeeping)
     const float eps = a.noise[(((size_t)r * 2 + (a.is_disc ? 1 : 0)) * d.N + a.slot) * d.nzw + 4 + c];
@@ -1047,7 +1100,7 @@ __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, cons
   }
 }
 int sq_launch_slot_tail_bwd(const TailBwdArgs& a, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_slot_tail_bwd, dim3(d.R), dim3(128), 0, s, a, d);
+  hipLaunchKernelGGL(k_slot_tail_bwd, dim3(d.R), dim3(128), (size_t)d.nw * (d.nh / 2 + 1) * sizeof(float), s, a, d);
   return 0;
 }
 
