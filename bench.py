@@ -152,6 +152,8 @@ def main():
          init_params(F, hw, seed=0, mean_img=obs.mean((0, 1)), jitter=0.02).items()}
     device = "cuda:{}".format(local_rank)
     core = SqairCore(F, hw, device=device)
+    # one stream for everything (noise draw, graph replays, optimiser, reductions): see SqairCore.on_stream
+    torch.cuda.set_stream(core.stream)
     core.set_params(P)
     model = Model(obs, None, core, K, presence=nums, outputs="minimal")
     gen = torch.Generator(device=device)

@@ -95,6 +95,23 @@ class SqairCore(object):
     def _stream(self):
         return C.c_void_p(self.stream.cuda_stream)
 
+    def on_stream(self):
+        """Context manager making the core's stream torch's current stream.  Run whole loops (noise draw, forward /
+        gradient evaluation, optimiser, metric reads) inside it: with a second active stream (e.g. the default one,
+        joined by events every step) every kernel of the replayed graphs measures ~1 us slower on this stack
+        (forward 6.0 -> 5.0 ms, training step 15.6 -> 13.6 ms at cfg-2)."""
+        return torch.cuda.stream(self.stream)
+
+    def _join_in(self):
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
+
+    def _join_out(self):
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            cur.wait_stream(self.stream)
+
     # ---- parameters ------------------------------------------------------------------------------
     def set_params(self, params):
         """params: dict name -> array (sqair_amd.params naming) or a flat float32 vector."""
@@ -111,11 +128,11 @@ class SqairCore(object):
 
     def pack(self):
         with torch.cuda.device(self.device):
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._join_in()
             _capi.check(self.handle, self.lib.sqair_pack_params(self.handle, self.flat.data_ptr(),
                                                                 self.packed.data_ptr(), self._stream()),
                         "sqair_pack_params")
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self._join_out()
         self._graph_ready = False
 
     # ---- buffers for a (T, B) shape ----------------------------------------------------------------
@@ -188,7 +205,7 @@ class SqairCore(object):
         """Launches the whole T-frame forward pass + the ELBO reductions on the current stream.  ``train`` keeps the
         tape for the backward pass (larger workspace, allocated on first use)."""
         with torch.cuda.device(self.device):
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._join_in()
             if train:
                 nb = self.lib.sqair_train_workspace_bytes(self.handle, self.T, self.B)
                 if getattr(self, "train_ws", None) is None or self.train_ws.numel() * 4 < nb:
@@ -210,7 +227,7 @@ class SqairCore(object):
                 self.log_weights.data_ptr(), self.elbo_iwae_per_example.data_ptr(),
                 self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.scalars.data_ptr(),
                 self.c_means, len(self.mean_names), self.iw_means.data_ptr(), self._stream()), "sqair_elbo")
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self._join_out()
 
     def backward(self, t_offset=0):
         """Full backward pass after forward(train=True): gradient of the VIMCO target / T w.r.t. every parameter.
@@ -222,13 +239,13 @@ class SqairCore(object):
                 self.bwd_scratch = torch.empty(nb // 4, dtype=torch.float32, device=self.device)
             if getattr(self, "flat_grad", None) is None:
                 self.flat_grad = torch.zeros_like(self.flat)
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._join_in()
             _capi.check(self.handle, self.lib.sqair_backward(
                 self.handle, self.flat.data_ptr(), self.packed.data_ptr(), self.obs.data_ptr(), self.noise.data_ptr(),
                 self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.T, self.B, int(t_offset),
                 self.train_ws.data_ptr(), self.train_ws.numel() * 4, self.bwd_scratch.data_ptr(), nb,
                 self.flat_grad.data_ptr(), self._stream()), "sqair_backward")
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self._join_out()
         return self.flat_grad
 
     def grad_step(self, t_offset=0, use_graph=True):
@@ -255,9 +272,9 @@ class SqairCore(object):
             self._train_graph_ready = True
             self._train_graph_key = (self._shape, int(t_offset))
         with torch.cuda.device(self.device):
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._join_in()
             _capi.check(self.handle, self.lib.sqair_capture_launch(self.handle, 1, self._stream()), "sqair_capture_launch")
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self._join_out()
         return self.flat_grad
 
     def _issue_train(self, t_offset):
@@ -297,13 +314,13 @@ class SqairCore(object):
             scratch = torch.empty(nb // 4, dtype=torch.float32, device=self.device)
             flat_grad = torch.zeros_like(self.flat)
             d_rec = torch.zeros(self.T, M, 64, dtype=torch.float32, device=self.device)
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._join_in()
             _capi.check(self.handle, self.lib.sqair_backward_decoder(
                 self.handle, self.flat.data_ptr(), self.packed.data_ptr(), self.obs.data_ptr(),
                 self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.T, self.B,
                 self.workspace.data_ptr(), self.ws_bytes, scratch.data_ptr(), nb, flat_grad.data_ptr(), d_rec.data_ptr(),
                 self._stream()), "sqair_backward_decoder")
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self._join_out()
             torch.cuda.synchronize(self.device)
         grads = {}
         for name, (o, shape) in self.offsets.items():
@@ -317,10 +334,10 @@ class SqairCore(object):
         sqair_profile_forward in include/sqair_hip.h)."""
         ms, n, fl, empty = C.c_double(), C.c_int(), C.c_double(), C.c_double()
         with torch.cuda.device(self.device):
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._join_in()
             _capi.check(self.handle, self.lib.sqair_profile_forward(*(self._args(t_offset) + (
                 C.byref(ms), C.byref(n), C.byref(fl), C.byref(empty)))), "sqair_profile_forward")
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self._join_out()
         return dict(linear_ms=ms.value, launches=n.value, executed_flops=fl.value, forward_ms_events=empty.value)
 
     def graph_nodes(self):
@@ -355,15 +372,19 @@ class Model(object):
 
     # `sess.run` --------------------------------------------------------------------------------------
     def run(self, noise=None, generator=None, resample_u=None, use_graph=None):
+        """``sess.run`` of the whole output dict: synchronous like its reference counterpart (returns when the results
+        are in the output tensors).  Everything is issued on the core's own stream."""
         core = self.core
         if use_graph is not None:
             self._use_graph = bool(use_graph)
-        if noise is not None:
-            core.noise.copy_(torch.as_tensor(noise, dtype=torch.float32).reshape(core.noise.shape))
-        else:
-            core.draw_noise(generator)
-        core.forward(use_graph=self._use_graph)
-        self._collect(resample_u)
+        with core.on_stream():
+            if noise is not None:
+                core.noise.copy_(torch.as_tensor(noise, dtype=torch.float32).reshape(core.noise.shape))
+            else:
+                core.draw_noise(generator)
+            core.forward(use_graph=self._use_graph)
+            self._collect(resample_u)
+        core.stream.synchronize()
         self._ran = True
         return self
 
@@ -449,19 +470,20 @@ class Model(object):
             if l2_reg != 0.0:
                 target = target + l2_reg * 0.5 * (core.flat ** 2).sum()
             return target, None
-        if not self._ran:
-            core.draw_noise()
-        core.grad_step(use_graph=self._use_graph)
-        if l2_reg != 0.0:
-            with torch.cuda.device(core.device):
+        with core.on_stream():
+            if not self._ran:
+                core.draw_noise()
+            core.grad_step(use_graph=self._use_graph)
+            if l2_reg != 0.0:
                 _capi.check(core.handle, core.lib.sqair_add_l2_grad(
                     core.handle, core.flat.data_ptr(), core.flat_grad.data_ptr(), core.n_params, float(l2_reg),
-                    C.c_void_p(torch.cuda.current_stream(core.device).cuda_stream)), "sqair_add_l2_grad")
-        self._collect()
+                    core._stream()), "sqair_add_l2_grad")
+            self._collect()
+            target = self.vimco_target
+            if l2_reg != 0.0:
+                target = target + l2_reg * 0.5 * (core.flat ** 2).sum()
+        core.stream.synchronize()
         self._ran = True
-        target = self.vimco_target
-        if l2_reg != 0.0:
-            target = target + l2_reg * 0.5 * (core.flat ** 2).sum()
         gvs = [(g, name) for name, g in core.grads_by_name().items()]
         assert len(gvs) == len(core.spec)
         return target, gvs

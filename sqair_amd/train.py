@@ -103,24 +103,25 @@ class Trainer(object):
         self.use_graph = bool(use_graph)
 
     def step(self, obs=None, noise=None, generator=None):
+        """One training step, asynchronous on the core's stream (``core.stream.synchronize()`` or read metrics inside
+        ``core.on_stream()`` to observe results)."""
         import torch
         from . import _capi
         from .dist import allreduce_flat_grads
         core, F = self.core, self.F
-        if obs is not None:
-            core.obs.copy_(torch.as_tensor(obs, dtype=torch.float32).reshape(core.obs.shape))
-        if noise is not None:
-            core.noise.copy_(torch.as_tensor(noise, dtype=torch.float32).reshape(core.noise.shape))
-        else:
-            core.draw_noise(generator)
-        g = core.grad_step(use_graph=self.use_graph)
-        l2 = float(getattr(F, "l2", 0.0))
-        if l2 != 0.0:
-            with torch.cuda.device(core.device):
+        with core.on_stream():
+            if obs is not None:
+                core.obs.copy_(torch.as_tensor(obs, dtype=torch.float32).reshape(core.obs.shape))
+            if noise is not None:
+                core.noise.copy_(torch.as_tensor(noise, dtype=torch.float32).reshape(core.noise.shape))
+            else:
+                core.draw_noise(generator)
+            g = core.grad_step(use_graph=self.use_graph)
+            l2 = float(getattr(F, "l2", 0.0))
+            if l2 != 0.0:
                 _capi.check(core.handle, core.lib.sqair_add_l2_grad(
-                    core.handle, core.flat.data_ptr(), g.data_ptr(), core.n_params, l2,
-                    C.c_void_p(torch.cuda.current_stream(core.device).cuda_stream)), "sqair_add_l2_grad")
-        allreduce_flat_grads(g)
-        self.opt.apply_gradients(g, learning_rate(F, self.step_no))
+                    core.handle, core.flat.data_ptr(), g.data_ptr(), core.n_params, l2, core._stream()), "sqair_add_l2_grad")
+            allreduce_flat_grads(g)
+            self.opt.apply_gradients(g, learning_rate(F, self.step_no))
         self.step_no += 1
         return g

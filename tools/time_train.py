@@ -1,0 +1,28 @@
+"""Quick A/B timer: gradient evaluation (one HIP-graph replay) and inference forward at BASELINE configs[1]."""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np, torch
+from sqair_amd.data import config_inputs
+from sqair_amd.flags import make_flags
+from sqair_amd.model import Model, SqairCore
+from tests.hip_util import params32
+ov, obs, _, _ = config_inputs(2)
+F = make_flags(**ov)
+hw = obs.shape[2:4]
+core = SqairCore(F, hw)
+core.set_params(params32(F, hw, 1, 0.02, obs.mean((0, 1))))
+Model(obs, None, core, int(F.k_particles), outputs="minimal")
+gen = torch.Generator(device="cuda").manual_seed(0)
+core.draw_noise(gen)
+for name, fn in (("grad_step", lambda: core.grad_step(use_graph=True)), ("forward", lambda: core.forward(use_graph=True))):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / 20 * 1e3)
+    print("%s: min %.3f ms  median %.3f ms  (%d x 20 replays) first %.3f last %.3f" % (name, min(ts), float(np.median(ts)), len(ts), ts[0], ts[-1]))
