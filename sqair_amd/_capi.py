@@ -114,6 +114,9 @@ def lib():
             raise ImportError(
                 "libsqair_hip.so is missing ({}): build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `python sqair_amd/csrc/build.py`; sqair_amd has no CPU fallback".format(LIB_PATH))
+        # torch first: its wheel bundles its own HIP runtime; loading ours before it would put two runtimes into the
+        # process (the second one then reports "no ROCm-capable device")
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)
