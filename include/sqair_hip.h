@@ -237,6 +237,17 @@ int sqair_backward(SqairHandle* h, const float* flat_params, const void* packed,
                    const float* importance_weights, const float* vimco_signal, int T, int B, int t_offset,
                    void* train_workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
                    float* flat_grad, void* stream);
+/* XCD-persistent forward pass: same arguments and results as sqair_forward; the frame loop runs as ONE launch in which
+ * every XCD owns a group of particle rows for the whole pass (rows never interact: SequentialAIR's loop body is per-row,
+ * sqair/seq.py:69-279) and layers are separated by per-XCD arrival counters instead of kernel boundaries.  `program` is
+ * caller-owned device memory of sqair_program_bytes(h, T, B) bytes holding the op list and the counters; the list is
+ * rebuilt (one synchronous upload) when a pointer / shape argument changes.  sqair_persistent_status: 0 = the last pass
+ * completed, 1 = a team barrier timed out (results invalid; every spin is bounded). */
+int64_t sqair_program_bytes(const SqairHandle* h, int T, int B);
+int sqair_forward_persistent(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
+                             const float* noise, int T, int B, int t_offset, const SqairOutputs* out, void* workspace,
+                             int64_t workspace_bytes, void* program, int64_t program_bytes, void* stream);
+int sqair_persistent_status(SqairHandle* h, const void* program, void* stream);
 /* Graph capture of any sequence of the calls above on one stream (the training step up to the gradient all-reduce
  * is ~3000 short dependent launches): _begin, issue the calls, _end(slot 0..3) -> node count (>= 0) or error (< 0);
  * _launch replays the slot.  Captured calls keep the pointers they were given. */

@@ -87,6 +87,11 @@ _PROTOS = {
     "sqair_backward_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
     "sqair_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                  C.c_void_p, C.c_void_p]),
+    "sqair_program_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    "sqair_forward_persistent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_int, C.POINTER(SqairOutputs), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                           C.c_void_p]),
+    "sqair_persistent_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "sqair_capture_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sqair_capture_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "sqair_capture_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

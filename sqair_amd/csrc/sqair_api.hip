@@ -604,6 +604,16 @@ int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipSt
   l.a.bias = packed + pl.b + L.b_off;
   l.a.M = M;
   l.a.N = L.N;
+  if (h->rec != nullptr) {  // XCD-persistent path: the op is recorded, the persistent kernel executes it
+    XOp op;
+    op.type = XOP_LINEAR; op.kc = L.kc; op.nt = L.nt; op.sync_after = 1;
+    op.u.lin = l.a;
+    auto rmul_of = [](int rdiv) { return rdiv <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)rdiv) + 1u; };
+    for (int i = 0; i < op.u.lin.nseg; ++i) op.u.lin.seg[i].rmul = rmul_of(op.u.lin.seg[i].rdiv);
+    op.u.lin.add_rmul = rmul_of(op.u.lin.add_rdiv);
+    h->rec->push_back(op);
+    return 0;
+  }
   if (h->prof && h->prof_n < PROF_MAX) {
     int ksum = 0;
     for (int w : L.seg_width) ksum += w;
@@ -617,9 +627,36 @@ int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipSt
   return rc;
 }
 
+static int emit_crop(SqairHandle* h, const CropArgs& ca, POff po, Dims d, int nslots, hipStream_t s) {
+  if (h->rec == nullptr) return sq_launch_crop(ca, po, d, nslots, s);
+  XOp op; op.type = XOP_CROP; op.nslots = nslots; op.sync_after = 1; op.u.crop = ca;
+  h->rec->push_back(op);
+  return 0;
+}
+static int emit_tail(SqairHandle* h, const TailArgs& ta, Dims d, hipStream_t s) {
+  if (h->rec == nullptr) return sq_launch_slot_tail(ta, d, s);
+  XOp op; op.type = XOP_TAIL; op.sync_after = 1; op.u.tail = ta;
+  h->rec->push_back(op);
+  return 0;
+}
+static int emit_latsum(SqairHandle* h, const float* f, const float* rec_p, float* c, Dims d, hipStream_t s) {
+  if (h->rec == nullptr) return sq_launch_latent_sum(f, rec_p, c, d, s);
+  XOp op; op.type = XOP_LATSUM; op.sync_after = 1; op.u.lat = XLatArgs{f, rec_p, c};
+  h->rec->push_back(op);
+  return 0;
+}
+static int emit_compact(SqairHandle* h, const CompactArgs& ka, POff po, Dims d, hipStream_t s) {
+  if (h->rec == nullptr) return sq_launch_compact(ka, po, d, s);
+  XOp op; op.type = XOP_COMPACT; op.sync_after = 1; op.u.comp = ka;
+  h->rec->push_back(op);
+  return 0;
+}
+
+// parts: 1 = prologue (workspace clear, initial state, input encoder), 2 = the frame loop, 4 = epilogue (log-probabilities,
+// decoder, final state copies).  The XCD-persistent path runs 1 and 4 as launches and RECORDS 2 (h->rec) for its kernel.
 int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, const float* obs, const float* noise,
                     int T, int B, int t_offset, const SqairOutputs* outp, float* wsbase, int64_t ws_bytes,
-                    hipStream_t s, bool train) {
+                    hipStream_t s, bool train, int parts) {
   const SqairConfig& c = h->cfg;
   if (!flat || !packed || !obs || !noise || !outp || !wsbase || T < 1 || B < 1) {
     sq_set_error(h, "sqair_forward: null argument or bad T/B");
@@ -644,6 +681,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   // The GEMM A-operand contract wants every float it may touch to be finite (padding meets zero weights, but
   // 0 * NaN = NaN) and slot records are read as 56-wide segments before all their fields are written in a frame:
   // clear the caller's (garbage) workspace once per pass
+  if (parts & 1) {
   sq_zero_fill(wsbase, (int64_t)((float*)w.prof_ts - wsbase), s);
   // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
   sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0), w.state(w.prior_m, 0), w.last_id[0], w.disc_init_rec,
@@ -654,8 +692,9 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     Lin b; b.seg(w.ienc_a, nh, nh).out(w.ienc_b, nh).act(ACT_ELU); RUN(b, L_IENC1, T * B);
     Lin p; p.seg(w.ienc_b, nh, nh).out(w.pre_disc, nh); RUN(p, L_PREDISC, T * B);
   }
+  }
 
-  for (int t = 0; t < T; ++t) {
+  for (int t = 0; (parts & 2) && t < T; ++t) {
     const int pp = t & 1, pn = pp ^ 1;
     const float* img = obs + (size_t)t * B * P_;
     const float* nz = noise + (size_t)t * R * 2 * N * nzw;
@@ -703,7 +742,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
       CropArgs ca; memset(&ca, 0, sizeof(ca));
       ca.mode = CROP_PROP1; ca.img = img; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N;
       ca.out = g1; ca.out_row_mul = N; ca.rec_prev = rec_prev; ca.wb = wb; ca.wb_ld = WB_LD; ca.flat = flat;
-      sq_launch_crop(ca, po, d, N, s);
+      emit_crop(h, ca, po, d, N, s);
       Lin a; a.seg(g1, G2, G2).out(pea, nh).act(ACT_ELU); RUN(a, L_GENC0, M);
       Lin b; b.seg(pea, nh, nh).out(peb, nh).act(ACT_ELU); RUN(b, L_GENC1, M);
       Lin l; l.seg(peb, nh, nh).out(m1, M1_LD); RUN(l, L_WHAT_LOC, M);
@@ -746,7 +785,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         ca.mask_row_add = k; ca.out = g2; ca.out_row_mul = train ? N : 1; ca.rec_prev = rec_prev; ca.rec_new = rec_p_t;
         ca.t2 = t2; ca.t2_ld = rl; ca.w3 = w.w3_prop; ca.noise = nz; ca.flat = flat; ca.slot = k;
         if (train) { ca.tp_out = w.slot(w.tp, TP_LD, t, 0, k); ca.tp_out_ld = w.sld(TP_LD); }
-        sq_launch_crop(ca, po, d, 1, s);
+        emit_crop(h, ca, po, d, 1, s);
       }
       {
         Lin a; a.seg(g2, gl2, G2).out(e1, rl).act(ACT_ELU); RUN(a, L_GENC0, R);
@@ -773,14 +812,14 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         ta.wp = packed + pl.w + h->layers[L_PROP_S1].w_off; ta.flat = flat;
         ta.w2_off = po.prop_steps_l1_w; ta.b2_off = po.prop_steps_l1_b;
         if (train) { ta.s1h_out = w.slot(w.s1h, S1_LD, t, 0, k); ta.s1h_ld = w.sld(S1_LD); }
-        sq_launch_slot_tail(ta, d, s);
+        emit_tail(h, ta, d, s);
       }
     }
     // ---- F. summary of propagated latents -> discovery conditioning (sqair_modules.py:368-385, :501) ----
     {
       Lin a; a.seg(rec_p_t, RW, rec::ZW).out(lea, nh).act(ACT_ELU); RUN(a, L_LAT0, M);
       Lin b; b.seg(lea, nh, nh).out(leb, nh).act(ACT_ELU); RUN(b, L_LAT1, M);
-      sq_launch_latent_sum(leb, rec_p_t, cvec, d, s);
+      emit_latsum(h, leb, rec_p_t, cvec, d, s);
       Lin p; p.seg(cvec, nh, nh).add(w.pre_disc + (size_t)t * B * nh, nh, nh, K).out(w.pre_d, nh); RUN(p, L_PRED, R);
       if (c.rec_where_prior) {
         Lin q; q.seg(w.rn_init_state, 0, 4).seg(cvec, nh, nh).out(spre_t, 128); RUN(q, L_RNCOND, R);
@@ -810,7 +849,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         ca.mode = CROP_DISC; ca.img = img; ca.out = g2; ca.out_row_mul = train ? N : 1; ca.rec_new = rec_d_t; ca.t2 = t2;
         ca.t2_ld = rl; ca.w3 = w.w3_disc; ca.noise = nz; ca.flat = flat; ca.slot = j;
         if (train) { ca.tp_out = w.slot(w.tp, TP_LD, t, 1, j); ca.tp_out_ld = w.sld(TP_LD); }
-        sq_launch_crop(ca, po, d, 1, s);
+        emit_crop(h, ca, po, d, 1, s);
         Lin a; a.seg(g2, gl2, G2).out(e1, rl).act(ACT_ELU); RUN(a, L_GENC0, R);
         Lin b; b.seg(e1, rl, nh).out(e2, rl).act(ACT_ELU); RUN(b, L_GENC1, R);
         Lin e; e.seg(e2, rl, nh).out(enc, el).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
@@ -822,7 +861,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         ta.wp = packed + pl.w + h->layers[L_DISC_S1].w_off; ta.flat = flat;
         ta.w2_off = po.disc_steps_l1_w; ta.b2_off = po.disc_steps_l1_b;
         if (train) { ta.s1h_out = w.slot(w.s1h, S1_LD, t, 1, j); ta.s1h_ld = w.sld(S1_LD); }
-        sq_launch_slot_tail(ta, d, s);
+        emit_tail(h, ta, d, s);
       }
     }
     // ---- I. merge / compaction (the log-probabilities H and the decoder J are off the recurrence's critical path:
@@ -834,9 +873,10 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
       ka.rec_next = rec_next; ka.temporal_next = w.state(w.temporal_m, t + 1); ka.prior_next = w.state(w.prior_m, t + 1);
       ka.flat = flat; ka.t = t; ka.out = out;
       ka.src_out = train ? w.src + (size_t)t * M : nullptr;
-      sq_launch_compact(ka, po, d, s);
+      emit_compact(h, ka, po, d, s);
     }
   }
+  if (!(parts & 4)) return 0;
   // ---- H. log-probabilities of all T frames in one launch (grid R x T) ----
   {
     LogprobArgs la; memset(&la, 0, sizeof(la));
@@ -874,7 +914,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
 static int forward_impl(SqairHandle* h, const float* flat, const float* packed, const float* obs, const float* noise,
                         int T, int B, int t_offset, const SqairOutputs* outp, float* wsbase, int64_t ws_bytes,
                         hipStream_t s) {
-  return sq_forward_impl(h, flat, packed, obs, noise, T, B, t_offset, outp, wsbase, ws_bytes, s, false);
+  return sq_forward_impl(h, flat, packed, obs, noise, T, B, t_offset, outp, wsbase, ws_bytes, s, false, 7);
 }
 
 // Training-mode forward pass: identical launch sequence and results, but every intermediate the backward pass needs
@@ -884,7 +924,98 @@ extern "C" int sqair_forward_train(SqairHandle* h, const float* flat_params, con
                                    void* workspace, int64_t workspace_bytes, void* stream) {
   if (!h) return -1;
   return sq_forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
-                         workspace_bytes, (hipStream_t)stream, true);
+                         workspace_bytes, (hipStream_t)stream, true, 7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// XCD-persistent forward pass (sqair_persist.hip): same results as sqair_forward, the frame loop as ONE launch.
+// `program` is caller-owned device memory (sqair_program_bytes) that holds the recorded op list and the team
+// counters; the list is rebuilt (one synchronous upload) whenever any pointer / shape argument changes.
+// ------------------------------------------------------------------------------------------------
+extern "C" int64_t sqair_program_bytes(const SqairHandle* h, int T, int B) {
+  if (!h || T < 1 || B < 1) return -1;
+  const int64_t per_frame = 64 + 32 * (int64_t)h->cfg.n_steps_per_image;
+  return (int64_t)T * per_frame * (int64_t)sizeof(XOp) + XSYNC_WORDS * 4 + 256;
+}
+
+extern "C" int sqair_forward_persistent(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
+                                        const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
+                                        void* workspace, int64_t workspace_bytes, void* program, int64_t program_bytes,
+                                        void* stream) {
+  if (!h || !out || !program) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  if (program_bytes < sqair_program_bytes(h, T, B)) {
+    sq_set_error(h, "sqair_forward_persistent: program buffer too small");
+    return -1;
+  }
+  const SqairConfig& c = h->cfg;
+  const int R = B * c.k_particles;
+  Dims d{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles, R, B, 4 + c.n_what + 1};
+  unsigned* sync = (unsigned*)program;
+  XOp* prog_dev = (XOp*)((char*)program + XSYNC_WORDS * 4 + (256 - (XSYNC_WORDS * 4) % 256) % 256);
+  // key of the cached program: every argument that is baked into the ops
+  std::vector<uint64_t> key = {(uint64_t)flat_params, (uint64_t)packed, (uint64_t)obs, (uint64_t)noise, (uint64_t)T, (uint64_t)B,
+                               (uint64_t)t_offset, (uint64_t)workspace, (uint64_t)program};
+  const void* const* op = (const void* const*)out;
+  for (size_t i = 0; i < sizeof(SqairOutputs) / sizeof(void*); ++i) key.push_back((uint64_t)op[i]);
+  if (key != h->xprog_key) {
+    h->xprog.clear();
+    h->rec = &h->xprog;
+    const int rc = sq_forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
+                                   workspace_bytes, s, false, 2);
+    h->rec = nullptr;
+    if (rc != 0) return rc;
+    if ((int64_t)h->xprog.size() * (int64_t)sizeof(XOp) + XSYNC_WORDS * 4 + 256 > program_bytes) {
+      sq_set_error(h, "sqair_forward_persistent: op list larger than the program buffer");
+      return -1;
+    }
+    SQ_CHECK_HIP(hipMemcpyAsync(prog_dev, h->xprog.data(), h->xprog.size() * sizeof(XOp), hipMemcpyHostToDevice, s));
+    SQ_CHECK_HIP(hipStreamSynchronize(s));
+    h->xprog_key = key;
+    if (h->n_cu == 0) {
+      int dev = 0;
+      SQ_CHECK_HIP(hipGetDevice(&dev));
+      SQ_CHECK_HIP(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+  }
+  int rc = sq_forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
+                           workspace_bytes, s, false, 1);
+  if (rc != 0) return rc;
+  sq_zero_fill((float*)sync, XSYNC_WORDS, s);
+  const char* xdump = getenv("SQAIR_XPROF_DUMP");  // per-op device-clock stamps of (first team, rank 0), CSV
+  unsigned long long* tst = nullptr;
+  if (xdump != nullptr) {
+    const Workspace wx = sq_carve(h, T, B, (float*)workspace, false);
+    tst = wx.prof_ts;  // 5 * PROF_MAX * 2 floats = 5 * PROF_MAX 64-bit words
+    if (2 * h->xprog.size() > 5 * (size_t)PROF_MAX) tst = nullptr;
+  }
+  sq_launch_persistent(prog_dev, (int)h->xprog.size(), h->po, d, sync, h->n_cu, s, tst);
+  if (tst != nullptr) {
+    std::vector<unsigned long long> hts(2 * h->xprog.size());
+    SQ_CHECK_HIP(hipMemcpyAsync(hts.data(), tst, hts.size() * 8, hipMemcpyDeviceToHost, s));
+    SQ_CHECK_HIP(hipStreamSynchronize(s));
+    FILE* f = fopen(xdump, "w");
+    if (f) {
+      fprintf(f, "op,type,kc,nt,M,start_ticks,end_ticks\n");
+      for (size_t i = 0; i < h->xprog.size(); ++i)
+        fprintf(f, "%zu,%d,%d,%d,%d,%llu,%llu\n", i, h->xprog[i].type, h->xprog[i].kc, h->xprog[i].nt,
+                h->xprog[i].type == XOP_LINEAR ? h->xprog[i].u.lin.M : 0, hts[2 * i] - hts[0], hts[2 * i + 1] - hts[0]);
+      fclose(f);
+    }
+  }
+  rc = sq_forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
+                       workspace_bytes, s, false, 4);
+  if (rc != 0) return rc;
+  SQ_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+// 0 = the last persistent pass completed; 1 = a team barrier timed out (results invalid)
+extern "C" int sqair_persistent_status(SqairHandle* h, const void* program, void* stream) {
+  if (!h || !program) return -1;
+  unsigned word = 0;
+  SQ_CHECK_HIP(hipMemcpyAsync(&word, (const unsigned*)program + 17, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  SQ_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return word != 0 ? 1 : 0;
 }
 
 extern "C" int sqair_forward(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,

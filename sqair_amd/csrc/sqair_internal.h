@@ -5,6 +5,7 @@
 #include <map>
 
 #include "sqair_glue.h"
+#include "sqair_persist.h"
 
 struct ParamEntry {
   std::string name;
@@ -50,6 +51,11 @@ struct SqairHandle {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int graph_nodes = 0;
+  // XCD-persistent forward: op recording (sq_forward_impl emits into `rec` instead of launching) + cached program
+  std::vector<XOp>* rec = nullptr;
+  std::vector<XOp> xprog;
+  std::vector<uint64_t> xprog_key;
+  int n_cu = 0;
   // generic capture slots (sqair_capture_begin / _end / _launch): any sequence of C-ABI calls as one HIP graph
   hipGraph_t cap_graph[4] = {nullptr, nullptr, nullptr, nullptr};
   hipGraphExec_t cap_exec[4] = {nullptr, nullptr, nullptr, nullptr};

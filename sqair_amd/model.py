@@ -189,6 +189,7 @@ class SqairCore(object):
         self._train_graph_ready = False
         self.train_ws = None
         self.bwd_scratch = None
+        self.program = None
 
     def draw_noise(self, generator=None):
         """eps ~ N(0,1) for the Normals, u ~ U[0,1) for the presence Bernoullis, on device."""
@@ -201,12 +202,19 @@ class SqairCore(object):
                 self.noise.data_ptr(), self.T, self.B, int(t_offset), C.byref(self.c_out),
                 self.workspace.data_ptr(), self.ws_bytes, self._stream())
 
-    def forward(self, t_offset=0, use_graph=False, train=False):
+    def forward(self, t_offset=0, use_graph=False, train=False, persistent=False):
         """Launches the whole T-frame forward pass + the ELBO reductions on the current stream.  ``train`` keeps the
-        tape for the backward pass (larger workspace, allocated on first use)."""
+        tape for the backward pass (larger workspace, allocated on first use).  ``persistent``: the frame loop as one
+        XCD-persistent launch (sqair_forward_persistent) instead of ~94 launches per frame."""
         with torch.cuda.device(self.device):
             self._join_in()
-            if train:
+            if persistent and not train:
+                nb = self.lib.sqair_program_bytes(self.handle, self.T, self.B)
+                if getattr(self, "program", None) is None or self.program.numel() * 4 < nb:
+                    self.program = torch.zeros((nb + 3) // 4, dtype=torch.float32, device=self.device)
+                _capi.check(self.handle, self.lib.sqair_forward_persistent(
+                    *(self._args(t_offset)[:-1] + (self.program.data_ptr(), nb, self._stream()))), "sqair_forward_persistent")
+            elif train:
                 nb = self.lib.sqair_train_workspace_bytes(self.handle, self.T, self.B)
                 if getattr(self, "train_ws", None) is None or self.train_ws.numel() * 4 < nb:
                     self.train_ws = torch.empty(nb // 4, dtype=torch.float32, device=self.device)
@@ -342,6 +350,10 @@ class SqairCore(object):
 
     def graph_nodes(self):
         return self.lib.sqair_graph_nodes(self.handle)
+
+    def persistent_status(self):
+        """0 after a completed persistent pass, 1 if a team barrier timed out (synchronises the stream)."""
+        return self.lib.sqair_persistent_status(self.handle, self.program.data_ptr(), self._stream())
 
 
 class Model(object):

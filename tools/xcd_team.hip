@@ -1,0 +1,241 @@
+// Microbenchmark for the XCD-persistent execution idea: rows of the SQAIR pass never interact,
+// so each XCD can own a row group for a whole chain of dependent dense layers and hand activations over through its
+// OWN L2 (plain stores, L1-bypassing sc1 loads, one per-XCD arrival counter) instead of a device-wide kernel boundary.
+// Chain: X <- tanh(X W_l) for `phases` dependent layers, 32 rows per XCD team, K = N = 256 (16 KB weight tile per task).
+// Compared against the same chain as one launch per layer (graph replay) for time, and element by element for
+// correctness (a stale read anywhere in the chain changes the result).
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/xcd_team tools/xcd_team.hip && /tmp/xcd_team
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+constexpr int ROWS = 32, KD = 256, ND = 256, TASKS = (ROWS / 16) * (ND / 16);
+
+__device__ __forceinline__ f32x4 load_sc1(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// one 16x16 output tile: 4 waves split K, LDS reduce.  `use_sc1`: A operand with L1-bypassing loads.
+template <bool SC1>
+__device__ __forceinline__ void tile(const float* __restrict__ in, const float* __restrict__ Wp, float* __restrict__ out, int rt,
+                                     int nt, float* red) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
+  const float* rp = in + (size_t)(rt * 16 + (lane & 15)) * KD;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + ((size_t)nt * 16) * 64 + lane;
+  f32x4 av[4], bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = wave + 4 * j;
+    if (SC1) av[j] = load_sc1(rp + g * 16 + kq * 4);
+    else av[j] = *reinterpret_cast<const f32x4*>(rp + g * 16 + kq * 4);
+    bv[j] = wp[(size_t)g * 64];
+  }
+  if (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc, 0, 0, 0);
+  }
+  float* r = red + wave * 256;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[(4 * kq + i) * 16 + (lane & 15)] = acc[i];
+  __syncthreads();
+  const float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+  out[(size_t)(rt * 16 + (tid >> 4)) * ND + nt * 16 + (tid & 15)] = tanhf(v);
+  __syncthreads();
+}
+
+// launch-per-layer version: grid = 8 teams x TASKS
+__global__ __launch_bounds__(256) void k_layer(const float* X, const float* W, float* Y) {
+  __shared__ float red[1024];
+  const int team = blockIdx.x / TASKS, task = blockIdx.x % TASKS;
+  tile<false>(X + (size_t)team * ROWS * KD, W, Y + (size_t)team * ROWS * ND, task / 16, task % 16, red);
+}
+
+__global__ __launch_bounds__(256) void k_team(float* X, const float* W, int phases, int nlayers, unsigned* team_count,
+                                              unsigned* gcount, unsigned* bar, int* xcc_of_block) {
+  extern __shared__ float lds[];  // > 80 KB requested: one workgroup per CU
+  float* red = lds;
+  __shared__ unsigned s_rank, s_size, s_xcc;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    x &= 0xf;
+    s_xcc = x;
+    s_rank = atomicAdd(&team_count[x], 1u);
+    __hip_atomic_fetch_add(gcount, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(gcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spin) __builtin_amdgcn_s_sleep(2);
+    s_size = __hip_atomic_load(&team_count[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xcc_of_block[blockIdx.x] = (int)x;
+  }
+  __syncthreads();
+  const unsigned rank = s_rank, size = s_size, xcc = s_xcc;
+  unsigned* mybar = bar + xcc * 64;
+  for (int ph = 0; ph < phases; ++ph) {
+    const float* in = X + ((size_t)(ph & 1) * 8 + xcc) * ROWS * KD;
+    float* out = X + ((size_t)((ph + 1) & 1) * 8 + xcc) * ROWS * ND;
+    const float* Wl = W + (size_t)(ph % nlayers) * KD * ND;
+    for (unsigned task = rank; task < (unsigned)TASKS; task += size) tile<true>(in, Wl, out, task / 16, task % 16, red);
+    // team barrier: stores drained to L2, one arrival per workgroup on the XCD's counter, sc1 poll
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(mybar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)(ph + 1) * size;
+      for (int spin = 0; spin < (1 << 20) && __hip_atomic_load(mybar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(1);  // bounded: never hang the box
+    }
+    __syncthreads();
+  }
+}
+
+// variant: one task per workgroup, the NEXT layer's weight fragments are requested before the team barrier (they do not
+// depend on it), so after the barrier only the activation loads (same-XCD L2) stand before the MFMAs
+__global__ __launch_bounds__(256) void k_team_pf(float* X, const float* W, int phases, int nlayers, unsigned* team_count,
+                                                 unsigned* gcount, unsigned* bar) {
+  extern __shared__ float lds[];
+  float* red = lds;
+  __shared__ unsigned s_rank, s_size, s_xcc;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
+  if (tid == 0) {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    x &= 0xf;
+    s_xcc = x;
+    s_rank = atomicAdd(&team_count[x], 1u);
+    __hip_atomic_fetch_add(gcount, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(gcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spin) __builtin_amdgcn_s_sleep(2);
+    s_size = __hip_atomic_load(&team_count[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const unsigned rank = s_rank, size = s_size, xcc = s_xcc;
+  if (size != (unsigned)TASKS) return;  // this variant assumes exactly one task per workgroup
+  unsigned* mybar = bar + xcc * 64;
+  const int rt = rank / 16, nt = rank % 16;
+  f32x4 bv[4];
+  {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(W) + ((size_t)nt * 16) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = wp[(size_t)(wave + 4 * j) * 64];
+  }
+  for (int ph = 0; ph < phases; ++ph) {
+    const float* in = X + ((size_t)(ph & 1) * 8 + xcc) * ROWS * KD;
+    float* out = X + ((size_t)((ph + 1) & 1) * 8 + xcc) * ROWS * ND;
+    const float* rp = in + (size_t)(rt * 16 + (lane & 15)) * KD;
+    f32x4 av[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) av[j] = load_sc1(rp + (wave + 4 * j) * 16 + kq * 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc, 0, 0, 0);
+    }
+    // next layer's weights: requested now, consumed after the barrier
+    {
+      const f32x4* wp = reinterpret_cast<const f32x4*>(W + (size_t)((ph + 1) % nlayers) * KD * ND) + ((size_t)nt * 16) * 64 + lane;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = wp[(size_t)(wave + 4 * j) * 64];
+    }
+    float* r = red + wave * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[(4 * kq + i) * 16 + (lane & 15)] = acc[i];
+    __syncthreads();
+    const float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+    out[(size_t)(rt * 16 + (tid >> 4)) * ND + nt * 16 + (tid & 15)] = tanhf(v);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (also lands the prefetched weights: they are L2/MALL hits by then)
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(mybar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)(ph + 1) * size;
+      for (int spin = 0; spin < (1 << 20) && __hip_atomic_load(mybar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+  }
+}
+
+int main() {
+  const int nlayers = 24, phases = 2000;
+  std::vector<float> hW((size_t)nlayers * KD * ND), hX((size_t)2 * 8 * ROWS * KD, 0.0f);
+  srand(1);
+  // packed layout [nt][kc][64][4]; values +-U/8 keep tanh in its interesting range
+  for (auto& v : hW) v = ((float)rand() / RAND_MAX - 0.5f) * 0.25f;
+  for (size_t i = 0; i < (size_t)8 * ROWS * KD; ++i) hX[i] = (float)rand() / RAND_MAX - 0.5f;
+  float *dW, *dX, *dA, *dB;
+  unsigned *team_count, *gcount, *bar;
+  int* xcc_of_block;
+  CK(hipMalloc(&dW, hW.size() * 4)); CK(hipMalloc(&dX, hX.size() * 4));
+  CK(hipMalloc(&dA, (size_t)8 * ROWS * KD * 4)); CK(hipMalloc(&dB, (size_t)8 * ROWS * KD * 4));
+  CK(hipMalloc(&team_count, 64)); CK(hipMalloc(&gcount, 64)); CK(hipMalloc(&bar, 8 * 64 * 4)); CK(hipMalloc(&xcc_of_block, 256 * 4));
+  CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+  hipStream_t s; CK(hipStreamCreate(&s));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  // ---- reference: one launch per layer, graph replay
+  CK(hipMemcpy(dA, hX.data(), (size_t)8 * ROWS * KD * 4, hipMemcpyHostToDevice));
+  hipGraph_t g; hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  for (int ph = 0; ph < phases; ++ph)
+    hipLaunchKernelGGL(k_layer, dim3(8 * TASKS), dim3(256), 0, s, (ph & 1) ? dB : dA, dW + (size_t)(ph % nlayers) * KD * ND, (ph & 1) ? dA : dB);
+  CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+  std::vector<float> ref((size_t)8 * ROWS * KD);
+  CK(hipMemcpy(ref.data(), (phases & 1) ? dB : dA, ref.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(dA, hX.data(), (size_t)8 * ROWS * KD * 4, hipMemcpyHostToDevice));
+  CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+  float ms_ref; CK(hipEventElapsedTime(&ms_ref, e0, e1));
+  // ---- persistent, XCD teams
+  const size_t shm = 96 * 1024;
+  CK(hipFuncSetAttribute((const void*)k_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  float ms_team = 0;
+  std::vector<float> got(ref.size());
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipMemcpy(dX, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(team_count, 0, 64)); CK(hipMemset(gcount, 0, 64)); CK(hipMemset(bar, 0, 8 * 64 * 4));
+    CK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(k_team, dim3(256), dim3(256), shm, s, dX, dW, phases, nlayers, team_count, gcount, bar, xcc_of_block);
+    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+    CK(hipEventElapsedTime(&ms_team, e0, e1));
+  }
+  CK(hipMemcpy(got.data(), dX + (size_t)(phases & 1) * 8 * ROWS * KD, got.size() * 4, hipMemcpyDeviceToHost));
+  // ---- prefetching variant
+  CK(hipFuncSetAttribute((const void*)k_team_pf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  float ms_pf = 0;
+  std::vector<float> got2(ref.size());
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipMemcpy(dX, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(team_count, 0, 64)); CK(hipMemset(gcount, 0, 64)); CK(hipMemset(bar, 0, 8 * 64 * 4));
+    CK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(k_team_pf, dim3(256), dim3(256), shm, s, dX, dW, phases, nlayers, team_count, gcount, bar);
+    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+    CK(hipEventElapsedTime(&ms_pf, e0, e1));
+  }
+  CK(hipMemcpy(got2.data(), dX + (size_t)(phases & 1) * 8 * ROWS * KD, got2.size() * 4, hipMemcpyDeviceToHost));
+  double maxerr2 = 0; size_t bad2 = 0;
+  for (size_t i = 0; i < ref.size(); ++i) { double e = fabs((double)ref[i] - got2[i]); if (e > maxerr2) maxerr2 = e; if (e > 1e-5) ++bad2; }
+  unsigned tc[16]; CK(hipMemcpy(tc, team_count, 64, hipMemcpyDeviceToHost));
+  int hx[256]; CK(hipMemcpy(hx, xcc_of_block, 1024, hipMemcpyDeviceToHost));
+  int modok = 0; for (int b = 0; b < 256; ++b) modok += hx[b] == b % 8;
+  // the team owning region t is the XCD with id t; reference team index = region index: same data per region
+  double maxerr = 0; size_t bad = 0;
+  for (size_t i = 0; i < ref.size(); ++i) { double e = fabs((double)ref[i] - got[i]); if (e > maxerr) maxerr = e; if (e > 1e-5) ++bad; }
+  printf("team sizes:"); for (int i = 0; i < 8; ++i) printf(" %u", tc[i]); printf("   blocks with xcc == b %% 8: %d / 256\n", modok);
+  printf("launch-per-layer (graph): %.3f ms = %.2f us/layer\n", ms_ref, ms_ref * 1e3 / phases);
+  printf("XCD-persistent teams    : %.3f ms = %.2f us/layer   max |diff| %.3g, mismatching %zu / %zu\n", ms_team, ms_team * 1e3 / phases,
+         maxerr, bad, ref.size());
+  printf("  + weight prefetch     : %.3f ms = %.2f us/layer   max |diff| %.3g, mismatching %zu / %zu\n", ms_pf, ms_pf * 1e3 / phases, maxerr2,
+         bad2, ref.size());
+  return 0;
+}
