@@ -52,12 +52,6 @@ int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float*
                          int w3p_off, int w3d_off, const float* flat,
                          POff po, Dims d, hipStream_t s);
 int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s);
-int sq_launch_what_disc(const float* enc, int enc_ld, const float* noise, float* rec_d, int slot, Dims d,
-                        hipStream_t s);
-int sq_launch_what_prop(const float* hraw, int h_ld, const float* enc, int enc_ld, const float* rec_prev,
-                        const float* noise, float* rec_p, int slot, Dims d, hipStream_t s);
-int sq_launch_steps(const float* s1, int s1_ld, const float* flat, int w_off, int b_off, const float* rec_prev,
-                    float* rec_new, const float* noise, int slot, int is_disc, Dims d, hipStream_t s);
 // Tail of a propagation / discovery slot in one launch: what-sample, the what-dependent part of the steps
 // predictor's hidden layer (small MFMA, K = 56), its output layer (dot with w2) and the presence Bernoulli.
 struct TailArgs {

@@ -2,6 +2,7 @@
 // log-probabilities with the presence mask applied in-kernel, slot compaction and the IWAE / VIMCO
 // reductions.  All HBM-bound gather / scatter / reduce work (class 2).
 #include "sqair_glue.h"
+#include "sqair_rowops.h"
 
 // ------------------------------------------------------------------------------------------------
 // initial recurrent state (reference: sqair/seq.py:86-100, sqair_modules.py:352-366, core.py:156-162)
@@ -51,301 +52,16 @@ int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float*
 // the propagation / discovery core is drawn in the same launch (core.py:323-334, :217-227).
 // ------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_crop(const CropArgs a, const POff po, const Dims d) {
+// one workgroup per particle row (a per-sequence kernel staging the frame in LDS for its K particles had only B = 32
+// workgroups at the headline config and measured 10.3 us; this one 5-6 us with the frame served by L1 / L2)
+__global__ __launch_bounds__(256) void k_crop_row(const CropArgs a, const POff po, const Dims d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* img_s = smem;                       // H*W
-  float* coord_s = smem + d.H * d.W;         // K * 4 (sx, sy, tx, ty)
-  float* tab_s = coord_s + d.K * 4;          // K * 2G * 2 : per particle x0f,wx per column ; y0f,wy per row
-  const int b = blockIdx.x;
-  const int slot = (a.mode == CROP_PROP1) ? (int)blockIdx.y : a.slot;
-  const int tid = threadIdx.x;
-  const int P = d.H * d.W;
-  const int G = d.G, G2 = d.G * d.G;
-  const int mrow_add = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
-  const int orow_add = a.out_row_add + (a.mode == CROP_PROP1 ? slot : 0);
-
-  // ---- stage the frame in LDS (one HBM read of the frame for all K particles); the mask values of this
-  // thread's pixels are requested in the same burst (unconditional, clamped loads: a guarded load makes hipcc
-  // drain vmcnt at every branch and the kernel degenerates into one memory round trip per pixel)
-  const float* __restrict__ img = a.img + (size_t)b * P;
-  constexpr int IPT = 10, MPT = 8;
-  const int npix = d.K * G2;
-  const bool has_mask = a.mask != nullptr;
-  const float* mbase = has_mask ? a.mask : img;
-  float mk[MPT];
-#pragma unroll
-  for (int q = 0; q < MPT; ++q) {
-    const int idx = min(tid + q * 256, npix - 1);
-    const int kp = idx / G2, pix = idx - kp * G2;
-    const size_t off = has_mask ? ((size_t)(b * d.K + kp) * a.mask_row_mul + mrow_add) * G2 + pix : 0;
-    mk[q] = mbase[off];
-  }
-  float v0[IPT];  // first (for 50x50: only) batch of frame pixels of this thread, requested before anything else
-#pragma unroll
-  for (int q = 0; q < IPT; ++q) v0[q] = img[min(q * 256 + tid, P - 1)];
-  // ---- `where` of every particle row: one HALF-wavefront (32 lanes) per row.  When the transform MLP's input is
-  // given, its output layer (nh -> 8) is evaluated right here — each lane owns nh/32 inputs, 8 half-wave
-  // reductions — and lanes 0..3 go straight on to the sample (no extra launch, no LDS round trip).  All operands
-  // (weights, eps, previous where, scale offset, Cholesky factor) are requested before the first reduction.
-  const bool fused_tp = a.t2 != nullptr && (a.mode == CROP_PROP2 || a.mode == CROP_DISC);
-  const int hw = tid >> 5, hl = tid & 31;
-  const int per = d.nh / 32;  // inputs per lane (8 for nh = 256); nh % 128 == 0 assumed for the float4 path
-  for (int kp = hw; kp < d.K; kp += 8) {
-    const int r = b * d.K + kp;
-    const int ci = hl & 3;  // component handled by lanes 0..3 (other lanes compute a harmless duplicate)
-    float tp_loc = 0.0f, tp_raw = 0.0f;
-    // operands of the sample
-    float e[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zp = 0.0f, off = 0.0f, chv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wbv = 0.0f, lg = 0.0f;
-    if (a.mode == CROP_PLAIN) {
-      lg = a.logits[(size_t)r * 4 + ci];
-    } else if (a.mode == CROP_PROP1) {
-      zp = a.rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHERE + ci];
-      wbv = a.wb[((size_t)r * d.N + slot) * a.wb_ld + ci];
-    } else {
-      const float* eps = a.noise + (((size_t)r * 2 + (a.mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) e[jj] = eps[jj];
-      if (a.mode == CROP_DISC) {
-        off = a.flat[po.disc_scale_offset];
-      } else {
-        off = a.flat[po.prop_scale_offset];
-        zp = a.rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHERE + ci];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) chv[jj] = tril4(a.flat + po.cholesky, ci, min(jj, ci));
-      }
-      if (!fused_tp) {
-        tp_loc = a.tp[(size_t)r * a.tp_ld + ci];
-        tp_raw = a.tp[(size_t)r * a.tp_ld + 4 + ci];
-      }
-    }
-    if (fused_tp) {
-      float part[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-      const float4* x4 = reinterpret_cast<const float4*>(a.t2 + (size_t)r * a.t2_ld + per * hl);
-      const float4* w4 = reinterpret_cast<const float4*>(a.w3) + (size_t)per * hl * 2;  // rows per*hl.., 8 outputs each
-      for (int q = 0; q < per / 4; ++q) {
-        const float4 x = x4[q];
-        const float xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-          const float4 wa = w4[(q * 4 + ii) * 2], wb2 = w4[(q * 4 + ii) * 2 + 1];
-          part[0] += xs[ii] * wa.x; part[1] += xs[ii] * wa.y; part[2] += xs[ii] * wa.z; part[3] += xs[ii] * wa.w;
-          part[4] += xs[ii] * wb2.x; part[5] += xs[ii] * wb2.y; part[6] += xs[ii] * wb2.z; part[7] += xs[ii] * wb2.w;
-        }
-      }
-#pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        float v = part[o];
-        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-        part[o] = v + a.w3[d.nh * 8 + o];
-      }
-      tp_loc = ci == 0 ? part[0] : (ci == 1 ? part[1] : (ci == 2 ? part[2] : part[3]));
-      tp_raw = ci == 0 ? part[4] : (ci == 1 ? part[5] : (ci == 2 ? part[6] : part[7]));
-      if (a.tp_out != nullptr && hl < 4) {
-        a.tp_out[(size_t)r * a.tp_out_ld + ci] = tp_loc;
-        a.tp_out[(size_t)r * a.tp_out_ld + 4 + ci] = tp_raw;
-      }
-    }
-    float wl;
-    if (a.mode == CROP_PLAIN) {
-      wl = lg;
-    } else if (a.mode == CROP_PROP1) {
-      wl = zp + wbv * 0.1f;
-    } else {
-      float loc, sc;
-      if (a.mode == CROP_DISC) {
-        loc = tp_loc;
-        sc = sq_softplus(tp_raw + off) + 1e-2f;
-        wl = loc + sc * (ci == 0 ? e[0] : (ci == 1 ? e[1] : (ci == 2 ? e[2] : e[3])));
-      } else {
-        loc = zp + 1.0f * tp_loc;
-        sc = sq_softplus(tp_raw + off - 1.0f) + 1e-2f;
-        float acc = 0.0f;  // row ci of L = T * sc[:,None] + diag(sc), times eps
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          if (jj <= ci) acc += (chv[jj] * sc + (jj == ci ? sc : 0.0f)) * e[jj];
-        wl = loc + acc;
-      }
-      if (hl < 4) {
-        float* rn = a.rec_new + ((size_t)r * d.N + slot) * rec::W;
-        rn[rec::WHERE + ci] = wl;
-        rn[rec::WHERE_LOC + ci] = loc;
-        rn[rec::WHERE_SCALE + ci] = sc;
-      }
-    }
-    if (hl < 4) coord_s[kp * 4 + ci] = (ci & 2) ? tanhf(wl) : fmaxf(sq_sigmoid(wl), 1e-4f);
-  }
-#pragma unroll
-  for (int q = 0; q < IPT; ++q) {
-    const int idx = q * 256 + tid;
-    if (idx < P) img_s[idx] = v0[q];
-  }
-  for (int base = 256 * IPT; base < P; base += 256 * IPT) {  // frames larger than 2560 pixels
-    float v[IPT];
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) v[q] = img[min(base + q * 256 + tid, P - 1)];
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) {
-      const int idx = base + q * 256 + tid;
-      if (idx < P) img_s[idx] = v[q];
-    }
-  }
-  __syncthreads();
-  // per particle: source coordinates of the G columns and G rows
-  for (int i = tid; i < d.K * 2 * G; i += 256) {
-    const int kp = i / (2 * G), q = i % (2 * G);
-    const bool is_y = q >= G;
-    const int j = is_y ? q - G : q;
-    const float gn = -1.0f + 2.0f * (float)j / (float)(G - 1);
-    const float sc = coord_s[kp * 4 + (is_y ? 1 : 0)], tr = coord_s[kp * 4 + (is_y ? 3 : 2)];
-    const float L = (float)((is_y ? d.H : d.W) - 1);
-    const float x = 0.5f * L * (sc * gn + tr + 1.0f);
-    const float x0 = floorf(x);
-    tab_s[(kp * 2 * G + q) * 2 + 0] = x0;
-    tab_s[(kp * 2 * G + q) * 2 + 1] = x - x0;
-  }
-  __syncthreads();
-  for (int base = 0; base < npix; base += 256 * MPT) {
-    if (base > 0 && has_mask) {  // more than MPT pixels per thread (K*G*G > 2048): fetch the next batch of mask values
-#pragma unroll
-      for (int q = 0; q < MPT; ++q) {
-        const int idx = min(base + tid + q * 256, npix - 1);
-        const int kp = idx / G2, pix = idx - kp * G2;
-        mk[q] = a.mask[((size_t)(b * d.K + kp) * a.mask_row_mul + mrow_add) * G2 + pix];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < MPT; ++q) {
-      const int idx = base + tid + q * 256;
-      if (idx >= npix) break;
-      const int kp = idx / G2, pix = idx - kp * G2;
-      const int r = b * d.K + kp;
-      const int i = pix / G, j = pix - i * G;
-      const float* tb = tab_s + (size_t)kp * 2 * G * 2;
-      const float x0f = tb[j * 2], wx1 = tb[j * 2 + 1];
-      const float y0f = tb[(G + i) * 2], wy1 = tb[(G + i) * 2 + 1];
-      const int x0 = (int)x0f, y0 = (int)y0f;
-      float v = 0.0f;
-#pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {
-        const int yy = y0 + dy;
-        const float wy = dy ? wy1 : 1.0f - wy1;
-        if (yy < 0 || yy >= d.H) continue;
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          const int xx = x0 + dx;
-          const float wx = dx ? wx1 : 1.0f - wx1;
-          if (xx < 0 || xx >= d.W) continue;
-          v += wy * wx * img_s[yy * d.W + xx];
-        }
-      }
-      a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + pix] = has_mask ? v * mk[q] : v;
-    }
-  }
+  x_crop_row<LdPlain>(a, po, d, blockIdx.x, a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot, smem);
 }
 
 int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
-  const size_t shm = ((size_t)d.H * d.W + d.K * 4 + (size_t)d.K * 2 * d.G * 2 + d.K * 8) * sizeof(float);
-  static bool big_lds = false;
-  if (shm > 48 * 1024 && !big_lds) {  // 128x128 frames: 64 KiB + tables, CDNA4 has 160 KiB of LDS per CU
-    (void)hipFuncSetAttribute((const void*)k_crop, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipGetLastError();
-    big_lds = true;
-  }
-  hipLaunchKernelGGL(k_crop, dim3(d.B, nslots), dim3(256), shm, s, a, po, d);
-  return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// what ~ N(loc, scale) for discovery (reference: sqair/core.py:213-215)
-// ------------------------------------------------------------------------------------------------
-__global__ void k_what_disc(const float* __restrict__ enc, int enc_ld, const float* __restrict__ noise,
-                            float* __restrict__ rec_d, int slot, Dims d) {
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int c = threadIdx.x & 63;
-  if (r >= d.R || c >= d.nw) return;
-  const float loc = enc[(size_t)r * enc_ld + c];
-  const float sc = enc[(size_t)r * enc_ld + d.nw + c];
-  const float eps = noise[(((size_t)r * 2 + 1) * d.N + slot) * d.nzw + 4 + c];
-  float* rn = rec_d + ((size_t)r * d.N + slot) * rec::W;
-  rn[rec::WHAT + c] = loc + sc * eps;
-  rn[rec::WHAT_LOC + c] = loc;
-  rn[rec::WHAT_SCALE + c] = sc;
-}
-int sq_launch_what_disc(const float* enc, int enc_ld, const float* noise, float* rec_d, int slot, Dims d,
-                        hipStream_t s) {
-  hipLaunchKernelGGL(k_what_disc, dim3((d.R + 3) / 4), dim3(256), 0, s, enc, enc_ld, noise, rec_d, slot, d);
-  return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// gated what update of propagation (reference: sqair/core.py:336-359)
-// ------------------------------------------------------------------------------------------------
-__global__ void k_what_prop(const float* __restrict__ hraw, int h_ld, const float* __restrict__ enc, int enc_ld,
-                            const float* __restrict__ rec_prev, const float* __restrict__ noise,
-                            float* __restrict__ rec_p, int slot, Dims d) {
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int c = threadIdx.x & 63;
-  if (r >= d.R || c >= d.nw) return;
-  const int nw = d.nw;
-  const float* hr = hraw + (size_t)r * h_ld;
-  const float t_loc = hr[c];
-  const float t_scale = sq_softplus(hr[nw + c]) + 1e-2f;
-  const float fg = sq_sigmoid(hr[2 * nw + c]) * 0.9999f;
-  const float ig = sq_sigmoid(hr[3 * nw + c]) * 0.9999f;
-  const float tg = sq_sigmoid(hr[4 * nw + c]) * 0.9999f;
-  const float loc2 = enc[(size_t)r * enc_ld + c];
-  const float sc2 = enc[(size_t)r * enc_ld + nw + c];
-  const float what_tm1 = rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHAT + c];
-  const float loc = fg * what_tm1 + (1.0f - ig) * loc2 + (1.0f - tg) * t_loc;
-  const float sc = (1.0f - ig) * sc2 + (1.0f - tg) * t_scale;
-  const float eps = noise[(((size_t)r * 2 + 0) * d.N + slot) * d.nzw + 4 + c];
-  float* rn = rec_p + ((size_t)r * d.N + slot) * rec::W;
-  rn[rec::WHAT + c] = loc + sc * eps;
-  rn[rec::WHAT_LOC + c] = loc;
-  rn[rec::WHAT_SCALE + c] = sc;
-}
-int sq_launch_what_prop(const float* hraw, int h_ld, const float* enc, int enc_ld, const float* rec_prev,
-                        const float* noise, float* rec_p, int slot, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_what_prop, dim3((d.R + 3) / 4), dim3(256), 0, s, hraw, h_ld, enc, enc_ld, rec_prev, noise,
-                     rec_p, slot, d);
-  return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// StepsPredictor output layer + presence Bernoulli (reference: sqair/modules.py:506-524,
-// sqair/core.py:141-144).  One wavefront per row: 128-long dot product, wave reduction.
-// ------------------------------------------------------------------------------------------------
-__global__ void k_steps(const float* __restrict__ s1, int s1_ld, const float* __restrict__ flat, int w_off, int b_off,
-                        const float* __restrict__ rec_prev, float* __restrict__ rec_new,
-                        const float* __restrict__ noise, int slot, int is_disc, Dims d) {
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (r >= d.R) return;
-  const int nsp = d.nh / 2;
-  // every operand is requested before the reduction (one memory round trip)
-  const float bias = flat[b_off];
-  const float u = noise[(((size_t)r * 2 + (is_disc ? 1 : 0)) * d.N + slot) * d.nzw + 4 + d.nw];
-  float prev;
-  if (is_disc) prev = slot == 0 ? 1.0f : rec_new[((size_t)r * d.N + slot - 1) * rec::W + rec::PRES];
-  else prev = rec_prev[((size_t)r * d.N + slot) * rec::W + rec::PRES];
-  float acc = 0.0f;
-  for (int i = lane; i < nsp; i += 64) acc += s1[(size_t)r * s1_ld + i] * flat[w_off + i];
-  acc = sq_wave_sum(acc);
-  if (lane == 0) {
-    const float raw = acc + bias;
-    const float logit = prev * raw + (prev - 1.0f) * 88.0f;
-    const float prob = sq_sigmoid(logit);
-    float* rn = rec_new + ((size_t)r * d.N + slot) * rec::W;
-    rn[rec::PRES] = (u < prob ? 1.0f : 0.0f) * prev;
-    rn[rec::LOGIT] = logit;
-    rn[rec::PROB] = prob;
-  }
-}
-int sq_launch_steps(const float* s1, int s1_ld, const float* flat, int w_off, int b_off, const float* rec_prev,
-                    float* rec_new, const float* noise, int slot, int is_disc, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_steps, dim3((d.R + 3) / 4), dim3(256), 0, s, s1, s1_ld, flat, w_off, b_off, rec_prev, rec_new,
-                     noise, slot, is_disc, d);
+  const size_t shm = (4 + (size_t)4 * d.G) * sizeof(float);
+  hipLaunchKernelGGL(k_crop_row, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
   return 0;
 }
 

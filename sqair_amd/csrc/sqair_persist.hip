@@ -14,6 +14,7 @@
 // flag and every workgroup leaves), and ops only ever read rows of their own team.
 #include "sqair_internal.h"
 #include "sqair_persist.h"
+#include "sqair_rowops.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -42,7 +43,7 @@ __device__ __forceinline__ f32x4 ld4_sc1(const float* p) {
 
 struct Team {
   int rank, size;      // this workgroup inside its XCD team
-  int r0, r1;          // rows b' owned by the team (r0 multiple of 16)
+  int r0, r1;          // rows b' owned by the team
   unsigned* bar;       // the team's arrival counter
   unsigned phase;      // barriers passed so far
   int* abort_flag;
@@ -71,18 +72,67 @@ __device__ __forceinline__ bool team_barrier(Team& tm) {
   return s_ok != 0;
 }
 
-// ---- dense layer: one 16x16 tile per task, arithmetic identical to k_linear (sqair_linear_kernel.inc) ---------------
-__device__ void x_linear(const LinArgs& a, int kc_total, int n_tiles, int m0, int m1, const Team& tm, float* red) {
+// ---- dense layer over the team's rows [m0, m1) ----------------------------------------------------------------------
+// operand addressing shared by both tilings
+struct XSegs {
+  const float* rp[4];
+  int cum[4], lim[4];
+};
+__device__ __forceinline__ XSegs x_segs(const LinArgs& a, int arow) {
+  XSegs sg;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool on = i < a.nseg;
+    const LinSeg& seg = a.seg[on ? i : 0];
+    const int row = seg.rmul ? (int)__umulhi((unsigned)arow, seg.rmul) : arow;
+    sg.rp[i] = seg.p + (size_t)row * seg.ld;
+    sg.cum[i] = on ? c : 0x7fffffff;
+    sg.lim[i] = ((seg.width + 3) & ~3) - 4;
+    c += on ? (seg.width + 15) >> 4 : 0;
+  }
+  return sg;
+}
+__device__ __forceinline__ const float* x_aptr(const XSegs& sg, int g, int kq) {
+  const bool s1 = g >= sg.cum[1], s2 = g >= sg.cum[2], s3 = g >= sg.cum[3];
+  const float* rp = s3 ? sg.rp[3] : (s2 ? sg.rp[2] : (s1 ? sg.rp[1] : sg.rp[0]));
+  const int cb = s3 ? sg.cum[3] : (s2 ? sg.cum[2] : (s1 ? sg.cum[1] : 0));
+  const int lim = s3 ? sg.lim[3] : (s2 ? sg.lim[2] : (s1 ? sg.lim[1] : sg.lim[0]));
+  return rp + min((g - cb) * 16 + kq * 4, lim);
+}
+// epilogue of one output element (m, n) with pre-activation sum v (bias and addend already included)
+__device__ __forceinline__ void x_epilogue(const LinArgs& a, int m, int n, float v, float p_e0, float p_e1, float p_scale) {
+  if (a.epi == EPI_ACT) {
+    v = sq_act(v, n < a.act_split ? a.act_a : a.act_b);
+    a.out[(size_t)m * a.out_ld + n] = v * a.scale * p_scale;
+  } else if (a.epi == EPI_GRU1) {
+    const int nh = a.nh;
+    if (n < nh) a.out[(size_t)m * a.out_ld + n] = sq_sigmoid(v);
+    else if (n < 2 * nh) {
+      const float rg = sq_sigmoid(v);
+      a.o1[(size_t)m * a.o1_ld + (n - nh)] = rg * p_e0;
+      if (a.o3 != nullptr) a.o3[(size_t)m * a.o3_ld + (n - nh)] = rg;
+    } else a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
+  } else {
+    const float hc = tanhf(v);
+    a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1) * p_e0 + p_e1 * hc;
+    if (a.o1 != nullptr) a.o1[(size_t)m * a.o1_ld + n] = hc;
+  }
+}
+
+// (1) workgroup per 16x16 tile, 4 waves split K (lowest latency; arithmetic order of k_linear): used when the op has
+//     at most one tile per workgroup of the team
+__device__ void x_linear_wg(const LinArgs& a, int kc_total, int n_tiles, int m0, int m1, const Team& tm, float* red) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
-  const int tm0 = m0 >> 4, tm1 = (m1 + 15) >> 4;
-  const int tasks = (tm1 - tm0) * n_tiles;
+  const int mt = (m1 - m0 + 15) >> 4;
+  const int tasks = mt * n_tiles;
   for (int task = tm.rank; task < tasks; task += tm.size) {
-    const int tile_n = task % n_tiles, tile_m = tm0 + task / n_tiles;
-    const int arow = min(tile_m * 16 + (lane & 15), a.M - 1);
-    const int m = tile_m * 16 + (tid >> 4);
+    const int tile_n = task % n_tiles, mbase = m0 + (task / n_tiles) * 16;
+    const int arow = min(mbase + (lane & 15), m1 - 1);
+    const int m = mbase + (tid >> 4);
     const int n = tile_n * 16 + (tid & 15);
-    const bool live = m < a.M && n < a.N;
-    const int mc = min(m, a.M - 1), nc = min(n, a.N - 1);
+    const bool live = m < m1 && n < a.N;
+    const int mc = min(m, m1 - 1), nc = min(n, a.N - 1);
     const float* pb = a.bias + nc;
     const bool use_add = a.add != nullptr && nc < a.add_n;
     const bool g1 = a.epi == EPI_GRU1 && nc >= a.nh && nc < 2 * a.nh;
@@ -94,21 +144,9 @@ __device__ void x_linear(const LinArgs& a, int kc_total, int n_tiles, int m0, in
     const float p_bias = *pb;
     float p_add = ldf(pa);
     const float p_e0 = ldf(pe0), p_e1 = ldf(pe1);
-    float p_scale = a.scale_ptr != nullptr ? *a.scale_ptr : 1.0f;
+    const float p_scale = a.scale_ptr != nullptr ? *a.scale_ptr : 1.0f;
     p_add = use_add ? p_add : 0.0f;
-
-    int cum1 = 0x7fffffff, cum2 = 0x7fffffff, cum3 = 0x7fffffff;
-#define SQ_ROWOF(sg) ((sg).rmul ? (int)__umulhi((unsigned)arow, (sg).rmul) : arow)
-    const float* rp0 = a.seg[0].p + (size_t)SQ_ROWOF(a.seg[0]) * a.seg[0].ld;
-    const float* rp1 = rp0; const float* rp2 = rp0; const float* rp3 = rp0;
-    int lim0 = ((a.seg[0].width + 3) & ~3) - 4, lim1 = 0, lim2 = 0, lim3 = 0;
-    {
-      int c = (a.seg[0].width + 15) >> 4;
-      if (a.nseg > 1) { cum1 = c; c += (a.seg[1].width + 15) >> 4; rp1 = a.seg[1].p + (size_t)SQ_ROWOF(a.seg[1]) * a.seg[1].ld; lim1 = ((a.seg[1].width + 3) & ~3) - 4; }
-      if (a.nseg > 2) { cum2 = c; c += (a.seg[2].width + 15) >> 4; rp2 = a.seg[2].p + (size_t)SQ_ROWOF(a.seg[2]) * a.seg[2].ld; lim2 = ((a.seg[2].width + 3) & ~3) - 4; }
-      if (a.nseg > 3) { cum3 = c; rp3 = a.seg[3].p + (size_t)SQ_ROWOF(a.seg[3]) * a.seg[3].ld; lim3 = ((a.seg[3].width + 3) & ~3) - 4; }
-    }
-#undef SQ_ROWOF
+    const XSegs sg = x_segs(a, arow);
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
     const f32x4* __restrict__ wz = reinterpret_cast<const f32x4*>(a.wzero) + lane;
@@ -122,11 +160,7 @@ __device__ void x_linear(const LinArgs& a, int kc_total, int n_tiles, int m0, in
       for (int j = 0; j < NCH; ++j) {
         const bool valid = base + j < nmine;
         const int g = valid ? wave + 4 * (base + j) : wave;
-        const bool s1 = g >= cum1, s2 = g >= cum2, s3 = g >= cum3;
-        const float* rp = s3 ? rp3 : (s2 ? rp2 : (s1 ? rp1 : rp0));
-        const int cb = s3 ? cum3 : (s2 ? cum2 : (s1 ? cum1 : 0));
-        const int lim = s3 ? lim3 : (s2 ? lim2 : (s1 ? lim1 : lim0));
-        ap[j] = rp + min((g - cb) * 16 + kq * 4, lim);
+        ap[j] = x_aptr(sg, g, kq);
         bv[j] = *(valid ? wp + (size_t)g * 64 : wz);
       }
       ld4x4_sc1(ap[0], ap[1], ap[2], ap[3], av[0], av[1], av[2], av[3]);
@@ -144,166 +178,87 @@ __device__ void x_linear(const LinArgs& a, int kc_total, int n_tiles, int m0, in
     r[(4 * kq + 2) * 16 + (lane & 15)] = acc0.z + acc1.z;
     r[(4 * kq + 3) * 16 + (lane & 15)] = acc0.w + acc1.w;
     __syncthreads();
-    if (live) {
-      float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + p_bias + p_add;
-      if (a.epi == EPI_ACT) {
-        v = sq_act(v, n < a.act_split ? a.act_a : a.act_b);
-        a.out[(size_t)m * a.out_ld + n] = v * a.scale * p_scale;
-      } else if (a.epi == EPI_GRU1) {
-        const int nh = a.nh;
-        if (n < nh) a.out[(size_t)m * a.out_ld + n] = sq_sigmoid(v);
-        else if (n < 2 * nh) {
-          const float rg = sq_sigmoid(v);
-          a.o1[(size_t)m * a.o1_ld + (n - nh)] = rg * p_e0;
-          if (a.o3 != nullptr) a.o3[(size_t)m * a.o3_ld + (n - nh)] = rg;
-        } else a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
-      } else {
-        const float hc = tanhf(v);
-        a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1) * p_e0 + p_e1 * hc;
-        if (a.o1 != nullptr) a.o1[(size_t)m * a.o1_ld + n] = hc;
-      }
-    }
+    if (live) x_epilogue(a, m, n, red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + p_bias + p_add, p_e0, p_e1, p_scale);
     __syncthreads();
   }
 }
 
-// ---- spatial-transformer crop of ONE particle row (arithmetic of k_crop, sqair_glue.hip) ---------------------------
-__device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int r, int slot, float* smem) {
-  float* coord_s = smem;        // 4
-  float* tab_s = smem + 4;      // 2 * 2G
-  const int tid = threadIdx.x, b = r / d.K;
-  const int P = d.H * d.W, G = d.G, G2 = d.G * d.G;
-  const int mrow_add = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
-  const int orow_add = a.out_row_add + (a.mode == CROP_PROP1 ? slot : 0);
-  const float* __restrict__ img = a.img + (size_t)b * P;
-  const bool has_mask = a.mask != nullptr;
-  const bool fused_tp = a.t2 != nullptr && (a.mode == CROP_PROP2 || a.mode == CROP_DISC);
-  if (tid < 32) {
-    const int hl = tid, ci = hl & 3;
-    const int per = d.nh / 32;
-    float tp_loc = 0.0f, tp_raw = 0.0f;
-    float e[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zp = 0.0f, off = 0.0f, chv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wbv = 0.0f, lg = 0.0f;
-    if (a.mode == CROP_PLAIN) {
-      lg = ldf(a.logits + (size_t)r * 4 + ci);
-    } else if (a.mode == CROP_PROP1) {
-      zp = ldf(a.rec_prev + ((size_t)r * d.N + slot) * rec::W + rec::WHERE + ci);
-      wbv = ldf(a.wb + ((size_t)r * d.N + slot) * a.wb_ld + ci);
-    } else {
-      const float* eps = a.noise + (((size_t)r * 2 + (a.mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
+// (2) wavefront per 16x16 tile, whole K in the wave (no LDS, no workgroup barrier): 4 tiles in flight per workgroup; used
+//     when the op has more tiles than the team has workgroups
+__device__ void x_linear_wave(const LinArgs& a, int kc_total, int n_tiles, int m0, int m1, const Team& tm) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
+  const int mt = (m1 - m0 + 15) >> 4;
+  const int tasks = mt * n_tiles;
+  const int nwaves = tm.size * 4;
+  for (int task = tm.rank + tm.size * wave; task < tasks; task += nwaves) {  // wave w of workgroup r: tasks r + size*w, ...
+    const int tile_n = task % n_tiles, mbase = m0 + (task / n_tiles) * 16;
+    const int arow = min(mbase + (lane & 15), m1 - 1);
+    const int n = tile_n * 16 + (lane & 15);
+    const int nc = min(n, a.N - 1);
+    const float* pb = a.bias + nc;
+    const bool use_add = a.add != nullptr && nc < a.add_n;
+    const bool g1 = a.epi == EPI_GRU1 && nc >= a.nh && nc < 2 * a.nh;
+    const bool g2 = a.epi == EPI_GRU2;
+    const float p_bias = *pb;
+    const float p_scale = a.scale_ptr != nullptr ? *a.scale_ptr : 1.0f;
+    float p_add[4], p_e0[4], p_e1[4];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) e[jj] = eps[jj];
-      if (a.mode == CROP_DISC) {
-        off = a.flat[po.disc_scale_offset];
-      } else {
-        off = a.flat[po.prop_scale_offset];
-        zp = ldf(a.rec_prev + ((size_t)r * d.N + slot) * rec::W + rec::WHERE + ci);
+    for (int i = 0; i < 4; ++i) {  // this lane's 4 outputs: rows mbase + 4 kq + i, column n
+      const int mc = min(mbase + 4 * kq + i, m1 - 1);
+      const int mcd = a.add_rmul ? (int)__umulhi((unsigned)mc, a.add_rmul) : mc;
+      const float* pa = use_add ? a.add + (size_t)mcd * a.add_ld + nc : pb;
+      const float* pe0 = g1 ? a.e0 + (size_t)mc * a.e0_ld + (nc - a.nh) : (g2 ? a.e0 + (size_t)mc * a.e0_ld + nc : pb);
+      const float* pe1 = g2 ? a.e1 + (size_t)mc * a.e1_ld + nc : pb;
+      p_add[i] = ldf(pa); p_e0[i] = ldf(pe0); p_e1[i] = ldf(pe1);
+    }
+    const XSegs sg = x_segs(a, arow);
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
+    const f32x4* __restrict__ wz = reinterpret_cast<const f32x4*>(a.wzero) + lane;
+    constexpr int NCH = 8;
+#pragma unroll 1
+    for (int base = 0; base < kc_total; base += NCH) {
+      f32x4 av[NCH], bv[NCH];
+      const float* ap[NCH];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) chv[jj] = tril4(a.flat + po.cholesky, ci, min(jj, ci));
+      for (int j = 0; j < NCH; ++j) {
+        const bool valid = base + j < kc_total;
+        const int g = valid ? base + j : 0;
+        ap[j] = x_aptr(sg, g, kq);
+        bv[j] = *(valid ? wp + (size_t)g * 64 : wz);
       }
-      if (!fused_tp) {
-        tp_loc = ldf(a.tp + (size_t)r * a.tp_ld + ci);
-        tp_raw = ldf(a.tp + (size_t)r * a.tp_ld + 4 + ci);
+      ld4x4_sc1(ap[0], ap[1], ap[2], ap[3], av[0], av[1], av[2], av[3]);
+      ld4x4_sc1(ap[4], ap[5], ap[6], ap[7], av[4], av[5], av[6], av[7]);
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
       }
     }
-    if (fused_tp) {
-      float part[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-      const float* xrow = a.t2 + (size_t)r * a.t2_ld + per * hl;
-      const float4* w4 = reinterpret_cast<const float4*>(a.w3) + (size_t)per * hl * 2;
-      f32x4 xv[4];  // per / 4 <= 4 (nh <= 512)
-      for (int q = 0; q < per / 4; ++q) xv[q] = ld4_sc1(xrow + 4 * q);
-      for (int q = 0; q < per / 4; ++q) {
-        const f32x4 x = xv[q];
-        const float xs[4] = {x.x, x.y, x.z, x.w};
+    const float accv[4] = {acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w};
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-          const float4 wa = w4[(q * 4 + ii) * 2], wb2 = w4[(q * 4 + ii) * 2 + 1];
-          part[0] += xs[ii] * wa.x; part[1] += xs[ii] * wa.y; part[2] += xs[ii] * wa.z; part[3] += xs[ii] * wa.w;
-          part[4] += xs[ii] * wb2.x; part[5] += xs[ii] * wb2.y; part[6] += xs[ii] * wb2.z; part[7] += xs[ii] * wb2.w;
-        }
-      }
-#pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        float v = part[o];
-        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-        part[o] = v + a.w3[d.nh * 8 + o];
-      }
-      tp_loc = ci == 0 ? part[0] : (ci == 1 ? part[1] : (ci == 2 ? part[2] : part[3]));
-      tp_raw = ci == 0 ? part[4] : (ci == 1 ? part[5] : (ci == 2 ? part[6] : part[7]));
-      if (a.tp_out != nullptr && hl < 4) {
-        a.tp_out[(size_t)r * a.tp_out_ld + ci] = tp_loc;
-        a.tp_out[(size_t)r * a.tp_out_ld + 4 + ci] = tp_raw;
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int m = mbase + 4 * kq + i;
+      if (m < m1 && n < a.N) x_epilogue(a, m, n, accv[i] + p_bias + (use_add ? p_add[i] : 0.0f), p_e0[i], p_e1[i], p_scale);
     }
-    float wl;
-    if (a.mode == CROP_PLAIN) {
-      wl = lg;
-    } else if (a.mode == CROP_PROP1) {
-      wl = zp + wbv * 0.1f;
-    } else {
-      float loc, sc;
-      if (a.mode == CROP_DISC) {
-        loc = tp_loc;
-        sc = sq_softplus(tp_raw + off) + 1e-2f;
-        wl = loc + sc * (ci == 0 ? e[0] : (ci == 1 ? e[1] : (ci == 2 ? e[2] : e[3])));
-      } else {
-        loc = zp + 1.0f * tp_loc;
-        sc = sq_softplus(tp_raw + off - 1.0f) + 1e-2f;
-        float acc = 0.0f;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          if (jj <= ci) acc += (chv[jj] * sc + (jj == ci ? sc : 0.0f)) * e[jj];
-        wl = loc + acc;
-      }
-      if (hl < 4) {
-        float* rn = a.rec_new + ((size_t)r * d.N + slot) * rec::W;
-        rn[rec::WHERE + ci] = wl;
-        rn[rec::WHERE_LOC + ci] = loc;
-        rn[rec::WHERE_SCALE + ci] = sc;
-      }
-    }
-    if (hl < 4) coord_s[ci] = (ci & 2) ? tanhf(wl) : fmaxf(sq_sigmoid(wl), 1e-4f);
   }
-  __syncthreads();
-  for (int i = tid; i < 2 * G; i += 256) {
-    const bool is_y = i >= G;
-    const int j = is_y ? i - G : i;
-    const float gn = -1.0f + 2.0f * (float)j / (float)(G - 1);
-    const float sc = coord_s[is_y ? 1 : 0], tr = coord_s[is_y ? 3 : 2];
-    const float L = (float)((is_y ? d.H : d.W) - 1);
-    const float x = 0.5f * L * (sc * gn + tr + 1.0f);
-    const float x0 = floorf(x);
-    tab_s[i * 2 + 0] = x0;
-    tab_s[i * 2 + 1] = x - x0;
-  }
-  __syncthreads();
-  for (int pix = tid; pix < G2; pix += 256) {
-    const float mk = has_mask ? ldf(a.mask + ((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix) : 1.0f;
-    const int i = pix / G, j = pix - i * G;
-    const float x0f = tab_s[j * 2], wx1 = tab_s[j * 2 + 1];
-    const float y0f = tab_s[(G + i) * 2], wy1 = tab_s[(G + i) * 2 + 1];
-    const int x0 = (int)x0f, y0 = (int)y0f;
-    float v = 0.0f;
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-      const int yy = y0 + dy;
-      const float wy = dy ? wy1 : 1.0f - wy1;
-      if (yy < 0 || yy >= d.H) continue;
-#pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        const int xx = x0 + dx;
-        const float wx = dx ? wx1 : 1.0f - wx1;
-        if (xx < 0 || xx >= d.W) continue;
-        v += wy * wx * img[yy * d.W + xx];
-      }
-    }
-    a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + pix] = has_mask ? v * mk : v;
-  }
-  __syncthreads();
 }
 
+__device__ __forceinline__ void x_linear(const LinArgs& a, int kc_total, int n_tiles, int m0, int m1, const Team& tm, float* red) {
+  const int tasks = ((m1 - m0 + 15) >> 4) * n_tiles;
+  if (tasks <= tm.size) x_linear_wg(a, kc_total, n_tiles, m0, m1, tm, red);
+  else x_linear_wave(a, kc_total, n_tiles, m0, m1, tm);
+}
+
+struct LdSc1 {
+  static __device__ __forceinline__ float f(const float* p) { return ldf(p); }
+  static __device__ __forceinline__ sq_f32x4 f4(const float* p) { return ld4_sc1(p); }
+};
+
 // ---- tail of a slot for 16 rows (arithmetic of k_slot_tail) -----------------------------------------------------------
-__device__ void x_tail16(const TailArgs& a, const Dims& d, int row0, float* smem) {
+__device__ void x_tail16(const TailArgs& a, const Dims& d, int row0, int rlim, float* smem) {  // rows [row0, min(row0 + 16, rlim))
   constexpr int ZLD = 68;
   float* zt = smem;                 // 16 * ZLD
   float* rs = smem + 16 * ZLD;      // 4 * 16
@@ -320,10 +275,10 @@ __device__ void x_tail16(const TailArgs& a, const Dims& d, int row0, float* smem
 #pragma unroll
     for (int c = 0; c < 4; ++c) bv[t][c] = wp4[(size_t)(tile * 4 + c) * 64 + lane];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sp[t][i] = ldf(a.s1p + (size_t)min(row0 + 4 * kq + i, d.R - 1) * a.s1p_ld + col);
+    for (int i = 0; i < 4; ++i) sp[t][i] = ldf(a.s1p + (size_t)min(row0 + 4 * kq + i, rlim - 1) * a.s1p_ld + col);
     w2v[t] = a.flat[a.w2_off + col];
   }
-  const int pr = min(row0 + (tid & 15), d.R - 1);
+  const int pr = min(row0 + (tid & 15), rlim - 1);
   const float b2 = a.flat[a.b2_off];
   const float u = a.noise[(((size_t)pr * 2 + (a.is_disc ? 1 : 0)) * d.N + a.slot) * d.nzw + 4 + nw];
   float prev;
@@ -336,7 +291,7 @@ __device__ void x_tail16(const TailArgs& a, const Dims& d, int row0, float* smem
   for (int q = 0; q < EPT; ++q) {
     const int e = min(tid + 256 * q, nel - 1);
     const int rr = e / nw, c = e - rr * nw;
-    const int r = min(row0 + rr, d.R - 1);
+    const int r = min(row0 + rr, rlim - 1);
     v_loc[q] = ldf(a.enc + (size_t)r * a.enc_ld + c);
     v_sc[q] = ldf(a.enc + (size_t)r * a.enc_ld + nw + c);
     v_eps[q] = a.noise[(((size_t)r * 2 + (a.is_disc ? 1 : 0)) * d.N + a.slot) * d.nzw + 4 + c];
@@ -375,7 +330,7 @@ __device__ void x_tail16(const TailArgs& a, const Dims& d, int row0, float* smem
       }
       const float what = loc + sc * v_eps[q];
       zt[rr * ZLD + rec::WHAT + c] = what;
-      if (row0 + rr < d.R) {
+      if (row0 + rr < rlim) {
         float* rn = a.rec_new + ((size_t)(row0 + rr) * d.N + a.slot) * rec::W;
         rn[rec::WHAT + c] = what;
         rn[rec::WHAT_LOC + c] = loc;
@@ -405,7 +360,7 @@ __device__ void x_tail16(const TailArgs& a, const Dims& d, int row0, float* smem
       if (wave + 4 * t < n_tiles) {
         const float hv = sq_elu(acc[t][i] + sp[t][i]);
         v += hv * w2v[t];
-        if (a.s1h_out != nullptr && row0 + 4 * kq + i < d.R)
+        if (a.s1h_out != nullptr && row0 + 4 * kq + i < rlim)
           a.s1h_out[(size_t)(row0 + 4 * kq + i) * a.s1h_ld + (wave + 4 * t) * 16 + (lane & 15)] = hv;
       }
     v += __shfl_xor(v, 1, 64);
@@ -419,7 +374,7 @@ __device__ void x_tail16(const TailArgs& a, const Dims& d, int row0, float* smem
     for (int i = 0; i < 4; ++i) rs[wave * 16 + 4 * kq + i] = part[i];
   }
   __syncthreads();
-  if (tid < 16 && row0 + tid < d.R) {
+  if (tid < 16 && row0 + tid < rlim) {
     const float raw = rs[0 * 16 + tid] + rs[1 * 16 + tid] + rs[2 * 16 + tid] + rs[3 * 16 + tid] + b2;
     const float logit = prev * raw + (prev - 1.0f) * 88.0f;
     const float prob = sq_sigmoid(logit);
@@ -560,10 +515,10 @@ __global__ __launch_bounds__(256) void k_xcd_persistent(const XOp* __restrict__ 
         ++nteams;
       }
     }
-    const int tiles = (d.R + 15) / 16;
-    const int base = tiles / nteams, rem = tiles % nteams;
-    const int t0 = my_index * base + min(my_index, rem), t1 = t0 + base + (my_index < rem ? 1 : 0);
-    s_team[0] = (int)rank; s_team[1] = ok ? my_size : 0; s_team[2] = min(t0 * 16, d.R); s_team[3] = min(t1 * 16, d.R);
+    // rows are dealt evenly (a team's range need not be a multiple of the 16-row MFMA tile: its last tile is ragged)
+    const int base = d.R / nteams, rem = d.R % nteams;
+    const int q0 = my_index * base + min(my_index, rem), q1 = q0 + base + (my_index < rem ? 1 : 0);
+    s_team[0] = (int)rank; s_team[1] = ok ? my_size : 0; s_team[2] = q0; s_team[3] = q1;
     s_team[4] = (int)x;
   }
   __syncthreads();
@@ -598,11 +553,11 @@ __global__ __launch_bounds__(256) void k_xcd_persistent(const XOp* __restrict__ 
         case XOP_CROP: {
           const int tasks = rows * op.nslots;
           for (int task = tm.rank; task < tasks; task += tm.size)
-            x_crop_row(op.u.crop, po, d, tm.r0 + task / op.nslots, op.u.crop.mode == CROP_PROP1 ? task % op.nslots : op.u.crop.slot, red);
+            x_crop_row<LdSc1>(op.u.crop, po, d, tm.r0 + task / op.nslots, op.u.crop.mode == CROP_PROP1 ? task % op.nslots : op.u.crop.slot, red);
           break;
         }
         case XOP_TAIL:
-          for (int task = tm.rank; task * 16 < rows; task += tm.size) x_tail16(op.u.tail, d, tm.r0 + task * 16, red);
+          for (int task = tm.rank; task * 16 < rows; task += tm.size) x_tail16(op.u.tail, d, tm.r0 + task * 16, tm.r1, red);
           break;
         case XOP_LATSUM:
           for (int task = tm.rank; task < rows; task += tm.size) x_latsum_row(op.u.lat, d, tm.r0 + task);

@@ -1,0 +1,152 @@
+// Per-row spatial-transformer crop, shared by the launch-per-op path (k_crop_row, plain loads) and the XCD-persistent
+// executor (L1-bypassing loads of data written earlier in the same launch).  Arithmetic order of the original
+// per-sequence k_crop (sqair_glue.hip): results are bit-identical.
+#pragma once
+#include "sqair_glue.h"
+
+typedef float sq_f32x4 __attribute__((ext_vector_type(4)));
+struct LdPlain {
+  static __device__ __forceinline__ float f(const float* p) { return *p; }
+  static __device__ __forceinline__ sq_f32x4 f4(const float* p) { return *reinterpret_cast<const sq_f32x4*>(p); }
+};
+
+template <class LD>
+__device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int r, int slot, float* smem) {
+  float* coord_s = smem;        // 4
+  float* tab_s = smem + 4;      // 2 * 2G
+  const int tid = threadIdx.x, b = r / d.K;
+  const int P = d.H * d.W, G = d.G, G2 = d.G * d.G;
+  const int mrow_add = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
+  const int orow_add = a.out_row_add + (a.mode == CROP_PROP1 ? slot : 0);
+  const float* __restrict__ img = a.img + (size_t)b * P;
+  const bool has_mask = a.mask != nullptr;
+  const bool fused_tp = a.t2 != nullptr && (a.mode == CROP_PROP2 || a.mode == CROP_DISC);
+  constexpr int MPT = 2;  // mask values of this thread's first pixels, requested before anything else
+  float mk0[MPT];
+#pragma unroll
+  for (int q = 0; q < MPT; ++q)
+    mk0[q] = has_mask ? LD::f(a.mask + ((size_t)r * a.mask_row_mul + mrow_add) * G2 + min(tid + 256 * q, G2 - 1)) : 1.0f;
+  if (tid < 32) {
+    const int hl = tid, ci = hl & 3;
+    const int per = d.nh / 32;
+    float tp_loc = 0.0f, tp_raw = 0.0f;
+    float e[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zp = 0.0f, off = 0.0f, chv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wbv = 0.0f, lg = 0.0f;
+    if (a.mode == CROP_PLAIN) {
+      lg = LD::f(a.logits + (size_t)r * 4 + ci);
+    } else if (a.mode == CROP_PROP1) {
+      zp = LD::f(a.rec_prev + ((size_t)r * d.N + slot) * rec::W + rec::WHERE + ci);
+      wbv = LD::f(a.wb + ((size_t)r * d.N + slot) * a.wb_ld + ci);
+    } else {
+      const float* eps = a.noise + (((size_t)r * 2 + (a.mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) e[jj] = eps[jj];
+      if (a.mode == CROP_DISC) {
+        off = a.flat[po.disc_scale_offset];
+      } else {
+        off = a.flat[po.prop_scale_offset];
+        zp = LD::f(a.rec_prev + ((size_t)r * d.N + slot) * rec::W + rec::WHERE + ci);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) chv[jj] = tril4(a.flat + po.cholesky, ci, min(jj, ci));
+      }
+      if (!fused_tp) {
+        tp_loc = LD::f(a.tp + (size_t)r * a.tp_ld + ci);
+        tp_raw = LD::f(a.tp + (size_t)r * a.tp_ld + 4 + ci);
+      }
+    }
+    if (fused_tp) {
+      float part[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      const float* xrow = a.t2 + (size_t)r * a.t2_ld + per * hl;
+      const float4* w4 = reinterpret_cast<const float4*>(a.w3) + (size_t)per * hl * 2;
+      sq_f32x4 xv[4];  // per / 4 <= 4 (nh <= 512)
+      for (int q = 0; q < per / 4; ++q) xv[q] = LD::f4(xrow + 4 * q);
+      for (int q = 0; q < per / 4; ++q) {
+        const sq_f32x4 x = xv[q];
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const float4 wa = w4[(q * 4 + ii) * 2], wb2 = w4[(q * 4 + ii) * 2 + 1];
+          part[0] += xs[ii] * wa.x; part[1] += xs[ii] * wa.y; part[2] += xs[ii] * wa.z; part[3] += xs[ii] * wa.w;
+          part[4] += xs[ii] * wb2.x; part[5] += xs[ii] * wb2.y; part[6] += xs[ii] * wb2.z; part[7] += xs[ii] * wb2.w;
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        float v = part[o];
+        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+        part[o] = v + a.w3[d.nh * 8 + o];
+      }
+      tp_loc = ci == 0 ? part[0] : (ci == 1 ? part[1] : (ci == 2 ? part[2] : part[3]));
+      tp_raw = ci == 0 ? part[4] : (ci == 1 ? part[5] : (ci == 2 ? part[6] : part[7]));
+      if (a.tp_out != nullptr && hl < 4) {
+        a.tp_out[(size_t)r * a.tp_out_ld + ci] = tp_loc;
+        a.tp_out[(size_t)r * a.tp_out_ld + 4 + ci] = tp_raw;
+      }
+    }
+    float wl;
+    if (a.mode == CROP_PLAIN) {
+      wl = lg;
+    } else if (a.mode == CROP_PROP1) {
+      wl = zp + wbv * 0.1f;
+    } else {
+      float loc, sc;
+      if (a.mode == CROP_DISC) {
+        loc = tp_loc;
+        sc = sq_softplus(tp_raw + off) + 1e-2f;
+        wl = loc + sc * (ci == 0 ? e[0] : (ci == 1 ? e[1] : (ci == 2 ? e[2] : e[3])));
+      } else {
+        loc = zp + 1.0f * tp_loc;
+        sc = sq_softplus(tp_raw + off - 1.0f) + 1e-2f;
+        float acc = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          if (jj <= ci) acc += (chv[jj] * sc + (jj == ci ? sc : 0.0f)) * e[jj];
+        wl = loc + acc;
+      }
+      if (hl < 4) {
+        float* rn = a.rec_new + ((size_t)r * d.N + slot) * rec::W;
+        rn[rec::WHERE + ci] = wl;
+        rn[rec::WHERE_LOC + ci] = loc;
+        rn[rec::WHERE_SCALE + ci] = sc;
+      }
+    }
+    if (hl < 4) coord_s[ci] = (ci & 2) ? tanhf(wl) : fmaxf(sq_sigmoid(wl), 1e-4f);
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * G; i += 256) {
+    const bool is_y = i >= G;
+    const int j = is_y ? i - G : i;
+    const float gn = -1.0f + 2.0f * (float)j / (float)(G - 1);
+    const float sc = coord_s[is_y ? 1 : 0], tr = coord_s[is_y ? 3 : 2];
+    const float L = (float)((is_y ? d.H : d.W) - 1);
+    const float x = 0.5f * L * (sc * gn + tr + 1.0f);
+    const float x0 = floorf(x);
+    tab_s[i * 2 + 0] = x0;
+    tab_s[i * 2 + 1] = x - x0;
+  }
+  __syncthreads();
+  for (int pix = tid, q = 0; pix < G2; pix += 256, ++q) {
+    const float mk = q < MPT ? mk0[q < MPT ? q : 0] : (has_mask ? LD::f(a.mask + ((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix) : 1.0f);
+    const int i = pix / G, j = pix - i * G;
+    const float x0f = tab_s[j * 2], wx1 = tab_s[j * 2 + 1];
+    const float y0f = tab_s[(G + i) * 2], wy1 = tab_s[(G + i) * 2 + 1];
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    float v = 0.0f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int yy = y0 + dy;
+      const float wy = dy ? wy1 : 1.0f - wy1;
+      if (yy < 0 || yy >= d.H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int xx = x0 + dx;
+        const float wx = dx ? wx1 : 1.0f - wx1;
+        if (xx < 0 || xx >= d.W) continue;
+        v += wy * wx * img[yy * d.W + xx];
+      }
+    }
+    a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + pix] = has_mask ? v * mk : v;
+  }
+  __syncthreads();
+}
+
