@@ -190,10 +190,10 @@ static void launch_nch(const LinArgs& a, const PackedLayer& L, int grid, hipStre
   (void)grid;
   const dim3 g(L.nt, (a.M + 15) / 16);
   switch (a.nseg) {  // the segment count is a template parameter: dead segment-selection code disappears
-    case 1: hipLaunchKernelGGL((k_linear<NCH, 1>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts); break;
-    case 2: hipLaunchKernelGGL((k_linear<NCH, 2>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts); break;
-    case 3: hipLaunchKernelGGL((k_linear<NCH, 3>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts); break;
-    default: hipLaunchKernelGGL((k_linear<NCH, 4>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts); break;
+    case 1: hipLaunchKernelGGL((k_linear<NCH, 1>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts); break;
+    case 2: hipLaunchKernelGGL((k_linear<NCH, 2>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts); break;
+    case 3: hipLaunchKernelGGL((k_linear<NCH, 3>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts); break;
+    default: hipLaunchKernelGGL((k_linear<NCH, 4>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts); break;
   }
 }
 

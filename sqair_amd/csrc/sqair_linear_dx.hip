@@ -24,11 +24,14 @@ __device__ __forceinline__ float dx_dact(float g, float o, int act) {
 }
 
 template <int NCH>
-__global__ __launch_bounds__(256) void k_linear_dx(const DxArgs a, const int kc_total) {
+__global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpre0, const float* __restrict__ wp0, const int ld0,
+                                                   const int width0, const int M0, const int kc_total, const DxArgs a) {
+  // leading scalars (copies of a.dpre / a.wp / a.ld / a.width / a.M): preloaded into SGPRs with the launch, so the operand
+  // loads do not wait for the s_load of the struct (see sqair_linear_kernel.inc)
   __shared__ float red[4 * 256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tile_n = blockIdx.x, tile_m = blockIdx.y;
-  const int arow = min(tile_m * 16 + (lane & 15), a.M - 1);
+  const int arow = min(tile_m * 16 + (lane & 15), M0 - 1);
   const int kq = lane >> 4;
   // ---- epilogue operands (addend, saved activation), requested before the operand loads
   const int m = tile_m * 16 + (tid >> 4);
@@ -46,10 +49,10 @@ __global__ __launch_bounds__(256) void k_linear_dx(const DxArgs a, const int kc_
   const float p_add = *pa, p_saved = *ps;
   const float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : dummy);
 
-  const float* rp = a.dpre + (size_t)arow * a.ld;
-  const int lim = ((a.width + 3) & ~3) - 4;
+  const float* rp = dpre0 + (size_t)arow * ld0;
+  const int lim = ((width0 + 3) & ~3) - 4;
   f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
+  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wp0) + ((size_t)tile_n * kc_total) * 64 + lane;
   const f32x4* __restrict__ wz = reinterpret_cast<const f32x4*>(a.wzero) + lane;
   const int nmine = (kc_total - wave + 3) >> 2;  // this wave owns chunks g = wave + 4 i
 #pragma unroll 1
@@ -93,15 +96,15 @@ int sq_launch_linear_dx(const DxArgs& a, int kc, int nt, hipStream_t s) {
   if (g.x == 0 || g.y == 0) return 0;
   const int per_wave = (kc + 3) / 4;
   switch (per_wave) {
-    case 1: hipLaunchKernelGGL(k_linear_dx<1>, g, dim3(256), 0, s, a, kc); break;
-    case 2: hipLaunchKernelGGL(k_linear_dx<2>, g, dim3(256), 0, s, a, kc); break;
-    case 3: hipLaunchKernelGGL(k_linear_dx<3>, g, dim3(256), 0, s, a, kc); break;
-    case 4: hipLaunchKernelGGL(k_linear_dx<4>, g, dim3(256), 0, s, a, kc); break;
-    case 5: hipLaunchKernelGGL(k_linear_dx<5>, g, dim3(256), 0, s, a, kc); break;
-    case 6: hipLaunchKernelGGL(k_linear_dx<6>, g, dim3(256), 0, s, a, kc); break;
-    case 7: hipLaunchKernelGGL(k_linear_dx<7>, g, dim3(256), 0, s, a, kc); break;
-    case 8: hipLaunchKernelGGL(k_linear_dx<8>, g, dim3(256), 0, s, a, kc); break;
-    default: hipLaunchKernelGGL(k_linear_dx<9>, g, dim3(256), 0, s, a, kc); break;
+    case 1: hipLaunchKernelGGL(k_linear_dx<1>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
+    case 2: hipLaunchKernelGGL(k_linear_dx<2>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
+    case 3: hipLaunchKernelGGL(k_linear_dx<3>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
+    case 4: hipLaunchKernelGGL(k_linear_dx<4>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
+    case 5: hipLaunchKernelGGL(k_linear_dx<5>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
+    case 6: hipLaunchKernelGGL(k_linear_dx<6>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
+    case 7: hipLaunchKernelGGL(k_linear_dx<7>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
+    case 8: hipLaunchKernelGGL(k_linear_dx<8>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
+    default: hipLaunchKernelGGL(k_linear_dx<9>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
   }
   return 0;
 }
