@@ -11,6 +11,7 @@
 //   k_wgrad               dW += A^T dY, db += colsum(dY) on the fp32 matrix cores, written in the reference's
 //                         [in, out] layout straight into the flat gradient buffer
 #include "sqair_glue.h"
+#include "sqair_bwd.h"
 
 typedef float f32x4_b __attribute__((ext_vector_type(4)));
 
@@ -638,17 +639,6 @@ __device__ __forceinline__ float delu_from_out(float o) { return o > 0.0f ? 1.0f
 // ------------------------------------------------------------------------------------------------
 // log-probability adjoint, all T frames in one launch (grid R x T), mirror of k_logprob.
 // ------------------------------------------------------------------------------------------------
-struct LogprobBwdArgs {
-  const float* rec_p; const float* rec_d; const float* rec_m;   // forward records [T][M][168] / merged [T+1][M][168]
-  const float* pstats; int ps_ld; const float* spre;
-  const float* g_lw; const float* g_dl;                          // [T][R]
-  float* d_rec_p; float* d_rec_d; float* d_rec_m;                // gradient records (accumulated)
-  float* d_pstats;                                               // [T][M][ps_ld] (written)
-  float* d_spre;                                                 // [T][R][128] (written)
-  const float* flat; float* flat_grad;
-  int t_global0;
-  SqairConfig cfg;
-};
 
 constexpr int SQ_SMALL_MAX = 1024;
 struct SmallParamTab { int n; int src[16]; int len[16]; int dst[16]; };
@@ -978,14 +968,6 @@ int sq_launch_logprob_bwd(const LogprobBwdArgs& a, POff po, Dims d, int T, hipSt
 // ------------------------------------------------------------------------------------------------
 // compaction adjoint: route the gradients of the merged slots of frame t+1 back to their source slots
 // ------------------------------------------------------------------------------------------------
-struct CompactBwdArgs {
-  const int* src;                 // [R][N]
-  const float* d_rec_next;        // gradient records of the merged slots [M][168]
-  const float* d_temporal_next; const float* d_prior_next;   // [M][nh]
-  float* d_rec_p; float* d_rec_d; // gradient records of this frame (accumulated)
-  float* d_temporal_p; float* d_prior_p;                     // [M][nh] (written: every propagation slot)
-  float* flat_grad;
-};
 __global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, const POff po, const Dims d) {
   const int r = blockIdx.x, tid = threadIdx.x, N = d.N, nh = d.nh, RW = rec::W;
   __shared__ int inv_s[2 * SQ_MAXN];  // source slot -> destination (or -1)
@@ -1024,19 +1006,6 @@ int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t 
 // slot-tail adjoint (mirror of k_slot_tail): presence logit -> steps-predictor output / hidden layer -> what,
 // then the what-sample adjoint (gated mixture for propagation).  One workgroup (128 threads) per row.
 // ------------------------------------------------------------------------------------------------
-struct TailBwdArgs {
-  int is_disc, slot;
-  const float* rec_prev; const float* rec_new; float* d_rec_new; float* d_rec_prev;  // records / gradient records
-  const float* s1h; int s1h_ld;         // saved hidden activations [R][nh/2]
-  const float* hraw; int h_ld; const float* enc; int enc_ld; const float* noise;
-  float* d_s1pre; int ds_ld;            // out: gradient of the hidden pre-activation [R][nh/2] (T1's extra columns)
-  float* d_s1pre2; int ds2_ld;          // optional second copy (the S1 columns of the PRE gradient, propagation)
-  int enc_pre;                          // disc: write d_enc as the PRE-activation gradient of the what head (softplus')
-  float* d_enc; int de_ld;              // out (=): gradient of (loc, scale) of the glimpse encoder
-  float* d_hraw; int dh_ld;             // out (=, prop): gradient of the raw head / gate pre-activations
-  const float* flat; float* flat_grad;
-  int w2_off, b2_off, wwhat_off;        // steps.l1 {w,b}; first `what` row of steps.l0.w ([in, nh/2] layout)
-};
 __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, const Dims d) {
   __shared__ float ds_s[128];
   extern __shared__ float wt_s[];  // the `what` rows of steps.l0.w, [nw][nsp + 1] (padded: conflict-free row reads)
@@ -1054,13 +1023,12 @@ __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, cons
   if (tid < nsp) {
     const float hv = a.s1h[(size_t)r * a.s1h_ld + tid];
     const float w2 = a.flat[a.w2_off + tid];
-    unsafeAtomicAdd(&a.flat_grad[a.w2_off + tid], hv * d_raw);
     const float g = d_raw * w2 * delu_from_out(hv);
     ds_s[tid] = g;
     a.d_s1pre[(size_t)r * a.ds_ld + tid] = g;
     if (a.d_s1pre2 != nullptr) a.d_s1pre2[(size_t)r * a.ds2_ld + tid] = g;
   }
-  if (tid == 0) unsafeAtomicAdd(&a.flat_grad[a.b2_off], d_raw);
+  if (tid == 0) a.d_raw_out[(size_t)r * a.dr_ld] = d_raw;
   __syncthreads();
   if (tid < nw) {
     const int c = tid;
@@ -1109,19 +1077,6 @@ int sq_launch_slot_tail_bwd(const TailBwdArgs& a, Dims d, hipStream_t s) {
 // record) -> adjoint of the where sample -> d(transform output) [R][8], d(previous where), d(mask).
 // modes as CropMode.  One workgroup per sequence.
 // ------------------------------------------------------------------------------------------------
-struct CropChainBwdArgs {
-  int mode, slot;
-  const float* img;                      // frame [B,H,W]
-  const float* rec_prev; const float* rec_new;   // forward records (where lives in rec_new for PROP2 / DISC)
-  float* d_rec_prev; float* d_rec_new;   // gradient records
-  const float* wb; int wb_ld;            // PROP1: raw where-bias output
-  float* d_wb;                           // PROP1 out: [M][wb_ld]
-  const float* mask; int mask_row_mul, mask_row_add; float* d_mask;  // optional; d_mask accumulated (+=)
-  const float* g_out; int g_row_mul, g_row_add;                       // d glimpse [rows][G2]
-  const float* tp; int tp_ld;            // saved transform output (loc 0:4, raw 4:8)
-  float* d_tp; int dtp_ld;               // out
-  const float* noise; const float* flat; float* flat_grad;
-};
 __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a, const POff po, const Dims d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* img_s = smem;
@@ -1196,27 +1151,73 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
           d_sc += dW * eps[i];
           const float off = a.flat[po.disc_scale_offset];
           d_raw = d_sc * sq_sigmoid(tp[4 + i] + off);
-          unsafeAtomicAdd(&a.flat_grad[po.disc_scale_offset], d_raw);
         } else {
           const float* ch = a.flat + po.cholesky;
           const float sci = a.rec_new[((size_t)r * d.N + slot) * RW + rec::WHERE_SCALE + i];
           float lin = 0.0f;
           for (int j = 0; j <= i; ++j) {
             lin += (tril4(ch, i, j) + (i == j ? 1.0f : 0.0f)) * eps[j];
-            const int q = i * 4 + j;
-            unsafeAtomicAdd(&a.flat_grad[po.cholesky + (q < 6 ? 4 + q : 15 - q)], dW * sci * eps[j]);
           }
           d_sc += dW * lin;
           const float off = a.flat[po.prop_scale_offset];
           d_raw = d_sc * sq_sigmoid(tp[4 + i] + off - 1.0f);
-          unsafeAtomicAdd(&a.flat_grad[po.prop_scale_offset], d_raw);
           a.d_rec_prev[((size_t)r * d.N + slot) * RW + rec::WHERE + i] += d_loc;  // loc = where_{t-1} + transform
         }
         a.d_tp[(size_t)r * a.dtp_ld + i] = d_loc;
         a.d_tp[(size_t)r * a.dtp_ld + 4 + i] = d_raw;
+        // total gradient of the sample, kept for k_where_param_grads (scale offsets / Cholesky factor: one batched
+        // reduction over all uses at the end of the sweep instead of 640-way contended atomics per launch)
+        drn[rec::WHERE + i] = dW;
       }
     }
   }
+}
+// gradients of transform.scale_offset (prop / disc) and of the Cholesky factor of the propagation where-posterior over all
+// (frame, row, slot) uses: rows of the tapes [T][R][N]; d_tp [2 phases][rows][ld], gradient records hold the total d where
+__global__ __launch_bounds__(256) void k_where_param_grads(const float* __restrict__ d_tp, int tp_ld, const float* __restrict__ d_rec_p,
+                                                           const float* __restrict__ rec_p, const float* __restrict__ noise, int rows,
+                                                           int RN, int N, int nzw, float* __restrict__ flat_grad, POff po) {
+  __shared__ float red[4][12];
+  float acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+    const int t = row / RN, rk = row - t * RN, r = rk / N, k = rk - r * N;
+    const float* tp_p = d_tp + (size_t)row * tp_ld;
+    const float* tp_d = d_tp + ((size_t)rows + row) * tp_ld;
+    acc[10] += tp_p[4] + tp_p[5] + tp_p[6] + tp_p[7];
+    acc[11] += tp_d[4] + tp_d[5] + tp_d[6] + tp_d[7];
+    const float* eps = noise + ((((size_t)t * (RN / N) + r) * 2 + 0) * N + k) * nzw;
+    const float* dr = d_rec_p + (size_t)row * rec::W;
+    const float* rp = rec_p + (size_t)row * rec::W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float g = dr[rec::WHERE + i] * rp[rec::WHERE_SCALE + i];
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const int q = i * 4 + j;  // fill_triangular index -> element of cholesky_scale
+        acc[q < 6 ? 4 + q : 15 - q] += g * eps[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = sq_wave_sum(acc[i]);
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 12; ++i) red[threadIdx.x >> 6][i] = acc[i];
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    float* dst = threadIdx.x < 10 ? flat_grad + po.cholesky + threadIdx.x
+                                  : (threadIdx.x == 10 ? flat_grad + po.prop_scale_offset : flat_grad + po.disc_scale_offset);
+    unsafeAtomicAdd(dst, v);
+  }
+}
+int sq_launch_where_param_grads(const float* d_tp, int tp_ld, const float* d_rec_p, const float* rec_p, const float* noise, int T,
+                                Dims d, float* flat_grad, POff po, hipStream_t s) {
+  const int rows = T * d.R * d.N;
+  hipLaunchKernelGGL(k_where_param_grads, dim3(32), dim3(256), 0, s, d_tp, tp_ld, d_rec_p, rec_p, noise, rows, d.R * d.N, d.N, d.nzw,
+                     flat_grad, po);
+  return 0;
 }
 int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
   const size_t shm = (size_t)d.H * d.W * sizeof(float);

@@ -13,82 +13,7 @@
 // record order and accumulate straight into "gradient records".
 #include "sqair_internal.h"
 #include "sqair_dx.h"
-
-// launchers from sqair_bwd.hip
-struct LogprobBwdArgs {
-  const float* rec_p; const float* rec_d; const float* rec_m;
-  const float* pstats; int ps_ld; const float* spre;
-  const float* g_lw; const float* g_dl;
-  float* d_rec_p; float* d_rec_d; float* d_rec_m;
-  float* d_pstats;
-  float* d_spre;
-  const float* flat; float* flat_grad;
-  int t_global0;
-  SqairConfig cfg;
-};
-struct CompactBwdArgs {
-  const int* src;
-  const float* d_rec_next;
-  const float* d_temporal_next; const float* d_prior_next;
-  float* d_rec_p; float* d_rec_d;
-  float* d_temporal_p; float* d_prior_p;
-  float* flat_grad;
-};
-struct TailBwdArgs {
-  int is_disc, slot;
-  const float* rec_prev; const float* rec_new; float* d_rec_new; float* d_rec_prev;
-  const float* s1h; int s1h_ld;
-  const float* hraw; int h_ld; const float* enc; int enc_ld; const float* noise;
-  float* d_s1pre; int ds_ld;
-  float* d_s1pre2; int ds2_ld;
-  int enc_pre;
-  float* d_enc; int de_ld;
-  float* d_hraw; int dh_ld;
-  const float* flat; float* flat_grad;
-  int w2_off, b2_off, wwhat_off;
-};
-struct CropChainBwdArgs {
-  int mode, slot;
-  const float* img;
-  const float* rec_prev; const float* rec_new;
-  float* d_rec_prev; float* d_rec_new;
-  const float* wb; int wb_ld;
-  float* d_wb;
-  const float* mask; int mask_row_mul, mask_row_add; float* d_mask;
-  const float* g_out; int g_row_mul, g_row_add;
-  const float* tp; int tp_ld;
-  float* d_tp; int dtp_ld;
-  const float* noise; const float* flat; float* flat_grad;
-};
-int sq_launch_logprob_bwd(const LogprobBwdArgs& a, POff po, Dims d, int T, hipStream_t s);
-int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t s);
-int sq_launch_slot_tail_bwd(const TailBwdArgs& a, Dims d, hipStream_t s);
-int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nslots, hipStream_t s);
-int sq_launch_gru_bwd_a(const float* d_hn, int dhn_ld, const float* z, int z_ld, const float* hc, int hc_ld,
-                        const float* hprev, int h_ld, float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh,
-                        int accumulate_dh, hipStream_t s, float* dup_z = nullptr, int dup_ld = 0);
-int sq_launch_gru_bwd_b(const float* d_rh, int drh_ld, const float* rg, int r_ld, const float* hprev, int h_ld,
-                        float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh, hipStream_t s, float* dup_r = nullptr,
-                        int dup_ld = 0);
-int sq_launch_dact2(const float* din, int in_ld, const float* saved, int s_ld, float* dout, int out_ld, int rows, int cols,
-                    int act_a, int act_b, int split, int acc, hipStream_t s);
-int sq_launch_colsum(const float* dy, int ld, int rows, int cols, float* out, int acc, hipStream_t s);
-int sq_launch_latent_sum_bwd(const float* d_c, const float* rec_p, const float* f_out, float* d_f, Dims d, hipStream_t s);
-int sq_launch_sum_slots(const float* d_rnn, float* d_pre_d, float* d_pre_disc, int B, int K, int N, int nh, hipStream_t s);
-int sq_launch_particle_sum(const float* in, float* out, int B, int K, int nh, hipStream_t s);
-int sq_launch_axpy2d(const float* x, int x_ld, float* y, int y_ld, int rows, int cols, int acc, hipStream_t s);
-int sq_launch_wgrad(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int Kdim,
-                    int Ndim, int accumulate, hipStream_t s, const int* rowmap = nullptr, const float* alpha_ptr = nullptr);
-int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_ld, const float* img, const float* mean_img,
-                                const float* g_ll, float* d_glimpse, float* d_rec, int d_rec_ld, float* d_mean_rows,
-                                float std_fg, float std_bg, int T, Dims d, hipStream_t s);
-int sq_launch_reduce_rows(const float* rows, float* out, int R, int P, int accumulate, hipStream_t s);
-int sq_launch_elbo_bwd(const float* iw, const float* sig, int T, int B, int K, float* g_lw, float* g_dl, hipStream_t s);
-int sq_launch_dot_scale(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s);
-int sq_launch_dot_scale_atomic(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s);
-int sq_launch_reduce_rows_atomic(const float* rows, float* out, int R, int P, hipStream_t s);
-int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim,
-                        hipStream_t s, const int* rowmap, const float* alpha_ptr, float* db_a, float* db_b);
+#include "sqair_bwd.h"
 
 // a few elementwise helpers local to the driver
 __global__ void k_mul2d(const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld, float* __restrict__ out,
@@ -162,7 +87,7 @@ struct BwdSpace {
   float *d_rec_m, *d_rec_p, *d_rec_d;          // gradient records
   float *d_tm[2], *d_pm[2];                    // d temporal / prior merged state, by frame parity
   float *d_temporal_p, *d_prior_p;
-  float *d_pstats, *d_spre;
+  float *d_pstats, *d_spre, *d_raw;
   // per-frame pre-activation gradients (kept for the batched weight gradients)
   float *d_pgru1, *d_hid1, *d_wb, *d_maskpre, *d_pea, *d_peb, *d_m1, *d_pre, *d_lea, *d_leb, *d_pre_d, *d_pre_disc;
   // per-slot pre-activation gradients [2][T][R][N][W]
@@ -190,7 +115,7 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   b.d_rec_m = take((T + 1) * M * rec::W); b.d_rec_p = take(MT * rec::W); b.d_rec_d = take(MT * rec::W);
   for (int i = 0; i < 2; ++i) { b.d_tm[i] = take(M * nh); b.d_pm[i] = take(M * nh); }
   b.d_temporal_p = take(M * nh); b.d_prior_p = take(M * nh);
-  b.d_pstats = take(MT * PS_LD); b.d_spre = take(T * R * 128);
+  b.d_pstats = take(MT * PS_LD); b.d_spre = take(T * R * 128); b.d_raw = take(2 * MT);
   b.d_pgru1 = take(MT * 3 * nh); b.d_hid1 = take(MT * 256); b.d_wb = take(MT * WB_LD); b.d_maskpre = take(MT * G2);
   b.d_pea = take(MT * nh); b.d_peb = take(MT * nh); b.d_m1 = take(MT * M1_LD); b.d_pre = take(MT * pre_ld);
   b.d_lea = take(MT * nh); b.d_leb = take(MT * nh); b.d_pre_d = take(T * R * nh); b.d_pre_disc = take((int64_t)T * B * nh);
@@ -379,7 +304,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         TailBwdArgs ta; memset(&ta, 0, sizeof(ta));
         ta.is_disc = 1; ta.slot = j; ta.rec_prev = rec_prev; ta.rec_new = rec_d_t; ta.d_rec_new = d_rec_d_t;
         ta.d_rec_prev = d_rec_prev; ta.s1h = cslotp(w.s1h, S1_LD, t, 1, j); ta.s1h_ld = s1l; ta.enc = enc; ta.enc_ld = el;
-        ta.noise = nz; ta.d_s1pre = d_t1 + nh; ta.ds_ld = t1l; ta.d_enc = d_enc3; ta.de_ld = el; ta.enc_pre = 1; ta.flat = flat;
+        ta.noise = nz; ta.d_s1pre = d_t1 + nh; ta.ds_ld = t1l; ta.d_enc = d_enc3; ta.de_ld = el; ta.enc_pre = 1; ta.d_raw_out = slotp(b.d_raw, 1, t, 1, j); ta.dr_ld = N; ta.flat = flat;
         ta.flat_grad = flat_grad; ta.w2_off = po.disc_steps_l1_w; ta.b2_off = po.disc_steps_l1_b;
         ta.wwhat_off = (int)P(h, "disc.steps.l0.w") + nh * nsp;
         sq_launch_slot_tail_bwd(ta, d, s);
@@ -461,7 +386,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         ta.d_rec_prev = d_rec_prev; ta.s1h = cslotp(w.s1h, S1_LD, t, 0, k); ta.s1h_ld = s1l;
         ta.hraw = cslotp(w.hraw, HRAW_LD, t, 0, k); ta.h_ld = hl; ta.enc = enc; ta.enc_ld = el; ta.noise = nz;
         ta.d_s1pre = d_t1 + nh; ta.ds_ld = t1l; ta.d_s1pre2 = d_pre_k + 2 * nh; ta.ds2_ld = pre_rld;
-        ta.d_enc = b.d_enc; ta.de_ld = ENC_LD; ta.d_hraw = d_hraw; ta.dh_ld = hl;
+        ta.d_enc = b.d_enc; ta.de_ld = ENC_LD; ta.d_hraw = d_hraw; ta.dh_ld = hl; ta.d_raw_out = slotp(b.d_raw, 1, t, 0, k); ta.dr_ld = N;
         ta.flat = flat; ta.flat_grad = flat_grad; ta.w2_off = po.prop_steps_l1_w; ta.b2_off = po.prop_steps_l1_b;
         ta.wwhat_off = (int)P(h, "prop.steps.l0.w") + 2 * nh * nsp;
         sq_launch_slot_tail_bwd(ta, d, s);
@@ -621,6 +546,12 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     wgrad(L_DISC_T2, {{w.t1 + ph1 * T1_LD, T1_LD}}, b.d_t2 + ph1 * nh, nh, MT);
     wgrad(L_DISC_T3, {{w.t2 + ph1 * nh, nh}}, b.d_tp + ph1 * TP_LD, TP_LD, MT);
     wgrad(L_DISC_S1, {{w.rec_d_all, RW}}, b.d_t1 + ph1 * T1_LD + nh, T1_LD, MT);
+    sq_launch_where_param_grads(b.d_tp, TP_LD, b.d_rec_p, w.rec_p_all, noise, T, d, flat_grad, po, s);
+    // output layer of the steps predictors (nh/2 -> 1): d w2 = s1h^T d_raw, d b2 = sum d_raw, all uses at once
+    sq_launch_wgrad_acc(w.s1h, S1_LD, b.d_raw, 1, flat_grad + po.prop_steps_l1_w, 1, MT, nsp, 1, s, nullptr, nullptr,
+                        flat_grad + po.prop_steps_l1_b, nullptr);
+    sq_launch_wgrad_acc(w.s1h + ph1 * S1_LD, S1_LD, b.d_raw + ph1, 1, flat_grad + po.disc_steps_l1_w, 1, MT, nsp, 1, s, nullptr, nullptr,
+                        flat_grad + po.disc_steps_l1_b, nullptr);
   }
   SQ_CHECK_HIP(hipGetLastError());
   return 0;
