@@ -199,3 +199,34 @@ def test_training_mode_forward_is_bitwise_identical():
     for k, v in core.out.items():
         assert torch.equal(v, ref[k]), k
     assert torch.equal(core.log_weights, lw)
+
+
+@pytest.mark.parametrize("K,N,T,B,hw", [(3, 3, 3, 8, (50, 50)), (5, 4, 4, 13, (50, 50)), (2, 2, 2, 3, (64, 48))])
+def test_xcd_persistent_forward_matches_launch_per_layer(K, N, T, B, hw):
+    """The frame loop as ONE XCD-persistent launch (per-XCD teams, L2 hand-offs, bounded team barriers) against the
+    launch-per-layer path: same presence decisions, every output within 5e-5 of its scale (the batched layers use a
+    different K-split, so the last bits differ), no barrier time-out.  B*K is deliberately not a multiple of 16."""
+    from sqair_amd.model import Model, SqairCore
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    d = make_sequences(B, T=T, canvas=hw, seed=31)
+    obs = to_float(d["imgs"])
+    core = SqairCore(F, hw)
+    core.set_params(params32(F, hw, 5, 0.05, obs.mean((0, 1))))
+    Model(obs, None, core, K, presence=d["nums"])
+    with core.on_stream():
+        core.noise.copy_(torch.as_tensor(draw_noise(np.random.default_rng(7), T, B * K, N, 55)).reshape(core.noise.shape))
+        core.forward()
+        core.stream.synchronize()
+        ref = {k: v.clone() for k, v in core.out.items()}
+        lw = core.log_weights.clone()
+        for rep in range(2):  # the second pass reuses the cached op list
+            for v in core.out.values():
+                v.zero_()
+            core.forward(persistent=True)
+            core.stream.synchronize()
+            assert core.persistent_status() == 0
+            assert torch.equal(core.out["presence"], ref["presence"])
+            for k, v in core.out.items():
+                scale = max(float(ref[k].abs().max()), 1e-6)
+                assert float((v - ref[k]).abs().max()) <= 5e-5 * scale, (k, rep)
+            assert float((core.log_weights - lw).abs().max()) <= 1e-4 * float(lw.abs().max())
