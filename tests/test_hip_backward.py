@@ -394,3 +394,38 @@ def test_full_size_cfg2_backward_is_finite_and_times():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     print("cfg2 gradient evaluation: %.2f ms (%d graph nodes)" % (dt * 1e3, core.train_graph_nodes))
+
+
+def test_checkpoint_round_trip_restores_parameters_and_optimiser_slots(tmp_path):
+    """a checkpoint keyed by TF variable names restores parameters, RMSProp slots and the step."""
+    from sqair_amd import checkpoint as ck
+    from sqair_amd.data import make_sequences, to_float
+    from sqair_amd.model import Model, SqairCore
+    from sqair_amd.train import Trainer
+    from tests.hip_util import params32
+    K, N, T, B, hw = 2, 3, 2, 2, (50, 50)
+    F = make_flags(k_particles=K, n_steps_per_image=N, learning_rate=1e-4)
+    obs = to_float(make_sequences(B, T=T, canvas=hw, seed=2)["imgs"])
+    core = SqairCore(F, hw)
+    core.set_params(params32(F, hw, 4, 0.05, obs.mean((0, 1))))
+    tr = Trainer(Model(obs, None, core, K, outputs="minimal"), F)
+    for i in range(2):
+        tr.step(generator=torch.Generator(device="cuda").manual_seed(i))
+    torch.cuda.synchronize()
+    path = str(tmp_path / "model.ckpt.npz")
+    ck.save_checkpoint(path, core, tr.opt, global_step=tr.step_no)
+    core2 = SqairCore(F, hw)
+    core2.set_params(params32(F, hw, 9, 0.05))
+    tr2 = Trainer(Model(obs, None, core2, K, outputs="minimal"), F)
+    step = ck.load_checkpoint(path, core2, tr2.opt)
+    torch.cuda.synchronize()
+    assert step == 2
+    assert torch.equal(core2.flat, core.flat) and torch.equal(tr2.opt.ms, tr.opt.ms) and torch.equal(tr2.opt.mom, tr.opt.mom)
+    # and the restored model evaluates identically
+    g = torch.Generator(device="cuda")
+    for c in (core, core2):
+        with c.on_stream():
+            c.draw_noise(g.manual_seed(5))
+            c.forward()
+        c.stream.synchronize()
+    assert torch.equal(core.log_weights, core2.log_weights)
