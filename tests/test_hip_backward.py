@@ -429,3 +429,24 @@ def test_checkpoint_round_trip_restores_parameters_and_optimiser_slots(tmp_path)
             c.forward()
         c.stream.synchronize()
     assert torch.equal(core.log_weights, core2.log_weights)
+
+
+@pytest.mark.parametrize("flags", [
+    dict(prop_prior_type="rw"),
+    dict(prop_prior_type="guided", masked_glimpse=False),
+    dict(disc_prior_type="geom", rec_where_prior=False),
+])
+def test_full_backward_flag_variants(flags):
+    """The adjoint branches the default flags never take: random-walk / guided propagation priors (the prior statistics
+    feed back into z_{t-1}), geometric step prior, fixed where prior, unmasked glimpses."""
+    report, ref, _ = _full_backward_case(K=3, N=3, T=3, B=3, hw=(50, 50), seed=11, flags=flags)
+    assert float(ref.prop_pres.sum()) > 0
+    _check_report(report)
+
+
+@pytest.mark.parametrize("K,N,T,B,hw", [(2, 6, 2, 2, (50, 50)), (2, 3, 2, 2, (128, 128)), (4, 2, 3, 5, (40, 56))])
+def test_full_backward_other_shapes(K, N, T, B, hw):
+    """N = 6 slots (BASELINE configs[3]), 128x128 frames (configs[4]: the frame no longer fits the default LDS window),
+    a non-square frame with B*K not a multiple of the 16-row MFMA tile."""
+    report, _, _ = _full_backward_case(K, N, T, B, hw, seed=21)
+    _check_report(report)
