@@ -46,7 +46,17 @@ void sq_set_error(SqairHandle*, const std::string&) {}
 #include "sqair_linear_kernel.inc"
 #undef SQ_KLINEAR_NAME
 #undef SQ_ABL_NO_B
+#define SQ_PREFETCH_NEXT_W
+#define SQ_KLINEAR_NAME k_aff_pf
+#include "sqair_linear_kernel.inc"
+#undef SQ_KLINEAR_NAME
+#undef SQ_PREFETCH_NEXT_W
 #undef SQ_ROWTILE_XCD_AFFINITY
+#define SQ_PREFETCH_NEXT_W
+#define SQ_KLINEAR_NAME k_full_pf
+#include "sqair_linear_kernel.inc"
+#undef SQ_KLINEAR_NAME
+#undef SQ_PREFETCH_NEXT_W
 
 template <class F>
 double time_graph(hipStream_t s, int nodes, int reps, F launch) {
@@ -92,24 +102,26 @@ int main() {
   RUN("full, 40 WG (M=160, N=64)", k_full, 160, 4, false);
   RUN("full, 16 WG (M=16, N=256)", k_full, 16, 16, false);
   RUN("full, 640 WG (M=640)", k_full, 640, 16, true);
-  // instruction-cache pressure: rotate through differently-instantiated copies of the same kernel
-  {
-    typedef void (*KF)(const LinArgs, const int, const int, unsigned long long*);
-    KF ks[] = {k_full<4>, k_full<5>, k_full<6>, k_full<7>, k_full<8>, k_full<9>, k_full<10>, k_noepi<4>, k_noepi<5>, k_noepi<6>,
-               k_noepi<7>, k_noepi<8>, k_nob<4>, k_nob<5>, k_nob<6>, k_nob<7>, k_aff<4>, k_aff<5>, k_aff<6>, k_aff<7>};
-    for (int nk : {1, 4, 8, 12, 20}) {
-      char nm[64]; snprintf(nm, 64, "rotating %d kernel instantiations", nk);
-      printf("%-34s %.2f us/node\n", nm, time_graph(s, NODES, REPS, [&](int i) {
-        LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);
-        hipLaunchKernelGGL(ks[i % nk], dim3(16, 10), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a, (unsigned long long*)nullptr); }));
-    }
-  }
   for (int L : {1, 16, 64}) {
     char nm[64]; snprintf(nm, 64, "row-tile XCD affinity, %d w mats", L);
     printf("%-34s %.2f us/node\n", nm, time_graph(s, NODES, REPS, [&](int i) {
       LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);
       a.wp = w + 256 + (size_t)(i % L) * nt * kc * 256;
       hipLaunchKernelGGL(k_aff<4>, dim3(256), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a, (unsigned long long*)nullptr); }));
+  }
+  for (int L : {16, 64}) {
+    char nm[64]; snprintf(nm, 64, "affinity + next-W prefetch, %d mats", L);
+    printf("%-34s %.2f us/node\n", nm, time_graph(s, NODES, REPS, [&](int i) {
+      LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);
+      a.wp = w + 256 + (size_t)(i % L) * nt * kc * 256;
+      a.e1 = w + 256 + (size_t)((i + 1) % L) * nt * kc * 256;
+      hipLaunchKernelGGL(k_aff_pf<4>, dim3(256), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a, (unsigned long long*)nullptr); }));
+    snprintf(nm, 64, "n-tile map + next-W prefetch, %d mats", L);
+    printf("%-34s %.2f us/node\n", nm, time_graph(s, NODES, REPS, [&](int i) {
+      LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);
+      a.wp = w + 256 + (size_t)(i % L) * nt * kc * 256;
+      a.e1 = w + 256 + (size_t)((i + 1) % L) * nt * kc * 256;
+      hipLaunchKernelGGL(k_full_pf<4>, dim3(16, 10), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a, (unsigned long long*)nullptr); }));
   }
   printf("%-34s %.2f us/node\n", "row-tile XCD affinity, no B loads", time_graph(s, NODES, REPS, [&](int i) {
       LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);

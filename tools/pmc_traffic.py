@@ -1,0 +1,43 @@
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> profiles/hbm_traffic.json.
+Run on the GPU box:  cd /tmp && export TMPDIR=/tmp &&
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python $REPO/bench.py --steps 3 --warmup 1 --train-steps 3 --no-cpu-baseline
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python $REPO/bench.py ... (same)
+  python $REPO/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $REPO/gpurun_out/hbm_traffic.json
+bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE doubled on gfx950, MI355X_MICROARCH.md section HBM)."""
+import collections, csv, glob, json, os, sys
+
+
+def load(d, counter):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            name = name.split("<")[0]
+            agg[name][0] += 1
+            agg[name][1] += float(r["Counter_Value"])
+    return agg
+
+
+fa, wa = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+out = {}
+for k in sorted(set(fa) | set(wa)):
+    nf, f = fa.get(k, [0, 0.0])
+    nw, w = wa.get(k, [0, 0.0])
+    n = max(nf, nw, 1)
+    if not k.startswith("k_"):
+        continue
+    out[k] = dict(launches=n, fetch_kb_raw=f / max(nf, 1), write_kb=w / max(nw, 1),
+                  hbm_bytes_per_launch=(2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0)
+lin = [v for k, v in out.items() if k in ("k_linear", "k_linear_rows")]
+tot_n = sum(v["launches"] for v in lin)
+blob = dict(k_linear_bytes_per_launch=sum(v["hbm_bytes_per_launch"] * v["launches"] for v in lin) / max(tot_n, 1),
+            method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (python bench.py --steps 3 --warmup 1 "
+                   "--train-steps 3 --no-cpu-baseline); bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE doubled per "
+                   "MI355X_MICROARCH.md (gfx950 reports half the bytes of 16 B/lane coalesced reads), WRITE_SIZE uncalibrated; "
+                   "k_linear_bytes_per_launch = average over all k_linear / k_linear_rows launches",
+            per_kernel=out)
+json.dump(blob, open(sys.argv[3], "w"), indent=1)
+print(json.dumps({k: round(v["hbm_bytes_per_launch"]) for k, v in out.items()}, indent=0))
