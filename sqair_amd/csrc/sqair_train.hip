@@ -93,7 +93,7 @@ struct BwdSpace {
   // per-slot pre-activation gradients [2][T][R][N][W]
   float *d_rnn, *d_t1, *d_t2, *d_tp, *d_e1, *d_e2, *d_enc3, *d_gru1, *d_hraw;
   // scratch
-  float *d_mask, *d_g, *d_g1, *d_c, *dcat, *tmp, *tmp2, *d_r[2], *dhn, *d_rh, *d_enc, *d_hid1out;
+  float *d_mask, *d_g, *d_g1, *d_c, *tmp, *d_r[2], *dhn, *d_rh, *d_enc;
   float *d_gl, *d_mean_rows, *bufa, *bufb, *d_ia, *d_ib, *zs, *rs, *rh;
   int64_t total;
 };
@@ -124,9 +124,9 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   b.d_e1 = take(S * nh); b.d_e2 = take(S * nh); b.d_enc3 = take(S * ENC_LD); b.d_gru1 = take(MT * 3 * nh);
   b.d_hraw = take(MT * HRAW_LD);
   b.d_mask = take(M * G2); b.d_g = take(R * G2); b.d_g1 = take(M * G2); b.d_c = take(R * nh);
-  b.dcat = take(M * 512); b.tmp = take(M * 512); b.tmp2 = take(M * 512);
+  b.tmp = take(M * 512);
   b.d_r[0] = take(R * nh); b.d_r[1] = take(R * nh); b.dhn = take(M * nh); b.d_rh = take(M * nh);
-  b.d_enc = take(R * ENC_LD); b.d_hid1out = take(M * 256);
+  b.d_enc = take(R * ENC_LD);
   const int64_t big = MT * (nh > G2 ? nh : G2);
   b.d_gl = take(MT * G2); b.d_mean_rows = take(T * R * P_); b.bufa = take(big); b.bufb = take(big);
   b.d_ia = take((int64_t)T * B * nh); b.d_ib = take((int64_t)T * B * nh);
