@@ -183,3 +183,86 @@ def test_fp32_mode_close_to_fp64():
     b = O.SqairOracle(P, cfg, torch.float32).model(obs, nz)
     if torch.equal(a.presence, b.presence.double()):
         assert abs(float(a.elbo_iwae) - float(b.elbo_iwae)) <= 1e-4 * abs(float(a.elbo_iwae))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Cross-checks of the oracle's primitives against INDEPENDENT implementations of the same published definitions
+# (torch.distributions / torch.nn / scipy were not written from this repo's restatement): as close as this container
+# gets to pinning the third-party arithmetic (TF 1.6 contrib.distributions, Sonnet cells) without TF.
+# ---------------------------------------------------------------------------------------------------------------------
+def test_log_probs_match_torch_distributions():
+    import torch.distributions as D
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(7, 5, dtype=torch.float64, generator=g)
+    loc = torch.randn(7, 5, dtype=torch.float64, generator=g)
+    scale = torch.rand(7, 5, dtype=torch.float64, generator=g) + 0.1
+    assert torch.allclose(O.normal_log_prob(x, loc, scale), D.Normal(loc, scale).log_prob(x), atol=1e-12)
+    logits = torch.randn(9, dtype=torch.float64, generator=g) * 5
+    for v in (0.0, 1.0):
+        b = torch.full_like(logits, v)
+        assert torch.allclose(O.bernoulli_log_prob(b, logits), D.Bernoulli(logits=logits).log_prob(b), atol=1e-12)
+    # extreme logits (the -88 of absent slots) stay finite and exact
+    big = torch.tensor([-88.0, 88.0], dtype=torch.float64)
+    assert torch.allclose(O.bernoulli_log_prob(torch.tensor([0.0, 1.0], dtype=torch.float64), big),
+                          torch.zeros(2, dtype=torch.float64), atol=1e-30)
+    # MultivariateNormalTriL
+    L = torch.tril(torch.randn(6, 4, 4, dtype=torch.float64, generator=g) * 0.3, diagonal=-1) + torch.diag_embed(
+        torch.rand(6, 4, dtype=torch.float64, generator=g) + 0.5)
+    xm, lm = torch.randn(6, 4, dtype=torch.float64, generator=g), torch.randn(6, 4, dtype=torch.float64, generator=g)
+    want = D.MultivariateNormal(lm, scale_tril=L).log_prob(xm)
+    assert torch.allclose(O.SqairOracle.mvn_tril_log_prob(xm, lm, L), want, atol=1e-10)
+
+
+def test_fill_triangular_matches_the_documented_examples():
+    """tfd.fill_triangular docstring: [1..6] -> [[4,0,0],[6,5,0],[3,2,1]]; [1..10] (n = 4) follows the same clockwise
+    spiral: rows [7,0,0,0], [8? ...] are fixed by reshape(concat(v[n:], reverse(v)), [n, n])."""
+    m3 = O.fill_triangular(torch.arange(1.0, 7.0), 3)
+    assert m3.tolist() == [[4.0, 0.0, 0.0], [6.0, 5.0, 0.0], [3.0, 2.0, 1.0]]
+    m4 = O.fill_triangular(torch.arange(1.0, 11.0), 4)
+    assert m4.tolist() == [[5.0, 0.0, 0.0, 0.0], [9.0, 10.0, 0.0, 0.0], [8.0, 7.0, 6.0, 0.0], [4.0, 3.0, 2.0, 1.0]]
+
+
+def test_vanilla_rnn_matches_torch_rnncell_and_gru_matches_its_equations():
+    g = torch.Generator().manual_seed(1)
+    nin, nh, B = 7, 5, 3
+    P = {"c.i2h.w": torch.randn(nin, nh, dtype=torch.float64, generator=g), "c.i2h.b": torch.randn(nh, dtype=torch.float64, generator=g),
+         "c.h2h.w": torch.randn(nh, nh, dtype=torch.float64, generator=g), "c.h2h.b": torch.randn(nh, dtype=torch.float64, generator=g)}
+    x, h = torch.randn(B, nin, dtype=torch.float64, generator=g), torch.randn(B, nh, dtype=torch.float64, generator=g)
+    cell = torch.nn.RNNCell(nin, nh, nonlinearity="tanh").double()
+    with torch.no_grad():
+        cell.weight_ih.copy_(P["c.i2h.w"].T); cell.weight_hh.copy_(P["c.h2h.w"].T)
+        cell.bias_ih.copy_(P["c.i2h.b"]); cell.bias_hh.copy_(P["c.h2h.b"])
+        assert torch.allclose(O.vanilla_rnn(P, "c", x, h), cell(x, h), atol=1e-12)
+    # snt.GRU is NOT torch.nn.GRUCell (Sonnet applies the reset gate before the recurrent matmul): check the limits
+    # that pin the equations instead: z -> 0 keeps the state, z -> 1 with r -> 0 gives tanh(x W_h + b_h)
+    G = {"g.w" + k: torch.randn(nin, nh, dtype=torch.float64, generator=g) for k in "zrh"}
+    G.update({"g.u" + k: torch.randn(nh, nh, dtype=torch.float64, generator=g) for k in "zrh"})
+    G.update({"g.b" + k: torch.zeros(nh, dtype=torch.float64) for k in "zrh"})
+    keep = dict(G); keep["g.bz"] = torch.full((nh,), -60.0, dtype=torch.float64)
+    assert torch.allclose(O.gru(keep, "g", x, h), h, atol=1e-12)
+    new = dict(G); new["g.bz"] = torch.full((nh,), 60.0, dtype=torch.float64); new["g.br"] = torch.full((nh,), -60.0, dtype=torch.float64)
+    assert torch.allclose(O.gru(new, "g", x, h), torch.tanh(x @ G["g.wh"]), atol=1e-10)
+    # and with r -> 1 the candidate sees the full recurrent term
+    full = dict(new); full["g.br"] = torch.full((nh,), 60.0, dtype=torch.float64)
+    assert torch.allclose(O.gru(full, "g", x, h), torch.tanh(x @ G["g.wh"] + h @ G["g.uh"]), atol=1e-10)
+
+
+def test_step_distributions_match_independent_formulas():
+    import torch.distributions as D
+    from scipy.special import logsumexp
+    # Categorical(logits).log_prob = log_softmax
+    lg = torch.tensor([[0.3, -1.2, 2.0, 0.0]], dtype=torch.float64)
+    want = lg.numpy()[0] - logsumexp(lg.numpy()[0])
+    assert np.allclose(D.Categorical(logits=lg).log_prob(torch.tensor([2])).item(), want[2])
+    assert np.allclose(torch.log_softmax(lg, -1).numpy()[0], want)
+    # tfd.Geometric(probs=p) counts failures before the first success: log p(k) = k log(1 - p) + log p
+    p = 0.25
+    for k in range(4):
+        assert np.isclose(D.Geometric(probs=torch.tensor(p)).log_prob(torch.tensor(float(k))).item(), k * np.log(1 - p) + np.log(p))
+    # NumStepsDistribution: the modified geometric built from Bernoulli step probabilities sums to one and its last bin
+    # is the probability of all steps succeeding
+    pr = torch.tensor([[0.9, 0.5, 0.2]], dtype=torch.float64)
+    joint = O.bernoulli_to_modified_geometric(pr)
+    assert np.isclose(joint.sum().item(), 1.0) and np.isclose(joint[0, -1].item(), 0.9 * 0.5 * 0.2)
+    assert np.isclose(joint[0, 1].item(), 0.9 * (1 - 0.5))
+    assert np.isclose(O.num_steps_log_prob(joint, torch.tensor([1.0])).item(), np.log(0.45))
