@@ -8,7 +8,120 @@ typedef float sq_f32x4 __attribute__((ext_vector_type(4)));
 struct LdPlain {
   static __device__ __forceinline__ float f(const float* p) { return *p; }
   static __device__ __forceinline__ sq_f32x4 f4(const float* p) { return *reinterpret_cast<const sq_f32x4*>(p); }
+  static __device__ __forceinline__ void f4x4(const float* p0, const float* p1, const float* p2, const float* p3, sq_f32x4& v0,
+                                              sq_f32x4& v1, sq_f32x4& v2, sq_f32x4& v3) {
+    v0 = f4(p0); v1 = f4(p1); v2 = f4(p2); v3 = f4(p3);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMAs (see sqair_linear_kernel.inc)
+  }
 };
+
+// ---- dense-layer tile shared by the grouped launch (sqair_linear.hip) and the persistent executor -----------------------
+// operand addressing shared by both tilings
+struct XSegs {
+  const float* rp[4];
+  int cum[4], lim[4];
+};
+__device__ __forceinline__ XSegs x_segs(const LinArgs& a, int arow) {
+  XSegs sg;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool on = i < a.nseg;
+    const LinSeg& seg = a.seg[on ? i : 0];
+    const int row = seg.rmul ? (int)__umulhi((unsigned)arow, seg.rmul) : arow;
+    sg.rp[i] = seg.p + (size_t)row * seg.ld;
+    sg.cum[i] = on ? c : 0x7fffffff;
+    sg.lim[i] = ((seg.width + 3) & ~3) - 4;
+    c += on ? (seg.width + 15) >> 4 : 0;
+  }
+  return sg;
+}
+__device__ __forceinline__ const float* x_aptr(const XSegs& sg, int g, int kq) {
+  const bool s1 = g >= sg.cum[1], s2 = g >= sg.cum[2], s3 = g >= sg.cum[3];
+  const float* rp = s3 ? sg.rp[3] : (s2 ? sg.rp[2] : (s1 ? sg.rp[1] : sg.rp[0]));
+  const int cb = s3 ? sg.cum[3] : (s2 ? sg.cum[2] : (s1 ? sg.cum[1] : 0));
+  const int lim = s3 ? sg.lim[3] : (s2 ? sg.lim[2] : (s1 ? sg.lim[1] : sg.lim[0]));
+  return rp + min((g - cb) * 16 + kq * 4, lim);
+}
+// epilogue of one output element (m, n) with pre-activation sum v (bias and addend already included)
+__device__ __forceinline__ void x_epilogue(const LinArgs& a, int m, int n, float v, float p_e0, float p_e1, float p_scale) {
+  if (a.epi == EPI_ACT) {
+    v = sq_act(v, n < a.act_split ? a.act_a : a.act_b);
+    a.out[(size_t)m * a.out_ld + n] = v * a.scale * p_scale;
+  } else if (a.epi == EPI_GRU1) {
+    const int nh = a.nh;
+    if (n < nh) a.out[(size_t)m * a.out_ld + n] = sq_sigmoid(v);
+    else if (n < 2 * nh) {
+      const float rg = sq_sigmoid(v);
+      a.o1[(size_t)m * a.o1_ld + (n - nh)] = rg * p_e0;
+      if (a.o3 != nullptr) a.o3[(size_t)m * a.o3_ld + (n - nh)] = rg;
+    } else a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
+  } else {
+    const float hc = tanhf(v);
+    a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1) * p_e0 + p_e1 * hc;
+    if (a.o1 != nullptr) a.o1[(size_t)m * a.o1_ld + n] = hc;
+  }
+}
+
+// One 16x16 output tile by one workgroup: 4 waves split K, LDS reduce (arithmetic order of k_linear).  LD selects how
+// activations are loaded (plain for ordinary launches, L1-bypassing inside the persistent executor).
+template <class LD>
+__device__ void x_linear_tile(const LinArgs& a, int kc_total, int tile_n, int mbase, int m1, float* red) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
+  const int arow = min(mbase + (lane & 15), m1 - 1);
+  const int m = mbase + (tid >> 4);
+  const int n = tile_n * 16 + (tid & 15);
+  const bool live = m < m1 && n < a.N;
+  const int mc = min(m, m1 - 1), nc = min(n, a.N - 1);
+  const float* pb = a.bias + nc;
+  const bool use_add = a.add != nullptr && nc < a.add_n;
+  const bool g1 = a.epi == EPI_GRU1 && nc >= a.nh && nc < 2 * a.nh;
+  const bool g2 = a.epi == EPI_GRU2;
+  const int mcd = a.add_rmul ? (int)__umulhi((unsigned)mc, a.add_rmul) : mc;
+  const float* pa = use_add ? a.add + (size_t)mcd * a.add_ld + nc : pb;
+  const float* pe0 = g1 ? a.e0 + (size_t)mc * a.e0_ld + (nc - a.nh) : (g2 ? a.e0 + (size_t)mc * a.e0_ld + nc : pb);
+  const float* pe1 = g2 ? a.e1 + (size_t)mc * a.e1_ld + nc : pb;
+  const float p_bias = *pb;
+  float p_add = LD::f(pa);
+  const float p_e0 = LD::f(pe0), p_e1 = LD::f(pe1);
+  const float p_scale = a.scale_ptr != nullptr ? *a.scale_ptr : 1.0f;
+  p_add = use_add ? p_add : 0.0f;
+  const XSegs sg = x_segs(a, arow);
+  sq_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  const sq_f32x4* __restrict__ wp = reinterpret_cast<const sq_f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
+  const sq_f32x4* __restrict__ wz = reinterpret_cast<const sq_f32x4*>(a.wzero) + lane;
+  const int nmine = (kc_total - wave + 3) >> 2;
+  constexpr int NCH = 4;
+#pragma unroll 1
+  for (int base = 0; base < nmine; base += NCH) {
+    sq_f32x4 av[NCH], bv[NCH];
+    const float* ap[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const bool valid = base + j < nmine;
+      const int g = valid ? wave + 4 * (base + j) : wave;
+      ap[j] = x_aptr(sg, g, kq);
+      bv[j] = *(valid ? wp + (size_t)g * 64 : wz);
+    }
+    LD::f4x4(ap[0], ap[1], ap[2], ap[3], av[0], av[1], av[2], av[3]);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
+    }
+  }
+  float* r = red + wave * 256;
+  r[(4 * kq + 0) * 16 + (lane & 15)] = acc0.x + acc1.x;
+  r[(4 * kq + 1) * 16 + (lane & 15)] = acc0.y + acc1.y;
+  r[(4 * kq + 2) * 16 + (lane & 15)] = acc0.z + acc1.z;
+  r[(4 * kq + 3) * 16 + (lane & 15)] = acc0.w + acc1.w;
+  __syncthreads();
+  if (live) x_epilogue(a, m, n, red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + p_bias + p_add, p_e0, p_e1, p_scale);
+  __syncthreads();
+}
+
 
 template <class LD>
 __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int r, int slot, float* smem) {
