@@ -1,0 +1,68 @@
+"""End-to-end training run on synthetic moving glyphs with the reference's driver semantics (scripts/experiment.py:126-185):
+minibatches drawn with replacement (data.py:203-216), RMSProp(momentum .9) with the piecewise-constant learning rate,
+VIMCO target, K = 5 particles; logs the training ELBO per frame and the validation ELBO on held-out sequences.
+    python tools/train_demo.py [steps] [lr] > profiles/r01_train_curve.json
+"""
+import json
+import sys
+import time
+
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+
+from sqair_amd.data import make_sequences, to_float
+from sqair_amd.dataio import MinibatchFeed
+from sqair_amd.flags import make_flags
+from sqair_amd.model import Model, SqairCore
+from sqair_amd.params import init_params
+from sqair_amd.train import Trainer
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+lr = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-5
+T, B, K, N, hw = 10, 32, 5, 4, (50, 50)
+F = make_flags(k_particles=K, n_steps_per_image=N, learning_rate=lr, train_itr=steps)
+train = make_sequences(2048, T=T, canvas=hw, n_objects=(0, 2), seed=1)
+valid = make_sequences(256, T=T, canvas=hw, n_objects=(0, 2), seed=2)
+feed = MinibatchFeed(dict(imgs=to_float(train["imgs"]), nums=train["nums"], coords=train["coords"]), B, shuffle=True, seed=0)
+vfeed = MinibatchFeed(dict(imgs=to_float(valid["imgs"]), nums=valid["nums"], coords=valid["coords"]), B, shuffle=False)
+mean_img = to_float(train["imgs"]).mean((0, 1))
+core = SqairCore(F, hw)
+core.set_params({k: np.asarray(v, dtype=np.float32) for k, v in init_params(F, hw, seed=0, mean_img=mean_img).items()})
+model = Model(to_float(train["imgs"][:, :B]), None, core, K, outputs="minimal")
+trainer = Trainer(model, F)
+gen = torch.Generator(device="cuda").manual_seed(0)
+
+
+def validate():
+    tot, n = 0.0, 0
+    with core.on_stream():
+        for _ in range(256 // B):
+            core.obs.copy_(torch.as_tensor(vfeed.next()["imgs"]))
+            core.draw_noise(gen)
+            core.forward(use_graph=True)
+            tot += float(core.scalars[1])
+            n += 1
+    return tot / n / T
+
+
+log = []
+t0 = time.perf_counter()
+run = 0.0
+for it in range(steps + 1):
+    if it % max(1, steps // 30) == 0:
+        rec = dict(step=it, valid_elbo_iwae_per_frame=validate(), train_elbo_iwae_per_frame_running=run,
+                   seconds=time.perf_counter() - t0)
+        log.append(rec)
+        print(rec, file=sys.stderr)
+    if it == steps:
+        break
+    batch = feed.next(it)
+    trainer.step(obs=batch["imgs"], generator=gen)
+    if it % 10 == 0:
+        with core.on_stream():
+            e = float(core.scalars[1]) / T
+        run = e if it == 0 else 0.9 * run + 0.1 * e
+print(json.dumps(dict(config=dict(T=T, B=B, K=K, N=N, hw=hw, steps=steps, learning_rate=lr, opt="rmsprop(momentum .9)",
+                                  schedule=F.schedule, data="2048 synthetic 2-glyph sequences, 256 held out"),
+                      upper_bound_per_frame=2500 * (-np.log(0.3) - 0.5 * np.log(2 * np.pi)), curve=log)))
