@@ -450,3 +450,48 @@ def test_full_backward_other_shapes(K, N, T, B, hw):
     a non-square frame with B*K not a multiple of the 16-row MFMA tile."""
     report, _, _ = _full_backward_case(K, N, T, B, hw, seed=21)
     _check_report(report)
+
+
+def test_full_size_gradient_is_the_mean_of_shard_gradients():
+    """BASELINE configs[1] / configs[2] shape (T10, 50x50, B32, K5, N4): the gradient of the full batch equals the mean
+    of the gradients of its two 16-sequence shards run as separate problems on the same noise rows — the identity the
+    data-parallel training step relies on (all-reduce(sum) / world == reduce_mean over the global batch,
+    sqair/model.py:91-93, sqair/targets.py:75)."""
+    from sqair_amd.data import config_inputs
+    from sqair_amd.dist import shard_batch, shard_noise
+    from sqair_amd.model import Model, SqairCore
+    from tests.hip_util import draw_noise, params32
+    ov, obs, _, _ = config_inputs(2)
+    F = make_flags(**ov)
+    K, N = int(F.k_particles), int(F.n_steps_per_image)
+    hw = obs.shape[2:4]
+    T, B = obs.shape[:2]
+    P = params32(F, hw, 1, 0.02, obs.mean((0, 1)))
+    noise = draw_noise(np.random.default_rng(5), T, B * K, N, 55)
+
+    def grad_of(o, nz):
+        core = SqairCore(F, hw)
+        core.set_params(P)
+        Model(o, None, core, K, outputs="minimal")
+        with core.on_stream():
+            core.noise.copy_(torch.as_tensor(nz).reshape(core.noise.shape))
+            g = core.grad_step(use_graph=True).clone()
+            target = float(core.scalars[2])
+        core.stream.synchronize()
+        return g, target
+
+    g_full, t_full = grad_of(obs, noise)
+    parts = [grad_of(shard_batch(obs, r, 2), shard_noise(noise, K, r, 2)) for r in range(2)]
+    g_mean = 0.5 * (parts[0][0] + parts[1][0])
+    assert abs(0.5 * (parts[0][1] + parts[1][1]) - t_full) <= 1e-5 * abs(t_full)
+    scale = float(g_full.abs().max())
+    assert torch.isfinite(g_full).all() and scale > 0
+    assert float((g_full - g_mean).abs().max()) <= 2e-4 * scale
+
+
+def test_full_backward_cfg2_sub_batch_against_oracle():
+    """Headline shape in T, K, N and frame size (T10, 50x50, K5, N4) on an 8-sequence sub-batch: every parameter's gradient
+    against autograd through the fp64 oracle."""
+    report, ref, _ = _full_backward_case(K=5, N=4, T=10, B=8, hw=(50, 50), seed=1236)
+    assert float(ref.prop_pres.sum()) > 0
+    _check_report(report)
