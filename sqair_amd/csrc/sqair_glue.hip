@@ -56,11 +56,17 @@ int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float*
 // workgroups at the headline config and measured 10.3 us; this one 5-6 us with the frame served by L1 / L2)
 __global__ __launch_bounds__(256) void k_crop_row(const CropArgs a, const POff po, const Dims d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  x_crop_row<LdPlain>(a, po, d, blockIdx.x, a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot, smem);
+  x_crop_row<LdPlain>(a, po, d, blockIdx.x, a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot, smem, true);
 }
 
 int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
-  const size_t shm = (4 + (size_t)4 * d.G) * sizeof(float);
+  const size_t shm = (4 + (size_t)4 * d.G + (size_t)d.H * d.W) * sizeof(float);
+  static bool big_lds = false;
+  if (shm > 48 * 1024 && !big_lds) {  // 128x128 frames: 64 KiB + tables, CDNA4 has 160 KiB of LDS per CU
+    (void)hipFuncSetAttribute((const void*)k_crop_row, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipGetLastError();
+    big_lds = true;
+  }
   hipLaunchKernelGGL(k_crop_row, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
   return 0;
 }

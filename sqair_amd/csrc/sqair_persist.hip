@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_xcd_persistent(const XOp* __restrict__ 
         case XOP_CROP: {
           const int tasks = rows * op.nslots;
           for (int task = tm.rank; task < tasks; task += tm.size)
-            x_crop_row<LdSc1>(op.u.crop, po, d, tm.r0 + task / op.nslots, op.u.crop.mode == CROP_PROP1 ? task % op.nslots : op.u.crop.slot, red);
+            x_crop_row<LdSc1>(op.u.crop, po, d, tm.r0 + task / op.nslots, op.u.crop.mode == CROP_PROP1 ? task % op.nslots : op.u.crop.slot, red, false);
           break;
         }
         case XOP_TAIL:

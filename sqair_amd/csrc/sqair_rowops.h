@@ -124,9 +124,11 @@ __device__ void x_linear_tile(const LinArgs& a, int kc_total, int tile_n, int mb
 
 
 template <class LD>
-__device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int r, int slot, float* smem) {
+__device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int r, int slot, float* smem, bool stage_img) {
   float* coord_s = smem;        // 4
   float* tab_s = smem + 4;      // 2 * 2G
+  float* img_s = smem + 4 + 4 * d.G;  // H*W when stage_img: the frame is pulled into LDS WHILE wave 0 computes `where`, so
+                                      // the gather below does not start a second memory round trip after it
   const int tid = threadIdx.x, b = r / d.K;
   const int P = d.H * d.W, G = d.G, G2 = d.G * d.G;
   const int mrow_add = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
@@ -134,7 +136,13 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
   const float* __restrict__ img = a.img + (size_t)b * P;
   const bool has_mask = a.mask != nullptr;
   const bool fused_tp = a.t2 != nullptr && (a.mode == CROP_PROP2 || a.mode == CROP_DISC);
-  constexpr int MPT = 2;  // mask values of this thread's first pixels, requested before anything else
+  constexpr int IPT = 10;  // first 2560 frame pixels: requested before anything else, stored after the where computation
+  float v0[IPT];
+  if (stage_img) {
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) v0[q] = img[min(q * 256 + tid, P - 1)];
+  }
+  constexpr int MPT = 2;  // mask values of this thread's first pixels, requested up front as well
   float mk0[MPT];
 #pragma unroll
   for (int q = 0; q < MPT; ++q)
@@ -225,7 +233,16 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
     }
     if (hl < 4) coord_s[ci] = (ci & 2) ? tanhf(wl) : fmaxf(sq_sigmoid(wl), 1e-4f);
   }
+  if (stage_img) {
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      const int idx = q * 256 + tid;
+      if (idx < P) img_s[idx] = v0[q];
+    }
+    for (int idx = 256 * IPT + tid; idx < P; idx += 256) img_s[idx] = img[idx];  // frames larger than 2560 pixels
+  }
   __syncthreads();
+  const float* __restrict__ src = stage_img ? img_s : img;
   for (int i = tid; i < 2 * G; i += 256) {
     const bool is_y = i >= G;
     const int j = is_y ? i - G : i;
@@ -255,7 +272,7 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
         const int xx = x0 + dx;
         const float wx = dx ? wx1 : 1.0f - wx1;
         if (xx < 0 || xx >= d.W) continue;
-        v += wy * wx * img[yy * d.W + xx];
+        v += wy * wx * src[yy * d.W + xx];
       }
     }
     a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + pix] = has_mask ? v * mk : v;

@@ -109,9 +109,17 @@ class Trainer(object):
         from . import _capi
         from .dist import allreduce_flat_grads
         core, F = self.core, self.F
+        if obs is not None:
+            obs = torch.as_tensor(obs, dtype=torch.float32)
+            if obs.dim() == 5:
+                obs = obs[..., 0]
+            if int(obs.shape[0]) != core.T or int(obs.shape[1]) != core.B:
+                # sequence-length curriculum (mnist_tools.py:80-92) or a new batch size: re-bind the buffers for the new
+                # shape (the gradient graph is re-captured on the next evaluation)
+                core.bind(int(obs.shape[0]), int(obs.shape[1]), core._shape[2])
         with core.on_stream():
             if obs is not None:
-                core.obs.copy_(torch.as_tensor(obs, dtype=torch.float32).reshape(core.obs.shape))
+                core.obs.copy_(obs.reshape(core.obs.shape))
             if noise is not None:
                 core.noise.copy_(torch.as_tensor(noise, dtype=torch.float32).reshape(core.noise.shape))
             else:

@@ -495,3 +495,30 @@ def test_full_backward_cfg2_sub_batch_against_oracle():
     report, ref, _ = _full_backward_case(K=5, N=4, T=10, B=8, hw=(50, 50), seed=1236)
     assert float(ref.prop_pres.sum()) > 0
     _check_report(report)
+
+
+def test_trainer_follows_the_sequence_length_curriculum():
+    """seq_len / stage_itr curriculum (mnist_tools.py:80-92): the feed hands out longer sequences as training proceeds and
+    the trainer re-binds its buffers (and re-captures the gradient graph) for the new T."""
+    from sqair_amd.data import make_sequences, to_float
+    from sqair_amd.dataio import MinibatchFeed
+    from sqair_amd.model import Model, SqairCore
+    from sqair_amd.train import Trainer, curriculum_seq_len
+    from tests.hip_util import params32
+    K, N, B, hw = 2, 2, 4, (50, 50)
+    F = make_flags(k_particles=K, n_steps_per_image=N, learning_rate=1e-4, seq_len=2, stage_itr=2)
+    d = make_sequences(8, T=4, canvas=hw, seed=4)
+    feed = MinibatchFeed(dict(imgs=to_float(d["imgs"]), nums=d["nums"], coords=d["coords"]), B, shuffle=True, seed=0,
+                         seq_len=F.seq_len, stage_itr=F.stage_itr)
+    core = SqairCore(F, hw)
+    core.set_params(params32(F, hw, 4, 0.05, to_float(d["imgs"]).mean((0, 1))))
+    tr = Trainer(Model(to_float(d["imgs"][:2, :B]), None, core, K, outputs="minimal"), F)
+    seen = []
+    for it in range(6):
+        batch = feed.next(it)
+        assert batch["imgs"].shape[0] == curriculum_seq_len(F, it, 4)
+        tr.step(obs=batch["imgs"], generator=torch.Generator(device="cuda").manual_seed(it))
+        seen.append(core.T)
+    core.stream.synchronize()
+    assert seen == [2, 2, 3, 3, 4, 4]
+    assert torch.isfinite(core.flat).all()
