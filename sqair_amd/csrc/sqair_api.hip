@@ -682,16 +682,15 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   // 0 * NaN = NaN) and slot records are read as 56-wide segments before all their fields are written in a frame:
   // clear the caller's (garbage) workspace once per pass
   if (parts & 1) {
-  sq_zero_fill(wsbase, (int64_t)((float*)w.prof_ts - wsbase), s);
-  // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
-  sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0), w.state(w.prior_m, 0), w.last_id[0], w.disc_init_rec,
-                       w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc,
-                       (int)P(h, "prop.transform.l2.w"), (int)P(h, "disc.transform.l2.w"), flat, po, d, s);
-  {  // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
+    sq_zero_fill(wsbase, (int64_t)((float*)w.prof_ts - wsbase), s);
+    // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
+    sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0), w.state(w.prior_m, 0), w.last_id[0], w.disc_init_rec,
+                         w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc,
+                         (int)P(h, "prop.transform.l2.w"), (int)P(h, "disc.transform.l2.w"), flat, po, d, s);
+    // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
     Lin a; a.seg(obs, P_, P_).out(w.ienc_a, nh).act(ACT_ELU); RUN(a, L_IENC0, T * B);
     Lin b; b.seg(w.ienc_a, nh, nh).out(w.ienc_b, nh).act(ACT_ELU); RUN(b, L_IENC1, T * B);
     Lin p; p.seg(w.ienc_b, nh, nh).out(w.pre_disc, nh); RUN(p, L_PREDISC, T * B);
-  }
   }
 
   for (int t = 0; (parts & 2) && t < T; ++t) {

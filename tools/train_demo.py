@@ -21,7 +21,8 @@ from sqair_amd.train import Trainer
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 lr = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-5
 T, B, K, N, hw = 10, 32, 5, 4, (50, 50)
-F = make_flags(k_particles=K, n_steps_per_image=N, learning_rate=lr, train_itr=steps)
+train_itr = int(sys.argv[3]) if len(sys.argv) > 3 else steps   # the piecewise-constant schedule is relative to train_itr
+F = make_flags(k_particles=K, n_steps_per_image=N, learning_rate=lr, train_itr=train_itr)
 train = make_sequences(2048, T=T, canvas=hw, n_objects=(0, 2), seed=1)
 valid = make_sequences(256, T=T, canvas=hw, n_objects=(0, 2), seed=2)
 feed = MinibatchFeed(dict(imgs=to_float(train["imgs"]), nums=train["nums"], coords=train["coords"]), B, shuffle=True, seed=0)
@@ -63,6 +64,6 @@ for it in range(steps + 1):
         with core.on_stream():
             e = float(core.scalars[1]) / T
         run = e if it == 0 else 0.9 * run + 0.1 * e
-print(json.dumps(dict(config=dict(T=T, B=B, K=K, N=N, hw=hw, steps=steps, learning_rate=lr, opt="rmsprop(momentum .9)",
+print(json.dumps(dict(config=dict(T=T, B=B, K=K, N=N, hw=hw, steps=steps, train_itr=train_itr, learning_rate=lr, opt="rmsprop(momentum .9)",
                                   schedule=F.schedule, data="2048 synthetic 2-glyph sequences, 256 held out"),
                       upper_bound_per_frame=2500 * (-np.log(0.3) - 0.5 * np.log(2 * np.pi)), curve=log)))
