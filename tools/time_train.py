@@ -5,7 +5,11 @@ import numpy as np, torch
 from sqair_amd.data import config_inputs
 from sqair_amd.flags import make_flags
 from sqair_amd.model import Model, SqairCore
-from tests.hip_util import params32
+from sqair_amd.params import init_params
+
+
+def params32(F, hw, seed, jitter, mean_img=None):
+    return {k: np.asarray(v, dtype=np.float32) for k, v in init_params(F, hw, seed=seed, mean_img=mean_img, jitter=jitter).items()}
 ov, obs, _, _ = config_inputs(2)
 F = make_flags(**ov)
 hw = obs.shape[2:4]

@@ -4,7 +4,11 @@ import numpy as np, torch
 from sqair_amd.data import config_inputs, make_sequences, to_float
 from sqair_amd.flags import make_flags
 from sqair_amd.model import Model, SqairCore
-from tests.hip_util import params32, draw_noise
+from sqair_amd.params import init_params
+
+
+def params32(F, hw, seed, jitter, mean_img=None):
+    return {k: np.asarray(v, dtype=np.float32) for k, v in init_params(F, hw, seed=seed, mean_img=mean_img, jitter=jitter).items()}
 small = len(sys.argv) > 1 and sys.argv[1] == "small"
 if small:
     K, N, T, B, hw = 3, 3, 3, 8, (50, 50)
