@@ -160,8 +160,12 @@ def main():
     gen.manual_seed(1000 + rank)
     use_graph = not args.no_graph
 
+    step_no = [0]
+
     def step():
-        model.core.draw_noise(gen)
+        # device-side Philox noise keyed by (seed, step, position in the GLOBAL batch): ranks draw what one GPU would draw
+        model.core.draw_noise(seed=1000, step=step_no[0], global_batch=B * world, b0=rank * B)
+        step_no[0] += 1
         model.core.forward(use_graph=use_graph)
 
     for _ in range(args.warmup):
@@ -204,14 +208,14 @@ def main():
         Ftr = make_flags(**dict(ov, learning_rate=1e-5, train_itr=1000000))
         trainer = Trainer(model, Ftr, use_graph=use_graph)
         for _ in range(max(2, min(args.warmup, 3))):
-            trainer.step(generator=gen)
+            trainer.step(seed=2000, global_batch=B * world, b0=rank * B)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_train):
-            trainer.step(generator=gen)
+            trainer.step(seed=2000, global_batch=B * world, b0=rank * B)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

@@ -248,6 +248,12 @@ int sqair_forward_persistent(SqairHandle* h, const float* flat_params, const voi
                              const float* noise, int T, int B, int t_offset, const SqairOutputs* out, void* workspace,
                              int64_t workspace_bytes, void* program, int64_t program_bytes, void* stream);
 int sqair_persistent_status(SqairHandle* h, const void* program, void* stream);
+/* Device-side noise for one pass: fills noise[T, B*K, 2, N, 4 + n_what + 1] with eps ~ N(0,1) / u ~ U[0,1) (last entry
+ * of every slot) from Philox4x32-10 keyed by (seed, step, position in the GLOBAL batch): a rank that owns sequences
+ * [b0, b0 + B) of a global batch of global_B draws exactly the rows one GPU would have drawn for them.  Replaces the
+ * tfd `.sample()` calls the reference makes inside its graph (sqair/core.py:226, sqair/modules.py:60, :485). */
+int sqair_fill_noise(SqairHandle* h, float* noise, int T, int B, int global_B, int b0, uint64_t seed, uint64_t step,
+                     void* stream);
 /* Graph capture of any sequence of the calls above on one stream (the training step up to the gradient all-reduce
  * is ~3000 short dependent launches): _begin, issue the calls, _end(slot 0..3) -> node count (>= 0) or error (< 0);
  * _launch replays the slot.  Captured calls keep the pointers they were given. */

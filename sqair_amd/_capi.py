@@ -92,6 +92,7 @@ _PROTOS = {
                                            C.c_int, C.POINTER(SqairOutputs), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                            C.c_void_p]),
     "sqair_persistent_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sqair_fill_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "sqair_capture_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sqair_capture_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "sqair_capture_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -599,3 +599,59 @@ extern "C" int sqair_add_l2_grad(SqairHandle* h, const float* flat_params, float
   SQ_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Noise of a pass generated on the device ("noise blobs or Philox (seed, offset)"): eps ~ N(0, 1) for the
+// Normal samples, u ~ U[0, 1) for the presence Bernoullis, layout [T, B', 2, N, 4 + n_what + 1].  Philox4x32-10 (Salmon et
+// al., SC'11), counter = (global element index, step), key = seed: every element is a pure function of (seed, step,
+// its position in the GLOBAL batch), so a rank that owns sequences [b0, b0 + B) of a global batch draws exactly the rows it
+// would have seen on one GPU (the reference draws inside the TF graph: tfd .sample() at core.py:226, modules.py:60, :485).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ void k_fill_noise(float* __restrict__ noise, int64_t n_local, int64_t per_frame_local, int64_t per_frame_global,
+                             int64_t row0_elems, int nzw, unsigned long long seed, unsigned long long step) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // quad of 4 consecutive LOCAL elements
+  if (q * 4 >= n_local) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t e = q * 4 + j;
+    if (e >= n_local) break;
+    const int64_t t = e / per_frame_local, within = e - t * per_frame_local;
+    const unsigned long long g = (unsigned long long)(t * per_frame_global + row0_elems + within);  // global element index
+    unsigned r[4];  // one Philox block per element (counter = element index): elements are independent by construction
+    philox4x32_10((unsigned)g, (unsigned)(g >> 32), (unsigned)step, (unsigned)(step >> 32), (unsigned)seed, (unsigned)(seed >> 32), r);
+    float v;
+    if ((int)(g % (unsigned long long)nzw) == nzw - 1) {
+      v = (float)(r[2] >> 8) * (1.0f / 16777216.0f);  // u in [0, 1), 24 bits
+    } else {  // Box-Muller, u1 in (0, 1]
+      const float u1 = ((float)(r[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+      v = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    }
+    noise[e] = v;
+  }
+}
+extern "C" int sqair_fill_noise(SqairHandle* h, float* noise, int T, int B, int global_B, int b0, uint64_t seed, uint64_t step,
+                                void* stream) {
+  if (!h || !noise || T < 1 || B < 1 || global_B < B || b0 < 0 || b0 + B > global_B) return -1;
+  const SqairConfig& c = h->cfg;
+  const int nzw = 4 + c.n_what + 1;
+  const int64_t per_row = (int64_t)2 * c.n_steps_per_image * nzw;
+  const int64_t per_frame_local = (int64_t)B * c.k_particles * per_row, per_frame_global = (int64_t)global_B * c.k_particles * per_row;
+  const int64_t n_local = (int64_t)T * per_frame_local;
+  const int64_t quads = (n_local + 3) / 4;
+  hipLaunchKernelGGL(k_fill_noise, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, noise, n_local,
+                     per_frame_local, per_frame_global, (int64_t)b0 * c.k_particles * per_row, nzw, (unsigned long long)seed,
+                     (unsigned long long)step);
+  SQ_CHECK_HIP(hipGetLastError());
+  return 0;
+}

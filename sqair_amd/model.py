@@ -191,10 +191,20 @@ class SqairCore(object):
         self.bwd_scratch = None
         self.program = None
 
-    def draw_noise(self, generator=None):
-        """eps ~ N(0,1) for the Normals, u ~ U[0,1) for the presence Bernoullis, on device."""
-        self.noise.normal_(generator=generator)
-        self.noise[..., -1].uniform_(generator=generator)
+    def draw_noise(self, generator=None, seed=None, step=0, global_batch=None, b0=0):
+        """eps ~ N(0,1) for the Normals, u ~ U[0,1) for the presence Bernoullis, on device.  With ``seed`` the library's own
+        Philox generator fills the buffer in ONE launch, keyed by (seed, step, position in the global batch) so that every
+        data-parallel rank draws the rows one GPU would have drawn; otherwise torch's generator is used."""
+        if seed is None:
+            self.noise.normal_(generator=generator)
+            self.noise[..., -1].uniform_(generator=generator)
+            return
+        with torch.cuda.device(self.device):
+            self._join_in()
+            _capi.check(self.handle, self.lib.sqair_fill_noise(
+                self.handle, self.noise.data_ptr(), self.T, self.B, int(global_batch or self.B), int(b0), int(seed), int(step),
+                self._stream()), "sqair_fill_noise")
+            self._join_out()
 
     # ---- execution ---------------------------------------------------------------------------------
     def _args(self, t_offset):

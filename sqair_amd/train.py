@@ -102,7 +102,7 @@ class Trainer(object):
         self.step_no = 0
         self.use_graph = bool(use_graph)
 
-    def step(self, obs=None, noise=None, generator=None):
+    def step(self, obs=None, noise=None, generator=None, seed=None, global_batch=None, b0=0):
         """One training step, asynchronous on the core's stream (``core.stream.synchronize()`` or read metrics inside
         ``core.on_stream()`` to observe results)."""
         import torch
@@ -122,6 +122,8 @@ class Trainer(object):
                 core.obs.copy_(obs.reshape(core.obs.shape))
             if noise is not None:
                 core.noise.copy_(torch.as_tensor(noise, dtype=torch.float32).reshape(core.noise.shape))
+            elif seed is not None:  # library Philox keyed by (seed, step, position in the global batch)
+                core.draw_noise(seed=seed, step=self.step_no, global_batch=global_batch, b0=b0)
             else:
                 core.draw_noise(generator)
             g = core.grad_step(use_graph=self.use_graph)

@@ -197,3 +197,34 @@ def test_elbo_iwae_vimco(B, K, T):
         assert np.abs(sig.cpu().numpy() - sig_ref.numpy()).max() < 5e-3
     finally:
         lib.sqair_destroy(h)
+
+
+@pytest.mark.gpu
+def test_device_noise_is_standard_and_shard_invariant():
+    """sqair_fill_noise: N(0,1) / U[0,1) moments, determinism in (seed, step), and the data-parallel property: a rank that
+    owns sequences [b0, b0 + B) of the global batch draws exactly the rows of the one-GPU draw."""
+    from sqair_amd.flags import make_flags
+    from sqair_amd.model import SqairCore
+    F = make_flags(k_particles=5, n_steps_per_image=4)
+    core = SqairCore(F, (50, 50))
+    core.bind(10, 32, "minimal")
+    core.draw_noise(seed=7, step=3)
+    torch.cuda.synchronize()
+    full = core.noise.clone()
+    eps, u = full[..., :-1].double(), full[..., -1].double()
+    assert abs(float(eps.mean())) < 5e-3 and abs(float(eps.var()) - 1.0) < 1e-2
+    assert abs(float((eps ** 4).mean()) - 3.0) < 0.1                       # kurtosis of a Normal
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 5e-3
+    assert abs(float(u.var()) - 1.0 / 12.0) < 2e-3
+    core.draw_noise(seed=7, step=3)
+    torch.cuda.synchronize()
+    assert torch.equal(core.noise, full)
+    core.draw_noise(seed=7, step=4)
+    torch.cuda.synchronize()
+    assert not torch.equal(core.noise, full)
+    assert abs(float((core.noise[..., :-1] * full[..., :-1]).mean())) < 5e-3  # consecutive steps are uncorrelated
+    shard = SqairCore(F, (50, 50))
+    shard.bind(10, 8, "minimal")
+    shard.draw_noise(seed=7, step=3, global_batch=32, b0=16)
+    torch.cuda.synchronize()
+    assert torch.equal(shard.noise, full[:, 16 * 5:24 * 5])
