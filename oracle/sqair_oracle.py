@@ -61,6 +61,9 @@ def make_cfg(F, img_hw):
         where_prior_mean=sp + [0.0, 0.0], output_std=std, background_std=std,
         transition=str(F.transition), time_transition=str(F.time_transition),
         prior_transition=str(F.prior_transition), where_update_scale=1.0, min_std=1e-2,
+        # generation modes (mlp_mnist_model.py:51, seq.py:46, :198-200); generate_after is a constructor argument of
+        # SequentialAIR only (no flag), carried here as an optional attribute of the flags object
+        sample_from_prior=bool(getattr(F, "sample_from_prior", False)), generate_after=int(getattr(F, "generate_after", -1)),
     )
 
 
@@ -427,7 +430,7 @@ class SqairOracle(object):
                    temporal_state=temporal_new)
         return out, (what, where, pres, hidden)
 
-    def propagate(self, img, z_tm1, temporal_state, prior_state, noise):
+    def propagate(self, img, z_tm1, temporal_state, prior_state, noise, gen_noise=None, do_generate=False):
         """Propagate._build/_compute_log_probs (sqair_modules.py:250-329) + SequentialSSM
         (propagate.py:168-184)."""
         c = self.cfg
@@ -443,13 +446,22 @@ class SqairOracle(object):
                                              noise[:, k, 0:4], noise[:, k, 4:4 + nw], noise[:, k, 4 + nw:])
             outs.append(o)
         ho = {k: torch.stack([o[k] for o in outs], 1) for k in outs[0]}
-        pres = ho["presence"].squeeze(-1)
-        pres_tm1 = z_tm1[2].squeeze(-1)
-        # posteriors (sqair_modules.py:49-60, :328-329)
-        q_what = normal_log_prob(ho["what"], ho["what_loc"], ho["what_scale"]).sum(-1)
-        q_where = self.mvn_tril_log_prob(ho["where"], ho["where_loc"], self.where_tril(ho["where_scale"]))
-        q_pres = bernoulli_log_prob(pres, ho["presence_logit"].squeeze(-1))
+        pres = ho["presence"].squeeze(-1)  # the posterior path's presence: masks and prior Bernoulli use it even when
+        pres_tm1 = z_tm1[2].squeeze(-1)    # the hidden outputs are replaced below (sqair_modules.py:286, :310-318)
         pw_loc, pw_scale, pa_loc, pa_scale, p_logit = prior_stats
+        s_what, s_where, s_pres = ho["what"], ho["where"], pres
+        if c.sample_from_prior:
+            # sqair_modules.py:294-302: samples = [p.sample() for p in priors] replace the points at which the
+            # POSTERIORS are evaluated; the hidden outputs themselves only when do_generate
+            s_what = pa_loc + pa_scale * gen_noise[..., 4:4 + nw]
+            s_where = pw_loc + pw_scale * gen_noise[..., 0:4]
+            s_pres = (gen_noise[..., 4 + nw] < torch.sigmoid(p_logit.squeeze(-1))).to(self.dtype)
+            if do_generate:
+                ho["what"], ho["where"], ho["presence"] = s_what, s_where, s_pres.unsqueeze(-1)
+        # posteriors (sqair_modules.py:49-60, :328-329)
+        q_what = normal_log_prob(s_what, ho["what_loc"], ho["what_scale"]).sum(-1)
+        q_where = self.mvn_tril_log_prob(s_where, ho["where_loc"], self.where_tril(ho["where_scale"]))
+        q_pres = bernoulli_log_prob(s_pres, ho["presence_logit"].squeeze(-1))
         p_what = normal_log_prob(ho["what"], pa_loc, pa_scale).sum(-1)
         p_where = normal_log_prob(ho["where"], pw_loc, pw_scale).sum(-1)
         p_pres = bernoulli_log_prob(pres, p_logit.squeeze(-1))
@@ -502,7 +514,24 @@ class SqairOracle(object):
             lps.append(normal_log_prob(sample, loc, scale))
         return torch.stack(lps, 1)
 
-    def discover(self, img, conditioning, prior_conditioning, t, noise):
+    def recurrent_normal_sample(self, eps, conditioning):
+        """RecurrentNormal.sample (modules.py:619-629): x_k = loc(x_{k-1}) + scale(x_{k-1}) eps_k, same never-advanced
+        RNN state as log_prob."""
+        P = self.P
+        B, N = eps.shape[:2]
+        state = torch.cat([P["disc.rn.init_state"].expand(B, -1), conditioning], -1)
+        state = elu(linear(P, "disc.rn.cond", state))
+        sample = P["disc.rn.init_sample"].expand(B, -1)
+        xs = []
+        for k in range(N):
+            o = vanilla_rnn(P, "disc.rn", sample, state)
+            st = linear(P, "disc.rn.readout", o)
+            loc, scale = st[..., :4], softplus(st[..., 4:]) + 1e-2
+            sample = loc + scale * eps[:, k]
+            xs.append(sample)
+        return torch.stack(xs, 1)
+
+    def discover(self, img, conditioning, prior_conditioning, t, noise, gen_noise=None, do_generate=False):
         """Discover._build/_discover/_compute_log_probs/_make_priors (sqair_modules.py:94-229)."""
         c = self.cfg
         P = self.P
@@ -516,8 +545,17 @@ class SqairOracle(object):
                                            noise[:, j, 4 + nw:])
             outs.append(o)
         ho = {k: torch.stack([o[k] for o in outs], 1) for k in outs[0]}
+        num_steps = ho["presence"].squeeze(-1).sum(-1)  # _discover (sqair_modules.py:146): before any replacement
+        where_cond = torch.cat([conditioning, prior_conditioning], -1)
+        if c.sample_from_prior and do_generate:
+            # sqair_modules.py:157-170: what ~ N(0, I), where ~ the where prior, presence zeroed (`* 0.`)
+            ho["what"] = gen_noise[..., 4:4 + nw]
+            if c.rec_where_prior:
+                ho["where"] = self.recurrent_normal_sample(gen_noise[..., 0:4], where_cond)
+            else:
+                ho["where"] = torch.tensor(c.where_prior_mean, dtype=self.dtype) + gen_noise[..., 0:4]
+            ho["presence"] = torch.zeros_like(ho["presence"])
         pres = ho["presence"].squeeze(-1)
-        num_steps = pres.sum(-1)
         joint = bernoulli_to_modified_geometric(ho["presence_prob"].squeeze(-1))
         q_what = normal_log_prob(ho["what"], ho["what_loc"], ho["what_scale"]).sum(-1) * pres
         q_where = normal_log_prob(ho["where"], ho["where_loc"], ho["where_scale"]).sum(-1) * pres
@@ -525,7 +563,6 @@ class SqairOracle(object):
         # priors (sqair_modules.py:199-226)
         p_what = normal_log_prob(ho["what"], torch.zeros((), dtype=self.dtype),
                                  torch.ones((), dtype=self.dtype)).sum(-1) * pres
-        where_cond = torch.cat([conditioning, prior_conditioning], -1)
         if c.rec_where_prior:
             p_where = self.recurrent_normal_log_prob(ho["where"], where_cond).sum(-1) * pres
         else:
@@ -554,15 +591,17 @@ class SqairOracle(object):
         f = mlp2_hidden(self.P, "seq.latent_enc", torch.cat([what, where], -1).reshape(B * N, -1))
         return (f.reshape(B, N, -1) * presence).sum(-2)
 
-    def timestep(self, img, z_tm1, temporal_state, prior_state, last_used_id, prev_ids, t, noise):
+    def timestep(self, img, z_tm1, temporal_state, prior_state, last_used_id, prev_ids, t, noise, gen_noise=None):
         """SQAIRTimestep._build/_propagate_and_discover/_choose_latents (sqair_modules.py:446-582)."""
         c = self.cfg
         B, N = img.shape[0], c.N
-        prop = self.propagate(img, z_tm1, temporal_state, prior_state, noise[:, 0])
+        do_generate = c.generate_after > 0 and t > c.generate_after  # seq.py:198-200
+        gn = gen_noise if gen_noise is not None else torch.zeros_like(noise)
+        prop = self.propagate(img, z_tm1, temporal_state, prior_state, noise[:, 0], gn[:, 0], do_generate)
         cond = self.encode_latents(prop["what"], prop["where"], prop["presence"])
         prior_logits = prop["prior_stats"][-1].squeeze(-1)
         exp_steps = ((torch.sigmoid(prior_logits) - 0.5) / N).sum(-1, keepdim=True)
-        disc = self.discover(img, cond, exp_steps, t, noise[:, 1])
+        disc = self.discover(img, cond, exp_steps, t, noise[:, 1], gn[:, 1], do_generate)
         # merge (sqair_modules.py:514-582)
         names = "what what_loc what_scale where where_loc where_scale presence_prob presence presence_logit".split()
         init_temporal = self.P["seq.temporal_init"][None].expand(B, N, -1)
@@ -606,7 +645,7 @@ class SqairOracle(object):
         return canvas, std, glimpse.reshape(B, N, c.G, c.G)
 
     # ---- sequence unroll -------------------------------------------------------------
-    def sequence(self, tiled_obs, noise):
+    def sequence(self, tiled_obs, noise, gen_noise=None):
         """SequentialAIR._build/_prepare_loop_vars/_loop_body/_compute_log_weights
         (seq.py:69-279).  tiled_obs [T,B',H,W]; noise [T,B',2,N,4+n_what+1]."""
         c = self.cfg
@@ -628,7 +667,7 @@ class SqairOracle(object):
 
         for t in range(T):
             img = tiled_obs[t]
-            o = self.timestep(img, z, temporal, prior, last_id, prev_ids, t, noise[t])
+            o = self.timestep(img, z, temporal, prior, last_id, prev_ids, t, noise[t], None if gen_noise is None else gen_noise[t])
             z_t = o["z_t"]
             canvas, std, glimpse = self.decode(z_t[0], z_t[1], z_t[2])
             data_ll = normal_log_prob(img, canvas, std).sum((1, 2))
@@ -681,7 +720,7 @@ class SqairOracle(object):
         return out
 
     # ---- Model (model.py) ------------------------------------------------------------
-    def model(self, obs, noise, num=None, resample_u=None):
+    def model(self, obs, noise, num=None, resample_u=None, gen_noise=None):
         """Model.__init__/_build (model.py:43-148).  obs [T,B,H,W] in [0,1]; ``num`` is the
         ground-truth prefix-ones presence [T,B,n_max+1] used for the step accuracy."""
         c = self.cfg
@@ -690,7 +729,11 @@ class SqairOracle(object):
         noise = torch.as_tensor(np.asarray(noise), dtype=self.dtype)
         T, B = obs.shape[:2]
         tiled = tile_input_for_iwae(obs, K)
-        o = self.sequence(tiled, noise)
+        if gen_noise is not None:
+            gen_noise = torch.as_tensor(np.asarray(gen_noise), dtype=self.dtype)
+        if c.sample_from_prior and gen_noise is None:
+            raise ValueError("sample_from_prior needs gen_noise (the prior samples' eps / u), same layout as noise")
+        o = self.sequence(tiled, noise, gen_noise)
         m = SimpleNamespace(outputs=o, **{k: v for k, v in o.items() if not k.startswith("_")})
         m.log_weights = o["log_weights_per_timestep"].sum(0).reshape(B, K)
         m.elbo_vae = m.log_weights.mean()

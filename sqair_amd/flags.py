@@ -41,6 +41,9 @@ MODEL_FLAGS = dict(
     prop_step_bias=5.0,
     sample_from_prior=False,
     rec_where_prior=True,
+    # not a reference flag: the `generate_after` constructor argument of SequentialAIR (seq.py:46, :198-200), which the
+    # shipped config never sets; frames t > generate_after are generated from the priors when sample_from_prior is on
+    generate_after=-1,
 )
 
 DATA_FLAGS = dict(train_path="seq_mnist_train.pickle", valid_path="seq_mnist_validation.pickle",

@@ -266,3 +266,48 @@ def test_step_distributions_match_independent_formulas():
     assert np.isclose(joint.sum().item(), 1.0) and np.isclose(joint[0, -1].item(), 0.9 * 0.5 * 0.2)
     assert np.isclose(joint[0, 1].item(), 0.9 * (1 - 0.5))
     assert np.isclose(O.num_steps_log_prob(joint, torch.tensor([1.0])).item(), np.log(0.45))
+
+
+def _gen_case(**flags):
+    F = make_flags(n_steps_per_image=3, k_particles=2, **flags)
+    hw = (20, 20)
+    cfg = O.make_cfg(F, hw)
+    P = init_params(F, hw, seed=5, jitter=0.2)
+    rng = np.random.default_rng(3)
+    T, B = 4, 3
+    obs = rng.uniform(size=(T, B, *hw))
+    nz = rng.standard_normal((T, B * 2, 2, 3, O.noise_width(cfg)))
+    nz[..., -1] = rng.uniform(size=nz.shape[:-1])
+    gn = rng.standard_normal(nz.shape)
+    gn[..., -1] = rng.uniform(size=nz.shape[:-1])
+    return O.SqairOracle(P, cfg), obs, nz, gn
+
+
+def test_sample_from_prior_only_moves_the_posterior_evaluation_points():
+    """mlp_mnist_model.py:51 + sqair_modules.py:294-302 with generate_after unset (the only combination the flags can
+    reach): latents, canvases, priors are unchanged; the propagation posterior log-probs are evaluated at prior samples."""
+    base, obs, nz, gn = _gen_case()
+    sfp, _, _, _ = _gen_case(sample_from_prior=True)
+    a, b = base.model(obs, nz), sfp.model(obs, nz, gen_noise=gn)
+    for k in ("what", "where", "presence", "canvas", "obj_id", "prop_what_prior_log_prob", "prop_prior_log_prob",
+              "disc_what_log_prob", "disc_log_prob", "log_p_z_per_sample", "data_ll_per_sample"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert not torch.equal(a.prop_what_log_prob[1:], b.prop_what_log_prob[1:])
+    assert not torch.equal(a.prop_where_log_prob[1:], b.prop_where_log_prob[1:])
+    assert not torch.equal(a.log_q_z_given_x_per_sample, b.log_q_z_given_x_per_sample)
+
+
+def test_generation_after_t_samples_the_priors():
+    """seq.py:198-200: frames t > generate_after take what / where / presence of propagated objects from the prior and
+    discover nothing (sqair_modules.py:157-170: presence `* 0.`); earlier frames are untouched."""
+    base, obs, nz, gn = _gen_case(sample_from_prior=True)
+    gen, _, _, _ = _gen_case(sample_from_prior=True, generate_after=1)
+    a, b = base.model(obs, nz, gen_noise=gn), gen.model(obs, nz, gen_noise=gn)
+    for k in ("what", "where", "presence", "canvas", "log_weights_per_timestep"):
+        assert torch.equal(getattr(a, k)[:2], getattr(b, k)[:2]), k          # t = 0, 1 (t > 1 generates)
+    assert float(b.disc_pres[2:].abs().sum()) == 0.0
+    assert float(b.num_disc_steps_per_sample[:2].sum()) > 0                  # discovery still counts its own steps
+    # a propagated, generated object is a prior sample: its presence is the prior Bernoulli's draw
+    assert set(np.unique(b.prop_pres[2:].numpy())) <= {0.0, 1.0}
+    assert not torch.equal(a.what[2:], b.what[2:]) or float(a.presence[2:].sum()) == 0.0
+    assert torch.isfinite(b.log_weights).all()
