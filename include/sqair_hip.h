@@ -52,6 +52,8 @@ typedef struct SqairConfig {
   float output_std;              /* effective p(x|z) std: fl32(fl32(sqrt(flag))^2), modules.py:419-422 */
   float background_std;          /* same for background pixels (bg_std=None -> output_std)       */
   float where_prior_mean[4];     /* scale_prior x2, 0, 0 (non-recurrent where prior only)        */
+  int32_t sample_from_prior;     /* flag sample_from_prior (mlp_mnist_model.py:51): needs sqair_set_generation_noise */
+  int32_t generate_after;        /* SequentialAIR(generate_after=..) (seq.py:46, :198-200); <= 0: never generate     */
 } SqairConfig;
 
 typedef struct SqairHandle SqairHandle;
@@ -248,6 +250,13 @@ int sqair_forward_persistent(SqairHandle* h, const float* flat_params, const voi
                              const float* noise, int T, int B, int t_offset, const SqairOutputs* out, void* workspace,
                              int64_t workspace_bytes, void* program, int64_t program_bytes, void* stream);
 int sqair_persistent_status(SqairHandle* h, const void* program, void* stream);
+/* Generation modes (sqair/sqair_modules.py:157-170, :294-302, sqair/seq.py:198-200).  With
+ * cfg.sample_from_prior the propagation posterior log-probabilities are evaluated at samples of the propagation PRIOR, and
+ * in frames t > cfg.generate_after those samples replace what / where / presence of the propagated objects, discovery's
+ * what ~ N(0, I), where ~ its (recurrent) prior and presence = 0.  The extra draws come from `gen_noise`, same layout
+ * and meaning as `noise` ([T, B*K, 2, N, 4 + n_what + 1]); the pointer is remembered by the handle and used by the
+ * following forward calls.  Forward / inference only. */
+int sqair_set_generation_noise(SqairHandle* h, const float* gen_noise);
 /* Device-side noise for one pass: fills noise[T, B*K, 2, N, 4 + n_what + 1] with eps ~ N(0,1) / u ~ U[0,1) (last entry
  * of every slot) from Philox4x32-10 keyed by (seed, step, position in the GLOBAL batch): a rank that owns sequences
  * [b0, b0 + B) of a global batch of global_B draws exactly the rows one GPU would have drawn for them.  Replaces the

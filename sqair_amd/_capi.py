@@ -33,6 +33,7 @@ class SqairConfig(C.Structure):
         ("masked_glimpse", C.c_int32), ("rec_where_prior", C.c_int32),
         ("prop_prior_step_bias", C.c_float), ("step_success_prob", C.c_float), ("output_std", C.c_float),
         ("background_std", C.c_float), ("where_prior_mean", C.c_float * 4),
+        ("sample_from_prior", C.c_int32), ("generate_after", C.c_int32),
     ]
 
 
@@ -92,6 +93,7 @@ _PROTOS = {
                                            C.c_int, C.POINTER(SqairOutputs), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                            C.c_void_p]),
     "sqair_persistent_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sqair_set_generation_noise": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sqair_fill_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "sqair_capture_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sqair_capture_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),

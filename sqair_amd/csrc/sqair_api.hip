@@ -569,6 +569,7 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.glimpse = take((int64_t)T * M * G2);
   w.dec_a = take((int64_t)T * M * nh);
   w.dec_b = take((int64_t)T * M * nh);
+  w.gen = take(c.sample_from_prior ? (int64_t)T * M * gen::W : 64);
   w.prof_ts = (unsigned long long*)take(5 * PROF_MAX * 2);
   w.total = o;
   return w;
@@ -664,6 +665,10 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   }
   if (ws_bytes < sq_carve(h, T, B, nullptr, train).total * 4) {
     sq_set_error(h, "sqair_forward: workspace too small");
+    return -1;
+  }
+  if (c.sample_from_prior && (train || h->rec != nullptr || h->gen_noise == nullptr)) {
+    sq_set_error(h, "sample_from_prior: inference through sqair_forward / sqair_graph_capture only, after sqair_set_generation_noise");
     return -1;
   }
   const SqairOutputs out = *outp;
@@ -814,6 +819,15 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         emit_tail(h, ta, d, s);
       }
     }
+    // ---- generation modes: prior samples of the propagated objects (sqair_modules.py:294-302) ----
+    const bool do_generate = c.sample_from_prior && c.generate_after > 0 && (t_offset + t) > c.generate_after;  // seq.py:198-200
+    GenArgs ga; memset(&ga, 0, sizeof(ga));
+    if (c.sample_from_prior) {
+      ga.rec_p = rec_p_t; ga.rec_d = rec_d_t; ga.rec_prev = rec_prev; ga.pstats = pstats_t; ga.ps_ld = PS_LD; ga.spre = spre_t;
+      ga.gen_noise = h->gen_noise + (size_t)t * R * 2 * N * nzw; ga.gen = w.gen + (size_t)t * M * gen::W; ga.flat = flat;
+      ga.do_generate = do_generate ? 1 : 0; ga.cfg = c;
+      sq_launch_generate_prop(ga, po, d, s);
+    }
     // ---- F. summary of propagated latents -> discovery conditioning (sqair_modules.py:368-385, :501) ----
     {
       Lin a; a.seg(rec_p_t, RW, rec::ZW).out(lea, nh).act(ACT_ELU); RUN(a, L_LAT0, M);
@@ -863,6 +877,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         emit_tail(h, ta, d, s);
       }
     }
+    if (do_generate) sq_launch_generate_disc(ga, po, d, s);  // sqair_modules.py:157-170
     // ---- I. merge / compaction (the log-probabilities H and the decoder J are off the recurrence's critical path:
     //      they run once for all T frames after the loop)
     {
@@ -881,7 +896,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     LogprobArgs la; memset(&la, 0, sizeof(la));
     la.rec_p = w.rec_p_all; la.rec_d = w.rec_d_all; la.rec_prev = w.rec_m_all; la.pstats = w.pstats; la.ps_ld = PS_LD;
     la.spre = w.spre; la.flat = flat; la.t_global = t_offset; la.t = 0; la.n_frames = T; la.qz = w.qz; la.pz = w.pz;
-    la.disc_lp = w.dlp; la.out = out; la.cfg = c;
+    la.disc_lp = w.dlp; la.out = out; la.cfg = c; la.gen = c.sample_from_prior ? w.gen : nullptr;
     sq_launch_logprob(la, po, d, s);
   }
   // ---- J. decoder of all T frames as three M = T*B'*N row GEMMs + one insert / log-likelihood launch
@@ -1104,6 +1119,12 @@ extern "C" int sqair_graph_capture(SqairHandle* h, const float* flat_params, con
   SQ_CHECK_HIP(hipGraphGetNodes(g, nullptr, &nn));
   h->graph_nodes = (int)nn;
   SQ_CHECK_HIP(hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0));
+  return 0;
+}
+
+extern "C" int sqair_set_generation_noise(SqairHandle* h, const float* gen_noise) {
+  if (!h) return -1;
+  h->gen_noise = gen_noise;
   return 0;
 }
 

@@ -78,10 +78,29 @@ struct LogprobArgs {
   int t;                              // index of the first frame inside the output tensors
   int n_frames;                       // frames covered by the launch (inputs are [n_frames][...] contiguous)
   float* qz; float* pz; float* disc_lp;  // frame scalars [R]
+  const float* gen;                   // sample_from_prior: generation records [n_frames][R*N][64] (see GenArgs), else NULL
   SqairOutputs out;
   SqairConfig cfg;
 };
 int sq_launch_logprob(const LogprobArgs& a, POff po, Dims d, hipStream_t s);
+
+// Generation modes (sqair_modules.py:157-170, :294-302).  Generation record of slot (r, k), 64 floats:
+//   [0:4] where ~ prior, [4:54] what ~ prior, [54] presence ~ Bernoulli(prior logit), [55] the posterior path's own
+//   propagation presence, [56] the posterior path's own discovery presence of step k
+namespace gen {
+constexpr int WHERE = 0, WHAT = 4, PRES = 54, ORIG_PRES = 55, ORIG_DPRES = 56, W = 64;
+}
+struct GenArgs {
+  float* rec_p; float* rec_d; const float* rec_prev;   // records of this frame (overwritten when generating)
+  const float* pstats; int ps_ld; const float* spre;   // prior statistics / where-prior conditioning of this frame
+  const float* gen_noise;                              // frame slice of the second noise tensor [R][2][N][nzw]
+  float* gen;                                          // generation records of this frame [R*N][64]
+  const float* flat;
+  int do_generate;
+  SqairConfig cfg;
+};
+int sq_launch_generate_prop(const GenArgs& a, POff po, Dims d, hipStream_t s);
+int sq_launch_generate_disc(const GenArgs& a, POff po, Dims d, hipStream_t s);
 
 struct CompactArgs {
   const float* rec_p; const float* rec_d; const float* rec_prev;

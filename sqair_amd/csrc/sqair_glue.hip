@@ -306,7 +306,13 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
     const float* rp = recp_s + k * RW;
     const float* rm = recm_s + k * RW;
     const float* ps = ps_s + k * a.ps_ld;
-    const float pres = rp[rec::PRES], pres_tm1 = rm[rec::PRES];
+    // sample_from_prior (sqair_modules.py:294-318): the posteriors are evaluated at samples of the PRIOR (generation
+    // record), the priors at the hidden outputs (replaced in generated frames), every mask and the prior Bernoulli at the
+    // posterior path's own presence
+    const float* gr = a.gen != nullptr ? a.gen + (fs + (size_t)r * N + k) * gen::W : nullptr;
+    const float pres_hidden = rp[rec::PRES];
+    const float pres = gr != nullptr ? gr[gen::ORIG_PRES] : pres_hidden, pres_tm1 = rm[rec::PRES];
+    const float pres_q = gr != nullptr ? gr[gen::PRES] : pres;
     const float logit = rp[rec::LOGIT], logit_tm1 = rm[rec::LOGIT];
     float pl = ps[0] + a.cfg.prop_prior_step_bias;
     pl = pres_tm1 * pl + (pres_tm1 - 1.0f) * 88.0f;
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
     float qw = 0.0f, pw = 0.0f;
     if (lane < nw) {
       const float x = rp[rec::WHAT + lane];
-      qw = sq_normal_lp(x, rp[rec::WHAT_LOC + lane], rp[rec::WHAT_SCALE + lane]);
+      qw = sq_normal_lp(gr != nullptr ? gr[gen::WHAT + lane] : x, rp[rec::WHAT_LOC + lane], rp[rec::WHAT_SCALE + lane]);
       float ploc = ps[5 + lane];
       if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHAT + lane];
       else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHAT + lane] + 0.1f * ploc;
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
       float sq = 0.0f, logdet = 0.0f;
       for (int i = 0; i < 4; ++i) {
         const float sci = rp[rec::WHERE_SCALE + i];
-        float acc = rp[rec::WHERE + i] - rp[rec::WHERE_LOC + i];
+        float acc = (gr != nullptr ? gr[gen::WHERE + i] : rp[rec::WHERE + i]) - rp[rec::WHERE_LOC + i];
         for (int jj = 0; jj < i; ++jj) acc -= tril4(ch_s, i, jj) * sci * y[jj];
         const float lii = tril4(ch_s, i, i) * sci + sci;
         y[i] = acc / lii;
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
       }
       q_where = -0.5f * sq - logdet - 2.0f * LOG2PI;
     }
-    const float q_pres = sq_bernoulli_lp(pres, logit);
+    const float q_pres = sq_bernoulli_lp(pres_q, logit);
     const float p_pres = sq_bernoulli_lp(pres, pl);
     const float m = pres_tm1 * pres;
     if (lane == 0) {
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
       if (a.out.prop_what_prior_log_prob) a.out.prop_what_prior_log_prob[o] = p_what * m;
       if (a.out.prop_where_prior_log_prob) a.out.prop_where_prior_log_prob[o] = p_where * m;
       if (a.out.prop_prob) a.out.prop_prob[o] = expf(q_pres) * pres_tm1;
-      if (a.out.prop_pres) a.out.prop_pres[o] = pres;
+      if (a.out.prop_pres) a.out.prop_pres[o] = pres_hidden;
     }
     q_prop += (q_what + q_where) * m;
     p_prop += (p_what + p_where) * m;
@@ -421,7 +427,10 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
     }
     q_disc += (q_what + q_where) * pres;
     p_disc += (p_what + p_where) * pres;
-    n_disc += pres;
+    // num_steps is what discovery itself inferred (sqair_modules.py:146), also when the frame is generated and the
+    // hidden presence has been zeroed
+    const bool generated = a.gen != nullptr && a.cfg.generate_after > 0 && t_global > a.cfg.generate_after;
+    n_disc += generated ? a.gen[(fs + (size_t)r * N + j) * gen::W + gen::ORIG_DPRES] : pres;
   }
   if (lane != 0) return;
   // NumStepsDistribution (float64 inside, prior.py:61-67)
@@ -479,6 +488,114 @@ int sq_launch_logprob(const LogprobArgs& a, POff po, Dims d, hipStream_t s) {
   const size_t shm = ((size_t)3 * d.N * rec::W + (size_t)d.N * a.ps_ld + 128 + 128 + 516 + 20 + 40 + 4 + 20 +
                       11 * (d.N + 1) + 2 * (d.N + 1) + 16) * sizeof(float);
   hipLaunchKernelGGL(k_logprob, dim3(d.R, a.n_frames), dim3(256), shm, s, a, po, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generation modes (reference: Propagate._compute_log_probs sqair/sqair_modules.py:294-302, Discover._compute_log_probs
+// :157-170, do_generate sqair/seq.py:198-200, RecurrentNormal.sample sqair/modules.py:619-629).  One wavefront per row.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gen_prior_logit(const GenArgs& a, const float* rm, const float* ps) {
+  const float pres_tm1 = rm[rec::PRES];
+  float pl = ps[0] + a.cfg.prop_prior_step_bias;
+  pl = pres_tm1 * pl + (pres_tm1 - 1.0f) * 88.0f;
+  if (a.cfg.prop_prior_type != 0) pl = rm[rec::LOGIT] + 0.1f * pl;
+  return pl;
+}
+// propagation: samples of the prior for every slot -> generation record; replaces the hidden outputs when generating
+__global__ __launch_bounds__(64) void k_generate_prop(const GenArgs a, const Dims d) {
+  const int r = blockIdx.x, lane = threadIdx.x, N = d.N, nw = d.nw;
+  for (int k = 0; k < N; ++k) {
+    const size_t rk = (size_t)r * N + k;
+    float* rp = a.rec_p + rk * rec::W;
+    const float* rm = a.rec_prev + rk * rec::W;
+    const float* ps = a.pstats + rk * a.ps_ld;
+    const float* gn = a.gen_noise + (((size_t)r * 2 + 0) * N + k) * d.nzw;
+    float* g = a.gen + rk * gen::W;
+    if (lane < nw) {
+      float ploc = ps[5 + lane];
+      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHAT + lane];
+      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHAT + lane] + 0.1f * ploc;
+      const float v = ploc + (sq_softplus(ps[9 + nw + lane]) + 1e-2f) * gn[4 + lane];
+      g[gen::WHAT + lane] = v;
+      if (a.do_generate) rp[rec::WHAT + lane] = v;
+    }
+    if (lane < 4) {
+      float ploc = ps[1 + lane];
+      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHERE + lane];
+      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHERE + lane] + 0.1f * ploc;
+      const float v = ploc + (sq_softplus(ps[5 + nw + lane]) + 1e-2f) * gn[lane];
+      g[gen::WHERE + lane] = v;
+      if (a.do_generate) rp[rec::WHERE + lane] = v;
+    }
+    if (lane == 0) {
+      const float sp = gn[4 + nw] < sq_sigmoid(gen_prior_logit(a, rm, ps)) ? 1.0f : 0.0f;
+      g[gen::PRES] = sp;
+      g[gen::ORIG_PRES] = rp[rec::PRES];
+      if (a.do_generate) rp[rec::PRES] = sp;
+    }
+  }
+}
+// discovery (generated frames only): what ~ N(0, I), where ~ the where prior, presence = 0; keeps the original presence
+__global__ __launch_bounds__(64) void k_generate_disc(const GenArgs a, const POff po, const Dims d) {
+  const int r = blockIdx.x, lane = threadIdx.x, N = d.N, nw = d.nw;
+  const float* flat = a.flat;
+  float hs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (a.cfg.rec_where_prior) {
+    float e_sum = 0.0f;
+    for (int k = 0; k < N; ++k)
+      e_sum += (sq_sigmoid(gen_prior_logit(a, a.rec_prev + ((size_t)r * N + k) * rec::W, a.pstats + ((size_t)r * N + k) * a.ps_ld)) - 0.5f) / (float)N;
+    float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = lane; i < 128; i += 64) {
+      const float sv = sq_elu(a.spre[(size_t)r * 128 + i] + e_sum * flat[po.rn_cond_w + (4 + d.nh) * 128 + i]);
+      for (int jj = 0; jj < 4; ++jj) part[jj] += sv * flat[po.rn_h2h_w + i * 4 + jj];
+    }
+    for (int jj = 0; jj < 4; ++jj) hs[jj] = sq_wave_sum(part[jj]) + flat[po.rn_h2h_b + jj] + flat[po.rn_i2h_b + jj];
+  }
+  float xprev[4];
+  for (int i = 0; i < 4; ++i) xprev[i] = flat[po.rn_init_sample + i];
+  for (int j = 0; j < N; ++j) {
+    const size_t rj = (size_t)r * N + j;
+    float* rd = a.rec_d + rj * rec::W;
+    const float* gn = a.gen_noise + (((size_t)r * 2 + 1) * N + j) * d.nzw;
+    if (lane == 0) a.gen[rj * gen::W + gen::ORIG_DPRES] = rd[rec::PRES];
+    if (lane < nw) rd[rec::WHAT + lane] = gn[4 + lane];
+    float x[4];
+    for (int c = 0; c < 4; ++c) {  // every lane computes the 4 components (tiny), lane 0 stores
+      float loc, sc;
+      if (a.cfg.rec_where_prior) {
+        float o[4];
+        for (int mm = 0; mm < 4; ++mm) {
+          float acc = hs[mm];
+          for (int i = 0; i < 4; ++i) acc += xprev[i] * flat[po.rn_i2h_w + i * 4 + mm];
+          o[mm] = tanhf(acc);
+        }
+        loc = flat[po.rn_readout_b + c];
+        float raw = flat[po.rn_readout_b + 4 + c];
+        for (int mm = 0; mm < 4; ++mm) {
+          loc += o[mm] * flat[po.rn_readout_w + mm * 8 + c];
+          raw += o[mm] * flat[po.rn_readout_w + mm * 8 + 4 + c];
+        }
+        sc = sq_softplus(raw) + 1e-2f;
+      } else {
+        loc = a.cfg.where_prior_mean[c];
+        sc = 1.0f;
+      }
+      x[c] = loc + sc * gn[c];
+    }
+    __syncthreads();
+    if (lane < 4) rd[rec::WHERE + lane] = x[lane];
+    if (lane == 0) rd[rec::PRES] = 0.0f;
+    for (int c = 0; c < 4; ++c) xprev[c] = x[c];
+  }
+}
+int sq_launch_generate_prop(const GenArgs& a, POff po, Dims d, hipStream_t s) {
+  (void)po;
+  hipLaunchKernelGGL(k_generate_prop, dim3(d.R), dim3(64), 0, s, a, d);
+  return 0;
+}
+int sq_launch_generate_disc(const GenArgs& a, POff po, Dims d, hipStream_t s) {
+  hipLaunchKernelGGL(k_generate_disc, dim3(d.R), dim3(64), 0, s, a, po, d);
   return 0;
 }
 

@@ -56,6 +56,7 @@ struct SqairHandle {
   std::vector<XOp> xprog;
   std::vector<uint64_t> xprog_key;
   int n_cu = 0;
+  const float* gen_noise = nullptr;  // sqair_set_generation_noise
   // generic capture slots (sqair_capture_begin / _end / _launch): any sequence of C-ABI calls as one HIP graph
   hipGraph_t cap_graph[4] = {nullptr, nullptr, nullptr, nullptr};
   hipGraphExec_t cap_exec[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -135,6 +136,7 @@ struct Workspace {
   float *r, *t1, *t2, *tp, *g2, *e1, *e2, *enc, *hraw, *s1h, *gz, *gr, *ghc, *grh, *gxh;  // per slot
   int* src;                                      // train: compaction source slot [T][R][N]
   float *qz, *pz, *dlp, *dll, *glimpse, *dec_a, *dec_b;
+  float* gen;                                    // sample_from_prior: [T][M][64] prior samples + original presences
   unsigned long long* prof_ts;
   int64_t total;  // floats
 

@@ -38,8 +38,6 @@ def make_config(F, img_hw):
         raise NotImplementedError(
             "HIP path implements the shipped cells (transition=VanillaRNN, time_transition=GRU, "
             "prior_transition=GRU); got {}/{}/{}".format(F.transition, F.time_transition, F.prior_transition))
-    if F.sample_from_prior:
-        raise NotImplementedError("sample_from_prior / generation modes are outside the hot path (SURVEY 8(f))")
     p = get_params(F)
     sp = parse_string_flag(F.scale_prior, num_elements=2)
     std = float(np.float32(np.float32(np.sqrt(F.output_std)) ** np.float32(2.0)))  # modules.py:419-422
@@ -47,7 +45,8 @@ def make_config(F, img_hw):
         int(img_hw[0]), int(img_hw[1]), int(F.glimpse_size), int(F.n_steps_per_image), int(F.n_what),
         int(p.n_hidden), int(F.k_particles), _PRIOR_TYPES[F.prop_prior_type], _DISC_PRIOR_TYPES[F.disc_prior_type],
         int(bool(F.masked_glimpse)), int(bool(F.rec_where_prior)), float(F.prop_prior_step_bias),
-        float(F.step_success_prob), std, std, (C.c_float * 4)(sp[0], sp[1], 0.0, 0.0))
+        float(F.step_success_prob), std, std, (C.c_float * 4)(sp[0], sp[1], 0.0, 0.0),
+        int(bool(F.sample_from_prior)), int(getattr(F, "generate_after", -1)))
 
 
 class SqairCore(object):
@@ -167,6 +166,11 @@ class SqairCore(object):
             self.out = {n: torch.zeros(shapes[n], dtype=torch.float32, device=self.device) for n in wanted}
             self.obs = torch.zeros(T, B, H, W, dtype=torch.float32, device=self.device)
             self.noise = torch.zeros(T, R, 2, N, self.nzw, dtype=torch.float32, device=self.device)
+            self.gen_noise = None
+            if self.cfg.sample_from_prior:  # second set of draws: the prior samples of the generation modes
+                self.gen_noise = torch.zeros(T, R, 2, N, self.nzw, dtype=torch.float32, device=self.device)
+                _capi.check(self.handle, self.lib.sqair_set_generation_noise(self.handle, self.gen_noise.data_ptr()),
+                            "sqair_set_generation_noise")
             self.ws_bytes = self.lib.sqair_workspace_bytes(self.handle, T, B)
             self.workspace = torch.empty(self.ws_bytes // 4, dtype=torch.float32, device=self.device)
             # ELBO outputs
@@ -198,6 +202,9 @@ class SqairCore(object):
         if seed is None:
             self.noise.normal_(generator=generator)
             self.noise[..., -1].uniform_(generator=generator)
+            if self.gen_noise is not None:
+                self.gen_noise.normal_(generator=generator)
+                self.gen_noise[..., -1].uniform_(generator=generator)
             return
         with torch.cuda.device(self.device):
             self._join_in()
@@ -393,7 +400,7 @@ class Model(object):
         self._use_graph = False
 
     # `sess.run` --------------------------------------------------------------------------------------
-    def run(self, noise=None, generator=None, resample_u=None, use_graph=None):
+    def run(self, noise=None, generator=None, resample_u=None, use_graph=None, gen_noise=None):
         """``sess.run`` of the whole output dict: synchronous like its reference counterpart (returns when the results
         are in the output tensors).  Everything is issued on the core's own stream."""
         core = self.core
@@ -402,6 +409,8 @@ class Model(object):
         with core.on_stream():
             if noise is not None:
                 core.noise.copy_(torch.as_tensor(noise, dtype=torch.float32).reshape(core.noise.shape))
+                if gen_noise is not None:
+                    core.gen_noise.copy_(torch.as_tensor(gen_noise, dtype=torch.float32).reshape(core.noise.shape))
             else:
                 core.draw_noise(generator)
             core.forward(use_graph=self._use_graph)

@@ -230,3 +230,45 @@ def test_xcd_persistent_forward_matches_launch_per_layer(K, N, T, B, hw):
                 scale = max(float(ref[k].abs().max()), 1e-6)
                 assert float((v - ref[k]).abs().max()) <= 5e-5 * scale, (k, rep)
             assert float((core.log_weights - lw).abs().max()) <= 1e-4 * float(lw.abs().max())
+
+
+@pytest.mark.parametrize("generate_after,prior", [(-1, "rnn"), (1, "rnn"), (1, "guided"), (2, "rw")])
+def test_generation_modes_vs_live_oracle(generate_after, prior):
+    """`sample_from_prior` (posterior log-probs at prior samples, sqair_modules.py:294-302) and
+    generation of the frames t > generate_after from the priors (seq.py:198-200, sqair_modules.py:157-170)."""
+    from oracle import sqair_oracle as O
+    from sqair_amd.model import Model, SqairCore
+    K, N, T, B, hw = 3, 3, 5, 3, (32, 40)
+    F = make_flags(k_particles=K, n_steps_per_image=N, sample_from_prior=True, generate_after=generate_after,
+                   prop_prior_type=prior, rec_where_prior=(prior != "rw"))
+    d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=20, seed=13)
+    obs = to_float(d["imgs"])
+    P = params32(F, hw, 6, 0.05, obs.mean((0, 1)))
+    core = SqairCore(F, hw)
+    core.set_params(P)
+    m = Model(obs, None, core, K, presence=d["nums"])
+    orc = O.SqairOracle(P, O.make_cfg(F, hw), torch.float64)
+    for attempt in range(30):
+        rng = np.random.default_rng(400 + attempt)
+        noise, gen_noise = draw_noise(rng, T, B * K, N, 55), draw_noise(rng, T, B * K, N, 55)
+        with torch.no_grad():
+            ref = orc.model(obs, noise, num=d["nums"], gen_noise=gen_noise)
+        m.run(noise=noise, gen_noise=gen_noise)
+        if all(np.array_equal(getattr(m, k).cpu().numpy(), getattr(ref, k).numpy()) for k in ("prop_pres", "disc_pres", "presence")):
+            break
+    else:
+        pytest.fail("no noise draw with identical discrete decisions")
+    if generate_after > 0:
+        assert float(m.disc_pres[generate_after + 1:].abs().sum()) == 0.0
+        assert float(m.num_disc_steps_per_sample[:generate_after + 1].sum()) > 0
+    worst = 0.0
+    for k, v in core.out.items():
+        name = "_" + k if k.startswith("final_") else k
+        want = ref.outputs[name].numpy() if name in ref.outputs else None
+        if want is None:
+            continue
+        got = v.cpu().numpy().reshape(want.shape)
+        err = np.abs(got - want).max() / max(np.abs(want).max(), 1.0)
+        worst = max(worst, err)
+        assert err <= 2e-5, (k, err)
+    assert abs(float(m.elbo_iwae) - float(ref.elbo_iwae)) <= 1e-4 * abs(float(ref.elbo_iwae))
