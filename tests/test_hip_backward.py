@@ -522,3 +522,14 @@ def test_trainer_follows_the_sequence_length_curriculum():
     core.stream.synchronize()
     assert seen == [2, 2, 3, 3, 4, 4]
     assert torch.isfinite(core.flat).all()
+
+
+@pytest.mark.parametrize("K,N,T,B,hw", [(2, 8, 2, 2, (50, 50)), (64, 1, 2, 1, (50, 50)), (2, 1, 1, 1, (50, 50))])
+def test_edges_of_the_supported_range_forward_and_backward(K, N, T, B, hw):
+    """N = 8 slots (SQ_MAXN), K = 64 particles, the smallest problem (one slot, one frame, one sequence): outputs and every
+    parameter gradient against the fp64 oracle."""
+    report, ref, core = _full_backward_case(K, N, T, B, hw, seed=31)
+    _check_report(report)
+    lw = core.out["log_weights_per_timestep"].cpu().numpy()
+    want = ref.log_weights_per_timestep.detach().numpy()
+    assert np.abs(lw - want).max() <= 1e-4 * np.abs(want).max()
