@@ -533,3 +533,36 @@ def test_edges_of_the_supported_range_forward_and_backward(K, N, T, B, hw):
     lw = core.out["log_weights_per_timestep"].cpu().numpy()
     want = ref.log_weights_per_timestep.detach().numpy()
     assert np.abs(lw - want).max() <= 1e-4 * np.abs(want).max()
+
+
+def test_rccl_all_reduce_on_the_gradient_buffer_single_rank():
+    """The step's collective through torch.distributed's RCCL backend, issued while the core's stream is the current
+    stream (world size 1 on this box: the reduction is the identity, what is checked is that the call composes with the
+    one-stream discipline and the replayed gradient graph)."""
+    import torch.distributed as dist
+    from sqair_amd.data import make_sequences, to_float
+    from sqair_amd.model import Model, SqairCore
+    from tests.hip_util import params32
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    K, N, T, B, hw = 2, 2, 2, 2, (50, 50)
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    obs = to_float(make_sequences(B, T=T, canvas=hw, seed=2)["imgs"])
+    core = SqairCore(F, hw)
+    core.set_params(params32(F, hw, 4, 0.05, obs.mean((0, 1))))
+    Model(obs, None, core, K, outputs="minimal")
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29617", world_size=1, rank=0)
+    try:
+        with core.on_stream():
+            core.draw_noise(seed=3, step=0)
+            g = core.grad_step(use_graph=True)
+            before = g.clone()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            g.div_(dist.get_world_size())
+            after = g.clone()
+            again = core.grad_step(use_graph=True).clone()   # (overwrites the same flat gradient buffer)
+        core.stream.synchronize()
+        assert torch.equal(after, before)
+        assert float((again - before).abs().max()) <= 1e-5 * float(before.abs().max())
+    finally:
+        dist.destroy_process_group()
