@@ -173,6 +173,10 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+        # RCCL writes its start-up banner (NCCL_DEBUG=VERSION on the GPU boxes) to the C stdout buffer at communicator
+        # creation: push it out now, on every rank, so that rank 0's JSON line is the LAST thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -301,7 +305,10 @@ def main():
         line["speedup_vs_cpu_baseline"] = value / world / cpu["value"]
         if train is not None:
             train["speedup_vs_cpu_baseline"] = train["value"] / world / cpu["train_value"]
-    print(json.dumps(line))
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
