@@ -110,6 +110,15 @@ def gru(P, name, x, h):
     return (1.0 - z) * h + z * hc
 
 
+def lstm(P, name, x, h, c, forget_bias=1.0):
+    """snt.LSTM (dm_sonnet 1.14, restated): gates = [x, h] w_gates + b_gates, split into (i, j, f, o);
+    c' = sigmoid(f + forget_bias) c + sigmoid(i) tanh(j); h' = tanh(c') sigmoid(o).  Returns (h', c')."""
+    g = torch.cat([x, h], -1) @ P[name + ".w"] + P[name + ".b"]
+    i, j, f, o = torch.chunk(g, 4, -1)
+    c2 = torch.sigmoid(f + forget_bias) * c + torch.sigmoid(i) * torch.tanh(j)
+    return torch.tanh(c2) * torch.sigmoid(o), c2
+
+
 def normal_log_prob(x, loc, scale):
     """tfd.Normal.log_prob."""
     return -0.5 * ((x - loc) / scale) ** 2 - torch.log(scale) - 0.5 * LOG_2PI
@@ -307,8 +316,8 @@ class SqairOracle(object):
     def __init__(self, params, cfg, dtype=torch.float64, requires_grad=False):
         self.cfg = cfg
         self.dtype = dtype
-        if cfg.transition != "VanillaRNN" or cfg.time_transition != "GRU" or cfg.prior_transition != "GRU":
-            raise NotImplementedError("oracle restates the shipped cells only (VanillaRNN / GRU / GRU)")
+        if cfg.transition != "VanillaRNN" or cfg.time_transition not in ("GRU", "LSTM") or cfg.prior_transition != "GRU":
+            raise NotImplementedError("oracle restates transition=VanillaRNN, time_transition in {GRU, LSTM}, prior_transition=GRU")
         if cfg.prop_prior_type not in ("rnn", "rw", "guided"):
             raise ValueError('Invalid prior type: "{}"'.format(cfg.prop_prior_type))  # propagate.py:42-43
         if cfg.disc_prior_type not in ("cat", "geom"):
@@ -400,6 +409,12 @@ class SqairOracle(object):
         P = self.P
         what_tm1, where_tm1, pres_tm1, logit_tm1 = z_tm1_k
         what_km1, where_km1, pres_km1, hidden = state
+        # core.py:284: temporal_state = nest.flatten(temporal_hidden_state)[-1] — the GRU state itself, the CELL state of an
+        # LSTM.  An LSTMState travels here as one tensor [hidden | cell] (so that compaction treats it like any feature).
+        lstm_time = c.time_transition == "LSTM"
+        temporal_full = temporal_state
+        if lstm_time:
+            temporal_state = temporal_full[..., c.n_hidden:]
         # rnn_inpt (core.py:291-304)
         where_bias = mlp_1hidden_out(P, "prop.where_bias", temporal_state) * 0.1
         loc1, _ = self.air_encoder(img, where_tm1 + where_bias, mask_inpt=temporal_state)
@@ -415,9 +430,14 @@ class SqairOracle(object):
         where = loc + (L @ eps_where.unsqueeze(-1)).squeeze(-1)
         # what (core.py:336-359)
         loc2, scale2 = self.air_encoder(img, where, mask_inpt=temporal_state)
-        temporal_new = gru(P, "prop.temporal_gru", torch.cat([hidden, where, loc2, scale2], -1), temporal_state)
-        t_loc, t_scale = self.gaussian_head("prop.what_head", temporal_new)
-        gates = torch.sigmoid(linear(P, "prop.gates", temporal_new)) * 0.9999
+        cell_inpt = torch.cat([hidden, where, loc2, scale2], -1)
+        if lstm_time:
+            temporal_out, cell_new = lstm(P, "prop.temporal_lstm", cell_inpt, temporal_full[..., :c.n_hidden], temporal_state)
+            temporal_new = torch.cat([temporal_out, cell_new], -1)
+        else:
+            temporal_new = temporal_out = gru(P, "prop.temporal_gru", cell_inpt, temporal_state)
+        t_loc, t_scale = self.gaussian_head("prop.what_head", temporal_out)
+        gates = torch.sigmoid(linear(P, "prop.gates", temporal_out)) * 0.9999
         nw = c.n_what
         fg, ig, tg = gates[..., :nw], gates[..., nw:2 * nw], gates[..., 2 * nw:]
         what_loc = fg * what_tm1 + (1.0 - ig) * loc2 + (1.0 - tg) * t_loc
@@ -591,6 +611,12 @@ class SqairOracle(object):
         f = mlp2_hidden(self.P, "seq.latent_enc", torch.cat([what, where], -1).reshape(B * N, -1))
         return (f.reshape(B, N, -1) * presence).sum(-2)
 
+    def initial_temporal_state(self):
+        """initial_temporal_state (sqair_modules.py:352-366): trainable; [hidden | cell] for an LSTM."""
+        if self.cfg.time_transition == "LSTM":
+            return torch.cat([self.P["seq.temporal_init"], self.P["seq.temporal_init_c"]], -1)
+        return self.P["seq.temporal_init"]
+
     def timestep(self, img, z_tm1, temporal_state, prior_state, last_used_id, prev_ids, t, noise, gen_noise=None):
         """SQAIRTimestep._build/_propagate_and_discover/_choose_latents (sqair_modules.py:446-582)."""
         c = self.cfg
@@ -604,7 +630,7 @@ class SqairOracle(object):
         disc = self.discover(img, cond, exp_steps, t, noise[:, 1], gn[:, 1], do_generate)
         # merge (sqair_modules.py:514-582)
         names = "what what_loc what_scale where where_loc where_scale presence_prob presence presence_logit".split()
-        init_temporal = self.P["seq.temporal_init"][None].expand(B, N, -1)
+        init_temporal = self.initial_temporal_state()[None].expand(B, N, -1)
         init_prior = self.P["seq.prior_init"][None].expand(B, N, -1)
         temporal_cat = torch.cat([prop["temporal_state"], init_temporal], 1)
         prior_cat = torch.cat([prop["prior_state"], init_prior], 1)
@@ -654,7 +680,7 @@ class SqairOracle(object):
         dt = self.dtype
         z = (torch.zeros(B, N, nw, dtype=dt), torch.zeros(B, N, 4, dtype=dt), torch.zeros(B, N, 1, dtype=dt),
              torch.zeros(B, N, 1, dtype=dt))
-        temporal = self.P["seq.temporal_init"][None].expand(B, N, -1)
+        temporal = self.initial_temporal_state()[None].expand(B, N, -1)
         prior = self.P["seq.prior_init"][None].expand(B, N, -1)
         prev_ids = -torch.ones(B, N, 1, dtype=dt)
         last_id = -torch.ones(B, 1, dtype=dt)
