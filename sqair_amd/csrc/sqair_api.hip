@@ -91,7 +91,8 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "disc.rnn.i2h", nh + nh + nw + 4 + 1, nh);
   add_param(h, "disc.step_prior_bias", 1, N + 1);
   add_param(h, "disc.step_prior_timestep_bias", 1, N + 1);
-  add_gru(h, "prop.temporal_gru", nh + 4 + 2 * nw, nh);
+  if (c.time_lstm) add_lin(h, "prop.temporal_lstm", (nh + 4 + 2 * nw) + nh, 4 * nh);  // snt.LSTM: w_gates [x | h] rows, b_gates
+  else add_gru(h, "prop.temporal_gru", nh + 4 + 2 * nw, nh);
   add_gru(h, "prop.prior_gru", nw + 4, nh);
   add_lin(h, "prop.prior_linear", nh, 2 * (4 + nw) + 1);
   add_param(h, "prop.cholesky_scale", 1, 10);
@@ -110,6 +111,7 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "prop.rnn.i2h", nw + (nw + 5) + (nw + 5) + nh, nh);
   add_param(h, "seq.prior_init", 1, nh);
   add_param(h, "seq.temporal_init", 1, nh);
+  if (c.time_lstm) add_param(h, "seq.temporal_init_c", 1, nh);  // LSTMState(hidden, cell): adjacent, read as one [2 nh] row
   add_lin(h, "seq.latent_enc.l0", nw + 4, nh);
   add_lin(h, "seq.latent_enc.l1", nh, nh);
 
@@ -309,6 +311,7 @@ static void build_plan(SqairHandle* h) {
     s1.bias_a = "prop.steps.l0.b";
     bl.push_back(s1);
     for (const char* g : {"z", "r"}) {
+      if (c.time_lstm) break;  // the LSTM's recurrent rows read the HIDDEN half of the state: their own layer below
       ColBlock u;
       u.ncols = nh; u.col0 = 0;
       u.seg = {{"", RowMap()}, {"", RowMap()}, {std::string("prop.temporal_gru.u") + g, rm_range(0, nh)}};
@@ -328,7 +331,18 @@ static void build_plan(SqairHandle* h) {
               {cb1(nh, 0, "prop.transform.l0.w", rm_range(0, nh)), cb1(nsp, 0, "prop.steps.l0.w", rm_range(0, nh))});
   simple(L_PROP_T2, "prop.transform.l1", nh, nh);
   simple(L_PROP_T3, "prop.transform.l2", nh, 8);
-  {
+  if (c.time_lstm) {
+    // temporal LSTM (core.py:340-341 with time_transition=LSTM): gate pre-activations (i, j, f, o) = [x | h] w_gates + b.
+    // L_PROP_GRU1 holds the x rows [hidden nh | where 4 | loc nw | scale nw], L_PROP_GRU2 the h rows + bias (applied to
+    // all slots of a frame at once, before the slot loop).
+    const std::string w = "prop.temporal_lstm.w";
+    const int fin = nh + 4 + 2 * nw;
+    ColBlock b;
+    b.ncols = 4 * nh; b.col0 = 0;
+    b.seg = {{w, rm_range(0, nh)}, {w, rm_range(nh, 4)}, {w, rm_range(nh + 4, 2 * nw)}};
+    build_layer(h, L_PROP_GRU1, {nh, 4, 2 * nw}, {b});
+    build_layer(h, L_PROP_GRU2, {nh}, {cb1(4 * nh, 0, w, rm_range(fin, nh), "prop.temporal_lstm.b")});
+  } else {
     // temporal GRU input [hidden nh | where 4 | loc nw | scale nw] (core.py:340-341)
     std::vector<ColBlock> bl;
     const char* g[3] = {"z", "r", "h"};
@@ -341,8 +355,8 @@ static void build_plan(SqairHandle* h) {
       bl.push_back(b);
     }
     build_layer(h, L_PROP_GRU1, {nh, 4, 2 * nw}, bl);
+    simple(L_PROP_GRU2, "prop.temporal_gru.uh", nh, nh, 0, false);
   }
-  simple(L_PROP_GRU2, "prop.temporal_gru.uh", nh, nh, 0, false);
   build_layer(h, L_PROP_HEADS, {nh},
               {cb1(2 * nw, 0, "prop.what_head.w", rm_range(0, nh), "prop.what_head.b"),
                cb1(3 * nw, 0, "prop.gates.w", rm_range(0, nh), "prop.gates.b")});
@@ -430,7 +444,7 @@ extern "C" int sqair_create(const SqairConfig* cfg, SqairHandle** out) {
   build_inventory(h);
   // GRU candidate matrices are bare [nh, nh] parameters: give build_plan's simple() a ".w" alias
   h->pidx["prop.prior_gru.uh.w"] = h->pidx["prop.prior_gru.uh"];
-  h->pidx["prop.temporal_gru.uh.w"] = h->pidx["prop.temporal_gru.uh"];
+  if (!cfg->time_lstm) h->pidx["prop.temporal_gru.uh.w"] = h->pidx["prop.temporal_gru.uh"];
   build_plan(h);
   build_plan_T(h);
   *out = h;
@@ -500,6 +514,8 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   Workspace w;
   memset(&w, 0, sizeof(w));
   w.train = train; w.T = T; w.B = B; w.R = (int)R; w.M = (int)M; w.N = (int)N; w.nh = (int)nh;
+  const int64_t snh = c.time_lstm ? 2 * nh : nh;  // temporal state of a slot: [hidden | cell] for the LSTM
+  w.snh = (int)snh;
   int64_t o = 0;
   auto take = [&](int64_t n) {
     float* p = base ? base + o : nullptr;
@@ -512,7 +528,7 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.ienc_b = take((int64_t)T * B * nh);
   w.pre_disc = take((int64_t)T * B * nh);
   w.rec_m_all = take((int64_t)(T + 1) * M * rec::W);
-  w.temporal_m = take((train ? T + 1 : 2) * M * nh);
+  w.temporal_m = take((train ? T + 1 : 2) * M * snh);
   w.prior_m = take((train ? T + 1 : 2) * M * nh);
   w.last_id[0] = take(R);
   w.last_id[1] = take(R);
@@ -525,7 +541,7 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.rn_init_state = take(4);
   w.w3_prop = take(nh * 8 + 8);
   w.w3_disc = take(nh * 8 + 8);
-  w.temporal_p = take(F * M * nh);
+  w.temporal_p = take(F * M * snh);
   w.prior_p = take(F * M * nh);
   w.pgz = take(F * M * nh);
   w.pgr = take(F * M * nh);
@@ -561,6 +577,9 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.ghc = take(S * R * nh);
   w.grh = take(R * nh);
   w.gxh = take(R * nh);
+  // LSTM: recurrent gate pre-activations of all slots of a frame, and the kept gate pre-activations per slot
+  w.lpre = take(c.time_lstm ? M * 4 * nh : 64);
+  w.lgates = take(c.time_lstm ? (train ? (int64_t)T * N : 1) * R * 4 * nh : 64);
   w.src = (int*)take(train ? (int64_t)T * M : 64);
   w.qz = take((int64_t)T * R);
   w.pz = take((int64_t)T * R);
@@ -675,11 +694,11 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   const int nh = c.n_hidden, nw = c.n_what, N = c.n_steps_per_image, K = c.k_particles;
   const int R = B * K, M = R * N, G2 = c.glimpse_size * c.glimpse_size, P_ = c.img_h * c.img_w;
   const int nzw = 4 + nw + 1;
-  Dims d{c.img_h, c.img_w, c.glimpse_size, N, nw, nh, K, R, B, nzw};
+  Dims d = make_dims(c, B);
   const POff po = h->po;
   const Workspace w = sq_carve(h, T, B, wsbase, train);
   const int pre_ld = h->layers[L_PRE].nt * 16;
-  const int RW = rec::W;
+  const int RW = rec::W, snh = d.snh;
   const PackedLayout pl = packed_layout(h);
 
   // ---- sequence prologue -----------------------------------------------------------------------
@@ -689,7 +708,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   if (parts & 1) {
     sq_zero_fill(wsbase, (int64_t)((float*)w.prof_ts - wsbase), s);
     // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
-    sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0), w.state(w.prior_m, 0), w.last_id[0], w.disc_init_rec,
+    sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0, w.snh), w.state(w.prior_m, 0, w.nh), w.last_id[0], w.disc_init_rec,
                          w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc,
                          (int)P(h, "prop.transform.l2.w"), (int)P(h, "disc.transform.l2.w"), flat, po, d, s);
     // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
@@ -708,9 +727,11 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     float* rec_d_t = w.rec_d_all + (size_t)t * M * RW;
     float* pstats_t = w.pstats + (size_t)t * M * PS_LD;
     float* spre_t = w.spre + (size_t)t * R * 128;
-    const float* temporal_prev = w.state(w.temporal_m, t);
-    const float* prior_prev = w.state(w.prior_m, t);
-    float* temporal_p = w.frame(w.temporal_p, (int64_t)M * nh, t);
+    const float* temporal_prev = w.state(w.temporal_m, t, w.snh);
+    const float* prior_prev = w.state(w.prior_m, t, w.nh);
+    float* temporal_p = w.frame(w.temporal_p, (int64_t)M * snh, t);
+    const float* tau_prev = temporal_prev + d.toff;  // what the slot networks read as "temporal state" (core.py:284): the
+                                                     // GRU state / the CELL half of an LSTM state, row stride snh
     float* prior_p = w.frame(w.prior_p, (int64_t)M * nh, t);
     float* hid1 = w.frame(w.hid1, (int64_t)M * 256, t);
     float* wb = w.frame(w.wb, (int64_t)M * WB_LD, t);
@@ -737,7 +758,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     }
     // ---- B. where-bias MLP and glimpse-mask MLP of every slot (core.py:292, modules.py:350-356) ----
     {
-      Lin a; a.seg(temporal_prev, nh, nh).out(hid1, 256).act(ACT_ELU); RUN(a, L_TAU1, M);
+      Lin a; a.seg(tau_prev, snh, nh).out(hid1, 256).act(ACT_ELU); RUN(a, L_TAU1, M);
       Lin b; b.seg(hid1, 256, 128).out(wb, WB_LD); RUN(b, L_WB2, M);
       Lin m; m.seg(hid1 + 128, 256, 128).out(mask, G2).act(ACT_SIGMOID); RUN(m, L_MASK2, M);
     }
@@ -753,8 +774,11 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     }
     // ---- D. loop-invariant pre-activations of all slots ----
     {
-      Lin p; p.seg(m1, M1_LD, nw).seg(rec_prev, RW, rec::ZW).seg(temporal_prev, nh, nh).out(w.pre, pre_ld);
+      Lin p; p.seg(m1, M1_LD, nw).seg(rec_prev, RW, rec::ZW).seg(tau_prev, snh, nh).out(w.pre, pre_ld);
       RUN(p, L_PRE, M);
+      if (c.time_lstm) {  // recurrent rows of the LSTM gates: h_{t-1} W_h + b of every slot
+        Lin q; q.seg(temporal_prev, snh, nh).out(w.lpre, 4 * nh); RUN(q, L_PROP_GRU2, M);
+      }
     }
     // ---- E. propagation slots (propagate.py:168-184 static_rnn over PropagationCore) ----
     for (int k = 0; k < N; ++k) {
@@ -796,7 +820,15 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         Lin b; b.seg(e1, rl, nh).out(e2, rl).act(ACT_ELU); RUN(b, L_GENC1, R);
         Lin e; e.seg(e2, rl, nh).out(enc, el).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
       }
-      {
+      if (c.time_lstm) {
+        float* gates = train ? w.lgates + ((size_t)t * M + k) * 4 * nh : w.lgates;
+        const int gld = train ? N * 4 * nh : 4 * nh;
+        Lin gl; gl.seg(r_k, rl, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(enc, el, 2 * nw)
+                  .add(w.lpre + (size_t)k * 4 * nh, N * 4 * nh, 4 * nh).out(gates, gld);
+        RUN(gl, L_PROP_GRU1, R);
+        sq_launch_lstm_cell(gates, gld, tau_prev + (size_t)k * snh, N * snh, temporal_p + (size_t)k * snh, N * snh, R, nh, s);
+        Lin hd; hd.seg(temporal_p + (size_t)k * snh, N * snh, nh).out(hraw, hl); RUN(hd, L_PROP_HEADS, R);
+      } else {
         const float* tau_k = temporal_prev + (size_t)k * nh;
         Lin g1l; g1l.seg(r_k, rl, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(enc, el, 2 * nw)
                    .add(pre_k + 2 * nh + nh / 2, pre_rld, 2 * nh).out(gz, rl)
@@ -884,7 +916,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
       CompactArgs ka; memset(&ka, 0, sizeof(ka));
       ka.rec_p = rec_p_t; ka.rec_d = rec_d_t; ka.rec_prev = rec_prev; ka.temporal_p = temporal_p;
       ka.prior_p = prior_p; ka.last_id_prev = w.last_id[pp]; ka.last_id_next = w.last_id[pn];
-      ka.rec_next = rec_next; ka.temporal_next = w.state(w.temporal_m, t + 1); ka.prior_next = w.state(w.prior_m, t + 1);
+      ka.rec_next = rec_next; ka.temporal_next = w.state(w.temporal_m, t + 1, w.snh); ka.prior_next = w.state(w.prior_m, t + 1, w.nh);
       ka.flat = flat; ka.t = t; ka.out = out;
       ka.src_out = train ? w.src + (size_t)t * M : nullptr;
       emit_compact(h, ka, po, d, s);
@@ -917,9 +949,9 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   }
   // final recurrent state (for state-level parity checks)
   if (out.final_temporal_state)
-    sq_copy(out.final_temporal_state, w.state(w.temporal_m, T), (int64_t)M * nh, s);
+    sq_copy(out.final_temporal_state, w.state(w.temporal_m, T, w.snh), (int64_t)M * snh, s);
   if (out.final_prior_state)
-    sq_copy(out.final_prior_state, w.state(w.prior_m, T), (int64_t)M * nh, s);
+    sq_copy(out.final_prior_state, w.state(w.prior_m, T, w.nh), (int64_t)M * nh, s);
   if (out.final_last_used_id)
     sq_copy(out.final_last_used_id, w.last_id[T & 1], (int64_t)R, s);
   SQ_CHECK_HIP(hipGetLastError());
@@ -958,13 +990,17 @@ extern "C" int sqair_forward_persistent(SqairHandle* h, const float* flat_params
                                         void* stream) {
   if (!h || !out || !program) return -1;
   hipStream_t s = (hipStream_t)stream;
+  if (h->cfg.time_lstm) {
+    sq_set_error(h, "sqair_forward_persistent: the experimental persistent executor covers the GRU temporal cell only");
+    return -1;
+  }
   if (program_bytes < sqair_program_bytes(h, T, B)) {
     sq_set_error(h, "sqair_forward_persistent: program buffer too small");
     return -1;
   }
   const SqairConfig& c = h->cfg;
   const int R = B * c.k_particles;
-  Dims d{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles, R, B, 4 + c.n_what + 1};
+  Dims d = make_dims(c, B);
   unsigned* sync = (unsigned*)program;
   XOp* prog_dev = (XOp*)((char*)program + XSYNC_WORDS * 4 + (256 - (XSYNC_WORDS * 4) % 256) % 256);
   // key of the cached program: every argument that is baked into the ops
@@ -1156,8 +1192,7 @@ extern "C" int sqair_st_crop(SqairHandle* h, const float* img, const float* wher
                              int B, void* stream) {
   if (!h || !img || !where_logits || !out || B < 1) return -1;
   const SqairConfig& c = h->cfg;
-  Dims d{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles,
-         B * c.k_particles, B, 4 + c.n_what + 1};
+  Dims d = make_dims(c, B);
   CropArgs ca; memset(&ca, 0, sizeof(ca));
   ca.mode = CROP_PLAIN; ca.img = img; ca.logits = where_logits; ca.mask = mask; ca.mask_row_mul = 1; ca.out = out;
   ca.out_row_mul = 1;
@@ -1171,8 +1206,7 @@ extern "C" int sqair_st_insert_loglik(SqairHandle* h, const float* glimpse, cons
                                       float* data_ll, int B, void* stream) {
   if (!h || !glimpse || !where_logits || !presence || !img || !mean_img || !data_ll || B < 1) return -1;
   const SqairConfig& c = h->cfg;
-  Dims d{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles,
-         B * c.k_particles, B, 4 + c.n_what + 1};
+  Dims d = make_dims(c, B);
   InsertArgs ia; memset(&ia, 0, sizeof(ia));
   ia.glimpse = glimpse; ia.where_plain = where_logits; ia.pres_plain = presence; ia.img = img; ia.mean_img = mean_img;
   ia.canvas = canvas; ia.data_ll = data_ll; ia.std_fg = c.output_std; ia.std_bg = c.background_std;
@@ -1416,7 +1450,7 @@ extern "C" int sqair_backward_decoder(SqairHandle* h, const float* flat, const v
   const SqairConfig& c = h->cfg;
   const int nh = c.n_hidden, nw = c.n_what, N = c.n_steps_per_image, K = c.k_particles;
   const int R = B * K, M = R * N, MT = M * T, G2 = c.glimpse_size * c.glimpse_size, P_ = c.img_h * c.img_w;
-  Dims d{c.img_h, c.img_w, c.glimpse_size, N, nw, nh, K, R, B, 4 + nw + 1};
+  Dims d = make_dims(c, B);
   Workspace w = carve(h, T, B, (float*)workspace);
   const PackedLayout pl = packed_layout(h);
   const int RW = rec::W;

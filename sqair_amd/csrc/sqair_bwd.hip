@@ -94,8 +94,7 @@ extern "C" int sqair_st_crop_bwd(SqairHandle* h, const float* img, const float* 
   if (!h || !img || !where_logits || !g_out || !d_where_logits || B < 1) return -1;
   SqairConfig c;
   if (sqair_get_config(h, &c) != 0) return -1;
-  Dims d{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles,
-         B * c.k_particles, B, 4 + c.n_what + 1};
+  Dims d = make_dims(c, B);
   CropBwdArgs a{img, where_logits, mask, g_out, d_where_logits, d_mask};
   const size_t shm = (size_t)d.H * d.W * sizeof(float);
   static bool big = false;
@@ -293,8 +292,7 @@ extern "C" int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, 
     return -1;
   SqairConfig c;
   if (sqair_get_config(h, &c) != 0) return -1;
-  Dims d{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles,
-         B * c.k_particles, B, 4 + c.n_what + 1};
+  Dims d = make_dims(c, B);
   const int P = d.H * d.W;
   if (scratch_bytes < (int64_t)d.R * P * 4) return -1;
   InsertBwdArgs a{glimpse, where_logits, presence, img, mean_img, g_data_ll, d_glimpse, d_where_logits, (float*)scratch,
@@ -966,6 +964,37 @@ int sq_launch_logprob_bwd(const LogprobBwdArgs& a, POff po, Dims d, int T, hipSt
 }
 
 // ------------------------------------------------------------------------------------------------
+// LSTM cell adjoint (mirror of k_lstm_cell): from d h' and d c' to the gate pre-activation gradients (i, j, f, o)
+// and d c_prev; c' is recomputed from the kept gate pre-activations.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lstm_cell_bwd(const float* __restrict__ gates, int g_ld, const float* __restrict__ c_prev,
+                                                       int c_ld, const float* __restrict__ d_h, int dh_ld,
+                                                       const float* __restrict__ d_c, int dc_ld, float* __restrict__ d_gates,
+                                                       int dg_ld, float* __restrict__ d_cprev, int dcp_ld, int rows, int nh) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * nh) return;
+  const int r = e / nh, q = e - r * nh;
+  const float* g = gates + (size_t)r * g_ld;
+  const float si = sq_sigmoid(g[q]), tj = tanhf(g[nh + q]), sf = sq_sigmoid(g[2 * nh + q] + 1.0f), so = sq_sigmoid(g[3 * nh + q]);
+  const float cp = c_prev[(size_t)r * c_ld + q];
+  const float tc = tanhf(sf * cp + si * tj);
+  const float dh = d_h[(size_t)r * dh_ld + q];
+  const float dc = d_c[(size_t)r * dc_ld + q] + dh * so * (1.0f - tc * tc);
+  float* dg = d_gates + (size_t)r * dg_ld;
+  dg[q] = dc * tj * si * (1.0f - si);
+  dg[nh + q] = dc * si * (1.0f - tj * tj);
+  dg[2 * nh + q] = dc * cp * sf * (1.0f - sf);
+  dg[3 * nh + q] = dh * tc * so * (1.0f - so);
+  d_cprev[(size_t)r * dcp_ld + q] = dc * sf;
+}
+int sq_launch_lstm_cell_bwd(const float* gates, int g_ld, const float* c_prev, int c_ld, const float* d_h, int dh_ld, const float* d_c,
+                            int dc_ld, float* d_gates, int dg_ld, float* d_cprev, int dcp_ld, int rows, int nh, hipStream_t s) {
+  hipLaunchKernelGGL(k_lstm_cell_bwd, dim3((rows * nh + 255) / 256), dim3(256), 0, s, gates, g_ld, c_prev, c_ld, d_h, dh_ld, d_c, dc_ld,
+                     d_gates, dg_ld, d_cprev, dcp_ld, rows, nh);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // compaction adjoint: route the gradients of the merged slots of frame t+1 back to their source slots
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, const POff po, const Dims d) {
@@ -983,18 +1012,20 @@ __global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, con
     float* tgt = sl < N ? a.d_rec_p + ((size_t)r * N + sl) * RW : a.d_rec_d + ((size_t)r * N + (sl - N)) * RW;
     tgt[i] += g;
   }
+  const int snh = d.snh;
+  for (int e = tid; e < 2 * N * snh; e += 256) {
+    const int sl = e / snh, i = e - sl * snh;
+    const int dst = inv_s[sl];
+    const float gt = dst >= 0 ? a.d_temporal_next[((size_t)r * N + dst) * snh + i] : 0.0f;
+    if (sl < N) a.d_temporal_p[((size_t)r * N + sl) * snh + i] = gt;
+    else if (dst >= 0) unsafeAtomicAdd(&a.flat_grad[po.temporal_init + i], gt);  // a newly discovered object starts from
+  }                                                                                // the trainable initial states
   for (int e = tid; e < 2 * N * nh; e += 256) {
     const int sl = e / nh, i = e - sl * nh;
     const int dst = inv_s[sl];
-    const float gt = dst >= 0 ? a.d_temporal_next[((size_t)r * N + dst) * nh + i] : 0.0f;
     const float gp = dst >= 0 ? a.d_prior_next[((size_t)r * N + dst) * nh + i] : 0.0f;
-    if (sl < N) {
-      a.d_temporal_p[((size_t)r * N + sl) * nh + i] = gt;
-      a.d_prior_p[((size_t)r * N + sl) * nh + i] = gp;
-    } else if (dst >= 0) {  // a newly discovered object starts from the trainable initial states
-      unsafeAtomicAdd(&a.flat_grad[po.temporal_init + i], gt);
-      unsafeAtomicAdd(&a.flat_grad[po.prior_init + i], gp);
-    }
+    if (sl < N) a.d_prior_p[((size_t)r * N + sl) * nh + i] = gp;
+    else if (dst >= 0) unsafeAtomicAdd(&a.flat_grad[po.prior_init + i], gp);
   }
 }
 int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t s) {

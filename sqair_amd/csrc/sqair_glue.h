@@ -19,7 +19,14 @@ struct POff {
 struct Dims {
   int H, W, G, N, nw, nh, K, R, B;  // R = B*K rows
   int nzw;                          // noise width = 4 + nw + 1
+  int snh;                          // width of the temporal state of a slot: nh (GRU) or 2 nh = [hidden | cell] (LSTM)
+  int toff;                         // offset of the features the model reads from it: 0 (GRU state) / nh (LSTM cell, core.py:284)
 };
+inline Dims make_dims(const SqairConfig& c, int B) {
+  const int lstm = c.time_lstm != 0;
+  return Dims{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles, B * c.k_particles, B,
+              4 + c.n_what + 1, lstm ? 2 * c.n_hidden : c.n_hidden, lstm ? c.n_hidden : 0};
+}
 
 enum CropMode { CROP_PLAIN = 0, CROP_PROP1 = 1, CROP_PROP2 = 2, CROP_DISC = 3 };
 
@@ -47,6 +54,8 @@ struct CropArgs {
   int tp_out_ld;
 };
 
+int sq_launch_lstm_cell(const float* gates, int g_ld, const float* c_prev, int c_ld, float* state_out, int o_ld, int rows, int nh,
+                        hipStream_t s);
 int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float* last_id, float* disc_init_rec,
                          float* prop_rnn_init, float* disc_rnn_init, float* rn_init_state, float* w3_prop, float* w3_disc,
                          int w3p_off, int w3d_off, const float* flat,

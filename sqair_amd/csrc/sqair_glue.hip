@@ -16,10 +16,9 @@ __global__ void k_init_state(float* __restrict__ rec_m, float* __restrict__ temp
   const int rs = blockIdx.x;  // row*N + slot
   const int tid = threadIdx.x;
   for (int i = tid; i < rec::W; i += blockDim.x) rec_m[(size_t)rs * rec::W + i] = (i == rec::ID) ? -1.0f : 0.0f;
-  for (int i = tid; i < d.nh; i += blockDim.x) {
-    temporal_m[(size_t)rs * d.nh + i] = flat[po.temporal_init + i];
-    prior_m[(size_t)rs * d.nh + i] = flat[po.prior_init + i];
-  }
+  // LSTM: [hidden | cell] initial states are adjacent in the flat buffer (seq.temporal_init, seq.temporal_init_c)
+  for (int i = tid; i < d.snh; i += blockDim.x) temporal_m[(size_t)rs * d.snh + i] = flat[po.temporal_init + i];
+  for (int i = tid; i < d.nh; i += blockDim.x) prior_m[(size_t)rs * d.nh + i] = flat[po.prior_init + i];
   if (tid == 0 && (rs % d.N) == 0) last_id[rs / d.N] = -1.0f;
   if (rs == 0) {  // aligned copies of the small trainable initial states (GEMM A-operand contract)
     if (tid == 0) disc_init_rec[rec::PRES] = 1.0f;
@@ -35,6 +34,28 @@ __global__ void k_init_state(float* __restrict__ rec_m, float* __restrict__ temp
       w3_disc[i] = flat[w3d_off + i];
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LSTM cell epilogue of the propagation temporal cell (time_transition=LSTM; snt.LSTM, dm_sonnet 1.14: gates =
+// [x, h] w_gates + b_gates split (i, j, f, o); c' = sigmoid(f + 1) c + sigmoid(i) tanh(j); h' = tanh(c') sigmoid(o)).
+// `gates` holds the finished pre-activations of one slot, [rows][4 nh]; the new state goes to [h' | c'].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lstm_cell(const float* __restrict__ gates, int g_ld, const float* __restrict__ c_prev,
+                                                   int c_ld, float* __restrict__ state_out, int o_ld, int rows, int nh) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * nh) return;
+  const int r = e / nh, q = e - r * nh;
+  const float* g = gates + (size_t)r * g_ld;
+  const float gi = g[q], gj = g[nh + q], gf = g[2 * nh + q], go = g[3 * nh + q];
+  const float c = sq_sigmoid(gf + 1.0f) * c_prev[(size_t)r * c_ld + q] + sq_sigmoid(gi) * tanhf(gj);
+  state_out[(size_t)r * o_ld + q] = tanhf(c) * sq_sigmoid(go);
+  state_out[(size_t)r * o_ld + nh + q] = c;
+}
+int sq_launch_lstm_cell(const float* gates, int g_ld, const float* c_prev, int c_ld, float* state_out, int o_ld, int rows, int nh,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(k_lstm_cell, dim3((rows * nh + 255) / 256), dim3(256), 0, s, gates, g_ld, c_prev, c_ld, state_out, o_ld, rows, nh);
+  return 0;
 }
 
 int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float* last_id, float* disc_init_rec,
@@ -645,7 +666,8 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff
   __syncthreads();
   const size_t tr = (size_t)a.t * d.R + r;
   // copy the N survivors: record (168) + temporal state + prior state, one flat loop of independent loads
-  const int per = rec::W + 2 * nh;
+  const int snh = d.snh;
+  const int per = rec::W + snh + nh;
 #pragma unroll 4
   for (int e = tid; e < N * per; e += 256) {
     const int dst = e / per, i = e - dst * per;
@@ -655,12 +677,12 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff
     if (i < rec::W) {
       const float* rs = (prop ? a.rec_p : a.rec_d) + ((size_t)r * N + ss) * rec::W;
       a.rec_next[((size_t)r * N + dst) * rec::W + i] = (i == rec::ID) ? id_s[dst] : rs[i];
-    } else if (i < rec::W + nh) {
+    } else if (i < rec::W + snh) {
       const int q = i - rec::W;
-      a.temporal_next[((size_t)r * N + dst) * nh + q] =
-          prop ? a.temporal_p[((size_t)r * N + ss) * nh + q] : a.flat[po.temporal_init + q];
+      a.temporal_next[((size_t)r * N + dst) * snh + q] =
+          prop ? a.temporal_p[((size_t)r * N + ss) * snh + q] : a.flat[po.temporal_init + q];
     } else {
-      const int q = i - rec::W - nh;
+      const int q = i - rec::W - snh;
       a.prior_next[((size_t)r * N + dst) * nh + q] = prop ? a.prior_p[((size_t)r * N + ss) * nh + q] : a.flat[po.prior_init + q];
     }
   }

@@ -123,10 +123,10 @@ constexpr int PS_LD = 112, ENC_LD = 112, M1_LD = 64, HRAW_LD = 256, WB_LD = 4, T
 
 struct Workspace {
   bool train;
-  int T, B, R, M, N, nh;
+  int T, B, R, M, N, nh, snh;
   float *ienc_a, *ienc_b, *pre_disc;
   float *rec_m_all, *rec_p_all, *rec_d_all;
-  float *temporal_m, *prior_m;                   // train: [T+1][M][nh], else [2][M][nh]
+  float *temporal_m, *prior_m;                   // train: [T+1][M][snh | nh], else [2][M][snh | nh]
   float *last_id[2];
   float *zero_rec, *disc_init_rec, *prop_rnn_init, *disc_rnn_init, *rn_init_state, *w3_prop, *w3_disc;
   float *temporal_p, *prior_p;                   // per frame
@@ -134,6 +134,7 @@ struct Workspace {
   float *pstats, *spre;                          // always [T]
   float *hid1, *wb, *mask, *g1, *pea, *peb, *m1, *pre, *lea, *leb, *c, *pre_d;  // per frame
   float *r, *t1, *t2, *tp, *g2, *e1, *e2, *enc, *hraw, *s1h, *gz, *gr, *ghc, *grh, *gxh;  // per slot
+  float *lpre, *lgates;                          // LSTM temporal cell (time_lstm): [M][4nh], kept gates [T][R][N][4nh]
   int* src;                                      // train: compaction source slot [T][R][N]
   float *qz, *pz, *dlp, *dll, *glimpse, *dec_a, *dec_b;
   float* gen;                                    // sample_from_prior: [T][M][64] prior samples + original presences
@@ -141,7 +142,7 @@ struct Workspace {
   int64_t total;  // floats
 
   float* frame(float* base, int64_t per_frame, int t) const { return base + (train ? (size_t)t * per_frame : 0); }
-  float* state(float* base, int t) const { return base + (size_t)(train ? t : (t & 1)) * M * nh; }
+  float* state(float* base, int t, int width) const { return base + (size_t)(train ? t : (t & 1)) * M * width; }
   // slot buffer of width W: pointer of (frame t, phase ph, slot k) and its row stride
   float* slot(float* base, int W, int t, int ph, int k) const {
     return base + (train ? (((size_t)(ph * T + t) * R * N) + k) * W : 0);  // [phase][T][B'][N][W]

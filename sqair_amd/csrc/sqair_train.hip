@@ -113,15 +113,16 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   };
   b.g_lw = take(T * R); b.g_dl = take(T * R);
   b.d_rec_m = take((T + 1) * M * rec::W); b.d_rec_p = take(MT * rec::W); b.d_rec_d = take(MT * rec::W);
-  for (int i = 0; i < 2; ++i) { b.d_tm[i] = take(M * nh); b.d_pm[i] = take(M * nh); }
-  b.d_temporal_p = take(M * nh); b.d_prior_p = take(M * nh);
+  const int64_t snh = c.time_lstm ? 2 * nh : nh, gw = c.time_lstm ? 4 * nh : 3 * nh;  // temporal state / gate widths
+  for (int i = 0; i < 2; ++i) { b.d_tm[i] = take(M * snh); b.d_pm[i] = take(M * nh); }
+  b.d_temporal_p = take(M * snh); b.d_prior_p = take(M * nh);
   b.d_pstats = take(MT * PS_LD); b.d_spre = take(T * R * 128); b.d_raw = take(2 * MT);
   b.d_pgru1 = take(MT * 3 * nh); b.d_hid1 = take(MT * 256); b.d_wb = take(MT * WB_LD); b.d_maskpre = take(MT * G2);
   b.d_pea = take(MT * nh); b.d_peb = take(MT * nh); b.d_m1 = take(MT * M1_LD); b.d_pre = take(MT * pre_ld);
   b.d_lea = take(MT * nh); b.d_leb = take(MT * nh); b.d_pre_d = take(T * R * nh); b.d_pre_disc = take((int64_t)T * B * nh);
   const int64_t S = 2 * MT;
   b.d_rnn = take(S * nh); b.d_t1 = take(S * T1_LD); b.d_t2 = take(S * nh); b.d_tp = take(S * TP_LD);
-  b.d_e1 = take(S * nh); b.d_e2 = take(S * nh); b.d_enc3 = take(S * ENC_LD); b.d_gru1 = take(MT * 3 * nh);
+  b.d_e1 = take(S * nh); b.d_e2 = take(S * nh); b.d_enc3 = take(S * ENC_LD); b.d_gru1 = take(MT * gw);
   b.d_hraw = take(MT * HRAW_LD);
   b.d_mask = take(M * G2); b.d_g = take(R * G2); b.d_g1 = take(M * G2); b.d_c = take(R * nh);
   b.tmp = take(M * 512);
@@ -158,7 +159,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   const int nh = c.n_hidden, nw = c.n_what, N = c.n_steps_per_image, K = c.k_particles;
   const int R = B * K, M = R * N, MT = M * T, G2 = c.glimpse_size * c.glimpse_size, P_ = c.img_h * c.img_w;
   const int nzw = 4 + nw + 1, RW = rec::W, nsp = nh / 2;
-  Dims d{c.img_h, c.img_w, c.glimpse_size, N, nw, nh, K, R, B, nzw};
+  Dims d = make_dims(c, B);
+  const int snh = d.snh, gw = c.time_lstm ? 4 * nh : 3 * nh;
   const POff po = h->po;
   const Workspace w = sq_carve(h, T, B, (float*)train_workspace, true);
   const BwdSpace b = carve_bwd(h, T, B, (float*)scratch);
@@ -268,8 +270,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     float* d_rec_next = b.d_rec_m + (size_t)(t + 1) * M * RW;
     float* d_rec_p_t = b.d_rec_p + (size_t)t * M * RW;
     float* d_rec_d_t = b.d_rec_d + (size_t)t * M * RW;
-    const float* temporal_prev = w.state(w.temporal_m, t);
-    const float* prior_prev = w.state(w.prior_m, t);
+    const float* temporal_prev = w.state(w.temporal_m, t, w.snh);
+    const float* prior_prev = w.state(w.prior_m, t, w.nh);
     float* d_tau = b.d_tm[t & 1];       // d temporal_m[t]
     float* d_pprev = b.d_pm[t & 1];     // d prior_m[t]
     const int rl = N * nh, t1l = N * T1_LD, gl2 = N * G2, el = N * ENC_LD, hl = N * HRAW_LD, tpl = N * TP_LD, s1l = N * S1_LD;
@@ -281,7 +283,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       ka.d_prior_next = b.d_pm[(t + 1) & 1]; ka.d_rec_p = d_rec_p_t; ka.d_rec_d = d_rec_d_t;
       ka.d_temporal_p = b.d_temporal_p; ka.d_prior_p = b.d_prior_p; ka.flat_grad = flat_grad;
       sq_launch_compact_bwd(ka, po, d, s);
-      sq_zero_fill(d_tau, (int64_t)M * nh, s);
+      sq_zero_fill(d_tau, (int64_t)M * snh, s);
       sq_zero_fill(d_pprev, (int64_t)M * nh, s);
     }
     // ---- G^T. discovery steps
@@ -368,16 +370,17 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       float* d_e2 = slotp(b.d_e2, nh, t, 0, k);
       float* d_enc3 = slotp(b.d_enc3, ENC_LD, t, 0, k);
       float* d_rnn = slotp(b.d_rnn, nh, t, 0, k);
-      float* d_gru1 = b.d_gru1 + ((size_t)t * M + k) * 3 * nh;   // [T][R][N][3nh], row stride N*3nh
+      float* d_gru1 = b.d_gru1 + ((size_t)t * M + k) * gw;   // [T][R][N][3nh (GRU) | 4nh (LSTM)], row stride N*gw
       float* d_hraw = b.d_hraw + ((size_t)t * M + k) * HRAW_LD;
-      const int g1l = N * 3 * nh;
+      const int g1l = N * gw;
       const float* r_k = cslotp(w.r, nh, t, 0, k);
       const float* t1 = cslotp(w.t1, T1_LD, t, 0, k);
       const float* t2 = cslotp(w.t2, nh, t, 0, k);
       const float* e1 = cslotp(w.e1, nh, t, 0, k);
       const float* e2 = cslotp(w.e2, nh, t, 0, k);
       const float* enc = cslotp(w.enc, ENC_LD, t, 0, k);
-      const float* tau_k = temporal_prev + (size_t)k * nh;
+      const float* tau_k = temporal_prev + (size_t)k * snh;   // GRU: the state; LSTM: [hidden | cell], features = cell
+      float* d_tau_k = d_tau + (size_t)k * snh;
       float* d_pre_k = d_pre + (size_t)k * pre_ld;   // columns: rnn 0:nh | T1 nh:2nh | S1 2nh:2nh+nsp | z, r
       const int pre_rld = N * pre_ld;
       {
@@ -391,13 +394,20 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         ta.wwhat_off = (int)P(h, "prop.steps.l0.w") + 2 * nh * nsp;
         sq_launch_slot_tail_bwd(ta, d, s);
       }
-      // heads -> d tau'_k, + what the compaction sent back for this slot's new temporal state
-      { Dx x(d_hraw, hl); x.to(0, nh, b.dhn, nh).add(b.d_temporal_p + (size_t)k * nh, N * nh); CK(rundx(L_PROP_HEADS, x, R)); }
-      sq_launch_gru_bwd_a(b.dhn, nh, cslotp(w.gz, nh, t, 0, k), rl, cslotp(w.ghc, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l,
-                          d_tau + (size_t)k * nh, N * nh, R, nh, 1, s, d_pre_k + 2 * nh + nsp, pre_rld);
-      { Dx x(d_gru1 + 2 * nh, g1l); x.to(0, nh, b.d_rh, nh); CK(rundx(L_PROP_GRU2, x, R)); }
-      sq_launch_gru_bwd_b(b.d_rh, nh, cslotp(w.gr, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l, d_tau + (size_t)k * nh, N * nh,
-                          R, nh, s, d_pre_k + 3 * nh + nsp, pre_rld);
+      // heads -> d tau'_k (the new HIDDEN state), + what the compaction sent back for this slot's new temporal state
+      { Dx x(d_hraw, hl); x.to(0, nh, b.dhn, nh).add(b.d_temporal_p + (size_t)k * snh, N * snh); CK(rundx(L_PROP_HEADS, x, R)); }
+      if (c.time_lstm) {
+        // cell adjoint: gate pre-activation gradients (kept for the batched weight gradients and the recurrent-rows dX
+        // after the slot loop) and d c_{t-1} -- the first writer of the cell half of d_tau (sections D^T / B^T accumulate)
+        sq_launch_lstm_cell_bwd(w.lgates + ((size_t)t * M + k) * 4 * nh, N * 4 * nh, tau_k + nh, N * snh, b.dhn, nh,
+                                b.d_temporal_p + (size_t)k * snh + nh, N * snh, d_gru1, g1l, d_tau_k + nh, N * snh, R, nh, s);
+      } else {
+        sq_launch_gru_bwd_a(b.dhn, nh, cslotp(w.gz, nh, t, 0, k), rl, cslotp(w.ghc, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l,
+                            d_tau_k, N * nh, R, nh, 1, s, d_pre_k + 2 * nh + nsp, pre_rld);
+        { Dx x(d_gru1 + 2 * nh, g1l); x.to(0, nh, b.d_rh, nh); CK(rundx(L_PROP_GRU2, x, R)); }
+        sq_launch_gru_bwd_b(b.d_rh, nh, cslotp(w.gr, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l, d_tau_k, N * nh,
+                            R, nh, s, d_pre_k + 3 * nh + nsp, pre_rld);
+      }
       {  // gate GEMM inputs [r_k nh | where 4 (pad 16) | glimpse-encoder (loc, scale) 2 nw]
         Dx x(d_gru1, g1l);
         x.to(0, nh, b.d_r[k & 1], nh);
@@ -436,11 +446,14 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     }
     // ---- D^T. the loop-invariant pre-activation GEMM: segments [m1 nw (pad 64) | z_{t-1} record 56 (pad 64) | temporal nh]
     float* d_m1 = b.d_m1 + (size_t)t * M * M1_LD;
+    if (c.time_lstm) {  // recurrent rows of the LSTM gates, all slots at once: d h_{t-1} = d gates W_h^T (first writer)
+      Dx x(b.d_gru1 + (size_t)t * M * gw, gw); x.to(0, nh, d_tau, snh); CK(rundx(L_PROP_GRU2, x, M));
+    }
     {
       Dx x(d_pre, pre_ld);
       x.to(0, nw, d_m1, M1_LD);
       x.to(64, 64 + rec::ZW, d_rec_prev, RW).acc();
-      x.to(128, 128 + nh, d_tau, nh).acc();
+      x.to(128, 128 + nh, d_tau + d.toff, snh).acc();
       CK(rundx(L_PRE, x, M));
     }
     // ---- C^T. crop #1 and its encoder
@@ -468,7 +481,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         Dx x(d_maskpre, G2); x.to(0, 128, d_hid1 + 128, 256).dact(hid1 + 128, 256, ACT_ELU); CK(rundx(L_MASK2, x, M));
       }
       { Dx x(b.d_wb + (size_t)t * M * WB_LD, WB_LD); x.to(0, 128, d_hid1, 256).dact(hid1, 256, ACT_ELU); CK(rundx(L_WB2, x, M)); }
-      { Dx x(d_hid1, 256); x.to(0, nh, d_tau, nh).acc(); CK(rundx(L_TAU1, x, M)); }
+      { Dx x(d_hid1, 256); x.to(0, nh, d_tau + d.toff, snh).acc(); CK(rundx(L_TAU1, x, M)); }
     }
     // ---- A^T. prior GRU
     {
@@ -487,7 +500,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     }
   }
   // ================= initial states, input encoder =================
-  sq_launch_colsum(b.d_tm[0], nh, M, nh, flat_grad + po.temporal_init, 1, s);
+  sq_launch_colsum(b.d_tm[0], snh, M, snh, flat_grad + po.temporal_init, 1, s);
   sq_launch_colsum(b.d_pm[0], nh, M, nh, flat_grad + po.prior_init, 1, s);
   {
     const int TB = T * B;
@@ -501,7 +514,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   }
   // ================= batched weight gradients =================
   {
-    const float* tm_all = w.temporal_m;  // [T+1][M][nh]; frames 0..T-1 are the inputs
+    const float* tm_all = w.temporal_m;  // [T+1][M][snh]; frames 0..T-1 are the inputs
+    const float* tau_all = tm_all + d.toff;
     const float* pm_all = w.prior_m;
     // prior GRU
     wgrad(L_PRIOR_GRU1, {{w.rec_m_all, RW}, {pm_all, nh}}, b.d_pgru1, 3 * nh, MT);
@@ -509,7 +523,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     wgrad(L_PRIOR_GRU2, {{b.rh, nh}}, b.d_pgru1 + 2 * nh, 3 * nh, MT);
     wgrad(L_PRIOR_LIN, {{w.prior_p, nh}}, b.d_pstats, PS_LD, MT);
     // where-bias / mask MLPs
-    wgrad(L_TAU1, {{tm_all, nh}}, b.d_hid1, 256, MT);
+    wgrad(L_TAU1, {{tau_all, snh}}, b.d_hid1, 256, MT);
     wgrad(L_WB2, {{w.hid1, 256}}, b.d_wb, WB_LD, MT);
     if (c.masked_glimpse) wgrad(L_MASK2, {{w.hid1 + 128, 256}}, b.d_maskpre, G2, MT);
     // glimpse encoder: crop #1 (per frame, M rows) + both slot phases (2*T*R*N rows)
@@ -520,17 +534,21 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     wgrad(L_WHAT_LOC, {{w.peb, nh}}, b.d_m1, M1_LD, MT);
     wgrad(L_WHAT_HEAD, {{w.e2, nh}}, b.d_enc3, ENC_LD, 2 * MT);
     // loop-invariant pre-activations
-    wgrad(L_PRE, {{w.m1, M1_LD}, {w.rec_m_all, RW}, {tm_all, nh}}, b.d_pre, pre_ld, MT);
+    wgrad(L_PRE, {{w.m1, M1_LD}, {w.rec_m_all, RW}, {tau_all, snh}}, b.d_pre, pre_ld, MT);
     // propagation slot chain (phase 0 of the tapes)
     hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_p_all, w.r, w.zero_rec, w.prop_rnn_init, b.zs, b.rs, MT, N, nh);
     wgrad(L_PROP_RNN, {{b.zs, 64}, {b.rs, nh}}, b.d_rnn, nh, MT);
     wgrad(L_PROP_T1, {{w.r, nh}}, b.d_t1, T1_LD, MT);
     wgrad(L_PROP_T2, {{w.t1, T1_LD}}, b.d_t2, nh, MT);
     wgrad(L_PROP_T3, {{w.t2, nh}}, b.d_tp, TP_LD, MT);
-    wgrad(L_PROP_GRU1, {{w.r, nh}, {w.rec_p_all + rec::WHERE, RW}, {w.enc, ENC_LD}}, b.d_gru1, 3 * nh, MT);
-    hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.gr, nh, tm_all, nh, b.rh, nh, MT, nh);
-    wgrad(L_PROP_GRU2, {{b.rh, nh}}, b.d_gru1 + 2 * nh, 3 * nh, MT);
-    wgrad(L_PROP_HEADS, {{w.temporal_p, nh}}, b.d_hraw, HRAW_LD, MT);
+    wgrad(L_PROP_GRU1, {{w.r, nh}, {w.rec_p_all + rec::WHERE, RW}, {w.enc, ENC_LD}}, b.d_gru1, gw, MT);
+    if (c.time_lstm) {
+      wgrad(L_PROP_GRU2, {{tm_all, snh}}, b.d_gru1, gw, MT);   // recurrent rows + b_gates: A = h_{t-1}
+    } else {
+      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.gr, nh, tm_all, nh, b.rh, nh, MT, nh);
+      wgrad(L_PROP_GRU2, {{b.rh, nh}}, b.d_gru1 + 2 * nh, 3 * nh, MT);
+    }
+    wgrad(L_PROP_HEADS, {{w.temporal_p, snh}}, b.d_hraw, HRAW_LD, MT);
     wgrad(L_PROP_S1, {{w.rec_p_all, RW}}, b.d_t1 + nh, T1_LD, MT);
     // latent summary, discovery conditioning
     wgrad(L_LAT0, {{w.rec_p_all, RW}}, b.d_lea, nh, MT);

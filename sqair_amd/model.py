@@ -34,10 +34,11 @@ def make_config(F, img_hw):
         raise ValueError('Invalid prior type: "{}". Choose from {}.'.format(F.prop_prior_type, list(_PRIOR_TYPES)))
     if F.disc_prior_type not in _DISC_PRIOR_TYPES:
         raise ValueError("Invalid prior type: {}".format(F.disc_prior_type))
-    if (F.transition, F.time_transition, F.prior_transition) != ("VanillaRNN", "GRU", "GRU"):
+    if (F.transition, F.prior_transition) != ("VanillaRNN", "GRU") or F.time_transition not in ("GRU", "LSTM"):
         raise NotImplementedError(
-            "HIP path implements the shipped cells (transition=VanillaRNN, time_transition=GRU, "
-            "prior_transition=GRU); got {}/{}/{}".format(F.transition, F.time_transition, F.prior_transition))
+            "HIP path implements transition=VanillaRNN, time_transition in {{GRU, LSTM}}, prior_transition=GRU "
+            "(configs/mlp_mnist_model.py:86-87,125 pick Sonnet cells by name); got {}/{}/{}".format(
+                F.transition, F.time_transition, F.prior_transition))
     p = get_params(F)
     sp = parse_string_flag(F.scale_prior, num_elements=2)
     std = float(np.float32(np.float32(np.sqrt(F.output_std)) ** np.float32(2.0)))  # modules.py:419-422
@@ -46,7 +47,7 @@ def make_config(F, img_hw):
         int(p.n_hidden), int(F.k_particles), _PRIOR_TYPES[F.prop_prior_type], _DISC_PRIOR_TYPES[F.disc_prior_type],
         int(bool(F.masked_glimpse)), int(bool(F.rec_where_prior)), float(F.prop_prior_step_bias),
         float(F.step_success_prob), std, std, (C.c_float * 4)(sp[0], sp[1], 0.0, 0.0),
-        int(bool(F.sample_from_prior)), int(getattr(F, "generate_after", -1)))
+        int(bool(F.sample_from_prior)), int(getattr(F, "generate_after", -1)), int(F.time_transition == "LSTM"))
 
 
 class SqairCore(object):
@@ -71,6 +72,7 @@ class SqairCore(object):
         self.K = int(F.k_particles)
         self.nw = int(F.n_what)
         self.nh = get_params(F).n_hidden
+        self.snh = self.nh * (2 if F.time_transition == "LSTM" else 1)  # temporal state: [hidden | cell] for an LSTM
         self.G = int(F.glimpse_size)
         self.H, self.W = int(img_hw[0]), int(img_hw[1])
         self.nzw = self.lib.sqair_noise_width(self.handle)
@@ -152,7 +154,7 @@ class SqairCore(object):
             num_prop_steps_per_sample=(T, R), num_disc_steps_per_sample=(T, R), num_steps_per_sample=(T, R),
             prop_pres=(T, R, N), disc_pres=(T, R, N), data_ll_per_sample=(T, R), kl_per_sample=(T, R),
             log_q_z_given_x_per_sample=(T, R), log_p_z_per_sample=(T, R), log_weights_per_timestep=(T, R),
-            final_temporal_state=(R, N, nh), final_prior_state=(R, N, nh), final_last_used_id=(R,),
+            final_temporal_state=(R, N, self.snh), final_prior_state=(R, N, nh), final_last_used_id=(R,),
         )
         if outputs == "all":
             wanted = list(_capi.OUTPUT_FIELDS)

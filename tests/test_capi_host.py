@@ -29,10 +29,11 @@ def test_library_loads_and_exports_header_symbols(repo_root):
     assert lib.sqair_abi_version() == 1
 
 
-@pytest.mark.parametrize("N,hw", [(3, (50, 50)), (4, (50, 50)), (6, (50, 50)), (4, (128, 128))])
-def test_param_table_matches_python_spec(N, hw):
+@pytest.mark.parametrize("N,hw,cell", [(3, (50, 50), "GRU"), (4, (50, 50), "GRU"), (6, (50, 50), "GRU"), (4, (128, 128), "GRU"),
+                                       (3, (50, 50), "LSTM")])
+def test_param_table_matches_python_spec(N, hw, cell):
     lib = _capi.lib()
-    F = make_flags(n_steps_per_image=N)
+    F = make_flags(n_steps_per_image=N, time_transition=cell)
     cfg = make_config(F, hw)
     h = C.c_void_p()
     assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
@@ -47,7 +48,7 @@ def test_param_table_matches_python_spec(N, hw):
             assert cname.value.decode() == name
             assert coff.value == off[name][0]
             assert cnum.value == (int(np.prod(shape)) if len(shape) else 1)
-        if N == 3 and hw == (50, 50):
+        if N == 3 and hw == (50, 50) and cell == "GRU":
             assert total == 2951522  # reference notebooks/play.ipynb:362
         assert lib.sqair_packed_bytes(h) > total * 4
         assert lib.sqair_workspace_bytes(h, 10, 32) > 0

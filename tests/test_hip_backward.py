@@ -435,10 +435,11 @@ def test_checkpoint_round_trip_restores_parameters_and_optimiser_slots(tmp_path)
     dict(prop_prior_type="rw"),
     dict(prop_prior_type="guided", masked_glimpse=False),
     dict(disc_prior_type="geom", rec_where_prior=False),
+    dict(time_transition="LSTM"),
 ])
 def test_full_backward_flag_variants(flags):
     """The adjoint branches the default flags never take: random-walk / guided propagation priors (the prior statistics
-    feed back into z_{t-1}), geometric step prior, fixed where prior, unmasked glimpses."""
+    feed back into z_{t-1}), geometric step prior, fixed where prior, unmasked glimpses, the LSTM temporal cell."""
     report, ref, _ = _full_backward_case(K=3, N=3, T=3, B=3, hw=(50, 50), seed=11, flags=flags)
     assert float(ref.prop_pres.sum()) > 0
     _check_report(report)

@@ -60,17 +60,13 @@ def test_forward_matches_golden_fixture(name):
         assert abs(float(getattr(m, k)) - float(ref_model[k])) <= 1e-4 * max(1.0, abs(float(ref_model[k]))), k
 
 
-@pytest.mark.parametrize("prior,disc_prior,rec", [("rw", "cat", True), ("guided", "geom", True), ("rnn", "cat", False)])
-def test_forward_flag_variants_vs_live_oracle(prior, disc_prior, rec):
-    F = make_flags(k_particles=2, n_steps_per_image=3, prop_prior_type=prior, disc_prior_type=disc_prior,
-                   rec_where_prior=rec, masked_glimpse=(prior != "guided"))
-    hw = (32, 40)
-    T, B = 3, 3
+def _live_oracle_case(F, hw=(32, 40), T=3, B=3):
+    K, N = int(F.k_particles), int(F.n_steps_per_image)
     d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=20, seed=9)
     obs = to_float(d["imgs"])
     P = params32(F, hw, 5, 0.05, obs.mean((0, 1)))
     for attempt in range(50):
-        noise = draw_noise(np.random.default_rng(attempt), T, B * 2, 3, 55)
+        noise = draw_noise(np.random.default_rng(attempt), T, B * K, N, 55)
         ref = run_oracle(F, hw, P, obs, noise, nums=d["nums"])
         m = run_hip(F, hw, P, obs, noise, nums=d["nums"])
         if np.array_equal(m.prop_pres.cpu().numpy(), ref.prop_pres.numpy()) and \
@@ -80,6 +76,28 @@ def test_forward_flag_variants_vs_live_oracle(prior, disc_prior, rec):
     ref_model = {k: getattr(ref, k).numpy() for k in ("log_weights", "elbo_iwae_per_example", "elbo_vae", "elbo_iwae",
                                                       "data_ll", "kl", "log_p_z", "log_q_z_given_x")}
     _check_against(m, ref_out, ref_model, list(ref_out), T)
+    return m, ref
+
+
+@pytest.mark.parametrize("prior,disc_prior,rec", [("rw", "cat", True), ("guided", "geom", True), ("rnn", "cat", False)])
+def test_forward_flag_variants_vs_live_oracle(prior, disc_prior, rec):
+    F = make_flags(k_particles=2, n_steps_per_image=3, prop_prior_type=prior, disc_prior_type=disc_prior,
+                   rec_where_prior=rec, masked_glimpse=(prior != "guided"))
+    _live_oracle_case(F)
+
+
+@pytest.mark.parametrize("K,N,T,B", [(2, 3, 3, 3), (3, 4, 4, 2)])
+def test_forward_lstm_temporal_cell_vs_live_oracle(K, N, T, B):
+    """time_transition=LSTM (configs/mlp_mnist_model.py:86-87: cells are picked by name; north_star's "propagation LSTM
+    cell"): the temporal state of a slot is [hidden | cell], the slot networks read the CELL half (core.py:284), the
+    heads read the new hidden state."""
+    F = make_flags(k_particles=K, n_steps_per_image=N, time_transition="LSTM")
+    m, ref = _live_oracle_case(F, T=T, B=B)
+    assert float(ref.prop_pres.sum()) > 0, "case must exercise propagation"
+    got = m.outputs["final_temporal_state"].cpu().numpy()
+    want = ref.outputs["_final_temporal_state"].numpy()
+    assert got.shape == want.shape and got.shape[-1] == 512
+    assert np.abs(got - want).max() < 5e-4 * max(1.0, np.abs(want).max())
 
 
 def test_cfg2_full_size_properties():
