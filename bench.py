@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--cfg", type=int, default=2, help="BASELINE.json config id used as the workload (default 2)")
     ap.add_argument("--train-steps", type=int, default=-1,
                     help="steps of the extra training-step leg (default min(steps, 20); 0 = skip)")
+    ap.add_argument("--time-transition", default="GRU", choices=["GRU", "LSTM"],
+                    help="propagation temporal cell (the shipped config and BASELINE's metric use GRU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,6 +146,7 @@ def main():
         d = make_sequences(obs.shape[1], T=obs.shape[0], canvas=obs.shape[2:], n_objects=(0, nums.shape[-1] - 1),
                            obj_size=28 if obs.shape[2] <= 64 else 72, seed=1234 + args.cfg + 1000 * rank)
         obs, nums = to_float(d["imgs"]), d["nums"]
+    ov["time_transition"] = args.time_transition
     F = make_flags(**ov)
     hw = tuple(int(v) for v in obs.shape[2:])
     T, B = int(obs.shape[0]), int(obs.shape[1])
@@ -249,8 +252,11 @@ def main():
         prof = core.profile_linear()
     torch.cuda.synchronize()
     lin_ms = prof["linear_ms"]
+    nh_in = 256 + 4 + 2 * int(F.n_what)
     algo_flops_step = float(B * T) * (FLOP_PER_FRAME_CFG2 if (args.cfg in (2, 3)) else
                                      2.0 * K * {1: 10166288, 4: 20298656, 5: 27760960}[args.cfg])
+    if args.time_transition == "LSTM":  # a 4th gate over the same [x 360 | h 256] -> 256 input: + (360 + 256) * 256 MACs / slot
+        algo_flops_step += float(B * T) * 2.0 * K * N * (nh_in + 256) * 256
     achieved = algo_flops_step / (lin_ms * 1e-3) / 1e12
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -295,8 +301,8 @@ def main():
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cfg{}: T={} HxW={}x{} B={}/GPU K={} N={} forward (elbo_iwae), HIP-graph replay={}".format(
-            args.cfg, T, hw[0], hw[1], B, K, N, use_graph), "global_batch": B * world, "seq_len": T,
+        "config": {"workload": "cfg{}: T={} HxW={}x{} B={}/GPU K={} N={} temporal cell {} forward (elbo_iwae), HIP-graph replay={}".format(
+            args.cfg, T, hw[0], hw[1], B, K, N, args.time_transition, use_graph), "global_batch": B * world, "seq_len": T,
             "parallelism": "dp{}".format(world), "graph_nodes": core.graph_nodes()},
         "elbo_iwae_nats_per_seq": elbo, "elbo_vae_nats_per_seq": elbo_vae,
         "roofline": roofline, "cpu_baseline": cpu, "train": train,

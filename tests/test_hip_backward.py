@@ -280,14 +280,15 @@ def test_full_backward_matches_autograd(K, N, T, B, hw):
     _check_report(report)
 
 
-def test_grad_step_graph_replay_equals_eager():
+@pytest.mark.parametrize("cell", ["GRU", "LSTM"])
+def test_grad_step_graph_replay_equals_eager(cell):
     """forward(train) + ELBO + backward replayed as one HIP graph gives the eager gradients (float atomics in the
     small-parameter adjoints make the order of additions free: compare to 1e-5 of the largest gradient)."""
     from sqair_amd.data import make_sequences, to_float
     from sqair_amd.model import Model, SqairCore
     from tests.hip_util import draw_noise, params32
     K, N, T, B, hw = 3, 3, 3, 4, (50, 50)
-    F = make_flags(k_particles=K, n_steps_per_image=N)
+    F = make_flags(k_particles=K, n_steps_per_image=N, time_transition=cell)
     obs = to_float(make_sequences(B, T=T, canvas=hw, seed=3)["imgs"])
     core = SqairCore(F, hw)
     core.set_params(params32(F, hw, 4, 0.05, obs.mean((0, 1))))
