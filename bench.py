@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--cfg", type=int, default=2, help="BASELINE.json config id used as the workload (default 2)")
     ap.add_argument("--train-steps", type=int, default=-1,
                     help="steps of the extra training-step leg (default min(steps, 20); 0 = skip)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="sequences per GPU (default: the configuration's own; other values are batch-scaling experiments, "
+                         "not BASELINE's metric)")
     ap.add_argument("--time-transition", default="GRU", choices=["GRU", "LSTM"],
                     help="propagation temporal cell (the shipped config and BASELINE's metric use GRU)")
     args = ap.parse_args()
@@ -128,10 +131,14 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
-        import torch.distributed as dist
+    if world > 1 or os.environ.get("SQAIR_FORCE_DIST") == "1":  # (the env knob: single-rank RCCL group, to measure what
+        import torch.distributed as dist                            #  the collectives' own stream costs the graph replays)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend)  # "nccl" = RCCL on ROCm
+        kw = dict(device_id=torch.device("cuda", local_rank)) if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, **kw)  # "nccl" = RCCL on ROCm
     assert args.gpus == world, "--gpus {} but WORLD_SIZE {}".format(args.gpus, world)
 
     from sqair_amd.data import config_inputs
@@ -140,7 +147,7 @@ def main():
     from sqair_amd.params import init_params
 
     # every rank synthesises its own shard of the global batch (seeded by rank), weights are replicated
-    ov, obs, nums, _ = config_inputs(args.cfg)
+    ov, obs, nums, _ = config_inputs(args.cfg, B=args.batch or None)
     if rank > 0:
         from sqair_amd.data import make_sequences, to_float
         d = make_sequences(obs.shape[1], T=obs.shape[0], canvas=obs.shape[2:], n_objects=(0, nums.shape[-1] - 1),
