@@ -316,8 +316,8 @@ class SqairOracle(object):
     def __init__(self, params, cfg, dtype=torch.float64, requires_grad=False):
         self.cfg = cfg
         self.dtype = dtype
-        if cfg.transition != "VanillaRNN" or cfg.time_transition not in ("GRU", "LSTM") or cfg.prior_transition != "GRU":
-            raise NotImplementedError("oracle restates transition=VanillaRNN, time_transition in {GRU, LSTM}, prior_transition=GRU")
+        if cfg.transition != "VanillaRNN" or cfg.time_transition not in ("GRU", "LSTM") or cfg.prior_transition not in ("GRU", "LSTM"):
+            raise NotImplementedError("oracle restates transition=VanillaRNN, time_transition / prior_transition in {GRU, LSTM}")
         if cfg.prop_prior_type not in ("rnn", "rw", "guided"):
             raise ValueError('Invalid prior type: "{}"'.format(cfg.prop_prior_type))  # propagate.py:42-43
         if cfg.disc_prior_type not in ("cat", "geom"):
@@ -371,9 +371,15 @@ class SqairOracle(object):
         what_tm1, where_tm1, pres_tm1, logit_tm1 = z_tm1
         B, N = what_tm1.shape[:2]
         x = torch.cat([what_tm1, where_tm1], -1).reshape(B * N, -1)
-        h = gru(self.P, "prop.prior_gru", x, prior_state.reshape(B * N, -1))
+        ps = prior_state.reshape(B * N, -1)
+        if c.prior_transition == "LSTM":  # state travels as [hidden | cell]; the Linear reads the cell OUTPUT = new hidden
+            nh = c.n_hidden
+            h, c2 = lstm(self.P, "prop.prior_lstm", x, ps[:, :nh], ps[:, nh:])
+            new_state = torch.cat([h, c2], -1).reshape(B, N, -1)
+        else:
+            h = gru(self.P, "prop.prior_gru", x, ps)
+            new_state = h.reshape(B, N, -1)
         stats = linear(self.P, "prop.prior_linear", h).reshape(B, N, -1)
-        new_state = h.reshape(B, N, -1)
         logit = stats[..., :1] + c.prop_prior_step_bias
         logit = pres_tm1 * logit + (pres_tm1 - 1.0) * 88.0
         rest = stats[..., 1:]
@@ -611,6 +617,12 @@ class SqairOracle(object):
         f = mlp2_hidden(self.P, "seq.latent_enc", torch.cat([what, where], -1).reshape(B * N, -1))
         return (f.reshape(B, N, -1) * presence).sum(-2)
 
+    def initial_prior_state(self):
+        """initial_prior_state (sqair_modules.py:352-358): trainable; [hidden | cell] for an LSTM."""
+        if self.cfg.prior_transition == "LSTM":
+            return torch.cat([self.P["seq.prior_init"], self.P["seq.prior_init_c"]], -1)
+        return self.P["seq.prior_init"]
+
     def initial_temporal_state(self):
         """initial_temporal_state (sqair_modules.py:352-366): trainable; [hidden | cell] for an LSTM."""
         if self.cfg.time_transition == "LSTM":
@@ -631,7 +643,7 @@ class SqairOracle(object):
         # merge (sqair_modules.py:514-582)
         names = "what what_loc what_scale where where_loc where_scale presence_prob presence presence_logit".split()
         init_temporal = self.initial_temporal_state()[None].expand(B, N, -1)
-        init_prior = self.P["seq.prior_init"][None].expand(B, N, -1)
+        init_prior = self.initial_prior_state()[None].expand(B, N, -1)
         temporal_cat = torch.cat([prop["temporal_state"], init_temporal], 1)
         prior_cat = torch.cat([prop["prior_state"], init_prior], 1)
         hidden = [torch.cat([prop[n], disc[n]], 1) for n in names]
@@ -681,7 +693,7 @@ class SqairOracle(object):
         z = (torch.zeros(B, N, nw, dtype=dt), torch.zeros(B, N, 4, dtype=dt), torch.zeros(B, N, 1, dtype=dt),
              torch.zeros(B, N, 1, dtype=dt))
         temporal = self.initial_temporal_state()[None].expand(B, N, -1)
-        prior = self.P["seq.prior_init"][None].expand(B, N, -1)
+        prior = self.initial_prior_state()[None].expand(B, N, -1)
         prev_ids = -torch.ones(B, N, 1, dtype=dt)
         last_id = -torch.ones(B, 1, dtype=dt)
         tas = OrderedDict()

@@ -93,7 +93,8 @@ static void build_inventory(SqairHandle* h) {
   add_param(h, "disc.step_prior_timestep_bias", 1, N + 1);
   if (c.time_lstm) add_lin(h, "prop.temporal_lstm", (nh + 4 + 2 * nw) + nh, 4 * nh);  // snt.LSTM: w_gates [x | h] rows, b_gates
   else add_gru(h, "prop.temporal_gru", nh + 4 + 2 * nw, nh);
-  add_gru(h, "prop.prior_gru", nw + 4, nh);
+  if (c.prior_lstm) add_lin(h, "prop.prior_lstm", (nw + 4) + nh, 4 * nh);
+  else add_gru(h, "prop.prior_gru", nw + 4, nh);
   add_lin(h, "prop.prior_linear", nh, 2 * (4 + nw) + 1);
   add_param(h, "prop.cholesky_scale", 1, 10);
   add_lin(h, "prop.where_bias.l0", nh, 128);
@@ -110,6 +111,7 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "prop.rnn.h2h", nh, nh);
   add_lin(h, "prop.rnn.i2h", nw + (nw + 5) + (nw + 5) + nh, nh);
   add_param(h, "seq.prior_init", 1, nh);
+  if (c.prior_lstm) add_param(h, "seq.prior_init_c", 1, nh);
   add_param(h, "seq.temporal_init", 1, nh);
   if (c.time_lstm) add_param(h, "seq.temporal_init_c", 1, nh);  // LSTMState(hidden, cell): adjacent, read as one [2 nh] row
   add_lin(h, "seq.latent_enc.l0", nw + 4, nh);
@@ -260,8 +262,15 @@ static void build_plan(SqairHandle* h) {
   simple(L_IENC1, "enc.input.l1", nh, nh);
   // discovery RNN in_to_hidden = [input enc nh | conditioning nh | what nw | where 4 | presence 1] (core.py:164-177)
   build_layer(h, L_PREDISC, {nh}, {cb1(nh, 0, "disc.rnn.i2h.w", rm_range(0, nh), "disc.rnn.i2h.b", "disc.rnn.h2h.b")});
-  // prior GRU on [what, where]_{t-1} (propagate.py:78-81)
-  {
+  // prior cell on [what, where]_{t-1} (propagate.py:78-81)
+  if (c.prior_lstm) {  // gates (i, j, f, o) = [what, where | h] w_gates + b_gates in ONE layer (both inputs exist up front)
+    ColBlock b;
+    b.ncols = 4 * nh; b.col0 = 0;
+    b.seg = {{"prop.prior_lstm.w", rm_zrec(nw, nw, 0, -1)}, {"prop.prior_lstm.w", rm_range(nw + 4, nh)}};
+    b.bias_a = "prop.prior_lstm.b";
+    build_layer(h, L_PRIOR_GRU1, {rec::ZW, nh}, {b});
+    build_layer(h, L_PRIOR_GRU2, {nh}, {cb1(16, 0, "prop.prior_lstm.w", rm_none(nh))});  // unused placeholder layer
+  } else {
     const RowMap zx = rm_zrec(nw, nw, 0, -1);
     std::vector<ColBlock> bl;
     const char* g[3] = {"z", "r", "h"};
@@ -276,8 +285,8 @@ static void build_plan(SqairHandle* h) {
       bl.push_back(b);
     }
     build_layer(h, L_PRIOR_GRU1, {rec::ZW, nh}, bl);
+    simple(L_PRIOR_GRU2, "prop.prior_gru.uh", nh, nh, 0, false);
   }
-  simple(L_PRIOR_GRU2, "prop.prior_gru.uh", nh, nh, 0, false);
   // fix-up: uh is a bare matrix (no ".w" suffix) -> handled by simple() through name + ".w"; see alias below
   simple(L_PRIOR_LIN, "prop.prior_linear", nh, 2 * (4 + nw) + 1);
   build_layer(h, L_TAU1, {nh},
@@ -443,7 +452,7 @@ extern "C" int sqair_create(const SqairConfig* cfg, SqairHandle** out) {
   h->cfg = *cfg;
   build_inventory(h);
   // GRU candidate matrices are bare [nh, nh] parameters: give build_plan's simple() a ".w" alias
-  h->pidx["prop.prior_gru.uh.w"] = h->pidx["prop.prior_gru.uh"];
+  if (!cfg->prior_lstm) h->pidx["prop.prior_gru.uh.w"] = h->pidx["prop.prior_gru.uh"];
   if (!cfg->time_lstm) h->pidx["prop.temporal_gru.uh.w"] = h->pidx["prop.temporal_gru.uh"];
   build_plan(h);
   build_plan_T(h);
@@ -516,6 +525,8 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.train = train; w.T = T; w.B = B; w.R = (int)R; w.M = (int)M; w.N = (int)N; w.nh = (int)nh;
   const int64_t snh = c.time_lstm ? 2 * nh : nh;  // temporal state of a slot: [hidden | cell] for the LSTM
   w.snh = (int)snh;
+  const int64_t psnh = c.prior_lstm ? 2 * nh : nh;
+  w.psnh = (int)psnh;
   int64_t o = 0;
   auto take = [&](int64_t n) {
     float* p = base ? base + o : nullptr;
@@ -529,7 +540,7 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.pre_disc = take((int64_t)T * B * nh);
   w.rec_m_all = take((int64_t)(T + 1) * M * rec::W);
   w.temporal_m = take((train ? T + 1 : 2) * M * snh);
-  w.prior_m = take((train ? T + 1 : 2) * M * nh);
+  w.prior_m = take((train ? T + 1 : 2) * M * psnh);
   w.last_id[0] = take(R);
   w.last_id[1] = take(R);
   w.rec_p_all = take((int64_t)T * M * rec::W);
@@ -542,8 +553,8 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.w3_prop = take(nh * 8 + 8);
   w.w3_disc = take(nh * 8 + 8);
   w.temporal_p = take(F * M * snh);
-  w.prior_p = take(F * M * nh);
-  w.pgz = take(F * M * nh);
+  w.prior_p = take(F * M * psnh);
+  w.pgz = take(F * M * (c.prior_lstm ? 4 * nh : nh));  // GRU: z gate; LSTM: the four gate pre-activations
   w.pgr = take(F * M * nh);
   w.pghc = take(F * M * nh);
   w.pgrh = take(M * nh);
@@ -698,7 +709,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   const POff po = h->po;
   const Workspace w = sq_carve(h, T, B, wsbase, train);
   const int pre_ld = h->layers[L_PRE].nt * 16;
-  const int RW = rec::W, snh = d.snh;
+  const int RW = rec::W, snh = d.snh, psnh = d.psnh;
   const PackedLayout pl = packed_layout(h);
 
   // ---- sequence prologue -----------------------------------------------------------------------
@@ -708,7 +719,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   if (parts & 1) {
     sq_zero_fill(wsbase, (int64_t)((float*)w.prof_ts - wsbase), s);
     // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
-    sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0, w.snh), w.state(w.prior_m, 0, w.nh), w.last_id[0], w.disc_init_rec,
+    sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0, w.snh), w.state(w.prior_m, 0, w.psnh), w.last_id[0], w.disc_init_rec,
                          w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc,
                          (int)P(h, "prop.transform.l2.w"), (int)P(h, "disc.transform.l2.w"), flat, po, d, s);
     // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
@@ -728,11 +739,11 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     float* pstats_t = w.pstats + (size_t)t * M * PS_LD;
     float* spre_t = w.spre + (size_t)t * R * 128;
     const float* temporal_prev = w.state(w.temporal_m, t, w.snh);
-    const float* prior_prev = w.state(w.prior_m, t, w.nh);
+    const float* prior_prev = w.state(w.prior_m, t, w.psnh);
     float* temporal_p = w.frame(w.temporal_p, (int64_t)M * snh, t);
     const float* tau_prev = temporal_prev + d.toff;  // what the slot networks read as "temporal state" (core.py:284): the
                                                      // GRU state / the CELL half of an LSTM state, row stride snh
-    float* prior_p = w.frame(w.prior_p, (int64_t)M * nh, t);
+    float* prior_p = w.frame(w.prior_p, (int64_t)M * psnh, t);
     float* hid1 = w.frame(w.hid1, (int64_t)M * 256, t);
     float* wb = w.frame(w.wb, (int64_t)M * WB_LD, t);
     float* mask = w.frame(w.mask, (int64_t)M * G2, t);
@@ -745,7 +756,12 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     float* cvec = w.frame(w.c, (int64_t)R * nh, t);
 
     // ---- A. propagation prior (propagate.py:68-98): GRU over [what, where]_{t-1}, all slots ----
-    {
+    if (c.prior_lstm) {
+      float* pg = w.frame(w.pgz, (int64_t)M * 4 * nh, t);
+      Lin g; g.seg(rec_prev, RW, rec::ZW).seg(prior_prev, psnh, nh).out(pg, 4 * nh); RUN(g, L_PRIOR_GRU1, M);
+      sq_launch_lstm_cell(pg, 4 * nh, prior_prev + nh, psnh, prior_p, psnh, M, nh, s);
+      Lin pll; pll.seg(prior_p, psnh, nh).out(pstats_t, PS_LD); RUN(pll, L_PRIOR_LIN, M);
+    } else {
       float* pgz = w.frame(w.pgz, (int64_t)M * nh, t);
       Lin g1l; g1l.seg(rec_prev, RW, rec::ZW).seg(prior_prev, nh, nh).out(pgz, nh)
                  .gru1(prior_prev, nh, w.pgrh, nh, w.pgxh, nh, nh);
@@ -916,7 +932,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
       CompactArgs ka; memset(&ka, 0, sizeof(ka));
       ka.rec_p = rec_p_t; ka.rec_d = rec_d_t; ka.rec_prev = rec_prev; ka.temporal_p = temporal_p;
       ka.prior_p = prior_p; ka.last_id_prev = w.last_id[pp]; ka.last_id_next = w.last_id[pn];
-      ka.rec_next = rec_next; ka.temporal_next = w.state(w.temporal_m, t + 1, w.snh); ka.prior_next = w.state(w.prior_m, t + 1, w.nh);
+      ka.rec_next = rec_next; ka.temporal_next = w.state(w.temporal_m, t + 1, w.snh); ka.prior_next = w.state(w.prior_m, t + 1, w.psnh);
       ka.flat = flat; ka.t = t; ka.out = out;
       ka.src_out = train ? w.src + (size_t)t * M : nullptr;
       emit_compact(h, ka, po, d, s);
@@ -951,7 +967,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   if (out.final_temporal_state)
     sq_copy(out.final_temporal_state, w.state(w.temporal_m, T, w.snh), (int64_t)M * snh, s);
   if (out.final_prior_state)
-    sq_copy(out.final_prior_state, w.state(w.prior_m, T, w.nh), (int64_t)M * nh, s);
+    sq_copy(out.final_prior_state, w.state(w.prior_m, T, w.psnh), (int64_t)M * psnh, s);
   if (out.final_last_used_id)
     sq_copy(out.final_last_used_id, w.last_id[T & 1], (int64_t)R, s);
   SQ_CHECK_HIP(hipGetLastError());
@@ -990,8 +1006,8 @@ extern "C" int sqair_forward_persistent(SqairHandle* h, const float* flat_params
                                         void* stream) {
   if (!h || !out || !program) return -1;
   hipStream_t s = (hipStream_t)stream;
-  if (h->cfg.time_lstm) {
-    sq_set_error(h, "sqair_forward_persistent: the experimental persistent executor covers the GRU temporal cell only");
+  if (h->cfg.time_lstm || h->cfg.prior_lstm) {
+    sq_set_error(h, "sqair_forward_persistent: the experimental persistent executor covers the GRU cells only");
     return -1;
   }
   if (program_bytes < sqair_program_bytes(h, T, B)) {

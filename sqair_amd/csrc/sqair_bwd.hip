@@ -1020,11 +1020,12 @@ __global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, con
     if (sl < N) a.d_temporal_p[((size_t)r * N + sl) * snh + i] = gt;
     else if (dst >= 0) unsafeAtomicAdd(&a.flat_grad[po.temporal_init + i], gt);  // a newly discovered object starts from
   }                                                                                // the trainable initial states
-  for (int e = tid; e < 2 * N * nh; e += 256) {
-    const int sl = e / nh, i = e - sl * nh;
+  const int psnh = d.psnh;
+  for (int e = tid; e < 2 * N * psnh; e += 256) {
+    const int sl = e / psnh, i = e - sl * psnh;
     const int dst = inv_s[sl];
-    const float gp = dst >= 0 ? a.d_prior_next[((size_t)r * N + dst) * nh + i] : 0.0f;
-    if (sl < N) a.d_prior_p[((size_t)r * N + sl) * nh + i] = gp;
+    const float gp = dst >= 0 ? a.d_prior_next[((size_t)r * N + dst) * psnh + i] : 0.0f;
+    if (sl < N) a.d_prior_p[((size_t)r * N + sl) * psnh + i] = gp;
     else if (dst >= 0) unsafeAtomicAdd(&a.flat_grad[po.prior_init + i], gp);
   }
 }

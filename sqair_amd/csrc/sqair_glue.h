@@ -21,11 +21,13 @@ struct Dims {
   int nzw;                          // noise width = 4 + nw + 1
   int snh;                          // width of the temporal state of a slot: nh (GRU) or 2 nh = [hidden | cell] (LSTM)
   int toff;                         // offset of the features the model reads from it: 0 (GRU state) / nh (LSTM cell, core.py:284)
+  int psnh;                         // width of the propagation prior's recurrent state: nh (GRU) or 2 nh (LSTM)
 };
 inline Dims make_dims(const SqairConfig& c, int B) {
   const int lstm = c.time_lstm != 0;
   return Dims{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles, B * c.k_particles, B,
-              4 + c.n_what + 1, lstm ? 2 * c.n_hidden : c.n_hidden, lstm ? c.n_hidden : 0};
+              4 + c.n_what + 1, lstm ? 2 * c.n_hidden : c.n_hidden, lstm ? c.n_hidden : 0,
+              c.prior_lstm ? 2 * c.n_hidden : c.n_hidden};
 }
 
 enum CropMode { CROP_PLAIN = 0, CROP_PROP1 = 1, CROP_PROP2 = 2, CROP_DISC = 3 };

@@ -18,7 +18,7 @@ __global__ void k_init_state(float* __restrict__ rec_m, float* __restrict__ temp
   for (int i = tid; i < rec::W; i += blockDim.x) rec_m[(size_t)rs * rec::W + i] = (i == rec::ID) ? -1.0f : 0.0f;
   // LSTM: [hidden | cell] initial states are adjacent in the flat buffer (seq.temporal_init, seq.temporal_init_c)
   for (int i = tid; i < d.snh; i += blockDim.x) temporal_m[(size_t)rs * d.snh + i] = flat[po.temporal_init + i];
-  for (int i = tid; i < d.nh; i += blockDim.x) prior_m[(size_t)rs * d.nh + i] = flat[po.prior_init + i];
+  for (int i = tid; i < d.psnh; i += blockDim.x) prior_m[(size_t)rs * d.psnh + i] = flat[po.prior_init + i];
   if (tid == 0 && (rs % d.N) == 0) last_id[rs / d.N] = -1.0f;
   if (rs == 0) {  // aligned copies of the small trainable initial states (GEMM A-operand contract)
     if (tid == 0) disc_init_rec[rec::PRES] = 1.0f;
@@ -666,8 +666,8 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff
   __syncthreads();
   const size_t tr = (size_t)a.t * d.R + r;
   // copy the N survivors: record (168) + temporal state + prior state, one flat loop of independent loads
-  const int snh = d.snh;
-  const int per = rec::W + snh + nh;
+  const int snh = d.snh, psnh = d.psnh;
+  const int per = rec::W + snh + psnh;
 #pragma unroll 4
   for (int e = tid; e < N * per; e += 256) {
     const int dst = e / per, i = e - dst * per;
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff
           prop ? a.temporal_p[((size_t)r * N + ss) * snh + q] : a.flat[po.temporal_init + q];
     } else {
       const int q = i - rec::W - snh;
-      a.prior_next[((size_t)r * N + dst) * nh + q] = prop ? a.prior_p[((size_t)r * N + ss) * nh + q] : a.flat[po.prior_init + q];
+      a.prior_next[((size_t)r * N + dst) * psnh + q] = prop ? a.prior_p[((size_t)r * N + ss) * psnh + q] : a.flat[po.prior_init + q];
     }
   }
   // the 9 hidden outputs + object id (seq.py:121-134)

@@ -123,7 +123,7 @@ constexpr int PS_LD = 112, ENC_LD = 112, M1_LD = 64, HRAW_LD = 256, WB_LD = 4, T
 
 struct Workspace {
   bool train;
-  int T, B, R, M, N, nh, snh;
+  int T, B, R, M, N, nh, snh, psnh;
   float *ienc_a, *ienc_b, *pre_disc;
   float *rec_m_all, *rec_p_all, *rec_d_all;
   float *temporal_m, *prior_m;                   // train: [T+1][M][snh | nh], else [2][M][snh | nh]

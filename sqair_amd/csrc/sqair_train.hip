@@ -114,10 +114,11 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   b.g_lw = take(T * R); b.g_dl = take(T * R);
   b.d_rec_m = take((T + 1) * M * rec::W); b.d_rec_p = take(MT * rec::W); b.d_rec_d = take(MT * rec::W);
   const int64_t snh = c.time_lstm ? 2 * nh : nh, gw = c.time_lstm ? 4 * nh : 3 * nh;  // temporal state / gate widths
-  for (int i = 0; i < 2; ++i) { b.d_tm[i] = take(M * snh); b.d_pm[i] = take(M * nh); }
-  b.d_temporal_p = take(M * snh); b.d_prior_p = take(M * nh);
+  const int64_t psnh = c.prior_lstm ? 2 * nh : nh, pgw = c.prior_lstm ? 4 * nh : 3 * nh;
+  for (int i = 0; i < 2; ++i) { b.d_tm[i] = take(M * snh); b.d_pm[i] = take(M * psnh); }
+  b.d_temporal_p = take(M * snh); b.d_prior_p = take(M * psnh);
   b.d_pstats = take(MT * PS_LD); b.d_spre = take(T * R * 128); b.d_raw = take(2 * MT);
-  b.d_pgru1 = take(MT * 3 * nh); b.d_hid1 = take(MT * 256); b.d_wb = take(MT * WB_LD); b.d_maskpre = take(MT * G2);
+  b.d_pgru1 = take(MT * pgw); b.d_hid1 = take(MT * 256); b.d_wb = take(MT * WB_LD); b.d_maskpre = take(MT * G2);
   b.d_pea = take(MT * nh); b.d_peb = take(MT * nh); b.d_m1 = take(MT * M1_LD); b.d_pre = take(MT * pre_ld);
   b.d_lea = take(MT * nh); b.d_leb = take(MT * nh); b.d_pre_d = take(T * R * nh); b.d_pre_disc = take((int64_t)T * B * nh);
   const int64_t S = 2 * MT;
@@ -160,7 +161,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   const int R = B * K, M = R * N, MT = M * T, G2 = c.glimpse_size * c.glimpse_size, P_ = c.img_h * c.img_w;
   const int nzw = 4 + nw + 1, RW = rec::W, nsp = nh / 2;
   Dims d = make_dims(c, B);
-  const int snh = d.snh, gw = c.time_lstm ? 4 * nh : 3 * nh;
+  const int snh = d.snh, gw = c.time_lstm ? 4 * nh : 3 * nh, psnh = d.psnh, pgw = c.prior_lstm ? 4 * nh : 3 * nh;
   const POff po = h->po;
   const Workspace w = sq_carve(h, T, B, (float*)train_workspace, true);
   const BwdSpace b = carve_bwd(h, T, B, (float*)scratch);
@@ -271,7 +272,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     float* d_rec_p_t = b.d_rec_p + (size_t)t * M * RW;
     float* d_rec_d_t = b.d_rec_d + (size_t)t * M * RW;
     const float* temporal_prev = w.state(w.temporal_m, t, w.snh);
-    const float* prior_prev = w.state(w.prior_m, t, w.nh);
+    const float* prior_prev = w.state(w.prior_m, t, w.psnh);
     float* d_tau = b.d_tm[t & 1];       // d temporal_m[t]
     float* d_pprev = b.d_pm[t & 1];     // d prior_m[t]
     const int rl = N * nh, t1l = N * T1_LD, gl2 = N * G2, el = N * ENC_LD, hl = N * HRAW_LD, tpl = N * TP_LD, s1l = N * S1_LD;
@@ -284,7 +285,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       ka.d_temporal_p = b.d_temporal_p; ka.d_prior_p = b.d_prior_p; ka.flat_grad = flat_grad;
       sq_launch_compact_bwd(ka, po, d, s);
       sq_zero_fill(d_tau, (int64_t)M * snh, s);
-      sq_zero_fill(d_pprev, (int64_t)M * nh, s);
+      sq_zero_fill(d_pprev, (int64_t)M * psnh, s);
     }
     // ---- G^T. discovery steps
     float* d_pre_d = b.d_pre_d + (size_t)t * R * nh;
@@ -483,10 +484,17 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       { Dx x(b.d_wb + (size_t)t * M * WB_LD, WB_LD); x.to(0, 128, d_hid1, 256).dact(hid1, 256, ACT_ELU); CK(rundx(L_WB2, x, M)); }
       { Dx x(d_hid1, 256); x.to(0, nh, d_tau + d.toff, snh).acc(); CK(rundx(L_TAU1, x, M)); }
     }
-    // ---- A^T. prior GRU
-    {
-      float* d_pgru1 = b.d_pgru1 + (size_t)t * M * 3 * nh;
-      { Dx x(b.d_pstats + (size_t)t * M * PS_LD, PS_LD); x.to(0, nh, b.dhn, nh).add(b.d_prior_p, nh); CK(rundx(L_PRIOR_LIN, x, M)); }
+    // ---- A^T. prior cell
+    float* d_pgru1 = b.d_pgru1 + (size_t)t * M * pgw;
+    { Dx x(b.d_pstats + (size_t)t * M * PS_LD, PS_LD); x.to(0, nh, b.dhn, nh).add(b.d_prior_p, psnh); CK(rundx(L_PRIOR_LIN, x, M)); }
+    if (c.prior_lstm) {
+      sq_launch_lstm_cell_bwd(w.frame(w.pgz, (int64_t)M * 4 * nh, t), 4 * nh, prior_prev + nh, psnh, b.dhn, nh, b.d_prior_p + nh, psnh,
+                              d_pgru1, pgw, d_pprev + nh, psnh, M, nh, s);
+      Dx x(d_pgru1, pgw);   // [z_{t-1} record 56 (pad 64) | previous hidden state nh]
+      x.to(0, rec::ZW, d_rec_prev, RW).acc();
+      x.to(64, 64 + nh, d_pprev, psnh);
+      CK(rundx(L_PRIOR_GRU1, x, M));
+    } else {
       sq_launch_gru_bwd_a(b.dhn, nh, w.frame(w.pgz, (int64_t)M * nh, t), nh, w.frame(w.pghc, (int64_t)M * nh, t), nh, prior_prev, nh,
                           d_pgru1, 3 * nh, d_pprev, nh, M, nh, 1, s);
       { Dx x(d_pgru1 + 2 * nh, 3 * nh); x.to(0, nh, b.d_rh, nh); CK(rundx(L_PRIOR_GRU2, x, M)); }
@@ -501,7 +509,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   }
   // ================= initial states, input encoder =================
   sq_launch_colsum(b.d_tm[0], snh, M, snh, flat_grad + po.temporal_init, 1, s);
-  sq_launch_colsum(b.d_pm[0], nh, M, nh, flat_grad + po.prior_init, 1, s);
+  sq_launch_colsum(b.d_pm[0], psnh, M, psnh, flat_grad + po.prior_init, 1, s);
   {
     const int TB = T * B;
     CK(dx(L_PREDISC, b.d_pre_disc, nh, TB, b.tmp, nh, false));
@@ -518,10 +526,12 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     const float* tau_all = tm_all + d.toff;
     const float* pm_all = w.prior_m;
     // prior GRU
-    wgrad(L_PRIOR_GRU1, {{w.rec_m_all, RW}, {pm_all, nh}}, b.d_pgru1, 3 * nh, MT);
-    hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.pgr, nh, pm_all, nh, b.rh, nh, MT, nh);
-    wgrad(L_PRIOR_GRU2, {{b.rh, nh}}, b.d_pgru1 + 2 * nh, 3 * nh, MT);
-    wgrad(L_PRIOR_LIN, {{w.prior_p, nh}}, b.d_pstats, PS_LD, MT);
+    wgrad(L_PRIOR_GRU1, {{w.rec_m_all, RW}, {pm_all, psnh}}, b.d_pgru1, pgw, MT);
+    if (!c.prior_lstm) {
+      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.pgr, nh, pm_all, nh, b.rh, nh, MT, nh);
+      wgrad(L_PRIOR_GRU2, {{b.rh, nh}}, b.d_pgru1 + 2 * nh, 3 * nh, MT);
+    }
+    wgrad(L_PRIOR_LIN, {{w.prior_p, psnh}}, b.d_pstats, PS_LD, MT);
     // where-bias / mask MLPs
     wgrad(L_TAU1, {{tau_all, snh}}, b.d_hid1, 256, MT);
     wgrad(L_WB2, {{w.hid1, 256}}, b.d_wb, WB_LD, MT);

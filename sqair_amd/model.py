@@ -34,9 +34,9 @@ def make_config(F, img_hw):
         raise ValueError('Invalid prior type: "{}". Choose from {}.'.format(F.prop_prior_type, list(_PRIOR_TYPES)))
     if F.disc_prior_type not in _DISC_PRIOR_TYPES:
         raise ValueError("Invalid prior type: {}".format(F.disc_prior_type))
-    if (F.transition, F.prior_transition) != ("VanillaRNN", "GRU") or F.time_transition not in ("GRU", "LSTM"):
+    if F.transition != "VanillaRNN" or F.time_transition not in ("GRU", "LSTM") or F.prior_transition not in ("GRU", "LSTM"):
         raise NotImplementedError(
-            "HIP path implements transition=VanillaRNN, time_transition in {{GRU, LSTM}}, prior_transition=GRU "
+            "HIP path implements transition=VanillaRNN, time_transition and prior_transition in {{GRU, LSTM}} "
             "(configs/mlp_mnist_model.py:86-87,125 pick Sonnet cells by name); got {}/{}/{}".format(
                 F.transition, F.time_transition, F.prior_transition))
     p = get_params(F)
@@ -47,7 +47,8 @@ def make_config(F, img_hw):
         int(p.n_hidden), int(F.k_particles), _PRIOR_TYPES[F.prop_prior_type], _DISC_PRIOR_TYPES[F.disc_prior_type],
         int(bool(F.masked_glimpse)), int(bool(F.rec_where_prior)), float(F.prop_prior_step_bias),
         float(F.step_success_prob), std, std, (C.c_float * 4)(sp[0], sp[1], 0.0, 0.0),
-        int(bool(F.sample_from_prior)), int(getattr(F, "generate_after", -1)), int(F.time_transition == "LSTM"))
+        int(bool(F.sample_from_prior)), int(getattr(F, "generate_after", -1)), int(F.time_transition == "LSTM"),
+        int(F.prior_transition == "LSTM"))
 
 
 class SqairCore(object):
@@ -73,6 +74,7 @@ class SqairCore(object):
         self.nw = int(F.n_what)
         self.nh = get_params(F).n_hidden
         self.snh = self.nh * (2 if F.time_transition == "LSTM" else 1)  # temporal state: [hidden | cell] for an LSTM
+        self.psnh = self.nh * (2 if F.prior_transition == "LSTM" else 1)  # same for the propagation prior's state
         self.G = int(F.glimpse_size)
         self.H, self.W = int(img_hw[0]), int(img_hw[1])
         self.nzw = self.lib.sqair_noise_width(self.handle)
@@ -154,7 +156,7 @@ class SqairCore(object):
             num_prop_steps_per_sample=(T, R), num_disc_steps_per_sample=(T, R), num_steps_per_sample=(T, R),
             prop_pres=(T, R, N), disc_pres=(T, R, N), data_ll_per_sample=(T, R), kl_per_sample=(T, R),
             log_q_z_given_x_per_sample=(T, R), log_p_z_per_sample=(T, R), log_weights_per_timestep=(T, R),
-            final_temporal_state=(R, N, self.snh), final_prior_state=(R, N, nh), final_last_used_id=(R,),
+            final_temporal_state=(R, N, self.snh), final_prior_state=(R, N, self.psnh), final_last_used_id=(R,),
         )
         if outputs == "all":
             wanted = list(_capi.OUTPUT_FIELDS)

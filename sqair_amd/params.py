@@ -99,16 +99,23 @@ def param_spec(F, img_hw):
 
     # ---- propagation (core.py:230-359, propagate.py:46-120)
     pc = "propagation/propagation_core"
+    # Sonnet uniquifies module names per class in construction order (configs/mlp_mnist_model.py:116-125: transition cell,
+    # temporal cell, prior cell): gru / gru_1, lstm / lstm_1
     time_lstm = str(getattr(F, "time_transition", "GRU")) == "LSTM"
+    prior_lstm = str(getattr(F, "prior_transition", "GRU")) == "LSTM"
     if time_lstm:
         # snt.LSTM(n_hidden): gates = [x, h] w_gates + b_gates, split (i, j, f, o) (SURVEY Appendix B style restatement)
         fin = nh + 4 + 2 * nw
         spec.append(("prop.temporal_lstm.w", (fin + nh, 4 * nh), ("lin_w", fin + nh), "propagation/lstm/w_gates"))
         spec.append(("prop.temporal_lstm.b", (4 * nh,), ("zeros",), "propagation/lstm/b_gates"))
-        gru("prop.prior_gru", nw + 4, "propagation/gru")
     else:
         gru("prop.temporal_gru", nh + 4 + 2 * nw, "propagation/gru")
-        gru("prop.prior_gru", nw + 4, "propagation/gru_1")
+    if prior_lstm:
+        scope = "propagation/lstm_1" if time_lstm else "propagation/lstm"
+        spec.append(("prop.prior_lstm.w", (nw + 4 + nh, 4 * nh), ("lin_w", nw + 4 + nh), scope + "/w_gates"))
+        spec.append(("prop.prior_lstm.b", (4 * nh,), ("zeros",), scope + "/b_gates"))
+    else:
+        gru("prop.prior_gru", nw + 4, "propagation/gru" if time_lstm else "propagation/gru_1")
     lin("prop.prior_linear", nh, 2 * (4 + nw) + 1, "propagation/propagate_prior/linear")
     spec.append(("prop.cholesky_scale", (10,), ("glorot", 10, 10),
                  pc + "/affine_diag_normal/cholesky_scale"))
@@ -130,14 +137,17 @@ def param_spec(F, img_hw):
     lin("prop.rnn.i2h", nw + (nw + 4 + 1) + (nw + 4 + 1) + nh, nh, pc + "/vanilla_rnn/in_to_hidden")
 
     # ---- sequence (sqair_modules.py:332-385)
+    # trainable initial states, named after the cell's module name (RNNCore.initial_state(trainable=True)); an
+    # LSTMState(hidden, cell) has two variables, kept adjacent ([hidden | cell] is read as one row)
+    sq = "sequence/sequential_air/"
+    pmod = ("lstm_1" if time_lstm else "lstm") if prior_lstm else ("gru" if time_lstm else "gru_1")
+    spec.append(("seq.prior_init", (1, nh), ("zeros",), sq + pmod + "_initial_state_0/w"))
+    if prior_lstm:
+        spec.append(("seq.prior_init_c", (1, nh), ("zeros",), sq + pmod + "_initial_state_1/w"))
+    tmod = "lstm" if time_lstm else "gru"
+    spec.append(("seq.temporal_init", (1, nh), ("zeros",), sq + tmod + "_initial_state_0/w"))
     if time_lstm:
-        spec.append(("seq.prior_init", (1, nh), ("zeros",), "sequence/sequential_air/gru_initial_state_0/w"))
-        # LSTMState(hidden, cell): two trainable initial-state variables
-        spec.append(("seq.temporal_init", (1, nh), ("zeros",), "sequence/sequential_air/lstm_initial_state_0/w"))
-        spec.append(("seq.temporal_init_c", (1, nh), ("zeros",), "sequence/sequential_air/lstm_initial_state_1/w"))
-    else:
-        spec.append(("seq.prior_init", (1, nh), ("zeros",), "sequence/sequential_air/gru_1_initial_state_0/w"))
-        spec.append(("seq.temporal_init", (1, nh), ("zeros",), "sequence/sequential_air/gru_initial_state_0/w"))
+        spec.append(("seq.temporal_init_c", (1, nh), ("zeros",), sq + tmod + "_initial_state_1/w"))
     lin("seq.latent_enc.l0", nw + 4, nh, "sequence/sequential_air/sqair_timestep/mlp/linear")
     lin("seq.latent_enc.l1", nh, nh, "sequence/sequential_air/sqair_timestep/mlp/linear_1")
     return spec

@@ -86,6 +86,19 @@ def test_forward_flag_variants_vs_live_oracle(prior, disc_prior, rec):
     _live_oracle_case(F)
 
 
+@pytest.mark.parametrize("cells", [("GRU", "LSTM"), ("LSTM", "LSTM")])
+def test_forward_lstm_prior_cell_vs_live_oracle(cells):
+    """prior_transition=LSTM (configs/mlp_mnist_model.py:125): the propagation prior's recurrent state is [hidden | cell],
+    its Linear reads the cell output (propagate.py:80-83)."""
+    F = make_flags(k_particles=2, n_steps_per_image=3, time_transition=cells[0], prior_transition=cells[1])
+    m, ref = _live_oracle_case(F, T=4, B=3)
+    assert float(ref.prop_pres.sum()) > 0, "case must exercise propagation"
+    got = m.outputs["final_prior_state"].cpu().numpy()
+    want = ref.outputs["_final_prior_state"].numpy()
+    assert got.shape == want.shape and got.shape[-1] == 512
+    assert np.abs(got - want).max() < 5e-4 * max(1.0, np.abs(want).max())
+
+
 @pytest.mark.parametrize("K,N,T,B", [(2, 3, 3, 3), (3, 4, 4, 2)])
 def test_forward_lstm_temporal_cell_vs_live_oracle(K, N, T, B):
     """time_transition=LSTM (configs/mlp_mnist_model.py:86-87: cells are picked by name; north_star's "propagation LSTM
