@@ -205,6 +205,15 @@ int sqair_linear_test(SqairHandle* h, const float* x, const float* w, const floa
 int sqair_gru_test(SqairHandle* h, const float* x, const float* hstate, const float* gru_flat, float* h_out,
                    int M, int Kx, void* scratch, int64_t scratch_bytes, void* stream);
 
+/* snt.LSTM step (time_transition / prior_transition = LSTM; dm_sonnet 1.14 restated: gates (i, j, f, o) =
+ * [x, h] w_gates + b_gates; c' = sigmoid(f + 1) c + sigmoid(i) tanh(j); h' = tanh(c') sigmoid(o)):
+ * lstm_flat = w_gates [(Kx + nh), 4 nh] then b_gates [4 nh]; state_out [M, 2 nh] = [h' | c']. */
+int sqair_lstm_test(SqairHandle* h, const float* x, const float* hstate, const float* cstate, const float* lstm_flat,
+                    float* state_out, int M, int Kx, void* scratch, int64_t scratch_bytes, void* stream);
+/* adjoint of the element-wise cell: gate pre-activations [M, 4 nh], c_prev, d h', d c' -> d gates, d c_prev */
+int sqair_lstm_cell_bwd_test(SqairHandle* h, const float* gates, const float* c_prev, const float* d_h, const float* d_c,
+                             float* d_gates, float* d_cprev, int M, void* stream);
+
 /* ---- adjoint (backward) building blocks of the training step (sqair_st_crop_bwd,
  * sqair_st_insert_ll_bwd, ...; the reference gets them from TF autodiff, sqair/model.py:160) ---------- */
 /* d/d(where logits) [R,4] and optionally d/d(mask) [R,G*G] of the (masked) crop, given d/d(out) [R,G*G]. */

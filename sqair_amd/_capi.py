@@ -77,6 +77,8 @@ _PROTOS = {
                                     C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "sqair_gru_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_void_p, C.c_int64, C.c_void_p]),
+    "sqair_lstm_test": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "sqair_lstm_cell_bwd_test": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_void_p]),
     "sqair_get_config": (C.c_int, [C.c_void_p, C.POINTER(SqairConfig)]),
     "sqair_st_crop_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_void_p]),
     "sqair_st_insert_loglik_bwd": (C.c_int, [C.c_void_p] * 11 + [C.c_int64, C.c_int, C.c_void_p]),

@@ -1351,6 +1351,64 @@ extern "C" int sqair_gru_test(SqairHandle* h, const float* x, const float* hstat
   return 0;
 }
 
+// snt.LSTM step through the launches the forward pass uses: one gate GEMM over [x | h] + the element-wise cell kernel
+extern "C" int sqair_lstm_test(SqairHandle* h, const float* x, const float* hstate, const float* cstate, const float* lstm_flat,
+                               float* state_out, int M, int Kx, void* scratch, int64_t scratch_bytes, void* stream) {
+  if (!h || !x || !hstate || !cstate || !lstm_flat || !state_out || !scratch) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const int nh = h->cfg.n_hidden;
+  // lstm_flat: w_gates [(Kx + nh), 4 nh] then b_gates [4 nh] (the order of the reference's LSTM variables)
+  PackedLayer L;
+  L.seg_width = {Kx, nh};
+  L.kc = (Kx + 15) / 16 + (nh + 15) / 16;
+  L.nt = 4 * nh / 16; L.N = 4 * nh; L.w_off = 0; L.b_off = 0;
+  const int64_t nel = (int64_t)L.nt * L.kc * 256, nb = L.nt * 16;
+  const int kpad = (Kx + 3) & ~3;
+  const int64_t need = (2 * nel + 2 * nb + 256 + (int64_t)M * kpad + (int64_t)M * 4 * nh) * 4;
+  if (scratch_bytes < need) { sq_set_error(h, "sqair_lstm_test: scratch too small"); return -1; }
+  std::vector<int> idx(nel, -1), bidx(nb, -1);
+  adhoc_fill(idx, L.kc, 0, 0, 4 * nh, Kx, 0, 4 * nh, 0);
+  adhoc_fill(idx, L.kc, (Kx + 15) / 16, 0, 4 * nh, nh, (int64_t)Kx * 4 * nh, 4 * nh, 0);
+  for (int n = 0; n < 4 * nh; ++n) bidx[n] = (int)((int64_t)(Kx + nh) * 4 * nh + n);
+  float* f = (float*)scratch;
+  int* d_idx = (int*)f; f += nel;
+  float* d_w = f; f += nel;
+  int* d_bidx = (int*)f; f += nb;
+  float* d_b = f; f += nb;
+  float* d_zero = f; f += 256;
+  float* d_x = f; f += (int64_t)M * kpad;
+  float* d_g = f;
+  SQ_CHECK_HIP(hipMemsetAsync(d_zero, 0, (256 + (size_t)M * kpad) * 4, s));
+  SQ_CHECK_HIP(hipMemcpy2DAsync(d_x, (size_t)kpad * 4, x, (size_t)Kx * 4, (size_t)Kx * 4, M, hipMemcpyDeviceToDevice, s));
+  SQ_CHECK_HIP(hipMemcpyAsync(d_idx, idx.data(), nel * 4, hipMemcpyHostToDevice, s));
+  SQ_CHECK_HIP(hipMemcpyAsync(d_bidx, bidx.data(), nb * 4, hipMemcpyHostToDevice, s));
+  SQ_CHECK_HIP(hipStreamSynchronize(s));
+  sq_launch_pack(lstm_flat, d_w, d_idx, nel, s);
+  sq_launch_pack(lstm_flat, d_b, d_bidx, nb, s);
+  Lin g;
+  g.seg(d_x, kpad, Kx).seg(hstate, nh, nh).out(d_g, 4 * nh);
+  g.a.wp = d_w; g.a.wzero = d_zero; g.a.bias = d_b; g.a.M = M; g.a.N = 4 * nh;
+  if (sq_launch_linear(g.a, L, s) != 0) { sq_set_error(h, "sqair_lstm_test: A-operand contract violated"); return -5; }
+  sq_launch_lstm_cell(d_g, 4 * nh, cstate, nh, state_out, 2 * nh, M, nh, s);
+  SQ_CHECK_HIP(hipGetLastError());
+  SQ_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int sq_launch_lstm_cell_bwd(const float* gates, int g_ld, const float* c_prev, int c_ld, const float* d_h, int dh_ld, const float* d_c,
+                            int dc_ld, float* d_gates, int dg_ld, float* d_cprev, int dcp_ld, int rows, int nh, hipStream_t s);
+// adjoint of the element-wise LSTM cell: gates [M, 4 nh] (pre-activations i, j, f, o), c_prev, d h', d c' -> d gates, d c_prev
+extern "C" int sqair_lstm_cell_bwd_test(SqairHandle* h, const float* gates, const float* c_prev, const float* d_h, const float* d_c,
+                                        float* d_gates, float* d_cprev, int M, void* stream) {
+  if (!h || !gates || !c_prev || !d_h || !d_c || !d_gates || !d_cprev) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const int nh = h->cfg.n_hidden;
+  sq_launch_lstm_cell_bwd(gates, 4 * nh, c_prev, nh, d_h, nh, d_c, nh, d_gates, 4 * nh, d_cprev, nh, M, nh, s);
+  SQ_CHECK_HIP(hipGetLastError());
+  SQ_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-only introspection of the packing plan (tests/test_pack_plan.py emulates the packed GEMMs on
 // the CPU from these tables to check the row / column maps without a GPU)

@@ -84,6 +84,47 @@ def test_gru_step(handle, M, Kx):
     assert np.abs(out.cpu().numpy() - ref.numpy()).max() < 2e-5
 
 
+@pytest.mark.parametrize("M,Kx", [(160, 360), (640, 54), (7, 17)])
+def test_lstm_step_and_cell_adjoint(handle, M, Kx):
+    """snt.LSTM step (gate GEMM over [x | h] + k_lstm_cell) against the oracle's restatement, and the cell adjoint against
+    autograd through it."""
+    lib, h, _ = handle
+    nh = 256
+    rng = np.random.default_rng(Kx + 1)
+    P = {"l.w": (rng.standard_normal((Kx + nh, 4 * nh)) / np.sqrt(Kx + nh)).astype(np.float32),
+         "l.b": (rng.standard_normal(4 * nh) * 0.1).astype(np.float32)}
+    x = rng.standard_normal((M, Kx)).astype(np.float32)
+    hs = rng.standard_normal((M, nh)).astype(np.float32)
+    cs = rng.standard_normal((M, nh)).astype(np.float32)
+    out = torch.zeros(M, 2 * nh, device="cuda")
+    scratch = torch.empty(1 << 23, dtype=torch.float32, device="cuda")
+    ts = [dev(x), dev(hs), dev(cs), dev(np.concatenate([P["l.w"].ravel(), P["l.b"]]))]
+    rc = lib.sqair_lstm_test(h, *[t.data_ptr() for t in ts], out.data_ptr(), M, Kx, scratch.data_ptr(), scratch.numel() * 4, stream())
+    assert rc == 0, lib.sqair_last_error(h)
+    P64 = {k: torch.tensor(v, dtype=torch.float64) for k, v in P.items()}
+    h2, c2 = O.lstm(P64, "l", torch.tensor(x, dtype=torch.float64), torch.tensor(hs, dtype=torch.float64),
+                    torch.tensor(cs, dtype=torch.float64))
+    got = out.cpu().numpy()
+    assert np.abs(got[:, :nh] - h2.numpy()).max() < 2e-5
+    assert np.abs(got[:, nh:] - c2.numpy()).max() < 2e-5
+    # cell adjoint
+    gates = torch.tensor(rng.standard_normal((M, 4 * nh)), dtype=torch.float64, requires_grad=True)
+    cp = torch.tensor(cs, dtype=torch.float64, requires_grad=True)
+    i, j, f, o = torch.chunk(gates, 4, -1)
+    cn = torch.sigmoid(f + 1.0) * cp + torch.sigmoid(i) * torch.tanh(j)
+    hn = torch.tanh(cn) * torch.sigmoid(o)
+    dh = rng.standard_normal((M, nh)).astype(np.float32)
+    dc = rng.standard_normal((M, nh)).astype(np.float32)
+    ((hn * torch.tensor(dh, dtype=torch.float64)).sum() + (cn * torch.tensor(dc, dtype=torch.float64)).sum()).backward()
+    d_g = torch.zeros(M, 4 * nh, device="cuda")
+    d_cp = torch.zeros(M, nh, device="cuda")
+    ts = [dev(gates.detach().numpy().astype(np.float32)), dev(cs), dev(dh), dev(dc)]
+    rc = lib.sqair_lstm_cell_bwd_test(h, *[t.data_ptr() for t in ts], d_g.data_ptr(), d_cp.data_ptr(), M, stream())
+    assert rc == 0, lib.sqair_last_error(h)
+    assert np.abs(d_g.cpu().numpy() - gates.grad.numpy()).max() < 1e-5
+    assert np.abs(d_cp.cpu().numpy() - cp.grad.numpy()).max() < 1e-5
+
+
 @pytest.mark.parametrize("hw", [(50, 50), (128, 128), (37, 61)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_st_crop(hw, masked):
