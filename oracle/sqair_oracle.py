@@ -316,8 +316,8 @@ class SqairOracle(object):
     def __init__(self, params, cfg, dtype=torch.float64, requires_grad=False):
         self.cfg = cfg
         self.dtype = dtype
-        if cfg.transition != "VanillaRNN" or cfg.time_transition not in ("GRU", "LSTM") or cfg.prior_transition not in ("GRU", "LSTM"):
-            raise NotImplementedError("oracle restates transition=VanillaRNN, time_transition / prior_transition in {GRU, LSTM}")
+        if cfg.transition not in ("VanillaRNN", "LSTM") or cfg.time_transition not in ("GRU", "LSTM") or cfg.prior_transition not in ("GRU", "LSTM"):
+            raise NotImplementedError("oracle restates transition in {VanillaRNN, LSTM}, time_transition / prior_transition in {GRU, LSTM}")
         if cfg.prop_prior_type not in ("rnn", "rw", "guided"):
             raise ValueError('Invalid prior type: "{}"'.format(cfg.prop_prior_type))  # propagate.py:42-43
         if cfg.disc_prior_type not in ("cat", "geom"):
@@ -426,7 +426,7 @@ class SqairOracle(object):
         loc1, _ = self.air_encoder(img, where_tm1 + where_bias, mask_inpt=temporal_state)
         rnn_inpt = torch.cat([loc1, what_km1, where_km1, pres_km1, what_tm1, where_tm1, pres_tm1,
                               temporal_state], -1)
-        hidden = vanilla_rnn(P, "prop.rnn", rnn_inpt, hidden)
+        hidden, hidden_state = self.slot_rnn("prop", rnn_inpt, hidden)
         # where (core.py:323-334, modules.py:89-97)
         tp = linear(P, "prop.transform.l2", mlp2_hidden(P, "prop.transform",
                                                          torch.cat([hidden, where_tm1, temporal_state], -1)))
@@ -454,7 +454,22 @@ class SqairOracle(object):
         out = dict(what=what, what_loc=what_loc, what_scale=what_scale, where=where, where_loc=loc,
                    where_scale=scale, presence_prob=prob, presence=pres, presence_logit=logit,
                    temporal_state=temporal_new)
-        return out, (what, where, pres, hidden)
+        return out, (what, where, pres, hidden_state)
+
+    def slot_rnn(self, core, rnn_inpt, state):
+        """core.py:187-189 / :304-305: hidden_output, hidden_state = cell(rnn_inpt, hidden_state).  VanillaRNN: both are the
+        new hidden vector; LSTM (transition=LSTM): the state travels as [hidden | cell], the output is the new hidden."""
+        if self.cfg.transition == "LSTM":
+            nh = self.cfg.n_hidden
+            h, c2 = lstm(self.P, core + ".rnn_lstm", rnn_inpt, state[..., :nh], state[..., nh:])
+            return h, torch.cat([h, c2], -1)
+        h = vanilla_rnn(self.P, core + ".rnn", rnn_inpt, state)
+        return h, h
+
+    def initial_rnn_state(self, core):
+        if self.cfg.transition == "LSTM":
+            return torch.cat([self.P[core + ".rnn_init"], self.P[core + ".rnn_init_c"]], -1)
+        return self.P[core + ".rnn_init"]
 
     def propagate(self, img, z_tm1, temporal_state, prior_state, noise, gen_noise=None, do_generate=False):
         """Propagate._build/_compute_log_probs (sqair_modules.py:250-329) + SequentialSSM
@@ -464,7 +479,7 @@ class SqairOracle(object):
         N, nw = c.N, c.n_what
         prior_stats, prior_state = self.propagate_prior(z_tm1, prior_state)
         zeros = lambda n: torch.zeros(B, n, dtype=self.dtype)
-        state = (zeros(nw), zeros(4), zeros(1), self.P["prop.rnn_init"].expand(B, -1))
+        state = (zeros(nw), zeros(4), zeros(1), self.initial_rnn_state("prop").expand(B, -1))
         outs = []
         for k in range(N):
             z_k = tuple(z[:, k] for z in z_tm1)
@@ -511,7 +526,7 @@ class SqairOracle(object):
         P = self.P
         what_prev, where_prev, pres_prev, hidden = state
         rnn_inpt = torch.cat([self.input_encoder(img), conditioning, what_prev, where_prev, pres_prev], -1)
-        hidden = vanilla_rnn(P, "disc.rnn", rnn_inpt, hidden)
+        hidden, hidden_state = self.slot_rnn("disc", rnn_inpt, hidden)
         tp = linear(P, "disc.transform.l2", mlp2_hidden(P, "disc.transform", hidden))
         where_loc = tp[..., :4]
         where_scale = softplus(tp[..., 4:] + P["disc.transform.scale_offset"]) + 1e-2
@@ -521,7 +536,7 @@ class SqairOracle(object):
         pres, prob, logit = self.compute_presence("disc.steps", pres_prev, [hidden, what], u)
         out = dict(what=what, what_loc=what_loc, what_scale=what_scale, where=where, where_loc=where_loc,
                    where_scale=where_scale, presence_prob=prob, presence=pres, presence_logit=logit)
-        return out, (what, where, pres, hidden)
+        return out, (what, where, pres, hidden_state)
 
     def recurrent_normal_log_prob(self, samples, conditioning):
         """RecurrentNormal.log_prob -> RecurrentNormalImpl (modules.py:548-611).  The RNN state is
@@ -564,7 +579,7 @@ class SqairOracle(object):
         B = img.shape[0]
         N, nw = c.N, c.n_what
         zeros = lambda n: torch.zeros(B, n, dtype=self.dtype)
-        state = (zeros(nw), zeros(4), torch.ones(B, 1, dtype=self.dtype), P["disc.rnn_init"].expand(B, -1))
+        state = (zeros(nw), zeros(4), torch.ones(B, 1, dtype=self.dtype), self.initial_rnn_state("disc").expand(B, -1))
         outs = []
         for j in range(N):
             o, state = self.discovery_core(img, conditioning, state, noise[:, j, 0:4], noise[:, j, 4:4 + nw],

@@ -60,8 +60,11 @@ def param_spec(F, img_hw):
 
     # ---- discovery (core.py:146-227, sqair_modules.py:66-229, modules.py:548-630)
     d = "discovery/discover/discovery_core"
-    spec.append(("disc.rnn_init", (1, nh), ("zeros",),
-                 "discovery/discover/discovery/vanilla_rnn_initial_state_0/w"))
+    rnn_lstm = str(getattr(F, "transition", "VanillaRNN")) == "LSTM"   # the slot RNN of both cores (mlp_mnist_model.py:86)
+    rmod = "lstm" if rnn_lstm else "vanilla_rnn"
+    spec.append(("disc.rnn_init", (1, nh), ("zeros",), "discovery/discover/discovery/" + rmod + "_initial_state_0/w"))
+    if rnn_lstm:
+        spec.append(("disc.rnn_init_c", (1, nh), ("zeros",), "discovery/discover/discovery/" + rmod + "_initial_state_1/w"))
     lin("disc.steps_prior.l0", 1, 10, "discovery/discover/mlp/linear")
     lin("disc.steps_prior.l1", 10, N + 1, "discovery/discover/mlp/linear_1")
     rn = "discovery/discover/recurrent_normal_impl"
@@ -88,8 +91,13 @@ def param_spec(F, img_hw):
     lin("disc.transform.l2", nh, 8, d + "/stochastic_transform_param/mlp/linear_2")
     spec.append(("disc.transform.scale_offset", (), ("const", float(F.transform_var_bias)),
                  d + "/stochastic_transform_param/scale_offset"))
-    lin("disc.rnn.h2h", nh, nh, d + "/vanilla_rnn/hidden_to_hidden")
-    lin("disc.rnn.i2h", nh + nh + nw + 4 + 1, nh, d + "/vanilla_rnn/in_to_hidden")
+    fin_d = nh + nh + nw + 4 + 1
+    if rnn_lstm:
+        spec.append(("disc.rnn_lstm.w", (fin_d + nh, 4 * nh), ("lin_w", fin_d + nh), d + "/lstm/w_gates"))
+        spec.append(("disc.rnn_lstm.b", (4 * nh,), ("zeros",), d + "/lstm/b_gates"))
+    else:
+        lin("disc.rnn.h2h", nh, nh, d + "/vanilla_rnn/hidden_to_hidden")
+        lin("disc.rnn.i2h", fin_d, nh, d + "/vanilla_rnn/in_to_hidden")
 
     # ---- model-scope categorical step prior (sqair_modules.py:209-221)
     spec.append(("disc.step_prior_bias", (N + 1,), ("zeros",),
@@ -100,18 +108,26 @@ def param_spec(F, img_hw):
     # ---- propagation (core.py:230-359, propagate.py:46-120)
     pc = "propagation/propagation_core"
     # Sonnet uniquifies module names per class in construction order (configs/mlp_mnist_model.py:116-125: transition cell,
-    # temporal cell, prior cell): gru / gru_1, lstm / lstm_1
+    # temporal cell, prior cell): gru / gru_1, lstm / lstm_1 / lstm_2.  (Names of non-shipped cell choices are a best
+    # guess from that rule: no listing of such a model exists in the reference.)
+    n_lstm = [1 if rnn_lstm else 0]
+
+    def lstm_scope():
+        n_lstm[0] += 1
+        return "lstm" if n_lstm[0] == 1 else "lstm_{}".format(n_lstm[0] - 1)
     time_lstm = str(getattr(F, "time_transition", "GRU")) == "LSTM"
     prior_lstm = str(getattr(F, "prior_transition", "GRU")) == "LSTM"
     if time_lstm:
         # snt.LSTM(n_hidden): gates = [x, h] w_gates + b_gates, split (i, j, f, o) (SURVEY Appendix B style restatement)
         fin = nh + 4 + 2 * nw
-        spec.append(("prop.temporal_lstm.w", (fin + nh, 4 * nh), ("lin_w", fin + nh), "propagation/lstm/w_gates"))
-        spec.append(("prop.temporal_lstm.b", (4 * nh,), ("zeros",), "propagation/lstm/b_gates"))
+        tmod = lstm_scope()
+        spec.append(("prop.temporal_lstm.w", (fin + nh, 4 * nh), ("lin_w", fin + nh), "propagation/" + tmod + "/w_gates"))
+        spec.append(("prop.temporal_lstm.b", (4 * nh,), ("zeros",), "propagation/" + tmod + "/b_gates"))
     else:
         gru("prop.temporal_gru", nh + 4 + 2 * nw, "propagation/gru")
     if prior_lstm:
-        scope = "propagation/lstm_1" if time_lstm else "propagation/lstm"
+        pmod = lstm_scope()
+        scope = "propagation/" + pmod
         spec.append(("prop.prior_lstm.w", (nw + 4 + nh, 4 * nh), ("lin_w", nw + 4 + nh), scope + "/w_gates"))
         spec.append(("prop.prior_lstm.b", (4 * nh,), ("zeros",), scope + "/b_gates"))
     else:
@@ -131,20 +147,25 @@ def param_spec(F, img_hw):
                  pc + "/stochastic_transform_param/scale_offset"))
     lin("prop.what_head", nh, 2 * nw, pc + "/what/gaussian_from_param_vec/linear")
     lin("prop.gates", nh, 3 * nw, pc + "/what/linear", b_init=("const", 1.0))
-    spec.append(("prop.rnn_init", (1, nh), ("zeros",),
-                 "propagation/sequential_ssm/propagation/vanilla_rnn_initial_state_0/w"))
-    lin("prop.rnn.h2h", nh, nh, pc + "/vanilla_rnn/hidden_to_hidden")
-    lin("prop.rnn.i2h", nw + (nw + 4 + 1) + (nw + 4 + 1) + nh, nh, pc + "/vanilla_rnn/in_to_hidden")
+    spec.append(("prop.rnn_init", (1, nh), ("zeros",), "propagation/sequential_ssm/propagation/" + rmod + "_initial_state_0/w"))
+    fin_p = nw + (nw + 4 + 1) + (nw + 4 + 1) + nh
+    if rnn_lstm:
+        spec.append(("prop.rnn_init_c", (1, nh), ("zeros",), "propagation/sequential_ssm/propagation/" + rmod + "_initial_state_1/w"))
+        spec.append(("prop.rnn_lstm.w", (fin_p + nh, 4 * nh), ("lin_w", fin_p + nh), pc + "/lstm/w_gates"))
+        spec.append(("prop.rnn_lstm.b", (4 * nh,), ("zeros",), pc + "/lstm/b_gates"))
+    else:
+        lin("prop.rnn.h2h", nh, nh, pc + "/vanilla_rnn/hidden_to_hidden")
+        lin("prop.rnn.i2h", fin_p, nh, pc + "/vanilla_rnn/in_to_hidden")
 
     # ---- sequence (sqair_modules.py:332-385)
     # trainable initial states, named after the cell's module name (RNNCore.initial_state(trainable=True)); an
     # LSTMState(hidden, cell) has two variables, kept adjacent ([hidden | cell] is read as one row)
     sq = "sequence/sequential_air/"
-    pmod = ("lstm_1" if time_lstm else "lstm") if prior_lstm else ("gru" if time_lstm else "gru_1")
+    pmod = pmod if prior_lstm else ("gru" if time_lstm else "gru_1")
     spec.append(("seq.prior_init", (1, nh), ("zeros",), sq + pmod + "_initial_state_0/w"))
     if prior_lstm:
         spec.append(("seq.prior_init_c", (1, nh), ("zeros",), sq + pmod + "_initial_state_1/w"))
-    tmod = "lstm" if time_lstm else "gru"
+    tmod = tmod if time_lstm else "gru"
     spec.append(("seq.temporal_init", (1, nh), ("zeros",), sq + tmod + "_initial_state_0/w"))
     if time_lstm:
         spec.append(("seq.temporal_init_c", (1, nh), ("zeros",), sq + tmod + "_initial_state_1/w"))

@@ -334,7 +334,7 @@ def test_generation_after_t_samples_the_priors():
     assert torch.isfinite(b.log_weights).all()
 
 
-@pytest.mark.parametrize("cells", [("LSTM", "GRU"), ("GRU", "LSTM"), ("LSTM", "LSTM")])
+@pytest.mark.parametrize("cells", [("LSTM", "GRU"), ("GRU", "LSTM"), ("LSTM", "LSTM"), ("GRU", "GRU", "LSTM"), ("LSTM", "LSTM", "LSTM")])
 def test_lstm_cells_are_wired_into_the_model(cells):
     """time_transition / prior_transition = LSTM (configs/mlp_mnist_model.py:86-87,125): the recurrent states double to
     [hidden | cell], every parameter of the LSTM variant receives a gradient, and the parameter table swaps the nine GRU
@@ -342,7 +342,8 @@ def test_lstm_cells_are_wired_into_the_model(cells):
     from sqair_amd.data import make_sequences, to_float
     from sqair_amd.flags import make_flags
     from sqair_amd.params import init_params, param_spec
-    F = make_flags(k_particles=2, n_steps_per_image=3, time_transition=cells[0], prior_transition=cells[1])
+    rnn = cells[2] if len(cells) > 2 else "VanillaRNN"
+    F = make_flags(k_particles=2, n_steps_per_image=3, time_transition=cells[0], prior_transition=cells[1], transition=rnn)
     hw, T, B = (32, 40), 3, 2
     d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=20, seed=9)
     obs = to_float(d["imgs"])
@@ -362,3 +363,4 @@ def test_lstm_cells_are_wired_into_the_model(cells):
     assert len(set(tf_names)) == len(tf_names)
     assert ("prop.temporal_lstm.w" in names) == (cells[0] == "LSTM") and ("prop.temporal_gru.wz" in names) == (cells[0] == "GRU")
     assert ("prop.prior_lstm.w" in names) == (cells[1] == "LSTM") and ("seq.prior_init_c" in names) == (cells[1] == "LSTM")
+    assert ("prop.rnn_lstm.w" in names) == (rnn == "LSTM") == ("disc.rnn_init_c" in names) and ("prop.rnn.i2h.w" in names) == (rnn != "LSTM")
