@@ -66,6 +66,7 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "dec.l2", nh, G2);
   add_param(h, "dec.output_scale", 1, 1);
   add_param(h, "disc.rnn_init", 1, nh);
+  if (c.rnn_lstm) add_param(h, "disc.rnn_init_c", 1, nh);  // LSTMState(hidden, cell): adjacent rows
   add_lin(h, "disc.steps_prior.l0", 1, 10);
   add_lin(h, "disc.steps_prior.l1", 10, N + 1);
   add_param(h, "disc.rn.init_state", 1, 4);
@@ -87,8 +88,11 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "disc.transform.l1", nh, nh);
   add_lin(h, "disc.transform.l2", nh, 8);
   add_param(h, "disc.transform.scale_offset", 1, 1);
-  add_lin(h, "disc.rnn.h2h", nh, nh);
-  add_lin(h, "disc.rnn.i2h", nh + nh + nw + 4 + 1, nh);
+  if (c.rnn_lstm) add_lin(h, "disc.rnn_lstm", (nh + nh + nw + 4 + 1) + nh, 4 * nh);  // snt.LSTM w_gates [x | h], b_gates
+  else {
+    add_lin(h, "disc.rnn.h2h", nh, nh);
+    add_lin(h, "disc.rnn.i2h", nh + nh + nw + 4 + 1, nh);
+  }
   add_param(h, "disc.step_prior_bias", 1, N + 1);
   add_param(h, "disc.step_prior_timestep_bias", 1, N + 1);
   if (c.time_lstm) add_lin(h, "prop.temporal_lstm", (nh + 4 + 2 * nw) + nh, 4 * nh);  // snt.LSTM: w_gates [x | h] rows, b_gates
@@ -108,8 +112,13 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "prop.what_head", nh, 2 * nw);
   add_lin(h, "prop.gates", nh, 3 * nw);
   add_param(h, "prop.rnn_init", 1, nh);
-  add_lin(h, "prop.rnn.h2h", nh, nh);
-  add_lin(h, "prop.rnn.i2h", nw + (nw + 5) + (nw + 5) + nh, nh);
+  if (c.rnn_lstm) {
+    add_param(h, "prop.rnn_init_c", 1, nh);
+    add_lin(h, "prop.rnn_lstm", (nw + (nw + 5) + (nw + 5) + nh) + nh, 4 * nh);
+  } else {
+    add_lin(h, "prop.rnn.h2h", nh, nh);
+    add_lin(h, "prop.rnn.i2h", nw + (nw + 5) + (nw + 5) + nh, nh);
+  }
   add_param(h, "seq.prior_init", 1, nh);
   if (c.prior_lstm) add_param(h, "seq.prior_init_c", 1, nh);
   add_param(h, "seq.temporal_init", 1, nh);
@@ -261,7 +270,15 @@ static void build_plan(SqairHandle* h) {
   simple(L_IENC0, "enc.input.l0", P_, nh);
   simple(L_IENC1, "enc.input.l1", nh, nh);
   // discovery RNN in_to_hidden = [input enc nh | conditioning nh | what nw | where 4 | presence 1] (core.py:164-177)
-  build_layer(h, L_PREDISC, {nh}, {cb1(nh, 0, "disc.rnn.i2h.w", rm_range(0, nh), "disc.rnn.i2h.b", "disc.rnn.h2h.b")});
+  // slot RNN of both cores (flag transition): VanillaRNN -> nh pre-activation columns from in_to_hidden / hidden_to_hidden
+  // (two biases); LSTM -> 4 nh gate columns (i, j, f, o) from the [x | h] rows of w_gates (one bias)
+  const bool RL = c.rnn_lstm != 0;
+  const int rw = RL ? 4 * nh : nh;
+  const int fin_d = nh + nh + nw + 4 + 1, fin_p = nw + (nw + 5) + (nw + 5) + nh;
+  const std::string dW = RL ? "disc.rnn_lstm.w" : "disc.rnn.i2h.w", dU = RL ? "disc.rnn_lstm.w" : "disc.rnn.h2h.w";
+  const std::string pW = RL ? "prop.rnn_lstm.w" : "prop.rnn.i2h.w", pU = RL ? "prop.rnn_lstm.w" : "prop.rnn.h2h.w";
+  const int dU0 = RL ? fin_d : 0, pU0 = RL ? fin_p : 0;  // first recurrent row
+  build_layer(h, L_PREDISC, {nh}, {cb1(rw, 0, dW, rm_range(0, nh), RL ? "disc.rnn_lstm.b" : "disc.rnn.i2h.b", RL ? "" : "disc.rnn.h2h.b")});
   // prior cell on [what, where]_{t-1} (propagate.py:78-81)
   if (c.prior_lstm) {  // gates (i, j, f, o) = [what, where | h] w_gates + b_gates in ONE layer (both inputs exist up front)
     ColBlock b;
@@ -303,11 +320,9 @@ static void build_plan(SqairHandle* h) {
     const int tm1 = nw + (nw + 5);  // rnn input: [loc1 nw | what,where,pres (k-1) | what,where,pres (t-1) | temporal]
     std::vector<ColBlock> bl;
     ColBlock rnn;
-    rnn.ncols = nh; rnn.col0 = 0;
-    rnn.seg = {{"prop.rnn.i2h.w", rm_range(0, nw)},
-               {"prop.rnn.i2h.w", rm_zrec(nw, tm1 + nw, tm1, tm1 + nw + 4)},
-               {"prop.rnn.i2h.w", rm_range(tm1 + nw + 5, nh)}};
-    rnn.bias_a = "prop.rnn.i2h.b"; rnn.bias_b = "prop.rnn.h2h.b";
+    rnn.ncols = rw; rnn.col0 = 0;
+    rnn.seg = {{pW, rm_range(0, nw)}, {pW, rm_zrec(nw, tm1 + nw, tm1, tm1 + nw + 4)}, {pW, rm_range(tm1 + nw + 5, nh)}};
+    rnn.bias_a = RL ? "prop.rnn_lstm.b" : "prop.rnn.i2h.b"; rnn.bias_b = RL ? "" : "prop.rnn.h2h.b";
     bl.push_back(rnn);
     ColBlock t1;  // transform input [hidden nh | where_{t-1} 4 | temporal nh] (core.py:325-326)
     t1.ncols = nh; t1.col0 = 0;
@@ -331,8 +346,8 @@ static void build_plan(SqairHandle* h) {
   }
   {
     ColBlock b;  // explaining-away + recurrent part of the propagation RNN
-    b.ncols = nh; b.col0 = 0;
-    b.seg = {{"prop.rnn.i2h.w", rm_zrec(nw, nw + nw, nw, nw + nw + 4)}, {"prop.rnn.h2h.w", rm_range(0, nh)}};
+    b.ncols = rw; b.col0 = 0;
+    b.seg = {{pW, rm_zrec(nw, nw + nw, nw, nw + nw + 4)}, {pU, rm_range(pU0, nh)}};
     build_layer(h, L_PROP_RNN, {rec::ZW, nh}, {b});
   }
   // transform hidden layer 1 + (extra columns) the r_k rows of the steps predictor's hidden layer: both consume r_k
@@ -377,7 +392,7 @@ static void build_plan(SqairHandle* h) {
   }
   build_layer(h, L_LAT0, {rec::ZW}, {cb1(nh, 0, "seq.latent_enc.l0.w", rm_zrec(nw, nw, 0, -1), "seq.latent_enc.l0.b")});
   simple(L_LAT1, "seq.latent_enc.l1", nh, nh);
-  build_layer(h, L_PRED, {nh}, {cb1(nh, 0, "disc.rnn.i2h.w", rm_range(nh, nh))});
+  build_layer(h, L_PRED, {nh}, {cb1(rw, 0, dW, rm_range(nh, nh))});
   {
     ColBlock b;  // conditioning state of the recurrent where prior: [init_state 4 | cond nh | e 1] (modules.py:573-576)
     b.ncols = 128; b.col0 = 0;
@@ -387,8 +402,8 @@ static void build_plan(SqairHandle* h) {
   }
   {
     ColBlock b;
-    b.ncols = nh; b.col0 = 0;
-    b.seg = {{"disc.rnn.i2h.w", rm_zrec(nw, 2 * nh + nw, 2 * nh, 2 * nh + nw + 4)}, {"disc.rnn.h2h.w", rm_range(0, nh)}};
+    b.ncols = rw; b.col0 = 0;
+    b.seg = {{dW, rm_zrec(nw, 2 * nh + nw, 2 * nh, 2 * nh + nw + 4)}, {dU, rm_range(dU0, nh)}};
     build_layer(h, L_DISC_RNN, {rec::ZW, nh}, {b});
   }
   build_layer(h, L_DISC_T1, {nh},
@@ -537,7 +552,8 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   const int64_t S = train ? 2 * T * N : 1;  // per-slot multiplicity (x R rows)
   w.ienc_a = take((int64_t)T * B * nh);
   w.ienc_b = take((int64_t)T * B * nh);
-  w.pre_disc = take((int64_t)T * B * nh);
+  const int64_t rw = c.rnn_lstm ? 4 * nh : nh;  // slot-RNN pre-activation width (LSTM: the four gates)
+  w.pre_disc = take((int64_t)T * B * rw);
   w.rec_m_all = take((int64_t)(T + 1) * M * rec::W);
   w.temporal_m = take((train ? T + 1 : 2) * M * snh);
   w.prior_m = take((train ? T + 1 : 2) * M * psnh);
@@ -547,8 +563,8 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.rec_d_all = take((int64_t)T * M * rec::W);
   w.zero_rec = take(rec::W);
   w.disc_init_rec = take(rec::W);
-  w.prop_rnn_init = take(nh);
-  w.disc_rnn_init = take(nh);
+  w.prop_rnn_init = take(2 * nh);   // [hidden | cell] with an LSTM slot RNN
+  w.disc_rnn_init = take(2 * nh);
   w.rn_init_state = take(4);
   w.w3_prop = take(nh * 8 + 8);
   w.w3_disc = take(nh * 8 + 8);
@@ -572,8 +588,10 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.lea = take(F * M * nh);
   w.leb = take(F * M * nh);
   w.c = take(F * R * nh);
-  w.pre_d = take(R * nh);
+  w.pre_d = take(R * rw);
   w.r = take((train ? S : 2) * R * nh);
+  w.rc = take(c.rnn_lstm ? (train ? S : 2) * R * nh : 64);       // LSTM slot RNN: cell states, laid out like r
+  w.rgates = take(c.rnn_lstm ? (train ? S : 1) * R * 4 * nh : 64);  // and the kept gate pre-activations
   w.t1 = take(S * R * T1_LD);
   w.t2 = take(S * R * nh);
   w.tp = take(S * R * TP_LD);
@@ -710,6 +728,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   const Workspace w = sq_carve(h, T, B, wsbase, train);
   const int pre_ld = h->layers[L_PRE].nt * 16;
   const int RW = rec::W, snh = d.snh, psnh = d.psnh;
+  const int rw = c.rnn_lstm ? 4 * nh : nh;  // slot-RNN pre-activation width; pre columns: [rnn rw | T1 nh | S1 nh/2 | GRU z, r]
   const PackedLayout pl = packed_layout(h);
 
   // ---- sequence prologue -----------------------------------------------------------------------
@@ -725,7 +744,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
     Lin a; a.seg(obs, P_, P_).out(w.ienc_a, nh).act(ACT_ELU); RUN(a, L_IENC0, T * B);
     Lin b; b.seg(w.ienc_a, nh, nh).out(w.ienc_b, nh).act(ACT_ELU); RUN(b, L_IENC1, T * B);
-    Lin p; p.seg(w.ienc_b, nh, nh).out(w.pre_disc, nh); RUN(p, L_PREDISC, T * B);
+    Lin p; p.seg(w.ienc_b, nh, nh).out(w.pre_disc, rw); RUN(p, L_PREDISC, T * B);
   }
 
   for (int t = 0; (parts & 2) && t < T; ++t) {
@@ -814,12 +833,20 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         Lin a;
         if (k == 0) a.seg(w.zero_rec, 0, rec::ZW).seg(w.prop_rnn_init, 0, nh);
         else a.seg(rec_p_t + (size_t)(k - 1) * RW, N * RW, rec::ZW).seg(w.rslot(t, 0, k - 1), rl, nh);
-        a.add(pre_k, pre_rld, nh).out(r_k, rl).act(ACT_TANH);
-        RUN(a, L_PROP_RNN, R);
+        if (c.rnn_lstm) {
+          float* gates = train ? w.slot(w.rgates, 4 * nh, t, 0, k) : w.rgates;
+          a.add(pre_k, pre_rld, rw).out(gates, w.sld(4 * nh));
+          RUN(a, L_PROP_RNN, R);
+          sq_launch_lstm_cell2(gates, w.sld(4 * nh), k == 0 ? w.prop_rnn_init + nh : w.cslot(t, 0, k - 1), k == 0 ? 0 : rl, r_k, rl,
+                               w.cslot(t, 0, k), rl, R, nh, s);
+        } else {
+          a.add(pre_k, pre_rld, nh).out(r_k, rl).act(ACT_TANH);
+          RUN(a, L_PROP_RNN, R);
+        }
       }
       {
         // T1 columns [transform hidden 1 (ELU) | steps-predictor hidden pre-activation without `what` (linear)]
-        Lin a; a.seg(r_k, rl, nh).add(pre_k + nh, pre_rld, nh + nh / 2).out(t1, t1l).act2(ACT_ELU, ACT_NONE, nh);
+        Lin a; a.seg(r_k, rl, nh).add(pre_k + rw, pre_rld, nh + nh / 2).out(t1, t1l).act2(ACT_ELU, ACT_NONE, nh);
         RUN(a, L_PROP_T1, R);
         Lin b; b.seg(t1, t1l, nh).out(t2, rl).act(ACT_ELU); RUN(b, L_PROP_T2, R);
       }
@@ -847,7 +874,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
       } else {
         const float* tau_k = temporal_prev + (size_t)k * nh;
         Lin g1l; g1l.seg(r_k, rl, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(enc, el, 2 * nw)
-                   .add(pre_k + 2 * nh + nh / 2, pre_rld, 2 * nh).out(gz, rl)
+                   .add(pre_k + rw + nh + nh / 2, pre_rld, 2 * nh).out(gz, rl)
                    .gru1(tau_k, N * nh, w.grh, nh, w.gxh, nh, nh);
         if (train) { g1l.a.o3 = w.slot(w.gr, nh, t, 0, k); g1l.a.o3_ld = rl; }
         RUN(g1l, L_PROP_GRU1, R);
@@ -881,7 +908,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
       Lin a; a.seg(rec_p_t, RW, rec::ZW).out(lea, nh).act(ACT_ELU); RUN(a, L_LAT0, M);
       Lin b; b.seg(lea, nh, nh).out(leb, nh).act(ACT_ELU); RUN(b, L_LAT1, M);
       emit_latsum(h, leb, rec_p_t, cvec, d, s);
-      Lin p; p.seg(cvec, nh, nh).add(w.pre_disc + (size_t)t * B * nh, nh, nh, K).out(w.pre_d, nh); RUN(p, L_PRED, R);
+      Lin p; p.seg(cvec, nh, nh).add(w.pre_disc + (size_t)t * B * rw, rw, rw, K).out(w.pre_d, rw); RUN(p, L_PRED, R);
       if (c.rec_where_prior) {
         Lin q; q.seg(w.rn_init_state, 0, 4).seg(cvec, nh, nh).out(spre_t, 128); RUN(q, L_RNCOND, R);
       }
@@ -900,8 +927,16 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         Lin a;
         if (j == 0) a.seg(w.disc_init_rec, 0, rec::ZW).seg(w.disc_rnn_init, 0, nh);
         else a.seg(rec_d_t + (size_t)(j - 1) * RW, N * RW, rec::ZW).seg(w.rslot(t, 1, j - 1), rl, nh);
-        a.add(w.pre_d, nh, nh).out(r_j, rl).act(ACT_TANH);
-        RUN(a, L_DISC_RNN, R);
+        if (c.rnn_lstm) {
+          float* gates = train ? w.slot(w.rgates, 4 * nh, t, 1, j) : w.rgates;
+          a.add(w.pre_d, rw, rw).out(gates, w.sld(4 * nh));
+          RUN(a, L_DISC_RNN, R);
+          sq_launch_lstm_cell2(gates, w.sld(4 * nh), j == 0 ? w.disc_rnn_init + nh : w.cslot(t, 1, j - 1), j == 0 ? 0 : rl, r_j, rl,
+                               w.cslot(t, 1, j), rl, R, nh, s);
+        } else {
+          a.add(w.pre_d, nh, nh).out(r_j, rl).act(ACT_TANH);
+          RUN(a, L_DISC_RNN, R);
+        }
         Lin b; b.seg(r_j, rl, nh).out(t1, t1l).act2(ACT_ELU, ACT_NONE, nh); RUN(b, L_DISC_T1, R);
         Lin cc; cc.seg(t1, t1l, nh).out(t2, rl).act(ACT_ELU); RUN(cc, L_DISC_T2, R);
       }
@@ -1006,7 +1041,7 @@ extern "C" int sqair_forward_persistent(SqairHandle* h, const float* flat_params
                                         void* stream) {
   if (!h || !out || !program) return -1;
   hipStream_t s = (hipStream_t)stream;
-  if (h->cfg.time_lstm || h->cfg.prior_lstm) {
+  if (h->cfg.time_lstm || h->cfg.prior_lstm || h->cfg.rnn_lstm) {
     sq_set_error(h, "sqair_forward_persistent: the experimental persistent executor covers the GRU cells only");
     return -1;
   }
@@ -1396,7 +1431,8 @@ extern "C" int sqair_lstm_test(SqairHandle* h, const float* x, const float* hsta
 }
 
 int sq_launch_lstm_cell_bwd(const float* gates, int g_ld, const float* c_prev, int c_ld, const float* d_h, int dh_ld, const float* d_c,
-                            int dc_ld, float* d_gates, int dg_ld, float* d_cprev, int dcp_ld, int rows, int nh, hipStream_t s);
+                            int dc_ld, float* d_gates, int dg_ld, float* d_cprev, int dcp_ld, int rows, int nh, hipStream_t s,
+                            float* d_gates2 = nullptr, int dg2_ld = 0);
 // adjoint of the element-wise LSTM cell: gates [M, 4 nh] (pre-activations i, j, f, o), c_prev, d h', d c' -> d gates, d c_prev
 extern "C" int sqair_lstm_cell_bwd_test(SqairHandle* h, const float* gates, const float* c_prev, const float* d_h, const float* d_c,
                                         float* d_gates, float* d_cprev, int M, void* stream) {

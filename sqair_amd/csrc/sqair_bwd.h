@@ -64,7 +64,8 @@ int sq_launch_gru_bwd_b(const float* d_rh, int drh_ld, const float* rg, int r_ld
                         float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh, hipStream_t s, float* dup_r = nullptr,
                         int dup_ld = 0);
 int sq_launch_lstm_cell_bwd(const float* gates, int g_ld, const float* c_prev, int c_ld, const float* d_h, int dh_ld, const float* d_c,
-                            int dc_ld, float* d_gates, int dg_ld, float* d_cprev, int dcp_ld, int rows, int nh, hipStream_t s);
+                            int dc_ld, float* d_gates, int dg_ld, float* d_cprev, int dcp_ld, int rows, int nh, hipStream_t s,
+                            float* d_gates2 = nullptr, int dg2_ld = 0);   // d_c may be null (= 0); c_ld 0 broadcasts
 int sq_launch_dact2(const float* din, int in_ld, const float* saved, int s_ld, float* dout, int out_ld, int rows, int cols,
                     int act_a, int act_b, int split, int acc, hipStream_t s);
 int sq_launch_colsum(const float* dy, int ld, int rows, int cols, float* out, int acc, hipStream_t s);

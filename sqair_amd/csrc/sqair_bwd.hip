@@ -970,7 +970,8 @@ int sq_launch_logprob_bwd(const LogprobBwdArgs& a, POff po, Dims d, int T, hipSt
 __global__ __launch_bounds__(256) void k_lstm_cell_bwd(const float* __restrict__ gates, int g_ld, const float* __restrict__ c_prev,
                                                        int c_ld, const float* __restrict__ d_h, int dh_ld,
                                                        const float* __restrict__ d_c, int dc_ld, float* __restrict__ d_gates,
-                                                       int dg_ld, float* __restrict__ d_cprev, int dcp_ld, int rows, int nh) {
+                                                       int dg_ld, float* __restrict__ d_cprev, int dcp_ld, int rows, int nh,
+                                                       float* __restrict__ d_gates2, int dg2_ld) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= rows * nh) return;
   const int r = e / nh, q = e - r * nh;
@@ -979,18 +980,22 @@ __global__ __launch_bounds__(256) void k_lstm_cell_bwd(const float* __restrict__
   const float cp = c_prev[(size_t)r * c_ld + q];
   const float tc = tanhf(sf * cp + si * tj);
   const float dh = d_h[(size_t)r * dh_ld + q];
-  const float dc = d_c[(size_t)r * dc_ld + q] + dh * so * (1.0f - tc * tc);
+  const float dc = (d_c != nullptr ? d_c[(size_t)r * dc_ld + q] : 0.0f) + dh * so * (1.0f - tc * tc);
+  const float gi = dc * tj * si * (1.0f - si), gj = dc * si * (1.0f - tj * tj), gf = dc * cp * sf * (1.0f - sf);
+  const float go = dh * tc * so * (1.0f - so);
   float* dg = d_gates + (size_t)r * dg_ld;
-  dg[q] = dc * tj * si * (1.0f - si);
-  dg[nh + q] = dc * si * (1.0f - tj * tj);
-  dg[2 * nh + q] = dc * cp * sf * (1.0f - sf);
-  dg[3 * nh + q] = dh * tc * so * (1.0f - so);
+  dg[q] = gi; dg[nh + q] = gj; dg[2 * nh + q] = gf; dg[3 * nh + q] = go;
+  if (d_gates2 != nullptr) {  // second copy (the slot's block of the loop-invariant pre-activation gradient)
+    float* dg2 = d_gates2 + (size_t)r * dg2_ld;
+    dg2[q] = gi; dg2[nh + q] = gj; dg2[2 * nh + q] = gf; dg2[3 * nh + q] = go;
+  }
   d_cprev[(size_t)r * dcp_ld + q] = dc * sf;
 }
 int sq_launch_lstm_cell_bwd(const float* gates, int g_ld, const float* c_prev, int c_ld, const float* d_h, int dh_ld, const float* d_c,
-                            int dc_ld, float* d_gates, int dg_ld, float* d_cprev, int dcp_ld, int rows, int nh, hipStream_t s) {
+                            int dc_ld, float* d_gates, int dg_ld, float* d_cprev, int dcp_ld, int rows, int nh, hipStream_t s,
+                            float* d_gates2, int dg2_ld) {
   hipLaunchKernelGGL(k_lstm_cell_bwd, dim3((rows * nh + 255) / 256), dim3(256), 0, s, gates, g_ld, c_prev, c_ld, d_h, dh_ld, d_c, dc_ld,
-                     d_gates, dg_ld, d_cprev, dcp_ld, rows, nh);
+                     d_gates, dg_ld, d_cprev, dcp_ld, rows, nh, d_gates2, dg2_ld);
   return 0;
 }
 

@@ -22,12 +22,13 @@ struct Dims {
   int snh;                          // width of the temporal state of a slot: nh (GRU) or 2 nh = [hidden | cell] (LSTM)
   int toff;                         // offset of the features the model reads from it: 0 (GRU state) / nh (LSTM cell, core.py:284)
   int psnh;                         // width of the propagation prior's recurrent state: nh (GRU) or 2 nh (LSTM)
+  int rsnh;                         // width of the slot RNN's trainable initial state: nh (VanillaRNN) or 2 nh (LSTM)
 };
 inline Dims make_dims(const SqairConfig& c, int B) {
   const int lstm = c.time_lstm != 0;
   return Dims{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles, B * c.k_particles, B,
               4 + c.n_what + 1, lstm ? 2 * c.n_hidden : c.n_hidden, lstm ? c.n_hidden : 0,
-              c.prior_lstm ? 2 * c.n_hidden : c.n_hidden};
+              c.prior_lstm ? 2 * c.n_hidden : c.n_hidden, c.rnn_lstm ? 2 * c.n_hidden : c.n_hidden};
 }
 
 enum CropMode { CROP_PLAIN = 0, CROP_PROP1 = 1, CROP_PROP2 = 2, CROP_DISC = 3 };
@@ -56,6 +57,8 @@ struct CropArgs {
   int tp_out_ld;
 };
 
+int sq_launch_lstm_cell2(const float* gates, int g_ld, const float* c_prev, int c_ld, float* h_out, int h_ld, float* c_out, int co_ld,
+                         int rows, int nh, hipStream_t s);
 int sq_launch_lstm_cell(const float* gates, int g_ld, const float* c_prev, int c_ld, float* state_out, int o_ld, int rows, int nh,
                         hipStream_t s);
 int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float* last_id, float* disc_init_rec,

@@ -22,7 +22,7 @@ __global__ void k_init_state(float* __restrict__ rec_m, float* __restrict__ temp
   if (tid == 0 && (rs % d.N) == 0) last_id[rs / d.N] = -1.0f;
   if (rs == 0) {  // aligned copies of the small trainable initial states (GEMM A-operand contract)
     if (tid == 0) disc_init_rec[rec::PRES] = 1.0f;
-    for (int i = tid; i < d.nh; i += blockDim.x) {
+    for (int i = tid; i < d.rsnh; i += blockDim.x) {  // LSTM: [hidden | cell] initial rows are adjacent in the flat buffer
       prop_rnn_init[i] = flat[po.prop_rnn_init + i];
       disc_rnn_init[i] = flat[po.disc_rnn_init + i];
     }
@@ -42,20 +42,27 @@ __global__ void k_init_state(float* __restrict__ rec_m, float* __restrict__ temp
 // `gates` holds the finished pre-activations of one slot, [rows][4 nh]; the new state goes to [h' | c'].
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lstm_cell(const float* __restrict__ gates, int g_ld, const float* __restrict__ c_prev,
-                                                   int c_ld, float* __restrict__ state_out, int o_ld, int rows, int nh) {
+                                                   int c_ld, float* __restrict__ h_out, int h_ld, float* __restrict__ c_out,
+                                                   int co_ld, int rows, int nh) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= rows * nh) return;
   const int r = e / nh, q = e - r * nh;
   const float* g = gates + (size_t)r * g_ld;
   const float gi = g[q], gj = g[nh + q], gf = g[2 * nh + q], go = g[3 * nh + q];
   const float c = sq_sigmoid(gf + 1.0f) * c_prev[(size_t)r * c_ld + q] + sq_sigmoid(gi) * tanhf(gj);
-  state_out[(size_t)r * o_ld + q] = tanhf(c) * sq_sigmoid(go);
-  state_out[(size_t)r * o_ld + nh + q] = c;
+  h_out[(size_t)r * h_ld + q] = tanhf(c) * sq_sigmoid(go);
+  c_out[(size_t)r * co_ld + q] = c;
+}
+// c_ld = 0 broadcasts one initial cell row; hidden and cell may live in different buffers (slot RNN) or side by side
+int sq_launch_lstm_cell2(const float* gates, int g_ld, const float* c_prev, int c_ld, float* h_out, int h_ld, float* c_out, int co_ld,
+                         int rows, int nh, hipStream_t s) {
+  hipLaunchKernelGGL(k_lstm_cell, dim3((rows * nh + 255) / 256), dim3(256), 0, s, gates, g_ld, c_prev, c_ld, h_out, h_ld, c_out, co_ld,
+                     rows, nh);
+  return 0;
 }
 int sq_launch_lstm_cell(const float* gates, int g_ld, const float* c_prev, int c_ld, float* state_out, int o_ld, int rows, int nh,
                         hipStream_t s) {
-  hipLaunchKernelGGL(k_lstm_cell, dim3((rows * nh + 255) / 256), dim3(256), 0, s, gates, g_ld, c_prev, c_ld, state_out, o_ld, rows, nh);
-  return 0;
+  return sq_launch_lstm_cell2(gates, g_ld, c_prev, c_ld, state_out, o_ld, state_out + nh, o_ld, rows, nh, s);
 }
 
 int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float* last_id, float* disc_init_rec,

@@ -134,6 +134,7 @@ struct Workspace {
   float *pstats, *spre;                          // always [T]
   float *hid1, *wb, *mask, *g1, *pea, *peb, *m1, *pre, *lea, *leb, *c, *pre_d;  // per frame
   float *r, *t1, *t2, *tp, *g2, *e1, *e2, *enc, *hraw, *s1h, *gz, *gr, *ghc, *grh, *gxh;  // per slot
+  float *rc, *rgates;                            // LSTM slot RNN (rnn_lstm): cell states (like r), kept gates [.][4nh]
   float *lpre, *lgates;                          // LSTM temporal cell (time_lstm): [M][4nh], kept gates [T][R][N][4nh]
   int* src;                                      // train: compaction source slot [T][R][N]
   float *qz, *pz, *dlp, *dll, *glimpse, *dec_a, *dec_b;
@@ -148,6 +149,7 @@ struct Workspace {
     return base + (train ? (((size_t)(ph * T + t) * R * N) + k) * W : 0);  // [phase][T][B'][N][W]
   }
   int sld(int W) const { return train ? N * W : W; }
+  float* cslot(int t, int ph, int k) const { return train ? slot(rc, nh, t, ph, k) : rc + (size_t)(k & 1) * R * nh; }
   float* rslot(int t, int ph, int k) const {  // RNN hidden state: ping-pong over slots when no tape is kept
     return train ? slot(r, nh, t, ph, k) : r + (size_t)(k & 1) * R * nh;
   }

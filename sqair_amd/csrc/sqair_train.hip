@@ -94,6 +94,7 @@ struct BwdSpace {
   float *d_rnn, *d_t1, *d_t2, *d_tp, *d_e1, *d_e2, *d_enc3, *d_gru1, *d_hraw;
   // scratch
   float *d_mask, *d_g, *d_g1, *d_c, *tmp, *d_r[2], *dhn, *d_rh, *d_enc;
+  float *d_cs[2], *d_hk;                        // LSTM slot RNN: d cell state of the neighbouring slot, d hidden of this one
   float *d_gl, *d_mean_rows, *bufa, *bufb, *d_ia, *d_ib, *zs, *rs, *rh;
   int64_t total;
 };
@@ -115,20 +116,22 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   b.d_rec_m = take((T + 1) * M * rec::W); b.d_rec_p = take(MT * rec::W); b.d_rec_d = take(MT * rec::W);
   const int64_t snh = c.time_lstm ? 2 * nh : nh, gw = c.time_lstm ? 4 * nh : 3 * nh;  // temporal state / gate widths
   const int64_t psnh = c.prior_lstm ? 2 * nh : nh, pgw = c.prior_lstm ? 4 * nh : 3 * nh;
+  const int64_t rw = c.rnn_lstm ? 4 * nh : nh;  // slot-RNN pre-activation width
   for (int i = 0; i < 2; ++i) { b.d_tm[i] = take(M * snh); b.d_pm[i] = take(M * psnh); }
   b.d_temporal_p = take(M * snh); b.d_prior_p = take(M * psnh);
   b.d_pstats = take(MT * PS_LD); b.d_spre = take(T * R * 128); b.d_raw = take(2 * MT);
   b.d_pgru1 = take(MT * pgw); b.d_hid1 = take(MT * 256); b.d_wb = take(MT * WB_LD); b.d_maskpre = take(MT * G2);
   b.d_pea = take(MT * nh); b.d_peb = take(MT * nh); b.d_m1 = take(MT * M1_LD); b.d_pre = take(MT * pre_ld);
-  b.d_lea = take(MT * nh); b.d_leb = take(MT * nh); b.d_pre_d = take(T * R * nh); b.d_pre_disc = take((int64_t)T * B * nh);
+  b.d_lea = take(MT * nh); b.d_leb = take(MT * nh); b.d_pre_d = take(T * R * rw); b.d_pre_disc = take((int64_t)T * B * rw);
   const int64_t S = 2 * MT;
-  b.d_rnn = take(S * nh); b.d_t1 = take(S * T1_LD); b.d_t2 = take(S * nh); b.d_tp = take(S * TP_LD);
+  b.d_rnn = take(S * rw); b.d_t1 = take(S * T1_LD); b.d_t2 = take(S * nh); b.d_tp = take(S * TP_LD);
   b.d_e1 = take(S * nh); b.d_e2 = take(S * nh); b.d_enc3 = take(S * ENC_LD); b.d_gru1 = take(MT * gw);
   b.d_hraw = take(MT * HRAW_LD);
   b.d_mask = take(M * G2); b.d_g = take(R * G2); b.d_g1 = take(M * G2); b.d_c = take(R * nh);
   b.tmp = take(M * 512);
   b.d_r[0] = take(R * nh); b.d_r[1] = take(R * nh); b.dhn = take(M * nh); b.d_rh = take(M * nh);
   b.d_enc = take(R * ENC_LD);
+  b.d_cs[0] = take(R * nh); b.d_cs[1] = take(R * nh); b.d_hk = take(R * nh);
   const int64_t big = MT * (nh > G2 ? nh : G2);
   b.d_gl = take(MT * G2); b.d_mean_rows = take(T * R * P_); b.bufa = take(big); b.bufb = take(big);
   b.d_ia = take((int64_t)T * B * nh); b.d_ib = take((int64_t)T * B * nh);
@@ -162,6 +165,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   const int nzw = 4 + nw + 1, RW = rec::W, nsp = nh / 2;
   Dims d = make_dims(c, B);
   const int snh = d.snh, gw = c.time_lstm ? 4 * nh : 3 * nh, psnh = d.psnh, pgw = c.prior_lstm ? 4 * nh : 3 * nh;
+  const int rw = c.rnn_lstm ? 4 * nh : nh;  // slot-RNN pre-activation width; d_pre columns [rnn rw | T1 nh | S1 nsp | GRU z, r]
   const POff po = h->po;
   const Workspace w = sq_carve(h, T, B, (float*)train_workspace, true);
   const BwdSpace b = carve_bwd(h, T, B, (float*)scratch);
@@ -288,7 +292,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       sq_zero_fill(d_pprev, (int64_t)M * psnh, s);
     }
     // ---- G^T. discovery steps
-    float* d_pre_d = b.d_pre_d + (size_t)t * R * nh;
+    float* d_pre_d = b.d_pre_d + (size_t)t * R * rw;
     for (int j = N - 1; j >= 0; --j) {
       float* d_t1 = slotp(b.d_t1, T1_LD, t, 1, j);
       float* d_t2 = slotp(b.d_t2, nh, t, 1, j);
@@ -296,7 +300,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       float* d_e1 = slotp(b.d_e1, nh, t, 1, j);
       float* d_e2 = slotp(b.d_e2, nh, t, 1, j);
       float* d_enc3 = slotp(b.d_enc3, ENC_LD, t, 1, j);
-      float* d_rnn = slotp(b.d_rnn, nh, t, 1, j);
+      float* d_rnn = slotp(b.d_rnn, rw, t, 1, j);
+      const int drl = N * rw;
       const float* r_j = cslotp(w.r, nh, t, 1, j);
       const float* t1 = cslotp(w.t1, T1_LD, t, 1, j);
       const float* t2 = cslotp(w.t2, nh, t, 1, j);
@@ -324,25 +329,32 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       }
       { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_DISC_T3, x, R)); }
       { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU); CK(rundx(L_DISC_T2, x, R)); }
-      {  // d r_j = T1^T (incl. the steps-predictor columns) + what the next slot's RNN sent back; tanh' -> d pre-activation
+      if (c.rnn_lstm) {  // d h_j = T1^T + the next slot's RNN; cell adjoint -> gate pre-activation gradients, d c_{j-1}
+        Dx x(d_t1, t1l); x.to(0, nh, b.d_hk, nh);
+        if (j < N - 1) x.add(b.d_r[j & 1], nh);
+        CK(rundx(L_DISC_T1, x, R));
+        sq_launch_lstm_cell_bwd(cslotp(w.rgates, 4 * nh, t, 1, j), N * 4 * nh, j == 0 ? w.disc_rnn_init + nh : cslotp(w.rc, nh, t, 1, j - 1),
+                                j == 0 ? 0 : rl, b.d_hk, nh, j < N - 1 ? b.d_cs[j & 1] : nullptr, nh, d_rnn, drl, b.d_cs[(j + 1) & 1], nh, R, nh, s);
+      } else {  // d r_j = T1^T (incl. the steps-predictor columns) + what the next slot's RNN sent back; tanh' -> d pre-activation
         Dx x(d_t1, t1l); x.to(0, nh, d_rnn, rl);
         if (j < N - 1) x.add(b.d_r[j & 1], nh);
         x.dact(r_j, rl, ACT_TANH);
         CK(rundx(L_DISC_T1, x, R));
       }
       if (j > 0) {
-        Dx x(d_rnn, rl);
+        Dx x(d_rnn, drl);
         x.to(0, rec::ZW, d_rec_d_t + (size_t)(j - 1) * RW, N * RW).acc();
         x.to(64, 64 + nh, b.d_r[(j - 1) & 1], nh);
         CK(rundx(L_DISC_RNN, x, R));
       } else {
-        Dx x(d_rnn, rl); x.to(64, 64 + nh, b.tmp, nh); CK(rundx(L_DISC_RNN, x, R));
+        Dx x(d_rnn, drl); x.to(64, 64 + nh, b.tmp, nh); CK(rundx(L_DISC_RNN, x, R));
         sq_launch_colsum(b.tmp, nh, R, nh, flat_grad + po.disc_rnn_init, 1, s);
+        if (c.rnn_lstm) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.disc_rnn_init + nh, 1, s);
       }
     }
     // ---- F^T. conditioning of discovery on the propagated latents
-    sq_launch_sum_slots(b.d_rnn + (size_t)(T + t) * M * nh, d_pre_d, b.d_pre_disc + (size_t)t * B * nh, B, K, N, nh, s);
-    { Dx x(d_pre_d, nh); x.to(0, nh, b.d_c, nh); CK(rundx(L_PRED, x, R)); }
+    sq_launch_sum_slots(b.d_rnn + (size_t)(T + t) * M * rw, d_pre_d, b.d_pre_disc + (size_t)t * B * rw, B, K, N, rw, s);
+    { Dx x(d_pre_d, rw); x.to(0, nh, b.d_c, nh); CK(rundx(L_PRED, x, R)); }
     if (c.rec_where_prior) {
       Dx x(b.d_spre + (size_t)t * R * 128, 128);
       x.to(0, 4, b.tmp, 4);
@@ -370,7 +382,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       float* d_e1 = slotp(b.d_e1, nh, t, 0, k);
       float* d_e2 = slotp(b.d_e2, nh, t, 0, k);
       float* d_enc3 = slotp(b.d_enc3, ENC_LD, t, 0, k);
-      float* d_rnn = slotp(b.d_rnn, nh, t, 0, k);
+      float* d_rnn = slotp(b.d_rnn, rw, t, 0, k);
+      const int drl = N * rw;
       float* d_gru1 = b.d_gru1 + ((size_t)t * M + k) * gw;   // [T][R][N][3nh (GRU) | 4nh (LSTM)], row stride N*gw
       float* d_hraw = b.d_hraw + ((size_t)t * M + k) * HRAW_LD;
       const int g1l = N * gw;
@@ -389,7 +402,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         ta.is_disc = 0; ta.slot = k; ta.rec_prev = rec_prev; ta.rec_new = rec_p_t; ta.d_rec_new = d_rec_p_t;
         ta.d_rec_prev = d_rec_prev; ta.s1h = cslotp(w.s1h, S1_LD, t, 0, k); ta.s1h_ld = s1l;
         ta.hraw = cslotp(w.hraw, HRAW_LD, t, 0, k); ta.h_ld = hl; ta.enc = enc; ta.enc_ld = el; ta.noise = nz;
-        ta.d_s1pre = d_t1 + nh; ta.ds_ld = t1l; ta.d_s1pre2 = d_pre_k + 2 * nh; ta.ds2_ld = pre_rld;
+        ta.d_s1pre = d_t1 + nh; ta.ds_ld = t1l; ta.d_s1pre2 = d_pre_k + rw + nh; ta.ds2_ld = pre_rld;
         ta.d_enc = b.d_enc; ta.de_ld = ENC_LD; ta.d_hraw = d_hraw; ta.dh_ld = hl; ta.d_raw_out = slotp(b.d_raw, 1, t, 0, k); ta.dr_ld = N;
         ta.flat = flat; ta.flat_grad = flat_grad; ta.w2_off = po.prop_steps_l1_w; ta.b2_off = po.prop_steps_l1_b;
         ta.wwhat_off = (int)P(h, "prop.steps.l0.w") + 2 * nh * nsp;
@@ -404,10 +417,10 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
                                 b.d_temporal_p + (size_t)k * snh + nh, N * snh, d_gru1, g1l, d_tau_k + nh, N * snh, R, nh, s);
       } else {
         sq_launch_gru_bwd_a(b.dhn, nh, cslotp(w.gz, nh, t, 0, k), rl, cslotp(w.ghc, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l,
-                            d_tau_k, N * nh, R, nh, 1, s, d_pre_k + 2 * nh + nsp, pre_rld);
+                            d_tau_k, N * nh, R, nh, 1, s, d_pre_k + rw + nh + nsp, pre_rld);
         { Dx x(d_gru1 + 2 * nh, g1l); x.to(0, nh, b.d_rh, nh); CK(rundx(L_PROP_GRU2, x, R)); }
         sq_launch_gru_bwd_b(b.d_rh, nh, cslotp(w.gr, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l, d_tau_k, N * nh,
-                            R, nh, s, d_pre_k + 3 * nh + nsp, pre_rld);
+                            R, nh, s, d_pre_k + rw + 2 * nh + nsp, pre_rld);
       }
       {  // gate GEMM inputs [r_k nh | where 4 (pad 16) | glimpse-encoder (loc, scale) 2 nw]
         Dx x(d_gru1, g1l);
@@ -429,20 +442,28 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         sq_launch_crop_chain_bwd(ca, po, d, 1, s);
       }
       { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_PROP_T3, x, R)); }
-      { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU).dup(d_pre_k + nh, pre_rld); CK(rundx(L_PROP_T2, x, R)); }
-      {  // d r_k total = T1^T + (gate GEMM + next slot's RNN, accumulated in d_r[k & 1]); tanh' -> RNN pre-activation
+      { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU).dup(d_pre_k + rw, pre_rld); CK(rundx(L_PROP_T2, x, R)); }
+      if (c.rnn_lstm) {  // d h_k total, then the cell adjoint (second copy: this slot's block of d_pre)
+        Dx x(d_t1, t1l);
+        x.to(0, nh, b.d_hk, nh).add(b.d_r[k & 1], nh);
+        CK(rundx(L_PROP_T1, x, R));
+        sq_launch_lstm_cell_bwd(cslotp(w.rgates, 4 * nh, t, 0, k), N * 4 * nh, k == 0 ? w.prop_rnn_init + nh : cslotp(w.rc, nh, t, 0, k - 1),
+                                k == 0 ? 0 : rl, b.d_hk, nh, k < N - 1 ? b.d_cs[k & 1] : nullptr, nh, d_rnn, drl, b.d_cs[(k + 1) & 1], nh, R, nh, s,
+                                d_pre_k, pre_rld);
+      } else {  // d r_k total = T1^T + (gate GEMM + next slot's RNN, accumulated in d_r[k & 1]); tanh' -> RNN pre-activation
         Dx x(d_t1, t1l);
         x.to(0, nh, d_rnn, rl).add(b.d_r[k & 1], nh).dact(r_k, rl, ACT_TANH).dup(d_pre_k, pre_rld);
         CK(rundx(L_PROP_T1, x, R));
       }
       if (k > 0) {
-        Dx x(d_rnn, rl);
+        Dx x(d_rnn, drl);
         x.to(0, rec::ZW, d_rec_p_t + (size_t)(k - 1) * RW, N * RW).acc();
         x.to(64, 64 + nh, b.d_r[(k - 1) & 1], nh);
         CK(rundx(L_PROP_RNN, x, R));
       } else {
-        Dx x(d_rnn, rl); x.to(64, 64 + nh, b.tmp, nh); CK(rundx(L_PROP_RNN, x, R));
+        Dx x(d_rnn, drl); x.to(64, 64 + nh, b.tmp, nh); CK(rundx(L_PROP_RNN, x, R));
         sq_launch_colsum(b.tmp, nh, R, nh, flat_grad + po.prop_rnn_init, 1, s);
+        if (c.rnn_lstm) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.prop_rnn_init + nh, 1, s);
       }
     }
     // ---- D^T. the loop-invariant pre-activation GEMM: segments [m1 nw (pad 64) | z_{t-1} record 56 (pad 64) | temporal nh]
@@ -512,11 +533,11 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   sq_launch_colsum(b.d_pm[0], psnh, M, psnh, flat_grad + po.prior_init, 1, s);
   {
     const int TB = T * B;
-    CK(dx(L_PREDISC, b.d_pre_disc, nh, TB, b.tmp, nh, false));
+    CK(dx(L_PREDISC, b.d_pre_disc, rw, TB, b.tmp, nh, false));
     sq_launch_dact2(b.tmp, nh, w.ienc_b, nh, b.d_ib, nh, TB, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
     CK(dx(L_IENC1, b.d_ib, nh, TB, b.tmp, nh, false));
     sq_launch_dact2(b.tmp, nh, w.ienc_a, nh, b.d_ia, nh, TB, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-    wgrad(L_PREDISC, {{w.ienc_b, nh}}, b.d_pre_disc, nh, TB);
+    wgrad(L_PREDISC, {{w.ienc_b, nh}}, b.d_pre_disc, rw, TB);
     wgrad(L_IENC1, {{w.ienc_a, nh}}, b.d_ib, nh, TB);
     wgrad(L_IENC0, {{obs, P_}}, b.d_ia, nh, TB);
   }
@@ -547,7 +568,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     wgrad(L_PRE, {{w.m1, M1_LD}, {w.rec_m_all, RW}, {tau_all, snh}}, b.d_pre, pre_ld, MT);
     // propagation slot chain (phase 0 of the tapes)
     hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_p_all, w.r, w.zero_rec, w.prop_rnn_init, b.zs, b.rs, MT, N, nh);
-    wgrad(L_PROP_RNN, {{b.zs, 64}, {b.rs, nh}}, b.d_rnn, nh, MT);
+    wgrad(L_PROP_RNN, {{b.zs, 64}, {b.rs, nh}}, b.d_rnn, rw, MT);
     wgrad(L_PROP_T1, {{w.r, nh}}, b.d_t1, T1_LD, MT);
     wgrad(L_PROP_T2, {{w.t1, T1_LD}}, b.d_t2, nh, MT);
     wgrad(L_PROP_T3, {{w.t2, nh}}, b.d_tp, TP_LD, MT);
@@ -563,13 +584,13 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     // latent summary, discovery conditioning
     wgrad(L_LAT0, {{w.rec_p_all, RW}}, b.d_lea, nh, MT);
     wgrad(L_LAT1, {{w.lea, nh}}, b.d_leb, nh, MT);
-    wgrad(L_PRED, {{w.c, nh}}, b.d_pre_d, nh, T * R);
+    wgrad(L_PRED, {{w.c, nh}}, b.d_pre_d, rw, T * R);
     if (c.rec_where_prior) wgrad(L_RNCOND, {{w.rn_init_state, 0}, {w.c, nh}}, b.d_spre, 128, T * R);
     // discovery slot chain (phase 1 of the tapes)
     const size_t ph1 = (size_t)MT;
     hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_d_all, w.r + ph1 * nh, w.disc_init_rec, w.disc_rnn_init, b.zs,
                        b.rs, MT, N, nh);
-    wgrad(L_DISC_RNN, {{b.zs, 64}, {b.rs, nh}}, b.d_rnn + ph1 * nh, nh, MT);
+    wgrad(L_DISC_RNN, {{b.zs, 64}, {b.rs, nh}}, b.d_rnn + ph1 * rw, rw, MT);
     wgrad(L_DISC_T1, {{w.r + ph1 * nh, nh}}, b.d_t1 + ph1 * T1_LD, T1_LD, MT);
     wgrad(L_DISC_T2, {{w.t1 + ph1 * T1_LD, T1_LD}}, b.d_t2 + ph1 * nh, nh, MT);
     wgrad(L_DISC_T3, {{w.t2 + ph1 * nh, nh}}, b.d_tp + ph1 * TP_LD, TP_LD, MT);

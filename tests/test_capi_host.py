@@ -30,10 +30,12 @@ def test_library_loads_and_exports_header_symbols(repo_root):
 
 
 @pytest.mark.parametrize("N,hw,cell", [(3, (50, 50), "GRU"), (4, (50, 50), "GRU"), (6, (50, 50), "GRU"), (4, (128, 128), "GRU"),
-                                       (3, (50, 50), "LSTM"), (3, (50, 50), "GRU/LSTM"), (4, (50, 50), "LSTM/LSTM")])
+                                       (3, (50, 50), "LSTM"), (3, (50, 50), "GRU/LSTM"), (4, (50, 50), "LSTM/LSTM"),
+                                       (3, (50, 50), "GRU/GRU/LSTM"), (4, (50, 50), "LSTM/LSTM/LSTM")])
 def test_param_table_matches_python_spec(N, hw, cell):
     lib = _capi.lib()
-    F = make_flags(n_steps_per_image=N, time_transition=cell.split("/")[0], prior_transition=cell.split("/")[-1] if "/" in cell else "GRU")
+    cs = cell.split("/") + ["GRU", "VanillaRNN"][len(cell.split("/")) - 1:]
+    F = make_flags(n_steps_per_image=N, time_transition=cs[0], prior_transition=cs[1], transition=cs[2])
     cfg = make_config(F, hw)
     h = C.c_void_p()
     assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0

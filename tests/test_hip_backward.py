@@ -439,10 +439,12 @@ def test_checkpoint_round_trip_restores_parameters_and_optimiser_slots(tmp_path)
     dict(time_transition="LSTM"),
     dict(prior_transition="LSTM"),
     dict(time_transition="LSTM", prior_transition="LSTM", prop_prior_type="guided"),
+    dict(transition="LSTM"),
+    dict(transition="LSTM", time_transition="LSTM", prior_transition="LSTM"),
 ])
 def test_full_backward_flag_variants(flags):
     """The adjoint branches the default flags never take: random-walk / guided propagation priors (the prior statistics
-    feed back into z_{t-1}), geometric step prior, fixed where prior, unmasked glimpses, the LSTM temporal / prior cells."""
+    feed back into z_{t-1}), geometric step prior, fixed where prior, unmasked glimpses, the LSTM temporal / prior / slot-RNN cells."""
     report, ref, _ = _full_backward_case(K=3, N=3, T=3, B=3, hw=(50, 50), seed=11, flags=flags)
     assert float(ref.prop_pres.detach().sum()) > 0
     _check_report(report)

@@ -86,6 +86,15 @@ def test_forward_flag_variants_vs_live_oracle(prior, disc_prior, rec):
     _live_oracle_case(F)
 
 
+@pytest.mark.parametrize("cells", [("GRU", "GRU"), ("LSTM", "LSTM")])
+def test_forward_lstm_slot_rnn_vs_live_oracle(cells):
+    """transition=LSTM (configs/mlp_mnist_model.py:86): the slot RNN of the discovery and the propagation core carries
+    (hidden, cell) from slot to slot (core.py:187-189, :304-305); every consumer reads the hidden output."""
+    F = make_flags(k_particles=3, n_steps_per_image=4, transition="LSTM", time_transition=cells[0], prior_transition=cells[1])
+    m, ref = _live_oracle_case(F, T=4, B=3)
+    assert float(ref.prop_pres.sum()) > 0 and float(ref.disc_pres.sum()) > 0
+
+
 @pytest.mark.parametrize("cells", [("GRU", "LSTM"), ("LSTM", "LSTM")])
 def test_forward_lstm_prior_cell_vs_live_oracle(cells):
     """prior_transition=LSTM (configs/mlp_mnist_model.py:125): the propagation prior's recurrent state is [hidden | cell],
