@@ -119,6 +119,9 @@ def main():
                          "not BASELINE's metric)")
     ap.add_argument("--time-transition", default="GRU", choices=["GRU", "LSTM"],
                     help="propagation temporal cell (the shipped config and BASELINE's metric use GRU)")
+    ap.add_argument("--prior-transition", default="GRU", choices=["GRU", "LSTM"], help="propagation prior cell (shipped: GRU)")
+    ap.add_argument("--transition", default="VanillaRNN", choices=["VanillaRNN", "GRU", "LSTM"],
+                    help="slot RNN of both cores (shipped: VanillaRNN)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,7 +156,7 @@ def main():
         d = make_sequences(obs.shape[1], T=obs.shape[0], canvas=obs.shape[2:], n_objects=(0, nums.shape[-1] - 1),
                            obj_size=28 if obs.shape[2] <= 64 else 72, seed=1234 + args.cfg + 1000 * rank)
         obs, nums = to_float(d["imgs"]), d["nums"]
-    ov["time_transition"] = args.time_transition
+    ov.update(time_transition=args.time_transition, prior_transition=args.prior_transition, transition=args.transition)
     F = make_flags(**ov)
     hw = tuple(int(v) for v in obs.shape[2:])
     T, B = int(obs.shape[0]), int(obs.shape[1])
@@ -264,6 +267,10 @@ def main():
                                      2.0 * K * {1: 10166288, 4: 20298656, 5: 27760960}[args.cfg])
     if args.time_transition == "LSTM":  # a 4th gate over the same [x 360 | h 256] -> 256 input: + (360 + 256) * 256 MACs / slot
         algo_flops_step += float(B * T) * 2.0 * K * N * (nh_in + 256) * 256
+    if args.prior_transition == "LSTM":  # likewise over [what, where 54 | h 256]
+        algo_flops_step += float(B * T) * 2.0 * K * N * (int(F.n_what) + 4 + 256) * 256
+    gates = {"VanillaRNN": 1, "GRU": 3, "LSTM": 4}[args.transition] - 1   # extra gate blocks of the two slot RNNs
+    algo_flops_step += float(B * T) * 2.0 * K * N * gates * ((416 + 256) + (256 + 256 + int(F.n_what) + 5 + 256)) * 256
     achieved = algo_flops_step / (lin_ms * 1e-3) / 1e12
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -308,8 +315,8 @@ def main():
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cfg{}: T={} HxW={}x{} B={}/GPU K={} N={} temporal cell {} forward (elbo_iwae), HIP-graph replay={}".format(
-            args.cfg, T, hw[0], hw[1], B, K, N, args.time_transition, use_graph), "global_batch": B * world, "seq_len": T,
+        "config": {"workload": "cfg{}: T={} HxW={}x{} B={}/GPU K={} N={} cells {}/{}/{} forward (elbo_iwae), HIP-graph replay={}".format(
+            args.cfg, T, hw[0], hw[1], B, K, N, args.transition, args.time_transition, args.prior_transition, use_graph), "global_batch": B * world, "seq_len": T,
             "parallelism": "dp{}".format(world), "graph_nodes": core.graph_nodes()},
         "elbo_iwae_nats_per_seq": elbo, "elbo_vae_nats_per_seq": elbo_vae,
         "roofline": roofline, "cpu_baseline": cpu, "train": train,

@@ -56,7 +56,7 @@ typedef struct SqairConfig {
   int32_t generate_after;        /* SequentialAIR(generate_after=..) (seq.py:46, :198-200); <= 0: never generate     */
   int32_t time_lstm;             /* flag time_transition: 0 = GRU (shipped), 1 = LSTM (common_model_flags.py:49)    */
   int32_t prior_lstm;            /* flag prior_transition: 0 = GRU (shipped), 1 = LSTM (mlp_mnist_model.py:125)     */
-  int32_t rnn_lstm;              /* flag transition (slot RNN of both cores): 0 = VanillaRNN (shipped), 1 = LSTM    */
+  int32_t rnn_cell;              /* flag transition (slot RNN of both cores): 0 = VanillaRNN (shipped), 1 = LSTM, 2 = GRU */
 } SqairConfig;
 
 typedef struct SqairHandle SqairHandle;

@@ -316,8 +316,8 @@ class SqairOracle(object):
     def __init__(self, params, cfg, dtype=torch.float64, requires_grad=False):
         self.cfg = cfg
         self.dtype = dtype
-        if cfg.transition not in ("VanillaRNN", "LSTM") or cfg.time_transition not in ("GRU", "LSTM") or cfg.prior_transition not in ("GRU", "LSTM"):
-            raise NotImplementedError("oracle restates transition in {VanillaRNN, LSTM}, time_transition / prior_transition in {GRU, LSTM}")
+        if cfg.transition not in ("VanillaRNN", "GRU", "LSTM") or cfg.time_transition not in ("GRU", "LSTM") or cfg.prior_transition not in ("GRU", "LSTM"):
+            raise NotImplementedError("oracle restates transition in {VanillaRNN, GRU, LSTM}, time_transition / prior_transition in {GRU, LSTM}")
         if cfg.prop_prior_type not in ("rnn", "rw", "guided"):
             raise ValueError('Invalid prior type: "{}"'.format(cfg.prop_prior_type))  # propagate.py:42-43
         if cfg.disc_prior_type not in ("cat", "geom"):
@@ -463,7 +463,10 @@ class SqairOracle(object):
             nh = self.cfg.n_hidden
             h, c2 = lstm(self.P, core + ".rnn_lstm", rnn_inpt, state[..., :nh], state[..., nh:])
             return h, torch.cat([h, c2], -1)
-        h = vanilla_rnn(self.P, core + ".rnn", rnn_inpt, state)
+        if self.cfg.transition == "GRU":
+            h = gru(self.P, core + ".rnn_gru", rnn_inpt, state)
+        else:
+            h = vanilla_rnn(self.P, core + ".rnn", rnn_inpt, state)
         return h, h
 
     def initial_rnn_state(self, core):

@@ -66,7 +66,7 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "dec.l2", nh, G2);
   add_param(h, "dec.output_scale", 1, 1);
   add_param(h, "disc.rnn_init", 1, nh);
-  if (c.rnn_lstm) add_param(h, "disc.rnn_init_c", 1, nh);  // LSTMState(hidden, cell): adjacent rows
+  if ((c.rnn_cell == RNN_LSTM)) add_param(h, "disc.rnn_init_c", 1, nh);  // LSTMState(hidden, cell): adjacent rows
   add_lin(h, "disc.steps_prior.l0", 1, 10);
   add_lin(h, "disc.steps_prior.l1", 10, N + 1);
   add_param(h, "disc.rn.init_state", 1, 4);
@@ -88,7 +88,8 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "disc.transform.l1", nh, nh);
   add_lin(h, "disc.transform.l2", nh, 8);
   add_param(h, "disc.transform.scale_offset", 1, 1);
-  if (c.rnn_lstm) add_lin(h, "disc.rnn_lstm", (nh + nh + nw + 4 + 1) + nh, 4 * nh);  // snt.LSTM w_gates [x | h], b_gates
+  if ((c.rnn_cell == RNN_LSTM)) add_lin(h, "disc.rnn_lstm", (nh + nh + nw + 4 + 1) + nh, 4 * nh);  // snt.LSTM w_gates [x | h], b_gates
+  else if (c.rnn_cell == RNN_GRU) add_gru(h, "disc.rnn_gru", nh + nh + nw + 4 + 1, nh);
   else {
     add_lin(h, "disc.rnn.h2h", nh, nh);
     add_lin(h, "disc.rnn.i2h", nh + nh + nw + 4 + 1, nh);
@@ -112,9 +113,11 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "prop.what_head", nh, 2 * nw);
   add_lin(h, "prop.gates", nh, 3 * nw);
   add_param(h, "prop.rnn_init", 1, nh);
-  if (c.rnn_lstm) {
+  if ((c.rnn_cell == RNN_LSTM)) {
     add_param(h, "prop.rnn_init_c", 1, nh);
     add_lin(h, "prop.rnn_lstm", (nw + (nw + 5) + (nw + 5) + nh) + nh, 4 * nh);
+  } else if (c.rnn_cell == RNN_GRU) {
+    add_gru(h, "prop.rnn_gru", nw + (nw + 5) + (nw + 5) + nh, nh);
   } else {
     add_lin(h, "prop.rnn.h2h", nh, nh);
     add_lin(h, "prop.rnn.i2h", nw + (nw + 5) + (nw + 5) + nh, nh);
@@ -272,13 +275,37 @@ static void build_plan(SqairHandle* h) {
   // discovery RNN in_to_hidden = [input enc nh | conditioning nh | what nw | where 4 | presence 1] (core.py:164-177)
   // slot RNN of both cores (flag transition): VanillaRNN -> nh pre-activation columns from in_to_hidden / hidden_to_hidden
   // (two biases); LSTM -> 4 nh gate columns (i, j, f, o) from the [x | h] rows of w_gates (one bias)
-  const bool RL = c.rnn_lstm != 0;
-  const int rw = RL ? 4 * nh : nh;
+  // GRU -> 3 nh columns [z | r | candidate] from w{z,r,h} / u{z,r} / b{z,r,h} (the candidate's recurrent matrix u_h meets
+  // r * h in a second launch, L_*_RNN2).
+  const bool RL = c.rnn_cell == RNN_LSTM, RG = c.rnn_cell == RNN_GRU;
   const int fin_d = nh + nh + nw + 4 + 1, fin_p = nw + (nw + 5) + (nw + 5) + nh;
-  const std::string dW = RL ? "disc.rnn_lstm.w" : "disc.rnn.i2h.w", dU = RL ? "disc.rnn_lstm.w" : "disc.rnn.h2h.w";
-  const std::string pW = RL ? "prop.rnn_lstm.w" : "prop.rnn.i2h.w", pU = RL ? "prop.rnn_lstm.w" : "prop.rnn.h2h.w";
-  const int dU0 = RL ? fin_d : 0, pU0 = RL ? fin_p : 0;  // first recurrent row
-  build_layer(h, L_PREDISC, {nh}, {cb1(rw, 0, dW, rm_range(0, nh), RL ? "disc.rnn_lstm.b" : "disc.rnn.i2h.b", RL ? "" : "disc.rnn.h2h.b")});
+  // column blocks of the RNN pre-activation for a layer whose segments take the given rows of the INPUT weights
+  // (rows[s] empty = segment s carries no RNN input; rec_seg = the segment holding h_{k-1}, or -1)
+  auto rnn_blocks = [&](const std::string& core, const std::vector<RowMap>& rows, int rec_seg, bool bias, int fin) {
+    std::vector<ColBlock> out;
+    const int ngate = RG ? 3 : 1;
+    for (int g = 0; g < ngate; ++g) {
+      const std::string gs = std::string(1, "zrh"[g]);
+      const std::string W = RL ? core + ".rnn_lstm.w" : (RG ? core + ".rnn_gru.w" + gs : core + ".rnn.i2h.w");
+      const std::string U = RL ? core + ".rnn_lstm.w" : (RG ? core + ".rnn_gru.u" + gs : core + ".rnn.h2h.w");
+      ColBlock b;
+      b.ncols = RL ? 4 * nh : nh; b.col0 = 0;
+      for (size_t sgi = 0; sgi < rows.size(); ++sgi) {
+        if ((int)sgi == rec_seg) {
+          if (RG && g == 2) b.seg.push_back({"", RowMap()});
+          else b.seg.push_back({U, rm_range(RL ? fin : 0, nh)});
+        } else if (rows[sgi].empty()) b.seg.push_back({"", RowMap()});
+        else b.seg.push_back({W, rows[sgi]});
+      }
+      if (bias) {
+        b.bias_a = RL ? core + ".rnn_lstm.b" : (RG ? core + ".rnn_gru.b" + gs : core + ".rnn.i2h.b");
+        b.bias_b = (RL || RG) ? "" : core + ".rnn.h2h.b";
+      }
+      out.push_back(b);
+    }
+    return out;
+  };
+  build_layer(h, L_PREDISC, {nh}, rnn_blocks("disc", {rm_range(0, nh)}, -1, true, fin_d));
   // prior cell on [what, where]_{t-1} (propagate.py:78-81)
   if (c.prior_lstm) {  // gates (i, j, f, o) = [what, where | h] w_gates + b_gates in ONE layer (both inputs exist up front)
     ColBlock b;
@@ -319,11 +346,7 @@ static void build_plan(SqairHandle* h) {
   {
     const int tm1 = nw + (nw + 5);  // rnn input: [loc1 nw | what,where,pres (k-1) | what,where,pres (t-1) | temporal]
     std::vector<ColBlock> bl;
-    ColBlock rnn;
-    rnn.ncols = rw; rnn.col0 = 0;
-    rnn.seg = {{pW, rm_range(0, nw)}, {pW, rm_zrec(nw, tm1 + nw, tm1, tm1 + nw + 4)}, {pW, rm_range(tm1 + nw + 5, nh)}};
-    rnn.bias_a = RL ? "prop.rnn_lstm.b" : "prop.rnn.i2h.b"; rnn.bias_b = RL ? "" : "prop.rnn.h2h.b";
-    bl.push_back(rnn);
+    bl = rnn_blocks("prop", {rm_range(0, nw), rm_zrec(nw, tm1 + nw, tm1, tm1 + nw + 4), rm_range(tm1 + nw + 5, nh)}, -1, true, fin_p);
     ColBlock t1;  // transform input [hidden nh | where_{t-1} 4 | temporal nh] (core.py:325-326)
     t1.ncols = nh; t1.col0 = 0;
     t1.seg = {{"", RowMap()}, {"prop.transform.l0.w", rm_zrec(nw, nh, -1, -1)}, {"prop.transform.l0.w", rm_range(nh + 4, nh)}};
@@ -345,10 +368,10 @@ static void build_plan(SqairHandle* h) {
     build_layer(h, L_PRE, {nw, rec::ZW, nh}, bl);
   }
   {
-    ColBlock b;  // explaining-away + recurrent part of the propagation RNN
-    b.ncols = rw; b.col0 = 0;
-    b.seg = {{pW, rm_zrec(nw, nw + nw, nw, nw + nw + 4)}, {pU, rm_range(pU0, nh)}};
-    build_layer(h, L_PROP_RNN, {rec::ZW, nh}, {b});
+    // explaining-away + recurrent part of the propagation RNN
+    build_layer(h, L_PROP_RNN, {rec::ZW, nh}, rnn_blocks("prop", {rm_zrec(nw, nw + nw, nw, nw + nw + 4), RowMap()}, 1, false, fin_p));
+    if (RG) simple(L_PROP_RNN2, "prop.rnn_gru.uh", nh, nh, 0, false);
+    else build_layer(h, L_PROP_RNN2, {nh}, {cb1(16, 0, "prop.what_head.w", rm_none(nh))});  // unused placeholder
   }
   // transform hidden layer 1 + (extra columns) the r_k rows of the steps predictor's hidden layer: both consume r_k
   build_layer(h, L_PROP_T1, {nh},
@@ -392,7 +415,7 @@ static void build_plan(SqairHandle* h) {
   }
   build_layer(h, L_LAT0, {rec::ZW}, {cb1(nh, 0, "seq.latent_enc.l0.w", rm_zrec(nw, nw, 0, -1), "seq.latent_enc.l0.b")});
   simple(L_LAT1, "seq.latent_enc.l1", nh, nh);
-  build_layer(h, L_PRED, {nh}, {cb1(rw, 0, dW, rm_range(nh, nh))});
+  build_layer(h, L_PRED, {nh}, rnn_blocks("disc", {rm_range(nh, nh)}, -1, false, fin_d));
   {
     ColBlock b;  // conditioning state of the recurrent where prior: [init_state 4 | cond nh | e 1] (modules.py:573-576)
     b.ncols = 128; b.col0 = 0;
@@ -401,10 +424,9 @@ static void build_plan(SqairHandle* h) {
     build_layer(h, L_RNCOND, {4, nh}, {b});
   }
   {
-    ColBlock b;
-    b.ncols = rw; b.col0 = 0;
-    b.seg = {{dW, rm_zrec(nw, 2 * nh + nw, 2 * nh, 2 * nh + nw + 4)}, {dU, rm_range(dU0, nh)}};
-    build_layer(h, L_DISC_RNN, {rec::ZW, nh}, {b});
+    build_layer(h, L_DISC_RNN, {rec::ZW, nh}, rnn_blocks("disc", {rm_zrec(nw, 2 * nh + nw, 2 * nh, 2 * nh + nw + 4), RowMap()}, 1, false, fin_d));
+    if (RG) simple(L_DISC_RNN2, "disc.rnn_gru.uh", nh, nh, 0, false);
+    else build_layer(h, L_DISC_RNN2, {nh}, {cb1(16, 0, "prop.what_head.w", rm_none(nh))});  // unused placeholder
   }
   build_layer(h, L_DISC_T1, {nh},
               {cb1(nh, 0, "disc.transform.l0.w", rm_range(0, nh), "disc.transform.l0.b"),
@@ -468,6 +490,10 @@ extern "C" int sqair_create(const SqairConfig* cfg, SqairHandle** out) {
   build_inventory(h);
   // GRU candidate matrices are bare [nh, nh] parameters: give build_plan's simple() a ".w" alias
   if (!cfg->prior_lstm) h->pidx["prop.prior_gru.uh.w"] = h->pidx["prop.prior_gru.uh"];
+  if (cfg->rnn_cell == RNN_GRU) {
+    h->pidx["prop.rnn_gru.uh.w"] = h->pidx["prop.rnn_gru.uh"];
+    h->pidx["disc.rnn_gru.uh.w"] = h->pidx["disc.rnn_gru.uh"];
+  }
   if (!cfg->time_lstm) h->pidx["prop.temporal_gru.uh.w"] = h->pidx["prop.temporal_gru.uh"];
   build_plan(h);
   build_plan_T(h);
@@ -552,7 +578,7 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   const int64_t S = train ? 2 * T * N : 1;  // per-slot multiplicity (x R rows)
   w.ienc_a = take((int64_t)T * B * nh);
   w.ienc_b = take((int64_t)T * B * nh);
-  const int64_t rw = c.rnn_lstm ? 4 * nh : nh;  // slot-RNN pre-activation width (LSTM: the four gates)
+  const int64_t rw = sq_rnn_width(c);  // slot-RNN pre-activation width (LSTM: the four gates)
   w.pre_disc = take((int64_t)T * B * rw);
   w.rec_m_all = take((int64_t)(T + 1) * M * rec::W);
   w.temporal_m = take((train ? T + 1 : 2) * M * snh);
@@ -590,8 +616,8 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.c = take(F * R * nh);
   w.pre_d = take(R * rw);
   w.r = take((train ? S : 2) * R * nh);
-  w.rc = take(c.rnn_lstm ? (train ? S : 2) * R * nh : 64);       // LSTM slot RNN: cell states, laid out like r
-  w.rgates = take(c.rnn_lstm ? (train ? S : 1) * R * 4 * nh : 64);  // and the kept gate pre-activations
+  w.rc = take((c.rnn_cell == RNN_LSTM) ? (train ? S : 2) * R * nh : 64);       // LSTM slot RNN: cell states, laid out like r
+  w.rgates = take(c.rnn_cell != RNN_VANILLA ? (train ? S : 1) * R * rw : 64);  // kept: LSTM gate pre-activations / GRU [z | r | candidate]
   w.t1 = take(S * R * T1_LD);
   w.t2 = take(S * R * nh);
   w.tp = take(S * R * TP_LD);
@@ -728,7 +754,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   const Workspace w = sq_carve(h, T, B, wsbase, train);
   const int pre_ld = h->layers[L_PRE].nt * 16;
   const int RW = rec::W, snh = d.snh, psnh = d.psnh;
-  const int rw = c.rnn_lstm ? 4 * nh : nh;  // slot-RNN pre-activation width; pre columns: [rnn rw | T1 nh | S1 nh/2 | GRU z, r]
+  const int rw = sq_rnn_width(c);  // slot-RNN pre-activation width; pre columns: [rnn rw | T1 nh | S1 nh/2 | GRU z, r]
   const PackedLayout pl = packed_layout(h);
 
   // ---- sequence prologue -----------------------------------------------------------------------
@@ -833,12 +859,23 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         Lin a;
         if (k == 0) a.seg(w.zero_rec, 0, rec::ZW).seg(w.prop_rnn_init, 0, nh);
         else a.seg(rec_p_t + (size_t)(k - 1) * RW, N * RW, rec::ZW).seg(w.rslot(t, 0, k - 1), rl, nh);
-        if (c.rnn_lstm) {
+        if ((c.rnn_cell == RNN_LSTM)) {
           float* gates = train ? w.slot(w.rgates, 4 * nh, t, 0, k) : w.rgates;
           a.add(pre_k, pre_rld, rw).out(gates, w.sld(4 * nh));
           RUN(a, L_PROP_RNN, R);
           sq_launch_lstm_cell2(gates, w.sld(4 * nh), k == 0 ? w.prop_rnn_init + nh : w.cslot(t, 0, k - 1), k == 0 ? 0 : rl, r_k, rl,
                                w.cslot(t, 0, k), rl, R, nh, s);
+        } else if (c.rnn_cell == RNN_GRU) {  // snt.GRU in two launches, [z | r | tanh candidate] kept for the backward pass
+          float* g3 = train ? w.slot(w.rgates, 3 * nh, t, 0, k) : w.rgates;
+          const int g3l = w.sld(3 * nh);
+          const float* hp = k == 0 ? w.prop_rnn_init : w.rslot(t, 0, k - 1);
+          const int hpl = k == 0 ? 0 : rl;
+          a.add(pre_k, pre_rld, rw).out(g3, g3l).gru1(hp, hpl, w.grh, nh, w.gxh, nh, nh);
+          a.a.o3 = g3 + nh; a.a.o3_ld = g3l;
+          RUN(a, L_PROP_RNN, R);
+          Lin b2; b2.seg(w.grh, nh, nh).add(w.gxh, nh, nh).out(r_k, rl).gru2(hp, hpl, g3, g3l, nh);
+          b2.a.o1 = g3 + 2 * nh; b2.a.o1_ld = g3l;
+          RUN(b2, L_PROP_RNN2, R);
         } else {
           a.add(pre_k, pre_rld, nh).out(r_k, rl).act(ACT_TANH);
           RUN(a, L_PROP_RNN, R);
@@ -927,12 +964,23 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         Lin a;
         if (j == 0) a.seg(w.disc_init_rec, 0, rec::ZW).seg(w.disc_rnn_init, 0, nh);
         else a.seg(rec_d_t + (size_t)(j - 1) * RW, N * RW, rec::ZW).seg(w.rslot(t, 1, j - 1), rl, nh);
-        if (c.rnn_lstm) {
+        if ((c.rnn_cell == RNN_LSTM)) {
           float* gates = train ? w.slot(w.rgates, 4 * nh, t, 1, j) : w.rgates;
           a.add(w.pre_d, rw, rw).out(gates, w.sld(4 * nh));
           RUN(a, L_DISC_RNN, R);
           sq_launch_lstm_cell2(gates, w.sld(4 * nh), j == 0 ? w.disc_rnn_init + nh : w.cslot(t, 1, j - 1), j == 0 ? 0 : rl, r_j, rl,
                                w.cslot(t, 1, j), rl, R, nh, s);
+        } else if (c.rnn_cell == RNN_GRU) {
+          float* g3 = train ? w.slot(w.rgates, 3 * nh, t, 1, j) : w.rgates;
+          const int g3l = w.sld(3 * nh);
+          const float* hp = j == 0 ? w.disc_rnn_init : w.rslot(t, 1, j - 1);
+          const int hpl = j == 0 ? 0 : rl;
+          a.add(w.pre_d, rw, rw).out(g3, g3l).gru1(hp, hpl, w.grh, nh, w.gxh, nh, nh);
+          a.a.o3 = g3 + nh; a.a.o3_ld = g3l;
+          RUN(a, L_DISC_RNN, R);
+          Lin b2; b2.seg(w.grh, nh, nh).add(w.gxh, nh, nh).out(r_j, rl).gru2(hp, hpl, g3, g3l, nh);
+          b2.a.o1 = g3 + 2 * nh; b2.a.o1_ld = g3l;
+          RUN(b2, L_DISC_RNN2, R);
         } else {
           a.add(w.pre_d, nh, nh).out(r_j, rl).act(ACT_TANH);
           RUN(a, L_DISC_RNN, R);
@@ -1041,7 +1089,7 @@ extern "C" int sqair_forward_persistent(SqairHandle* h, const float* flat_params
                                         void* stream) {
   if (!h || !out || !program) return -1;
   hipStream_t s = (hipStream_t)stream;
-  if (h->cfg.time_lstm || h->cfg.prior_lstm || h->cfg.rnn_lstm) {
+  if (h->cfg.time_lstm || h->cfg.prior_lstm || h->cfg.rnn_cell) {
     sq_set_error(h, "sqair_forward_persistent: the experimental persistent executor covers the GRU cells only");
     return -1;
   }

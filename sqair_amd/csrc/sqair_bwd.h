@@ -59,7 +59,7 @@ int sq_launch_slot_tail_bwd(const TailBwdArgs& a, Dims d, hipStream_t s);
 int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nslots, hipStream_t s);
 int sq_launch_gru_bwd_a(const float* d_hn, int dhn_ld, const float* z, int z_ld, const float* hc, int hc_ld,
                         const float* hprev, int h_ld, float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh,
-                        int accumulate_dh, hipStream_t s, float* dup_z = nullptr, int dup_ld = 0);
+                        int accumulate_dh, hipStream_t s, float* dup_z = nullptr, int dup_ld = 0, int dup_h_off = -1);
 int sq_launch_gru_bwd_b(const float* d_rh, int drh_ld, const float* rg, int r_ld, const float* hprev, int h_ld,
                         float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh, hipStream_t s, float* dup_r = nullptr,
                         int dup_ld = 0);

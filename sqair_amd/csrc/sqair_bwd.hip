@@ -1277,7 +1277,7 @@ int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nsl
 __global__ void k_gru_bwd_a(const float* __restrict__ d_hn, int dhn_ld, const float* __restrict__ z, int z_ld,
                             const float* __restrict__ hc, int hc_ld, const float* __restrict__ hprev, int h_ld,
                             float* __restrict__ dpre1, int dp_ld, float* __restrict__ d_h, int dh_ld, int rows, int nh,
-                            int accumulate_dh, float* __restrict__ dup_z, int dup_ld) {
+                            int accumulate_dh, float* __restrict__ dup_z, int dup_ld, int dup_h_off) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * nh) return;
   const int m = i / nh, n = i - m * nh;
@@ -1286,7 +1286,9 @@ __global__ void k_gru_bwd_a(const float* __restrict__ d_hn, int dhn_ld, const fl
   const float dz = g * (hh - hp) * zz * (1.0f - zz);
   dpre1[(size_t)m * dp_ld + n] = dz;
   if (dup_z != nullptr) dup_z[(size_t)m * dup_ld + n] = dz;
-  dpre1[(size_t)m * dp_ld + 2 * nh + n] = g * zz * (1.0f - hh * hh);
+  const float dc = g * zz * (1.0f - hh * hh);
+  dpre1[(size_t)m * dp_ld + 2 * nh + n] = dc;
+  if (dup_z != nullptr && dup_h_off >= 0) dup_z[(size_t)m * dup_ld + dup_h_off + n] = dc;
   float* dh = d_h + (size_t)m * dh_ld + n;
   *dh = (accumulate_dh ? *dh : 0.0f) + g * (1.0f - zz);
 }
@@ -1304,9 +1306,9 @@ __global__ void k_gru_bwd_b(const float* __restrict__ d_rh, int drh_ld, const fl
 }
 int sq_launch_gru_bwd_a(const float* d_hn, int dhn_ld, const float* z, int z_ld, const float* hc, int hc_ld,
                         const float* hprev, int h_ld, float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh,
-                        int accumulate_dh, hipStream_t s, float* dup_z, int dup_ld) {
+                        int accumulate_dh, hipStream_t s, float* dup_z, int dup_ld, int dup_h_off) {
   hipLaunchKernelGGL(k_gru_bwd_a, dim3((rows * nh + 255) / 256), dim3(256), 0, s, d_hn, dhn_ld, z, z_ld, hc, hc_ld, hprev,
-                     h_ld, dpre1, dp_ld, d_h, dh_ld, rows, nh, accumulate_dh, dup_z, dup_ld);
+                     h_ld, dpre1, dp_ld, d_h, dh_ld, rows, nh, accumulate_dh, dup_z, dup_ld, dup_h_off);
   return 0;
 }
 int sq_launch_gru_bwd_b(const float* d_rh, int drh_ld, const float* rg, int r_ld, const float* hprev, int h_ld,

@@ -17,7 +17,7 @@ enum LayerId {
   L_IENC0, L_IENC1, L_PREDISC, L_PRIOR_GRU1, L_PRIOR_GRU2, L_PRIOR_LIN, L_TAU1, L_WB2, L_MASK2, L_GENC0, L_GENC1,
   L_WHAT_LOC, L_WHAT_HEAD, L_PRE, L_PROP_RNN, L_PROP_T1, L_PROP_T2, L_PROP_T3, L_PROP_GRU1, L_PROP_GRU2,
   L_PROP_HEADS, L_PROP_S1, L_LAT0, L_LAT1, L_PRED, L_RNCOND, L_DISC_RNN, L_DISC_T1, L_DISC_T2, L_DISC_T3,
-  L_DISC_S1, L_DEC0, L_DEC1, L_DEC2, L_COUNT
+  L_DISC_S1, L_DEC0, L_DEC1, L_DEC2, L_PROP_RNN2, L_DISC_RNN2, L_COUNT
 };
 
 struct SqairHandle {
@@ -134,7 +134,7 @@ struct Workspace {
   float *pstats, *spre;                          // always [T]
   float *hid1, *wb, *mask, *g1, *pea, *peb, *m1, *pre, *lea, *leb, *c, *pre_d;  // per frame
   float *r, *t1, *t2, *tp, *g2, *e1, *e2, *enc, *hraw, *s1h, *gz, *gr, *ghc, *grh, *gxh;  // per slot
-  float *rc, *rgates;                            // LSTM slot RNN (rnn_lstm): cell states (like r), kept gates [.][4nh]
+  float *rc, *rgates;                            // LSTM / GRU slot RNN: cell states (like r), kept gates [.][4nh | 3nh]
   float *lpre, *lgates;                          // LSTM temporal cell (time_lstm): [M][4nh], kept gates [T][R][N][4nh]
   int* src;                                      // train: compaction source slot [T][R][N]
   float *qz, *pz, *dlp, *dll, *glimpse, *dec_a, *dec_b;

@@ -116,7 +116,7 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   b.d_rec_m = take((T + 1) * M * rec::W); b.d_rec_p = take(MT * rec::W); b.d_rec_d = take(MT * rec::W);
   const int64_t snh = c.time_lstm ? 2 * nh : nh, gw = c.time_lstm ? 4 * nh : 3 * nh;  // temporal state / gate widths
   const int64_t psnh = c.prior_lstm ? 2 * nh : nh, pgw = c.prior_lstm ? 4 * nh : 3 * nh;
-  const int64_t rw = c.rnn_lstm ? 4 * nh : nh;  // slot-RNN pre-activation width
+  const int64_t rw = sq_rnn_width(c);  // slot-RNN pre-activation width
   for (int i = 0; i < 2; ++i) { b.d_tm[i] = take(M * snh); b.d_pm[i] = take(M * psnh); }
   b.d_temporal_p = take(M * snh); b.d_prior_p = take(M * psnh);
   b.d_pstats = take(MT * PS_LD); b.d_spre = take(T * R * 128); b.d_raw = take(2 * MT);
@@ -165,7 +165,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   const int nzw = 4 + nw + 1, RW = rec::W, nsp = nh / 2;
   Dims d = make_dims(c, B);
   const int snh = d.snh, gw = c.time_lstm ? 4 * nh : 3 * nh, psnh = d.psnh, pgw = c.prior_lstm ? 4 * nh : 3 * nh;
-  const int rw = c.rnn_lstm ? 4 * nh : nh;  // slot-RNN pre-activation width; d_pre columns [rnn rw | T1 nh | S1 nsp | GRU z, r]
+  const int rw = sq_rnn_width(c);  // slot-RNN pre-activation width; d_pre columns [rnn rw | T1 nh | S1 nsp | GRU z, r]
   const POff po = h->po;
   const Workspace w = sq_carve(h, T, B, (float*)train_workspace, true);
   const BwdSpace b = carve_bwd(h, T, B, (float*)scratch);
@@ -329,12 +329,23 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       }
       { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_DISC_T3, x, R)); }
       { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU); CK(rundx(L_DISC_T2, x, R)); }
-      if (c.rnn_lstm) {  // d h_j = T1^T + the next slot's RNN; cell adjoint -> gate pre-activation gradients, d c_{j-1}
+      if ((c.rnn_cell == RNN_LSTM)) {  // d h_j = T1^T + the next slot's RNN; cell adjoint -> gate pre-activation gradients, d c_{j-1}
         Dx x(d_t1, t1l); x.to(0, nh, b.d_hk, nh);
         if (j < N - 1) x.add(b.d_r[j & 1], nh);
         CK(rundx(L_DISC_T1, x, R));
         sq_launch_lstm_cell_bwd(cslotp(w.rgates, 4 * nh, t, 1, j), N * 4 * nh, j == 0 ? w.disc_rnn_init + nh : cslotp(w.rc, nh, t, 1, j - 1),
                                 j == 0 ? 0 : rl, b.d_hk, nh, j < N - 1 ? b.d_cs[j & 1] : nullptr, nh, d_rnn, drl, b.d_cs[(j + 1) & 1], nh, R, nh, s);
+      } else if (c.rnn_cell == RNN_GRU) {  // GRU adjoint in the two stages of the temporal cell; d h_{j-1} starts in d_r[(j-1)&1] / tmp
+        Dx x(d_t1, t1l); x.to(0, nh, b.d_hk, nh);
+        if (j < N - 1) x.add(b.d_r[j & 1], nh);
+        CK(rundx(L_DISC_T1, x, R));
+        const float* g3 = cslotp(w.rgates, 3 * nh, t, 1, j);
+        const float* hp = j == 0 ? w.disc_rnn_init : cslotp(w.r, nh, t, 1, j - 1);
+        const int g3l = N * 3 * nh, hpl = j == 0 ? 0 : rl;
+        float* dhp = j > 0 ? b.d_r[(j - 1) & 1] : b.tmp;
+        sq_launch_gru_bwd_a(b.d_hk, nh, g3, g3l, g3 + 2 * nh, g3l, hp, hpl, d_rnn, drl, dhp, nh, R, nh, 0, s);
+        { Dx y(d_rnn + 2 * nh, drl); y.to(0, nh, b.d_rh, nh); CK(rundx(L_DISC_RNN2, y, R)); }
+        sq_launch_gru_bwd_b(b.d_rh, nh, g3 + nh, g3l, hp, hpl, d_rnn, drl, dhp, nh, R, nh, s);
       } else {  // d r_j = T1^T (incl. the steps-predictor columns) + what the next slot's RNN sent back; tanh' -> d pre-activation
         Dx x(d_t1, t1l); x.to(0, nh, d_rnn, rl);
         if (j < N - 1) x.add(b.d_r[j & 1], nh);
@@ -345,11 +356,14 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         Dx x(d_rnn, drl);
         x.to(0, rec::ZW, d_rec_d_t + (size_t)(j - 1) * RW, N * RW).acc();
         x.to(64, 64 + nh, b.d_r[(j - 1) & 1], nh);
+        if (c.rnn_cell == RNN_GRU) x.acc();   // the gate adjoints above already put their direct part there
         CK(rundx(L_DISC_RNN, x, R));
       } else {
-        Dx x(d_rnn, drl); x.to(64, 64 + nh, b.tmp, nh); CK(rundx(L_DISC_RNN, x, R));
+        Dx x(d_rnn, drl); x.to(64, 64 + nh, b.tmp, nh);
+        if (c.rnn_cell == RNN_GRU) x.acc();
+        CK(rundx(L_DISC_RNN, x, R));
         sq_launch_colsum(b.tmp, nh, R, nh, flat_grad + po.disc_rnn_init, 1, s);
-        if (c.rnn_lstm) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.disc_rnn_init + nh, 1, s);
+        if ((c.rnn_cell == RNN_LSTM)) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.disc_rnn_init + nh, 1, s);
       }
     }
     // ---- F^T. conditioning of discovery on the propagated latents
@@ -443,13 +457,24 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       }
       { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_PROP_T3, x, R)); }
       { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU).dup(d_pre_k + rw, pre_rld); CK(rundx(L_PROP_T2, x, R)); }
-      if (c.rnn_lstm) {  // d h_k total, then the cell adjoint (second copy: this slot's block of d_pre)
+      if ((c.rnn_cell == RNN_LSTM)) {  // d h_k total, then the cell adjoint (second copy: this slot's block of d_pre)
         Dx x(d_t1, t1l);
         x.to(0, nh, b.d_hk, nh).add(b.d_r[k & 1], nh);
         CK(rundx(L_PROP_T1, x, R));
         sq_launch_lstm_cell_bwd(cslotp(w.rgates, 4 * nh, t, 0, k), N * 4 * nh, k == 0 ? w.prop_rnn_init + nh : cslotp(w.rc, nh, t, 0, k - 1),
                                 k == 0 ? 0 : rl, b.d_hk, nh, k < N - 1 ? b.d_cs[k & 1] : nullptr, nh, d_rnn, drl, b.d_cs[(k + 1) & 1], nh, R, nh, s,
                                 d_pre_k, pre_rld);
+      } else if (c.rnn_cell == RNN_GRU) {
+        Dx x(d_t1, t1l);
+        x.to(0, nh, b.d_hk, nh).add(b.d_r[k & 1], nh);
+        CK(rundx(L_PROP_T1, x, R));
+        const float* g3 = cslotp(w.rgates, 3 * nh, t, 0, k);
+        const float* hp = k == 0 ? w.prop_rnn_init : cslotp(w.r, nh, t, 0, k - 1);
+        const int g3l = N * 3 * nh, hpl = k == 0 ? 0 : rl;
+        float* dhp = k > 0 ? b.d_r[(k - 1) & 1] : b.tmp;
+        sq_launch_gru_bwd_a(b.d_hk, nh, g3, g3l, g3 + 2 * nh, g3l, hp, hpl, d_rnn, drl, dhp, nh, R, nh, 0, s, d_pre_k, pre_rld, 2 * nh);
+        { Dx y(d_rnn + 2 * nh, drl); y.to(0, nh, b.d_rh, nh); CK(rundx(L_PROP_RNN2, y, R)); }
+        sq_launch_gru_bwd_b(b.d_rh, nh, g3 + nh, g3l, hp, hpl, d_rnn, drl, dhp, nh, R, nh, s, d_pre_k + nh, pre_rld);
       } else {  // d r_k total = T1^T + (gate GEMM + next slot's RNN, accumulated in d_r[k & 1]); tanh' -> RNN pre-activation
         Dx x(d_t1, t1l);
         x.to(0, nh, d_rnn, rl).add(b.d_r[k & 1], nh).dact(r_k, rl, ACT_TANH).dup(d_pre_k, pre_rld);
@@ -459,11 +484,14 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         Dx x(d_rnn, drl);
         x.to(0, rec::ZW, d_rec_p_t + (size_t)(k - 1) * RW, N * RW).acc();
         x.to(64, 64 + nh, b.d_r[(k - 1) & 1], nh);
+        if (c.rnn_cell == RNN_GRU) x.acc();
         CK(rundx(L_PROP_RNN, x, R));
       } else {
-        Dx x(d_rnn, drl); x.to(64, 64 + nh, b.tmp, nh); CK(rundx(L_PROP_RNN, x, R));
+        Dx x(d_rnn, drl); x.to(64, 64 + nh, b.tmp, nh);
+        if (c.rnn_cell == RNN_GRU) x.acc();
+        CK(rundx(L_PROP_RNN, x, R));
         sq_launch_colsum(b.tmp, nh, R, nh, flat_grad + po.prop_rnn_init, 1, s);
-        if (c.rnn_lstm) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.prop_rnn_init + nh, 1, s);
+        if ((c.rnn_cell == RNN_LSTM)) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.prop_rnn_init + nh, 1, s);
       }
     }
     // ---- D^T. the loop-invariant pre-activation GEMM: segments [m1 nw (pad 64) | z_{t-1} record 56 (pad 64) | temporal nh]
@@ -569,6 +597,10 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     // propagation slot chain (phase 0 of the tapes)
     hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_p_all, w.r, w.zero_rec, w.prop_rnn_init, b.zs, b.rs, MT, N, nh);
     wgrad(L_PROP_RNN, {{b.zs, 64}, {b.rs, nh}}, b.d_rnn, rw, MT);
+    if (c.rnn_cell == RNN_GRU) {  // candidate's recurrent matrix: A = r * h_{k-1}
+      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.rgates + nh, 3 * nh, b.rs, nh, b.rh, nh, MT, nh);
+      wgrad(L_PROP_RNN2, {{b.rh, nh}}, b.d_rnn + 2 * nh, rw, MT);
+    }
     wgrad(L_PROP_T1, {{w.r, nh}}, b.d_t1, T1_LD, MT);
     wgrad(L_PROP_T2, {{w.t1, T1_LD}}, b.d_t2, nh, MT);
     wgrad(L_PROP_T3, {{w.t2, nh}}, b.d_tp, TP_LD, MT);
@@ -591,6 +623,10 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_d_all, w.r + ph1 * nh, w.disc_init_rec, w.disc_rnn_init, b.zs,
                        b.rs, MT, N, nh);
     wgrad(L_DISC_RNN, {{b.zs, 64}, {b.rs, nh}}, b.d_rnn + ph1 * rw, rw, MT);
+    if (c.rnn_cell == RNN_GRU) {
+      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.rgates + ph1 * 3 * nh + nh, 3 * nh, b.rs, nh, b.rh, nh, MT, nh);
+      wgrad(L_DISC_RNN2, {{b.rh, nh}}, b.d_rnn + ph1 * rw + 2 * nh, rw, MT);
+    }
     wgrad(L_DISC_T1, {{w.r + ph1 * nh, nh}}, b.d_t1 + ph1 * T1_LD, T1_LD, MT);
     wgrad(L_DISC_T2, {{w.t1 + ph1 * T1_LD, T1_LD}}, b.d_t2 + ph1 * nh, nh, MT);
     wgrad(L_DISC_T3, {{w.t2 + ph1 * nh, nh}}, b.d_tp + ph1 * TP_LD, TP_LD, MT);

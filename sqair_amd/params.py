@@ -60,8 +60,9 @@ def param_spec(F, img_hw):
 
     # ---- discovery (core.py:146-227, sqair_modules.py:66-229, modules.py:548-630)
     d = "discovery/discover/discovery_core"
-    rnn_lstm = str(getattr(F, "transition", "VanillaRNN")) == "LSTM"   # the slot RNN of both cores (mlp_mnist_model.py:86)
-    rmod = "lstm" if rnn_lstm else "vanilla_rnn"
+    rnn_cell = str(getattr(F, "transition", "VanillaRNN"))   # the slot RNN of both cores (mlp_mnist_model.py:86)
+    rnn_lstm, rnn_gru = rnn_cell == "LSTM", rnn_cell == "GRU"
+    rmod = "lstm" if rnn_lstm else ("gru" if rnn_gru else "vanilla_rnn")
     spec.append(("disc.rnn_init", (1, nh), ("zeros",), "discovery/discover/discovery/" + rmod + "_initial_state_0/w"))
     if rnn_lstm:
         spec.append(("disc.rnn_init_c", (1, nh), ("zeros",), "discovery/discover/discovery/" + rmod + "_initial_state_1/w"))
@@ -95,6 +96,8 @@ def param_spec(F, img_hw):
     if rnn_lstm:
         spec.append(("disc.rnn_lstm.w", (fin_d + nh, 4 * nh), ("lin_w", fin_d + nh), d + "/lstm/w_gates"))
         spec.append(("disc.rnn_lstm.b", (4 * nh,), ("zeros",), d + "/lstm/b_gates"))
+    elif rnn_gru:
+        gru("disc.rnn_gru", fin_d, d + "/gru")
     else:
         lin("disc.rnn.h2h", nh, nh, d + "/vanilla_rnn/hidden_to_hidden")
         lin("disc.rnn.i2h", fin_d, nh, d + "/vanilla_rnn/in_to_hidden")
@@ -110,11 +113,14 @@ def param_spec(F, img_hw):
     # Sonnet uniquifies module names per class in construction order (configs/mlp_mnist_model.py:116-125: transition cell,
     # temporal cell, prior cell): gru / gru_1, lstm / lstm_1 / lstm_2.  (Names of non-shipped cell choices are a best
     # guess from that rule: no listing of such a model exists in the reference.)
-    n_lstm = [1 if rnn_lstm else 0]
+    n_mod = {"lstm": 1 if rnn_lstm else 0, "gru": 1 if rnn_gru else 0}
+
+    def scope_of(kind):
+        n_mod[kind] += 1
+        return kind if n_mod[kind] == 1 else "{}_{}".format(kind, n_mod[kind] - 1)
 
     def lstm_scope():
-        n_lstm[0] += 1
-        return "lstm" if n_lstm[0] == 1 else "lstm_{}".format(n_lstm[0] - 1)
+        return scope_of("lstm")
     time_lstm = str(getattr(F, "time_transition", "GRU")) == "LSTM"
     prior_lstm = str(getattr(F, "prior_transition", "GRU")) == "LSTM"
     if time_lstm:
@@ -124,14 +130,16 @@ def param_spec(F, img_hw):
         spec.append(("prop.temporal_lstm.w", (fin + nh, 4 * nh), ("lin_w", fin + nh), "propagation/" + tmod + "/w_gates"))
         spec.append(("prop.temporal_lstm.b", (4 * nh,), ("zeros",), "propagation/" + tmod + "/b_gates"))
     else:
-        gru("prop.temporal_gru", nh + 4 + 2 * nw, "propagation/gru")
+        tmod = scope_of("gru")
+        gru("prop.temporal_gru", nh + 4 + 2 * nw, "propagation/" + tmod)
     if prior_lstm:
         pmod = lstm_scope()
         scope = "propagation/" + pmod
         spec.append(("prop.prior_lstm.w", (nw + 4 + nh, 4 * nh), ("lin_w", nw + 4 + nh), scope + "/w_gates"))
         spec.append(("prop.prior_lstm.b", (4 * nh,), ("zeros",), scope + "/b_gates"))
     else:
-        gru("prop.prior_gru", nw + 4, "propagation/gru" if time_lstm else "propagation/gru_1")
+        pmod = scope_of("gru")
+        gru("prop.prior_gru", nw + 4, "propagation/" + pmod)
     lin("prop.prior_linear", nh, 2 * (4 + nw) + 1, "propagation/propagate_prior/linear")
     spec.append(("prop.cholesky_scale", (10,), ("glorot", 10, 10),
                  pc + "/affine_diag_normal/cholesky_scale"))
@@ -153,6 +161,8 @@ def param_spec(F, img_hw):
         spec.append(("prop.rnn_init_c", (1, nh), ("zeros",), "propagation/sequential_ssm/propagation/" + rmod + "_initial_state_1/w"))
         spec.append(("prop.rnn_lstm.w", (fin_p + nh, 4 * nh), ("lin_w", fin_p + nh), pc + "/lstm/w_gates"))
         spec.append(("prop.rnn_lstm.b", (4 * nh,), ("zeros",), pc + "/lstm/b_gates"))
+    elif rnn_gru:
+        gru("prop.rnn_gru", fin_p, pc + "/gru")
     else:
         lin("prop.rnn.h2h", nh, nh, pc + "/vanilla_rnn/hidden_to_hidden")
         lin("prop.rnn.i2h", fin_p, nh, pc + "/vanilla_rnn/in_to_hidden")
@@ -161,11 +171,9 @@ def param_spec(F, img_hw):
     # trainable initial states, named after the cell's module name (RNNCore.initial_state(trainable=True)); an
     # LSTMState(hidden, cell) has two variables, kept adjacent ([hidden | cell] is read as one row)
     sq = "sequence/sequential_air/"
-    pmod = pmod if prior_lstm else ("gru" if time_lstm else "gru_1")
     spec.append(("seq.prior_init", (1, nh), ("zeros",), sq + pmod + "_initial_state_0/w"))
     if prior_lstm:
         spec.append(("seq.prior_init_c", (1, nh), ("zeros",), sq + pmod + "_initial_state_1/w"))
-    tmod = tmod if time_lstm else "gru"
     spec.append(("seq.temporal_init", (1, nh), ("zeros",), sq + tmod + "_initial_state_0/w"))
     if time_lstm:
         spec.append(("seq.temporal_init_c", (1, nh), ("zeros",), sq + tmod + "_initial_state_1/w"))

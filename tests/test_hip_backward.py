@@ -440,6 +440,7 @@ def test_checkpoint_round_trip_restores_parameters_and_optimiser_slots(tmp_path)
     dict(prior_transition="LSTM"),
     dict(time_transition="LSTM", prior_transition="LSTM", prop_prior_type="guided"),
     dict(transition="LSTM"),
+    dict(transition="GRU"),
     dict(transition="LSTM", time_transition="LSTM", prior_transition="LSTM"),
 ])
 def test_full_backward_flag_variants(flags):

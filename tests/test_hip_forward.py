@@ -86,6 +86,14 @@ def test_forward_flag_variants_vs_live_oracle(prior, disc_prior, rec):
     _live_oracle_case(F)
 
 
+def test_forward_gru_slot_rnn_vs_live_oracle():
+    """transition=GRU: the Sonnet GRU (reset gate applied BEFORE the recurrent candidate matmul) as the slot RNN of both
+    cores, two launches per slot like the temporal cell."""
+    F = make_flags(k_particles=3, n_steps_per_image=4, transition="GRU")
+    m, ref = _live_oracle_case(F, T=4, B=3)
+    assert float(ref.prop_pres.sum()) > 0 and float(ref.disc_pres.sum()) > 0
+
+
 @pytest.mark.parametrize("cells", [("GRU", "GRU"), ("LSTM", "LSTM")])
 def test_forward_lstm_slot_rnn_vs_live_oracle(cells):
     """transition=LSTM (configs/mlp_mnist_model.py:86): the slot RNN of the discovery and the propagation core carries

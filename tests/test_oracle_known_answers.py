@@ -334,7 +334,8 @@ def test_generation_after_t_samples_the_priors():
     assert torch.isfinite(b.log_weights).all()
 
 
-@pytest.mark.parametrize("cells", [("LSTM", "GRU"), ("GRU", "LSTM"), ("LSTM", "LSTM"), ("GRU", "GRU", "LSTM"), ("LSTM", "LSTM", "LSTM")])
+@pytest.mark.parametrize("cells", [("LSTM", "GRU"), ("GRU", "LSTM"), ("LSTM", "LSTM"), ("GRU", "GRU", "LSTM"), ("LSTM", "LSTM", "LSTM"),
+                                   ("GRU", "GRU", "GRU")])
 def test_lstm_cells_are_wired_into_the_model(cells):
     """time_transition / prior_transition = LSTM (configs/mlp_mnist_model.py:86-87,125): the recurrent states double to
     [hidden | cell], every parameter of the LSTM variant receives a gradient, and the parameter table swaps the nine GRU
@@ -363,4 +364,5 @@ def test_lstm_cells_are_wired_into_the_model(cells):
     assert len(set(tf_names)) == len(tf_names)
     assert ("prop.temporal_lstm.w" in names) == (cells[0] == "LSTM") and ("prop.temporal_gru.wz" in names) == (cells[0] == "GRU")
     assert ("prop.prior_lstm.w" in names) == (cells[1] == "LSTM") and ("seq.prior_init_c" in names) == (cells[1] == "LSTM")
-    assert ("prop.rnn_lstm.w" in names) == (rnn == "LSTM") == ("disc.rnn_init_c" in names) and ("prop.rnn.i2h.w" in names) == (rnn != "LSTM")
+    assert ("prop.rnn_lstm.w" in names) == (rnn == "LSTM") == ("disc.rnn_init_c" in names)
+    assert ("prop.rnn.i2h.w" in names) == (rnn == "VanillaRNN") and ("disc.rnn_gru.uh" in names) == (rnn == "GRU")

@@ -14,14 +14,14 @@ from sqair_amd.params import flatten_params, init_params, param_spec
 
 LAYERS = ("IENC0 IENC1 PREDISC PRIOR_GRU1 PRIOR_GRU2 PRIOR_LIN TAU1 WB2 MASK2 GENC0 GENC1 WHAT_LOC WHAT_HEAD PRE PROP_RNN "
           "PROP_T1 PROP_T2 PROP_T3 PROP_GRU1 PROP_GRU2 PROP_HEADS PROP_S1 LAT0 LAT1 PRED RNCOND DISC_RNN DISC_T1 DISC_T2 "
-          "DISC_T3 DISC_S1 DEC0 DEC1 DEC2").split()
+          "DISC_T3 DISC_S1 DEC0 DEC1 DEC2 PROP_RNN2 DISC_RNN2").split()
 NW, NH = 50, 256
 
 
 class Plan(object):
-    def __init__(self, N=4, hw=(20, 24)):
+    def __init__(self, N=4, hw=(20, 24), **flags):
         self.lib = _capi.lib()
-        self.F = make_flags(n_steps_per_image=N)
+        self.F = make_flags(n_steps_per_image=N, **flags)
         cfg = make_config(self.F, hw)
         self.h = C.c_void_p()
         assert self.lib.sqair_create(C.byref(cfg), C.byref(self.h)) == 0
@@ -156,3 +156,44 @@ def test_plain_layers(plan, name, pname):
     W = plan.P[pname + ".w"]
     x = np.random.default_rng(2).standard_normal((2, W.shape[0]))
     assert np.allclose(plan.apply(name, x), lin(plan.P, pname, x), atol=1e-9)
+
+
+@pytest.mark.parametrize("rnn", ["LSTM", "GRU"])
+def test_cell_variant_composites(rnn):
+    """The packing plans of the non-shipped cell choices (transition in {LSTM, GRU}, time_transition = prior_transition =
+    LSTM): hoisted + per-slot GEMMs add up to the cell's full pre-activation."""
+    plan = Plan(transition=rnn, time_transition="LSTM", prior_transition="LSTM")
+    try:
+        P, rng, R = plan.P, np.random.default_rng(2), 3
+        g = lambda n: rng.standard_normal((R, n))
+        loc1, what_km1, where_km1, pres_km1 = g(NW), g(NW), g(4), g(1)
+        what_tm1, where_tm1, pres_tm1, logit_tm1, tau, r_prev, r_k, hid = g(NW), g(4), g(1), g(1), g(NH), g(NH), g(NH), g(NH)
+        where_k, enc = g(4), g(2 * NW)
+        rw = NH * (4 if rnn == "LSTM" else 3)
+        pre = plan.apply("PRE", loc1, rec(where_tm1, what_tm1, pres_tm1, logit_tm1), tau)
+        assert pre.shape[1] == rw + NH + NH // 2          # the temporal LSTM's recurrent rows are their own layer
+        x = np.concatenate([loc1, what_km1, where_km1, pres_km1, what_tm1, where_tm1, pres_tm1, tau], -1)
+        got = pre[:, :rw] + plan.apply("PROP_RNN", rec(where_km1, what_km1, pres_km1, g(1)), r_prev)
+        ienc, cond = g(NH), g(NH)
+        xd = np.concatenate([ienc, cond, what_km1, where_km1, pres_km1], -1)
+        gotd = plan.apply("PREDISC", ienc) + plan.apply("PRED", cond) + plan.apply("DISC_RNN", rec(where_km1, what_km1, pres_km1, g(1)), r_prev)
+        if rnn == "LSTM":
+            assert np.allclose(got, np.concatenate([x, r_prev], -1) @ P["prop.rnn_lstm.w"] + P["prop.rnn_lstm.b"], atol=1e-9)
+            assert np.allclose(gotd, np.concatenate([xd, r_prev], -1) @ P["disc.rnn_lstm.w"] + P["disc.rnn_lstm.b"], atol=1e-9)
+        else:
+            for core, xx, yy in (("prop", x, got), ("disc", xd, gotd)):
+                for i, gate in enumerate("zr"):
+                    ref = xx @ P[core + ".rnn_gru.w" + gate] + r_prev @ P[core + ".rnn_gru.u" + gate] + P[core + ".rnn_gru.b" + gate]
+                    assert np.allclose(yy[:, i * NH:(i + 1) * NH], ref, atol=1e-9)
+                assert np.allclose(yy[:, 2 * NH:], xx @ P[core + ".rnn_gru.wh"] + P[core + ".rnn_gru.bh"], atol=1e-9)
+                assert np.allclose(plan.apply(core.upper() + "_RNN2", hid), hid @ P[core + ".rnn_gru.uh"], atol=1e-9)
+        # temporal LSTM: input rows per slot + recurrent rows (and the bias) for all slots at once
+        xin = np.concatenate([r_k, where_k, enc], -1)
+        gates = plan.apply("PROP_GRU1", r_k, where_k, enc) + plan.apply("PROP_GRU2", hid)
+        assert np.allclose(gates, np.concatenate([xin, hid], -1) @ P["prop.temporal_lstm.w"] + P["prop.temporal_lstm.b"], atol=1e-9)
+        # prior LSTM in one layer
+        pg = plan.apply("PRIOR_GRU1", rec(where_tm1, what_tm1, pres_tm1, logit_tm1), hid)
+        xp = np.concatenate([what_tm1, where_tm1], -1)
+        assert np.allclose(pg, np.concatenate([xp, hid], -1) @ P["prop.prior_lstm.w"] + P["prop.prior_lstm.b"], atol=1e-9)
+    finally:
+        plan.lib.sqair_destroy(plan.h)

@@ -36,15 +36,18 @@ gen = torch.Generator(device="cuda").manual_seed(0)
 
 
 def validate():
-    tot, n = 0.0, 0
+    """validation ELBO per frame and the importance-weighted mean number of inferred objects per frame (model.py:107-110)"""
+    tot, n, steps_tot = 0.0, 0, 0.0
+    i_ns = list(core.mean_names).index("num_steps_per_sample")
     with core.on_stream():
         for _ in range(256 // B):
             core.obs.copy_(torch.as_tensor(vfeed.next()["imgs"]))
             core.draw_noise(gen)
             core.forward(use_graph=True)
             tot += float(core.scalars[1])
+            steps_tot += float(core.iw_means[i_ns])
             n += 1
-    return tot / n / T
+    return tot / n / T, steps_tot / n
 
 
 log = []
@@ -52,8 +55,9 @@ t0 = time.perf_counter()
 run = 0.0
 for it in range(steps + 1):
     if it % max(1, steps // 30) == 0:
-        rec = dict(step=it, valid_elbo_iwae_per_frame=validate(), train_elbo_iwae_per_frame_running=run,
-                   seconds=time.perf_counter() - t0)
+        v_elbo, v_steps = validate()
+        rec = dict(step=it, valid_elbo_iwae_per_frame=v_elbo, valid_num_steps_per_frame=v_steps,
+                   train_elbo_iwae_per_frame_running=run, seconds=time.perf_counter() - t0)
         log.append(rec)
         print(rec, file=sys.stderr)
     if it == steps:
@@ -65,5 +69,6 @@ for it in range(steps + 1):
             e = float(core.scalars[1]) / T
         run = e if it == 0 else 0.9 * run + 0.1 * e
 print(json.dumps(dict(config=dict(T=T, B=B, K=K, N=N, hw=hw, steps=steps, train_itr=train_itr, learning_rate=lr, opt="rmsprop(momentum .9)",
-                                  schedule=F.schedule, data="2048 synthetic 2-glyph sequences, 256 held out"),
+                                  schedule=F.schedule, data="2048 synthetic 2-glyph sequences, 256 held out",
+                                  true_objects_per_frame=float(valid["nums"].sum(-1).mean())),
                       upper_bound_per_frame=2500 * (-np.log(0.3) - 0.5 * np.log(2 * np.pi)), curve=log)))
