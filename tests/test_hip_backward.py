@@ -308,7 +308,8 @@ def test_grad_step_graph_replay_equals_eager(cell):
     assert float((g2 - g0).abs().max()) > 1e-3 * float(g0.abs().max())
 
 
-def test_training_steps_track_oracle_rmsprop():
+@pytest.mark.parametrize("cells", [{}, dict(transition="LSTM", time_transition="LSTM", prior_transition="LSTM")])
+def test_training_steps_track_oracle_rmsprop(cells):
     """Three optimiser steps (graph replay + fused RMSProp + re-pack) against autograd + the NumPy restatement of the TF
     update on the fp64 oracle, same noise per step.  Every step starts from the HIP path's own fp32 parameters (the
     objective is curved enough that an fp32 rounding of the parameters changes the next gradient by ~1 %), while the
@@ -319,7 +320,7 @@ def test_training_steps_track_oracle_rmsprop():
     from sqair_amd.train import Trainer, learning_rate, rmsprop_reference
     from tests.hip_util import draw_noise, params32
     K, N, T, B, hw = 3, 3, 3, 3, (50, 50)
-    F = make_flags(k_particles=K, n_steps_per_image=N, learning_rate=1e-3, train_itr=100)
+    F = make_flags(k_particles=K, n_steps_per_image=N, learning_rate=1e-3, train_itr=100, **cells)
     obs = to_float(make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=24, seed=11)["imgs"])
     P = params32(F, hw, 4, 0.05, obs.mean((0, 1)))
     core = SqairCore(F, hw)

@@ -1,7 +1,8 @@
 """End-to-end training run on synthetic moving glyphs with the reference's driver semantics (scripts/experiment.py:126-185):
 minibatches drawn with replacement (data.py:203-216), RMSProp(momentum .9) with the piecewise-constant learning rate,
 VIMCO target, K = 5 particles; logs the training ELBO per frame and the validation ELBO on held-out sequences.
-    python tools/train_demo.py [steps] [lr] > profiles/r01_train_curve.json
+    python tools/train_demo.py [steps] [lr] [train_itr] [seq_len] [stage_itr] > profiles/r01_train_curve.json
+The reference's own recipe (scripts/train_multi_mnist.sh) is seq_len 3, stage_itr 100000 (sequence-length curriculum), 1 M iterations.
 """
 import json
 import sys
@@ -22,15 +23,18 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 lr = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-5
 T, B, K, N, hw = 10, 32, 5, 4, (50, 50)
 train_itr = int(sys.argv[3]) if len(sys.argv) > 3 else steps   # the piecewise-constant schedule is relative to train_itr
-F = make_flags(k_particles=K, n_steps_per_image=N, learning_rate=lr, train_itr=train_itr)
+seq_len = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+stage_itr = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+F = make_flags(k_particles=K, n_steps_per_image=N, learning_rate=lr, train_itr=train_itr, seq_len=seq_len, stage_itr=stage_itr)
 train = make_sequences(2048, T=T, canvas=hw, n_objects=(0, 2), seed=1)
 valid = make_sequences(256, T=T, canvas=hw, n_objects=(0, 2), seed=2)
-feed = MinibatchFeed(dict(imgs=to_float(train["imgs"]), nums=train["nums"], coords=train["coords"]), B, shuffle=True, seed=0)
+feed = MinibatchFeed(dict(imgs=to_float(train["imgs"]), nums=train["nums"], coords=train["coords"]), B, shuffle=True, seed=0,
+                     seq_len=seq_len, stage_itr=stage_itr)
 vfeed = MinibatchFeed(dict(imgs=to_float(valid["imgs"]), nums=valid["nums"], coords=valid["coords"]), B, shuffle=False)
 mean_img = to_float(train["imgs"]).mean((0, 1))
 core = SqairCore(F, hw)
 core.set_params({k: np.asarray(v, dtype=np.float32) for k, v in init_params(F, hw, seed=0, mean_img=mean_img).items()})
-model = Model(to_float(train["imgs"][:, :B]), None, core, K, outputs="minimal")
+model = Model(to_float(train["imgs"][:(seq_len if seq_len and stage_itr else T), :B]), None, core, K, outputs="minimal")
 trainer = Trainer(model, F)
 gen = torch.Generator(device="cuda").manual_seed(0)
 
@@ -39,15 +43,16 @@ def validate():
     """validation ELBO per frame and the importance-weighted mean number of inferred objects per frame (model.py:107-110)"""
     tot, n, steps_tot = 0.0, 0, 0.0
     i_ns = list(core.mean_names).index("num_steps_per_sample")
+    Tc = core.T   # the curriculum's current sequence length (validation sequences are truncated to it)
     with core.on_stream():
         for _ in range(256 // B):
-            core.obs.copy_(torch.as_tensor(vfeed.next()["imgs"]))
+            core.obs.copy_(torch.as_tensor(vfeed.next()["imgs"][:Tc]))
             core.draw_noise(gen)
             core.forward(use_graph=True)
             tot += float(core.scalars[1])
             steps_tot += float(core.iw_means[i_ns])
             n += 1
-    return tot / n / T, steps_tot / n
+    return tot / n / Tc, steps_tot / n
 
 
 log = []
@@ -57,7 +62,7 @@ for it in range(steps + 1):
     if it % max(1, steps // 30) == 0:
         v_elbo, v_steps = validate()
         rec = dict(step=it, valid_elbo_iwae_per_frame=v_elbo, valid_num_steps_per_frame=v_steps,
-                   train_elbo_iwae_per_frame_running=run, seconds=time.perf_counter() - t0)
+                   train_elbo_iwae_per_frame_running=run, seq_len=core.T, seconds=time.perf_counter() - t0)
         log.append(rec)
         print(rec, file=sys.stderr)
     if it == steps:
@@ -66,7 +71,7 @@ for it in range(steps + 1):
     trainer.step(obs=batch["imgs"], generator=gen)
     if it % 10 == 0:
         with core.on_stream():
-            e = float(core.scalars[1]) / T
+            e = float(core.scalars[1]) / core.T
         run = e if it == 0 else 0.9 * run + 0.1 * e
 print(json.dumps(dict(config=dict(T=T, B=B, K=K, N=N, hw=hw, steps=steps, train_itr=train_itr, learning_rate=lr, opt="rmsprop(momentum .9)",
                                   schedule=F.schedule, data="2048 synthetic 2-glyph sequences, 256 held out",
