@@ -502,8 +502,9 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     {
       Dx x(d_pre, pre_ld);
       x.to(0, nw, d_m1, M1_LD);
-      x.to(64, 64 + rec::ZW, d_rec_prev, RW).acc();
-      x.to(128, 128 + nh, d_tau + d.toff, snh).acc();
+      const int o1 = (nw + 15) / 16 * 16, o2 = o1 + 64;   // padded segment starts: [m1 nw | record 56 | temporal nh]
+      x.to(o1, o1 + rec::ZW, d_rec_prev, RW).acc();
+      x.to(o2, o2 + nh, d_tau + d.toff, snh).acc();
       CK(rundx(L_PRE, x, M));
     }
     // ---- C^T. crop #1 and its encoder

@@ -41,6 +41,8 @@ def make_config(F, img_hw):
             "(configs/mlp_mnist_model.py:86-87,125 pick Sonnet cells by name); got {}/{}/{}".format(
                 F.transition, F.time_transition, F.prior_transition))
     p = get_params(F)
+    if p.n_hidden not in (128, 256):
+        raise NotImplementedError("HIP path supports n_units 4 or 8 (n_hidden 128 / 256); got n_units={}".format(F.n_units))
     sp = parse_string_flag(F.scale_prior, num_elements=2)
     std = float(np.float32(np.float32(np.sqrt(F.output_std)) ** np.float32(2.0)))  # modules.py:419-422
     return _capi.SqairConfig(

@@ -67,6 +67,11 @@ def test_create_rejects_bad_config():
     cfg.n_steps_per_image = 0
     h = C.c_void_p()
     assert lib.sqair_create(C.byref(cfg), C.byref(h)) != 0
+    cfg = make_config(F, (50, 50))
+    cfg.n_hidden = 64          # n_units = 2: the row kernels are written for n_hidden 128 / 256
+    assert lib.sqair_create(C.byref(cfg), C.byref(h)) != 0
+    with pytest.raises(NotImplementedError):
+        make_config(make_flags(n_units=2), (50, 50))
 
 
 def test_flag_errors_mirror_reference():

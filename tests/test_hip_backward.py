@@ -232,7 +232,7 @@ def _full_backward_case(K, N, T, B, hw, seed, flags=None):
     m = Model(obs, None, core, K, outputs=names)
     ok = False
     for attempt in range(50):
-        noise = draw_noise(np.random.default_rng(100 + attempt), T, B * K, N, 55)
+        noise = draw_noise(np.random.default_rng(100 + attempt), T, B * K, N, 4 + int(F.n_what) + 1)
         orc = O.SqairOracle(P, O.make_cfg(F, hw), torch.float64, requires_grad=True)
         ref = orc.model(obs, noise)
         core.noise.copy_(torch.as_tensor(noise).reshape(core.noise.shape))
@@ -449,6 +449,19 @@ def test_full_backward_flag_variants(flags):
     feed back into z_{t-1}), geometric step prior, fixed where prior, unmasked glimpses, the LSTM temporal / prior / slot-RNN cells."""
     report, ref, _ = _full_backward_case(K=3, N=3, T=3, B=3, hw=(50, 50), seed=11, flags=flags)
     assert float(ref.prop_pres.detach().sum()) > 0
+    _check_report(report)
+
+
+@pytest.mark.parametrize("flags", [dict(n_units=4), dict(n_what=20), dict(n_what=7), dict(glimpse_size=12), dict(glimpse_size=28),
+                                   dict(n_units=4, n_what=7, glimpse_size=12)])
+def test_model_size_flags_forward_and_backward(flags):
+    """n_units (n_hidden = 32 * n_units; the reference's own --test_run uses n_units = 4, scripts/experiment.py:95), n_what and
+    glimpse_size other than the shipped 8 / 50 / 20: all outputs feeding the objective and every gradient against the oracle."""
+    report, ref, core = _full_backward_case(K=3, N=3, T=3, B=3, hw=(50, 50), seed=11, flags=flags)
+    assert float(ref.prop_pres.detach().sum()) > 0
+    lw = core.out["log_weights_per_timestep"].cpu().numpy()
+    want = ref.log_weights_per_timestep.detach().numpy()
+    assert np.abs(lw - want).max() <= 1e-4 * np.abs(want).max()
     _check_report(report)
 
 
