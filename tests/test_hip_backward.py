@@ -465,6 +465,18 @@ def test_model_size_flags_forward_and_backward(flags):
     _check_report(report)
 
 
+def test_scalar_hyper_parameter_flags_reach_the_kernels():
+    """output_std, scale_prior, prop_prior_step_bias, step_success_prob away from their defaults (with the priors that
+    read them: geometric step prior, fixed where prior): objective and gradients against the oracle."""
+    flags = dict(output_std=0.2, scale_prior="-1.5", prop_prior_step_bias=4.0, step_success_prob=0.6, disc_prior_type="geom",
+                 rec_where_prior=False, transform_var_bias=-2.0, output_scale=0.3, disc_step_bias=0.5, prop_step_bias=3.0)
+    report, ref, core = _full_backward_case(K=3, N=3, T=3, B=3, hw=(50, 50), seed=11, flags=flags)
+    lw = core.out["log_weights_per_timestep"].cpu().numpy()
+    want = ref.log_weights_per_timestep.detach().numpy()
+    assert np.abs(lw - want).max() <= 1e-4 * np.abs(want).max()
+    _check_report(report)
+
+
 @pytest.mark.parametrize("K,N,T,B,hw", [(2, 6, 2, 2, (50, 50)), (2, 3, 2, 2, (128, 128)), (4, 2, 3, 5, (40, 56))])
 def test_full_backward_other_shapes(K, N, T, B, hw):
     """N = 6 slots (BASELINE configs[3]), 128x128 frames (configs[4]: the frame no longer fits the default LDS window),
