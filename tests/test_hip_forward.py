@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 REL = 1e-4  # tolerance stated by north_star
 
 
-def _check_against(m, ref_out, ref_model, names, T):
+def _check_against(m, ref_out, ref_model, names, T, tol=5e-4):
     # discrete decisions first: exact
     for k in ("presence", "prop_pres", "disc_pres", "obj_id", "num_steps_per_sample"):
         if k in ref_out:
@@ -29,7 +29,7 @@ def _check_against(m, ref_out, ref_model, names, T):
         assert got.shape == ref.shape, (k, got.shape, ref.shape)
         scale = max(np.abs(ref).max(), 1.0)
         worst[k] = float(np.abs(got - ref).max() / scale)
-    bad = {k: v for k, v in worst.items() if v > 5e-4}
+    bad = {k: v for k, v in worst.items() if v > tol}
     assert not bad, bad
     for k in ("log_weights", "elbo_iwae_per_example"):
         assert rel_err(getattr(m, k).cpu().numpy(), ref_model[k]) < REL, k
@@ -60,7 +60,7 @@ def test_forward_matches_golden_fixture(name):
         assert abs(float(getattr(m, k)) - float(ref_model[k])) <= 1e-4 * max(1.0, abs(float(ref_model[k]))), k
 
 
-def _live_oracle_case(F, hw=(32, 40), T=3, B=3):
+def _live_oracle_case(F, hw=(32, 40), T=3, B=3, tol=5e-4):
     K, N = int(F.k_particles), int(F.n_steps_per_image)
     d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=20, seed=9)
     obs = to_float(d["imgs"])
@@ -75,7 +75,7 @@ def _live_oracle_case(F, hw=(32, 40), T=3, B=3):
     ref_out = {k: v.numpy() for k, v in ref.outputs.items() if not k.startswith("_")}
     ref_model = {k: getattr(ref, k).numpy() for k in ("log_weights", "elbo_iwae_per_example", "elbo_vae", "elbo_iwae",
                                                       "data_ll", "kl", "log_p_z", "log_q_z_given_x")}
-    _check_against(m, ref_out, ref_model, list(ref_out), T)
+    _check_against(m, ref_out, ref_model, list(ref_out), T, tol)
     return m, ref
 
 
@@ -128,6 +128,15 @@ def test_forward_lstm_temporal_cell_vs_live_oracle(K, N, T, B):
     want = ref.outputs["_final_temporal_state"].numpy()
     assert got.shape == want.shape and got.shape[-1] == 512
     assert np.abs(got - want).max() < 5e-4 * max(1.0, np.abs(want).max())
+
+
+def test_long_sequence_vs_live_oracle():
+    """T = 30 frames (the reference README runs its model on 100-frame sequences): 3x the unroll length of BASELINE's
+    configurations, objects entering and leaving; all outputs against the oracle.  fp32 rounding compounds through 30
+    recurrent frames: per-output tolerance 3e-3 of the output's scale (the ELBO terms stay within 1e-4 relative)."""
+    F = make_flags(k_particles=2, n_steps_per_image=3)
+    m, ref = _live_oracle_case(F, hw=(50, 50), T=30, B=2, tol=3e-3)
+    assert float(ref.prop_pres.sum()) > 10
 
 
 def test_cfg2_full_size_properties():
