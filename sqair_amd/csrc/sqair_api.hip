@@ -484,7 +484,7 @@ extern "C" int sqair_create(const SqairConfig* cfg, SqairHandle** out) {
   if (cfg->n_what < 1 || cfg->n_what > 50 || cfg->n_steps_per_image < 1 || cfg->n_steps_per_image > SQ_MAXN ||
       (cfg->n_hidden != 128 && cfg->n_hidden != 256) ||  // n_units 4 / 8 (row kernels read nh / 32 floats per lane as float4;
       cfg->glimpse_size < 2 ||                           //  slot buffers are laid out for nh <= 256)
-      cfg->img_h < 2 || cfg->img_w < 2 ||
+      cfg->img_h < 2 || cfg->img_w < 2 || ((cfg->img_h * cfg->img_w) % 4) != 0 ||  // frame rows are float4 GEMM operands
       cfg->k_particles < 1 || cfg->k_particles > 64)
     return -1;
   SqairHandle* h = new SqairHandle();

@@ -72,6 +72,8 @@ def test_create_rejects_bad_config():
     assert lib.sqair_create(C.byref(cfg), C.byref(h)) != 0
     with pytest.raises(NotImplementedError):
         make_config(make_flags(n_units=2), (50, 50))
+    with pytest.raises(NotImplementedError):
+        make_config(F, (37, 41))   # H * W must be a multiple of 4
 
 
 def test_flag_errors_mirror_reference():

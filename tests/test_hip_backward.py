@@ -24,7 +24,7 @@ def _handle(K, N, hw):
     return lib, h, F
 
 
-@pytest.mark.parametrize("hw", [(50, 50), (128, 128), (33, 47)])
+@pytest.mark.parametrize("hw", [(50, 50), (128, 128), (33, 48)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_st_crop_backward(hw, masked):
     lib, h, F = _handle(3, 4, hw)
@@ -477,7 +477,7 @@ def test_scalar_hyper_parameter_flags_reach_the_kernels():
     _check_report(report)
 
 
-@pytest.mark.parametrize("K,N,T,B,hw", [(2, 6, 2, 2, (50, 50)), (2, 3, 2, 2, (128, 128)), (4, 2, 3, 5, (40, 56))])
+@pytest.mark.parametrize("K,N,T,B,hw", [(2, 6, 2, 2, (50, 50)), (2, 3, 2, 2, (128, 128)), (4, 2, 3, 5, (40, 56)), (3, 3, 2, 3, (37, 44))])
 def test_full_backward_other_shapes(K, N, T, B, hw):
     """N = 6 slots (BASELINE configs[3]), 128x128 frames (configs[4]: the frame no longer fits the default LDS window),
     a non-square frame with B*K not a multiple of the 16-row MFMA tile."""
