@@ -54,8 +54,8 @@ typedef struct SqairConfig {
   float where_prior_mean[4];     /* scale_prior x2, 0, 0 (non-recurrent where prior only)        */
   int32_t sample_from_prior;     /* flag sample_from_prior (mlp_mnist_model.py:51): needs sqair_set_generation_noise */
   int32_t generate_after;        /* SequentialAIR(generate_after=..) (seq.py:46, :198-200); <= 0: never generate     */
-  int32_t time_lstm;             /* flag time_transition: 0 = GRU (shipped), 1 = LSTM (common_model_flags.py:49)    */
-  int32_t prior_lstm;            /* flag prior_transition: 0 = GRU (shipped), 1 = LSTM (mlp_mnist_model.py:125)     */
+  int32_t time_cell;             /* flag time_transition: 0 = GRU (shipped), 1 = LSTM, 2 = VanillaRNN (common_model_flags.py:49) */
+  int32_t prior_cell;            /* flag prior_transition: 0 = GRU (shipped), 1 = LSTM, 2 = VanillaRNN (mlp_mnist_model.py:125)  */
   int32_t rnn_cell;              /* flag transition (slot RNN of both cores): 0 = VanillaRNN (shipped), 1 = LSTM, 2 = GRU */
 } SqairConfig;
 

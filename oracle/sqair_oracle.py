@@ -316,8 +316,8 @@ class SqairOracle(object):
     def __init__(self, params, cfg, dtype=torch.float64, requires_grad=False):
         self.cfg = cfg
         self.dtype = dtype
-        if cfg.transition not in ("VanillaRNN", "GRU", "LSTM") or cfg.time_transition not in ("GRU", "LSTM") or cfg.prior_transition not in ("GRU", "LSTM"):
-            raise NotImplementedError("oracle restates transition in {VanillaRNN, GRU, LSTM}, time_transition / prior_transition in {GRU, LSTM}")
+        if cfg.transition not in ("VanillaRNN", "GRU", "LSTM") or cfg.time_transition not in ("VanillaRNN", "GRU", "LSTM") or cfg.prior_transition not in ("VanillaRNN", "GRU", "LSTM"):
+            raise NotImplementedError("oracle restates transition / time_transition / prior_transition in {VanillaRNN, GRU, LSTM}")
         if cfg.prop_prior_type not in ("rnn", "rw", "guided"):
             raise ValueError('Invalid prior type: "{}"'.format(cfg.prop_prior_type))  # propagate.py:42-43
         if cfg.disc_prior_type not in ("cat", "geom"):
@@ -377,7 +377,7 @@ class SqairOracle(object):
             h, c2 = lstm(self.P, "prop.prior_lstm", x, ps[:, :nh], ps[:, nh:])
             new_state = torch.cat([h, c2], -1).reshape(B, N, -1)
         else:
-            h = gru(self.P, "prop.prior_gru", x, ps)
+            h = vanilla_rnn(self.P, "prop.prior_rnn", x, ps) if c.prior_transition == "VanillaRNN" else gru(self.P, "prop.prior_gru", x, ps)
             new_state = h.reshape(B, N, -1)
         stats = linear(self.P, "prop.prior_linear", h).reshape(B, N, -1)
         logit = stats[..., :1] + c.prop_prior_step_bias
@@ -440,6 +440,8 @@ class SqairOracle(object):
         if lstm_time:
             temporal_out, cell_new = lstm(P, "prop.temporal_lstm", cell_inpt, temporal_full[..., :c.n_hidden], temporal_state)
             temporal_new = torch.cat([temporal_out, cell_new], -1)
+        elif c.time_transition == "VanillaRNN":
+            temporal_new = temporal_out = vanilla_rnn(P, "prop.temporal_rnn", cell_inpt, temporal_state)
         else:
             temporal_new = temporal_out = gru(P, "prop.temporal_gru", cell_inpt, temporal_state)
         t_loc, t_scale = self.gaussian_head("prop.what_head", temporal_out)

@@ -33,7 +33,7 @@ class SqairConfig(C.Structure):
         ("masked_glimpse", C.c_int32), ("rec_where_prior", C.c_int32),
         ("prop_prior_step_bias", C.c_float), ("step_success_prob", C.c_float), ("output_std", C.c_float),
         ("background_std", C.c_float), ("where_prior_mean", C.c_float * 4),
-        ("sample_from_prior", C.c_int32), ("generate_after", C.c_int32), ("time_lstm", C.c_int32), ("prior_lstm", C.c_int32), ("rnn_cell", C.c_int32),
+        ("sample_from_prior", C.c_int32), ("generate_after", C.c_int32), ("time_cell", C.c_int32), ("prior_cell", C.c_int32), ("rnn_cell", C.c_int32),
     ]
 
 

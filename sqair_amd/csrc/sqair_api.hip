@@ -96,10 +96,16 @@ static void build_inventory(SqairHandle* h) {
   }
   add_param(h, "disc.step_prior_bias", 1, N + 1);
   add_param(h, "disc.step_prior_timestep_bias", 1, N + 1);
-  if (c.time_lstm) add_lin(h, "prop.temporal_lstm", (nh + 4 + 2 * nw) + nh, 4 * nh);  // snt.LSTM: w_gates [x | h] rows, b_gates
-  else add_gru(h, "prop.temporal_gru", nh + 4 + 2 * nw, nh);
-  if (c.prior_lstm) add_lin(h, "prop.prior_lstm", (nw + 4) + nh, 4 * nh);
-  else add_gru(h, "prop.prior_gru", nw + 4, nh);
+  if ((c.time_cell == CELL_LSTM)) add_lin(h, "prop.temporal_lstm", (nh + 4 + 2 * nw) + nh, 4 * nh);  // snt.LSTM: w_gates [x | h] rows, b_gates
+  else if (c.time_cell == CELL_VANILLA) {  // snt.VanillaRNN: tanh(in_to_hidden(x) + hidden_to_hidden(h))
+    add_lin(h, "prop.temporal_rnn.h2h", nh, nh);
+    add_lin(h, "prop.temporal_rnn.i2h", nh + 4 + 2 * nw, nh);
+  } else add_gru(h, "prop.temporal_gru", nh + 4 + 2 * nw, nh);
+  if ((c.prior_cell == CELL_LSTM)) add_lin(h, "prop.prior_lstm", (nw + 4) + nh, 4 * nh);
+  else if (c.prior_cell == CELL_VANILLA) {
+    add_lin(h, "prop.prior_rnn.h2h", nh, nh);
+    add_lin(h, "prop.prior_rnn.i2h", nw + 4, nh);
+  } else add_gru(h, "prop.prior_gru", nw + 4, nh);
   add_lin(h, "prop.prior_linear", nh, 2 * (4 + nw) + 1);
   add_param(h, "prop.cholesky_scale", 1, 10);
   add_lin(h, "prop.where_bias.l0", nh, 128);
@@ -123,9 +129,9 @@ static void build_inventory(SqairHandle* h) {
     add_lin(h, "prop.rnn.i2h", nw + (nw + 5) + (nw + 5) + nh, nh);
   }
   add_param(h, "seq.prior_init", 1, nh);
-  if (c.prior_lstm) add_param(h, "seq.prior_init_c", 1, nh);
+  if ((c.prior_cell == CELL_LSTM)) add_param(h, "seq.prior_init_c", 1, nh);
   add_param(h, "seq.temporal_init", 1, nh);
-  if (c.time_lstm) add_param(h, "seq.temporal_init_c", 1, nh);  // LSTMState(hidden, cell): adjacent, read as one [2 nh] row
+  if ((c.time_cell == CELL_LSTM)) add_param(h, "seq.temporal_init_c", 1, nh);  // LSTMState(hidden, cell): adjacent, read as one [2 nh] row
   add_lin(h, "seq.latent_enc.l0", nw + 4, nh);
   add_lin(h, "seq.latent_enc.l1", nh, nh);
 
@@ -307,13 +313,20 @@ static void build_plan(SqairHandle* h) {
   };
   build_layer(h, L_PREDISC, {nh}, rnn_blocks("disc", {rm_range(0, nh)}, -1, true, fin_d));
   // prior cell on [what, where]_{t-1} (propagate.py:78-81)
-  if (c.prior_lstm) {  // gates (i, j, f, o) = [what, where | h] w_gates + b_gates in ONE layer (both inputs exist up front)
+  if ((c.prior_cell == CELL_LSTM)) {  // gates (i, j, f, o) = [what, where | h] w_gates + b_gates in ONE layer (both inputs exist up front)
     ColBlock b;
     b.ncols = 4 * nh; b.col0 = 0;
     b.seg = {{"prop.prior_lstm.w", rm_zrec(nw, nw, 0, -1)}, {"prop.prior_lstm.w", rm_range(nw + 4, nh)}};
     b.bias_a = "prop.prior_lstm.b";
     build_layer(h, L_PRIOR_GRU1, {rec::ZW, nh}, {b});
     build_layer(h, L_PRIOR_GRU2, {nh}, {cb1(16, 0, "prop.prior_lstm.w", rm_none(nh))});  // unused placeholder layer
+  } else if (c.prior_cell == CELL_VANILLA) {  // tanh([what, where] W_i + h W_h + b_i + b_h): one layer
+    ColBlock b;
+    b.ncols = nh; b.col0 = 0;
+    b.seg = {{"prop.prior_rnn.i2h.w", rm_zrec(nw, nw, 0, -1)}, {"prop.prior_rnn.h2h.w", rm_range(0, nh)}};
+    b.bias_a = "prop.prior_rnn.i2h.b"; b.bias_b = "prop.prior_rnn.h2h.b";
+    build_layer(h, L_PRIOR_GRU1, {rec::ZW, nh}, {b});
+    build_layer(h, L_PRIOR_GRU2, {nh}, {cb1(16, 0, "prop.prior_rnn.h2h.w", rm_none(nh))});  // unused placeholder layer
   } else {
     const RowMap zx = rm_zrec(nw, nw, 0, -1);
     std::vector<ColBlock> bl;
@@ -357,8 +370,15 @@ static void build_plan(SqairHandle* h) {
     s1.seg = {{"", RowMap()}, {"", RowMap()}, {"prop.steps.l0.w", rm_range(nh, nh)}};
     s1.bias_a = "prop.steps.l0.b";
     bl.push_back(s1);
+    if (c.time_cell == CELL_VANILLA) {  // the whole recurrent term of the temporal VanillaRNN is loop-invariant
+      ColBlock u;
+      u.ncols = nh; u.col0 = 0;
+      u.seg = {{"", RowMap()}, {"", RowMap()}, {"prop.temporal_rnn.h2h.w", rm_range(0, nh)}};
+      u.bias_a = "prop.temporal_rnn.i2h.b"; u.bias_b = "prop.temporal_rnn.h2h.b";
+      bl.push_back(u);
+    }
     for (const char* g : {"z", "r"}) {
-      if (c.time_lstm) break;  // the LSTM's recurrent rows read the HIDDEN half of the state: their own layer below
+      if (c.time_cell != CELL_GRU) break;  // (the LSTM's recurrent rows read the HIDDEN half of the state: their own layer below)
       ColBlock u;
       u.ncols = nh; u.col0 = 0;
       u.seg = {{"", RowMap()}, {"", RowMap()}, {std::string("prop.temporal_gru.u") + g, rm_range(0, nh)}};
@@ -378,7 +398,7 @@ static void build_plan(SqairHandle* h) {
               {cb1(nh, 0, "prop.transform.l0.w", rm_range(0, nh)), cb1(nsp, 0, "prop.steps.l0.w", rm_range(0, nh))});
   simple(L_PROP_T2, "prop.transform.l1", nh, nh);
   simple(L_PROP_T3, "prop.transform.l2", nh, 8);
-  if (c.time_lstm) {
+  if ((c.time_cell == CELL_LSTM)) {
     // temporal LSTM (core.py:340-341 with time_transition=LSTM): gate pre-activations (i, j, f, o) = [x | h] w_gates + b.
     // L_PROP_GRU1 holds the x rows [hidden nh | where 4 | loc nw | scale nw], L_PROP_GRU2 the h rows + bias (applied to
     // all slots of a frame at once, before the slot loop).
@@ -389,6 +409,13 @@ static void build_plan(SqairHandle* h) {
     b.seg = {{w, rm_range(0, nh)}, {w, rm_range(nh, 4)}, {w, rm_range(nh + 4, 2 * nw)}};
     build_layer(h, L_PROP_GRU1, {nh, 4, 2 * nw}, {b});
     build_layer(h, L_PROP_GRU2, {nh}, {cb1(4 * nh, 0, w, rm_range(fin, nh), "prop.temporal_lstm.b")});
+  } else if (c.time_cell == CELL_VANILLA) {
+    const std::string w = "prop.temporal_rnn.i2h.w";
+    ColBlock b;
+    b.ncols = nh; b.col0 = 0;
+    b.seg = {{w, rm_range(0, nh)}, {w, rm_range(nh, 4)}, {w, rm_range(nh + 4, 2 * nw)}};
+    build_layer(h, L_PROP_GRU1, {nh, 4, 2 * nw}, {b});
+    build_layer(h, L_PROP_GRU2, {nh}, {cb1(16, 0, "prop.temporal_rnn.h2h.w", rm_none(nh))});  // unused placeholder layer
   } else {
     // temporal GRU input [hidden nh | where 4 | loc nw | scale nw] (core.py:340-341)
     std::vector<ColBlock> bl;
@@ -491,12 +518,12 @@ extern "C" int sqair_create(const SqairConfig* cfg, SqairHandle** out) {
   h->cfg = *cfg;
   build_inventory(h);
   // GRU candidate matrices are bare [nh, nh] parameters: give build_plan's simple() a ".w" alias
-  if (!cfg->prior_lstm) h->pidx["prop.prior_gru.uh.w"] = h->pidx["prop.prior_gru.uh"];
+  if (cfg->prior_cell == CELL_GRU) h->pidx["prop.prior_gru.uh.w"] = h->pidx["prop.prior_gru.uh"];
   if (cfg->rnn_cell == RNN_GRU) {
     h->pidx["prop.rnn_gru.uh.w"] = h->pidx["prop.rnn_gru.uh"];
     h->pidx["disc.rnn_gru.uh.w"] = h->pidx["disc.rnn_gru.uh"];
   }
-  if (!cfg->time_lstm) h->pidx["prop.temporal_gru.uh.w"] = h->pidx["prop.temporal_gru.uh"];
+  if (cfg->time_cell == CELL_GRU) h->pidx["prop.temporal_gru.uh.w"] = h->pidx["prop.temporal_gru.uh"];
   build_plan(h);
   build_plan_T(h);
   *out = h;
@@ -566,9 +593,9 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   Workspace w;
   memset(&w, 0, sizeof(w));
   w.train = train; w.T = T; w.B = B; w.R = (int)R; w.M = (int)M; w.N = (int)N; w.nh = (int)nh;
-  const int64_t snh = c.time_lstm ? 2 * nh : nh;  // temporal state of a slot: [hidden | cell] for the LSTM
+  const int64_t snh = (c.time_cell == CELL_LSTM) ? 2 * nh : nh;  // temporal state of a slot: [hidden | cell] for the LSTM
   w.snh = (int)snh;
-  const int64_t psnh = c.prior_lstm ? 2 * nh : nh;
+  const int64_t psnh = (c.prior_cell == CELL_LSTM) ? 2 * nh : nh;
   w.psnh = (int)psnh;
   int64_t o = 0;
   auto take = [&](int64_t n) {
@@ -598,7 +625,7 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.w3_disc = take(nh * 8 + 8);
   w.temporal_p = take(F * M * snh);
   w.prior_p = take(F * M * psnh);
-  w.pgz = take(F * M * (c.prior_lstm ? 4 * nh : nh));  // GRU: z gate; LSTM: the four gate pre-activations
+  w.pgz = take(F * M * ((c.prior_cell == CELL_LSTM) ? 4 * nh : nh));  // GRU: z gate; LSTM: the four gate pre-activations
   w.pgr = take(F * M * nh);
   w.pghc = take(F * M * nh);
   w.pgrh = take(M * nh);
@@ -635,8 +662,8 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.grh = take(R * nh);
   w.gxh = take(R * nh);
   // LSTM: recurrent gate pre-activations of all slots of a frame, and the kept gate pre-activations per slot
-  w.lpre = take(c.time_lstm ? M * 4 * nh : 64);
-  w.lgates = take(c.time_lstm ? (train ? (int64_t)T * N : 1) * R * 4 * nh : 64);
+  w.lpre = take((c.time_cell == CELL_LSTM) ? M * 4 * nh : 64);
+  w.lgates = take((c.time_cell == CELL_LSTM) ? (train ? (int64_t)T * N : 1) * R * 4 * nh : 64);
   w.src = (int*)take(train ? (int64_t)T * M : 64);
   w.qz = take((int64_t)T * R);
   w.pz = take((int64_t)T * R);
@@ -803,11 +830,14 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     float* cvec = w.frame(w.c, (int64_t)R * nh, t);
 
     // ---- A. propagation prior (propagate.py:68-98): GRU over [what, where]_{t-1}, all slots ----
-    if (c.prior_lstm) {
+    if ((c.prior_cell == CELL_LSTM)) {
       float* pg = w.frame(w.pgz, (int64_t)M * 4 * nh, t);
       Lin g; g.seg(rec_prev, RW, rec::ZW).seg(prior_prev, psnh, nh).out(pg, 4 * nh); RUN(g, L_PRIOR_GRU1, M);
       sq_launch_lstm_cell(pg, 4 * nh, prior_prev + nh, psnh, prior_p, psnh, M, nh, s);
       Lin pll; pll.seg(prior_p, psnh, nh).out(pstats_t, PS_LD); RUN(pll, L_PRIOR_LIN, M);
+    } else if (c.prior_cell == CELL_VANILLA) {
+      Lin g; g.seg(rec_prev, RW, rec::ZW).seg(prior_prev, nh, nh).out(prior_p, nh).act(ACT_TANH); RUN(g, L_PRIOR_GRU1, M);
+      Lin pll; pll.seg(prior_p, nh, nh).out(pstats_t, PS_LD); RUN(pll, L_PRIOR_LIN, M);
     } else {
       float* pgz = w.frame(w.pgz, (int64_t)M * nh, t);
       Lin g1l; g1l.seg(rec_prev, RW, rec::ZW).seg(prior_prev, nh, nh).out(pgz, nh)
@@ -839,7 +869,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     {
       Lin p; p.seg(m1, M1_LD, nw).seg(rec_prev, RW, rec::ZW).seg(tau_prev, snh, nh).out(w.pre, pre_ld);
       RUN(p, L_PRE, M);
-      if (c.time_lstm) {  // recurrent rows of the LSTM gates: h_{t-1} W_h + b of every slot
+      if ((c.time_cell == CELL_LSTM)) {  // recurrent rows of the LSTM gates: h_{t-1} W_h + b of every slot
         Lin q; q.seg(temporal_prev, snh, nh).out(w.lpre, 4 * nh); RUN(q, L_PROP_GRU2, M);
       }
     }
@@ -902,7 +932,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         Lin b; b.seg(e1, rl, nh).out(e2, rl).act(ACT_ELU); RUN(b, L_GENC1, R);
         Lin e; e.seg(e2, rl, nh).out(enc, el).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
       }
-      if (c.time_lstm) {
+      if ((c.time_cell == CELL_LSTM)) {
         float* gates = train ? w.lgates + ((size_t)t * M + k) * 4 * nh : w.lgates;
         const int gld = train ? N * 4 * nh : 4 * nh;
         Lin gl; gl.seg(r_k, rl, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(enc, el, 2 * nw)
@@ -910,6 +940,11 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         RUN(gl, L_PROP_GRU1, R);
         sq_launch_lstm_cell(gates, gld, tau_prev + (size_t)k * snh, N * snh, temporal_p + (size_t)k * snh, N * snh, R, nh, s);
         Lin hd; hd.seg(temporal_p + (size_t)k * snh, N * snh, nh).out(hraw, hl); RUN(hd, L_PROP_HEADS, R);
+      } else if (c.time_cell == CELL_VANILLA) {  // tau' = tanh(x W_i + [tau W_h + b, hoisted into `pre`]) in one launch
+        Lin g; g.seg(r_k, rl, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(enc, el, 2 * nw)
+                 .add(pre_k + rw + nh + nh / 2, pre_rld, nh).out(temporal_p + (size_t)k * nh, N * nh).act(ACT_TANH);
+        RUN(g, L_PROP_GRU1, R);
+        Lin hd; hd.seg(temporal_p + (size_t)k * nh, N * nh, nh).out(hraw, hl); RUN(hd, L_PROP_HEADS, R);
       } else {
         const float* tau_k = temporal_prev + (size_t)k * nh;
         Lin g1l; g1l.seg(r_k, rl, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(enc, el, 2 * nw)
@@ -1091,7 +1126,7 @@ extern "C" int sqair_forward_persistent(SqairHandle* h, const float* flat_params
                                         void* stream) {
   if (!h || !out || !program) return -1;
   hipStream_t s = (hipStream_t)stream;
-  if (h->cfg.time_lstm || h->cfg.prior_lstm || h->cfg.rnn_cell) {
+  if (h->cfg.time_cell != CELL_GRU || h->cfg.prior_cell != CELL_GRU || h->cfg.rnn_cell != RNN_VANILLA) {
     sq_set_error(h, "sqair_forward_persistent: the experimental persistent executor covers the GRU cells only");
     return -1;
   }

@@ -24,14 +24,17 @@ struct Dims {
   int psnh;                         // width of the propagation prior's recurrent state: nh (GRU) or 2 nh (LSTM)
   int rsnh;                         // width of the slot RNN's trainable initial state: nh (VanillaRNN) or 2 nh (LSTM)
 };
-enum { RNN_VANILLA = 0, RNN_LSTM = 1, RNN_GRU = 2 };  // SqairConfig.rnn_cell (flag transition)
+enum { RNN_VANILLA = 0, RNN_LSTM = 1, RNN_GRU = 2 };    // SqairConfig.rnn_cell (flag transition)
+enum { CELL_GRU = 0, CELL_LSTM = 1, CELL_VANILLA = 2 };  // SqairConfig.time_cell / .prior_cell (flags time_transition / prior_transition)
 // pre-activation columns of the slot RNN: nh (VanillaRNN), the four LSTM gates, or the GRU's [z | r | candidate]
 inline int sq_rnn_width(const SqairConfig& c) { return c.n_hidden * (c.rnn_cell == RNN_LSTM ? 4 : (c.rnn_cell == RNN_GRU ? 3 : 1)); }
+// gate pre-activation columns of the temporal / prior cell: 3 nh (GRU: z, r, candidate), 4 nh (LSTM), nh (VanillaRNN)
+inline int sq_gate_width(const SqairConfig& c, int cell) { return c.n_hidden * (cell == CELL_LSTM ? 4 : (cell == CELL_VANILLA ? 1 : 3)); }
 inline Dims make_dims(const SqairConfig& c, int B) {
-  const int lstm = c.time_lstm != 0;
+  const int lstm = (c.time_cell == CELL_LSTM) != 0;
   return Dims{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles, B * c.k_particles, B,
               4 + c.n_what + 1, lstm ? 2 * c.n_hidden : c.n_hidden, lstm ? c.n_hidden : 0,
-              c.prior_lstm ? 2 * c.n_hidden : c.n_hidden, c.rnn_cell == RNN_LSTM ? 2 * c.n_hidden : c.n_hidden};
+              (c.prior_cell == CELL_LSTM) ? 2 * c.n_hidden : c.n_hidden, c.rnn_cell == RNN_LSTM ? 2 * c.n_hidden : c.n_hidden};
 }
 
 enum CropMode { CROP_PLAIN = 0, CROP_PROP1 = 1, CROP_PROP2 = 2, CROP_DISC = 3 };

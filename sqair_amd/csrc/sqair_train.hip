@@ -114,8 +114,8 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   };
   b.g_lw = take(T * R); b.g_dl = take(T * R);
   b.d_rec_m = take((T + 1) * M * rec::W); b.d_rec_p = take(MT * rec::W); b.d_rec_d = take(MT * rec::W);
-  const int64_t snh = c.time_lstm ? 2 * nh : nh, gw = c.time_lstm ? 4 * nh : 3 * nh;  // temporal state / gate widths
-  const int64_t psnh = c.prior_lstm ? 2 * nh : nh, pgw = c.prior_lstm ? 4 * nh : 3 * nh;
+  const int64_t snh = (c.time_cell == CELL_LSTM) ? 2 * nh : nh, gw = sq_gate_width(c, c.time_cell);  // temporal state / gate widths
+  const int64_t psnh = (c.prior_cell == CELL_LSTM) ? 2 * nh : nh, pgw = sq_gate_width(c, c.prior_cell);
   const int64_t rw = sq_rnn_width(c);  // slot-RNN pre-activation width
   for (int i = 0; i < 2; ++i) { b.d_tm[i] = take(M * snh); b.d_pm[i] = take(M * psnh); }
   b.d_temporal_p = take(M * snh); b.d_prior_p = take(M * psnh);
@@ -164,7 +164,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   const int R = B * K, M = R * N, MT = M * T, G2 = c.glimpse_size * c.glimpse_size, P_ = c.img_h * c.img_w;
   const int nzw = 4 + nw + 1, RW = rec::W, nsp = nh / 2;
   Dims d = make_dims(c, B);
-  const int snh = d.snh, gw = c.time_lstm ? 4 * nh : 3 * nh, psnh = d.psnh, pgw = c.prior_lstm ? 4 * nh : 3 * nh;
+  const int snh = d.snh, gw = sq_gate_width(c, c.time_cell), psnh = d.psnh, pgw = sq_gate_width(c, c.prior_cell);
   const int rw = sq_rnn_width(c);  // slot-RNN pre-activation width; d_pre columns [rnn rw | T1 nh | S1 nsp | GRU z, r]
   const POff po = h->po;
   const Workspace w = sq_carve(h, T, B, (float*)train_workspace, true);
@@ -423,8 +423,16 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         sq_launch_slot_tail_bwd(ta, d, s);
       }
       // heads -> d tau'_k (the new HIDDEN state), + what the compaction sent back for this slot's new temporal state
-      { Dx x(d_hraw, hl); x.to(0, nh, b.dhn, nh).add(b.d_temporal_p + (size_t)k * snh, N * snh); CK(rundx(L_PROP_HEADS, x, R)); }
-      if (c.time_lstm) {
+      if (c.time_cell == CELL_VANILLA) {  // tanh' folded into the same launch; second copy: the hoisted recurrent block of d_pre
+        Dx x(d_hraw, hl);
+        x.to(0, nh, d_gru1, g1l).add(b.d_temporal_p + (size_t)k * nh, N * nh)
+            .dact(w.frame(w.temporal_p, (int64_t)M * nh, t) + (size_t)k * nh, N * nh, ACT_TANH).dup(d_pre_k + rw + nh + nsp, pre_rld);
+        CK(rundx(L_PROP_HEADS, x, R));
+      } else {
+        Dx x(d_hraw, hl); x.to(0, nh, b.dhn, nh).add(b.d_temporal_p + (size_t)k * snh, N * snh); CK(rundx(L_PROP_HEADS, x, R));
+      }
+      if (c.time_cell == CELL_VANILLA) {
+      } else if ((c.time_cell == CELL_LSTM)) {
         // cell adjoint: gate pre-activation gradients (kept for the batched weight gradients and the recurrent-rows dX
         // after the slot loop) and d c_{t-1} -- the first writer of the cell half of d_tau (sections D^T / B^T accumulate)
         sq_launch_lstm_cell_bwd(w.lgates + ((size_t)t * M + k) * 4 * nh, N * 4 * nh, tau_k + nh, N * snh, b.dhn, nh,
@@ -496,7 +504,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     }
     // ---- D^T. the loop-invariant pre-activation GEMM: segments [m1 nw (pad 64) | z_{t-1} record 56 (pad 64) | temporal nh]
     float* d_m1 = b.d_m1 + (size_t)t * M * M1_LD;
-    if (c.time_lstm) {  // recurrent rows of the LSTM gates, all slots at once: d h_{t-1} = d gates W_h^T (first writer)
+    if ((c.time_cell == CELL_LSTM)) {  // recurrent rows of the LSTM gates, all slots at once: d h_{t-1} = d gates W_h^T (first writer)
       Dx x(b.d_gru1 + (size_t)t * M * gw, gw); x.to(0, nh, d_tau, snh); CK(rundx(L_PROP_GRU2, x, M));
     }
     {
@@ -536,8 +544,17 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     }
     // ---- A^T. prior cell
     float* d_pgru1 = b.d_pgru1 + (size_t)t * M * pgw;
+    if (c.prior_cell == CELL_VANILLA) {
+      { Dx x(b.d_pstats + (size_t)t * M * PS_LD, PS_LD);
+        x.to(0, nh, d_pgru1, pgw).add(b.d_prior_p, nh).dact(w.frame(w.prior_p, (int64_t)M * nh, t), nh, ACT_TANH);
+        CK(rundx(L_PRIOR_LIN, x, M)); }
+      Dx x(d_pgru1, pgw);   // [z_{t-1} record 56 (pad 64) | previous state nh]
+      x.to(0, rec::ZW, d_rec_prev, RW).acc();
+      x.to(64, 64 + nh, d_pprev, nh);
+      CK(rundx(L_PRIOR_GRU1, x, M));
+    } else {
     { Dx x(b.d_pstats + (size_t)t * M * PS_LD, PS_LD); x.to(0, nh, b.dhn, nh).add(b.d_prior_p, psnh); CK(rundx(L_PRIOR_LIN, x, M)); }
-    if (c.prior_lstm) {
+    if ((c.prior_cell == CELL_LSTM)) {
       sq_launch_lstm_cell_bwd(w.frame(w.pgz, (int64_t)M * 4 * nh, t), 4 * nh, prior_prev + nh, psnh, b.dhn, nh, b.d_prior_p + nh, psnh,
                               d_pgru1, pgw, d_pprev + nh, psnh, M, nh, s);
       Dx x(d_pgru1, pgw);   // [z_{t-1} record 56 (pad 64) | previous hidden state nh]
@@ -555,6 +572,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         x.to(64, 64 + nh, d_pprev, nh).acc();
         CK(rundx(L_PRIOR_GRU1, x, M));
       }
+    }
     }
   }
   // ================= initial states, input encoder =================
@@ -577,7 +595,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     const float* pm_all = w.prior_m;
     // prior GRU
     wgrad(L_PRIOR_GRU1, {{w.rec_m_all, RW}, {pm_all, psnh}}, b.d_pgru1, pgw, MT);
-    if (!c.prior_lstm) {
+    if (c.prior_cell == CELL_GRU) {
       hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.pgr, nh, pm_all, nh, b.rh, nh, MT, nh);
       wgrad(L_PRIOR_GRU2, {{b.rh, nh}}, b.d_pgru1 + 2 * nh, 3 * nh, MT);
     }
@@ -606,9 +624,9 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     wgrad(L_PROP_T2, {{w.t1, T1_LD}}, b.d_t2, nh, MT);
     wgrad(L_PROP_T3, {{w.t2, nh}}, b.d_tp, TP_LD, MT);
     wgrad(L_PROP_GRU1, {{w.r, nh}, {w.rec_p_all + rec::WHERE, RW}, {w.enc, ENC_LD}}, b.d_gru1, gw, MT);
-    if (c.time_lstm) {
+    if ((c.time_cell == CELL_LSTM)) {
       wgrad(L_PROP_GRU2, {{tm_all, snh}}, b.d_gru1, gw, MT);   // recurrent rows + b_gates: A = h_{t-1}
-    } else {
+    } else if (c.time_cell == CELL_GRU) {
       hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.gr, nh, tm_all, nh, b.rh, nh, MT, nh);
       wgrad(L_PROP_GRU2, {{b.rh, nh}}, b.d_gru1 + 2 * nh, 3 * nh, MT);
     }

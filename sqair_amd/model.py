@@ -34,10 +34,10 @@ def make_config(F, img_hw):
         raise ValueError('Invalid prior type: "{}". Choose from {}.'.format(F.prop_prior_type, list(_PRIOR_TYPES)))
     if F.disc_prior_type not in _DISC_PRIOR_TYPES:
         raise ValueError("Invalid prior type: {}".format(F.disc_prior_type))
-    if F.transition not in ("VanillaRNN", "LSTM", "GRU") or F.time_transition not in ("GRU", "LSTM") or \
-            F.prior_transition not in ("GRU", "LSTM"):
+    cells = ("VanillaRNN", "GRU", "LSTM")
+    if F.transition not in cells or F.time_transition not in cells or F.prior_transition not in cells:
         raise NotImplementedError(
-            "HIP path implements transition in {{VanillaRNN, GRU, LSTM}}, time_transition and prior_transition in {{GRU, LSTM}} "
+            "HIP path implements transition, time_transition and prior_transition in {{VanillaRNN, GRU, LSTM}} "
             "(configs/mlp_mnist_model.py:86-87,125 pick Sonnet cells by name); got {}/{}/{}".format(
                 F.transition, F.time_transition, F.prior_transition))
     p = get_params(F)
@@ -53,8 +53,8 @@ def make_config(F, img_hw):
         int(p.n_hidden), int(F.k_particles), _PRIOR_TYPES[F.prop_prior_type], _DISC_PRIOR_TYPES[F.disc_prior_type],
         int(bool(F.masked_glimpse)), int(bool(F.rec_where_prior)), float(F.prop_prior_step_bias),
         float(F.step_success_prob), std, std, (C.c_float * 4)(sp[0], sp[1], 0.0, 0.0),
-        int(bool(F.sample_from_prior)), int(getattr(F, "generate_after", -1)), int(F.time_transition == "LSTM"),
-        int(F.prior_transition == "LSTM"), {"VanillaRNN": 0, "LSTM": 1, "GRU": 2}[F.transition])
+        int(bool(F.sample_from_prior)), int(getattr(F, "generate_after", -1)), {"GRU": 0, "LSTM": 1, "VanillaRNN": 2}[F.time_transition],
+        {"GRU": 0, "LSTM": 1, "VanillaRNN": 2}[F.prior_transition], {"VanillaRNN": 0, "LSTM": 1, "GRU": 2}[F.transition])
 
 
 class SqairCore(object):

@@ -113,7 +113,7 @@ def param_spec(F, img_hw):
     # Sonnet uniquifies module names per class in construction order (configs/mlp_mnist_model.py:116-125: transition cell,
     # temporal cell, prior cell): gru / gru_1, lstm / lstm_1 / lstm_2.  (Names of non-shipped cell choices are a best
     # guess from that rule: no listing of such a model exists in the reference.)
-    n_mod = {"lstm": 1 if rnn_lstm else 0, "gru": 1 if rnn_gru else 0}
+    n_mod = {"lstm": 1 if rnn_lstm else 0, "gru": 1 if rnn_gru else 0, "vanilla_rnn": 0 if (rnn_lstm or rnn_gru) else 1}
 
     def scope_of(kind):
         n_mod[kind] += 1
@@ -123,7 +123,13 @@ def param_spec(F, img_hw):
         return scope_of("lstm")
     time_lstm = str(getattr(F, "time_transition", "GRU")) == "LSTM"
     prior_lstm = str(getattr(F, "prior_transition", "GRU")) == "LSTM"
-    if time_lstm:
+    time_van = str(getattr(F, "time_transition", "GRU")) == "VanillaRNN"
+    prior_van = str(getattr(F, "prior_transition", "GRU")) == "VanillaRNN"
+    if time_van:
+        tmod = scope_of("vanilla_rnn")
+        lin("prop.temporal_rnn.h2h", nh, nh, "propagation/" + tmod + "/hidden_to_hidden")
+        lin("prop.temporal_rnn.i2h", nh + 4 + 2 * nw, nh, "propagation/" + tmod + "/in_to_hidden")
+    elif time_lstm:
         # snt.LSTM(n_hidden): gates = [x, h] w_gates + b_gates, split (i, j, f, o) (SURVEY Appendix B style restatement)
         fin = nh + 4 + 2 * nw
         tmod = lstm_scope()
@@ -132,7 +138,11 @@ def param_spec(F, img_hw):
     else:
         tmod = scope_of("gru")
         gru("prop.temporal_gru", nh + 4 + 2 * nw, "propagation/" + tmod)
-    if prior_lstm:
+    if prior_van:
+        pmod = scope_of("vanilla_rnn")
+        lin("prop.prior_rnn.h2h", nh, nh, "propagation/" + pmod + "/hidden_to_hidden")
+        lin("prop.prior_rnn.i2h", nw + 4, nh, "propagation/" + pmod + "/in_to_hidden")
+    elif prior_lstm:
         pmod = lstm_scope()
         scope = "propagation/" + pmod
         spec.append(("prop.prior_lstm.w", (nw + 4 + nh, 4 * nh), ("lin_w", nw + 4 + nh), scope + "/w_gates"))

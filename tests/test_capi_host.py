@@ -32,7 +32,8 @@ def test_library_loads_and_exports_header_symbols(repo_root):
 @pytest.mark.parametrize("N,hw,cell", [(3, (50, 50), "GRU"), (4, (50, 50), "GRU"), (6, (50, 50), "GRU"), (4, (128, 128), "GRU"),
                                        (3, (50, 50), "LSTM"), (3, (50, 50), "GRU/LSTM"), (4, (50, 50), "LSTM/LSTM"),
                                        (3, (50, 50), "GRU/GRU/LSTM"), (4, (50, 50), "LSTM/LSTM/LSTM"),
-                                       (3, (50, 50), "GRU/GRU/GRU")])
+                                       (3, (50, 50), "GRU/GRU/GRU"), (3, (50, 50), "VanillaRNN/VanillaRNN/LSTM"),
+                                       (4, (50, 50), "VanillaRNN/LSTM/VanillaRNN")])
 def test_param_table_matches_python_spec(N, hw, cell):
     lib = _capi.lib()
     cs = cell.split("/") + ["GRU", "VanillaRNN"][len(cell.split("/")) - 1:]

@@ -442,6 +442,8 @@ def test_checkpoint_round_trip_restores_parameters_and_optimiser_slots(tmp_path)
     dict(time_transition="LSTM", prior_transition="LSTM", prop_prior_type="guided"),
     dict(transition="LSTM"),
     dict(transition="GRU"),
+    dict(time_transition="VanillaRNN", prior_transition="VanillaRNN"),
+    dict(transition="GRU", time_transition="VanillaRNN", prior_transition="LSTM"),
     dict(transition="LSTM", time_transition="LSTM", prior_transition="LSTM"),
 ])
 def test_full_backward_flag_variants(flags):

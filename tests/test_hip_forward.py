@@ -86,6 +86,13 @@ def test_forward_flag_variants_vs_live_oracle(prior, disc_prior, rec):
     _live_oracle_case(F)
 
 
+def test_forward_vanilla_temporal_and_prior_cells_vs_live_oracle():
+    """time_transition = prior_transition = VanillaRNN (Sonnet takes any core by name, mlp_mnist_model.py:86-87,125)."""
+    F = make_flags(k_particles=3, n_steps_per_image=4, time_transition="VanillaRNN", prior_transition="VanillaRNN")
+    m, ref = _live_oracle_case(F, T=4, B=3)
+    assert float(ref.prop_pres.sum()) > 0
+
+
 def test_forward_gru_slot_rnn_vs_live_oracle():
     """transition=GRU: the Sonnet GRU (reset gate applied BEFORE the recurrent candidate matmul) as the slot RNN of both
     cores, two launches per slot like the temporal cell."""

@@ -335,7 +335,7 @@ def test_generation_after_t_samples_the_priors():
 
 
 @pytest.mark.parametrize("cells", [("LSTM", "GRU"), ("GRU", "LSTM"), ("LSTM", "LSTM"), ("GRU", "GRU", "LSTM"), ("LSTM", "LSTM", "LSTM"),
-                                   ("GRU", "GRU", "GRU")])
+                                   ("GRU", "GRU", "GRU"), ("VanillaRNN", "VanillaRNN", "VanillaRNN")])
 def test_lstm_cells_are_wired_into_the_model(cells):
     """time_transition / prior_transition = LSTM (configs/mlp_mnist_model.py:86-87,125): the recurrent states double to
     [hidden | cell], every parameter of the LSTM variant receives a gradient, and the parameter table swaps the nine GRU
@@ -363,6 +363,7 @@ def test_lstm_cells_are_wired_into_the_model(cells):
     tf_names = [s[3] for s in param_spec(F, hw)]
     assert len(set(tf_names)) == len(tf_names)
     assert ("prop.temporal_lstm.w" in names) == (cells[0] == "LSTM") and ("prop.temporal_gru.wz" in names) == (cells[0] == "GRU")
+    assert ("prop.temporal_rnn.i2h.w" in names) == (cells[0] == "VanillaRNN") and ("prop.prior_rnn.h2h.b" in names) == (cells[1] == "VanillaRNN")
     assert ("prop.prior_lstm.w" in names) == (cells[1] == "LSTM") and ("seq.prior_init_c" in names) == (cells[1] == "LSTM")
     assert ("prop.rnn_lstm.w" in names) == (rnn == "LSTM") == ("disc.rnn_init_c" in names)
     assert ("prop.rnn.i2h.w" in names) == (rnn == "VanillaRNN") and ("disc.rnn_gru.uh" in names) == (rnn == "GRU")
