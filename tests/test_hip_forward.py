@@ -86,6 +86,16 @@ def test_forward_flag_variants_vs_live_oracle(prior, disc_prior, rec):
     _live_oracle_case(F)
 
 
+@pytest.mark.parametrize("rnn", ["VanillaRNN", "GRU", "LSTM"])
+def test_all_cell_combinations_forward(rnn):
+    """Every {VanillaRNN, GRU, LSTM} choice on time_transition x prior_transition for the given slot RNN (27 configurations
+    over the three parametrisations): ELBO terms and all outputs of a small case against the oracle."""
+    for tc in ("VanillaRNN", "GRU", "LSTM"):
+        for pc in ("VanillaRNN", "GRU", "LSTM"):
+            F = make_flags(k_particles=2, n_steps_per_image=2, transition=rnn, time_transition=tc, prior_transition=pc)
+            _live_oracle_case(F, hw=(24, 28), T=3, B=2)
+
+
 def test_forward_vanilla_temporal_and_prior_cells_vs_live_oracle():
     """time_transition = prior_transition = VanillaRNN (Sonnet takes any core by name, mlp_mnist_model.py:86-87,125)."""
     F = make_flags(k_particles=3, n_steps_per_image=4, time_transition="VanillaRNN", prior_transition="VanillaRNN")
