@@ -262,6 +262,15 @@ int sqair_forward_persistent(SqairHandle* h, const float* flat_params, const voi
                              const float* noise, int T, int B, int t_offset, const SqairOutputs* out, void* workspace,
                              int64_t workspace_bytes, void* program, int64_t program_bytes, void* stream);
 int sqair_persistent_status(SqairHandle* h, const void* program, void* stream);
+
+/* ---- layer chains (EXPERIMENTAL, off by default: measured slower than one launch per layer): the
+ * glimpse-encoder chain of a slot as ONE launch, rows split over per-XCD workgroup teams that hand activations over
+ * through their XCD's L2 (csrc/sqair_chain.hip).  Same results bit for bit; fewer graph nodes.  Needs the MI355X's 256 CUs;
+ * the placement assumption (workgroups with equal index mod 8 share an XCD) is checked by every launch: sqair_chain_status
+ * returns 0 when the last pass in `workspace` is valid, 1 (barrier time-out) or 2 (unexpected placement) when its results
+ * must be discarded — disable chains and re-run. */
+int sqair_enable_chains(SqairHandle* h, int on);
+int sqair_chain_status(SqairHandle* h, const void* workspace, int T, int B, int train, void* stream);
 /* Generation modes (sqair/sqair_modules.py:157-170, :294-302, sqair/seq.py:198-200).  With
  * cfg.sample_from_prior the propagation posterior log-probabilities are evaluated at samples of the propagation PRIOR, and
  * in frames t > cfg.generate_after those samples replace what / where / presence of the propagated objects, discovery's

@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["sqair_api.hip", "sqair_linear.hip", "sqair_glue.hip", "sqair_bwd.hip", "sqair_train.hip", "sqair_linear_dx.hip", "sqair_persist.hip"]
+SOURCES = ["sqair_api.hip", "sqair_linear.hip", "sqair_glue.hip", "sqair_bwd.hip", "sqair_train.hip", "sqair_linear_dx.hip", "sqair_persist.hip", "sqair_chain.hip"]
 OUT = os.path.join(os.path.dirname(HERE), "libsqair_hip.so")
 
 

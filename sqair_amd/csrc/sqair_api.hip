@@ -15,6 +15,7 @@
 //   * only the truly sequential part (explaining away: slot k needs slot k-1's sample) remains in
 //     the per-slot chain.
 #include "sqair_internal.h"
+#include "sqair_chain.h"
 
 void sq_set_error(SqairHandle* h, const std::string& msg) {
   if (h) h->err = msg;
@@ -673,6 +674,9 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.dec_a = take((int64_t)T * M * nh);
   w.dec_b = take((int64_t)T * M * nh);
   w.gen = take(c.sample_from_prior ? (int64_t)T * M * gen::W : 64);
+  w.chain_slots = T * 2 * (int)N * 3;
+  w.chain_bar = (unsigned*)take((int64_t)w.chain_slots * SQ_CHAIN_BAR_WORDS);
+  w.chain_status = (int*)take(64);
   w.prof_ts = (unsigned long long*)take(5 * PROF_MAX * 2);
   w.total = o;
   return w;
@@ -730,6 +734,54 @@ int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipSt
   if (rc != 0) sq_set_error(h, "internal: A-operand contract (16-byte aligned, ld % 4 == 0) violated in layer " + std::to_string((int)id));
   return rc;
 }
+
+// two or three dependent slot layers as ONE launch (sqair_chain.hip) when chains are enabled, else one launch each
+static int sq_run_chain(SqairHandle* h, Lin* const* ls, const LayerId* ids, int n, int M, const float* packed, const Workspace& w,
+                        hipStream_t s) {
+  const bool chain = h->use_chain && h->rec == nullptr && M >= 64 && h->chain_no < w.chain_slots;
+  if (!chain) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = sq_run(h, *ls[i], ids[i], M, packed, s);
+      if (rc != 0) return rc;
+    }
+    return 0;
+  }
+  const PackedLayout pl = packed_layout(h);
+  LinArgs la[3];
+  const PackedLayer* pls[3];
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const PackedLayer& L = h->layers[ids[i]];
+    Lin& l = *ls[i];
+    if (l.a.nseg != (int)L.seg_width.size()) { sq_set_error(h, "internal: segment count mismatch in chained layer " + std::to_string((int)ids[i])); return -3; }
+    int ksum = 0;
+    for (int j = 0; j < l.a.nseg; ++j) {
+      if (l.a.seg[j].width != L.seg_width[j]) { sq_set_error(h, "internal: segment width mismatch in chained layer " + std::to_string((int)ids[i])); return -3; }
+      ksum += L.seg_width[j];
+    }
+    l.a.wp = packed + pl.w + L.w_off; l.a.wzero = packed + pl.w; l.a.bias = packed + pl.b + L.b_off; l.a.M = M; l.a.N = L.N;
+    la[i] = l.a; pls[i] = &L;
+    flops += 2.0 * (double)M * (double)ksum * (double)L.N;
+  }
+  unsigned long long* pts = nullptr;
+  if (h->prof && h->prof_n < PROF_MAX) {
+    h->prof_flops += flops;
+    h->prof_layer.push_back(1000 + (int)ids[0]);  // 1000 + first layer id marks a chain in the per-launch dump
+    h->prof_m.push_back(M);
+    pts = h->prof_ts + h->prof_n++;
+  }
+  const int rc = sq_launch_chain(la, pls, n, M, w.chain_bar + (size_t)h->chain_no * SQ_CHAIN_BAR_WORDS, w.chain_status, pts, s);
+  ++h->chain_no;
+  if (rc != 0) sq_set_error(h, "internal: A-operand contract violated in a layer chain starting at layer " + std::to_string((int)ids[0]));
+  return rc;
+}
+#define RUN_CHAIN3(l0, id0, l1, id1, l2, id2, M)                                         \
+  do {                                                                                   \
+    Lin* _ls[3] = {&(l0), &(l1), &(l2)};                                                 \
+    const LayerId _ids[3] = {(id0), (id1), (id2)};                                       \
+    const int _rc = sq_run_chain(h, _ls, _ids, 3, (M), packed, w, s);                    \
+    if (_rc != 0) return _rc;                                                            \
+  } while (0)
 
 static int emit_crop(SqairHandle* h, const CropArgs& ca, POff po, Dims d, int nslots, hipStream_t s) {
   if (h->rec == nullptr) return sq_launch_crop(ca, po, d, nslots, s);
@@ -790,6 +842,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   // The GEMM A-operand contract wants every float it may touch to be finite (padding meets zero weights, but
   // 0 * NaN = NaN) and slot records are read as 56-wide segments before all their fields are written in a frame:
   // clear the caller's (garbage) workspace once per pass
+  if (parts & 1) h->chain_no = 0;
   if (parts & 1) {
     sq_zero_fill(wsbase, (int64_t)((float*)w.prof_ts - wsbase), s);
     // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
@@ -928,9 +981,10 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         emit_crop(h, ca, po, d, 1, s);
       }
       {
-        Lin a; a.seg(g2, gl2, G2).out(e1, rl).act(ACT_ELU); RUN(a, L_GENC0, R);
-        Lin b; b.seg(e1, rl, nh).out(e2, rl).act(ACT_ELU); RUN(b, L_GENC1, R);
-        Lin e; e.seg(e2, rl, nh).out(enc, el).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
+        Lin a; a.seg(g2, gl2, G2).out(e1, rl).act(ACT_ELU);
+        Lin b; b.seg(e1, rl, nh).out(e2, rl).act(ACT_ELU);
+        Lin e; e.seg(e2, rl, nh).out(enc, el).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw);
+        RUN_CHAIN3(a, L_GENC0, b, L_GENC1, e, L_WHAT_HEAD, R);
       }
       if ((c.time_cell == CELL_LSTM)) {
         float* gates = train ? w.lgates + ((size_t)t * M + k) * 4 * nh : w.lgates;
@@ -1031,9 +1085,10 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         ca.t2_ld = rl; ca.w3 = w.w3_disc; ca.noise = nz; ca.flat = flat; ca.slot = j;
         if (train) { ca.tp_out = w.slot(w.tp, TP_LD, t, 1, j); ca.tp_out_ld = w.sld(TP_LD); }
         emit_crop(h, ca, po, d, 1, s);
-        Lin a; a.seg(g2, gl2, G2).out(e1, rl).act(ACT_ELU); RUN(a, L_GENC0, R);
-        Lin b; b.seg(e1, rl, nh).out(e2, rl).act(ACT_ELU); RUN(b, L_GENC1, R);
-        Lin e; e.seg(e2, rl, nh).out(enc, el).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw); RUN(e, L_WHAT_HEAD, R);
+        Lin a; a.seg(g2, gl2, G2).out(e1, rl).act(ACT_ELU);
+        Lin b; b.seg(e1, rl, nh).out(e2, rl).act(ACT_ELU);
+        Lin e; e.seg(e2, rl, nh).out(enc, el).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw);
+        RUN_CHAIN3(a, L_GENC0, b, L_GENC1, e, L_WHAT_HEAD, R);
       }
       {
         TailArgs ta; memset(&ta, 0, sizeof(ta));
@@ -1110,6 +1165,34 @@ extern "C" int sqair_forward_train(SqairHandle* h, const float* flat_params, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// layer chains (sqair_chain.hip)
+extern "C" int sqair_enable_chains(SqairHandle* h, int on) {
+  if (!h) return -1;
+  if (on && h->n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sq_set_error(h, "sqair_enable_chains: no device"); return -1; }
+    h->n_cu = prop.multiProcessorCount;
+  }
+  if (on && h->n_cu != 256) {  // the team layout is the MI355X's: 8 XCDs x 32 CUs, one workgroup per CU
+    sq_set_error(h, "sqair_enable_chains: the team layout needs 256 CUs in 8 XCDs, found " + std::to_string(h->n_cu));
+    return -1;
+  }
+  h->use_chain = on != 0;
+  return 0;
+}
+// status word of the last pass run in `workspace` (a sqair_forward / sqair_graph_* workspace, or the train workspace with
+// train != 0): 0 = every chain launch completed with the expected placement, 1 = a team barrier timed out, 2 = a workgroup
+// was not on its expected XCD.  Non-zero: the pass's results must be discarded (disable chains and re-run).  Synchronises.
+extern "C" int sqair_chain_status(SqairHandle* h, const void* workspace, int T, int B, int train, void* stream) {
+  if (!h || !workspace || T < 1 || B < 1) return -1;
+  const Workspace w = sq_carve(h, T, B, (float*)workspace, train != 0);
+  int st = 0;
+  SQ_CHECK_HIP(hipMemcpyAsync(&st, w.chain_status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  SQ_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return st;
+}
+
 // XCD-persistent forward pass (sqair_persist.hip): same results as sqair_forward, the frame loop as ONE launch.
 // `program` is caller-owned device memory (sqair_program_bytes) that holds the recorded op list and the team
 // counters; the list is rebuilt (one synchronous upload) whenever any pointer / shape argument changes.

@@ -56,6 +56,9 @@ struct SqairHandle {
   std::vector<XOp> xprog;
   std::vector<uint64_t> xprog_key;
   int n_cu = 0;
+  // layer chains (sqair_chain.hip): several dependent slot layers per launch; off unless sqair_enable_chains(h, 1)
+  bool use_chain = false;
+  int chain_no = 0;  // chain launches issued so far in the pass being emitted (selects the counter slot)
   const float* gen_noise = nullptr;  // sqair_set_generation_noise
   // generic capture slots (sqair_capture_begin / _end / _launch): any sequence of C-ABI calls as one HIP graph
   hipGraph_t cap_graph[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -138,6 +141,9 @@ struct Workspace {
   float *lpre, *lgates;                          // LSTM temporal cell (time_lstm): [M][4nh], kept gates [T][R][N][4nh]
   int* src;                                      // train: compaction source slot [T][R][N]
   float *qz, *pz, *dlp, *dll, *glimpse, *dec_a, *dec_b;
+  unsigned* chain_bar;                           // layer chains: arrival counters, one 128-word slot per chain launch
+  int* chain_status;                             // and the pass's status word (zeroed with the workspace)
+  int chain_slots;
   float* gen;                                    // sample_from_prior: [T][M][64] prior samples + original presences
   unsigned long long* prof_ts;
   int64_t total;  // floats

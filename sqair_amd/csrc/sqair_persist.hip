@@ -118,7 +118,7 @@ __device__ void x_linear_wave(const LinArgs& a, int kc_total, int n_tiles, int m
       const float* pe1 = g2 ? a.e1 + (size_t)mc * a.e1_ld + nc : pb;
       p_add[i] = ldf(pa); p_e0[i] = ldf(pe0); p_e1[i] = ldf(pe1);
     }
-    const XSegs sg = x_segs(a, arow);
+    SQ_XSEGS(a, arow)
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
     const f32x4* __restrict__ wz = reinterpret_cast<const f32x4*>(a.wzero) + lane;
@@ -131,7 +131,7 @@ __device__ void x_linear_wave(const LinArgs& a, int kc_total, int n_tiles, int m
       for (int j = 0; j < NCH; ++j) {
         const bool valid = base + j < kc_total;
         const int g = valid ? base + j : 0;
-        ap[j] = x_aptr(sg, g, kq);
+        ap[j] = SQ_XAPTR(g, kq);
         bv[j] = *(valid ? wp + (size_t)g * 64 : wz);
       }
       ld4x4_sc1(ap[0], ap[1], ap[2], ap[3], av[0], av[1], av[2], av[3]);

@@ -17,30 +17,30 @@ struct LdPlain {
 
 // ---- dense-layer tile shared by the grouped launch (sqair_linear.hip) and the persistent executor -----------------------
 // operand addressing shared by both tilings
-struct XSegs {
-  const float* rp[4];
-  int cum[4], lim[4];
-};
-__device__ __forceinline__ XSegs x_segs(const LinArgs& a, int arow) {
-  XSegs sg;
-  int c = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bool on = i < a.nseg;
-    const LinSeg& seg = a.seg[on ? i : 0];
-    const int row = seg.rmul ? (int)__umulhi((unsigned)arow, seg.rmul) : arow;
-    sg.rp[i] = seg.p + (size_t)row * seg.ld;
-    sg.cum[i] = on ? c : 0x7fffffff;
-    sg.lim[i] = ((seg.width + 3) & ~3) - 4;
-    c += on ? (seg.width + 15) >> 4 : 0;
-  }
-  return sg;
-}
-__device__ __forceinline__ const float* x_aptr(const XSegs& sg, int g, int kq) {
-  const bool s1 = g >= sg.cum[1], s2 = g >= sg.cum[2], s3 = g >= sg.cum[3];
-  const float* rp = s3 ? sg.rp[3] : (s2 ? sg.rp[2] : (s1 ? sg.rp[1] : sg.rp[0]));
-  const int cb = s3 ? sg.cum[3] : (s2 ? sg.cum[2] : (s1 ? sg.cum[1] : 0));
-  const int lim = s3 ? sg.lim[3] : (s2 ? sg.lim[2] : (s1 ? sg.lim[1] : sg.lim[0]));
+// Per-lane A-operand addressing of up to four input segments.  Deliberately NOT a struct: a select chain over the members
+// of a struct returned by value is turned into an indexed load from a scratch copy of it (measured: 160 scratch
+// instructions in the chain kernel), so the eleven values live in named locals declared by SQ_XSEGS.
+#define SQ_XSEG1(i)                                                                                      \
+  const LinSeg& xs_seg##i = a.seg[i];                                                                    \
+  const int xs_row##i = xs_seg##i.rmul ? (int)__umulhi((unsigned)arow, xs_seg##i.rmul) : arow;           \
+  const float* const xs_rp##i = xs_seg##i.p + (size_t)xs_row##i * xs_seg##i.ld;                          \
+  const int xs_lim##i = ((xs_seg##i.width + 3) & ~3) - 4;
+// constant indices into a.seg (a runtime index into a by-value kernel argument goes through scratch as well); unused
+// segments are value-initialised and never dereferenced: their chunk range is empty
+#define SQ_XSEGS(a, arow)                                                                                \
+  SQ_XSEG1(0) SQ_XSEG1(1) SQ_XSEG1(2) SQ_XSEG1(3)                                                        \
+  const int xs_c1 = (xs_seg0.width + 15) >> 4;                                                           \
+  const int xs_c2 = xs_c1 + ((a).nseg > 1 ? (xs_seg1.width + 15) >> 4 : 0);                              \
+  const int xs_c3 = xs_c2 + ((a).nseg > 2 ? (xs_seg2.width + 15) >> 4 : 0);                              \
+  const int xs_cum1 = (a).nseg > 1 ? xs_c1 : 0x7fffffff, xs_cum2 = (a).nseg > 2 ? xs_c2 : 0x7fffffff,    \
+            xs_cum3 = (a).nseg > 3 ? xs_c3 : 0x7fffffff;
+#define SQ_XAPTR(g, kq) x_aptr(xs_rp0, xs_rp1, xs_rp2, xs_rp3, xs_cum1, xs_cum2, xs_cum3, xs_lim0, xs_lim1, xs_lim2, xs_lim3, (g), (kq))
+__device__ __forceinline__ const float* x_aptr(const float* rp0, const float* rp1, const float* rp2, const float* rp3, int cum1, int cum2,
+                                               int cum3, int lim0, int lim1, int lim2, int lim3, int g, int kq) {
+  const bool s1 = g >= cum1, s2 = g >= cum2, s3 = g >= cum3;
+  const float* rp = s3 ? rp3 : (s2 ? rp2 : (s1 ? rp1 : rp0));
+  const int cb = s3 ? cum3 : (s2 ? cum2 : (s1 ? cum1 : 0));
+  const int lim = s3 ? lim3 : (s2 ? lim2 : (s1 ? lim1 : lim0));
   return rp + min((g - cb) * 16 + kq * 4, lim);
 }
 // epilogue of one output element (m, n) with pre-activation sum v (bias and addend already included)
@@ -86,7 +86,7 @@ __device__ void x_linear_tile(const LinArgs& a, int kc_total, int tile_n, int mb
   const float p_e0 = LD::f(pe0), p_e1 = LD::f(pe1);
   const float p_scale = a.scale_ptr != nullptr ? *a.scale_ptr : 1.0f;
   p_add = use_add ? p_add : 0.0f;
-  const XSegs sg = x_segs(a, arow);
+  SQ_XSEGS(a, arow)
   sq_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
   const sq_f32x4* __restrict__ wp = reinterpret_cast<const sq_f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
   const sq_f32x4* __restrict__ wz = reinterpret_cast<const sq_f32x4*>(a.wzero) + lane;
@@ -100,7 +100,7 @@ __device__ void x_linear_tile(const LinArgs& a, int kc_total, int tile_n, int mb
     for (int j = 0; j < NCH; ++j) {
       const bool valid = base + j < nmine;
       const int g = valid ? wave + 4 * (base + j) : wave;
-      ap[j] = x_aptr(sg, g, kq);
+      ap[j] = SQ_XAPTR(g, kq);
       bv[j] = *(valid ? wp + (size_t)g * 64 : wz);
     }
     LD::f4x4(ap[0], ap[1], ap[2], ap[3], av[0], av[1], av[2], av[3]);

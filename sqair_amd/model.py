@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -61,7 +62,9 @@ class SqairCore(object):
     """Thin owner of a library handle + the device buffers it needs (parameters, packed parameters,
     workspace, noise, outputs) for one (T, B) shape on one device / stream."""
 
-    def __init__(self, F, img_hw, device="cuda:0"):
+    def __init__(self, F, img_hw, device="cuda:0", chains=None):
+        """chains: run the dependent MLP chains of a slot as one launch each (csrc/sqair_chain.hip; same results, fewer
+        graph nodes).  None = the environment variable SQAIR_CHAINS (default off)."""
         if not torch.cuda.is_available():
             raise RuntimeError("sqair_amd needs a HIP device (no CPU fallback)")
         self.F = F
@@ -92,6 +95,25 @@ class SqairCore(object):
             self.stream = torch.cuda.Stream(device=self.device)
         self._shape = None
         self._graph_ready = False
+        self.chains = False
+        if chains is None:
+            chains = os.environ.get("SQAIR_CHAINS", "0") == "1"
+        if chains:
+            self.set_chains(True)
+
+    def set_chains(self, on):
+        with torch.cuda.device(self.device):
+            _capi.check(self.handle, self.lib.sqair_enable_chains(self.handle, int(bool(on))), "sqair_enable_chains")
+        self.chains = bool(on)
+        self._graph_ready = False
+        self._train_graph_ready = False
+
+    def chain_status(self, train=False):
+        """0 = the last pass (inference workspace, or the training tape with train=True) is valid; 1 / 2 = a layer-chain
+        launch timed out / ran with an unexpected workgroup placement: discard the pass, set_chains(False), re-run."""
+        ws = self.train_ws if train else self.workspace
+        with torch.cuda.device(self.device):
+            return int(self.lib.sqair_chain_status(self.handle, ws.data_ptr(), self.T, self.B, int(bool(train)), self._stream()))
 
     def __del__(self):
         try:

@@ -167,6 +167,75 @@ __global__ __launch_bounds__(256) void k_team_pf(float* X, const float* W, int p
   }
 }
 
+
+// SHORT persistent launches: one launch = `L` dependent layers (a slot's MLP chain), teams taken from the STATIC mapping
+// block b -> XCD b % 8 (verified against HW_REG_XCC_ID: a mismatch raises `err` instead of computing garbage), so there is
+// no formation barrier; L - 1 team barriers on a per-launch counter slot (zeroed once at the start of the graph); the next
+// layer's weights are requested before each barrier.
+__global__ __launch_bounds__(256) void k_chain(float* X, const float* W, int L, int layer0, int nlayers, int buf0, unsigned* bar, int* err) {
+  extern __shared__ float lds[];
+  float* red = lds;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
+  const unsigned xcc = blockIdx.x & 7, rank = blockIdx.x >> 3;
+  if (tid == 0) {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if ((x & 0xf) != xcc) *err = 1;
+  }
+  unsigned* mybar = bar + xcc * 64;
+  const int rt = rank / 16, nt = rank % 16;
+  f32x4 bv[4];
+  {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(W + (size_t)(layer0 % nlayers) * KD * ND) + ((size_t)nt * 16) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = wp[(size_t)(wave + 4 * j) * 64];
+  }
+  for (int ph = 0; ph < L; ++ph) {
+    const float* in = X + ((size_t)((buf0 + ph) & 1) * 8 + xcc) * ROWS * KD;
+    float* out = X + ((size_t)((buf0 + ph + 1) & 1) * 8 + xcc) * ROWS * ND;
+    const float* rp = in + (size_t)(rt * 16 + (lane & 15)) * KD;
+    f32x4 av[4];
+    if (ph == 0) {   // written by the PREVIOUS launch: ordinary loads
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f32x4*>(rp + (wave + 4 * j) * 16 + kq * 4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[j] = load_sc1(rp + (wave + 4 * j) * 16 + kq * 4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc, 0, 0, 0);
+    }
+    if (ph + 1 < L) {
+      const f32x4* wp = reinterpret_cast<const f32x4*>(W + (size_t)((layer0 + ph + 1) % nlayers) * KD * ND) + ((size_t)nt * 16) * 64 + lane;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = wp[(size_t)(wave + 4 * j) * 64];
+    }
+    float* r = red + wave * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[(4 * kq + i) * 16 + (lane & 15)] = acc[i];
+    __syncthreads();
+    const float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+    out[(size_t)(rt * 16 + (tid >> 4)) * ND + nt * 16 + (tid & 15)] = tanhf(v);
+    if (ph + 1 < L) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(mybar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (unsigned)(ph + 1) * 32u;
+        for (int spin = 0; spin < (1 << 20) && __hip_atomic_load(mybar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(1);
+      }
+      __syncthreads();
+    }
+  }
+}
+__global__ void k_zero_u(unsigned* p, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) p[i] = 0; }
+
 int main() {
   const int nlayers = 24, phases = 2000;
   std::vector<float> hW((size_t)nlayers * KD * ND), hX((size_t)2 * 8 * ROWS * KD, 0.0f);
@@ -237,5 +306,31 @@ int main() {
          maxerr, bad, ref.size());
   printf("  + weight prefetch     : %.3f ms = %.2f us/layer   max |diff| %.3g, mismatching %zu / %zu\n", ms_pf, ms_pf * 1e3 / phases, maxerr2,
          bad2, ref.size());
+  // ---- short persistent launches: L layers per launch, graph of phases / L launches
+  for (int L : {1, 2, 3, 4}) {
+    const int nodes = phases / L;
+    unsigned* cbar; int* derr;
+    CK(hipMalloc(&cbar, (size_t)nodes * 8 * 64 * 4)); CK(hipMalloc(&derr, 4)); CK(hipMemset(derr, 0, 4));
+    CK(hipFuncSetAttribute((const void*)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipGraph_t g2; hipGraphExec_t ge2;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipLaunchKernelGGL(k_zero_u, dim3((nodes * 8 * 64 + 255) / 256), dim3(256), 0, s, cbar, nodes * 8 * 64);
+    for (int n = 0; n < nodes; ++n)
+      hipLaunchKernelGGL(k_chain, dim3(256), dim3(256), shm, s, dX, dW, L, n * L, nlayers, (n * L) & 1, cbar + (size_t)n * 8 * 64, derr);
+    CK(hipStreamEndCapture(s, &g2)); CK(hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0));
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipMemcpy(dX, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
+      CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(ge2, s)); CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    std::vector<float> got3(ref.size());
+    CK(hipMemcpy(got3.data(), dX + (size_t)((nodes * L) & 1) * 8 * ROWS * KD, got3.size() * 4, hipMemcpyDeviceToHost));
+    int herr = 0; CK(hipMemcpy(&herr, derr, 4, hipMemcpyDeviceToHost));
+    double me = 0; size_t bd = 0;
+    if (nodes * L == phases) for (size_t i = 0; i < ref.size(); ++i) { double e = fabs((double)ref[i] - got3[i]); if (e > me) me = e; if (e > 1e-5) ++bd; }
+    printf("chain launches, L=%d layers : %.3f ms = %.2f us/layer = %.2f us/launch   placement error %d   max |diff| %.3g, mismatching %zu%s\n", L, ms,
+           ms * 1e3 / (nodes * L), ms * 1e3 / nodes, herr, me, bd, nodes * L == phases ? "" : " (not compared: phases % L != 0)");
+  }
   return 0;
 }
