@@ -1,3 +1,7 @@
+"""Layer chains (sqair_enable_chains) against the launch-per-layer path at BASELINE configs[1]: bit-identity of all outputs,
+status word, time per pass and per gradient evaluation, device-clock phase stamps of the chain launches.
+    python tools/try_chain.py
+"""
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 from sqair_amd.data import config_inputs
