@@ -67,7 +67,7 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "dec.l2", nh, G2);
   add_param(h, "dec.output_scale", 1, 1);
   add_param(h, "disc.rnn_init", 1, nh);
-  if ((c.rnn_cell == RNN_LSTM)) add_param(h, "disc.rnn_init_c", 1, nh);  // LSTMState(hidden, cell): adjacent rows
+  if (c.rnn_cell == RNN_LSTM) add_param(h, "disc.rnn_init_c", 1, nh);  // LSTMState(hidden, cell): adjacent rows
   add_lin(h, "disc.steps_prior.l0", 1, 10);
   add_lin(h, "disc.steps_prior.l1", 10, N + 1);
   add_param(h, "disc.rn.init_state", 1, 4);
@@ -89,7 +89,7 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "disc.transform.l1", nh, nh);
   add_lin(h, "disc.transform.l2", nh, 8);
   add_param(h, "disc.transform.scale_offset", 1, 1);
-  if ((c.rnn_cell == RNN_LSTM)) add_lin(h, "disc.rnn_lstm", (nh + nh + nw + 4 + 1) + nh, 4 * nh);  // snt.LSTM w_gates [x | h], b_gates
+  if (c.rnn_cell == RNN_LSTM) add_lin(h, "disc.rnn_lstm", (nh + nh + nw + 4 + 1) + nh, 4 * nh);  // snt.LSTM w_gates [x | h], b_gates
   else if (c.rnn_cell == RNN_GRU) add_gru(h, "disc.rnn_gru", nh + nh + nw + 4 + 1, nh);
   else {
     add_lin(h, "disc.rnn.h2h", nh, nh);
@@ -97,12 +97,12 @@ static void build_inventory(SqairHandle* h) {
   }
   add_param(h, "disc.step_prior_bias", 1, N + 1);
   add_param(h, "disc.step_prior_timestep_bias", 1, N + 1);
-  if ((c.time_cell == CELL_LSTM)) add_lin(h, "prop.temporal_lstm", (nh + 4 + 2 * nw) + nh, 4 * nh);  // snt.LSTM: w_gates [x | h] rows, b_gates
+  if (c.time_cell == CELL_LSTM) add_lin(h, "prop.temporal_lstm", (nh + 4 + 2 * nw) + nh, 4 * nh);  // snt.LSTM: w_gates [x | h] rows, b_gates
   else if (c.time_cell == CELL_VANILLA) {  // snt.VanillaRNN: tanh(in_to_hidden(x) + hidden_to_hidden(h))
     add_lin(h, "prop.temporal_rnn.h2h", nh, nh);
     add_lin(h, "prop.temporal_rnn.i2h", nh + 4 + 2 * nw, nh);
   } else add_gru(h, "prop.temporal_gru", nh + 4 + 2 * nw, nh);
-  if ((c.prior_cell == CELL_LSTM)) add_lin(h, "prop.prior_lstm", (nw + 4) + nh, 4 * nh);
+  if (c.prior_cell == CELL_LSTM) add_lin(h, "prop.prior_lstm", (nw + 4) + nh, 4 * nh);
   else if (c.prior_cell == CELL_VANILLA) {
     add_lin(h, "prop.prior_rnn.h2h", nh, nh);
     add_lin(h, "prop.prior_rnn.i2h", nw + 4, nh);
@@ -120,7 +120,7 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "prop.what_head", nh, 2 * nw);
   add_lin(h, "prop.gates", nh, 3 * nw);
   add_param(h, "prop.rnn_init", 1, nh);
-  if ((c.rnn_cell == RNN_LSTM)) {
+  if (c.rnn_cell == RNN_LSTM) {
     add_param(h, "prop.rnn_init_c", 1, nh);
     add_lin(h, "prop.rnn_lstm", (nw + (nw + 5) + (nw + 5) + nh) + nh, 4 * nh);
   } else if (c.rnn_cell == RNN_GRU) {
@@ -130,9 +130,9 @@ static void build_inventory(SqairHandle* h) {
     add_lin(h, "prop.rnn.i2h", nw + (nw + 5) + (nw + 5) + nh, nh);
   }
   add_param(h, "seq.prior_init", 1, nh);
-  if ((c.prior_cell == CELL_LSTM)) add_param(h, "seq.prior_init_c", 1, nh);
+  if (c.prior_cell == CELL_LSTM) add_param(h, "seq.prior_init_c", 1, nh);
   add_param(h, "seq.temporal_init", 1, nh);
-  if ((c.time_cell == CELL_LSTM)) add_param(h, "seq.temporal_init_c", 1, nh);  // LSTMState(hidden, cell): adjacent, read as one [2 nh] row
+  if (c.time_cell == CELL_LSTM) add_param(h, "seq.temporal_init_c", 1, nh);  // LSTMState(hidden, cell): adjacent, read as one [2 nh] row
   add_lin(h, "seq.latent_enc.l0", nw + 4, nh);
   add_lin(h, "seq.latent_enc.l1", nh, nh);
 
@@ -314,7 +314,7 @@ static void build_plan(SqairHandle* h) {
   };
   build_layer(h, L_PREDISC, {nh}, rnn_blocks("disc", {rm_range(0, nh)}, -1, true, fin_d));
   // prior cell on [what, where]_{t-1} (propagate.py:78-81)
-  if ((c.prior_cell == CELL_LSTM)) {  // gates (i, j, f, o) = [what, where | h] w_gates + b_gates in ONE layer (both inputs exist up front)
+  if (c.prior_cell == CELL_LSTM) {  // gates (i, j, f, o) = [what, where | h] w_gates + b_gates in ONE layer (both inputs exist up front)
     ColBlock b;
     b.ncols = 4 * nh; b.col0 = 0;
     b.seg = {{"prop.prior_lstm.w", rm_zrec(nw, nw, 0, -1)}, {"prop.prior_lstm.w", rm_range(nw + 4, nh)}};
@@ -399,7 +399,7 @@ static void build_plan(SqairHandle* h) {
               {cb1(nh, 0, "prop.transform.l0.w", rm_range(0, nh)), cb1(nsp, 0, "prop.steps.l0.w", rm_range(0, nh))});
   simple(L_PROP_T2, "prop.transform.l1", nh, nh);
   simple(L_PROP_T3, "prop.transform.l2", nh, 8);
-  if ((c.time_cell == CELL_LSTM)) {
+  if (c.time_cell == CELL_LSTM) {
     // temporal LSTM (core.py:340-341 with time_transition=LSTM): gate pre-activations (i, j, f, o) = [x | h] w_gates + b.
     // L_PROP_GRU1 holds the x rows [hidden nh | where 4 | loc nw | scale nw], L_PROP_GRU2 the h rows + bias (applied to
     // all slots of a frame at once, before the slot loop).
@@ -594,9 +594,9 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   Workspace w;
   memset(&w, 0, sizeof(w));
   w.train = train; w.T = T; w.B = B; w.R = (int)R; w.M = (int)M; w.N = (int)N; w.nh = (int)nh;
-  const int64_t snh = (c.time_cell == CELL_LSTM) ? 2 * nh : nh;  // temporal state of a slot: [hidden | cell] for the LSTM
+  const int64_t snh = c.time_cell == CELL_LSTM ? 2 * nh : nh;  // temporal state of a slot: [hidden | cell] for the LSTM
   w.snh = (int)snh;
-  const int64_t psnh = (c.prior_cell == CELL_LSTM) ? 2 * nh : nh;
+  const int64_t psnh = c.prior_cell == CELL_LSTM ? 2 * nh : nh;
   w.psnh = (int)psnh;
   int64_t o = 0;
   auto take = [&](int64_t n) {
@@ -646,7 +646,7 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.c = take(F * R * nh);
   w.pre_d = take(R * rw);
   w.r = take((train ? S : 2) * R * nh);
-  w.rc = take((c.rnn_cell == RNN_LSTM) ? (train ? S : 2) * R * nh : 64);       // LSTM slot RNN: cell states, laid out like r
+  w.rc = take(c.rnn_cell == RNN_LSTM ? (train ? S : 2) * R * nh : 64);       // LSTM slot RNN: cell states, laid out like r
   w.rgates = take(c.rnn_cell != RNN_VANILLA ? (train ? S : 1) * R * rw : 64);  // kept: LSTM gate pre-activations / GRU [z | r | candidate]
   w.t1 = take(S * R * T1_LD);
   w.t2 = take(S * R * nh);
@@ -663,8 +663,8 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.grh = take(R * nh);
   w.gxh = take(R * nh);
   // LSTM: recurrent gate pre-activations of all slots of a frame, and the kept gate pre-activations per slot
-  w.lpre = take((c.time_cell == CELL_LSTM) ? M * 4 * nh : 64);
-  w.lgates = take((c.time_cell == CELL_LSTM) ? (train ? (int64_t)T * N : 1) * R * 4 * nh : 64);
+  w.lpre = take(c.time_cell == CELL_LSTM ? M * 4 * nh : 64);
+  w.lgates = take(c.time_cell == CELL_LSTM ? (train ? (int64_t)T * N : 1) * R * 4 * nh : 64);
   w.src = (int*)take(train ? (int64_t)T * M : 64);
   w.qz = take((int64_t)T * R);
   w.pz = take((int64_t)T * R);
@@ -883,7 +883,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     float* cvec = w.frame(w.c, (int64_t)R * nh, t);
 
     // ---- A. propagation prior (propagate.py:68-98): GRU over [what, where]_{t-1}, all slots ----
-    if ((c.prior_cell == CELL_LSTM)) {
+    if (c.prior_cell == CELL_LSTM) {
       float* pg = w.frame(w.pgz, (int64_t)M * 4 * nh, t);
       Lin g; g.seg(rec_prev, RW, rec::ZW).seg(prior_prev, psnh, nh).out(pg, 4 * nh); RUN(g, L_PRIOR_GRU1, M);
       sq_launch_lstm_cell(pg, 4 * nh, prior_prev + nh, psnh, prior_p, psnh, M, nh, s);
@@ -922,7 +922,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     {
       Lin p; p.seg(m1, M1_LD, nw).seg(rec_prev, RW, rec::ZW).seg(tau_prev, snh, nh).out(w.pre, pre_ld);
       RUN(p, L_PRE, M);
-      if ((c.time_cell == CELL_LSTM)) {  // recurrent rows of the LSTM gates: h_{t-1} W_h + b of every slot
+      if (c.time_cell == CELL_LSTM) {  // recurrent rows of the LSTM gates: h_{t-1} W_h + b of every slot
         Lin q; q.seg(temporal_prev, snh, nh).out(w.lpre, 4 * nh); RUN(q, L_PROP_GRU2, M);
       }
     }
@@ -944,7 +944,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         Lin a;
         if (k == 0) a.seg(w.zero_rec, 0, rec::ZW).seg(w.prop_rnn_init, 0, nh);
         else a.seg(rec_p_t + (size_t)(k - 1) * RW, N * RW, rec::ZW).seg(w.rslot(t, 0, k - 1), rl, nh);
-        if ((c.rnn_cell == RNN_LSTM)) {
+        if (c.rnn_cell == RNN_LSTM) {
           float* gates = train ? w.slot(w.rgates, 4 * nh, t, 0, k) : w.rgates;
           a.add(pre_k, pre_rld, rw).out(gates, w.sld(4 * nh));
           RUN(a, L_PROP_RNN, R);
@@ -986,7 +986,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         Lin e; e.seg(e2, rl, nh).out(enc, el).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw);
         RUN_CHAIN3(a, L_GENC0, b, L_GENC1, e, L_WHAT_HEAD, R);
       }
-      if ((c.time_cell == CELL_LSTM)) {
+      if (c.time_cell == CELL_LSTM) {
         float* gates = train ? w.lgates + ((size_t)t * M + k) * 4 * nh : w.lgates;
         const int gld = train ? N * 4 * nh : 4 * nh;
         Lin gl; gl.seg(r_k, rl, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(enc, el, 2 * nw)
@@ -1055,7 +1055,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         Lin a;
         if (j == 0) a.seg(w.disc_init_rec, 0, rec::ZW).seg(w.disc_rnn_init, 0, nh);
         else a.seg(rec_d_t + (size_t)(j - 1) * RW, N * RW, rec::ZW).seg(w.rslot(t, 1, j - 1), rl, nh);
-        if ((c.rnn_cell == RNN_LSTM)) {
+        if (c.rnn_cell == RNN_LSTM) {
           float* gates = train ? w.slot(w.rgates, 4 * nh, t, 1, j) : w.rgates;
           a.add(w.pre_d, rw, rw).out(gates, w.sld(4 * nh));
           RUN(a, L_DISC_RNN, R);

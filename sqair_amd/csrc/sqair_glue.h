@@ -31,7 +31,7 @@ inline int sq_rnn_width(const SqairConfig& c) { return c.n_hidden * (c.rnn_cell 
 // gate pre-activation columns of the temporal / prior cell: 3 nh (GRU: z, r, candidate), 4 nh (LSTM), nh (VanillaRNN)
 inline int sq_gate_width(const SqairConfig& c, int cell) { return c.n_hidden * (cell == CELL_LSTM ? 4 : (cell == CELL_VANILLA ? 1 : 3)); }
 inline Dims make_dims(const SqairConfig& c, int B) {
-  const int lstm = (c.time_cell == CELL_LSTM) != 0;
+  const bool lstm = c.time_cell == CELL_LSTM;
   return Dims{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles, B * c.k_particles, B,
               4 + c.n_what + 1, lstm ? 2 * c.n_hidden : c.n_hidden, lstm ? c.n_hidden : 0,
               (c.prior_cell == CELL_LSTM) ? 2 * c.n_hidden : c.n_hidden, c.rnn_cell == RNN_LSTM ? 2 * c.n_hidden : c.n_hidden};

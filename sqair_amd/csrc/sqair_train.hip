@@ -114,8 +114,8 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   };
   b.g_lw = take(T * R); b.g_dl = take(T * R);
   b.d_rec_m = take((T + 1) * M * rec::W); b.d_rec_p = take(MT * rec::W); b.d_rec_d = take(MT * rec::W);
-  const int64_t snh = (c.time_cell == CELL_LSTM) ? 2 * nh : nh, gw = sq_gate_width(c, c.time_cell);  // temporal state / gate widths
-  const int64_t psnh = (c.prior_cell == CELL_LSTM) ? 2 * nh : nh, pgw = sq_gate_width(c, c.prior_cell);
+  const int64_t snh = c.time_cell == CELL_LSTM ? 2 * nh : nh, gw = sq_gate_width(c, c.time_cell);  // temporal state / gate widths
+  const int64_t psnh = c.prior_cell == CELL_LSTM ? 2 * nh : nh, pgw = sq_gate_width(c, c.prior_cell);
   const int64_t rw = sq_rnn_width(c);  // slot-RNN pre-activation width
   for (int i = 0; i < 2; ++i) { b.d_tm[i] = take(M * snh); b.d_pm[i] = take(M * psnh); }
   b.d_temporal_p = take(M * snh); b.d_prior_p = take(M * psnh);
@@ -329,7 +329,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       }
       { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_DISC_T3, x, R)); }
       { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU); CK(rundx(L_DISC_T2, x, R)); }
-      if ((c.rnn_cell == RNN_LSTM)) {  // d h_j = T1^T + the next slot's RNN; cell adjoint -> gate pre-activation gradients, d c_{j-1}
+      if (c.rnn_cell == RNN_LSTM) {  // d h_j = T1^T + the next slot's RNN; cell adjoint -> gate pre-activation gradients, d c_{j-1}
         Dx x(d_t1, t1l); x.to(0, nh, b.d_hk, nh);
         if (j < N - 1) x.add(b.d_r[j & 1], nh);
         CK(rundx(L_DISC_T1, x, R));
@@ -363,7 +363,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         if (c.rnn_cell == RNN_GRU) x.acc();
         CK(rundx(L_DISC_RNN, x, R));
         sq_launch_colsum(b.tmp, nh, R, nh, flat_grad + po.disc_rnn_init, 1, s);
-        if ((c.rnn_cell == RNN_LSTM)) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.disc_rnn_init + nh, 1, s);
+        if (c.rnn_cell == RNN_LSTM) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.disc_rnn_init + nh, 1, s);
       }
     }
     // ---- F^T. conditioning of discovery on the propagated latents
@@ -432,7 +432,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         Dx x(d_hraw, hl); x.to(0, nh, b.dhn, nh).add(b.d_temporal_p + (size_t)k * snh, N * snh); CK(rundx(L_PROP_HEADS, x, R));
       }
       if (c.time_cell == CELL_VANILLA) {
-      } else if ((c.time_cell == CELL_LSTM)) {
+      } else if (c.time_cell == CELL_LSTM) {
         // cell adjoint: gate pre-activation gradients (kept for the batched weight gradients and the recurrent-rows dX
         // after the slot loop) and d c_{t-1} -- the first writer of the cell half of d_tau (sections D^T / B^T accumulate)
         sq_launch_lstm_cell_bwd(w.lgates + ((size_t)t * M + k) * 4 * nh, N * 4 * nh, tau_k + nh, N * snh, b.dhn, nh,
@@ -465,7 +465,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       }
       { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_PROP_T3, x, R)); }
       { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU).dup(d_pre_k + rw, pre_rld); CK(rundx(L_PROP_T2, x, R)); }
-      if ((c.rnn_cell == RNN_LSTM)) {  // d h_k total, then the cell adjoint (second copy: this slot's block of d_pre)
+      if (c.rnn_cell == RNN_LSTM) {  // d h_k total, then the cell adjoint (second copy: this slot's block of d_pre)
         Dx x(d_t1, t1l);
         x.to(0, nh, b.d_hk, nh).add(b.d_r[k & 1], nh);
         CK(rundx(L_PROP_T1, x, R));
@@ -499,12 +499,12 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         if (c.rnn_cell == RNN_GRU) x.acc();
         CK(rundx(L_PROP_RNN, x, R));
         sq_launch_colsum(b.tmp, nh, R, nh, flat_grad + po.prop_rnn_init, 1, s);
-        if ((c.rnn_cell == RNN_LSTM)) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.prop_rnn_init + nh, 1, s);
+        if (c.rnn_cell == RNN_LSTM) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.prop_rnn_init + nh, 1, s);
       }
     }
     // ---- D^T. the loop-invariant pre-activation GEMM: segments [m1 nw (pad 64) | z_{t-1} record 56 (pad 64) | temporal nh]
     float* d_m1 = b.d_m1 + (size_t)t * M * M1_LD;
-    if ((c.time_cell == CELL_LSTM)) {  // recurrent rows of the LSTM gates, all slots at once: d h_{t-1} = d gates W_h^T (first writer)
+    if (c.time_cell == CELL_LSTM) {  // recurrent rows of the LSTM gates, all slots at once: d h_{t-1} = d gates W_h^T (first writer)
       Dx x(b.d_gru1 + (size_t)t * M * gw, gw); x.to(0, nh, d_tau, snh); CK(rundx(L_PROP_GRU2, x, M));
     }
     {
@@ -554,7 +554,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       CK(rundx(L_PRIOR_GRU1, x, M));
     } else {
     { Dx x(b.d_pstats + (size_t)t * M * PS_LD, PS_LD); x.to(0, nh, b.dhn, nh).add(b.d_prior_p, psnh); CK(rundx(L_PRIOR_LIN, x, M)); }
-    if ((c.prior_cell == CELL_LSTM)) {
+    if (c.prior_cell == CELL_LSTM) {
       sq_launch_lstm_cell_bwd(w.frame(w.pgz, (int64_t)M * 4 * nh, t), 4 * nh, prior_prev + nh, psnh, b.dhn, nh, b.d_prior_p + nh, psnh,
                               d_pgru1, pgw, d_pprev + nh, psnh, M, nh, s);
       Dx x(d_pgru1, pgw);   // [z_{t-1} record 56 (pad 64) | previous hidden state nh]
@@ -624,7 +624,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     wgrad(L_PROP_T2, {{w.t1, T1_LD}}, b.d_t2, nh, MT);
     wgrad(L_PROP_T3, {{w.t2, nh}}, b.d_tp, TP_LD, MT);
     wgrad(L_PROP_GRU1, {{w.r, nh}, {w.rec_p_all + rec::WHERE, RW}, {w.enc, ENC_LD}}, b.d_gru1, gw, MT);
-    if ((c.time_cell == CELL_LSTM)) {
+    if (c.time_cell == CELL_LSTM) {
       wgrad(L_PROP_GRU2, {{tm_all, snh}}, b.d_gru1, gw, MT);   // recurrent rows + b_gates: A = h_{t-1}
     } else if (c.time_cell == CELL_GRU) {
       hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.gr, nh, tm_all, nh, b.rh, nh, MT, nh);
