@@ -263,6 +263,14 @@ int sqair_forward_persistent(SqairHandle* h, const float* flat_params, const voi
                              int64_t workspace_bytes, void* program, int64_t program_bytes, void* stream);
 int sqair_persistent_status(SqairHandle* h, const void* program, void* stream);
 
+/* ---- workspace clearing.  By default every pass starts by zero-filling the caller's workspace (60 MB for inference,
+ * 308 MB for the training tape at BASELINE configs[1]: ~1-2 % of a step), so that a workspace may hold garbage and may be
+ * shared between shapes.  A caller that keeps ONE workspace per (T, B, inference | training) can clear it once with
+ * sqair_clear_workspace and switch the per-pass fill off with sqair_set_workspace_clearing(h, 0): every buffer is then
+ * either rewritten by the pass or keeps the zeros / finite padding it never overwrites.  Re-clear after changing T or B. */
+int sqair_set_workspace_clearing(SqairHandle* h, int each_pass);
+int sqair_clear_workspace(SqairHandle* h, void* workspace, int64_t workspace_bytes, int T, int B, int train, void* stream);
+
 /* ---- layer chains (EXPERIMENTAL, off by default: measured slower than one launch per layer): the
  * glimpse-encoder chain of a slot as ONE launch, rows split over per-XCD workgroup teams that hand activations over
  * through their XCD's L2 (csrc/sqair_chain.hip).  Same results bit for bit; fewer graph nodes.  Needs the MI355X's 256 CUs;

@@ -77,6 +77,8 @@ _PROTOS = {
                                     C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "sqair_gru_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_void_p, C.c_int64, C.c_void_p]),
+    "sqair_set_workspace_clearing": (C.c_int, [C.c_void_p, C.c_int]),
+    "sqair_clear_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sqair_enable_chains": (C.c_int, [C.c_void_p, C.c_int]),
     "sqair_chain_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sqair_lstm_test": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -844,7 +844,11 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   // clear the caller's (garbage) workspace once per pass
   if (parts & 1) h->chain_no = 0;
   if (parts & 1) {
-    sq_zero_fill(wsbase, (int64_t)((float*)w.prof_ts - wsbase), s);
+    // (clear_each_pass = false: the caller cleared this workspace once with sqair_clear_workspace and reuses it with the
+    //  same T and B -- every buffer is then either rewritten by the pass or holds finite values / zeros it never overwrites;
+    //  only the arrival counters of the layer chains must start from zero)
+    if (h->clear_each_pass) sq_zero_fill(wsbase, (int64_t)((float*)w.prof_ts - wsbase), s);
+    else if (h->use_chain) sq_zero_fill((float*)w.chain_bar, (int64_t)((float*)w.prof_ts - (float*)w.chain_bar), s);
     // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
     sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0, w.snh), w.state(w.prior_m, 0, w.psnh), w.last_id[0], w.disc_init_rec,
                          w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc,
@@ -1165,6 +1169,22 @@ extern "C" int sqair_forward_train(SqairHandle* h, const float* flat_params, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// workspace clearing policy (see sq_forward_impl's prologue)
+extern "C" int sqair_set_workspace_clearing(SqairHandle* h, int each_pass) {
+  if (!h) return -1;
+  h->clear_each_pass = each_pass != 0;
+  return 0;
+}
+extern "C" int sqair_clear_workspace(SqairHandle* h, void* workspace, int64_t workspace_bytes, int T, int B, int train, void* stream) {
+  if (!h || !workspace || T < 1 || B < 1) return -1;
+  const int64_t need = train ? sqair_train_workspace_bytes(h, T, B) : sqair_workspace_bytes(h, T, B);
+  if (workspace_bytes < need) { sq_set_error(h, "sqair_clear_workspace: workspace too small"); return -1; }
+  const Workspace w = sq_carve(h, T, B, (float*)workspace, train != 0);
+  sq_zero_fill((float*)workspace, (int64_t)((float*)w.prof_ts - (float*)workspace), (hipStream_t)stream);
+  SQ_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // layer chains (sqair_chain.hip)
 extern "C" int sqair_enable_chains(SqairHandle* h, int on) {
   if (!h) return -1;

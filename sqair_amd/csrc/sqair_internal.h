@@ -57,6 +57,7 @@ struct SqairHandle {
   std::vector<uint64_t> xprog_key;
   int n_cu = 0;
   // layer chains (sqair_chain.hip): several dependent slot layers per launch; off unless sqair_enable_chains(h, 1)
+  bool clear_each_pass = true;  // zero the caller's workspace at the start of every pass (sqair_set_workspace_clearing)
   bool use_chain = false;
   int chain_no = 0;  // chain launches issued so far in the pass being emitted (selects the counter slot)
   const float* gen_noise = nullptr;  // sqair_set_generation_noise

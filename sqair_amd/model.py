@@ -95,11 +95,19 @@ class SqairCore(object):
             self.stream = torch.cuda.Stream(device=self.device)
         self._shape = None
         self._graph_ready = False
+        _capi.check(self.handle, self.lib.sqair_set_workspace_clearing(self.handle, 0), "sqair_set_workspace_clearing")
         self.chains = False
         if chains is None:
             chains = os.environ.get("SQAIR_CHAINS", "0") == "1"
         if chains:
             self.set_chains(True)
+
+    def _clear_ws(self, ws, train):
+        """One workspace per (T, B, inference | training) is cleared ONCE here; the per-pass zero fill of the library is
+        switched off for this handle (include/sqair_hip.h: sqair_set_workspace_clearing)."""
+        _capi.check(self.handle, self.lib.sqair_clear_workspace(self.handle, ws.data_ptr(), ws.numel() * 4, self.T_bind, self.B_bind,
+                                                                 int(train), self._stream()), "sqair_clear_workspace")
+        self.stream.synchronize()
 
     def set_chains(self, on):
         with torch.cuda.device(self.device):
@@ -172,6 +180,7 @@ class SqairCore(object):
             return
         N, K, nw, G, H, W, nh = self.N, self.K, self.nw, self.G, self.H, self.W, self.nh
         R = B * K
+        self.T_bind, self.B_bind = int(T), int(B)
         shapes = dict(
             what=(T, R, N, nw), what_loc=(T, R, N, nw), what_scale=(T, R, N, nw), where=(T, R, N, 4),
             where_loc=(T, R, N, 4), where_scale=(T, R, N, 4), presence_prob=(T, R, N), presence=(T, R, N),
@@ -205,6 +214,7 @@ class SqairCore(object):
                             "sqair_set_generation_noise")
             self.ws_bytes = self.lib.sqair_workspace_bytes(self.handle, T, B)
             self.workspace = torch.empty(self.ws_bytes // 4, dtype=torch.float32, device=self.device)
+            self._clear_ws(self.workspace, False)
             # ELBO outputs
             self.log_weights = torch.zeros(B, K, dtype=torch.float32, device=self.device)
             self.elbo_iwae_per_example = torch.zeros(B, dtype=torch.float32, device=self.device)
@@ -267,6 +277,7 @@ class SqairCore(object):
                 nb = self.lib.sqair_train_workspace_bytes(self.handle, self.T, self.B)
                 if getattr(self, "train_ws", None) is None or self.train_ws.numel() * 4 < nb:
                     self.train_ws = torch.empty(nb // 4, dtype=torch.float32, device=self.device)
+                    self._clear_ws(self.train_ws, True)
                 args = list(self._args(t_offset))
                 args[9], args[10] = self.train_ws.data_ptr(), nb
                 _capi.check(self.handle, self.lib.sqair_forward_train(*args), "sqair_forward_train")
