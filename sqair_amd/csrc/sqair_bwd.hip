@@ -1009,29 +1009,37 @@ __global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, con
   __syncthreads();
   if (tid < N) inv_s[a.src[(size_t)r * N + tid]] = tid;
   __syncthreads();
-  for (int e = tid; e < 2 * N * RW; e += 256) {
-    const int sl = e / RW, i = e - sl * RW;
+  typedef float cf4 __attribute__((ext_vector_type(4)));   // all gradient rows are 16-byte aligned: 16-byte units throughout
+  const int r4 = RW / 4;
+  for (int e = tid; e < 2 * N * r4; e += 256) {
+    const int sl = e / r4, i = e - sl * r4;
     const int dst = inv_s[sl];
     if (dst < 0) continue;
-    const float g = a.d_rec_next[((size_t)r * N + dst) * RW + i];
-    float* tgt = sl < N ? a.d_rec_p + ((size_t)r * N + sl) * RW : a.d_rec_d + ((size_t)r * N + (sl - N)) * RW;
-    tgt[i] += g;
+    const cf4 g = reinterpret_cast<const cf4*>(a.d_rec_next + ((size_t)r * N + dst) * RW)[i];
+    cf4* tgt = reinterpret_cast<cf4*>(sl < N ? a.d_rec_p + ((size_t)r * N + sl) * RW : a.d_rec_d + ((size_t)r * N + (sl - N)) * RW) + i;
+    *tgt += g;
   }
-  const int snh = d.snh;
-  for (int e = tid; e < 2 * N * snh; e += 256) {
-    const int sl = e / snh, i = e - sl * snh;
+  const int snh = d.snh, t4 = snh / 4;
+  for (int e = tid; e < 2 * N * t4; e += 256) {
+    const int sl = e / t4, i = e - sl * t4;
     const int dst = inv_s[sl];
-    const float gt = dst >= 0 ? a.d_temporal_next[((size_t)r * N + dst) * snh + i] : 0.0f;
-    if (sl < N) a.d_temporal_p[((size_t)r * N + sl) * snh + i] = gt;
-    else if (dst >= 0) unsafeAtomicAdd(&a.flat_grad[po.temporal_init + i], gt);  // a newly discovered object starts from
-  }                                                                                // the trainable initial states
-  const int psnh = d.psnh;
-  for (int e = tid; e < 2 * N * psnh; e += 256) {
-    const int sl = e / psnh, i = e - sl * psnh;
+    const cf4 gt = dst >= 0 ? reinterpret_cast<const cf4*>(a.d_temporal_next + ((size_t)r * N + dst) * snh)[i] : cf4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (sl < N) reinterpret_cast<cf4*>(a.d_temporal_p + ((size_t)r * N + sl) * snh)[i] = gt;
+    else if (dst >= 0) {  // a newly discovered object starts from the trainable initial states
+#pragma unroll
+      for (int q = 0; q < 4; ++q) unsafeAtomicAdd(&a.flat_grad[po.temporal_init + 4 * i + q], gt[q]);
+    }
+  }
+  const int psnh = d.psnh, p4 = psnh / 4;
+  for (int e = tid; e < 2 * N * p4; e += 256) {
+    const int sl = e / p4, i = e - sl * p4;
     const int dst = inv_s[sl];
-    const float gp = dst >= 0 ? a.d_prior_next[((size_t)r * N + dst) * psnh + i] : 0.0f;
-    if (sl < N) a.d_prior_p[((size_t)r * N + sl) * psnh + i] = gp;
-    else if (dst >= 0) unsafeAtomicAdd(&a.flat_grad[po.prior_init + i], gp);
+    const cf4 gp = dst >= 0 ? reinterpret_cast<const cf4*>(a.d_prior_next + ((size_t)r * N + dst) * psnh)[i] : cf4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (sl < N) reinterpret_cast<cf4*>(a.d_prior_p + ((size_t)r * N + sl) * psnh)[i] = gp;
+    else if (dst >= 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) unsafeAtomicAdd(&a.flat_grad[po.prior_init + 4 * i + q], gp[q]);
+    }
   }
 }
 int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t s) {

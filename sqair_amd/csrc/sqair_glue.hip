@@ -672,25 +672,35 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff
   }
   __syncthreads();
   const size_t tr = (size_t)a.t * d.R + r;
-  // copy the N survivors: record (168) + temporal state + prior state, one flat loop of independent loads
+  // copy the N survivors: record (168) + temporal state + prior state, as 16-byte units (all rows are 16-byte aligned;
+  // only the trainable initial states of newly discovered objects come from the unaligned flat parameter buffer)
+  typedef float cf4 __attribute__((ext_vector_type(4)));
   const int snh = d.snh, psnh = d.psnh;
-  const int per = rec::W + snh + psnh;
-#pragma unroll 4
-  for (int e = tid; e < N * per; e += 256) {
-    const int dst = e / per, i = e - dst * per;
+  const int r4 = rec::W / 4, t4 = snh / 4, per4 = r4 + t4 + psnh / 4;
+  for (int e = tid; e < N * per4; e += 256) {
+    const int dst = e / per4, i = e - dst * per4;
     const int sidx = src_s[dst];
     const bool prop = sidx < N;
     const int ss = prop ? sidx : sidx - N;
-    if (i < rec::W) {
+    if (i < r4) {
       const float* rs = (prop ? a.rec_p : a.rec_d) + ((size_t)r * N + ss) * rec::W;
-      a.rec_next[((size_t)r * N + dst) * rec::W + i] = (i == rec::ID) ? id_s[dst] : rs[i];
-    } else if (i < rec::W + snh) {
-      const int q = i - rec::W;
-      a.temporal_next[((size_t)r * N + dst) * snh + q] =
-          prop ? a.temporal_p[((size_t)r * N + ss) * snh + q] : a.flat[po.temporal_init + q];
+      cf4 v = reinterpret_cast<const cf4*>(rs)[i];
+      if (i == rec::ID / 4) v[rec::ID % 4] = id_s[dst];
+      reinterpret_cast<cf4*>(a.rec_next + ((size_t)r * N + dst) * rec::W)[i] = v;
     } else {
-      const int q = i - rec::W - snh;
-      a.prior_next[((size_t)r * N + dst) * psnh + q] = prop ? a.prior_p[((size_t)r * N + ss) * psnh + q] : a.flat[po.prior_init + q];
+      const bool tmp = i < r4 + t4;
+      const int q = tmp ? i - r4 : i - r4 - t4;
+      const int w = tmp ? snh : psnh;
+      const float* sp = tmp ? a.temporal_p : a.prior_p;
+      float* dp = tmp ? a.temporal_next : a.prior_next;
+      cf4 v;
+      if (prop) {
+        v = reinterpret_cast<const cf4*>(sp + ((size_t)r * N + ss) * w)[q];
+      } else {
+        const float* ip = a.flat + (tmp ? po.temporal_init : po.prior_init) + 4 * q;
+        v = cf4{ip[0], ip[1], ip[2], ip[3]};
+      }
+      reinterpret_cast<cf4*>(dp + ((size_t)r * N + dst) * w)[q] = v;
     }
   }
   // the 9 hidden outputs + object id (seq.py:121-134)
