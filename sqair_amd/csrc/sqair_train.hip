@@ -94,6 +94,7 @@ struct BwdSpace {
   float *d_rnn, *d_t1, *d_t2, *d_tp, *d_e1, *d_e2, *d_enc3, *d_gru1, *d_hraw;
   // scratch
   float *d_mask, *d_g, *d_g1, *d_c, *tmp, *d_r[2], *dhn, *d_rh, *d_enc;
+  float *d_init_p, *d_init_d, *d_rn0;            // per-frame dX rows of the trainable initial states: summed once after the sweep
   float *d_cs[2], *d_hk;                        // LSTM slot RNN: d cell state of the neighbouring slot, d hidden of this one
   float *d_gl, *d_mean_rows, *bufa, *bufb, *d_ia, *d_ib, *zs, *rs, *rh;
   int64_t total;
@@ -129,6 +130,7 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   b.d_hraw = take(MT * HRAW_LD);
   b.d_mask = take(M * G2); b.d_g = take(R * G2); b.d_g1 = take(M * G2); b.d_c = take(R * nh);
   b.tmp = take(M * 512);
+  b.d_init_p = take(T * R * nh); b.d_init_d = take(T * R * nh); b.d_rn0 = take(T * R * 4);
   b.d_r[0] = take(R * nh); b.d_r[1] = take(R * nh); b.dhn = take(M * nh); b.d_rh = take(M * nh);
   b.d_enc = take(R * ENC_LD);
   b.d_cs[0] = take(R * nh); b.d_cs[1] = take(R * nh); b.d_hk = take(R * nh);
@@ -288,8 +290,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       ka.d_prior_next = b.d_pm[(t + 1) & 1]; ka.d_rec_p = d_rec_p_t; ka.d_rec_d = d_rec_d_t;
       ka.d_temporal_p = b.d_temporal_p; ka.d_prior_p = b.d_prior_p; ka.flat_grad = flat_grad;
       sq_launch_compact_bwd(ka, po, d, s);
-      sq_zero_fill(d_tau, (int64_t)M * snh, s);
-      sq_zero_fill(d_pprev, (int64_t)M * psnh, s);
+      sq_zero_fill(d_tau, (int64_t)(d_pprev + (size_t)M * psnh - d_tau), s);  // d_tm[i] and d_pm[i] are carved back to back: one fill
     }
     // ---- G^T. discovery steps
     float* d_pre_d = b.d_pre_d + (size_t)t * R * rw;
@@ -342,7 +343,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         const float* g3 = cslotp(w.rgates, 3 * nh, t, 1, j);
         const float* hp = j == 0 ? w.disc_rnn_init : cslotp(w.r, nh, t, 1, j - 1);
         const int g3l = N * 3 * nh, hpl = j == 0 ? 0 : rl;
-        float* dhp = j > 0 ? b.d_r[(j - 1) & 1] : b.tmp;
+        float* dhp = j > 0 ? b.d_r[(j - 1) & 1] : b.d_init_d + (size_t)t * R * nh;
         sq_launch_gru_bwd_a(b.d_hk, nh, g3, g3l, g3 + 2 * nh, g3l, hp, hpl, d_rnn, drl, dhp, nh, R, nh, 0, s);
         { Dx y(d_rnn + 2 * nh, drl); y.to(0, nh, b.d_rh, nh); CK(rundx(L_DISC_RNN2, y, R)); }
         sq_launch_gru_bwd_b(b.d_rh, nh, g3 + nh, g3l, hp, hpl, d_rnn, drl, dhp, nh, R, nh, s);
@@ -359,10 +360,9 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         if (c.rnn_cell == RNN_GRU) x.acc();   // the gate adjoints above already put their direct part there
         CK(rundx(L_DISC_RNN, x, R));
       } else {
-        Dx x(d_rnn, drl); x.to(64, 64 + nh, b.tmp, nh);
+        Dx x(d_rnn, drl); x.to(64, 64 + nh, b.d_init_d + (size_t)t * R * nh, nh);   // d (initial hidden state): column sum after the sweep
         if (c.rnn_cell == RNN_GRU) x.acc();
         CK(rundx(L_DISC_RNN, x, R));
-        sq_launch_colsum(b.tmp, nh, R, nh, flat_grad + po.disc_rnn_init, 1, s);
         if (c.rnn_cell == RNN_LSTM) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.disc_rnn_init + nh, 1, s);
       }
     }
@@ -371,10 +371,9 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     { Dx x(d_pre_d, rw); x.to(0, nh, b.d_c, nh); CK(rundx(L_PRED, x, R)); }
     if (c.rec_where_prior) {
       Dx x(b.d_spre + (size_t)t * R * 128, 128);
-      x.to(0, 4, b.tmp, 4);
+      x.to(0, 4, b.d_rn0 + (size_t)t * R * 4, 4);
       x.to(16, 16 + nh, b.d_c, nh).acc();
       CK(rundx(L_RNCOND, x, R));
-      sq_launch_colsum(b.tmp, 4, R, 4, flat_grad + po.rn_init_state, 1, s);
     }
     {
       float* d_leb = b.d_leb + (size_t)t * M * nh;
@@ -479,7 +478,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         const float* g3 = cslotp(w.rgates, 3 * nh, t, 0, k);
         const float* hp = k == 0 ? w.prop_rnn_init : cslotp(w.r, nh, t, 0, k - 1);
         const int g3l = N * 3 * nh, hpl = k == 0 ? 0 : rl;
-        float* dhp = k > 0 ? b.d_r[(k - 1) & 1] : b.tmp;
+        float* dhp = k > 0 ? b.d_r[(k - 1) & 1] : b.d_init_p + (size_t)t * R * nh;
         sq_launch_gru_bwd_a(b.d_hk, nh, g3, g3l, g3 + 2 * nh, g3l, hp, hpl, d_rnn, drl, dhp, nh, R, nh, 0, s, d_pre_k, pre_rld, 2 * nh);
         { Dx y(d_rnn + 2 * nh, drl); y.to(0, nh, b.d_rh, nh); CK(rundx(L_PROP_RNN2, y, R)); }
         sq_launch_gru_bwd_b(b.d_rh, nh, g3 + nh, g3l, hp, hpl, d_rnn, drl, dhp, nh, R, nh, s, d_pre_k + nh, pre_rld);
@@ -495,10 +494,9 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         if (c.rnn_cell == RNN_GRU) x.acc();
         CK(rundx(L_PROP_RNN, x, R));
       } else {
-        Dx x(d_rnn, drl); x.to(64, 64 + nh, b.tmp, nh);
+        Dx x(d_rnn, drl); x.to(64, 64 + nh, b.d_init_p + (size_t)t * R * nh, nh);
         if (c.rnn_cell == RNN_GRU) x.acc();
         CK(rundx(L_PROP_RNN, x, R));
-        sq_launch_colsum(b.tmp, nh, R, nh, flat_grad + po.prop_rnn_init, 1, s);
         if (c.rnn_cell == RNN_LSTM) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.prop_rnn_init + nh, 1, s);
       }
     }
@@ -576,6 +574,9 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     }
   }
   // ================= initial states, input encoder =================
+  sq_launch_colsum(b.d_init_p, nh, T * R, nh, flat_grad + po.prop_rnn_init, 1, s);
+  sq_launch_colsum(b.d_init_d, nh, T * R, nh, flat_grad + po.disc_rnn_init, 1, s);
+  if (c.rec_where_prior) sq_launch_colsum(b.d_rn0, 4, T * R, 4, flat_grad + po.rn_init_state, 1, s);
   sq_launch_colsum(b.d_tm[0], snh, M, snh, flat_grad + po.temporal_init, 1, s);
   sq_launch_colsum(b.d_pm[0], psnh, M, psnh, flat_grad + po.prior_init, 1, s);
   {
