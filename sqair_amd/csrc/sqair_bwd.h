@@ -20,7 +20,8 @@ struct CompactBwdArgs {
   const float* d_temporal_next; const float* d_prior_next;   // [M][nh]
   float* d_rec_p; float* d_rec_d; // gradient records of this frame (accumulated)
   float* d_temporal_p; float* d_prior_p;                     // [M][nh] (written: every propagation slot)
-  float* flat_grad;
+  float* d_new_temporal; float* d_new_prior;                 // [R][snh], [R][psnh]: per row, the gradient reaching the trainable
+                                                             // initial states through this frame's newly discovered objects
 };
 
 struct TailBwdArgs {

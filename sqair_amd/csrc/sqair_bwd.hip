@@ -1019,27 +1019,39 @@ __global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, con
     cf4* tgt = reinterpret_cast<cf4*>(sl < N ? a.d_rec_p + ((size_t)r * N + sl) * RW : a.d_rec_d + ((size_t)r * N + (sl - N)) * RW) + i;
     *tgt += g;
   }
+  // recurrent states: propagated slots get the gradient of the merged slot they became; newly discovered objects started
+  // from the trainable initial states -- their gradients are summed per row here and over rows / frames after the sweep
+  // (atomics on the 2 x nh parameter words from every row serialise in L2)
+  const cf4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
   const int snh = d.snh, t4 = snh / 4;
-  for (int e = tid; e < 2 * N * t4; e += 256) {
+  for (int e = tid; e < N * t4; e += 256) {
     const int sl = e / t4, i = e - sl * t4;
     const int dst = inv_s[sl];
-    const cf4 gt = dst >= 0 ? reinterpret_cast<const cf4*>(a.d_temporal_next + ((size_t)r * N + dst) * snh)[i] : cf4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (sl < N) reinterpret_cast<cf4*>(a.d_temporal_p + ((size_t)r * N + sl) * snh)[i] = gt;
-    else if (dst >= 0) {  // a newly discovered object starts from the trainable initial states
-#pragma unroll
-      for (int q = 0; q < 4; ++q) unsafeAtomicAdd(&a.flat_grad[po.temporal_init + 4 * i + q], gt[q]);
+    reinterpret_cast<cf4*>(a.d_temporal_p + ((size_t)r * N + sl) * snh)[i] =
+        dst >= 0 ? reinterpret_cast<const cf4*>(a.d_temporal_next + ((size_t)r * N + dst) * snh)[i] : zero4;
+  }
+  for (int i = tid; i < t4; i += 256) {
+    cf4 acc = zero4;
+    for (int sl = N; sl < 2 * N; ++sl) {
+      const int dst = inv_s[sl];
+      if (dst >= 0) acc += reinterpret_cast<const cf4*>(a.d_temporal_next + ((size_t)r * N + dst) * snh)[i];
     }
+    reinterpret_cast<cf4*>(a.d_new_temporal + (size_t)r * snh)[i] = acc;
   }
   const int psnh = d.psnh, p4 = psnh / 4;
-  for (int e = tid; e < 2 * N * p4; e += 256) {
+  for (int e = tid; e < N * p4; e += 256) {
     const int sl = e / p4, i = e - sl * p4;
     const int dst = inv_s[sl];
-    const cf4 gp = dst >= 0 ? reinterpret_cast<const cf4*>(a.d_prior_next + ((size_t)r * N + dst) * psnh)[i] : cf4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (sl < N) reinterpret_cast<cf4*>(a.d_prior_p + ((size_t)r * N + sl) * psnh)[i] = gp;
-    else if (dst >= 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) unsafeAtomicAdd(&a.flat_grad[po.prior_init + 4 * i + q], gp[q]);
+    reinterpret_cast<cf4*>(a.d_prior_p + ((size_t)r * N + sl) * psnh)[i] =
+        dst >= 0 ? reinterpret_cast<const cf4*>(a.d_prior_next + ((size_t)r * N + dst) * psnh)[i] : zero4;
+  }
+  for (int i = tid; i < p4; i += 256) {
+    cf4 acc = zero4;
+    for (int sl = N; sl < 2 * N; ++sl) {
+      const int dst = inv_s[sl];
+      if (dst >= 0) acc += reinterpret_cast<const cf4*>(a.d_prior_next + ((size_t)r * N + dst) * psnh)[i];
     }
+    reinterpret_cast<cf4*>(a.d_new_prior + (size_t)r * psnh)[i] = acc;
   }
 }
 int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t s) {

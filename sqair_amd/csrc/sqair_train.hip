@@ -94,6 +94,7 @@ struct BwdSpace {
   float *d_rnn, *d_t1, *d_t2, *d_tp, *d_e1, *d_e2, *d_enc3, *d_gru1, *d_hraw;
   // scratch
   float *d_mask, *d_g, *d_g1, *d_c, *tmp, *d_r[2], *dhn, *d_rh, *d_enc;
+  float *d_new_t, *d_new_p;                      // [T][R][snh | psnh]: compaction adjoint rows for the initial recurrent states
   float *d_init_p, *d_init_d, *d_rn0;            // per-frame dX rows of the trainable initial states: summed once after the sweep
   float *d_cs[2], *d_hk;                        // LSTM slot RNN: d cell state of the neighbouring slot, d hidden of this one
   float *d_gl, *d_mean_rows, *bufa, *bufb, *d_ia, *d_ib, *zs, *rs, *rh;
@@ -130,6 +131,7 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   b.d_hraw = take(MT * HRAW_LD);
   b.d_mask = take(M * G2); b.d_g = take(R * G2); b.d_g1 = take(M * G2); b.d_c = take(R * nh);
   b.tmp = take(M * 512);
+  b.d_new_t = take(T * R * snh); b.d_new_p = take(T * R * psnh);
   b.d_init_p = take(T * R * nh); b.d_init_d = take(T * R * nh); b.d_rn0 = take(T * R * 4);
   b.d_r[0] = take(R * nh); b.d_r[1] = take(R * nh); b.dhn = take(M * nh); b.d_rh = take(M * nh);
   b.d_enc = take(R * ENC_LD);
@@ -288,7 +290,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       CompactBwdArgs ka; memset(&ka, 0, sizeof(ka));
       ka.src = w.src + (size_t)t * M; ka.d_rec_next = d_rec_next; ka.d_temporal_next = b.d_tm[(t + 1) & 1];
       ka.d_prior_next = b.d_pm[(t + 1) & 1]; ka.d_rec_p = d_rec_p_t; ka.d_rec_d = d_rec_d_t;
-      ka.d_temporal_p = b.d_temporal_p; ka.d_prior_p = b.d_prior_p; ka.flat_grad = flat_grad;
+      ka.d_temporal_p = b.d_temporal_p; ka.d_prior_p = b.d_prior_p;
+      ka.d_new_temporal = b.d_new_t + (size_t)t * R * snh; ka.d_new_prior = b.d_new_p + (size_t)t * R * psnh;
       sq_launch_compact_bwd(ka, po, d, s);
       sq_zero_fill(d_tau, (int64_t)(d_pprev + (size_t)M * psnh - d_tau), s);  // d_tm[i] and d_pm[i] are carved back to back: one fill
     }
@@ -577,6 +580,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   sq_launch_colsum(b.d_init_p, nh, T * R, nh, flat_grad + po.prop_rnn_init, 1, s);
   sq_launch_colsum(b.d_init_d, nh, T * R, nh, flat_grad + po.disc_rnn_init, 1, s);
   if (c.rec_where_prior) sq_launch_colsum(b.d_rn0, 4, T * R, 4, flat_grad + po.rn_init_state, 1, s);
+  sq_launch_colsum(b.d_new_t, snh, T * R, snh, flat_grad + po.temporal_init, 1, s);
+  sq_launch_colsum(b.d_new_p, psnh, T * R, psnh, flat_grad + po.prior_init, 1, s);
   sq_launch_colsum(b.d_tm[0], snh, M, snh, flat_grad + po.temporal_init, 1, s);
   sq_launch_colsum(b.d_pm[0], psnh, M, psnh, flat_grad + po.prior_init, 1, s);
   {
