@@ -185,6 +185,102 @@ __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wider throughput variant (EPI_ACT layers only): every wave takes ONE 16-row tile against NT consecutive 16-column weight
+// slabs, so an activation fragment loaded once feeds NT MFMA chains (k_linear_rows: NT = 1) and the traffic towards L2 per
+// MFMA drops from 5 KB to (4 + NT) KB per 4 * NT tiles.  Accumulation order per output element = k_linear_rows'
+// (two accumulators, x/z and y/w), i.e. bit-identical results.
+// ---------------------------------------------------------------------------------------------------
+template <int NCH, int NT>
+__global__ __launch_bounds__(256) void k_linear_wide(const LinArgs a, const int kc_total, const int n_tiles,
+                                                     unsigned long long* __restrict__ prof_ts) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
+  const int tile_n0 = blockIdx.x * NT;
+  const int tile_m = blockIdx.y * 4 + wave;
+  const int arow = min(tile_m * 16 + (lane & 15), a.M - 1);
+  unsigned long long t_start = 0;
+  if (prof_ts != nullptr && tid == 0) t_start = wall_clock64();
+  float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : a.bias);
+  p_scale = a.scale_ptr != nullptr ? p_scale : 1.0f;
+  int cum1 = 0x7fffffff, cum2 = 0x7fffffff, cum3 = 0x7fffffff;
+#define SQ_ROWOF(sg) ((sg).rmul ? (int)__umulhi((unsigned)arow, (sg).rmul) : arow)
+  const float* rp0 = a.seg[0].p + (size_t)SQ_ROWOF(a.seg[0]) * a.seg[0].ld;
+  const float* rp1 = rp0; const float* rp2 = rp0; const float* rp3 = rp0;
+  int lim0 = ((a.seg[0].width + 3) & ~3) - 4, lim1 = 0, lim2 = 0, lim3 = 0;
+  {
+    int c = (a.seg[0].width + 15) >> 4;
+    if (a.nseg > 1) { cum1 = c; c += (a.seg[1].width + 15) >> 4; rp1 = a.seg[1].p + (size_t)SQ_ROWOF(a.seg[1]) * a.seg[1].ld; lim1 = ((a.seg[1].width + 3) & ~3) - 4; }
+    if (a.nseg > 2) { cum2 = c; c += (a.seg[2].width + 15) >> 4; rp2 = a.seg[2].p + (size_t)SQ_ROWOF(a.seg[2]) * a.seg[2].ld; lim2 = ((a.seg[2].width + 3) & ~3) - 4; }
+    if (a.nseg > 3) { cum3 = c; rp3 = a.seg[3].p + (size_t)SQ_ROWOF(a.seg[3]) * a.seg[3].ld; lim3 = ((a.seg[3].width + 3) & ~3) - 4; }
+  }
+#undef SQ_ROWOF
+  f32x4 acc0[NT], acc1[NT];
+  const f32x4* wp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    acc0[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc1[t] = acc0[t];
+    wp[t] = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)min(tile_n0 + t, n_tiles - 1) * kc_total) * 64 + lane;  // surplus tiles re-read the last slab
+  }
+  const f32x4* __restrict__ wz = reinterpret_cast<const f32x4*>(a.wzero) + lane;
+#pragma unroll 1
+  for (int base = 0; base < kc_total; base += NCH) {
+    f32x4 av[NCH], bv[NT][NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const bool valid = base + j < kc_total;
+      const int g = valid ? base + j : 0;
+      const bool s1 = g >= cum1, s2 = g >= cum2, s3 = g >= cum3;
+      const float* rp = s3 ? rp3 : (s2 ? rp2 : (s1 ? rp1 : rp0));
+      const int cb = s3 ? cum3 : (s2 ? cum2 : (s1 ? cum1 : 0));
+      const int lim = s3 ? lim3 : (s2 ? lim2 : (s1 ? lim1 : lim0));
+      av[j] = *reinterpret_cast<const f32x4*>(rp + min((g - cb) * 16 + kq * 4, lim));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[t][j] = *(valid ? wp[t] + (size_t)g * 64 : wz);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[t][j].x, acc0[t], 0, 0, 0);
+        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[t][j].y, acc1[t], 0, 0, 0);
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[t][j].z, acc0[t], 0, 0, 0);
+        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[t][j].w, acc1[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = (tile_n0 + t) * 16 + (lane & 15);
+    if (tile_n0 + t < n_tiles && n < a.N) {
+      const float p_bias = a.bias[n];
+      const bool use_add = a.add != nullptr && n < a.add_n;
+      const int act = n < a.act_split ? a.act_a : a.act_b;
+      const float accv[4] = {acc0[t].x + acc1[t].x, acc0[t].y + acc1[t].y, acc0[t].z + acc1[t].z, acc0[t].w + acc1[t].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = tile_m * 16 + 4 * kq + i;
+        if (m < a.M) {
+          float p_add = 0.0f;
+          if (use_add) {
+            const int mcd = a.add_rmul ? (int)__umulhi((unsigned)m, a.add_rmul) : m;
+            p_add = a.add[(size_t)mcd * a.add_ld + n];
+          }
+          const float v = sq_act(accv[i] + p_bias + p_add, act);
+          a.out[(size_t)m * a.out_ld + n] = v * a.scale * p_scale;
+        }
+      }
+    }
+  }
+  if (prof_ts != nullptr) {
+    __syncthreads();
+    if (tid == 0) {
+      atomicMin(prof_ts, t_start);
+      atomicMax(prof_ts + 4096, wall_clock64());
+    }
+  }
+}
+
 template <int NCH>
 static void launch_nch(const LinArgs& a, const PackedLayer& L, int grid, hipStream_t s, unsigned long long* prof_ts) {
   (void)grid;
@@ -211,6 +307,16 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
     if ((reinterpret_cast<uintptr_t>(sg.p) & 15) != 0 || (sg.ld & 3) != 0 || sg.width < 1 || sg.rdiv < 1) return -5;
   }
   if (a.M >= 2048 || (a.M >= 256 && L.kc * L.nt >= 400 && L.kc <= 32)) {  // big batched once-per-frame layers: throughput variant
+    // two column slabs per wave for launches with >= 1024 rows (measured at cfg-2 shapes: the 640-row per-frame layers lose
+    // 2 % with it, the 6400-row decoder layers are neutral, and at 256 sequences per GPU -- where the slot layers have 1280
+    // rows -- the whole pass gains 10 %; four slabs per wave: +4 % only)
+    const int wgs2 = ((L.nt + 1) / 2) * ((mt + 3) / 4);
+    if (a.epi == EPI_ACT && L.kc <= 32 && L.nt >= 2 && a.M >= 1024 && wgs2 >= 128) {
+      const dim3 g2((L.nt + 1) / 2, (mt + 3) / 4);
+      if (L.kc <= 4) hipLaunchKernelGGL((k_linear_wide<4, 2>), g2, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+      else hipLaunchKernelGGL((k_linear_wide<8, 2>), g2, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+      return 0;
+    }
     const dim3 grid_r(L.nt, (mt + 3) / 4);
     if (L.kc <= 4) hipLaunchKernelGGL(k_linear_rows<4>, grid_r, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
     else if (L.kc <= 8) hipLaunchKernelGGL(k_linear_rows<8>, grid_r, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
