@@ -124,25 +124,45 @@ def main():
                     help="slot RNN of both cores (shipped: VanillaRNN)")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher — one rank per GPU under torch.distributed.run, exactly the
+        # command line the driver uses; the ranks' stdout (rank 0's JSON line last) passes through
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    # (SQAIR_DIST_BACKEND=gloo lets two ranks share one GPU for a functional check of the N > 1 code path on a 1-GPU box)
-    backend = os.environ.get("SQAIR_DIST_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count()
+    if args.gpus != world:
+        raise SystemExit("--gpus {} but WORLD_SIZE {} (launch one rank per GPU, or run without WORLD_SIZE)".format(args.gpus, world))
+    n_dev = torch.cuda.device_count()
+    # RCCL wants one device per rank.  With fewer visible devices than ranks (the 1-GPU test box) the ranks share devices
+    # and the process group falls back to gloo — a functional check of the N > 1 code path, reported as such
+    # ("rccl_ranks": 0); SQAIR_DIST_BACKEND overrides.
+    backend = os.environ.get("SQAIR_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("SQAIR_FORCE_DIST") == "1":  # (the env knob: single-rank RCCL group, to measure what
-        import torch.distributed as dist                            #  the collectives' own stream costs the graph replays)
+        import torch.distributed as dist                            #  a communicator in the process costs the graph replays)
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = dict(device_id=torch.device("cuda", local_rank)) if backend == "nccl" else {}
         dist.init_process_group(backend=backend, **kw)  # "nccl" = RCCL on ROCm
-    assert args.gpus == world, "--gpus {} but WORLD_SIZE {}".format(args.gpus, world)
+    # the training step's gradient all-reduce goes through RCCL's C API on the library's own launch stream
+    comm = None
+    if dist is not None and backend == "nccl":
+        from sqair_amd.rccl import RcclComm
+        comm = RcclComm.from_process_group("cuda:{}".format(local_rank))
 
     from sqair_amd.data import config_inputs
     from sqair_amd.flags import make_flags
@@ -223,7 +243,7 @@ def main():
     if n_train > 0:
         from sqair_amd.train import Trainer
         Ftr = make_flags(**dict(ov, learning_rate=1e-5, train_itr=1000000))
-        trainer = Trainer(model, Ftr, use_graph=use_graph)
+        trainer = Trainer(model, Ftr, use_graph=use_graph, comm=comm)
         for _ in range(max(2, min(args.warmup, 3))):
             trainer.step(seed=2000, global_batch=B * world, b0=rank * B)
         torch.cuda.synchronize()
@@ -244,8 +264,10 @@ def main():
             el = float(tt.item())
         train = dict(value=frames_per_step / (el / n_train), unit="frames/s", ms_per_step=el / n_train * 1e3, steps=n_train,
                      scaling="weak", graph_nodes=getattr(core, "train_graph_nodes", None),
-                     collective="all-reduce(sum) of {} fp32 gradients ({:.1f} MB) per step over RCCL, / world".format(
-                         core.n_params, core.n_params * 4 / 1e6) if world > 1 else "none (1 rank)",
+                     collective="all-reduce(sum) of {} fp32 gradients ({:.1f} MB) per step, {}; 1/world folded into the fused "
+                                "RMSProp kernel".format(core.n_params, core.n_params * 4 / 1e6,
+                                                        "ncclAllReduce (RCCL C API) on the launch stream" if comm is not None
+                                                        else "torch.distributed " + backend) if world > 1 else "none (1 rank)",
                      what="draw noise + forward(train) + VIMCO target + backward (one HIP-graph replay) + all-reduce + "
                           "RMSProp + re-pack; finite={}".format(bool(torch.isfinite(core.flat).all())))
         core.set_params(P)  # back to the benchmark parameters for the parity / roofline legs below
@@ -253,6 +275,8 @@ def main():
     if rank != 0:
         if dist is not None:
             dist.barrier()
+            if comm is not None:
+                comm.destroy()
             dist.destroy_process_group()
         return
 
@@ -315,6 +339,7 @@ def main():
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "rccl_ranks": comm.n_ranks if comm is not None else 0, "dist_backend": (backend if dist is not None else None),
         "config": {"workload": "cfg{}: T={} HxW={}x{} B={}/GPU K={} N={} cells {}/{}/{} forward (elbo_iwae), HIP-graph replay={}".format(
             args.cfg, T, hw[0], hw[1], B, K, N, args.transition, args.time_transition, args.prior_transition, use_graph), "global_batch": B * world, "seq_len": T,
             "parallelism": "dp{}".format(world), "graph_nodes": core.graph_nodes()},
@@ -331,6 +356,8 @@ def main():
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
+        if comm is not None:
+            comm.destroy()
         dist.destroy_process_group()
 
 

@@ -52,9 +52,19 @@ def reduce_scalars(values, world=None):
     return t
 
 
-def allreduce_flat_grads(flat_grad):
-    """The single collective of a training step: sum the flat gradient buffer over ranks, divide by world."""
+def allreduce_flat_grads(flat_grad, comm=None, stream=None):
+    """The single collective of a training step: sum the flat gradient buffer over the ranks, in place.  Returns the
+    factor 1 / world that turns the sum into the reference's ``reduce_mean`` over the global batch — the caller folds it
+    into the fused optimiser kernel (``sqair_rmsprop_step``'s ``grad_scale``) instead of spending a kernel on a division.
+
+    ``comm`` (a ``sqair_amd.rccl.RcclComm``) enqueues ``ncclAllReduce`` on ``stream`` — the library's own launch stream,
+    so the step stays on ONE hardware queue; without it the default ``torch.distributed`` group is used (gloo in the CPU
+    tests and on boxes with fewer devices than ranks)."""
+    if comm is not None:
+        if comm.world > 1:
+            comm.all_reduce_sum_(flat_grad, stream)
+        return 1.0 / comm.world
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
-        flat_grad.div_(dist.get_world_size())
-    return flat_grad
+        return 1.0 / dist.get_world_size()
+    return 1.0

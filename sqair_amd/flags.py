@@ -50,10 +50,10 @@ DATA_FLAGS = dict(train_path="seq_mnist_train.pickle", valid_path="seq_mnist_val
                   seq_len=0, stage_itr=0)
 
 DRIVER_FLAGS = dict(
-    data_config="configs/seq_mnist_data.py", model_config="configs/mlp_mnist_model.py",
+    data_config="configs/orig_seq_mnist.py", model_config="configs/mlp_mnist_model.py",
     results_dir="../checkpoints", run_name="test_run", batch_size=32,
     log_itr=int(1e4), report_loss_every=int(1e3), save_itr=int(1e5), fig_itr=int(1e4),
-    train_itr=int(2e6), resume=False, log_at_start=False, eval_on_train=False,
+    train_itr=int(2e6), resume=False, log_at_start=False, eval_on_train=True,
     eval_size_fraction=1.0, opt="rmsprop", learning_rate=1e-5, l2=0.0, schedule="4,6,10",
     test_run=False, gpu="0", debug=False,
 )

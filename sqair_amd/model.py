@@ -253,6 +253,10 @@ class SqairCore(object):
             _capi.check(self.handle, self.lib.sqair_fill_noise(
                 self.handle, self.noise.data_ptr(), self.T, self.B, int(global_batch or self.B), int(b0), int(seed), int(step),
                 self._stream()), "sqair_fill_noise")
+            if self.gen_noise is not None:  # the prior samples of the generation modes: an independent Philox key
+                _capi.check(self.handle, self.lib.sqair_fill_noise(
+                    self.handle, self.gen_noise.data_ptr(), self.T, self.B, int(global_batch or self.B), int(b0),
+                    int(seed) ^ 0x9E3779B97F4A7C15, int(step), self._stream()), "sqair_fill_noise")
             self._join_out()
 
     # ---- execution ---------------------------------------------------------------------------------
@@ -442,6 +446,27 @@ class Model(object):
         self._ran = False
         self._use_graph = False
 
+    def rebind(self, obs, presence=None):
+        """New input tensors of a possibly different [T, B] (the sequence-length curriculum, mnist_tools.py:80-92, or a new
+        batch size): the reference re-slices its input pipeline; here the core's buffers are re-bound and the model's
+        own shape-dependent attributes follow, so that metrics normalise by the CURRENT T and compare against the
+        CURRENT frames."""
+        core = self.core
+        obs = torch.as_tensor(obs, dtype=torch.float32)
+        if obs.dim() == 5:
+            obs = obs[..., 0]
+        self.obs = obs.to(core.device)
+        if presence is not None:
+            self.gt_presence = torch.as_tensor(presence, dtype=torch.float32).to(core.device)
+        elif self.gt_presence is not None and tuple(self.gt_presence.shape[:2]) != tuple(obs.shape[:2]):
+            self.gt_presence = None   # ground truth of another batch: the accuracy is undefined until a new one is given
+        self.n_timesteps, self.batch_size = int(obs.shape[0]), int(obs.shape[1])
+        self.tiled_batch_size = self.batch_size * self.k_particles
+        core.bind(self.n_timesteps, self.batch_size, core._shape[2] if core._shape else "all")
+        with core.on_stream():
+            core.obs.copy_(self.obs)
+        self._ran = False
+
     # `sess.run` --------------------------------------------------------------------------------------
     def run(self, noise=None, generator=None, resample_u=None, use_graph=None, gen_noise=None):
         """``sess.run`` of the whole output dict: synchronous like its reference counterpart (returns when the results
@@ -534,7 +559,8 @@ class Model(object):
         """reference: sqair/model.py:150-168.  Returns (target, grads_and_vars): the VIMCO target (already divided
         by T, plus the l2 term) from the fused ELBO kernel and, when an optimiser is given, the gradients of every
         trainable variable from the HIP backward pass as a list of (gradient tensor, variable name) — the
-        reference's ``opt.compute_gradients(target)``.  ``opt.apply_gradients(gvs)`` (sqair_amd.train.Optimizer)
+        reference's ``opt.compute_gradients(target)``; the tensors are views of ``core.flat_grad``.
+        ``opt.apply_gradients(gvs)`` (sqair_amd.train.Optimizer; learning rate from the flags' schedule unless given)
         performs the update."""
         core = self.core
         if opt is None:

@@ -9,7 +9,8 @@ checkpoint can be mapped onto the flat buffer later.
 
 The flat buffer is what crosses the C-ABI (``sqair_bind_params``): entries in the order of
 ``param_spec`` below, each row-major, fp32, no padding.  ``include/sqair_hip.h`` documents
-the same order; ``tests/test_params.py`` checks that the C library's table agrees.
+the same order; ``tests/test_tf_variables.py`` checks names, shapes and scope totals against the
+reference's listing, ``tests/test_capi_host.py`` that the C library's table agrees.
 
 Initialisers restate the defaults the reference relies on:
 ``snt.Linear`` w ~ TruncNormal(0, 1/sqrt(fan_in)) and b = 0 unless overridden
@@ -59,7 +60,11 @@ def param_spec(F, img_hw):
                  "decoder/air_decoder/decoder/output_scale"))
 
     # ---- discovery (core.py:146-227, sqair_modules.py:66-229, modules.py:548-630)
-    d = "discovery/discover/discovery_core"
+    # TF variable scopes, verbatim from the reference's own listing (notebooks/play.ipynb:239-362, committed as
+    # tests/golden/tf_variables.json): the shared estimators live under the DiscoveryCore module scope
+    # `discovery/discovery_core`, the cells constructed in configs/mlp_mnist_model.py:98,118-125 directly under
+    # `discovery/` and `propagation/`, trainable initial states under <calling scope>/<cell scope>_initial_state_i.
+    d = "discovery/discovery_core"
     rnn_cell = str(getattr(F, "transition", "VanillaRNN"))   # the slot RNN of both cores (mlp_mnist_model.py:86)
     rnn_lstm, rnn_gru = rnn_cell == "LSTM", rnn_cell == "GRU"
     rmod = "lstm" if rnn_lstm else ("gru" if rnn_gru else "vanilla_rnn")
@@ -69,7 +74,7 @@ def param_spec(F, img_hw):
     lin("disc.steps_prior.l0", 1, 10, "discovery/discover/mlp/linear")
     lin("disc.steps_prior.l1", 10, N + 1, "discovery/discover/mlp/linear_1")
     rn = "discovery/discover/recurrent_normal_impl"
-    spec.append(("disc.rn.init_state", (1, 4), ("zeros",), rn + "/vanilla_rnn_initial_state_0/w"))
+    spec.append(("disc.rn.init_state", (1, 4), ("zeros",), rn + "/" + rn + "/vanilla_rnn_initial_state_0/w"))
     spec.append(("disc.rn.init_sample", (1, 4), ("glorot", 1, 4), rn + "/init_sample"))
     sp = parse_string_flag(F.scale_prior, num_elements=2)
     lin("disc.rn.readout", 4, 8, rn + "/linear",
@@ -94,19 +99,19 @@ def param_spec(F, img_hw):
                  d + "/stochastic_transform_param/scale_offset"))
     fin_d = nh + nh + nw + 4 + 1
     if rnn_lstm:
-        spec.append(("disc.rnn_lstm.w", (fin_d + nh, 4 * nh), ("lin_w", fin_d + nh), d + "/lstm/w_gates"))
-        spec.append(("disc.rnn_lstm.b", (4 * nh,), ("zeros",), d + "/lstm/b_gates"))
+        spec.append(("disc.rnn_lstm.w", (fin_d + nh, 4 * nh), ("lin_w", fin_d + nh), "discovery/lstm/w_gates"))
+        spec.append(("disc.rnn_lstm.b", (4 * nh,), ("zeros",), "discovery/lstm/b_gates"))
     elif rnn_gru:
-        gru("disc.rnn_gru", fin_d, d + "/gru")
+        gru("disc.rnn_gru", fin_d, "discovery/gru")
     else:
-        lin("disc.rnn.h2h", nh, nh, d + "/vanilla_rnn/hidden_to_hidden")
-        lin("disc.rnn.i2h", fin_d, nh, d + "/vanilla_rnn/in_to_hidden")
+        lin("disc.rnn.h2h", nh, nh, "discovery/vanilla_rnn/hidden_to_hidden")
+        lin("disc.rnn.i2h", fin_d, nh, "discovery/vanilla_rnn/in_to_hidden")
 
     # ---- model-scope categorical step prior (sqair_modules.py:209-221)
     spec.append(("disc.step_prior_bias", (N + 1,), ("zeros",),
-                 "model/sequential_air/sqair_timestep/discover/step_prior_bias"))
+                 "model/sequential_air/while/sqair_timestep/discover/step_prior_bias"))
     spec.append(("disc.step_prior_timestep_bias", (N + 1,), ("vec", [10.0] + [0.0] * N),
-                 "model/sequential_air/sqair_timestep/discover/step_prior_timestep_bias"))
+                 "model/sequential_air/while/sqair_timestep/discover/step_prior_timestep_bias"))
 
     # ---- propagation (core.py:230-359, propagate.py:46-120)
     pc = "propagation/propagation_core"
@@ -169,18 +174,18 @@ def param_spec(F, img_hw):
     fin_p = nw + (nw + 4 + 1) + (nw + 4 + 1) + nh
     if rnn_lstm:
         spec.append(("prop.rnn_init_c", (1, nh), ("zeros",), "propagation/sequential_ssm/propagation/" + rmod + "_initial_state_1/w"))
-        spec.append(("prop.rnn_lstm.w", (fin_p + nh, 4 * nh), ("lin_w", fin_p + nh), pc + "/lstm/w_gates"))
-        spec.append(("prop.rnn_lstm.b", (4 * nh,), ("zeros",), pc + "/lstm/b_gates"))
+        spec.append(("prop.rnn_lstm.w", (fin_p + nh, 4 * nh), ("lin_w", fin_p + nh), "propagation/lstm/w_gates"))
+        spec.append(("prop.rnn_lstm.b", (4 * nh,), ("zeros",), "propagation/lstm/b_gates"))
     elif rnn_gru:
-        gru("prop.rnn_gru", fin_p, pc + "/gru")
+        gru("prop.rnn_gru", fin_p, "propagation/gru")
     else:
-        lin("prop.rnn.h2h", nh, nh, pc + "/vanilla_rnn/hidden_to_hidden")
-        lin("prop.rnn.i2h", fin_p, nh, pc + "/vanilla_rnn/in_to_hidden")
+        lin("prop.rnn.h2h", nh, nh, "propagation/vanilla_rnn/hidden_to_hidden")
+        lin("prop.rnn.i2h", fin_p, nh, "propagation/vanilla_rnn/in_to_hidden")
 
     # ---- sequence (sqair_modules.py:332-385)
     # trainable initial states, named after the cell's module name (RNNCore.initial_state(trainable=True)); an
     # LSTMState(hidden, cell) has two variables, kept adjacent ([hidden | cell] is read as one row)
-    sq = "sequence/sequential_air/"
+    sq = "sequence/sequential_air/propagation/"
     spec.append(("seq.prior_init", (1, nh), ("zeros",), sq + pmod + "_initial_state_0/w"))
     if prior_lstm:
         spec.append(("seq.prior_init_c", (1, nh), ("zeros",), sq + pmod + "_initial_state_1/w"))

@@ -27,7 +27,8 @@ def lr_schedule(F):
 
 def learning_rate(F, step):
     bounds, values = lr_schedule(F)
-    i = int(np.searchsorted(np.asarray(bounds), step, side="right"))
+    # tf.train.piecewise_constant: values[0] for x <= boundaries[0], values[i] for boundaries[i-1] < x <= boundaries[i]
+    i = int(np.searchsorted(np.asarray(bounds), step, side="left"))
     return values[i]
 
 
@@ -62,11 +63,27 @@ class Optimizer(object):
         self.mom = torch.zeros_like(core.flat)
         self.t = 0
 
-    def apply_gradients(self, flat_grad, lr, grad_scale=1.0):
-        """theta <- theta - update(grad_scale * flat_grad); re-packs the weights for the next forward pass."""
+    def compute_gradients(self, model, l2_reg=0.0):
+        """``opt.compute_gradients(target)`` of the reference (model.py:159-161): evaluates the VIMCO target and the gradient
+        of every trainable variable for the model's current batch; returns the (gradient, variable name) list."""
+        return model.make_target(self, l2_reg=l2_reg)[1]
+
+    def apply_gradients(self, grads, lr=None, grad_scale=1.0, global_step=None):
+        """theta <- theta - update(grad_scale * grad); re-packs the weights for the next forward pass.  ``grads`` is the
+        core's flat gradient tensor or the (gradient, name) list ``Model.make_target`` / ``compute_gradients`` return (its
+        entries are views of that flat tensor).  ``lr`` defaults to the piecewise schedule of the core's flags at
+        ``global_step`` (experiment.py:127-138; default: the number of updates applied so far)."""
         import torch
         from . import _capi
         core = self.core
+        if isinstance(grads, (list, tuple)):
+            if len(grads) != len(core.spec):
+                raise ValueError("expected one (gradient, name) pair per variable ({}), got {}".format(len(core.spec), len(grads)))
+            flat_grad = core.flat_grad
+        else:
+            flat_grad = grads
+        if lr is None:
+            lr = learning_rate(core.F, self.t if global_step is None else int(global_step))
         self.t += 1
         if self.kind == "rmsprop":
             with torch.cuda.device(core.device):
@@ -96,13 +113,16 @@ class Trainer(object):
     buffer over the ranks (the single collective of the step, RCCL over xGMI), apply the optimiser.
     ``model`` is a ``sqair_amd.model.Model`` bound to this rank's shard."""
 
-    def __init__(self, model, F, use_graph=True):
+    def __init__(self, model, F, use_graph=True, comm=None):
+        """comm: a ``sqair_amd.rccl.RcclComm`` — the gradient all-reduce is then enqueued on the core's own stream
+        (``ncclAllReduce``); None = the default ``torch.distributed`` group, if one is initialised."""
         self.model, self.core, self.F = model, model.core, F
+        self.comm = comm
         self.opt = Optimizer(self.core, getattr(F, "opt", "rmsprop"))
         self.step_no = 0
         self.use_graph = bool(use_graph)
 
-    def step(self, obs=None, noise=None, generator=None, seed=None, global_batch=None, b0=0):
+    def step(self, obs=None, noise=None, generator=None, seed=None, global_batch=None, b0=0, presence=None):
         """One training step, asynchronous on the core's stream (``core.stream.synchronize()`` or read metrics inside
         ``core.on_stream()`` to observe results)."""
         import torch
@@ -114,12 +134,18 @@ class Trainer(object):
             if obs.dim() == 5:
                 obs = obs[..., 0]
             if int(obs.shape[0]) != core.T or int(obs.shape[1]) != core.B:
-                # sequence-length curriculum (mnist_tools.py:80-92) or a new batch size: re-bind the buffers for the new
-                # shape (the gradient graph is re-captured on the next evaluation)
-                core.bind(int(obs.shape[0]), int(obs.shape[1]), core._shape[2])
+                # sequence-length curriculum (mnist_tools.py:80-92) or a new batch size: re-bind through the Model so that
+                # its n_timesteps / batch_size / obs / ground truth follow (the gradient graph is re-captured on the next
+                # evaluation)
+                self.model.rebind(obs, presence=presence)
+                obs = None
+            else:
+                self.model.obs = obs.to(core.device)
+                if presence is not None:
+                    self.model.gt_presence = torch.as_tensor(presence, dtype=torch.float32).to(core.device)
         with core.on_stream():
             if obs is not None:
-                core.obs.copy_(obs.reshape(core.obs.shape))
+                core.obs.copy_(self.model.obs.reshape(core.obs.shape))
             if noise is not None:
                 core.noise.copy_(torch.as_tensor(noise, dtype=torch.float32).reshape(core.noise.shape))
             elif seed is not None:  # library Philox keyed by (seed, step, position in the global batch)
@@ -131,7 +157,7 @@ class Trainer(object):
             if l2 != 0.0:
                 _capi.check(core.handle, core.lib.sqair_add_l2_grad(
                     core.handle, core.flat.data_ptr(), g.data_ptr(), core.n_params, l2, core._stream()), "sqair_add_l2_grad")
-            allreduce_flat_grads(g)
-            self.opt.apply_gradients(g, learning_rate(F, self.step_no))
+            scale = allreduce_flat_grads(g, comm=self.comm, stream=core.stream)
+            self.opt.apply_gradients(g, learning_rate(F, self.step_no), grad_scale=scale)
         self.step_no += 1
         return g

@@ -43,7 +43,8 @@ def _worker(rank, world, port, out):
     orc = O.SqairOracle(P, O.make_cfg(F, hw), torch.float64, requires_grad=True)
     m = orc.model(obs_r, nz_r)
     orc.make_target(m).backward()
-    g = sqdist.allreduce_flat_grads(_flat_grad(orc, spec))
+    g = _flat_grad(orc, spec)
+    g = g * sqdist.allreduce_flat_grads(g)   # in-place sum; the returned 1 / world goes into the optimiser's grad_scale
     sc = sqdist.reduce_scalars(torch.tensor([float(m.elbo_iwae), float(m.elbo_vae)], dtype=torch.float64))
     if rank == 0:
         np.savez(out, grad=g.numpy(), scalars=sc.numpy(), lw=m.log_weights.detach().numpy())

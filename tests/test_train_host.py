@@ -11,8 +11,10 @@ def test_lr_schedule_matches_reference_defaults():
     bounds, values = lr_schedule(F)
     assert bounds == [400000, 1000000]
     assert np.allclose(values, [1e-5, 1e-5 / 3, 1e-5 / 9])
-    assert learning_rate(F, 0) == 1e-5 and learning_rate(F, 399999) == 1e-5
-    assert np.isclose(learning_rate(F, 400000), 1e-5 / 3) and np.isclose(learning_rate(F, 1999999), 1e-5 / 9)
+    # tf.train.piecewise_constant is closed on the right: values[0] for step <= boundaries[0]
+    assert learning_rate(F, 0) == 1e-5 and learning_rate(F, 400000) == 1e-5
+    assert np.isclose(learning_rate(F, 400001), 1e-5 / 3) and np.isclose(learning_rate(F, 1000000), 1e-5 / 3)
+    assert np.isclose(learning_rate(F, 1000001), 1e-5 / 9) and np.isclose(learning_rate(F, 1999999), 1e-5 / 9)
 
 
 def test_curriculum():
