@@ -20,6 +20,7 @@
 //   * epilogue fuses bias, a precomputed partial sum (loop-invariant part of the pre-activation),
 //     the activation, and the GRU gate arithmetic.
 #include "sqair_common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -324,6 +325,12 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
     return 0;
   }
   const int per_wave = (L.kc + 3) / 4;
+  static const int one_variant = getenv("SQAIR_ONE_LINEAR") ? atoi(getenv("SQAIR_ONE_LINEAR")) : 0;  // experiment knob
+  if (one_variant && per_wave <= 8) {
+    const dim3 g(L.nt, (a.M + 15) / 16);
+    hipLaunchKernelGGL((k_linear<8, 4>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts);
+    return 0;
+  }
   switch (per_wave) {
     case 1: launch_nch<1>(a, L, grid, s, prof_ts); break;
     case 2: launch_nch<2>(a, L, grid, s, prof_ts); break;

@@ -518,8 +518,9 @@ class Model(object):
         cdf = torch.cumsum(self.importance_weights, -1)
         self.iw_resampling_idx = (cdf <= u).sum(-1).clamp(max=K - 1)
         if "canvas" in core.out:
-            tiled = self.obs.repeat_interleave(K, dim=1)
-            self.mse_per_sample = ((tiled - core.out["canvas"]) ** 2).mean((0, 2, 3))
+            # model.py:112-115 against the K-tiled observation — broadcast over the particle axis, never materialised (a1)
+            cv = core.out["canvas"].reshape(T, B, K, core.H, core.W)
+            self.mse_per_sample = ((self.obs[:, :, None] - cv) ** 2).mean((0, 3, 4)).reshape(B * K)
             self.mse = self._imp_weighted_mean(self.mse_per_sample)
             self.raw_mse = self.mse_per_sample.mean()
         if self.gt_presence is not None and "num_steps_per_sample" in core.out:

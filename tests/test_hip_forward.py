@@ -11,7 +11,7 @@ import torch
 from sqair_amd.data import config_inputs, make_sequences, to_float
 from sqair_amd.flags import make_flags
 from sqair_amd.model import Model, SqairCore
-from tests.hip_util import GOLDEN, draw_noise, params32, rel_err, run_hip, run_oracle
+from tests.hip_util import GOLDEN, MARGIN, draw_noise, params32, presence_margins, rel_err, run_hip, run_oracle, stable_noise
 
 pytestmark = pytest.mark.gpu
 
@@ -66,13 +66,11 @@ def _live_oracle_case(F, hw=(32, 40), T=3, B=3, tol=5e-4):
     d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=20, seed=9)
     obs = to_float(d["imgs"])
     P = params32(F, hw, 5, 0.05, obs.mean((0, 1)))
-    for attempt in range(50):
-        noise = draw_noise(np.random.default_rng(attempt), T, B * K, N, 55)
-        ref = run_oracle(F, hw, P, obs, noise, nums=d["nums"])
-        m = run_hip(F, hw, P, obs, noise, nums=d["nums"])
-        if np.array_equal(m.prop_pres.cpu().numpy(), ref.prop_pres.numpy()) and \
-                np.array_equal(m.disc_pres.cpu().numpy(), ref.disc_pres.numpy()):
-            break
+    # the draw is chosen on the ORACLE's own decision margin (never on the HIP result); presence must then agree exactly
+    noise, ref, _, _ = stable_noise(F, hw, P, obs, T, B * K, N, nums=d["nums"])
+    m = run_hip(F, hw, P, obs, noise, nums=d["nums"])
+    assert np.array_equal(m.prop_pres.cpu().numpy(), ref.prop_pres.numpy())
+    assert np.array_equal(m.disc_pres.cpu().numpy(), ref.disc_pres.numpy())
     ref_out = {k: v.numpy() for k, v in ref.outputs.items() if not k.startswith("_")}
     ref_model = {k: getattr(ref, k).numpy() for k in ("log_weights", "elbo_iwae_per_example", "elbo_vae", "elbo_iwae",
                                                       "data_ll", "kl", "log_p_z", "log_q_z_given_x")}
@@ -197,15 +195,17 @@ def test_cfg2_full_size_properties():
         assert len(seen) == 0 or seen.max() <= m1.outputs["final_last_used_id"].cpu().numpy()[r]
     # (d) the sub-batch against the fp64 oracle (8 sequences x 5 particles x 10 frames: a few seconds)
     ref = run_oracle(F, hw, P, obs[:, sub], nz_sub, nums=nums[:, sub])
-    same = np.array_equal(m3.presence.cpu().numpy(), ref.presence.numpy())
-    if same:
-        assert rel_err(m3.log_weights.cpu().numpy(), ref.log_weights.numpy()) < REL
+    # every row whose closest Bernoulli is further than MARGIN from its threshold must decide identically and agree to
+    # the north-star tolerance; rows inside the margin (a handful in 1600 draws, if any) are reported, not compared
+    stable = (presence_margins(ref.outputs, nz_sub) >= MARGIN)
+    agree = (m3.presence.cpu().numpy() == ref.presence.numpy()).all((0, 2))
+    print("cfg-2 sub-batch: {} of {} rows decision-stable, {} rows agree".format(int(stable.sum()), stable.size, int(agree.sum())))
+    assert stable.mean() > 0.8
+    assert agree[stable].all()
+    a, b = m3.log_weights.cpu().numpy().reshape(-1)[stable], ref.log_weights.numpy().reshape(-1)[stable]
+    assert np.abs(a - b).max() <= REL * np.abs(b).max()
+    if stable.all():
         assert abs(float(m3.elbo_iwae) - float(ref.elbo_iwae)) <= REL * abs(float(ref.elbo_iwae))
-    else:  # a borderline Bernoulli flipped somewhere in 1600 draws: compare the rows that agree
-        agree = (m3.presence.cpu().numpy() == ref.presence.numpy()).all((0, 2)).reshape(8, K)
-        assert agree.mean() > 0.9
-        a, b = m3.log_weights.cpu().numpy()[agree], ref.log_weights.numpy()[agree]
-        assert np.abs(a - b).max() <= REL * np.abs(b).max()
 
 
 @pytest.mark.parametrize("cfg_id,B", [(4, 8), (5, 4)])
@@ -218,13 +218,10 @@ def test_other_baseline_configs_vs_oracle(cfg_id, B):
     T, K, N = 4, int(F.k_particles), int(F.n_steps_per_image)
     obs, nums = obs[:T], nums[:T]
     P = params32(F, hw, 7, 0.03, obs.mean((0, 1)))
-    for attempt in range(30):
-        noise = draw_noise(np.random.default_rng(50 + attempt), T, B * K, N, 55)
-        ref = run_oracle(F, hw, P, obs, noise, nums=nums)
-        m = run_hip(F, hw, P, obs, noise, nums=nums)
-        if np.array_equal(m.prop_pres.cpu().numpy(), ref.prop_pres.numpy()) and \
-                np.array_equal(m.disc_pres.cpu().numpy(), ref.disc_pres.numpy()):
-            break
+    noise, ref, _, _ = stable_noise(F, hw, P, obs, T, B * K, N, seed0=50, nums=nums)
+    m = run_hip(F, hw, P, obs, noise, nums=nums)
+    assert np.array_equal(m.prop_pres.cpu().numpy(), ref.prop_pres.numpy())
+    assert np.array_equal(m.disc_pres.cpu().numpy(), ref.disc_pres.numpy())
     ref_out = {k: v.numpy() for k, v in ref.outputs.items() if not k.startswith("_")}
     ref_model = {k: getattr(ref, k).numpy() for k in ("log_weights", "elbo_iwae_per_example", "elbo_vae", "elbo_iwae",
                                                       "data_ll", "kl", "log_p_z", "log_q_z_given_x")}
@@ -323,13 +320,14 @@ def test_generation_modes_vs_live_oracle(generate_after, prior):
     core.set_params(P)
     m = Model(obs, None, core, K, presence=d["nums"])
     orc = O.SqairOracle(P, O.make_cfg(F, hw), torch.float64)
-    for attempt in range(30):
+    for attempt in range(3):   # (Bernoullis drawn from the PRIOR in these modes are outside presence_margins' reach)
         rng = np.random.default_rng(400 + attempt)
         noise, gen_noise = draw_noise(rng, T, B * K, N, 55), draw_noise(rng, T, B * K, N, 55)
         with torch.no_grad():
             ref = orc.model(obs, noise, num=d["nums"], gen_noise=gen_noise)
         m.run(noise=noise, gen_noise=gen_noise)
         if all(np.array_equal(getattr(m, k).cpu().numpy(), getattr(ref, k).numpy()) for k in ("prop_pres", "disc_pres", "presence")):
+            print("generation mode: identical discrete decisions on draw", attempt + 1)
             break
     else:
         pytest.fail("no noise draw with identical discrete decisions")
