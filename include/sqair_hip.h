@@ -251,17 +251,6 @@ int sqair_backward(SqairHandle* h, const float* flat_params, const void* packed,
                    const float* importance_weights, const float* vimco_signal, int T, int B, int t_offset,
                    void* train_workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
                    float* flat_grad, void* stream);
-/* XCD-persistent forward pass: same arguments and results as sqair_forward; the frame loop runs as ONE launch in which
- * every XCD owns a group of particle rows for the whole pass (rows never interact: SequentialAIR's loop body is per-row,
- * sqair/seq.py:69-279) and layers are separated by per-XCD arrival counters instead of kernel boundaries.  `program` is
- * caller-owned device memory of sqair_program_bytes(h, T, B) bytes holding the op list and the counters; the list is
- * rebuilt (one synchronous upload) when a pointer / shape argument changes.  sqair_persistent_status: 0 = the last pass
- * completed, 1 = a team barrier timed out (results invalid; every spin is bounded). */
-int64_t sqair_program_bytes(const SqairHandle* h, int T, int B);
-int sqair_forward_persistent(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
-                             const float* noise, int T, int B, int t_offset, const SqairOutputs* out, void* workspace,
-                             int64_t workspace_bytes, void* program, int64_t program_bytes, void* stream);
-int sqair_persistent_status(SqairHandle* h, const void* program, void* stream);
 
 /* ---- workspace clearing.  By default every pass starts by zero-filling the caller's workspace (60 MB for inference,
  * 308 MB for the training tape at BASELINE configs[1]: ~1-2 % of a step), so that a workspace may hold garbage and may be
@@ -271,14 +260,6 @@ int sqair_persistent_status(SqairHandle* h, const void* program, void* stream);
 int sqair_set_workspace_clearing(SqairHandle* h, int each_pass);
 int sqair_clear_workspace(SqairHandle* h, void* workspace, int64_t workspace_bytes, int T, int B, int train, void* stream);
 
-/* ---- layer chains (EXPERIMENTAL, off by default: measured slower than one launch per layer): the
- * glimpse-encoder chain of a slot as ONE launch, rows split over per-XCD workgroup teams that hand activations over
- * through their XCD's L2 (csrc/sqair_chain.hip).  Same results bit for bit; fewer graph nodes.  Needs the MI355X's 256 CUs;
- * the placement assumption (workgroups with equal index mod 8 share an XCD) is checked by every launch: sqair_chain_status
- * returns 0 when the last pass in `workspace` is valid, 1 (barrier time-out) or 2 (unexpected placement) when its results
- * must be discarded — disable chains and re-run. */
-int sqair_enable_chains(SqairHandle* h, int on);
-int sqair_chain_status(SqairHandle* h, const void* workspace, int T, int B, int train, void* stream);
 /* Generation modes (sqair/sqair_modules.py:157-170, :294-302, sqair/seq.py:198-200).  With
  * cfg.sample_from_prior the propagation posterior log-probabilities are evaluated at samples of the propagation PRIOR, and
  * in frames t > cfg.generate_after those samples replace what / where / presence of the propagated objects, discovery's

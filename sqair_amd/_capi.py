@@ -79,8 +79,6 @@ _PROTOS = {
                                  C.c_void_p, C.c_int64, C.c_void_p]),
     "sqair_set_workspace_clearing": (C.c_int, [C.c_void_p, C.c_int]),
     "sqair_clear_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "sqair_enable_chains": (C.c_int, [C.c_void_p, C.c_int]),
-    "sqair_chain_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sqair_lstm_test": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "sqair_lstm_cell_bwd_test": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_void_p]),
     "sqair_get_config": (C.c_int, [C.c_void_p, C.POINTER(SqairConfig)]),
@@ -94,11 +92,6 @@ _PROTOS = {
     "sqair_backward_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
     "sqair_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                  C.c_void_p, C.c_void_p]),
-    "sqair_program_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
-    "sqair_forward_persistent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                           C.c_int, C.POINTER(SqairOutputs), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
-                                           C.c_void_p]),
-    "sqair_persistent_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "sqair_set_generation_noise": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sqair_fill_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "sqair_capture_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -108,6 +101,8 @@ _PROTOS = {
     "sqair_rmsprop_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "sqair_linear_bwd_test": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_int64, C.c_void_p]),
+    "sqair_debug_linear_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "sqair_debug_layers": (C.c_int, [C.c_void_p]),
     "sqair_debug_layer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

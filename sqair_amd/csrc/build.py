@@ -4,13 +4,13 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["sqair_api.hip", "sqair_linear.hip", "sqair_glue.hip", "sqair_bwd.hip", "sqair_train.hip", "sqair_linear_dx.hip", "sqair_persist.hip", "sqair_chain.hip"]
+SOURCES = ["sqair_api.hip", "sqair_linear.hip", "sqair_glue.hip", "sqair_bwd.hip", "sqair_train.hip", "sqair_linear_dx.hip"]
 OUT = os.path.join(os.path.dirname(HERE), "libsqair_hip.so")
 
 
 def build(force=False, verbose=False):
     srcs = [os.path.join(HERE, s) for s in SOURCES]
-    deps = srcs + [os.path.join(HERE, f) for f in ("sqair_common.h", "sqair_glue.h", "sqair_internal.h", "sqair_dx.h", "sqair_persist.h", "sqair_rowops.h", "sqair_bwd.h", "sqair_linear_kernel.inc")] + \
+    deps = srcs + [os.path.join(HERE, f) for f in ("sqair_common.h", "sqair_glue.h", "sqair_internal.h", "sqair_dx.h", "sqair_rowops.h", "sqair_lin_device.h", "sqair_bwd.h", "sqair_linear_kernel.inc")] + \
         [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "sqair_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT

@@ -15,7 +15,6 @@
 //   * only the truly sequential part (explaining away: slot k needs slot k-1's sample) remains in
 //     the per-slot chain.
 #include "sqair_internal.h"
-#include "sqair_chain.h"
 
 void sq_set_error(SqairHandle* h, const std::string& msg) {
   if (h) h->err = msg;
@@ -674,9 +673,6 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.dec_a = take((int64_t)T * M * nh);
   w.dec_b = take((int64_t)T * M * nh);
   w.gen = take(c.sample_from_prior ? (int64_t)T * M * gen::W : 64);
-  w.chain_slots = T * 2 * (int)N * 3;
-  w.chain_bar = (unsigned*)take((int64_t)w.chain_slots * SQ_CHAIN_BAR_WORDS);
-  w.chain_status = (int*)take(64);
   w.prof_ts = (unsigned long long*)take(5 * PROF_MAX * 2);
   w.total = o;
   return w;
@@ -712,16 +708,6 @@ int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipSt
   l.a.bias = packed + pl.b + L.b_off;
   l.a.M = M;
   l.a.N = L.N;
-  if (h->rec != nullptr) {  // XCD-persistent path: the op is recorded, the persistent kernel executes it
-    XOp op;
-    op.type = XOP_LINEAR; op.kc = L.kc; op.nt = L.nt; op.sync_after = 1;
-    op.u.lin = l.a;
-    auto rmul_of = [](int rdiv) { return rdiv <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)rdiv) + 1u; };
-    for (int i = 0; i < op.u.lin.nseg; ++i) op.u.lin.seg[i].rmul = rmul_of(op.u.lin.seg[i].rdiv);
-    op.u.lin.add_rmul = rmul_of(op.u.lin.add_rdiv);
-    h->rec->push_back(op);
-    return 0;
-  }
   if (h->prof && h->prof_n < PROF_MAX) {
     int ksum = 0;
     for (int w : L.seg_width) ksum += w;
@@ -735,81 +721,22 @@ int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipSt
   return rc;
 }
 
-// two or three dependent slot layers as ONE launch (sqair_chain.hip) when chains are enabled, else one launch each
-static int sq_run_chain(SqairHandle* h, Lin* const* ls, const LayerId* ids, int n, int M, const float* packed, const Workspace& w,
-                        hipStream_t s) {
-  const bool chain = h->use_chain && h->rec == nullptr && M >= 64 && h->chain_no < w.chain_slots;
-  if (!chain) {
-    for (int i = 0; i < n; ++i) {
-      const int rc = sq_run(h, *ls[i], ids[i], M, packed, s);
-      if (rc != 0) return rc;
-    }
-    return 0;
-  }
-  const PackedLayout pl = packed_layout(h);
-  LinArgs la[3];
-  const PackedLayer* pls[3];
-  double flops = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const PackedLayer& L = h->layers[ids[i]];
-    Lin& l = *ls[i];
-    if (l.a.nseg != (int)L.seg_width.size()) { sq_set_error(h, "internal: segment count mismatch in chained layer " + std::to_string((int)ids[i])); return -3; }
-    int ksum = 0;
-    for (int j = 0; j < l.a.nseg; ++j) {
-      if (l.a.seg[j].width != L.seg_width[j]) { sq_set_error(h, "internal: segment width mismatch in chained layer " + std::to_string((int)ids[i])); return -3; }
-      ksum += L.seg_width[j];
-    }
-    l.a.wp = packed + pl.w + L.w_off; l.a.wzero = packed + pl.w; l.a.bias = packed + pl.b + L.b_off; l.a.M = M; l.a.N = L.N;
-    la[i] = l.a; pls[i] = &L;
-    flops += 2.0 * (double)M * (double)ksum * (double)L.N;
-  }
-  unsigned long long* pts = nullptr;
-  if (h->prof && h->prof_n < PROF_MAX) {
-    h->prof_flops += flops;
-    h->prof_layer.push_back(1000 + (int)ids[0]);  // 1000 + first layer id marks a chain in the per-launch dump
-    h->prof_m.push_back(M);
-    pts = h->prof_ts + h->prof_n++;
-  }
-  const int rc = sq_launch_chain(la, pls, n, M, w.chain_bar + (size_t)h->chain_no * SQ_CHAIN_BAR_WORDS, w.chain_status, pts, s);
-  ++h->chain_no;
-  if (rc != 0) sq_set_error(h, "internal: A-operand contract violated in a layer chain starting at layer " + std::to_string((int)ids[0]));
-  return rc;
-}
-#define RUN_CHAIN3(l0, id0, l1, id1, l2, id2, M)                                         \
-  do {                                                                                   \
-    Lin* _ls[3] = {&(l0), &(l1), &(l2)};                                                 \
-    const LayerId _ids[3] = {(id0), (id1), (id2)};                                       \
-    const int _rc = sq_run_chain(h, _ls, _ids, 3, (M), packed, w, s);                    \
-    if (_rc != 0) return _rc;                                                            \
+// three dependent slot layers: one launch each (a single multi-layer launch with in-launch hand-offs was built and
+// measured slower twice in round 1 -- tools/xcd_team.hip, DESIGN.md section 8 -- and left the library)
+#define RUN_CHAIN3(l0, id0, l1, id1, l2, id2, M) \
+  do {                                            \
+    RUN(l0, id0, M);                              \
+    RUN(l1, id1, M);                              \
+    RUN(l2, id2, M);                              \
   } while (0)
 
-static int emit_crop(SqairHandle* h, const CropArgs& ca, POff po, Dims d, int nslots, hipStream_t s) {
-  if (h->rec == nullptr) return sq_launch_crop(ca, po, d, nslots, s);
-  XOp op; op.type = XOP_CROP; op.nslots = nslots; op.sync_after = 1; op.u.crop = ca;
-  h->rec->push_back(op);
-  return 0;
-}
-static int emit_tail(SqairHandle* h, const TailArgs& ta, Dims d, hipStream_t s) {
-  if (h->rec == nullptr) return sq_launch_slot_tail(ta, d, s);
-  XOp op; op.type = XOP_TAIL; op.sync_after = 1; op.u.tail = ta;
-  h->rec->push_back(op);
-  return 0;
-}
-static int emit_latsum(SqairHandle* h, const float* f, const float* rec_p, float* c, Dims d, hipStream_t s) {
-  if (h->rec == nullptr) return sq_launch_latent_sum(f, rec_p, c, d, s);
-  XOp op; op.type = XOP_LATSUM; op.sync_after = 1; op.u.lat = XLatArgs{f, rec_p, c};
-  h->rec->push_back(op);
-  return 0;
-}
-static int emit_compact(SqairHandle* h, const CompactArgs& ka, POff po, Dims d, hipStream_t s) {
-  if (h->rec == nullptr) return sq_launch_compact(ka, po, d, s);
-  XOp op; op.type = XOP_COMPACT; op.sync_after = 1; op.u.comp = ka;
-  h->rec->push_back(op);
-  return 0;
-}
+static int emit_crop(SqairHandle* h, const CropArgs& ca, POff po, Dims d, int nslots, hipStream_t s) { (void)h; return sq_launch_crop(ca, po, d, nslots, s); }
+static int emit_tail(SqairHandle* h, const TailArgs& ta, Dims d, hipStream_t s) { (void)h; return sq_launch_slot_tail(ta, d, s); }
+static int emit_latsum(SqairHandle* h, const float* f, const float* rec_p, float* c, Dims d, hipStream_t s) { (void)h; return sq_launch_latent_sum(f, rec_p, c, d, s); }
+static int emit_compact(SqairHandle* h, const CompactArgs& ka, POff po, Dims d, hipStream_t s) { (void)h; return sq_launch_compact(ka, po, d, s); }
 
 // parts: 1 = prologue (workspace clear, initial state, input encoder), 2 = the frame loop, 4 = epilogue (log-probabilities,
-// decoder, final state copies).  The XCD-persistent path runs 1 and 4 as launches and RECORDS 2 (h->rec) for its kernel.
+// decoder, final state copies).
 int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, const float* obs, const float* noise,
                     int T, int B, int t_offset, const SqairOutputs* outp, float* wsbase, int64_t ws_bytes,
                     hipStream_t s, bool train, int parts) {
@@ -822,7 +749,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     sq_set_error(h, "sqair_forward: workspace too small");
     return -1;
   }
-  if (c.sample_from_prior && (train || h->rec != nullptr || h->gen_noise == nullptr)) {
+  if (c.sample_from_prior && (train || h->gen_noise == nullptr)) {
     sq_set_error(h, "sample_from_prior: inference through sqair_forward / sqair_graph_capture only, after sqair_set_generation_noise");
     return -1;
   }
@@ -842,13 +769,10 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   // The GEMM A-operand contract wants every float it may touch to be finite (padding meets zero weights, but
   // 0 * NaN = NaN) and slot records are read as 56-wide segments before all their fields are written in a frame:
   // clear the caller's (garbage) workspace once per pass
-  if (parts & 1) h->chain_no = 0;
   if (parts & 1) {
     // (clear_each_pass = false: the caller cleared this workspace once with sqair_clear_workspace and reuses it with the
-    //  same T and B -- every buffer is then either rewritten by the pass or holds finite values / zeros it never overwrites;
-    //  only the arrival counters of the layer chains must start from zero)
+    //  same T and B -- every buffer is then either rewritten by the pass or holds finite values / zeros it never overwrites)
     if (h->clear_each_pass) sq_zero_fill(wsbase, (int64_t)((float*)w.prof_ts - wsbase), s);
-    else if (h->use_chain) sq_zero_fill((float*)w.chain_bar, (int64_t)((float*)w.prof_ts - (float*)w.chain_bar), s);
     // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
     sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0, w.snh), w.state(w.prior_m, 0, w.psnh), w.last_id[0], w.disc_init_rec,
                          w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc,
@@ -1185,128 +1109,6 @@ extern "C" int sqair_clear_workspace(SqairHandle* h, void* workspace, int64_t wo
   return 0;
 }
 
-// layer chains (sqair_chain.hip)
-extern "C" int sqair_enable_chains(SqairHandle* h, int on) {
-  if (!h) return -1;
-  if (on && h->n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sq_set_error(h, "sqair_enable_chains: no device"); return -1; }
-    h->n_cu = prop.multiProcessorCount;
-  }
-  if (on && h->n_cu != 256) {  // the team layout is the MI355X's: 8 XCDs x 32 CUs, one workgroup per CU
-    sq_set_error(h, "sqair_enable_chains: the team layout needs 256 CUs in 8 XCDs, found " + std::to_string(h->n_cu));
-    return -1;
-  }
-  h->use_chain = on != 0;
-  return 0;
-}
-// status word of the last pass run in `workspace` (a sqair_forward / sqair_graph_* workspace, or the train workspace with
-// train != 0): 0 = every chain launch completed with the expected placement, 1 = a team barrier timed out, 2 = a workgroup
-// was not on its expected XCD.  Non-zero: the pass's results must be discarded (disable chains and re-run).  Synchronises.
-extern "C" int sqair_chain_status(SqairHandle* h, const void* workspace, int T, int B, int train, void* stream) {
-  if (!h || !workspace || T < 1 || B < 1) return -1;
-  const Workspace w = sq_carve(h, T, B, (float*)workspace, train != 0);
-  int st = 0;
-  SQ_CHECK_HIP(hipMemcpyAsync(&st, w.chain_status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
-  SQ_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-  return st;
-}
-
-// XCD-persistent forward pass (sqair_persist.hip): same results as sqair_forward, the frame loop as ONE launch.
-// `program` is caller-owned device memory (sqair_program_bytes) that holds the recorded op list and the team
-// counters; the list is rebuilt (one synchronous upload) whenever any pointer / shape argument changes.
-// ------------------------------------------------------------------------------------------------
-extern "C" int64_t sqair_program_bytes(const SqairHandle* h, int T, int B) {
-  if (!h || T < 1 || B < 1) return -1;
-  const int64_t per_frame = 64 + 32 * (int64_t)h->cfg.n_steps_per_image;
-  return (int64_t)T * per_frame * (int64_t)sizeof(XOp) + XSYNC_WORDS * 4 + 256;
-}
-
-extern "C" int sqair_forward_persistent(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
-                                        const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
-                                        void* workspace, int64_t workspace_bytes, void* program, int64_t program_bytes,
-                                        void* stream) {
-  if (!h || !out || !program) return -1;
-  hipStream_t s = (hipStream_t)stream;
-  if (h->cfg.time_cell != CELL_GRU || h->cfg.prior_cell != CELL_GRU || h->cfg.rnn_cell != RNN_VANILLA) {
-    sq_set_error(h, "sqair_forward_persistent: the experimental persistent executor covers the GRU cells only");
-    return -1;
-  }
-  if (program_bytes < sqair_program_bytes(h, T, B)) {
-    sq_set_error(h, "sqair_forward_persistent: program buffer too small");
-    return -1;
-  }
-  const SqairConfig& c = h->cfg;
-  const int R = B * c.k_particles;
-  Dims d = make_dims(c, B);
-  unsigned* sync = (unsigned*)program;
-  XOp* prog_dev = (XOp*)((char*)program + XSYNC_WORDS * 4 + (256 - (XSYNC_WORDS * 4) % 256) % 256);
-  // key of the cached program: every argument that is baked into the ops
-  std::vector<uint64_t> key = {(uint64_t)flat_params, (uint64_t)packed, (uint64_t)obs, (uint64_t)noise, (uint64_t)T, (uint64_t)B,
-                               (uint64_t)t_offset, (uint64_t)workspace, (uint64_t)program};
-  const void* const* op = (const void* const*)out;
-  for (size_t i = 0; i < sizeof(SqairOutputs) / sizeof(void*); ++i) key.push_back((uint64_t)op[i]);
-  if (key != h->xprog_key) {
-    h->xprog.clear();
-    h->rec = &h->xprog;
-    const int rc = sq_forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
-                                   workspace_bytes, s, false, 2);
-    h->rec = nullptr;
-    if (rc != 0) return rc;
-    if ((int64_t)h->xprog.size() * (int64_t)sizeof(XOp) + XSYNC_WORDS * 4 + 256 > program_bytes) {
-      sq_set_error(h, "sqair_forward_persistent: op list larger than the program buffer");
-      return -1;
-    }
-    SQ_CHECK_HIP(hipMemcpyAsync(prog_dev, h->xprog.data(), h->xprog.size() * sizeof(XOp), hipMemcpyHostToDevice, s));
-    SQ_CHECK_HIP(hipStreamSynchronize(s));
-    h->xprog_key = key;
-    if (h->n_cu == 0) {
-      int dev = 0;
-      SQ_CHECK_HIP(hipGetDevice(&dev));
-      SQ_CHECK_HIP(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
-  }
-  int rc = sq_forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
-                           workspace_bytes, s, false, 1);
-  if (rc != 0) return rc;
-  sq_zero_fill((float*)sync, XSYNC_WORDS, s);
-  const char* xdump = getenv("SQAIR_XPROF_DUMP");  // per-op device-clock stamps of (first team, rank 0), CSV
-  unsigned long long* tst = nullptr;
-  if (xdump != nullptr) {
-    const Workspace wx = sq_carve(h, T, B, (float*)workspace, false);
-    tst = wx.prof_ts;  // 5 * PROF_MAX * 2 floats = 5 * PROF_MAX 64-bit words
-    if (2 * h->xprog.size() > 5 * (size_t)PROF_MAX) tst = nullptr;
-  }
-  sq_launch_persistent(prog_dev, (int)h->xprog.size(), h->po, d, sync, h->n_cu, s, tst);
-  if (tst != nullptr) {
-    std::vector<unsigned long long> hts(2 * h->xprog.size());
-    SQ_CHECK_HIP(hipMemcpyAsync(hts.data(), tst, hts.size() * 8, hipMemcpyDeviceToHost, s));
-    SQ_CHECK_HIP(hipStreamSynchronize(s));
-    FILE* f = fopen(xdump, "w");
-    if (f) {
-      fprintf(f, "op,type,kc,nt,M,start_ticks,end_ticks\n");
-      for (size_t i = 0; i < h->xprog.size(); ++i)
-        fprintf(f, "%zu,%d,%d,%d,%d,%llu,%llu\n", i, h->xprog[i].type, h->xprog[i].kc, h->xprog[i].nt,
-                h->xprog[i].type == XOP_LINEAR ? h->xprog[i].u.lin.M : 0, hts[2 * i] - hts[0], hts[2 * i + 1] - hts[0]);
-      fclose(f);
-    }
-  }
-  rc = sq_forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
-                       workspace_bytes, s, false, 4);
-  if (rc != 0) return rc;
-  SQ_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-// 0 = the last persistent pass completed; 1 = a team barrier timed out (results invalid)
-extern "C" int sqair_persistent_status(SqairHandle* h, const void* program, void* stream) {
-  if (!h || !program) return -1;
-  unsigned word = 0;
-  SQ_CHECK_HIP(hipMemcpyAsync(&word, (const unsigned*)program + 17, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
-  SQ_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-  return word != 0 ? 1 : 0;
-}
-
 extern "C" int sqair_forward(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
                              const float* noise, int T, int B, int t_offset, const SqairOutputs* out, void* workspace,
                              int64_t workspace_bytes, void* stream) {
@@ -1511,7 +1313,32 @@ extern "C" int sqair_linear_test(SqairHandle* h, const float* x, const float* wm
   if (sq_launch_linear(l.a, L, s) != 0) { sq_set_error(h, "sqair_linear_test: A-operand contract violated"); return -5; }
   SQ_CHECK_HIP(hipGetLastError());
   SQ_CHECK_HIP(hipStreamSynchronize(s));
+  if (h->debug_reps > 0) {  // sqair_debug_linear_time: the same launch `reps` times back to back between two events
+    hipEvent_t ea, eb;
+    SQ_CHECK_HIP(hipEventCreate(&ea));
+    SQ_CHECK_HIP(hipEventCreate(&eb));
+    for (int i = 0; i < 3; ++i) sq_launch_linear(l.a, L, s);
+    (void)hipEventRecord(ea, s);
+    for (int i = 0; i < h->debug_reps; ++i) sq_launch_linear(l.a, L, s);
+    (void)hipEventRecord(eb, s);
+    SQ_CHECK_HIP(hipStreamSynchronize(s));
+    float ms = 0.0f;
+    SQ_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb));
+    h->debug_us = ms * 1e3f / (float)h->debug_reps;
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+  }
   return 0;
+}
+// measurement helper (tools/time_linear.py): average time of one dense launch of the given shape, launches back to back
+extern "C" int sqair_debug_linear_time(SqairHandle* h, const float* x, const float* wmat, const float* b, float* y, int M, int Kdim,
+                                       int Ndim, int act, void* scratch, int64_t scratch_bytes, int reps, float* us_out, void* stream) {
+  if (!h || !us_out || reps < 1) return -1;
+  h->debug_reps = reps;
+  const int rc = sqair_linear_test(h, x, wmat, b, y, M, Kdim, Ndim, act, scratch, scratch_bytes, stream);
+  h->debug_reps = 0;
+  *us_out = h->debug_us;
+  return rc;
 }
 
 extern "C" int sqair_gru_test(SqairHandle* h, const float* x, const float* hstate, const float* gru_flat, float* h_out,

@@ -5,7 +5,6 @@
 #include <map>
 
 #include "sqair_glue.h"
-#include "sqair_persist.h"
 
 struct ParamEntry {
   std::string name;
@@ -51,15 +50,9 @@ struct SqairHandle {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int graph_nodes = 0;
-  // XCD-persistent forward: op recording (sq_forward_impl emits into `rec` instead of launching) + cached program
-  std::vector<XOp>* rec = nullptr;
-  std::vector<XOp> xprog;
-  std::vector<uint64_t> xprog_key;
-  int n_cu = 0;
-  // layer chains (sqair_chain.hip): several dependent slot layers per launch; off unless sqair_enable_chains(h, 1)
+  int debug_reps = 0;       // sqair_debug_linear_time
+  float debug_us = 0.0f;
   bool clear_each_pass = true;  // zero the caller's workspace at the start of every pass (sqair_set_workspace_clearing)
-  bool use_chain = false;
-  int chain_no = 0;  // chain launches issued so far in the pass being emitted (selects the counter slot)
   const float* gen_noise = nullptr;  // sqair_set_generation_noise
   // generic capture slots (sqair_capture_begin / _end / _launch): any sequence of C-ABI calls as one HIP graph
   hipGraph_t cap_graph[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -142,9 +135,6 @@ struct Workspace {
   float *lpre, *lgates;                          // LSTM temporal cell (time_lstm): [M][4nh], kept gates [T][R][N][4nh]
   int* src;                                      // train: compaction source slot [T][R][N]
   float *qz, *pz, *dlp, *dll, *glimpse, *dec_a, *dec_b;
-  unsigned* chain_bar;                           // layer chains: arrival counters, one 128-word slot per chain launch
-  int* chain_status;                             // and the pass's status word (zeroed with the workspace)
-  int chain_slots;
   float* gen;                                    // sample_from_prior: [T][M][64] prior samples + original presences
   unsigned long long* prof_ts;
   int64_t total;  // floats

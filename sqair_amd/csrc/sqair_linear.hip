@@ -20,6 +20,8 @@
 //   * epilogue fuses bias, a precomputed partial sum (loop-invariant part of the pre-activation),
 //     the activation, and the GRU gate arithmetic.
 #include "sqair_common.h"
+#include "sqair_lin_device.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -187,90 +189,157 @@ __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Wider throughput variant (EPI_ACT layers only): every wave takes ONE 16-row tile against NT consecutive 16-column weight
-// slabs, so an activation fragment loaded once feeds NT MFMA chains (k_linear_rows: NT = 1) and the traffic towards L2 per
-// MFMA drops from 5 KB to (4 + NT) KB per 4 * NT tiles.  Accumulation order per output element = k_linear_rows'
-// (two accumulators, x/z and y/w), i.e. bit-identical results.
+// Macro-tile throughput kernel.  Every wave owns MT 16-row tiles x NT 16-column weight slabs (a 16 MT x 16 NT block of
+// the output): an activation fragment feeds NT MFMA chains, a weight fragment MT of them, so the bytes a CU pulls out of
+// L2 per MFMA fall from 2 KB (k_linear_rows) to (MT + NT) / (MT NT) KB; the 4 waves of a workgroup stack along M and share
+// the NT weight slabs through the L1.  What a CU can pull out of L2 (~50 GB/s measured, tools/chain_floor.hip) is the
+// roof of the 16x16-tile kernels from M ~ 640 rows up, not the matrix pipe.
+// The K loop is software-pipelined: the operand loads of block i + 1 are issued before the MFMAs of block i.
+// Accumulation order per output element = k_linear_rows' (chunks in order, accumulator 0 takes the x / z sub-steps,
+// accumulator 1 the y / w ones, summed at the end): results are bit-identical across the rows / wide / macro-tile variants,
+// so the tile shape is a pure performance choice.  All three epilogues.
 // ---------------------------------------------------------------------------------------------------
-template <int NCH, int NT>
-__global__ __launch_bounds__(256) void k_linear_wide(const LinArgs a, const int kc_total, const int n_tiles,
-                                                     unsigned long long* __restrict__ prof_ts) {
+template <int NCH, int MT, int NT, bool COAL = false>
+__global__ __launch_bounds__(256) void k_linear_mt(const LinArgs a, const int kc_total, const int n_tiles,
+                                                   unsigned long long* __restrict__ prof_ts) {
+  static_assert(MT == 1 || MT == 2, "row tiles per wave");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
+  // COAL: the A fragment is LOADED with 4 consecutive lanes on the 64 contiguous bytes of one row's chunk (16 row segments
+  // per instruction instead of 64 scattered 16-byte pieces) and brought into the MFMA operand order (lane = row + 16 kq) by
+  // four ds_bpermute_b32 -- same values, same arithmetic.
+  const int lrow = COAL ? (lane >> 2) : (lane & 15);   // row of the 16-row tile this lane LOADS
+  const int lkq = COAL ? (lane & 3) : kq;              // 4-float piece of the 16-wide chunk this lane LOADS
+  const int bp_src = (4 * (lane & 15) + kq) * 4;       // byte address for ds_bpermute: the loading lane that holds my operand
   const int tile_n0 = blockIdx.x * NT;
-  const int tile_m = blockIdx.y * 4 + wave;
-  const int arow = min(tile_m * 16 + (lane & 15), a.M - 1);
+  const int tile_m0 = (blockIdx.y * 4 + wave) * MT;
   unsigned long long t_start = 0;
   if (prof_ts != nullptr && tid == 0) t_start = wall_clock64();
-  float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : a.bias);
-  p_scale = a.scale_ptr != nullptr ? p_scale : 1.0f;
+  // segment table (wave-uniform) + per-lane row pointers of the (up to two) row tiles, all in NAMED locals: a select
+  // chain over members of the by-value argument struct or over elements of a local array is turned into an indexed load
+  // from a scratch copy (seen in this kernel's first version: flat loads, s_waitcnt vmcnt(0) after each of them)
   int cum1 = 0x7fffffff, cum2 = 0x7fffffff, cum3 = 0x7fffffff;
-#define SQ_ROWOF(sg) ((sg).rmul ? (int)__umulhi((unsigned)arow, (sg).rmul) : arow)
-  const float* rp0 = a.seg[0].p + (size_t)SQ_ROWOF(a.seg[0]) * a.seg[0].ld;
-  const float* rp1 = rp0; const float* rp2 = rp0; const float* rp3 = rp0;
+  const int arowA = min(tile_m0 * 16 + lrow, a.M - 1);
+  const int arowB = min((tile_m0 + MT - 1) * 16 + lrow, a.M - 1);
+#define SQ_ROWOF(sg, r) ((sg).rmul ? (int)__umulhi((unsigned)(r), (sg).rmul) : (r))
+  const float* rpA0 = a.seg[0].p + (size_t)SQ_ROWOF(a.seg[0], arowA) * a.seg[0].ld;
+  const float* rpB0 = a.seg[0].p + (size_t)SQ_ROWOF(a.seg[0], arowB) * a.seg[0].ld;
+  const float *rpA1 = rpA0, *rpA2 = rpA0, *rpA3 = rpA0, *rpB1 = rpB0, *rpB2 = rpB0, *rpB3 = rpB0;
   int lim0 = ((a.seg[0].width + 3) & ~3) - 4, lim1 = 0, lim2 = 0, lim3 = 0;
   {
     int c = (a.seg[0].width + 15) >> 4;
-    if (a.nseg > 1) { cum1 = c; c += (a.seg[1].width + 15) >> 4; rp1 = a.seg[1].p + (size_t)SQ_ROWOF(a.seg[1]) * a.seg[1].ld; lim1 = ((a.seg[1].width + 3) & ~3) - 4; }
-    if (a.nseg > 2) { cum2 = c; c += (a.seg[2].width + 15) >> 4; rp2 = a.seg[2].p + (size_t)SQ_ROWOF(a.seg[2]) * a.seg[2].ld; lim2 = ((a.seg[2].width + 3) & ~3) - 4; }
-    if (a.nseg > 3) { cum3 = c; rp3 = a.seg[3].p + (size_t)SQ_ROWOF(a.seg[3]) * a.seg[3].ld; lim3 = ((a.seg[3].width + 3) & ~3) - 4; }
+    if (a.nseg > 1) {
+      cum1 = c; c += (a.seg[1].width + 15) >> 4; lim1 = ((a.seg[1].width + 3) & ~3) - 4;
+      rpA1 = a.seg[1].p + (size_t)SQ_ROWOF(a.seg[1], arowA) * a.seg[1].ld;
+      rpB1 = a.seg[1].p + (size_t)SQ_ROWOF(a.seg[1], arowB) * a.seg[1].ld;
+    }
+    if (a.nseg > 2) {
+      cum2 = c; c += (a.seg[2].width + 15) >> 4; lim2 = ((a.seg[2].width + 3) & ~3) - 4;
+      rpA2 = a.seg[2].p + (size_t)SQ_ROWOF(a.seg[2], arowA) * a.seg[2].ld;
+      rpB2 = a.seg[2].p + (size_t)SQ_ROWOF(a.seg[2], arowB) * a.seg[2].ld;
+    }
+    if (a.nseg > 3) {
+      cum3 = c; lim3 = ((a.seg[3].width + 3) & ~3) - 4;
+      rpA3 = a.seg[3].p + (size_t)SQ_ROWOF(a.seg[3], arowA) * a.seg[3].ld;
+      rpB3 = a.seg[3].p + (size_t)SQ_ROWOF(a.seg[3], arowB) * a.seg[3].ld;
+    }
   }
 #undef SQ_ROWOF
-  f32x4 acc0[NT], acc1[NT];
+  f32x4 acc0[MT][NT], acc1[MT][NT];
   const f32x4* wp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    acc0[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc1[t] = acc0[t];
-    wp[t] = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)min(tile_n0 + t, n_tiles - 1) * kc_total) * 64 + lane;  // surplus tiles re-read the last slab
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { acc0[i][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc1[i][t] = acc0[i][t]; }
+    wp[t] = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)min(tile_n0 + t, n_tiles - 1) * kc_total) * 64 + lane;  // surplus slabs re-read the last one
   }
   const f32x4* __restrict__ wz = reinterpret_cast<const f32x4*>(a.wzero) + lane;
+
+  // Operand loads of one block of NCH chunks.  No branches: a chunk beyond the end re-reads A chunk 0 against the packed
+  // buffer's block of zero weights (acc + x * 0 = acc exactly, the A operand is finite by contract).
+#define SQ_MT_ISSUE(AV, BV, BASE)                                                                   \
+  _Pragma("unroll") for (int j = 0; j < NCH; ++j) {                                                 \
+    const bool valid = (BASE) + j < kc_total;                                                       \
+    const int g = valid ? (BASE) + j : 0;                                                           \
+    const bool s1 = g >= cum1, s2 = g >= cum2, s3 = g >= cum3;                                      \
+    const int cb = s3 ? cum3 : (s2 ? cum2 : (s1 ? cum1 : 0));                                       \
+    const int lim = s3 ? lim3 : (s2 ? lim2 : (s1 ? lim1 : lim0));                                   \
+    const int kk = min((g - cb) * 16 + lkq * 4, lim);                                               \
+    const float* pA = s3 ? rpA3 : (s2 ? rpA2 : (s1 ? rpA1 : rpA0));                                 \
+    AV[j][0] = *reinterpret_cast<const f32x4*>(pA + kk);                                            \
+    if (MT > 1) {                                                                                   \
+      const float* pB = s3 ? rpB3 : (s2 ? rpB2 : (s1 ? rpB1 : rpB0));                               \
+      AV[j][MT - 1] = *reinterpret_cast<const f32x4*>(pB + kk);                                     \
+    }                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) BV[j][t] = *(valid ? wp[t] + (size_t)g * 64 : wz); \
+  }
+#define SQ_MT_CONSUME(AV, BV)                                                                       \
+  if (COAL) {                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < NCH; ++j) {                                               \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                              \
+        AV[j][i].x = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_src, __float_as_int(AV[j][i].x))); \
+        AV[j][i].y = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_src, __float_as_int(AV[j][i].y))); \
+        AV[j][i].z = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_src, __float_as_int(AV[j][i].z))); \
+        AV[j][i].w = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_src, __float_as_int(AV[j][i].w))); \
+      }                                                                                             \
+    }                                                                                               \
+  }                                                                                                 \
+  _Pragma("unroll") for (int j = 0; j < NCH; ++j) {                                                 \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                              \
+        acc0[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[j][i].x, BV[j][t].x, acc0[i][t], 0, 0, 0); \
+        acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[j][i].y, BV[j][t].y, acc1[i][t], 0, 0, 0); \
+        acc0[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[j][i].z, BV[j][t].z, acc0[i][t], 0, 0, 0); \
+        acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[j][i].w, BV[j][t].w, acc1[i][t], 0, 0, 0); \
+      }                                                                                             \
+    }                                                                                               \
+  }
+  f32x4 av0[NCH][MT], bv0[NCH][NT], av1[NCH][MT], bv1[NCH][NT];
+  SQ_MT_ISSUE(av0, bv0, 0)
 #pragma unroll 1
-  for (int base = 0; base < kc_total; base += NCH) {
-    f32x4 av[NCH], bv[NT][NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const bool valid = base + j < kc_total;
-      const int g = valid ? base + j : 0;
-      const bool s1 = g >= cum1, s2 = g >= cum2, s3 = g >= cum3;
-      const float* rp = s3 ? rp3 : (s2 ? rp2 : (s1 ? rp1 : rp0));
-      const int cb = s3 ? cum3 : (s2 ? cum2 : (s1 ? cum1 : 0));
-      const int lim = s3 ? lim3 : (s2 ? lim2 : (s1 ? lim1 : lim0));
-      av[j] = *reinterpret_cast<const f32x4*>(rp + min((g - cb) * 16 + kq * 4, lim));
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bv[t][j] = *(valid ? wp[t] + (size_t)g * 64 : wz);
-    }
+  for (int base = 0; base < kc_total; base += 2 * NCH) {
+    SQ_MT_ISSUE(av1, bv1, base + NCH)
     __builtin_amdgcn_sched_barrier(0);
+    SQ_MT_CONSUME(av0, bv0)
+    __builtin_amdgcn_sched_barrier(0);
+    SQ_MT_ISSUE(av0, bv0, base + 2 * NCH)
+    __builtin_amdgcn_sched_barrier(0);
+    SQ_MT_CONSUME(av1, bv1)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef SQ_MT_ISSUE
+#undef SQ_MT_CONSUME
+
+  // Epilogue as ONE rolled loop over the wave's MT * NT * 4 output elements per lane: the sums are parked in LDS (wave-private
+  // slab, element-major) so that the loop body -- the three epilogue kinds with their exp / tanh / log1p expansions -- exists
+  // once.  Unrolled over the elements this kernel was 27 - 93 KB of code and every launch paid tens of microseconds of cold
+  // instruction fetch (measured in the pass: 67 us against 17 us for the same tile shape with a small epilogue).
+  __shared__ float epi_s[4][MT * NT * 4][64];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
+  for (int i = 0; i < MT; ++i) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[t][j].x, acc0[t], 0, 0, 0);
-        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[t][j].y, acc1[t], 0, 0, 0);
-        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[t][j].z, acc0[t], 0, 0, 0);
-        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[t][j].w, acc1[t], 0, 0, 0);
-      }
+    for (int t = 0; t < NT; ++t) {
+      epi_s[wave][(i * NT + t) * 4 + 0][lane] = acc0[i][t].x + acc1[i][t].x;
+      epi_s[wave][(i * NT + t) * 4 + 1][lane] = acc0[i][t].y + acc1[i][t].y;
+      epi_s[wave][(i * NT + t) * 4 + 2][lane] = acc0[i][t].z + acc1[i][t].z;
+      epi_s[wave][(i * NT + t) * 4 + 3][lane] = acc0[i][t].w + acc1[i][t].w;
     }
   }
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
+  float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : a.bias);
+  p_scale = a.scale_ptr != nullptr ? p_scale : 1.0f;
+  const bool g2 = a.epi == EPI_GRU2;
+#pragma unroll 1
+  for (int e = 0; e < MT * NT * 4; ++e) {
+    const int q = e & 3, t = (e >> 2) % NT, i = (e >> 2) / NT;
     const int n = (tile_n0 + t) * 16 + (lane & 15);
-    if (tile_n0 + t < n_tiles && n < a.N) {
-      const float p_bias = a.bias[n];
+    const int m = (tile_m0 + i) * 16 + 4 * kq + q;
+    if (tile_n0 + t < n_tiles && n < a.N && m < a.M) {
       const bool use_add = a.add != nullptr && n < a.add_n;
-      const int act = n < a.act_split ? a.act_a : a.act_b;
-      const float accv[4] = {acc0[t].x + acc1[t].x, acc0[t].y + acc1[t].y, acc0[t].z + acc1[t].z, acc0[t].w + acc1[t].w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = tile_m * 16 + 4 * kq + i;
-        if (m < a.M) {
-          float p_add = 0.0f;
-          if (use_add) {
-            const int mcd = a.add_rmul ? (int)__umulhi((unsigned)m, a.add_rmul) : m;
-            p_add = a.add[(size_t)mcd * a.add_ld + n];
-          }
-          const float v = sq_act(accv[i] + p_bias + p_add, act);
-          a.out[(size_t)m * a.out_ld + n] = v * a.scale * p_scale;
-        }
-      }
+      const bool g1 = a.epi == EPI_GRU1 && n >= a.nh && n < 2 * a.nh;
+      float p_add = 0.0f, p_e0 = 0.0f, p_e1 = 0.0f;
+      if (use_add) p_add = a.add[(size_t)(a.add_rmul ? (int)__umulhi((unsigned)m, a.add_rmul) : m) * a.add_ld + n];
+      if (g1) p_e0 = a.e0[(size_t)m * a.e0_ld + (n - a.nh)];
+      if (g2) { p_e0 = a.e0[(size_t)m * a.e0_ld + n]; p_e1 = a.e1[(size_t)m * a.e1_ld + n]; }
+      x_epilogue(a, m, n, epi_s[wave][e][lane] + a.bias[n] + p_add, p_e0, p_e1, p_scale);
     }
   }
   if (prof_ts != nullptr) {
@@ -280,6 +349,34 @@ __global__ __launch_bounds__(256) void k_linear_wide(const LinArgs a, const int 
       atomicMax(prof_ts + 4096, wall_clock64());
     }
   }
+}
+
+// Tile shape of the throughput variants, from measurements of the layer shapes of the pass (tools/time_linear.py, MI355X):
+// rows x slabs per wave and whether the A fragment is loaded row-contiguously (COAL).  SQAIR_MT="MT,NT[,COAL]" overrides.
+struct MtShape { int mt, nt, coal; };
+static MtShape pick_mt_shape(int M, int n_tiles, int kc) {
+  static int ov_mt = -1, ov_nt = -1, ov_coal = -1;
+  if (ov_mt < 0) {
+    ov_mt = ov_nt = 0;
+    const char* e = getenv("SQAIR_MT");
+    if (e != nullptr) sscanf(e, "%d,%d,%d", &ov_mt, &ov_nt, &ov_coal);
+  }
+  (void)kc;
+  MtShape sh;
+  if (M >= 2048) sh = MtShape{1, (M >= 16384 && n_tiles >= 2) ? 2 : 1, 1};
+  else if (n_tiles >= 64) sh = MtShape{1, 1, 1};
+  else if (n_tiles >= 32) sh = MtShape{1, 2, 0};
+  else sh = MtShape{1, 1, 0};
+  if (ov_mt > 0 && ov_nt > 0) { sh.mt = ov_mt; sh.nt = ov_nt; }
+  if (ov_coal >= 0) sh.coal = ov_coal;
+  return sh;
+}
+
+template <int NCH, int MT, int NT>
+static void launch_mt(const LinArgs& a, const PackedLayer& L, int mt, bool coal, hipStream_t s, unsigned long long* prof_ts) {
+  const dim3 g((L.nt + NT - 1) / NT, (mt + 4 * MT - 1) / (4 * MT));
+  if (coal) hipLaunchKernelGGL((k_linear_mt<NCH, MT, NT, true>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+  else hipLaunchKernelGGL((k_linear_mt<NCH, MT, NT, false>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
 }
 
 template <int NCH>
@@ -307,30 +404,20 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
     const LinSeg& sg = a.seg[i];
     if ((reinterpret_cast<uintptr_t>(sg.p) & 15) != 0 || (sg.ld & 3) != 0 || sg.width < 1 || sg.rdiv < 1) return -5;
   }
-  if (a.M >= 2048 || (a.M >= 256 && L.kc * L.nt >= 400 && L.kc <= 32)) {  // big batched once-per-frame layers: throughput variant
-    // two column slabs per wave for launches with >= 1024 rows (measured at cfg-2 shapes: the 640-row per-frame layers lose
-    // 2 % with it, the 6400-row decoder layers are neutral, and at 256 sequences per GPU -- where the slot layers have 1280
-    // rows -- the whole pass gains 10 %; four slabs per wave: +4 % only)
-    const int wgs2 = ((L.nt + 1) / 2) * ((mt + 3) / 4);
-    if (a.epi == EPI_ACT && L.kc <= 32 && L.nt >= 2 && a.M >= 1024 && wgs2 >= 128) {
-      const dim3 g2((L.nt + 1) / 2, (mt + 3) / 4);
-      if (L.kc <= 4) hipLaunchKernelGGL((k_linear_wide<4, 2>), g2, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
-      else hipLaunchKernelGGL((k_linear_wide<8, 2>), g2, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+  if (a.M >= 2048 || (a.M >= 256 && L.kc * L.nt >= 400 && L.kc <= 32)) {  // big batched layers: throughput variants
+    // (all of them accumulate in the same order: the tile shape never changes a result)
+    if (L.kc <= 4) {  // K <= 64: one block of loads, nothing to pipeline
+      const dim3 grid_r(L.nt, (mt + 3) / 4);
+      hipLaunchKernelGGL(k_linear_rows<4>, grid_r, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
       return 0;
     }
-    const dim3 grid_r(L.nt, (mt + 3) / 4);
-    if (L.kc <= 4) hipLaunchKernelGGL(k_linear_rows<4>, grid_r, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
-    else if (L.kc <= 8) hipLaunchKernelGGL(k_linear_rows<8>, grid_r, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
-    else hipLaunchKernelGGL(k_linear_rows<12>, grid_r, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+    const MtShape sh = pick_mt_shape(a.M, L.nt, L.kc);
+    if (sh.mt == 2) launch_mt<3, 2, 2>(a, L, mt, sh.coal != 0, s, prof_ts);
+    else if (sh.nt >= 2) launch_mt<4, 1, 2>(a, L, mt, sh.coal != 0, s, prof_ts);
+    else launch_mt<4, 1, 1>(a, L, mt, sh.coal != 0, s, prof_ts);
     return 0;
   }
   const int per_wave = (L.kc + 3) / 4;
-  static const int one_variant = getenv("SQAIR_ONE_LINEAR") ? atoi(getenv("SQAIR_ONE_LINEAR")) : 0;  // experiment knob
-  if (one_variant && per_wave <= 8) {
-    const dim3 g(L.nt, (a.M + 15) / 16);
-    hipLaunchKernelGGL((k_linear<8, 4>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts);
-    return 0;
-  }
   switch (per_wave) {
     case 1: launch_nch<1>(a, L, grid, s, prof_ts); break;
     case 2: launch_nch<2>(a, L, grid, s, prof_ts); break;

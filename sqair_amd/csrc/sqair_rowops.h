@@ -1,6 +1,6 @@
-// Per-row spatial-transformer crop, shared by the launch-per-op path (k_crop_row, plain loads) and the XCD-persistent
-// executor (L1-bypassing loads of data written earlier in the same launch).  Arithmetic order of the original
-// per-sequence k_crop (sqair_glue.hip): results are bit-identical.
+// Per-row spatial-transformer crop (k_crop_row).  The load flavour is a template parameter (plain loads in the product;
+// an L1-bypassing flavour served the in-launch hand-off experiments of round 1).  Arithmetic order of the original
+// per-sequence k_crop: results are bit-identical.
 #pragma once
 #include "sqair_glue.h"
 
@@ -14,114 +14,6 @@ struct LdPlain {
     __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMAs (see sqair_linear_kernel.inc)
   }
 };
-
-// ---- dense-layer tile shared by the grouped launch (sqair_linear.hip) and the persistent executor -----------------------
-// operand addressing shared by both tilings
-// Per-lane A-operand addressing of up to four input segments.  Deliberately NOT a struct: a select chain over the members
-// of a struct returned by value is turned into an indexed load from a scratch copy of it (measured: 160 scratch
-// instructions in the chain kernel), so the eleven values live in named locals declared by SQ_XSEGS.
-#define SQ_XSEG1(i)                                                                                      \
-  const LinSeg& xs_seg##i = a.seg[i];                                                                    \
-  const int xs_row##i = xs_seg##i.rmul ? (int)__umulhi((unsigned)arow, xs_seg##i.rmul) : arow;           \
-  const float* const xs_rp##i = xs_seg##i.p + (size_t)xs_row##i * xs_seg##i.ld;                          \
-  const int xs_lim##i = ((xs_seg##i.width + 3) & ~3) - 4;
-// constant indices into a.seg (a runtime index into a by-value kernel argument goes through scratch as well); unused
-// segments are value-initialised and never dereferenced: their chunk range is empty
-#define SQ_XSEGS(a, arow)                                                                                \
-  SQ_XSEG1(0) SQ_XSEG1(1) SQ_XSEG1(2) SQ_XSEG1(3)                                                        \
-  const int xs_c1 = (xs_seg0.width + 15) >> 4;                                                           \
-  const int xs_c2 = xs_c1 + ((a).nseg > 1 ? (xs_seg1.width + 15) >> 4 : 0);                              \
-  const int xs_c3 = xs_c2 + ((a).nseg > 2 ? (xs_seg2.width + 15) >> 4 : 0);                              \
-  const int xs_cum1 = (a).nseg > 1 ? xs_c1 : 0x7fffffff, xs_cum2 = (a).nseg > 2 ? xs_c2 : 0x7fffffff,    \
-            xs_cum3 = (a).nseg > 3 ? xs_c3 : 0x7fffffff;
-#define SQ_XAPTR(g, kq) x_aptr(xs_rp0, xs_rp1, xs_rp2, xs_rp3, xs_cum1, xs_cum2, xs_cum3, xs_lim0, xs_lim1, xs_lim2, xs_lim3, (g), (kq))
-__device__ __forceinline__ const float* x_aptr(const float* rp0, const float* rp1, const float* rp2, const float* rp3, int cum1, int cum2,
-                                               int cum3, int lim0, int lim1, int lim2, int lim3, int g, int kq) {
-  const bool s1 = g >= cum1, s2 = g >= cum2, s3 = g >= cum3;
-  const float* rp = s3 ? rp3 : (s2 ? rp2 : (s1 ? rp1 : rp0));
-  const int cb = s3 ? cum3 : (s2 ? cum2 : (s1 ? cum1 : 0));
-  const int lim = s3 ? lim3 : (s2 ? lim2 : (s1 ? lim1 : lim0));
-  return rp + min((g - cb) * 16 + kq * 4, lim);
-}
-// epilogue of one output element (m, n) with pre-activation sum v (bias and addend already included)
-__device__ __forceinline__ void x_epilogue(const LinArgs& a, int m, int n, float v, float p_e0, float p_e1, float p_scale) {
-  if (a.epi == EPI_ACT) {
-    v = sq_act(v, n < a.act_split ? a.act_a : a.act_b);
-    a.out[(size_t)m * a.out_ld + n] = v * a.scale * p_scale;
-  } else if (a.epi == EPI_GRU1) {
-    const int nh = a.nh;
-    if (n < nh) a.out[(size_t)m * a.out_ld + n] = sq_sigmoid(v);
-    else if (n < 2 * nh) {
-      const float rg = sq_sigmoid(v);
-      a.o1[(size_t)m * a.o1_ld + (n - nh)] = rg * p_e0;
-      if (a.o3 != nullptr) a.o3[(size_t)m * a.o3_ld + (n - nh)] = rg;
-    } else a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
-  } else {
-    const float hc = tanhf(v);
-    a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1) * p_e0 + p_e1 * hc;
-    if (a.o1 != nullptr) a.o1[(size_t)m * a.o1_ld + n] = hc;
-  }
-}
-
-// One 16x16 output tile by one workgroup: 4 waves split K, LDS reduce (arithmetic order of k_linear).  LD selects how
-// activations are loaded (plain for ordinary launches, L1-bypassing inside the persistent executor).
-template <class LD>
-__device__ void x_linear_tile(const LinArgs& a, int kc_total, int tile_n, int mbase, int m1, float* red) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
-  const int arow = min(mbase + (lane & 15), m1 - 1);
-  const int m = mbase + (tid >> 4);
-  const int n = tile_n * 16 + (tid & 15);
-  const bool live = m < m1 && n < a.N;
-  const int mc = min(m, m1 - 1), nc = min(n, a.N - 1);
-  const float* pb = a.bias + nc;
-  const bool use_add = a.add != nullptr && nc < a.add_n;
-  const bool g1 = a.epi == EPI_GRU1 && nc >= a.nh && nc < 2 * a.nh;
-  const bool g2 = a.epi == EPI_GRU2;
-  const int mcd = a.add_rmul ? (int)__umulhi((unsigned)mc, a.add_rmul) : mc;
-  const float* pa = use_add ? a.add + (size_t)mcd * a.add_ld + nc : pb;
-  const float* pe0 = g1 ? a.e0 + (size_t)mc * a.e0_ld + (nc - a.nh) : (g2 ? a.e0 + (size_t)mc * a.e0_ld + nc : pb);
-  const float* pe1 = g2 ? a.e1 + (size_t)mc * a.e1_ld + nc : pb;
-  const float p_bias = *pb;
-  float p_add = LD::f(pa);
-  const float p_e0 = LD::f(pe0), p_e1 = LD::f(pe1);
-  const float p_scale = a.scale_ptr != nullptr ? *a.scale_ptr : 1.0f;
-  p_add = use_add ? p_add : 0.0f;
-  SQ_XSEGS(a, arow)
-  sq_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-  const sq_f32x4* __restrict__ wp = reinterpret_cast<const sq_f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
-  const sq_f32x4* __restrict__ wz = reinterpret_cast<const sq_f32x4*>(a.wzero) + lane;
-  const int nmine = (kc_total - wave + 3) >> 2;
-  constexpr int NCH = 4;
-#pragma unroll 1
-  for (int base = 0; base < nmine; base += NCH) {
-    sq_f32x4 av[NCH], bv[NCH];
-    const float* ap[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const bool valid = base + j < nmine;
-      const int g = valid ? wave + 4 * (base + j) : wave;
-      ap[j] = SQ_XAPTR(g, kq);
-      bv[j] = *(valid ? wp + (size_t)g * 64 : wz);
-    }
-    LD::f4x4(ap[0], ap[1], ap[2], ap[3], av[0], av[1], av[2], av[3]);
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
-    }
-  }
-  float* r = red + wave * 256;
-  r[(4 * kq + 0) * 16 + (lane & 15)] = acc0.x + acc1.x;
-  r[(4 * kq + 1) * 16 + (lane & 15)] = acc0.y + acc1.y;
-  r[(4 * kq + 2) * 16 + (lane & 15)] = acc0.z + acc1.z;
-  r[(4 * kq + 3) * 16 + (lane & 15)] = acc0.w + acc1.w;
-  __syncthreads();
-  if (live) x_epilogue(a, m, n, red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + p_bias + p_add, p_e0, p_e1, p_scale);
-  __syncthreads();
-}
-
 
 template <class LD>
 __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int r, int slot, float* smem, bool stage_img) {

@@ -62,9 +62,7 @@ class SqairCore(object):
     """Thin owner of a library handle + the device buffers it needs (parameters, packed parameters,
     workspace, noise, outputs) for one (T, B) shape on one device / stream."""
 
-    def __init__(self, F, img_hw, device="cuda:0", chains=None):
-        """chains: run the dependent MLP chains of a slot as one launch each (csrc/sqair_chain.hip; same results, fewer
-        graph nodes).  None = the environment variable SQAIR_CHAINS (default off)."""
+    def __init__(self, F, img_hw, device="cuda:0"):
         if not torch.cuda.is_available():
             raise RuntimeError("sqair_amd needs a HIP device (no CPU fallback)")
         self.F = F
@@ -96,11 +94,6 @@ class SqairCore(object):
         self._shape = None
         self._graph_ready = False
         _capi.check(self.handle, self.lib.sqair_set_workspace_clearing(self.handle, 0), "sqair_set_workspace_clearing")
-        self.chains = False
-        if chains is None:
-            chains = os.environ.get("SQAIR_CHAINS", "0") == "1"
-        if chains:
-            self.set_chains(True)
 
     def _clear_ws(self, ws, train):
         """One workspace per (T, B, inference | training) is cleared ONCE here; the per-pass zero fill of the library is
@@ -108,20 +101,6 @@ class SqairCore(object):
         _capi.check(self.handle, self.lib.sqair_clear_workspace(self.handle, ws.data_ptr(), ws.numel() * 4, self.T_bind, self.B_bind,
                                                                  int(train), self._stream()), "sqair_clear_workspace")
         self.stream.synchronize()
-
-    def set_chains(self, on):
-        with torch.cuda.device(self.device):
-            _capi.check(self.handle, self.lib.sqair_enable_chains(self.handle, int(bool(on))), "sqair_enable_chains")
-        self.chains = bool(on)
-        self._graph_ready = False
-        self._train_graph_ready = False
-
-    def chain_status(self, train=False):
-        """0 = the last pass (inference workspace, or the training tape with train=True) is valid; 1 / 2 = a layer-chain
-        launch timed out / ran with an unexpected workgroup placement: discard the pass, set_chains(False), re-run."""
-        ws = self.train_ws if train else self.workspace
-        with torch.cuda.device(self.device):
-            return int(self.lib.sqair_chain_status(self.handle, ws.data_ptr(), self.T, self.B, int(bool(train)), self._stream()))
 
     def __del__(self):
         try:
@@ -235,7 +214,6 @@ class SqairCore(object):
         self._train_graph_ready = False
         self.train_ws = None
         self.bwd_scratch = None
-        self.program = None
 
     def draw_noise(self, generator=None, seed=None, step=0, global_batch=None, b0=0):
         """eps ~ N(0,1) for the Normals, u ~ U[0,1) for the presence Bernoullis, on device.  With ``seed`` the library's own
@@ -265,19 +243,12 @@ class SqairCore(object):
                 self.noise.data_ptr(), self.T, self.B, int(t_offset), C.byref(self.c_out),
                 self.workspace.data_ptr(), self.ws_bytes, self._stream())
 
-    def forward(self, t_offset=0, use_graph=False, train=False, persistent=False):
+    def forward(self, t_offset=0, use_graph=False, train=False):
         """Launches the whole T-frame forward pass + the ELBO reductions on the current stream.  ``train`` keeps the
-        tape for the backward pass (larger workspace, allocated on first use).  ``persistent``: the frame loop as one
-        XCD-persistent launch (sqair_forward_persistent) instead of ~94 launches per frame."""
+        tape for the backward pass (larger workspace, allocated on first use)."""
         with torch.cuda.device(self.device):
             self._join_in()
-            if persistent and not train:
-                nb = self.lib.sqair_program_bytes(self.handle, self.T, self.B)
-                if getattr(self, "program", None) is None or self.program.numel() * 4 < nb:
-                    self.program = torch.zeros((nb + 3) // 4, dtype=torch.float32, device=self.device)
-                _capi.check(self.handle, self.lib.sqair_forward_persistent(
-                    *(self._args(t_offset)[:-1] + (self.program.data_ptr(), nb, self._stream()))), "sqair_forward_persistent")
-            elif train:
+            if train:
                 nb = self.lib.sqair_train_workspace_bytes(self.handle, self.T, self.B)
                 if getattr(self, "train_ws", None) is None or self.train_ws.numel() * 4 < nb:
                     self.train_ws = torch.empty(nb // 4, dtype=torch.float32, device=self.device)
@@ -414,10 +385,6 @@ class SqairCore(object):
 
     def graph_nodes(self):
         return self.lib.sqair_graph_nodes(self.handle)
-
-    def persistent_status(self):
-        """0 after a completed persistent pass, 1 if a team barrier timed out (synchronises the stream)."""
-        return self.lib.sqair_persistent_status(self.handle, self.program.data_ptr(), self._stream())
 
 
 class Model(object):

@@ -273,37 +273,6 @@ def test_training_mode_forward_is_bitwise_identical():
     assert torch.equal(core.log_weights, lw)
 
 
-@pytest.mark.parametrize("K,N,T,B,hw", [(3, 3, 3, 8, (50, 50)), (5, 4, 4, 13, (50, 50)), (2, 2, 2, 3, (64, 48))])
-def test_xcd_persistent_forward_matches_launch_per_layer(K, N, T, B, hw):
-    """The frame loop as ONE XCD-persistent launch (per-XCD teams, L2 hand-offs, bounded team barriers) against the
-    launch-per-layer path: same presence decisions, every output within 5e-5 of its scale (the batched layers use a
-    different K-split, so the last bits differ), no barrier time-out.  B*K is deliberately not a multiple of 16."""
-    from sqair_amd.model import Model, SqairCore
-    F = make_flags(k_particles=K, n_steps_per_image=N)
-    d = make_sequences(B, T=T, canvas=hw, seed=31)
-    obs = to_float(d["imgs"])
-    core = SqairCore(F, hw)
-    core.set_params(params32(F, hw, 5, 0.05, obs.mean((0, 1))))
-    Model(obs, None, core, K, presence=d["nums"])
-    with core.on_stream():
-        core.noise.copy_(torch.as_tensor(draw_noise(np.random.default_rng(7), T, B * K, N, 55)).reshape(core.noise.shape))
-        core.forward()
-        core.stream.synchronize()
-        ref = {k: v.clone() for k, v in core.out.items()}
-        lw = core.log_weights.clone()
-        for rep in range(2):  # the second pass reuses the cached op list
-            for v in core.out.values():
-                v.zero_()
-            core.forward(persistent=True)
-            core.stream.synchronize()
-            assert core.persistent_status() == 0
-            assert torch.equal(core.out["presence"], ref["presence"])
-            for k, v in core.out.items():
-                scale = max(float(ref[k].abs().max()), 1e-6)
-                assert float((v - ref[k]).abs().max()) <= 5e-5 * scale, (k, rep)
-            assert float((core.log_weights - lw).abs().max()) <= 1e-4 * float(lw.abs().max())
-
-
 @pytest.mark.parametrize("generate_after,prior", [(-1, "rnn"), (1, "rnn"), (1, "guided"), (2, "rw")])
 def test_generation_modes_vs_live_oracle(generate_after, prior):
     """`sample_from_prior` (posterior log-probs at prior samples, sqair_modules.py:294-302) and
@@ -345,33 +314,3 @@ def test_generation_modes_vs_live_oracle(generate_after, prior):
         worst = max(worst, err)
         assert err <= 2e-5, (k, err)
     assert abs(float(m.elbo_iwae) - float(ref.elbo_iwae)) <= 1e-4 * abs(float(ref.elbo_iwae))
-
-
-@pytest.mark.parametrize("K,N,T,B", [(5, 4, 3, 32), (3, 3, 2, 24)])
-def test_layer_chains_match_launch_per_layer_bit_for_bit(K, N, T, B):
-    """csrc/sqair_chain.hip (opt-in): the glimpse-encoder chain of every slot as ONE launch with per-XCD workgroup teams.
-    Same tile arithmetic as k_linear: every output bit-identical, fewer graph nodes, status word clean; the gradient graph
-    built on the chained forward pass agrees with the plain one (float atomics: 1e-5 of the largest gradient)."""
-    hw = (50, 50)
-    F = make_flags(k_particles=K, n_steps_per_image=N)
-    obs = to_float(make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), seed=4)["imgs"])
-    P = params32(F, hw, 3, 0.05, obs.mean((0, 1)))
-    noise = draw_noise(np.random.default_rng(5), T, B * K, N, 55)
-    res = {}
-    for chains in (False, True):
-        core = SqairCore(F, hw, chains=chains)
-        core.set_params(P)
-        Model(obs, None, core, K, outputs="all")
-        core.noise.copy_(torch.as_tensor(noise).reshape(core.noise.shape))
-        core.forward(use_graph=True)
-        torch.cuda.synchronize()
-        assert core.chain_status() == 0
-        out = {k: v.clone() for k, v in core.out.items()}
-        g = core.grad_step(use_graph=True).clone()
-        torch.cuda.synchronize()
-        assert core.chain_status(train=True) == 0
-        res[chains] = (out, g, core.graph_nodes())
-    assert res[True][2] < res[False][2]
-    for k, v in res[False][0].items():
-        assert torch.equal(v, res[True][0][k]), k
-    assert float((res[True][1] - res[False][1]).abs().max()) <= 1e-5 * float(res[False][1].abs().max())
