@@ -97,13 +97,36 @@ int sq_launch_pack_bias(const float* flat, float* packed_b, const int* idxa, con
 // device math (exact-ish fp32; no fast-math so that parity with the fp64 oracle holds to ~1e-6)
 // ---------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
-__device__ __forceinline__ float sq_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float sq_softplus(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
-__device__ __forceinline__ float sq_elu(float x) { return x > 0.0f ? x : expm1f(x); }
+// Activations of the dense-layer epilogues and the slot kernels, built on the hardware exp2 / log2 / rcp (1 ulp each) instead
+// of the libm expansions: the libm versions (expm1f, tanhf, log1pf, expf: 40-80 instructions apiece, inlined into every
+// epilogue) made up almost half of the dense kernel's code, and the kernels of the slot loop are sensitive to their size (a
+// dependent node starts with a partly cold instruction cache: 1.2 KB less code in k_linear measured -0.3 us per launch).
+// Absolute error <= ~1.7e-7 on outputs of order one (libm: ~6e-8), i.e. at the fp32 rounding level of the GEMM sums feeding them.
+// NOT used for the spatial-transformer geometry (to_coords: the shift tanh is multiplied by (W - 1) / 2 pixels and, in the
+// decoder's mask, by another factor 20 inside a sigmoid): crop, insert and their adjoints keep libm's tanhf there.
+__device__ __forceinline__ float sq_exp(float x) {
+  // e^x = 2^(x log2 e); the product is formed in two parts (t + r) so that its rounding error, which exp2 would amplify to
+  // |x| * 6e-8 relative, is put back to first order: 2^(t + r) = 2^t (1 + r ln 2)
+  const float t = x * 1.44269504088896340736f;
+  const float r = fmaf(x, 1.44269504088896340736f, -t) + x * 1.92596299112661746e-8f;
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.69314718055994530942f, e);
+}
+__device__ __forceinline__ float sq_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+__device__ __forceinline__ float sq_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + sq_exp(-x)); }
+__device__ __forceinline__ float sq_tanh(float x) {  // 1 - 2 / (e^{2x} + 1): saturates cleanly (e^{2x} = inf -> 1, 0 -> -1)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(sq_exp(2.0f * x) + 1.0f);
+}
+__device__ __forceinline__ float sq_log1p(float y) {  // y in [0, 1]: log(u) y / (u - 1) with u = fl(1 + y) undoes the rounding of 1 + y
+  const float u = 1.0f + y, d = u - 1.0f;
+  return d == 0.0f ? y : sq_log(u) * (y * __builtin_amdgcn_rcpf(d));
+}
+__device__ __forceinline__ float sq_softplus(float x) { return fmaxf(x, 0.0f) + sq_log1p(sq_exp(-fabsf(x))); }
+__device__ __forceinline__ float sq_elu(float x) { return x > 0.0f ? x : sq_exp(x) - 1.0f; }
 __device__ __forceinline__ float sq_act(float v, int act) {
   switch (act) {
     case ACT_ELU: return sq_elu(v);
-    case ACT_TANH: return tanhf(v);
+    case ACT_TANH: return sq_tanh(v);
     case ACT_SIGMOID: return sq_sigmoid(v);
     case ACT_SOFTPLUS_MIN: return sq_softplus(v) + 1e-2f;
     default: return v;

@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void k_lstm_cell(const float* __restrict__ gat
   const int r = e / nh, q = e - r * nh;
   const float* g = gates + (size_t)r * g_ld;
   const float gi = g[q], gj = g[nh + q], gf = g[2 * nh + q], go = g[3 * nh + q];
-  const float c = sq_sigmoid(gf + 1.0f) * c_prev[(size_t)r * c_ld + q] + sq_sigmoid(gi) * tanhf(gj);
-  h_out[(size_t)r * h_ld + q] = tanhf(c) * sq_sigmoid(go);
+  const float c = sq_sigmoid(gf + 1.0f) * c_prev[(size_t)r * c_ld + q] + sq_sigmoid(gi) * sq_tanh(gj);
+  h_out[(size_t)r * h_ld + q] = sq_tanh(c) * sq_sigmoid(go);
   c_out[(size_t)r * co_ld + q] = c;
 }
 // c_ld = 0 broadcasts one initial cell row; hidden and cell may live in different buffers (slot RNN) or side by side
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
         for (int mm = 0; mm < 4; ++mm) {
           float acc = hs[mm];
           for (int i = 0; i < 4; ++i) acc += xp[i] * i2h_s[i * 4 + mm];
-          o[mm] = tanhf(acc);
+          o[mm] = sq_tanh(acc);
         }
         float loc = ro_s[32 + lane], raw = ro_s[32 + 4 + lane];
         for (int mm = 0; mm < 4; ++mm) {
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(64) void k_generate_disc(const GenArgs a, const POf
         for (int mm = 0; mm < 4; ++mm) {
           float acc = hs[mm];
           for (int i = 0; i < 4; ++i) acc += xprev[i] * flat[po.rn_i2h_w + i * 4 + mm];
-          o[mm] = tanhf(acc);
+          o[mm] = sq_tanh(acc);
         }
         loc = flat[po.rn_readout_b + c];
         float raw = flat[po.rn_readout_b + 4 + c];

@@ -45,7 +45,7 @@ __device__ __forceinline__ void x_epilogue(const LinArgs& a, int m, int n, float
       if (a.o3 != nullptr) a.o3[(size_t)m * a.o3_ld + (n - nh)] = rg;
     } else a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
   } else {
-    const float hc = tanhf(v);
+    const float hc = sq_tanh(v);
     a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1) * p_e0 + p_e1 * hc;
     if (a.o1 != nullptr) a.o1[(size_t)m * a.o1_ld + n] = hc;
   }

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int 
         }
         else a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
       } else {
-        const float hc = tanhf(v);
+        const float hc = sq_tanh(v);
         a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1[i]) * p_e0[i] + p_e1[i] * hc;
         if (a.o1 != nullptr) a.o1[(size_t)m * a.o1_ld + n] = hc;
       }
@@ -379,15 +379,24 @@ static void launch_mt(const LinArgs& a, const PackedLayer& L, int mt, bool coal,
   else hipLaunchKernelGGL((k_linear_mt<NCH, MT, NT, false>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
 }
 
+template <int NCH, int NSEG>
+static void launch_seg(const LinArgs& a, const PackedLayer& L, hipStream_t s, unsigned long long* prof_ts) {
+  const dim3 g(L.nt, (a.M + 15) / 16);
+  // the GRU gate epilogues are compiled out of the instantiation the plain layers use (the slot loop rotates through ~10 code
+  // objects; the smaller they are, the more of them stay in the instruction cache)
+  if (a.epi == EPI_ACT)
+    hipLaunchKernelGGL((k_linear<NCH, NSEG, false>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts);
+  else
+    hipLaunchKernelGGL((k_linear<NCH, NSEG, true>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts);
+}
 template <int NCH>
 static void launch_nch(const LinArgs& a, const PackedLayer& L, int grid, hipStream_t s, unsigned long long* prof_ts) {
   (void)grid;
-  const dim3 g(L.nt, (a.M + 15) / 16);
   switch (a.nseg) {  // the segment count is a template parameter: dead segment-selection code disappears
-    case 1: hipLaunchKernelGGL((k_linear<NCH, 1>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts); break;
-    case 2: hipLaunchKernelGGL((k_linear<NCH, 2>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts); break;
-    case 3: hipLaunchKernelGGL((k_linear<NCH, 3>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts); break;
-    default: hipLaunchKernelGGL((k_linear<NCH, 4>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts); break;
+    case 1: launch_seg<NCH, 1>(a, L, s, prof_ts); break;
+    case 2: launch_seg<NCH, 2>(a, L, s, prof_ts); break;
+    case 3: launch_seg<NCH, 3>(a, L, s, prof_ts); break;
+    default: launch_seg<NCH, 4>(a, L, s, prof_ts); break;
   }
 }
 
