@@ -384,10 +384,14 @@ static void launch_seg(const LinArgs& a, const PackedLayer& L, hipStream_t s, un
   const dim3 g(L.nt, (a.M + 15) / 16);
   // the GRU gate epilogues are compiled out of the instantiation the plain layers use (the slot loop rotates through ~10 code
   // objects; the smaller they are, the more of them stay in the instruction cache)
-  if (a.epi == EPI_ACT)
-    hipLaunchKernelGGL((k_linear<NCH, NSEG, false>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts);
-  else
-    hipLaunchKernelGGL((k_linear<NCH, NSEG, true>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a, prof_ts);
+#define SQ_LAUNCH_KL(G, P) hipLaunchKernelGGL((k_linear<NCH, NSEG, G, P>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a.wzero, a, prof_ts)
+  // (likewise the device-clock stamps of the profiling pass exist only in the instantiations that pass launches)
+  if (prof_ts == nullptr) {
+    if (a.epi == EPI_ACT) SQ_LAUNCH_KL(false, false); else SQ_LAUNCH_KL(true, false);
+  } else {
+    if (a.epi == EPI_ACT) SQ_LAUNCH_KL(false, true); else SQ_LAUNCH_KL(true, true);
+  }
+#undef SQ_LAUNCH_KL
 }
 template <int NCH>
 static void launch_nch(const LinArgs& a, const PackedLayer& L, int grid, hipStream_t s, unsigned long long* prof_ts) {
