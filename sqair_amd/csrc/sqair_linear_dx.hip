@@ -18,22 +18,47 @@ __device__ __forceinline__ float dx_dact(float g, float o, int act) {
     case ACT_ELU: return g * (o > 0.0f ? 1.0f : o + 1.0f);
     case ACT_TANH: return g * (1.0f - o * o);
     case ACT_SIGMOID: return g * (o * (1.0f - o));
-    case ACT_SOFTPLUS_MIN: return g * (1.0f - expf(-(o - 1e-2f)));
+    case ACT_SOFTPLUS_MIN: return g * (1.0f - sq_exp(-(o - 1e-2f)));
     default: return g;
   }
 }
 
 template <int NCH>
 __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpre0, const float* __restrict__ wp0, const int ld0,
-                                                   const int width0, const int M0, const int kc_total, const DxArgs a) {
-  // leading scalars (copies of a.dpre / a.wp / a.ld / a.width / a.M): preloaded into SGPRs with the launch, so the operand
-  // loads do not wait for the s_load of the struct (see sqair_linear_kernel.inc)
+                                                   const int width0, const int M0, const int kc_total,
+                                                   const float* __restrict__ wzero0, const DxArgs a) {
+  // leading scalars (copies of a.dpre / a.wp / a.ld / a.width / a.M / a.wzero): preloaded into SGPRs with the launch, so the
+  // operand loads are issued before the s_load of the struct has returned; the epilogue operands, which need the struct, are
+  // requested right behind them and still ahead of the MFMAs (see sqair_linear_kernel.inc)
   __shared__ float red[4 * 256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tile_n = blockIdx.x, tile_m = blockIdx.y;
   const int arow = min(tile_m * 16 + (lane & 15), M0 - 1);
   const int kq = lane >> 4;
-  // ---- epilogue operands (addend, saved activation), requested before the operand loads
+  const float* rp = dpre0 + (size_t)arow * ld0;
+  const int lim = ((width0 + 3) & ~3) - 4;
+  f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wp0) + ((size_t)tile_n * kc_total) * 64 + lane;
+  const f32x4* __restrict__ wz = reinterpret_cast<const f32x4*>(wzero0) + lane;
+  const int nmine = (kc_total - wave + 3) >> 2;  // this wave owns chunks g = wave + 4 i
+  f32x4 av[NCH], bv[NCH];
+#define SQ_DX_ISSUE(BASE)                                                                    \
+  _Pragma("unroll") for (int j = 0; j < NCH; ++j) {                                          \
+    const bool valid = (BASE) + j < nmine;                                                   \
+    const int g = valid ? wave + 4 * ((BASE) + j) : wave;                                    \
+    av[j] = *reinterpret_cast<const f32x4*>(rp + min(g * 16 + kq * 4, lim));                 \
+    bv[j] = *(valid ? wp + (size_t)g * 64 : wz);                                             \
+  }
+#define SQ_DX_MFMA()                                                                         \
+  _Pragma("unroll") for (int j = 0; j < NCH; ++j) {                                          \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);            \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);            \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);            \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);            \
+  }
+  SQ_DX_ISSUE(0)
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- epilogue operands (addend, saved activation)
   const int m = tile_m * 16 + (tid >> 4);
   const int n = tile_n * 16 + (tid & 15);
   const int mc = min(m, a.M - 1);
@@ -43,37 +68,23 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
   const DxRange& rg = a.r[ri];
   const bool live = m < a.M && n >= rg.n0 && n < rg.n1;
   const int c = live ? n - rg.n0 : 0;
-  const float* dummy = a.wzero;
+  const float* dummy = wzero0;
   const float* pa = (live && rg.add != nullptr) ? rg.add + (size_t)mc * rg.add_ld + c : dummy;
   const float* ps = (live && rg.saved != nullptr) ? rg.saved + (size_t)mc * rg.saved_ld + c : dummy;
   const float p_add = *pa, p_saved = *ps;
   const float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : dummy);
-
-  const float* rp = dpre0 + (size_t)arow * ld0;
-  const int lim = ((width0 + 3) & ~3) - 4;
-  f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wp0) + ((size_t)tile_n * kc_total) * 64 + lane;
-  const f32x4* __restrict__ wz = reinterpret_cast<const f32x4*>(a.wzero) + lane;
-  const int nmine = (kc_total - wave + 3) >> 2;  // this wave owns chunks g = wave + 4 i
+  __builtin_amdgcn_sched_barrier(0);
+  SQ_DX_MFMA()
+  if (NCH == 9) {  // only the deepest instantiation loops (K > 576)
 #pragma unroll 1
-  for (int base = 0; base < nmine; base += NCH) {
-    f32x4 av[NCH], bv[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const bool valid = base + j < nmine;
-      const int g = valid ? wave + 4 * (base + j) : wave;
-      av[j] = *reinterpret_cast<const f32x4*>(rp + min(g * 16 + kq * 4, lim));
-      bv[j] = *(valid ? wp + (size_t)g * 64 : wz);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
+    for (int base = NCH; base < nmine; base += NCH) {
+      SQ_DX_ISSUE(base)
+      __builtin_amdgcn_sched_barrier(0);
+      SQ_DX_MFMA()
     }
   }
+#undef SQ_DX_ISSUE
+#undef SQ_DX_MFMA
   float* r = red + wave * 256;
   r[(4 * kq + 0) * 16 + (lane & 15)] = acc0.x + acc1.x;
   r[(4 * kq + 1) * 16 + (lane & 15)] = acc0.y + acc1.y;
@@ -96,15 +107,15 @@ int sq_launch_linear_dx(const DxArgs& a, int kc, int nt, hipStream_t s) {
   if (g.x == 0 || g.y == 0) return 0;
   const int per_wave = (kc + 3) / 4;
   switch (per_wave) {
-    case 1: hipLaunchKernelGGL(k_linear_dx<1>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
-    case 2: hipLaunchKernelGGL(k_linear_dx<2>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
-    case 3: hipLaunchKernelGGL(k_linear_dx<3>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
-    case 4: hipLaunchKernelGGL(k_linear_dx<4>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
-    case 5: hipLaunchKernelGGL(k_linear_dx<5>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
-    case 6: hipLaunchKernelGGL(k_linear_dx<6>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
-    case 7: hipLaunchKernelGGL(k_linear_dx<7>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
-    case 8: hipLaunchKernelGGL(k_linear_dx<8>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
-    default: hipLaunchKernelGGL(k_linear_dx<9>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a); break;
+    case 1: hipLaunchKernelGGL(k_linear_dx<1>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 2: hipLaunchKernelGGL(k_linear_dx<2>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 3: hipLaunchKernelGGL(k_linear_dx<3>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 4: hipLaunchKernelGGL(k_linear_dx<4>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 5: hipLaunchKernelGGL(k_linear_dx<5>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 6: hipLaunchKernelGGL(k_linear_dx<6>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 7: hipLaunchKernelGGL(k_linear_dx<7>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 8: hipLaunchKernelGGL(k_linear_dx<8>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    default: hipLaunchKernelGGL(k_linear_dx<9>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
   }
   return 0;
 }

@@ -114,7 +114,7 @@ int main() {
     a.seg[0] = LinSeg{in, KD, KD, 1}; a.nseg = 1; a.wp = w + 256 + (size_t)l * wl; a.wzero = w; a.bias = b; a.out = out; a.out_ld = ND;
     a.M = M; a.N = ND; a.epi = EPI_ACT; a.act_a = ACT_ELU; a.act_split = 1 << 30; a.scale = 1.0f; a.add_rdiv = 1;
     hipLaunchKernelGGL(k_full<4>, dim3(NT, (M + 15) / 16), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M,
-                       KC, NT, a, (unsigned long long*)nullptr);
+                       KC, NT, a.wzero, a, (unsigned long long*)nullptr);
   };
   // correctness: 3 chained layers
   lin(x, y, 0); lin(y, yref, 1); lin(yref, y, 2); hipMemcpyAsync(yref, y, M * KD * 4, hipMemcpyDeviceToDevice, s);

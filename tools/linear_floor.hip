@@ -90,7 +90,7 @@ int main() {
 #define RUN(name, kern, m, ntu, statin)                                                                         \
   printf("%-34s %.2f us/node\n", name, time_graph(s, NODES, REPS, [&](int i) {                                    \
     LinArgs a = mk((statin) ? x : ((i & 1) ? y : x), (statin) ? y : ((i & 1) ? x : y), m, ntu);                   \
-    hipLaunchKernelGGL(kern<4>, dim3((ntu), ((m) + 15) / 16), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, ntu, a, (unsigned long long*)nullptr); }));
+    hipLaunchKernelGGL(kern<4>, dim3((ntu), ((m) + 15) / 16), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, ntu, a.wzero, a, (unsigned long long*)nullptr); }));
   RUN("full 160x256x256 (160 WG)", k_full, 160, 16, false);
   RUN("full, static input", k_full, 160, 16, true);
   RUN("no MFMA (VALU fma instead)", k_nomfma, 160, 16, false);
@@ -107,7 +107,7 @@ int main() {
     printf("%-34s %.2f us/node\n", nm, time_graph(s, NODES, REPS, [&](int i) {
       LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);
       a.wp = w + 256 + (size_t)(i % L) * nt * kc * 256;
-      hipLaunchKernelGGL(k_aff<4>, dim3(256), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a, (unsigned long long*)nullptr); }));
+      hipLaunchKernelGGL(k_aff<4>, dim3(256), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a.wzero, a, (unsigned long long*)nullptr); }));
   }
   for (int L : {16, 64}) {
     char nm[64]; snprintf(nm, 64, "affinity + next-W prefetch, %d mats", L);
@@ -115,24 +115,24 @@ int main() {
       LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);
       a.wp = w + 256 + (size_t)(i % L) * nt * kc * 256;
       a.e1 = w + 256 + (size_t)((i + 1) % L) * nt * kc * 256;
-      hipLaunchKernelGGL(k_aff_pf<4>, dim3(256), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a, (unsigned long long*)nullptr); }));
+      hipLaunchKernelGGL(k_aff_pf<4>, dim3(256), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a.wzero, a, (unsigned long long*)nullptr); }));
     snprintf(nm, 64, "n-tile map + next-W prefetch, %d mats", L);
     printf("%-34s %.2f us/node\n", nm, time_graph(s, NODES, REPS, [&](int i) {
       LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);
       a.wp = w + 256 + (size_t)(i % L) * nt * kc * 256;
       a.e1 = w + 256 + (size_t)((i + 1) % L) * nt * kc * 256;
-      hipLaunchKernelGGL(k_full_pf<4>, dim3(16, 10), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a, (unsigned long long*)nullptr); }));
+      hipLaunchKernelGGL(k_full_pf<4>, dim3(16, 10), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a.wzero, a, (unsigned long long*)nullptr); }));
   }
   printf("%-34s %.2f us/node\n", "row-tile XCD affinity, no B loads", time_graph(s, NODES, REPS, [&](int i) {
       LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);
-      hipLaunchKernelGGL(k_aff_nob<4>, dim3(256), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a, (unsigned long long*)nullptr); }));
+      hipLaunchKernelGGL(k_aff_nob<4>, dim3(256), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a.wzero, a, (unsigned long long*)nullptr); }));
   // cycle through L different 256 KB weight matrices (the forward pass touches ~12 MB of weights per frame)
   for (int L : {2, 8, 16, 32, 48, 64}) {
     char nm[64]; snprintf(nm, 64, "full, %d rotating weight mats", L);
     printf("%-34s %.2f us/node\n", nm, time_graph(s, NODES, REPS, [&](int i) {
       LinArgs a = mk((i & 1) ? y : x, (i & 1) ? x : y, 160, 16);
       a.wp = w + 256 + (size_t)(i % L) * nt * kc * 256;
-      hipLaunchKernelGGL(k_full<4>, dim3(16, 10), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a, (unsigned long long*)nullptr); }));
+      hipLaunchKernelGGL(k_full<4>, dim3(16, 10), dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, kc, 16, a.wzero, a, (unsigned long long*)nullptr); }));
   }
   return 0;
 }
