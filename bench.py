@@ -12,10 +12,12 @@ shard (weak scaling, the sharding of configs[2]; no collective on the data path 
 frames/step = B * T per rank (all K particles of a frame count as one frame).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel k_linear (fp32 MFMA dense layers): achieved = algorithmic FLOPs of
-                 the step as the reference graph computes them (135.4 MFLOP/frame
-                 at cfg-2) / summed k_linear time of the step, measured live with HIP events around
-                 every launch on the launch stream; peak = 157.3 TFLOP/s dense fp32 matrix.
+  roofline     — dominant kernel family k_linear (fp32 MFMA dense layers): achieved = algorithmic FLOPs per
+                 launch (135.4 MFLOP/frame at cfg-2, as the reference graph computes
+                 them, / dense launches per step) / average launch duration, measured live with one
+                 HIP-event pair around replays of a graph of the pass's dense launches (boundary
+                 included); frac_device_clock (in-kernel only) and frac_rocprof (profiles/, recomputable
+                 with tools/roofline_from_rocprof.py) are reported beside it; peak = 157.3 TFLOP/s.
   cpu_baseline — the oracle (PyTorch-CPU fp32 restatement at the reference's op granularity,
                  kind "port": the TF1 reference cannot run here) timed on the host cores on a bounded
                  sample of the same workload; only this leg imports oracle/.
@@ -280,10 +282,26 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel: HIP events around every k_linear launch of one step ----
+    # ---- roofline of the dominant kernel (the fp32-MFMA dense layers) ----
+    # Three measurements of "average dense-launch duration", all reported; `frac` uses (1):
+    #  (1) HIP events, live: a graph holding ONLY the dense launches of the pass (same kernels / arguments / order) replayed
+    #      between one event pair on the launch stream -> duration per launch INCLUDING the dependent kernel boundary, i.e. what
+    #      a per-dispatch profiler sees, without a profiler attached;
+    #  (2) device clock, live: first-workgroup-start -> last-workgroup-end per launch (s_memrealtime, stamped by the kernels in
+    #      one eager pass) -> in-kernel time only, no boundary;
+    #  (3) rocprofv3 --kernel-trace --stats of this command, committed under profiles/ for THIS build (build_id must match):
+    #      per-dispatch duration under the profiler (its floor for a trivial dependent kernel is ~4.2-4.5 us on this stack).
+    from sqair_amd._capi import build_id
+    bid = build_id()
     prof = None
     for _ in range(3):
         prof = core.profile_linear()
+    torch.cuda.synchronize()
+    core.forward(use_graph=use_graph)          # a real pass: finite activations in the workspace for the dense-only replay
+    if use_graph:
+        lg = core.profile_linear_graph(replays=20)
+    else:  # (--no-graph is what the PMC passes use: rocprofv3's counter collection crashes on graph launches)
+        lg = dict(ms_per_replay=float("nan"), launches=prof["launches"], avg_launch_us=float("nan"))
     torch.cuda.synchronize()
     lin_ms = prof["linear_ms"]
     nh_in = 256 + 4 + 2 * int(F.n_what)
@@ -295,29 +313,61 @@ def main():
         algo_flops_step += float(B * T) * 2.0 * K * N * (int(F.n_what) + 4 + 256) * 256
     gates = {"VanillaRNN": 1, "GRU": 3, "LSTM": 4}[args.transition] - 1   # extra gate blocks of the two slot RNNs
     algo_flops_step += float(B * T) * 2.0 * K * N * gates * ((416 + 256) + (256 + 256 + int(F.n_what) + 5 + 256)) * 256
-    achieved = algo_flops_step / (lin_ms * 1e-3) / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
+    n_launch = prof["launches"]
+    algo_per_launch = algo_flops_step / n_launch
+    exec_per_launch = prof["executed_flops"] / n_launch
+    us_events = lg["avg_launch_us"]
+    us_clock = lin_ms * 1e3 / n_launch
+
+    def tf(flop, us):
+        return flop / (us * 1e-6) / 1e12
+
+    rocprof = None
+    stats_path = os.path.join(ROOT, "profiles", "r02_kernel_stats.csv")
+    meta_path = os.path.join(ROOT, "profiles", "r02_profile_meta.json")
+    traffic = traffic_note = None
+    if os.path.exists(meta_path):
         try:
-            traffic = json.load(open(tpath)).get("k_linear_bytes_per_launch")
-        except Exception:
-            traffic = None
+            meta = json.load(open(meta_path))
+            same_build = meta.get("build_id") == bid
+            if os.path.exists(stats_path) and args.cfg == 2 and not args.batch:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from roofline_from_rocprof import dense_average_ns
+                avg_ns, per = dense_average_ns(stats_path)
+                dom = max(per, key=lambda k: per[k][0])
+                rocprof = dict(avg_launch_us=avg_ns / 1e3, dominant=dom, dominant_avg_launch_us=per[dom][1] / 1e3,
+                               frac=tf(algo_per_launch, avg_ns / 1e3) / PEAK_FP32_MFMA_TFLOPS,
+                               frac_dominant=tf(algo_per_launch, per[dom][1] / 1e3) / PEAK_FP32_MFMA_TFLOPS,
+                               same_build_as_this_run=same_build, profile_build_id=meta.get("build_id"),
+                               recompute="python tools/roofline_from_rocprof.py profiles/r02_kernel_stats.csv")
+            tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("build_id") == bid:
+                    traffic = tj.get("dominant_bytes_per_launch")
+                    traffic_note = "PMC FETCH_SIZE / WRITE_SIZE of {} on this build (profiles/r02_hbm_traffic.json, two separate --pmc passes)".format(tj.get("dominant"))
+                else:
+                    traffic_note = "profiles/r02_hbm_traffic.json was measured on build {} != this build {}: not quoted".format(tj.get("build_id"), bid)
+        except Exception as e:  # a broken profile file must not take the bench line down
+            traffic_note = "profiles unreadable: {}".format(e)
     roofline = dict(
-        kernel="k_linear (fp32 MFMA 16x16x4 dense layers, {} launches/step)".format(prof["launches"]),
-        bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP32_MFMA_TFLOPS,
-        traffic=traffic,
-        algorithmic_flops_per_launch=algo_flops_step / prof["launches"],
-        avg_launch_us=lin_ms * 1e3 / prof["launches"],
-        timer="per launch: first-workgroup-start to last-workgroup-end on the 100 MHz device wall clock (s_memrealtime), "
-              "summed over the launches of one eager step; per-launch HIP events cannot resolve ~2-5 us kernels "
-              "(an empty event pair costs ~7.8 us here), one HIP-event pair brackets the whole pass instead",
-        step_ms_hip_events_eager=prof["forward_ms_events"],
-        executed_flops_per_step=prof["executed_flops"],
-        executed_tflops=prof["executed_flops"] / (lin_ms * 1e-3) / 1e12,
-        k_linear_share_of_step=lin_ms / ms_per_step,
-        note="achieved = as-reference algorithmic FLOPs of the step (input encoder counted N times, mask MLP twice, as the "
-             "reference graph computes them) / summed k_linear time; executed_* counts what the hoisted launch sequence runs",
+        kernel="k_linear family (fp32 MFMA 16x16x4 dense layers, {} launches/step)".format(n_launch),
+        bound="mfma", achieved=tf(algo_per_launch, us_events), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+        frac=tf(algo_per_launch, us_events) / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_note=traffic_note,
+        frac_is="frac_hip_events: algorithmic FLOPs per launch / average launch duration incl. the dependent kernel boundary, one "
+                "HIP-event pair around 20 replays of a graph of the pass's dense launches only",
+        frac_hip_events=tf(algo_per_launch, us_events) / PEAK_FP32_MFMA_TFLOPS,
+        frac_device_clock=tf(algo_per_launch, us_clock) / PEAK_FP32_MFMA_TFLOPS,
+        frac_rocprof=(rocprof or {}).get("frac"),
+        frac_executed_hip_events=tf(exec_per_launch, us_events) / PEAK_FP32_MFMA_TFLOPS,
+        frac_executed_device_clock=tf(exec_per_launch, us_clock) / PEAK_FP32_MFMA_TFLOPS,
+        avg_launch_us=us_events, avg_launch_us_device_clock=us_clock, rocprof=rocprof,
+        algorithmic_flops_per_launch=algo_per_launch, executed_flops_per_launch=exec_per_launch,
+        dense_only_graph_ms=lg["ms_per_replay"], dense_share_of_step=lg["ms_per_replay"] / ms_per_step,
+        step_ms_hip_events_eager=prof["forward_ms_events"], build_id=bid,
+        note="algorithmic = as-reference FLOPs of the step (SURVEY.md 8(d): input encoder counted N times, mask MLP twice, as the "
+             "reference graph computes them); executed = what the hoisted launch sequence runs.  Per-launch HIP events cannot "
+             "resolve 2-5 us kernels (an empty pair costs ~8 us here), hence the dense-only graph.",
     )
 
     cpu = None

@@ -173,6 +173,14 @@ int sqair_profile_forward(SqairHandle* h, const float* flat_params, const void* 
                           void* workspace, int64_t workspace_bytes, void* stream, double* linear_ms,
                           int* linear_launches, double* linear_flops, double* forward_ms_events);
 
+/* The dense launches of one pass, and only they, captured as a HIP graph and replayed `replays` times between two HIP
+ * events on `stream`: *ms_per_replay / *launches is the average dense-launch duration including the dependent kernel
+ * boundary (what a per-dispatch profiler reports), measured without a profiler attached.  The workspace must have been
+ * used by a real pass of the same shape before (the dense kernels read what that pass left behind). */
+int sqair_profile_linear_graph(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
+                               const float* noise, int T, int B, int t_offset, const SqairOutputs* out, void* workspace,
+                               int64_t workspace_bytes, void* stream, int replays, double* ms_per_replay, int* launches);
+
 /* ---- objective ---------------------------------------------------------------------------------
  * Fused IWAE / VIMCO reductions over [T,B,K] (reference: Model._build sqair/model.py:88-103,
  * targets.iwae / vimco_control_variate / vimco sqair/targets.py:38-75, make_target model.py:150-158,

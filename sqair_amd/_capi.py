@@ -66,6 +66,9 @@ _PROTOS = {
                                         C.c_int, C.c_int, C.POINTER(SqairOutputs), C.c_void_p, C.c_int64,
                                         C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sqair_profile_linear_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(SqairOutputs), C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
+                                             C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "sqair_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sqair_graph_nodes": (C.c_int, [C.c_void_p]),
     "sqair_elbo": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -135,6 +138,20 @@ def lib():
             raise ImportError("libsqair_hip.so ABI version mismatch")
         _lib = l
     return _lib
+
+
+def build_id():
+    """Short hash of the kernel sources libsqair_hip.so is built from (csrc/ + include/sqair_hip.h): profiles carry it so that a
+    number is only ever quoted next to the build it was measured on."""
+    import hashlib
+    hsh = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    files = sorted(f for f in os.listdir(src) if f.endswith((".hip", ".h", ".inc")))
+    for f in files:
+        hsh.update(f.encode())
+        hsh.update(open(os.path.join(src, f), "rb").read())
+    hsh.update(open(os.path.join(os.path.dirname(_HERE), "include", "sqair_hip.h"), "rb").read())
+    return hsh.hexdigest()[:16]
 
 
 def check(handle, rc, what):

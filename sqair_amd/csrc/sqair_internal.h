@@ -50,6 +50,8 @@ struct SqairHandle {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int graph_nodes = 0;
+  bool only_linear = false; // sqair_profile_linear_graph: emit the dense launches only
+  int emit_extra = 0;
   int debug_reps = 0;       // sqair_debug_linear_time
   float debug_us = 0.0f;
   bool clear_each_pass = true;  // zero the caller's workspace at the start of every pass (sqair_set_workspace_clearing)

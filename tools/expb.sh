@@ -1,6 +1,2 @@
 cd /root/repo
-B="python bench.py --no-cpu-baseline --train-steps 20 --steps 40 --warmup 5"
-for i in 1 2; do
-$B 2>/dev/null | tail -1 | python -c "import json,sys; j=json.load(sys.stdin); print('ms_per_step', j['ms_per_step'], 'train', j['train']['ms_per_step'])"
-done
-python -m pytest tests/test_hip_backward.py -m gpu -q -x 2>&1 | grep "passed\|failed" | head -3
+for m in 0 1 2 3 5 6 7; do SQAIR_EMIT_EXTRA=$m python bench.py --no-cpu-baseline --train-steps 0 --steps 10 --warmup 2 2>/dev/null | tail -1 | python -c "import json,sys; j=json.load(sys.stdin); r=j['roofline']; print('extra=$m graph_ms', r['dense_only_graph_ms'], 'nodes', r['avg_launch_us'] and round(r['dense_only_graph_ms']*1e3/r['avg_launch_us']))"; done
