@@ -1,2 +1,2 @@
 cd /root/repo
-for m in 0 1 2 3 5 6 7; do SQAIR_EMIT_EXTRA=$m python bench.py --no-cpu-baseline --train-steps 0 --steps 10 --warmup 2 2>/dev/null | tail -1 | python -c "import json,sys; j=json.load(sys.stdin); r=j['roofline']; print('extra=$m graph_ms', r['dense_only_graph_ms'], 'nodes', r['avg_launch_us'] and round(r['dense_only_graph_ms']*1e3/r['avg_launch_us']))"; done
+timeout 400 python tools/train_demo.py 6000 1e-5 2000000 3 700 disc_step_bias=5 n_steps_per_image=3 > gpurun_out/r02_train_curve_disc_step_bias5.json 2> /tmp/err.log; tail -4 /tmp/err.log | cut -c1-300

@@ -1,7 +1,8 @@
 """End-to-end training run on synthetic moving glyphs with the reference's driver semantics (scripts/experiment.py:126-185):
 minibatches drawn with replacement (data.py:203-216), RMSProp(momentum .9) with the piecewise-constant learning rate,
 VIMCO target, K = 5 particles; logs the training ELBO per frame and the validation ELBO on held-out sequences.
-    python tools/train_demo.py [steps] [lr] [train_itr] [seq_len] [stage_itr] > profiles/r01_train_curve.json
+    python tools/train_demo.py [steps] [lr] [train_itr] [seq_len] [stage_itr] [flag=value ...] > profiles/rNN_train_curve.json
+(trailing flag=value pairs override any of the reference's flags, e.g. disc_step_bias=5 n_steps_per_image=3 opt=adam)
 The reference's own recipe (scripts/train_multi_mnist.sh) is seq_len 3, stage_itr 100000 (sequence-length curriculum), 1 M iterations.
 """
 import json
@@ -19,13 +20,16 @@ from sqair_amd.model import Model, SqairCore
 from sqair_amd.params import init_params
 from sqair_amd.train import Trainer
 
+over = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a)
+sys.argv = [a for a in sys.argv if "=" not in a]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 lr = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-5
 T, B, K, N, hw = 10, 32, 5, 4, (50, 50)
 train_itr = int(sys.argv[3]) if len(sys.argv) > 3 else steps   # the piecewise-constant schedule is relative to train_itr
 seq_len = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 stage_itr = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-F = make_flags(k_particles=K, n_steps_per_image=N, learning_rate=lr, train_itr=train_itr, seq_len=seq_len, stage_itr=stage_itr)
+N = int(over.get("n_steps_per_image", N))
+F = make_flags(**dict(dict(k_particles=K, n_steps_per_image=N, learning_rate=lr, train_itr=train_itr, seq_len=seq_len, stage_itr=stage_itr), **over))
 train = make_sequences(2048, T=T, canvas=hw, n_objects=(0, 2), seed=1)
 valid = make_sequences(256, T=T, canvas=hw, n_objects=(0, 2), seed=2)
 feed = MinibatchFeed(dict(imgs=to_float(train["imgs"]), nums=train["nums"], coords=train["coords"]), B, shuffle=True, seed=0,
@@ -73,7 +77,7 @@ for it in range(steps + 1):
         with core.on_stream():
             e = float(core.scalars[1]) / core.T
         run = e if it == 0 else 0.9 * run + 0.1 * e
-print(json.dumps(dict(config=dict(T=T, B=B, K=K, N=N, hw=hw, steps=steps, train_itr=train_itr, learning_rate=lr, opt="rmsprop(momentum .9)",
+print(json.dumps(dict(config=dict(T=T, B=B, K=K, N=N, hw=hw, steps=steps, train_itr=train_itr, learning_rate=lr, opt=str(F.opt), flag_overrides=over,
                                   schedule=F.schedule, data="2048 synthetic 2-glyph sequences, 256 held out",
                                   true_objects_per_frame=float(valid["nums"].sum(-1).mean())),
                       upper_bound_per_frame=2500 * (-np.log(0.3) - 0.5 * np.log(2 * np.pi)), curve=log)))
