@@ -722,6 +722,31 @@ int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipSt
   return rc;
 }
 
+// The tail of slot k fused into slot k + 1's VanillaRNN layer (k_rnn_tail, sqair_glue.hip): possible when the layer is exactly
+// [z-record (56 -> 4 chunks) | hidden state (nh)] -> nh with nh in {128, 256}.
+static bool can_fuse_tail(const SqairHandle* h, LayerId id) {
+  const PackedLayer& L = h->layers[id];
+  const int nh = h->cfg.n_hidden;
+  return h->cfg.rnn_cell == RNN_VANILLA && (nh == 128 || nh == 256) && L.seg_width.size() == 2 && L.seg_width[0] == rec::ZW &&
+         L.seg_width[1] == nh && L.kc == 4 + nh / 16 && L.nt == nh / 16 && L.N == nh && getenv("SQAIR_NO_TAIL_FUSION") == nullptr;
+}
+static int run_rnn_tail(SqairHandle* h, const TailArgs& ta, Dims d, LayerId id, const float* hid, int hid_ld, const float* add, int add_ld,
+                        float* out, int out_ld, const float* packed, hipStream_t s) {
+  const PackedLayer& L = h->layers[id];
+  const PackedLayout pl = packed_layout(h);
+  if (h->only_linear && (h->emit_extra & 4)) return 0;
+  unsigned long long* pts = nullptr;
+  if (h->prof && h->prof_n < PROF_MAX) {
+    h->prof_flops += 2.0 * (double)d.R * (double)(rec::ZW + d.nh) * (double)L.N;
+    h->prof_layer.push_back((int)id);
+    h->prof_m.push_back(d.R);
+    pts = h->prof_ts + h->prof_n++;
+  }
+  const int rc = sq_launch_rnn_tail(ta, d, hid, hid_ld, packed + pl.w + L.w_off, packed + pl.b + L.b_off, add, add_ld, out, out_ld, L.N, s, pts);
+  if (rc != 0) sq_set_error(h, "internal: k_rnn_tail launch rejected");
+  return rc;
+}
+
 // three dependent slot layers: one launch each (a single multi-layer launch with in-launch hand-offs was built and
 // measured slower twice in round 1 -- tools/xcd_team.hip, DESIGN.md section 8 -- and left the library)
 #define RUN_CHAIN3(l0, id0, l1, id1, l2, id2, M) \
@@ -784,6 +809,8 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     Lin p; p.seg(w.ienc_b, nh, nh).out(w.pre_disc, rw); RUN(p, L_PREDISC, T * B);
   }
 
+  const bool fuse_prop = can_fuse_tail(h, L_PROP_RNN), fuse_disc = can_fuse_tail(h, L_DISC_RNN);
+  TailArgs pending_tail; memset(&pending_tail, 0, sizeof(pending_tail));
   for (int t = 0; (parts & 2) && t < T; ++t) {
     const int pp = t & 1, pn = pp ^ 1;
     const float* img = obs + (size_t)t * B * P_;
@@ -890,6 +917,9 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
           Lin b2; b2.seg(w.grh, nh, nh).add(w.gxh, nh, nh).out(r_k, rl).gru2(hp, hpl, g3, g3l, nh);
           b2.a.o1 = g3 + 2 * nh; b2.a.o1_ld = g3l;
           RUN(b2, L_PROP_RNN2, R);
+        } else if (k > 0 && fuse_prop) {  // the previous slot's tail rides in this launch
+          const int rc = run_rnn_tail(h, pending_tail, d, L_PROP_RNN, w.rslot(t, 0, k - 1), rl, pre_k, pre_rld, r_k, rl, packed, s);
+          if (rc != 0) return rc;
         } else {
           a.add(pre_k, pre_rld, nh).out(r_k, rl).act(ACT_TANH);
           RUN(a, L_PROP_RNN, R);
@@ -948,7 +978,8 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         ta.wp = packed + pl.w + h->layers[L_PROP_S1].w_off; ta.flat = flat;
         ta.w2_off = po.prop_steps_l1_w; ta.b2_off = po.prop_steps_l1_b;
         if (train) { ta.s1h_out = w.slot(w.s1h, S1_LD, t, 0, k); ta.s1h_ld = w.sld(S1_LD); }
-        emit_tail(h, ta, d, s);
+        if (fuse_prop && k + 1 < N) pending_tail = ta;  // computed inside the next slot's RNN launch
+        else emit_tail(h, ta, d, s);
       }
     }
     // ---- generation modes: prior samples of the propagated objects (sqair_modules.py:294-302) ----
@@ -1001,6 +1032,9 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
           Lin b2; b2.seg(w.grh, nh, nh).add(w.gxh, nh, nh).out(r_j, rl).gru2(hp, hpl, g3, g3l, nh);
           b2.a.o1 = g3 + 2 * nh; b2.a.o1_ld = g3l;
           RUN(b2, L_DISC_RNN2, R);
+        } else if (j > 0 && fuse_disc) {
+          const int rc = run_rnn_tail(h, pending_tail, d, L_DISC_RNN, w.rslot(t, 1, j - 1), rl, w.pre_d, nh, r_j, rl, packed, s);
+          if (rc != 0) return rc;
         } else {
           a.add(w.pre_d, nh, nh).out(r_j, rl).act(ACT_TANH);
           RUN(a, L_DISC_RNN, R);
@@ -1026,7 +1060,8 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         ta.wp = packed + pl.w + h->layers[L_DISC_S1].w_off; ta.flat = flat;
         ta.w2_off = po.disc_steps_l1_w; ta.b2_off = po.disc_steps_l1_b;
         if (train) { ta.s1h_out = w.slot(w.s1h, S1_LD, t, 1, j); ta.s1h_ld = w.sld(S1_LD); }
-        emit_tail(h, ta, d, s);
+        if (fuse_disc && j + 1 < N) pending_tail = ta;
+        else emit_tail(h, ta, d, s);
       }
     }
     if (do_generate && !h->only_linear) sq_launch_generate_disc(ga, po, d, s);  // sqair_modules.py:157-170

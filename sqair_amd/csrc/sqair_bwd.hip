@@ -12,6 +12,7 @@
 //                         [in, out] layout straight into the flat gradient buffer
 #include "sqair_glue.h"
 #include "sqair_bwd.h"
+#include <stdlib.h>
 
 typedef float f32x4_b __attribute__((ext_vector_type(4)));
 
@@ -479,7 +480,8 @@ __global__ __launch_bounds__(256) void k_wgrad2(const float* __restrict__ A, int
 int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim,
                         hipStream_t s, const int* rowmap, const float* alpha_ptr, float* db_a, float* db_b) {
   const int kt = (Kdim + 31) / 32, nt = (Ndim + 31) / 32;
-  int zc = 2048 / (kt * nt);
+  static const int wg_target = getenv("SQAIR_WGRAD_WGS") ? atoi(getenv("SQAIR_WGRAD_WGS")) : 2048;  // measurement knob
+  int zc = wg_target / (kt * nt);
   const int max_z = (M + 63) / 64;
   if (zc > max_z) zc = max_z;
   if (zc < 1) zc = 1;

@@ -87,6 +87,8 @@ struct TailArgs {
   float* s1h_out; int s1h_ld;       // optional (training): the hidden activations elu(.) [R, nh/2]
 };
 int sq_launch_slot_tail(const TailArgs& a, Dims d, hipStream_t s);
+int sq_launch_rnn_tail(const TailArgs& ta, Dims d, const float* hid, int hid_ld, const float* wp, const float* bias, const float* add,
+                       int add_ld, float* out, int out_ld, int n_out, hipStream_t s, unsigned long long* prof_ts);
 int sq_launch_latent_sum(const float* f, const float* rec_p, float* c, Dims d, hipStream_t s);
 
 struct LogprobArgs {

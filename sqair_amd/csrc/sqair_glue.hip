@@ -110,12 +110,13 @@ int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims d) {
-  constexpr int ZLD = 68;
-  __shared__ __attribute__((aligned(16))) float zt[16 * ZLD];
-  __shared__ float rs[4][16];
+constexpr int ZLD = 68;
+// Body shared by k_slot_tail (one workgroup per 16 rows, results to memory) and k_rnn_tail (every workgroup of the NEXT slot's RNN
+// layer re-derives the tail of its 16 rows and keeps the z-record in LDS as the layer's first A segment).  FULL_Z: also place
+// where / presence / logit into the LDS tile `zt` (the what columns are always there); STORE: write the results to memory.
+template <bool FULL_Z>
+__device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, const int row0, const bool STORE, float* zt, float (*rs)[16]) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
-  const int row0 = blockIdx.x * 16;
   const int nw = d.nw, nsp = d.nh / 2;
   const int n_tiles = nsp / 16;  // 8 for nh = 256; wave w owns tiles w, w + 4, ...
   // ---- requests that do not depend on the sample: weights, partial pre-activations, w2, Bernoulli operands
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims 
       }
       const float what = loc + sc * v_eps[q];
       zt[rr * ZLD + rec::WHAT + c] = what;
-      if (row0 + rr < d.R) {
+      if (STORE && row0 + rr < d.R) {
         float* rn = a.rec_new + ((size_t)(row0 + rr) * d.N + a.slot) * rec::W;
         rn[rec::WHAT + c] = what;
         rn[rec::WHAT_LOC + c] = loc;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims 
       if (wave + 4 * t < n_tiles) {
         const float hv = sq_elu(acc[t][i] + sp[t][i]);
         v += hv * w2v[t];
-        if (a.s1h_out != nullptr && row0 + 4 * kq + i < d.R)
+        if (STORE && a.s1h_out != nullptr && row0 + 4 * kq + i < d.R)
           a.s1h_out[(size_t)(row0 + 4 * kq + i) * a.s1h_ld + (wave + 4 * t) * 16 + (lane & 15)] = hv;
       }
     v += __shfl_xor(v, 1, 64);
@@ -232,18 +233,111 @@ __global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims 
     for (int i = 0; i < 4; ++i) rs[wave][4 * kq + i] = part[i];
   }
   __syncthreads();
-  if (tid < 16 && row0 + tid < d.R) {
+  if (tid < 16) {
     const float raw = rs[0][tid] + rs[1][tid] + rs[2][tid] + rs[3][tid] + b2;
     const float logit = prev * raw + (prev - 1.0f) * 88.0f;
     const float prob = sq_sigmoid(logit);
-    float* rn = a.rec_new + ((size_t)(row0 + tid) * d.N + a.slot) * rec::W;
-    rn[rec::PRES] = (u < prob ? 1.0f : 0.0f) * prev;
-    rn[rec::LOGIT] = logit;
-    rn[rec::PROB] = prob;
+    const float pres = (u < prob ? 1.0f : 0.0f) * prev;
+    if (STORE && row0 + tid < d.R) {
+      float* rn = a.rec_new + ((size_t)(row0 + tid) * d.N + a.slot) * rec::W;
+      rn[rec::PRES] = pres;
+      rn[rec::LOGIT] = logit;
+      rn[rec::PROB] = prob;
+    }
+    if (FULL_Z) {  // (after the hidden-layer MFMAs have read the tile: they want zeros outside the what columns)
+      zt[tid * ZLD + rec::PRES] = pres;
+      zt[tid * ZLD + rec::LOGIT] = logit;
+      const float* wh = a.rec_new + ((size_t)pr * d.N + a.slot) * rec::W + rec::WHERE;  // written by this slot's crop launch
+#pragma unroll
+      for (int q = 0; q < 4; ++q) zt[tid * ZLD + rec::WHERE + q] = wh[q];
+    }
   }
 }
+
+__global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims d) {
+  __shared__ __attribute__((aligned(16))) float zt[16 * ZLD];
+  __shared__ float rs[4][16];
+  tail_body<false>(a, d, blockIdx.x * 16, true, zt, rs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Slot tail fused INTO the next slot's RNN layer (VanillaRNN slot cell, sqair/core.py:187-189, :304-305): the layer's first A
+// segment is the z-record of the slot that has just been finished, and the tail that completes it (what sample, steps-predictor
+// hidden layer, presence) is 16 rows of element-wise work plus a 16 x 64 x 128 MFMA product.  Every workgroup of the layer (one
+// 16 x 16 output tile; 16 of them share a row tile) re-derives the tail of its rows and keeps the z-record in LDS, the column-tile-0
+// workgroups write it to memory for the later consumers.  One dependent launch (~5.6 us as a graph node) less per slot, paid with
+// ~1 us of redundant work inside the layer.  The RNN part is k_linear's arithmetic (4 waves split the K chunks g = wave + 4 i in
+// order, two accumulators, LDS reduce), so the layer's result does not depend on whether the tail was fused.
+// ------------------------------------------------------------------------------------------------
+template <int NH>  // hidden-state chunks per wave = nh / 64
+__global__ __launch_bounds__(256) void k_rnn_tail(const TailArgs ta, const Dims d, const float* __restrict__ hid, const int hid_ld,
+                                                  const float* __restrict__ wp0, const float* __restrict__ bias,
+                                                  const float* __restrict__ add, const int add_ld, float* __restrict__ out,
+                                                  const int out_ld, const int n_out, unsigned long long* __restrict__ prof_ts) {
+  __shared__ __attribute__((aligned(16))) float zt[16 * ZLD];
+  __shared__ float rs[4][16];
+  __shared__ float red[4 * 256];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
+  const int tile_n = blockIdx.x, row0 = blockIdx.y * 16;
+  constexpr int KC = 4 + 4 * NH;
+  unsigned long long t_start = 0;
+  if (prof_ts != nullptr && tid == 0) t_start = wall_clock64();
+  // operands of the layer that do not depend on the tail: weights of my chunks, the hidden-state segment, the epilogue operands
+  const f32x4_t* __restrict__ wp = reinterpret_cast<const f32x4_t*>(wp0) + ((size_t)tile_n * KC) * 64 + lane;
+  const float* hrow = hid + (size_t)min(row0 + l15, d.R - 1) * hid_ld;
+  f32x4_t bz = wp[(size_t)wave * 64], bh[NH], ah[NH];
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int g = wave + 4 * (i + 1);
+    bh[i] = wp[(size_t)g * 64];
+    ah[i] = *reinterpret_cast<const f32x4_t*>(hrow + (g - 4) * 16 + kq * 4);
+  }
+  const int m = row0 + (tid >> 4), n = tile_n * 16 + (tid & 15);
+  const int mc = min(m, d.R - 1), nc = min(n, n_out - 1);
+  const float p_bias = bias[nc], p_add = add[(size_t)mc * add_ld + nc];
+  tail_body<true>(ta, d, row0, tile_n == 0, zt, rs);
+  __syncthreads();
+  const f32x4_t az = *reinterpret_cast<const f32x4_t*>(&zt[l15 * ZLD + 16 * wave + 4 * kq]);
+  f32x4_t acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(az.x, bz.x, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(az.y, bz.y, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(az.z, bz.z, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(az.w, bz.w, acc1, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i].x, bh[i].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i].y, bh[i].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i].z, bh[i].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i].w, bh[i].w, acc1, 0, 0, 0);
+  }
+  float* r = red + wave * 256;
+  r[(4 * kq + 0) * 16 + l15] = acc0.x + acc1.x;
+  r[(4 * kq + 1) * 16 + l15] = acc0.y + acc1.y;
+  r[(4 * kq + 2) * 16 + l15] = acc0.z + acc1.z;
+  r[(4 * kq + 3) * 16 + l15] = acc0.w + acc1.w;
+  __syncthreads();
+  if (m < d.R && n < n_out) out[(size_t)m * out_ld + n] = sq_tanh(red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + p_bias + p_add);
+  if (prof_ts != nullptr) {
+    __syncthreads();
+    if (tid == 0) {
+      atomicMin(prof_ts, t_start);
+      atomicMax(prof_ts + 4096, wall_clock64());
+    }
+  }
+}
+
 int sq_launch_slot_tail(const TailArgs& a, Dims d, hipStream_t s) {
   hipLaunchKernelGGL(k_slot_tail, dim3((d.R + 15) / 16), dim3(256), 0, s, a, d);
+  return 0;
+}
+// tail of slot `ta.slot` + the VanillaRNN layer of the next slot: out = tanh([z-record | hid] W + bias + add); wp / bias point at
+// the layer's packed weights (K chunks: 4 of the z-record, nh / 16 of the hidden state) and packed bias
+int sq_launch_rnn_tail(const TailArgs& ta, Dims d, const float* hid, int hid_ld, const float* wp, const float* bias, const float* add,
+                       int add_ld, float* out, int out_ld, int n_out, hipStream_t s, unsigned long long* prof_ts) {
+  const dim3 g((n_out + 15) / 16, (d.R + 15) / 16);
+  if (d.nh == 256) hipLaunchKernelGGL(k_rnn_tail<4>, g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
+  else if (d.nh == 128) hipLaunchKernelGGL(k_rnn_tail<2>, g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
+  else return -1;
   return 0;
 }
 

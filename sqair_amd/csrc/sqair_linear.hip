@@ -351,6 +351,155 @@ __global__ __launch_bounds__(256) void k_linear_mt(const LinArgs a, const int kc
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LDS-tiled throughput kernel for launches with thousands of rows (the decoder's T B' N rows, every layer from ~128 sequences
+// per GPU up).  Workgroup tile 128 x 32 TN, 2 x 2 waves, wave tile 64 x 16 TN (4 x TN MFMA tiles: an A fragment feeds TN
+// MFMAs, a B fragment 4).  The 128 x 32 activation block of a K step is fetched with 8 lanes on each row's 128 contiguous
+// bytes (full cache lines; the MFMA operand order would put 16 different rows into consecutive lanes), staged through a
+// padded LDS tile (register-staged double buffer: the global loads of step s + 1 are in flight while step s computes) and
+// read back as ds_read_b128 fragments; the weight fragments come straight from the packed buffer (already in operand order,
+// 1 KB contiguous per wave).  One accumulator per MFMA tile, chunks in order: results differ from the 16x16-tile kernels in
+// the last bits (different summation order), never between two launches of this kernel.
+// ---------------------------------------------------------------------------------------------------
+template <int TN>
+__global__ __launch_bounds__(256) void k_linear_lds(const LinArgs a, const int kc_total, const int n_tiles,
+                                                    unsigned long long* __restrict__ prof_ts) {
+  constexpr int LDA = 36;  // 32 floats of a K step + 4 of padding: the 16 rows of a fragment read land on distinct 16-byte slots
+  __shared__ __attribute__((aligned(16))) float lds[2 * 128 * LDA];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int row0 = blockIdx.y * 128;
+  const int tile_n0 = (blockIdx.x * 2 + wave_n) * TN;
+  unsigned long long t_start = 0;
+  if (prof_ts != nullptr && tid == 0) t_start = wall_clock64();
+  // segment table in named locals (see k_linear_mt)
+  const float* sp0 = a.seg[0].p; const float* sp1 = a.seg[1].p; const float* sp2 = a.seg[2].p; const float* sp3 = a.seg[3].p;
+  const int sl0 = a.seg[0].ld, sl1 = a.seg[1].ld, sl2 = a.seg[2].ld, sl3 = a.seg[3].ld;
+  const unsigned sm0 = a.seg[0].rmul, sm1 = a.seg[1].rmul, sm2 = a.seg[2].rmul, sm3 = a.seg[3].rmul;
+  const int w0 = a.seg[0].width, w1 = a.seg[1].width, w2 = a.seg[2].width, w3 = a.seg[3].width;
+  const int c1 = (w0 + 15) >> 4;
+  const int c2 = c1 + (a.nseg > 1 ? (w1 + 15) >> 4 : 0);
+  const int c3 = c2 + (a.nseg > 2 ? (w2 + 15) >> 4 : 0);
+  const int cum1 = a.nseg > 1 ? c1 : 0x7fffffff, cum2 = a.nseg > 2 ? c2 : 0x7fffffff, cum3 = a.nseg > 3 ? c3 : 0x7fffffff;
+  const int lim0 = ((w0 + 3) & ~3) - 4, lim1 = ((w1 + 3) & ~3) - 4, lim2 = ((w2 + 3) & ~3) - 4, lim3 = ((w3 + 3) & ~3) - 4;
+  // staging map: thread -> (row tid >> 3 of each 32-row pass, 16 bytes at float (tid & 7) * 4 of the 32-wide K step)
+  const int srow = tid >> 3, sk = (tid & 7) * 4;
+  const int sch = sk >> 4, skk = sk & 15;  // which of the step's two chunks, offset inside it
+  int arow[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) arow[p] = min(row0 + srow + 32 * p, a.M - 1);
+  f32x4 ra[4];
+#define SQ_LDS_STAGE(STEP)                                                                                   \
+  {                                                                                                           \
+    const int gq = 2 * (STEP) + sch;                                                                          \
+    const int g = gq < kc_total ? gq : 0; /* beyond the end: any finite data (the weights there are zero) */  \
+    const bool s1 = g >= cum1, s2 = g >= cum2, s3 = g >= cum3;                                                \
+    const float* sp = s3 ? sp3 : (s2 ? sp2 : (s1 ? sp1 : sp0));                                               \
+    const int sl = s3 ? sl3 : (s2 ? sl2 : (s1 ? sl1 : sl0));                                                  \
+    const unsigned sm = s3 ? sm3 : (s2 ? sm2 : (s1 ? sm1 : sm0));                                             \
+    const int cb = s3 ? cum3 : (s2 ? cum2 : (s1 ? cum1 : 0));                                                 \
+    const int lim = s3 ? lim3 : (s2 ? lim2 : (s1 ? lim1 : lim0));                                             \
+    const int kk = min((g - cb) * 16 + skk, lim);                                                             \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                           \
+      const int r = sm ? (int)__umulhi((unsigned)arow[p], sm) : arow[p];                                      \
+      ra[p] = *reinterpret_cast<const f32x4*>(sp + (size_t)r * sl + kk);                                      \
+    }                                                                                                         \
+  }
+#define SQ_LDS_WRITE(BUF)                                                                                     \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                               \
+    *reinterpret_cast<f32x4*>(&lds[(BUF) * 128 * LDA + (srow + 32 * p) * LDA + sk]) = ra[p];
+
+  f32x4 acc[4][TN];
+  const f32x4* wp[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    wp[t] = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)min(tile_n0 + t, n_tiles - 1) * kc_total) * 64 + lane;
+  }
+  const f32x4* __restrict__ wz = reinterpret_cast<const f32x4*>(a.wzero) + lane;
+  const int steps = (kc_total + 1) >> 1;
+  SQ_LDS_STAGE(0)
+  SQ_LDS_WRITE(0)
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < steps) SQ_LDS_STAGE(s + 1)
+    f32x4 bv[2][TN];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int g = 2 * s + c;
+#pragma unroll
+      for (int t = 0; t < TN; ++t) bv[c][t] = *(g < kc_total ? wp[t] + (size_t)g * 64 : wz);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x4 af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = *reinterpret_cast<const f32x4*>(&lds[buf * 128 * LDA + (wave_m * 64 + i * 16 + l15) * LDA + c * 16 + kq * 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bv[c][t].x, acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bv[c][t].y, acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bv[c][t].z, acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bv[c][t].w, acc[i][t], 0, 0, 0);
+        }
+      }
+    }
+    if (s + 1 < steps) {
+      SQ_LDS_WRITE(buf ^ 1)
+    }
+    __syncthreads();
+  }
+#undef SQ_LDS_STAGE
+#undef SQ_LDS_WRITE
+  // epilogue: rolled loop over the lane's 4 * TN * 4 outputs, sums parked in LDS (two rounds of two row tiles; see k_linear_mt)
+  float* epi = lds + wave * (2 * TN * 4 * 64);   // 4 waves x 2 TN x 4 x 64 floats <= 2 x 128 x 36
+  float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : a.bias);
+  p_scale = a.scale_ptr != nullptr ? p_scale : 1.0f;
+  const bool g2 = a.epi == EPI_GRU2;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const f32x4 v = acc[half * 2 + ii][t];
+        epi[((ii * TN + t) * 4 + 0) * 64 + lane] = v.x;
+        epi[((ii * TN + t) * 4 + 1) * 64 + lane] = v.y;
+        epi[((ii * TN + t) * 4 + 2) * 64 + lane] = v.z;
+        epi[((ii * TN + t) * 4 + 3) * 64 + lane] = v.w;
+      }
+    }
+#pragma unroll 1
+    for (int e = 0; e < 2 * TN * 4; ++e) {
+      const int q = e & 3, t = (e >> 2) % TN, ii = (e >> 2) / TN;
+      const int n = (tile_n0 + t) * 16 + l15;
+      const int m = row0 + wave_m * 64 + (half * 2 + ii) * 16 + 4 * kq + q;
+      if (tile_n0 + t < n_tiles && n < a.N && m < a.M) {
+        const bool use_add = a.add != nullptr && n < a.add_n;
+        const bool g1 = a.epi == EPI_GRU1 && n >= a.nh && n < 2 * a.nh;
+        float p_add = 0.0f, p_e0 = 0.0f, p_e1 = 0.0f;
+        if (use_add) p_add = a.add[(size_t)(a.add_rmul ? (int)__umulhi((unsigned)m, a.add_rmul) : m) * a.add_ld + n];
+        if (g1) p_e0 = a.e0[(size_t)m * a.e0_ld + (n - a.nh)];
+        if (g2) { p_e0 = a.e0[(size_t)m * a.e0_ld + n]; p_e1 = a.e1[(size_t)m * a.e1_ld + n]; }
+        x_epilogue(a, m, n, epi[e * 64 + lane] + a.bias[n] + p_add, p_e0, p_e1, p_scale);
+      }
+    }
+  }
+  if (prof_ts != nullptr) {
+    __syncthreads();
+    if (tid == 0) {
+      atomicMin(prof_ts, t_start);
+      atomicMax(prof_ts + 4096, wall_clock64());
+    }
+  }
+}
+
 // Tile shape of the throughput variants, from measurements of the layer shapes of the pass (tools/time_linear.py, MI355X):
 // rows x slabs per wave and whether the A fragment is loaded row-contiguously (COAL).  SQAIR_MT="MT,NT[,COAL]" overrides.
 struct MtShape { int mt, nt, coal; };
@@ -422,6 +571,13 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
     if (L.kc <= 4) {  // K <= 64: one block of loads, nothing to pipeline
       const dim3 grid_r(L.nt, (mt + 3) / 4);
       hipLaunchKernelGGL(k_linear_rows<4>, grid_r, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+      return 0;
+    }
+    // the LDS-tiled kernel pays once its 128 x 64 workgroup tiles fill the chip twice over (measured, tools/time_linear.py:
+    // 51200 x 256 x 256 118 -> 106 us, 5120 x 362 x 1152 80 -> 67 us; below that the macro-tile kernel's smaller tiles win)
+    static const int lds_wgs = getenv("SQAIR_LDS_WGS") ? atoi(getenv("SQAIR_LDS_WGS")) : 512;  // measurement knob
+    if (((a.M + 127) / 128) * ((L.nt + 3) / 4) >= lds_wgs) {
+      hipLaunchKernelGGL((k_linear_lds<2>), dim3((L.nt + 3) / 4, (a.M + 127) / 128), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
       return 0;
     }
     const MtShape sh = pick_mt_shape(a.M, L.nt, L.kc);

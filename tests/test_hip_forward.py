@@ -314,3 +314,39 @@ def test_generation_modes_vs_live_oracle(generate_after, prior):
         worst = max(worst, err)
         assert err <= 2e-5, (k, err)
     assert abs(float(m.elbo_iwae) - float(ref.elbo_iwae)) <= 1e-4 * abs(float(ref.elbo_iwae))
+
+
+@pytest.mark.parametrize("K,N,T,B,n_units", [(5, 4, 3, 32, 8), (3, 3, 2, 7, 4)])
+def test_tail_fused_into_the_next_rnn_layer_is_bitwise_identical(K, N, T, B, n_units):
+    """k_rnn_tail (the tail of slot k computed inside slot k + 1's VanillaRNN launch) against the launch-per-op sequence
+    (SQAIR_NO_TAIL_FUSION=1, read when the pass is issued): every output bit for bit, inference and training-mode forward."""
+    hw = (50, 50)
+    F = make_flags(k_particles=K, n_steps_per_image=N, n_units=n_units)
+    d = make_sequences(B, T=T, canvas=hw, n_objects=(0, 2), seed=5)
+    obs = to_float(d["imgs"])
+    P = params32(F, hw, 3, 0.05, obs.mean((0, 1)))
+    noise = draw_noise(np.random.default_rng(1), T, B * K, N, 4 + int(F.n_what) + 1)
+
+    def run(train):
+        core = SqairCore(F, hw)
+        core.set_params(P)
+        Model(obs, None, core, K, presence=d["nums"])
+        with core.on_stream():
+            core.noise.copy_(torch.as_tensor(noise).reshape(core.noise.shape))
+            core.forward(train=train)
+        core.stream.synchronize()
+        return {k: v.cpu().numpy().copy() for k, v in core.out.items()}, core.log_weights.cpu().numpy().copy()
+
+    os.environ.pop("SQAIR_NO_TAIL_FUSION", None)
+    fused, lw_f = run(False)
+    fused_t, lw_ft = run(True)
+    os.environ["SQAIR_NO_TAIL_FUSION"] = "1"
+    try:
+        plain, lw_p = run(False)
+    finally:
+        os.environ.pop("SQAIR_NO_TAIL_FUSION", None)
+    assert np.array_equal(lw_f, lw_p) and np.array_equal(lw_f, lw_ft)
+    for k in plain:
+        assert np.array_equal(fused[k], plain[k]), k
+        assert np.array_equal(fused_t[k], plain[k]), k
+    assert float(plain["presence"].sum()) > 0

@@ -1,2 +1,6 @@
 cd /root/repo
-timeout 400 python tools/train_demo.py 6000 1e-5 2000000 3 700 disc_step_bias=5 n_steps_per_image=3 > gpurun_out/r02_train_curve_disc_step_bias5.json 2> /tmp/err.log; tail -4 /tmp/err.log | cut -c1-300
+B="python bench.py --no-cpu-baseline --train-steps 20 --steps 60 --warmup 5"
+for i in 1 2; do
+$B 2>/dev/null | tail -1 | python -c "import json,sys; j=json.load(sys.stdin); print('ms_per_step', j['ms_per_step'], 'train', j['train']['ms_per_step'], 'nodes', j['config']['graph_nodes'])"
+done
+python -m pytest tests -m gpu -q 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | grep "BAD\|^E \|passed\|failed\|FAILED" | cut -c1-200 | head -20
