@@ -23,7 +23,7 @@ __device__ __forceinline__ float dx_dact(float g, float o, int act) {
   }
 }
 
-template <int NCH>
+template <int NCH, int GRU = 0>
 __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpre0, const float* __restrict__ wp0, const int ld0,
                                                    const int width0, const int M0, const int kc_total,
                                                    const float* __restrict__ wzero0, const DxArgs a) {
@@ -73,6 +73,14 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
   const float* ps = (live && rg.saved != nullptr) ? rg.saved + (size_t)mc * rg.saved_ld + c : dummy;
   const float p_add = *pa, p_saved = *ps;
   const float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : dummy);
+  float q_g0 = 0.0f, q_g1 = 0.0f, q_h = 0.0f, q_dh = 0.0f;
+  if (GRU != 0) {  // gate tapes of the GRU adjoint (columns 0 .. nh - 1 of range 0)
+    const int cg = min(c, a.gru.nh - 1);
+    q_g0 = a.gru.g0[(size_t)mc * a.gru.g0_ld + cg];
+    if (GRU == 1) q_g1 = a.gru.g1[(size_t)mc * a.gru.g1_ld + cg];
+    q_h = a.gru.hprev[(size_t)mc * a.gru.h_ld + cg];
+    if (GRU == 2 || a.gru.acc_dh) q_dh = a.gru.d_h[(size_t)mc * a.gru.dh_ld + cg];
+  }
   __builtin_amdgcn_sched_barrier(0);
   SQ_DX_MFMA()
   if (NCH == 9) {  // only the deepest instantiation loops (K > 576)
@@ -96,8 +104,25 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
     if (a.scale_ptr != nullptr) v *= p_scale;
     if (rg.add != nullptr) v += p_add;
     if (rg.saved != nullptr) v = dx_dact(v, p_saved, c < rg.act_split ? rg.act_a : rg.act_b);
-    rg.dst[(size_t)m * rg.dst_ld + c] = v;
-    if (rg.dst2 != nullptr) rg.dst2[(size_t)m * rg.dst2_ld + c] = v;
+    if (GRU == 1) {
+      const int nh = a.gru.nh;
+      const float dz = v * (q_g1 - q_h) * q_g0 * (1.0f - q_g0), dc = v * q_g0 * (1.0f - q_g1 * q_g1);
+      a.gru.dpre1[(size_t)m * a.gru.dp_ld + c] = dz;
+      a.gru.dpre1[(size_t)m * a.gru.dp_ld + 2 * nh + c] = dc;
+      if (a.gru.dup != nullptr) {
+        a.gru.dup[(size_t)m * a.gru.dup_ld + c] = dz;
+        if (a.gru.dup_h_off >= 0) a.gru.dup[(size_t)m * a.gru.dup_ld + a.gru.dup_h_off + c] = dc;
+      }
+      a.gru.d_h[(size_t)m * a.gru.dh_ld + c] = (a.gru.acc_dh ? q_dh : 0.0f) + v * (1.0f - q_g0);
+    } else if (GRU == 2) {
+      const float dr = v * q_h * q_g0 * (1.0f - q_g0);
+      a.gru.dpre1[(size_t)m * a.gru.dp_ld + a.gru.nh + c] = dr;
+      if (a.gru.dup != nullptr) a.gru.dup[(size_t)m * a.gru.dup_ld + c] = dr;
+      a.gru.d_h[(size_t)m * a.gru.dh_ld + c] = q_dh + v * q_g0;
+    } else {
+      rg.dst[(size_t)m * rg.dst_ld + c] = v;
+      if (rg.dst2 != nullptr) rg.dst2[(size_t)m * rg.dst2_ld + c] = v;
+    }
   }
 }
 
@@ -106,6 +131,13 @@ int sq_launch_linear_dx(const DxArgs& a, int kc, int nt, hipStream_t s) {
   const dim3 g(nt, (a.M + 15) / 16);
   if (g.x == 0 || g.y == 0) return 0;
   const int per_wave = (kc + 3) / 4;
+  if (a.gru.mode != 0) {  // GRU gate adjoints in the epilogue: one range [0, nh), K = nh or the what-head width (<= 16 chunks)
+    if (a.nranges != 1 || a.r[0].n0 != 0 || a.r[0].n1 != a.gru.nh || per_wave > 4 || a.r[0].saved != nullptr) return -6;
+#define SQ_DXG(G) hipLaunchKernelGGL((k_linear_dx<4, G>), g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a)
+    if (a.gru.mode == 1) SQ_DXG(1); else SQ_DXG(2);
+#undef SQ_DXG
+    return 0;
+  }
   switch (per_wave) {
     case 1: hipLaunchKernelGGL(k_linear_dx<1>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
     case 2: hipLaunchKernelGGL(k_linear_dx<2>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;

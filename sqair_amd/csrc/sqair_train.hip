@@ -80,6 +80,17 @@ struct Dx {
     return *this;
   }
   Dx& dup(float* p, int ld) { last().dst2 = p; last().dst2_ld = ld; return *this; }
+  // GRU gate adjoints in this launch's epilogue (DxGru): mode 1 = after the d h' GEMM, mode 2 = after the d(r h) GEMM
+  Dx& gru_a(const float* z, int z_ld, const float* hc, int hc_ld, const float* hprev, int h_ld, float* dpre1, int dp_ld, float* d_h,
+            int dh_ld, int acc_dh, int nh, float* dupp = nullptr, int dup_ld = 0, int dup_h_off = -1) {
+    a.gru = DxGru{1, z, z_ld, hc, hc_ld, hprev, h_ld, dpre1, dp_ld, d_h, dh_ld, acc_dh, dupp, dup_ld, dup_h_off, nh};
+    return *this;
+  }
+  Dx& gru_b(const float* r, int r_ld, const float* hprev, int h_ld, float* dpre1, int dp_ld, float* d_h, int dh_ld, int nh,
+            float* dupp = nullptr, int dup_ld = 0) {
+    a.gru = DxGru{2, r, r_ld, nullptr, 0, hprev, h_ld, dpre1, dp_ld, d_h, dh_ld, 1, dupp, dup_ld, -1, nh};
+    return *this;
+  }
 };
 
 struct BwdSpace {
@@ -430,6 +441,12 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         x.to(0, nh, d_gru1, g1l).add(b.d_temporal_p + (size_t)k * nh, N * nh)
             .dact(w.frame(w.temporal_p, (int64_t)M * nh, t) + (size_t)k * nh, N * nh, ACT_TANH).dup(d_pre_k + rw + nh + nsp, pre_rld);
         CK(rundx(L_PROP_HEADS, x, R));
+      } else if (c.time_cell == CELL_GRU) {  // d tau'_k and, in the same launch's epilogue, the gate adjoints that consume it
+        Dx x(d_hraw, hl);
+        x.to(0, nh, b.dhn, nh).add(b.d_temporal_p + (size_t)k * snh, N * snh)
+            .gru_a(cslotp(w.gz, nh, t, 0, k), rl, cslotp(w.ghc, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l, d_tau_k, N * nh, 1, nh,
+                   d_pre_k + rw + nh + nsp, pre_rld);
+        CK(rundx(L_PROP_HEADS, x, R));
       } else {
         Dx x(d_hraw, hl); x.to(0, nh, b.dhn, nh).add(b.d_temporal_p + (size_t)k * snh, N * snh); CK(rundx(L_PROP_HEADS, x, R));
       }
@@ -440,11 +457,10 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         sq_launch_lstm_cell_bwd(w.lgates + ((size_t)t * M + k) * 4 * nh, N * 4 * nh, tau_k + nh, N * snh, b.dhn, nh,
                                 b.d_temporal_p + (size_t)k * snh + nh, N * snh, d_gru1, g1l, d_tau_k + nh, N * snh, R, nh, s);
       } else {
-        sq_launch_gru_bwd_a(b.dhn, nh, cslotp(w.gz, nh, t, 0, k), rl, cslotp(w.ghc, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l,
-                            d_tau_k, N * nh, R, nh, 1, s, d_pre_k + rw + nh + nsp, pre_rld);
-        { Dx x(d_gru1 + 2 * nh, g1l); x.to(0, nh, b.d_rh, nh); CK(rundx(L_PROP_GRU2, x, R)); }
-        sq_launch_gru_bwd_b(b.d_rh, nh, cslotp(w.gr, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l, d_tau_k, N * nh,
-                            R, nh, s, d_pre_k + rw + 2 * nh + nsp, pre_rld);
+        Dx x(d_gru1 + 2 * nh, g1l);
+        x.to(0, nh, b.d_rh, nh).gru_b(cslotp(w.gr, nh, t, 0, k), rl, tau_k, N * nh, d_gru1, g1l, d_tau_k, N * nh, nh,
+                                     d_pre_k + rw + 2 * nh + nsp, pre_rld);
+        CK(rundx(L_PROP_GRU2, x, R));
       }
       {  // gate GEMM inputs [r_k nh | where 4 (pad 16) | glimpse-encoder (loc, scale) 2 nw]
         Dx x(d_gru1, g1l);
@@ -554,7 +570,14 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       x.to(64, 64 + nh, d_pprev, nh);
       CK(rundx(L_PRIOR_GRU1, x, M));
     } else {
-    { Dx x(b.d_pstats + (size_t)t * M * PS_LD, PS_LD); x.to(0, nh, b.dhn, nh).add(b.d_prior_p, psnh); CK(rundx(L_PRIOR_LIN, x, M)); }
+    {
+      Dx x(b.d_pstats + (size_t)t * M * PS_LD, PS_LD);
+      x.to(0, nh, b.dhn, nh).add(b.d_prior_p, psnh);
+      if (c.prior_cell == CELL_GRU)
+        x.gru_a(w.frame(w.pgz, (int64_t)M * nh, t), nh, w.frame(w.pghc, (int64_t)M * nh, t), nh, prior_prev, nh, d_pgru1, 3 * nh, d_pprev,
+                nh, 1, nh);
+      CK(rundx(L_PRIOR_LIN, x, M));
+    }
     if (c.prior_cell == CELL_LSTM) {
       sq_launch_lstm_cell_bwd(w.frame(w.pgz, (int64_t)M * 4 * nh, t), 4 * nh, prior_prev + nh, psnh, b.dhn, nh, b.d_prior_p + nh, psnh,
                               d_pgru1, pgw, d_pprev + nh, psnh, M, nh, s);
@@ -563,10 +586,11 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       x.to(64, 64 + nh, d_pprev, psnh);
       CK(rundx(L_PRIOR_GRU1, x, M));
     } else {
-      sq_launch_gru_bwd_a(b.dhn, nh, w.frame(w.pgz, (int64_t)M * nh, t), nh, w.frame(w.pghc, (int64_t)M * nh, t), nh, prior_prev, nh,
-                          d_pgru1, 3 * nh, d_pprev, nh, M, nh, 1, s);
-      { Dx x(d_pgru1 + 2 * nh, 3 * nh); x.to(0, nh, b.d_rh, nh); CK(rundx(L_PRIOR_GRU2, x, M)); }
-      sq_launch_gru_bwd_b(b.d_rh, nh, w.frame(w.pgr, (int64_t)M * nh, t), nh, prior_prev, nh, d_pgru1, 3 * nh, d_pprev, nh, M, nh, s);
+      {
+        Dx x(d_pgru1 + 2 * nh, 3 * nh);
+        x.to(0, nh, b.d_rh, nh).gru_b(w.frame(w.pgr, (int64_t)M * nh, t), nh, prior_prev, nh, d_pgru1, 3 * nh, d_pprev, nh, nh);
+        CK(rundx(L_PRIOR_GRU2, x, M));
+      }
       {  // [z_{t-1} record 56 (pad 64) | prior state nh]
         Dx x(d_pgru1, 3 * nh);
         x.to(0, rec::ZW, d_rec_prev, RW).acc();
