@@ -1069,16 +1069,33 @@ __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, cons
   __shared__ float ds_s[128];
   extern __shared__ float wt_s[];  // the `what` rows of steps.l0.w, [nw][nsp + 1] (padded: conflict-free row reads)
   const int r = blockIdx.x, tid = threadIdx.x, nw = d.nw, nsp = d.nh / 2, RW = rec::W;
+  const int sh = 31 - __clz(nsp);  // nsp = nh / 2 is 64 or 128 (sqair_create): shifts instead of 50 integer divisions per thread
   for (int e = tid; e < nw * nsp; e += 128) {  // coalesced, independent loads: one round trip
-    const int c = e / nsp, i = e - c * nsp;
+    const int c = e >> sh, i = e & (nsp - 1);
     wt_s[c * (nsp + 1) + i] = a.flat[a.wwhat_off + e];
   }
   const float* rn = a.rec_new + ((size_t)r * d.N + a.slot) * RW;
   float* drn = a.d_rec_new + ((size_t)r * d.N + a.slot) * RW;
+  (void)rn;
   float prev;
   if (a.is_disc) prev = a.slot == 0 ? 1.0f : a.rec_new[((size_t)r * d.N + a.slot - 1) * RW + rec::PRES];
   else prev = a.rec_prev[((size_t)r * d.N + a.slot) * RW + rec::PRES];
   const float d_raw = prev * drn[rec::LOGIT];
+  // two threads per what element (c = tid >> 1, each sums half of the hidden units); everything the second phase reads from
+  // memory is requested HERE, ahead of the barrier, so that the kernel makes one memory round trip instead of two
+  const int c = min(tid >> 1, nw - 1), half = tid & 1;
+  const bool lead = (tid >> 1) < nw && half == 0;
+  const float q_dw = drn[rec::WHAT + c], q_dloc = drn[rec::WHAT_LOC + c], q_dsc = drn[rec::WHAT_SCALE + c];
+  const float eps = a.noise[(((size_t)r * 2 + (a.is_disc ? 1 : 0)) * d.N + a.slot) * d.nzw + 4 + c];
+  const float loc2 = a.enc[(size_t)r * a.enc_ld + c], sc2 = a.enc[(size_t)r * a.enc_ld + nw + c];
+  float hv5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, wtm1 = 0.0f, q_dprev = 0.0f;
+  if (!a.is_disc) {
+    const float* hr = a.hraw + (size_t)r * a.h_ld;
+#pragma unroll
+    for (int g = 0; g < 5; ++g) hv5[g] = hr[g * nw + c];
+    wtm1 = a.rec_prev[((size_t)r * d.N + a.slot) * RW + rec::WHAT + c];
+    q_dprev = a.d_rec_prev[((size_t)r * d.N + a.slot) * RW + rec::WHAT + c];
+  }
   if (tid < nsp) {
     const float hv = a.s1h[(size_t)r * a.s1h_ld + tid];
     const float w2 = a.flat[a.w2_off + tid];
@@ -1089,32 +1106,31 @@ __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, cons
   }
   if (tid == 0) a.d_raw_out[(size_t)r * a.dr_ld] = d_raw;
   __syncthreads();
-  if (tid < nw) {
-    const int c = tid;
-    float dw = drn[rec::WHAT + c];
-    const float* wrow = wt_s + c * (nsp + 1);
-    for (int i = 0; i < nsp; ++i) dw += ds_s[i] * wrow[i];
+  float part = 0.0f;
+  {
+    const float* wrow = wt_s + c * (nsp + 1) + half * (nsp >> 1);
+    const float* dsp = ds_s + half * (nsp >> 1);
+    for (int i = 0; i < (nsp >> 1); ++i) part += dsp[i] * wrow[i];
+  }
+  part += __shfl_xor(part, 1, 64);
+  if (lead) {
+    const float dw = q_dw + part;
     drn[rec::WHAT + c] = dw;  // total gradient of the sample (kept for the batched weight gradients' bookkeeping)
-    const float eps = a.noise[(((size_t)r * 2 + (a.is_disc ? 1 : 0)) * d.N + a.slot) * d.nzw + 4 + c];
-    const float d_loc = dw + drn[rec::WHAT_LOC + c];
-    const float d_sc = dw * eps + drn[rec::WHAT_SCALE + c];
+    const float d_loc = dw + q_dloc;
+    const float d_sc = dw * eps + q_dsc;
     if (a.is_disc) {
       a.d_enc[(size_t)r * a.de_ld + c] = d_loc;
       // scale = softplus(raw) + 0.01  ->  d raw = d scale * (1 - exp(-(scale - 0.01)))
-      a.d_enc[(size_t)r * a.de_ld + nw + c] =
-          a.enc_pre ? d_sc * (1.0f - expf(-(a.enc[(size_t)r * a.enc_ld + nw + c] - 1e-2f))) : d_sc;
+      a.d_enc[(size_t)r * a.de_ld + nw + c] = a.enc_pre ? d_sc * (1.0f - sq_exp(-(sc2 - 1e-2f))) : d_sc;
     } else {
-      const float* hr = a.hraw + (size_t)r * a.h_ld;
-      const float t_loc = hr[c], h1 = hr[nw + c];
+      const float t_loc = hv5[0], h1 = hv5[1];
       const float t_scale = sq_softplus(h1) + 1e-2f;
-      const float s2 = sq_sigmoid(hr[2 * nw + c]), s3 = sq_sigmoid(hr[3 * nw + c]), s4 = sq_sigmoid(hr[4 * nw + c]);
+      const float s2 = sq_sigmoid(hv5[2]), s3 = sq_sigmoid(hv5[3]), s4 = sq_sigmoid(hv5[4]);
       const float fg = s2 * 0.9999f, ig = s3 * 0.9999f, tg = s4 * 0.9999f;
-      const float loc2 = a.enc[(size_t)r * a.enc_ld + c], sc2 = a.enc[(size_t)r * a.enc_ld + nw + c];
-      const float wtm1 = a.rec_prev[((size_t)r * d.N + a.slot) * RW + rec::WHAT + c];
       const float d_fg = d_loc * wtm1;
       const float d_ig = -d_loc * loc2 - d_sc * sc2;
       const float d_tg = -d_loc * t_loc - d_sc * t_scale;
-      a.d_rec_prev[((size_t)r * d.N + a.slot) * RW + rec::WHAT + c] += d_loc * fg;
+      a.d_rec_prev[((size_t)r * d.N + a.slot) * RW + rec::WHAT + c] = q_dprev + d_loc * fg;
       a.d_enc[(size_t)r * a.de_ld + c] = d_loc * (1.0f - ig);
       a.d_enc[(size_t)r * a.de_ld + nw + c] = d_sc * (1.0f - ig);
       float* dh = a.d_hraw + (size_t)r * a.dh_ld;
@@ -1145,20 +1161,53 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
   const int slot = a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot;
   const int P = d.H * d.W, G = d.G, G2 = d.G * d.G, RW = rec::W;
   const float* img = a.img + (size_t)b * P;
-  for (int i = tid; i < P; i += 256) img_s[i] = img[i];
-  __syncthreads();
   const int madd = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
   const int gadd = a.g_row_add + (a.mode == CROP_PROP1 ? slot : 0);
+  // everything the later phases read from memory is requested up front, next to the frame: the kernel then makes ONE memory
+  // round trip (it used to make three: frame | glimpse gradient + mask | the operands of the where-sample adjoint)
+  constexpr int PPT = 4;  // pixels per thread prefetched (covers G * G <= 1024)
+  float g_v[PPT], m_v[PPT], dm_v[PPT];
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) {
+    const int pix = min(tid + 256 * q, G2 - 1);
+    g_v[q] = a.g_out[((size_t)r * a.g_row_mul + gadd) * G2 + pix];
+    const size_t mi = ((size_t)r * a.mask_row_mul + madd) * G2 + pix;
+    m_v[q] = a.mask != nullptr ? a.mask[mi] : 1.0f;
+    dm_v[q] = a.mask != nullptr ? a.d_mask[mi] : 0.0f;
+  }
+  float wl[4];
   {
-    float wl[4];
     const float* wsrc = a.mode == CROP_PROP1 ? a.rec_prev + ((size_t)r * d.N + slot) * RW + rec::WHERE
                                              : a.rec_new + ((size_t)r * d.N + slot) * RW + rec::WHERE;
     for (int i = 0; i < 4; ++i) wl[i] = wsrc[i] + (a.mode == CROP_PROP1 ? 0.1f * a.wb[((size_t)r * d.N + slot) * a.wb_ld + i] : 0.0f);
+  }
+  // operands of the four where coordinates' adjoint (threads 0..3)
+  const int ci = tid & 3;
+  float* drn = a.d_rec_new + ((size_t)r * d.N + slot) * RW;
+  float q_dw = 0.0f, q_dloc = 0.0f, q_dsc = 0.0f, q_eps[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q_tp = 0.0f, q_off = 0.0f, q_dprev = 0.0f, q_ch[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (tid < 4) {
+    q_dprev = a.d_rec_prev[((size_t)r * d.N + slot) * RW + rec::WHERE + ci];
+    if (a.mode != CROP_PROP1) {
+      q_dw = drn[rec::WHERE + ci]; q_dloc = drn[rec::WHERE_LOC + ci]; q_dsc = drn[rec::WHERE_SCALE + ci];
+      const float* eps = a.noise + (((size_t)r * 2 + (a.mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q_eps[j] = eps[j];
+      q_tp = a.tp[(size_t)r * a.tp_ld + 4 + ci];
+      q_off = a.flat[a.mode == CROP_DISC ? po.disc_scale_offset : po.prop_scale_offset];
+      if (a.mode != CROP_DISC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q_ch[j] = tril4(a.flat + po.cholesky, ci, min(j, ci));
+      }
+    }
+  }
+  for (int i = tid; i < P; i += 256) img_s[i] = img[i];
+  __syncthreads();
+  {
     const float s0 = sq_sigmoid(wl[0]), s1 = sq_sigmoid(wl[1]);
     const float sx = fmaxf(s0, 1e-4f), sy = fmaxf(s1, 1e-4f), tx = tanhf(wl[2]), ty = tanhf(wl[3]);
     const float hx = 0.5f * (float)(d.W - 1), hy = 0.5f * (float)(d.H - 1);
     float dsx = 0.0f, dsy = 0.0f, dtx = 0.0f, dty = 0.0f;
-    for (int pix = tid; pix < G2; pix += 256) {
+    auto pixel = [&](const int pix, float g, const float mk, const float dmk) {
       const int i = pix / G, j = pix - i * G;
       const float gx = -1.0f + 2.0f * (float)j / (float)(G - 1), gy = -1.0f + 2.0f * (float)i / (float)(G - 1);
       const float x = hx * (sx * gx + tx + 1.0f), y = hy * (sy * gy + ty + 1.0f);
@@ -1176,16 +1225,22 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
       const float v = (1.0f - wy1) * ((1.0f - wx1) * t[0][0] + wx1 * t[0][1]) + wy1 * ((1.0f - wx1) * t[1][0] + wx1 * t[1][1]);
       const float dvdx = (1.0f - wy1) * (t[0][1] - t[0][0]) + wy1 * (t[1][1] - t[1][0]);
       const float dvdy = (1.0f - wx1) * (t[1][0] - t[0][0]) + wx1 * (t[1][1] - t[0][1]);
-      float g = a.g_out[((size_t)r * a.g_row_mul + gadd) * G2 + pix];
       if (a.mask != nullptr) {
-        const size_t mi = ((size_t)r * a.mask_row_mul + madd) * G2 + pix;
-        a.d_mask[mi] += g * v;
-        g *= a.mask[mi];
+        a.d_mask[((size_t)r * a.mask_row_mul + madd) * G2 + pix] = dmk + g * v;
+        g *= mk;
       }
       dsx += g * dvdx * hx * gx;
       dtx += g * dvdx * hx;
       dsy += g * dvdy * hy * gy;
       dty += g * dvdy * hy;
+    };
+#pragma unroll
+    for (int q = 0; q < PPT; ++q)
+      if (tid + 256 * q < G2) pixel(tid + 256 * q, g_v[q], m_v[q], dm_v[q]);
+    for (int pix = tid + 256 * PPT; pix < G2; pix += 256) {  // glimpses beyond 32 x 32: operands fetched in place
+      const size_t mi = ((size_t)r * a.mask_row_mul + madd) * G2 + pix;
+      pixel(pix, a.g_out[((size_t)r * a.g_row_mul + gadd) * G2 + pix], a.mask != nullptr ? a.mask[mi] : 1.0f,
+            a.mask != nullptr ? a.d_mask[mi] : 0.0f);
     }
     dsx = sq_wave_sum(dsx); dsy = sq_wave_sum(dsy); dtx = sq_wave_sum(dtx); dty = sq_wave_sum(dty);
     if (lane == 0) { red_s[wave][0] = dsx; red_s[wave][1] = dsy; red_s[wave][2] = dtx; red_s[wave][3] = dty; }
@@ -1196,31 +1251,24 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
       const float dl = i == 0 ? s0 * (1.0f - s0) : (i == 1 ? s1 * (1.0f - s1) : (i == 2 ? 1.0f - tx * tx : 1.0f - ty * ty));
       const float g_crop = tot * dl;
       if (a.mode == CROP_PROP1) {
-        a.d_rec_prev[((size_t)r * d.N + slot) * RW + rec::WHERE + i] += g_crop;
+        a.d_rec_prev[((size_t)r * d.N + slot) * RW + rec::WHERE + i] = q_dprev + g_crop;
         a.d_wb[((size_t)r * d.N + slot) * a.wb_ld + i] = 0.1f * g_crop;
       } else {
-        float* drn = a.d_rec_new + ((size_t)r * d.N + slot) * RW;
-        const float dW = drn[rec::WHERE + i] + g_crop;  // every other consumer has already accumulated here
-        const float* eps = a.noise + (((size_t)r * 2 + (a.mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
-        const float* tp = a.tp + (size_t)r * a.tp_ld;
-        const float d_loc = dW + drn[rec::WHERE_LOC + i];
-        float d_sc = drn[rec::WHERE_SCALE + i];
+        const float dW = q_dw + g_crop;  // every other consumer has already accumulated here
+        const float d_loc = dW + q_dloc;
+        float d_sc = q_dsc;
         float d_raw;
         if (a.mode == CROP_DISC) {
-          d_sc += dW * eps[i];
-          const float off = a.flat[po.disc_scale_offset];
-          d_raw = d_sc * sq_sigmoid(tp[4 + i] + off);
+          d_sc += dW * (i == 0 ? q_eps[0] : (i == 1 ? q_eps[1] : (i == 2 ? q_eps[2] : q_eps[3])));
+          d_raw = d_sc * sq_sigmoid(q_tp + q_off);
         } else {
-          const float* ch = a.flat + po.cholesky;
-          const float sci = a.rec_new[((size_t)r * d.N + slot) * RW + rec::WHERE_SCALE + i];
           float lin = 0.0f;
-          for (int j = 0; j <= i; ++j) {
-            lin += (tril4(ch, i, j) + (i == j ? 1.0f : 0.0f)) * eps[j];
-          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j <= i) lin += (q_ch[j] + (i == j ? 1.0f : 0.0f)) * q_eps[j];
           d_sc += dW * lin;
-          const float off = a.flat[po.prop_scale_offset];
-          d_raw = d_sc * sq_sigmoid(tp[4 + i] + off - 1.0f);
-          a.d_rec_prev[((size_t)r * d.N + slot) * RW + rec::WHERE + i] += d_loc;  // loc = where_{t-1} + transform
+          d_raw = d_sc * sq_sigmoid(q_tp + q_off - 1.0f);
+          a.d_rec_prev[((size_t)r * d.N + slot) * RW + rec::WHERE + i] = q_dprev + d_loc;  // loc = where_{t-1} + transform
         }
         a.d_tp[(size_t)r * a.dtp_ld + i] = d_loc;
         a.d_tp[(size_t)r * a.dtp_ld + 4 + i] = d_raw;
