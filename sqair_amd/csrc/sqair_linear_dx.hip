@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
   }
   __builtin_amdgcn_sched_barrier(0);
   SQ_DX_MFMA()
-  if (NCH == 9) {  // only the deepest instantiation loops (K > 576)
+  if (NCH == 18) {  // only the deepest instantiation loops (K > 1152)
 #pragma unroll 1
     for (int base = NCH; base < nmine; base += NCH) {
       SQ_DX_ISSUE(base)
@@ -147,7 +147,11 @@ int sq_launch_linear_dx(const DxArgs& a, int kc, int nt, hipStream_t s) {
     case 6: hipLaunchKernelGGL(k_linear_dx<6>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
     case 7: hipLaunchKernelGGL(k_linear_dx<7>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
     case 8: hipLaunchKernelGGL(k_linear_dx<8>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
-    default: hipLaunchKernelGGL(k_linear_dx<9>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 9: hipLaunchKernelGGL(k_linear_dx<9>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 10: case 11: case 12:  // K = 768: the GRU gate GEMMs' transposes, all 24 operand loads of a wave in flight at once
+      hipLaunchKernelGGL(k_linear_dx<12>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    default:                    // K = 1152 (the loop-invariant pre-activation GEMM's transpose) and deeper (looped)
+      hipLaunchKernelGGL(k_linear_dx<18>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
   }
   return 0;
 }
