@@ -501,7 +501,8 @@ __global__ __launch_bounds__(256) void k_linear_lds(const LinArgs a, const int k
 }
 
 // Tile shape of the throughput variants, from measurements of the layer shapes of the pass (tools/time_linear.py, MI355X):
-// rows x slabs per wave and whether the A fragment is loaded row-contiguously (COAL).  SQAIR_MT="MT,NT[,COAL]" overrides.
+// slabs per wave (1 or 2; two ROW tiles per wave -- template parameter MT = 2 -- measured slower on every shape of the pass and is
+// not instantiated) and whether the A fragment is loaded row-contiguously (COAL).  SQAIR_MT="1,NT[,COAL]" overrides.
 struct MtShape { int mt, nt, coal; };
 static MtShape pick_mt_shape(int M, int n_tiles, int kc) {
   static int ov_mt = -1, ov_nt = -1, ov_coal = -1;
@@ -581,8 +582,7 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
       return 0;
     }
     const MtShape sh = pick_mt_shape(a.M, L.nt, L.kc);
-    if (sh.mt == 2) launch_mt<3, 2, 2>(a, L, mt, sh.coal != 0, s, prof_ts);
-    else if (sh.nt >= 2) launch_mt<4, 1, 2>(a, L, mt, sh.coal != 0, s, prof_ts);
+    if (sh.nt >= 2) launch_mt<4, 1, 2>(a, L, mt, sh.coal != 0, s, prof_ts);
     else launch_mt<4, 1, 1>(a, L, mt, sh.coal != 0, s, prof_ts);
     return 0;
   }
