@@ -313,7 +313,9 @@ __global__ __launch_bounds__(256) void k_linear_mt(const LinArgs a, const int kc
   // slab, element-major) so that the loop body -- the three epilogue kinds with their exp / tanh / log1p expansions -- exists
   // once.  Unrolled over the elements this kernel was 27 - 93 KB of code and every launch paid tens of microseconds of cold
   // instruction fetch (measured in the pass: 67 us against 17 us for the same tile shape with a small epilogue).
-  __shared__ float epi_s[4][MT * NT * 4][64];
+  constexpr int E = MT * NT * 4;
+  __shared__ float epi_s[4][E][64];
+  __shared__ float epo_s[4][E][3][64];  // epilogue operands (addend, e0, e1) of the same elements, when the layer has any
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -327,18 +329,36 @@ __global__ __launch_bounds__(256) void k_linear_mt(const LinArgs a, const int kc
   float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : a.bias);
   p_scale = a.scale_ptr != nullptr ? p_scale : 1.0f;
   const bool g2 = a.epi == EPI_GRU2;
+  const bool has_operands = a.add != nullptr || a.epi != EPI_ACT;  // wave-uniform
+  if (has_operands) {
+    // all operand loads of the lane's E elements in ONE burst (clamped addresses, dummy = the bias word), parked in LDS for the
+    // rolled loop below: guarded loads inside that loop would cost one memory round trip per element
+    float qa[E], q0[E], q1[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int q = e & 3, t = (e >> 2) % NT, i = (e >> 2) / NT;
+      const int n = min((min(tile_n0 + t, n_tiles - 1)) * 16 + (lane & 15), a.N - 1);
+      const int m = min((tile_m0 + i) * 16 + 4 * kq + q, a.M - 1);
+      const float* pb = a.bias + n;
+      const bool use_add = a.add != nullptr && n < a.add_n;
+      const bool g1 = a.epi == EPI_GRU1 && n >= a.nh && n < 2 * a.nh;
+      const float* pa = use_add ? a.add + (size_t)(a.add_rmul ? (int)__umulhi((unsigned)m, a.add_rmul) : m) * a.add_ld + n : pb;
+      const float* pe0 = g1 ? a.e0 + (size_t)m * a.e0_ld + (n - a.nh) : (g2 ? a.e0 + (size_t)m * a.e0_ld + n : pb);
+      const float* pe1 = g2 ? a.e1 + (size_t)m * a.e1_ld + n : pb;
+      qa[e] = *pa; q0[e] = *pe0; q1[e] = *pe1;
+      if (!use_add) qa[e] = 0.0f;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) { epo_s[wave][e][0][lane] = qa[e]; epo_s[wave][e][1][lane] = q0[e]; epo_s[wave][e][2][lane] = q1[e]; }
+  }
 #pragma unroll 1
-  for (int e = 0; e < MT * NT * 4; ++e) {
+  for (int e = 0; e < E; ++e) {
     const int q = e & 3, t = (e >> 2) % NT, i = (e >> 2) / NT;
     const int n = (tile_n0 + t) * 16 + (lane & 15);
     const int m = (tile_m0 + i) * 16 + 4 * kq + q;
     if (tile_n0 + t < n_tiles && n < a.N && m < a.M) {
-      const bool use_add = a.add != nullptr && n < a.add_n;
-      const bool g1 = a.epi == EPI_GRU1 && n >= a.nh && n < 2 * a.nh;
       float p_add = 0.0f, p_e0 = 0.0f, p_e1 = 0.0f;
-      if (use_add) p_add = a.add[(size_t)(a.add_rmul ? (int)__umulhi((unsigned)m, a.add_rmul) : m) * a.add_ld + n];
-      if (g1) p_e0 = a.e0[(size_t)m * a.e0_ld + (n - a.nh)];
-      if (g2) { p_e0 = a.e0[(size_t)m * a.e0_ld + n]; p_e1 = a.e1[(size_t)m * a.e1_ld + n]; }
+      if (has_operands) { p_add = epo_s[wave][e][0][lane]; p_e0 = epo_s[wave][e][1][lane]; p_e1 = epo_s[wave][e][2][lane]; }
       x_epilogue(a, m, n, epi_s[wave][e][lane] + a.bias[n] + p_add, p_e0, p_e1, p_scale);
     }
   }
