@@ -86,6 +86,22 @@ int sq_launch_dot_scale_atomic(const float* a, const float* b, int64_t n, const 
 int sq_launch_reduce_rows_atomic(const float* rows, float* out, int R, int P, hipStream_t s);
 int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim,
                         hipStream_t s, const int* rowmap, const float* alpha_ptr, float* db_a, float* db_b);
+// Weight-gradient blocks collected over the backward pass and issued together (k_wgrad_group, sqair_bwd.hip): same
+// arguments as sq_launch_wgrad_acc; add() returns false for a block the grouped kernel does not take (small or unaligned:
+// the caller launches it on its own).  Operands must stay untouched until flush().
+struct WgDesc {
+  const float* A; const float* dY; float* dW; const int* rowmap; const float* alpha_ptr; float* db_a; float* db_b;
+  int lda, ldy, ldw, M, Kdim, Ndim, kt, n_tiles;
+  int wg_begin, m_per_wg, zc, pad_;  // filled by flush(): first workgroup of the block, rows and number of its M-chunks
+};
+constexpr int SQ_WG_MAXD = 32;
+struct WgGroup { WgDesc d[SQ_WG_MAXD]; int nd; };
+struct WgradBatch {
+  std::vector<WgDesc> blocks;
+  bool add(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim, const int* rowmap,
+           const float* alpha_ptr, float* db_a, float* db_b);
+  int flush(hipStream_t s);
+};
 
 int sq_launch_where_param_grads(const float* d_tp, int tp_ld, const float* d_rec_p, const float* rec_p, const float* noise, int T,
                                 Dims d, float* flat_grad, POff po, hipStream_t s);

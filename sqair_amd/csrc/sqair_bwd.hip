@@ -12,7 +12,10 @@
 //                         [in, out] layout straight into the flat gradient buffer
 #include "sqair_glue.h"
 #include "sqair_bwd.h"
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <algorithm>
 
 typedef float f32x4_b __attribute__((ext_vector_type(4)));
 
@@ -477,8 +480,125 @@ __global__ __launch_bounds__(256) void k_wgrad2(const float* __restrict__ A, int
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same product with a 64(k) x 64(n) macro tile per WAVE (wgrad3_body, sqair_wgrad_kernel.inc): 16 accumulators over the
+// wave's own row range of the workgroup's M-chunk, so one 16-byte load of A and one of dY per 4 rows feed 16 MFMAs (k_wgrad2:
+// 4 dword loads per 4 MFMAs), the loads run two 16-row steps (128 MFMAs) ahead of their use, and a workgroup issues a quarter
+// of k_wgrad2's atomics per flop.  The MFMA tile (i, j) of the macro tile holds k = 4 row + i, n = 4 col + j (interleaved),
+// which is what makes the operands of the four tiles one contiguous float4.  The 4 waves' tiles meet in LDS; a thread adds 16
+// sums onto the gradient with row-contiguous atomics.  Needs 16-byte aligned operand rows (wgrad3_operands_ok).
+// Measured (tools/wgrad_floor.hip, 256 x 256 block): 92 TFLOP/s of the 155 TFLOP/s the fp32 matrix cores deliver at
+// M = 51200; at M = 6400 a launch of its own is 20 us for 5 us of MFMAs -- hence the grouped launch below.
+// Built with -amdgpu-mfma-vgpr-form: with the accumulators in AGPRs the compiler moved all 64 of them to VGPRs and back
+// around every loop trip.
+// ------------------------------------------------------------------------------------------------
+#define SQ_KWGRAD_NAME k_wgrad3
+#define SQ_KWGRAD_BODY wgrad3_body
+#include "sqair_wgrad_kernel.inc"
+#undef SQ_KWGRAD_NAME
+#undef SQ_KWGRAD_BODY
+
+// All deferred blocks of a training step in ONE launch (WgradBatch, sqair_bwd.h): the blocks of the ~50 layers are
+// independent, each is far too small to fill the chip for long (a 256 x 256 block over 6400 rows is 0.84 GFLOP = 5 us of the
+// matrix cores, measured 20 us as its own launch: ramp-up, first-load latency, the LDS meeting and the atomics' drain are
+// each as long as the MFMAs), and back to back on one stream those fixed parts added up to 1.2 ms of a 9.9 ms step.  As one
+// grid of workgroups (a 64 x 64 tile x ~m_per_wg rows each) they overlap each other's fixed parts: 0.44 ms for the same
+// 62 blocks (32 GFLOP, 73 TFLOP/s); 100 TFLOP/s at 256 sequences per GPU.  The table of blocks travels in the kernel
+// arguments (<= 32 blocks a launch); a workgroup finds its block by a scalar walk.
+__global__ __launch_bounds__(256) void k_wgrad_group(const WgGroup g) {
+  extern __shared__ __attribute__((aligned(16))) float red3[];
+  int i = 0;
+  while (i + 1 < g.nd && (int)blockIdx.x >= g.d[i + 1].wg_begin) ++i;
+  const WgDesc& e = g.d[i];
+  const int local = (int)blockIdx.x - e.wg_begin;
+  // (Placing M-chunk z on XCD z % 8, so that an XCD pulls only its eighth of the operand rows over the fabric and the tiles'
+  // re-reads hit its L2, was measured neutral at 32 and at 256 sequences per GPU: the kernel is not fabric-bound.)
+  const int tile = local % e.n_tiles, zi = local / e.n_tiles;
+  wgrad3_body(e.A, e.lda, e.dY, e.ldy, e.dW, e.ldw, e.M, e.Kdim, e.Ndim, e.rowmap, e.alpha_ptr, e.db_a, e.db_b, e.m_per_wg, e.kt, tile, zi, red3);
+}
+// what the float4 operand loads of wgrad3_body need: 16-byte aligned rows, and a width that is not a multiple of 4 padded
+// inside its row
+static bool wgrad3_operands_ok(const float* A, int lda, const float* dY, int ldy, int Kdim, int Ndim) {
+  static const int use3 = getenv("SQAIR_WGRAD3") ? atoi(getenv("SQAIR_WGRAD3")) : 1;  // measurement knob: 0 = k_wgrad2 everywhere
+  const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)dY % 16 == 0) && lda % 4 == 0 && ldy % 4 == 0;
+  const bool padded = (Kdim % 4 == 0 || ((Kdim + 3) & ~3) <= lda) && (Ndim % 4 == 0 || ((Ndim + 3) & ~3) <= ldy);
+  return use3 > 0 && aligned && padded && Kdim >= 1 && Ndim >= 1;
+}
+// as its own launch the 64 x 64 macro tile only pays for blocks about that large
+static bool wgrad3_eligible(const float* A, int lda, const float* dY, int ldy, int M, int Kdim, int Ndim) {
+  return wgrad3_operands_ok(A, lda, dY, ldy, Kdim, Ndim) && Kdim % 4 == 0 && Ndim % 4 == 0 && Kdim >= 48 && Ndim >= 48 && M >= 256;
+}
+static const size_t WG3_LDS = (4 * 4096 + 256) * sizeof(float);
+bool WgradBatch::add(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim, const int* rowmap,
+                     const float* alpha_ptr, float* db_a, float* db_b) {
+  static const bool grouped = getenv("SQAIR_WGRAD_GROUP") ? atoi(getenv("SQAIR_WGRAD_GROUP")) != 0 : true;
+  if (!grouped || M < 1 || !wgrad3_operands_ok(A, lda, dY, ldy, Kdim, Ndim)) return false;
+  WgDesc e;
+  e.A = A; e.dY = dY; e.dW = dW; e.rowmap = rowmap; e.alpha_ptr = alpha_ptr; e.db_a = db_a; e.db_b = db_b;
+  e.lda = lda; e.ldy = ldy; e.ldw = ldw; e.M = M; e.Kdim = Kdim; e.Ndim = Ndim;
+  e.kt = (Kdim + 63) / 64; e.n_tiles = e.kt * ((Ndim + 63) / 64); e.wg_begin = 0;
+  blocks.push_back(e);
+  return true;
+}
+int WgradBatch::flush(hipStream_t s) {
+  static const int rows = getenv("SQAIR_WGRAD_ROWS") ? atoi(getenv("SQAIR_WGRAD_ROWS")) : 2048;  // target rows of a workgroup
+  static const bool dump = getenv("SQAIR_WGRAD_DUMP") != nullptr;  // print the block table of every flush
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k_wgrad_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG3_LDS);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  for (size_t i0 = 0; i0 < blocks.size(); i0 += SQ_WG_MAXD) {
+    WgGroup g;
+    memset(&g, 0, sizeof(g));
+    g.nd = (int)std::min(blocks.size() - i0, (size_t)SQ_WG_MAXD);
+    int total = 0;
+    for (int i = 0; i < g.nd; ++i) {
+      WgDesc& e = g.d[i];
+      e = blocks[i0 + i];
+      // equal chunks of about `rows` rows, at least 8 of them for a block with many rows (4 waves x a multiple of 4 rows each;
+      // the kernel masks a partial last step)
+      e.zc = e.M >= 2048 ? 8 * std::max(1, (e.M + 4 * rows) / (8 * rows)) : (e.M + rows - 1) / rows;
+      e.m_per_wg = ((e.M + e.zc - 1) / e.zc + 15) / 16 * 16;
+      e.zc = (e.M + e.m_per_wg - 1) / e.m_per_wg;
+      e.wg_begin = total;
+      total += e.n_tiles * e.zc;
+    }
+    if (dump)
+      for (int i = 0; i < g.nd; ++i)
+        fprintf(stderr, "wgrad block %2d: M %6d K %4d N %4d  tiles %3d  workgroups %5d  useful %.2f\n", (int)(i0 + i), g.d[i].M, g.d[i].Kdim,
+                g.d[i].Ndim, g.d[i].n_tiles, g.d[i].n_tiles * g.d[i].zc,
+                (double)g.d[i].Kdim * g.d[i].Ndim / (4096.0 * g.d[i].n_tiles));
+    hipLaunchKernelGGL(k_wgrad_group, dim3(total), dim3(256), WG3_LDS, s, g);
+  }
+  blocks.clear();
+  return 0;
+}
 int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim,
                         hipStream_t s, const int* rowmap, const float* alpha_ptr, float* db_a, float* db_b) {
+  static const int skip = getenv("SQAIR_WGRAD3") ? atoi(getenv("SQAIR_WGRAD3")) < 0 : 0;  // measurement knob: no weight gradients at all
+  const int wg3_target = 512;
+  if (skip) return 0;
+  if (wgrad3_eligible(A, lda, dY, ldy, M, Kdim, Ndim)) {
+    const int kt = (Kdim + 63) / 64, nt = (Ndim + 63) / 64;
+    int zc = wg3_target / (kt * nt);
+    const int max_z = (M + 63) / 64;
+    if (zc > max_z) zc = max_z;
+    if (zc < 1) zc = 1;
+    const int m_per_wg = ((M + zc - 1) / zc + 63) / 64 * 64;   // 4 waves x a multiple of 16 rows
+    zc = (M + m_per_wg - 1) / m_per_wg;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)k_wgrad3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG3_LDS);
+      (void)hipGetLastError();
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(k_wgrad3, dim3(kt * nt * zc), dim3(256), WG3_LDS, s, A, lda, dY, ldy, dW, ldw, M, Kdim, Ndim, rowmap, alpha_ptr, db_a,
+                       db_b, m_per_wg, kt, kt * nt);
+    return 0;
+  }
   const int kt = (Kdim + 31) / 32, nt = (Ndim + 31) / 32;
   static const int wg_target = getenv("SQAIR_WGRAD_WGS") ? atoi(getenv("SQAIR_WGRAD_WGS")) : 2048;  // measurement knob
   int zc = wg_target / (kt * nt);

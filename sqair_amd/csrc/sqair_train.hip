@@ -108,7 +108,12 @@ struct BwdSpace {
   float *d_new_t, *d_new_p;                      // [T][R][snh | psnh]: compaction adjoint rows for the initial recurrent states
   float *d_init_p, *d_init_d, *d_rn0;            // per-frame dX rows of the trainable initial states: summed once after the sweep
   float *d_cs[2], *d_hk;                        // LSTM slot RNN: d cell state of the neighbouring slot, d hidden of this one
-  float *d_gl, *d_mean_rows, *bufa, *bufb, *d_ia, *d_ib, *zs, *rs, *rh;
+  float *d_gl, *d_mean_rows, *bufa, *bufb, *d_ia, *d_ib;
+  float* bufc;  // [MT][nh] second pre-activation gradient of the decoder (bufb keeps the first for the grouped weight gradients)
+  // A operands built for the batched weight gradients (fully written before they are read: outside the zero-filled part).
+  // One copy per use -- the grouped launch at the end of the pass reads them all
+  float *zs[2], *rs[2], *rh[4];
+  int64_t zero_total;  // floats from the base that the pass expects zeroed
   int64_t total;
 };
 
@@ -150,7 +155,10 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   const int64_t big = MT * (nh > G2 ? nh : G2);
   b.d_gl = take(MT * G2); b.d_mean_rows = take(T * R * P_); b.bufa = take(big); b.bufb = take(big);
   b.d_ia = take((int64_t)T * B * nh); b.d_ib = take((int64_t)T * B * nh);
-  b.zs = take(MT * 64); b.rs = take(MT * nh); b.rh = take(MT * nh);
+  b.zero_total = o;
+  b.bufc = take(MT * nh);
+  for (int i = 0; i < 2; ++i) { b.zs[i] = take(MT * 64); b.rs[i] = take(MT * nh); }
+  for (int i = 0; i < 4; ++i) b.rh[i] = take(MT * nh);
   b.total = o;
   return b;
 }
@@ -193,7 +201,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     return -1;
   }
   sq_zero_fill(flat_grad, h->n_params, s);
-  sq_zero_fill((float*)scratch, b.total, s);
+  sq_zero_fill((float*)scratch, b.zero_total, s);
 
   // dX through the transposed pack: out[M][K of the forward layer] (+)= dpre[M][N] W^T.  Single-segment layers write
   // exactly their true input width; multi-segment layers write all 16 * kc padded columns (the caller splits them).
@@ -220,7 +228,9 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     return rc;
   };
   // batched weight + bias gradients of one layer over `rows` uses
-  auto wgrad = [&](LayerId id, std::vector<std::pair<const float*, int>> segs, const float* dY, int ldy, int rows) {
+  // `defer`: the block joins the grouped launch at the end of the pass (its operands must then stay as they are until there)
+  WgradBatch wbatch;
+  auto wgrad = [&](LayerId id, std::vector<std::pair<const float*, int>> segs, const float* dY, int ldy, int rows, bool defer = true) {
     // the bias gradient of a column block rides on the first weight-gradient launch of that block
     std::vector<char> bias_done(h->bg[id].size(), 0);
     for (const auto& e : h->wg[id]) {
@@ -233,6 +243,9 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
           bias_done[bi] = 1;
         }
       }
+      if (defer && wbatch.add(segs[e.seg].first, segs[e.seg].second, dY + e.n0, ldy, flat_grad + P(h, e.w) + e.col0, PC(h, e.w), rows,
+                              h->layers[id].seg_width[e.seg], e.ncols, rm_dev + e.rm_off, nullptr, dba, dbb))
+        continue;
       sq_launch_wgrad_acc(segs[e.seg].first, segs[e.seg].second, dY + e.n0, ldy, flat_grad + P(h, e.w) + e.col0, PC(h, e.w), rows,
                           h->layers[id].seg_width[e.seg], e.ncols, s, rm_dev + e.rm_off, nullptr, dba, dbb);
     }
@@ -259,15 +272,16 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     sq_launch_reduce_rows_atomic(b.d_mean_rows, flat_grad + po.dec_mean_img, T * R, P_, s);
     const float* scale = flat + po.dec_output_scale;
     sq_launch_dot_scale_atomic(b.d_gl, gl, (int64_t)MT * G2, scale, flat_grad + po.dec_output_scale, s);
-    sq_launch_wgrad_acc(w.dec_b, nh, b.d_gl, G2, flat_grad + P(h, "dec.l2.w"), G2, MT, nh, G2, s, nullptr, scale,
-                        flat_grad + P(h, "dec.l2.b"), nullptr);
+    if (!wbatch.add(w.dec_b, nh, b.d_gl, G2, flat_grad + P(h, "dec.l2.w"), G2, MT, nh, G2, nullptr, scale, flat_grad + P(h, "dec.l2.b"), nullptr))
+      sq_launch_wgrad_acc(w.dec_b, nh, b.d_gl, G2, flat_grad + P(h, "dec.l2.w"), G2, MT, nh, G2, s, nullptr, scale,
+                          flat_grad + P(h, "dec.l2.b"), nullptr);
     CK(dx(L_DEC2, b.d_gl, G2, MT, b.bufa, nh, false, scale));
     sq_launch_dact2(b.bufa, nh, w.dec_b, nh, b.bufb, nh, MT, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
     wgrad(L_DEC1, {{w.dec_a, nh}}, b.bufb, nh, MT);
     CK(dx(L_DEC1, b.bufb, nh, MT, b.bufa, nh, false));
-    sq_launch_dact2(b.bufa, nh, w.dec_a, nh, b.bufb, nh, MT, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-    wgrad(L_DEC0, {{rec_all, RW}}, b.bufb, nh, MT);
-    CK(dx(L_DEC0, b.bufb, nh, MT, d_rec_all, RW, true));
+    sq_launch_dact2(b.bufa, nh, w.dec_a, nh, b.bufc, nh, MT, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+    wgrad(L_DEC0, {{rec_all, RW}}, b.bufc, nh, MT);
+    CK(dx(L_DEC0, b.bufc, nh, MT, d_rec_all, RW, true));
   }
   // ================= H^T. log-probabilities, all frames =================
   {
@@ -626,8 +640,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     // prior GRU
     wgrad(L_PRIOR_GRU1, {{w.rec_m_all, RW}, {pm_all, psnh}}, b.d_pgru1, pgw, MT);
     if (c.prior_cell == CELL_GRU) {
-      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.pgr, nh, pm_all, nh, b.rh, nh, MT, nh);
-      wgrad(L_PRIOR_GRU2, {{b.rh, nh}}, b.d_pgru1 + 2 * nh, 3 * nh, MT);
+      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.pgr, nh, pm_all, nh, b.rh[0], nh, MT, nh);
+      wgrad(L_PRIOR_GRU2, {{b.rh[0], nh}}, b.d_pgru1 + 2 * nh, 3 * nh, MT);
     }
     wgrad(L_PRIOR_LIN, {{w.prior_p, psnh}}, b.d_pstats, PS_LD, MT);
     // where-bias / mask MLPs
@@ -644,11 +658,11 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     // loop-invariant pre-activations
     wgrad(L_PRE, {{w.m1, M1_LD}, {w.rec_m_all, RW}, {tau_all, snh}}, b.d_pre, pre_ld, MT);
     // propagation slot chain (phase 0 of the tapes)
-    hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_p_all, w.r, w.zero_rec, w.prop_rnn_init, b.zs, b.rs, MT, N, nh);
-    wgrad(L_PROP_RNN, {{b.zs, 64}, {b.rs, nh}}, b.d_rnn, rw, MT);
+    hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_p_all, w.r, w.zero_rec, w.prop_rnn_init, b.zs[0], b.rs[0], MT, N, nh);
+    wgrad(L_PROP_RNN, {{b.zs[0], 64}, {b.rs[0], nh}}, b.d_rnn, rw, MT);
     if (c.rnn_cell == RNN_GRU) {  // candidate's recurrent matrix: A = r * h_{k-1}
-      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.rgates + nh, 3 * nh, b.rs, nh, b.rh, nh, MT, nh);
-      wgrad(L_PROP_RNN2, {{b.rh, nh}}, b.d_rnn + 2 * nh, rw, MT);
+      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.rgates + nh, 3 * nh, b.rs[0], nh, b.rh[1], nh, MT, nh);
+      wgrad(L_PROP_RNN2, {{b.rh[1], nh}}, b.d_rnn + 2 * nh, rw, MT);
     }
     wgrad(L_PROP_T1, {{w.r, nh}}, b.d_t1, T1_LD, MT);
     wgrad(L_PROP_T2, {{w.t1, T1_LD}}, b.d_t2, nh, MT);
@@ -657,8 +671,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     if (c.time_cell == CELL_LSTM) {
       wgrad(L_PROP_GRU2, {{tm_all, snh}}, b.d_gru1, gw, MT);   // recurrent rows + b_gates: A = h_{t-1}
     } else if (c.time_cell == CELL_GRU) {
-      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.gr, nh, tm_all, nh, b.rh, nh, MT, nh);
-      wgrad(L_PROP_GRU2, {{b.rh, nh}}, b.d_gru1 + 2 * nh, 3 * nh, MT);
+      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.gr, nh, tm_all, nh, b.rh[2], nh, MT, nh);
+      wgrad(L_PROP_GRU2, {{b.rh[2], nh}}, b.d_gru1 + 2 * nh, 3 * nh, MT);
     }
     wgrad(L_PROP_HEADS, {{w.temporal_p, snh}}, b.d_hraw, HRAW_LD, MT);
     wgrad(L_PROP_S1, {{w.rec_p_all, RW}}, b.d_t1 + nh, T1_LD, MT);
@@ -669,12 +683,12 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     if (c.rec_where_prior) wgrad(L_RNCOND, {{w.rn_init_state, 0}, {w.c, nh}}, b.d_spre, 128, T * R);
     // discovery slot chain (phase 1 of the tapes)
     const size_t ph1 = (size_t)MT;
-    hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_d_all, w.r + ph1 * nh, w.disc_init_rec, w.disc_rnn_init, b.zs,
-                       b.rs, MT, N, nh);
-    wgrad(L_DISC_RNN, {{b.zs, 64}, {b.rs, nh}}, b.d_rnn + ph1 * rw, rw, MT);
+    hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_d_all, w.r + ph1 * nh, w.disc_init_rec, w.disc_rnn_init, b.zs[1],
+                       b.rs[1], MT, N, nh);
+    wgrad(L_DISC_RNN, {{b.zs[1], 64}, {b.rs[1], nh}}, b.d_rnn + ph1 * rw, rw, MT);
     if (c.rnn_cell == RNN_GRU) {
-      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.rgates + ph1 * 3 * nh + nh, 3 * nh, b.rs, nh, b.rh, nh, MT, nh);
-      wgrad(L_DISC_RNN2, {{b.rh, nh}}, b.d_rnn + ph1 * rw + 2 * nh, rw, MT);
+      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.rgates + ph1 * 3 * nh + nh, 3 * nh, b.rs[1], nh, b.rh[3], nh, MT, nh);
+      wgrad(L_DISC_RNN2, {{b.rh[3], nh}}, b.d_rnn + ph1 * rw + 2 * nh, rw, MT);
     }
     wgrad(L_DISC_T1, {{w.r + ph1 * nh, nh}}, b.d_t1 + ph1 * T1_LD, T1_LD, MT);
     wgrad(L_DISC_T2, {{w.t1 + ph1 * T1_LD, T1_LD}}, b.d_t2 + ph1 * nh, nh, MT);
@@ -687,6 +701,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     sq_launch_wgrad_acc(w.s1h + ph1 * S1_LD, S1_LD, b.d_raw + ph1, 1, flat_grad + po.disc_steps_l1_w, 1, MT, nsp, 1, s, nullptr, nullptr,
                         flat_grad + po.disc_steps_l1_b, nullptr);
   }
+  wbatch.flush(s);
   SQ_CHECK_HIP(hipGetLastError());
   return 0;
 }
