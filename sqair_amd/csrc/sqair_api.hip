@@ -809,7 +809,10 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     Lin p; p.seg(w.ienc_b, nh, nh).out(w.pre_disc, rw); RUN(p, L_PREDISC, T * B);
   }
 
-  const bool fuse_prop = can_fuse_tail(h, L_PROP_RNN), fuse_disc = can_fuse_tail(h, L_DISC_RNN);
+  // (the fused launch recomputes a slot's tail in each of the layer's nh / 16 column-tile workgroups: free while the pass is
+  // latency-bound (-0.2 ms at 160 rows), even at 320 rows, a loss from 640 on -- 20.5 us against 5.9 + 5.5 us at 1280 rows)
+  static const int tail_rows = getenv("SQAIR_TAIL_FUSION_ROWS") ? atoi(getenv("SQAIR_TAIL_FUSION_ROWS")) : 320;
+  const bool fuse_prop = d.R <= tail_rows && can_fuse_tail(h, L_PROP_RNN), fuse_disc = d.R <= tail_rows && can_fuse_tail(h, L_DISC_RNN);
   TailArgs pending_tail; memset(&pending_tail, 0, sizeof(pending_tail));
   for (int t = 0; (parts & 2) && t < T; ++t) {
     const int pp = t & 1, pn = pp ^ 1;

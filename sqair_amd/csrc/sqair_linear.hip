@@ -587,7 +587,14 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
     const LinSeg& sg = a.seg[i];
     if ((reinterpret_cast<uintptr_t>(sg.p) & 15) != 0 || (sg.ld & 3) != 0 || sg.width < 1 || sg.rdiv < 1) return -5;
   }
-  if (a.M >= 2048 || (a.M >= 256 && L.kc * L.nt >= 400 && L.kc <= 32)) {  // big batched layers: throughput variants
+  // Launches with thousands of rows: the throughput variants.  Below that the split-K kernel (one 16 x 16 tile per workgroup,
+  // 4 waves on the K range) is the faster one IN THE PASS on every configuration measured -- its time barely moves between 160
+  // and 1920 rows (4.7 -> 5.0 us), while the macro-tile kernels, ahead of it in back-to-back timing of one shape, lost 1 % of
+  // the forward pass at 32 sequences per GPU, 11 % at 64 and at cfg-4 (they were used from 256 rows up until round 2).
+  // Also tried for the 2048+ row launches and dropped: the split-K structure with a 32 x 32 and with a 64 x 64 workgroup tile
+  // (half / a quarter of the operand bytes per output tile): 22 - 25 us against 16 - 17 us on 5120 x 256 x 256, back to back.
+  static const int mt_rows = getenv("SQAIR_MT_ROWS") ? atoi(getenv("SQAIR_MT_ROWS")) : 2048;  // measurement knob
+  if (a.M >= mt_rows) {
     // (all of them accumulate in the same order: the tile shape never changes a result)
     if (L.kc <= 4) {  // K <= 64: one block of loads, nothing to pipeline
       const dim3 grid_r(L.nt, (mt + 3) / 4);

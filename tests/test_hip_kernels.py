@@ -27,7 +27,11 @@ def handle():
 
 @pytest.mark.parametrize("M,K,N,act", [(160, 256, 256, 1), (37, 54, 109, 0), (640, 400, 256, 1), (5, 2500, 256, 1),
                                        (160, 311, 256, 2), (160, 256, 8, 0), (33, 128, 400, 3), (160, 256, 100, 4),
-                                       (16, 16, 16, 0), (1, 3, 1, 0)])
+                                       (16, 16, 16, 0), (1, 3, 1, 0),
+                                       # thousands of rows: the 64 x 64 split-K kernel (ragged last row tile, column tiles past N,
+                                       # K that is not a multiple of 16, fewer chunks than waves, more than two blocks of chunks)
+                                       (2048, 256, 256, 1), (5120, 400, 256, 1), (2100, 311, 109, 2), (2049, 72, 8, 0),
+                                       (3000, 1100, 200, 4), (2048, 40, 64, 3)])
 def test_linear_mfma_matches_fp64(handle, M, K, N, act):
     lib, h, _ = handle
     rng = np.random.default_rng(M * 7 + K)
@@ -59,7 +63,7 @@ def test_linear_identity_asymmetric(handle):
     assert np.array_equal(y.cpu().numpy(), w)
 
 
-@pytest.mark.parametrize("M,Kx", [(160, 360), (640, 54), (7, 17)])
+@pytest.mark.parametrize("M,Kx", [(160, 360), (640, 54), (7, 17), (2304, 360), (2050, 54)])
 def test_gru_step(handle, M, Kx):
     lib, h, _ = handle
     nh = 256
