@@ -1512,8 +1512,8 @@ int sq_launch_gru_bwd_b(const float* d_rh, int drh_ld, const float* rg, int r_ld
 // strided elementwise helpers
 // ------------------------------------------------------------------------------------------------
 // out[m][n] = (acc ? out : 0) + in[m][n] * act'(saved[m][n])   with per-column-range activations (act_a below split)
-__global__ void k_dact2(const float* __restrict__ din, int in_ld, const float* __restrict__ saved, int s_ld,
-                        float* __restrict__ dout, int out_ld, int rows, int cols, int act_a, int act_b, int split, int acc) {
+__global__ void k_dact2(const float* din, int in_ld, const float* __restrict__ saved, int s_ld,
+                        float* dout, int out_ld, int rows, int cols, int act_a, int act_b, int split, int acc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * cols) return;
   const int m = i / cols, n = i - m * cols;

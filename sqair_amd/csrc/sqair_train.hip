@@ -96,7 +96,12 @@ struct Dx {
 struct BwdSpace {
   float *g_lw, *g_dl;
   float *d_rec_m, *d_rec_p, *d_rec_d;          // gradient records
-  float *d_tm[2], *d_pm[2];                    // d temporal / prior merged state, by frame parity
+  // d temporal / prior merged state, one buffer per frame boundary 0..T inside the part of the scratch that is cleared once
+  // per pass (by frame parity they needed a clear per frame: 10 extra launches on the critical path)
+  float *d_tm0, *d_pm0;
+  int64_t tm_stride, pm_stride;
+  float* d_tm(int t) const { return d_tm0 + (size_t)t * tm_stride; }
+  float* d_pm(int t) const { return d_pm0 + (size_t)t * pm_stride; }
   float *d_temporal_p, *d_prior_p;
   float *d_pstats, *d_spre, *d_raw;
   // per-frame pre-activation gradients (kept for the batched weight gradients)
@@ -104,7 +109,7 @@ struct BwdSpace {
   // per-slot pre-activation gradients [2][T][R][N][W]
   float *d_rnn, *d_t1, *d_t2, *d_tp, *d_e1, *d_e2, *d_enc3, *d_gru1, *d_hraw;
   // scratch
-  float *d_mask, *d_g, *d_g1, *d_c, *tmp, *d_r[2], *dhn, *d_rh, *d_enc;
+  float *d_g, *d_g1, *d_c, *tmp, *d_r[2], *dhn, *d_rh, *d_enc;
   float *d_new_t, *d_new_p;                      // [T][R][snh | psnh]: compaction adjoint rows for the initial recurrent states
   float *d_init_p, *d_init_d, *d_rn0;            // per-frame dX rows of the trainable initial states: summed once after the sweep
   float *d_cs[2], *d_hk;                        // LSTM slot RNN: d cell state of the neighbouring slot, d hidden of this one
@@ -135,7 +140,8 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   const int64_t snh = c.time_cell == CELL_LSTM ? 2 * nh : nh, gw = sq_gate_width(c, c.time_cell);  // temporal state / gate widths
   const int64_t psnh = c.prior_cell == CELL_LSTM ? 2 * nh : nh, pgw = sq_gate_width(c, c.prior_cell);
   const int64_t rw = sq_rnn_width(c);  // slot-RNN pre-activation width
-  for (int i = 0; i < 2; ++i) { b.d_tm[i] = take(M * snh); b.d_pm[i] = take(M * psnh); }
+  b.tm_stride = align64(M * snh); b.pm_stride = align64(M * psnh);
+  b.d_tm0 = take((T + 1) * b.tm_stride); b.d_pm0 = take((T + 1) * b.pm_stride);
   b.d_temporal_p = take(M * snh); b.d_prior_p = take(M * psnh);
   b.d_pstats = take(MT * PS_LD); b.d_spre = take(T * R * 128); b.d_raw = take(2 * MT);
   b.d_pgru1 = take(MT * pgw); b.d_hid1 = take(MT * 256); b.d_wb = take(MT * WB_LD); b.d_maskpre = take(MT * G2);
@@ -145,7 +151,7 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   b.d_rnn = take(S * rw); b.d_t1 = take(S * T1_LD); b.d_t2 = take(S * nh); b.d_tp = take(S * TP_LD);
   b.d_e1 = take(S * nh); b.d_e2 = take(S * nh); b.d_enc3 = take(S * ENC_LD); b.d_gru1 = take(MT * gw);
   b.d_hraw = take(MT * HRAW_LD);
-  b.d_mask = take(M * G2); b.d_g = take(R * G2); b.d_g1 = take(M * G2); b.d_c = take(R * nh);
+  b.d_g = take(R * G2); b.d_g1 = take(M * G2); b.d_c = take(R * nh);
   b.tmp = take(M * 512);
   b.d_new_t = take(T * R * snh); b.d_new_p = take(T * R * psnh);
   b.d_init_p = take(T * R * nh); b.d_init_d = take(T * R * nh); b.d_rn0 = take(T * R * 4);
@@ -306,19 +312,18 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     float* d_rec_d_t = b.d_rec_d + (size_t)t * M * RW;
     const float* temporal_prev = w.state(w.temporal_m, t, w.snh);
     const float* prior_prev = w.state(w.prior_m, t, w.psnh);
-    float* d_tau = b.d_tm[t & 1];       // d temporal_m[t]
-    float* d_pprev = b.d_pm[t & 1];     // d prior_m[t]
+    float* d_tau = b.d_tm(t);       // d temporal_m[t]
+    float* d_pprev = b.d_pm(t);     // d prior_m[t]
     const int rl = N * nh, t1l = N * T1_LD, gl2 = N * G2, el = N * ENC_LD, hl = N * HRAW_LD, tpl = N * TP_LD, s1l = N * S1_LD;
 
     // ---- I^T. compaction
     {
       CompactBwdArgs ka; memset(&ka, 0, sizeof(ka));
-      ka.src = w.src + (size_t)t * M; ka.d_rec_next = d_rec_next; ka.d_temporal_next = b.d_tm[(t + 1) & 1];
-      ka.d_prior_next = b.d_pm[(t + 1) & 1]; ka.d_rec_p = d_rec_p_t; ka.d_rec_d = d_rec_d_t;
+      ka.src = w.src + (size_t)t * M; ka.d_rec_next = d_rec_next; ka.d_temporal_next = b.d_tm(t + 1);
+      ka.d_prior_next = b.d_pm(t + 1); ka.d_rec_p = d_rec_p_t; ka.d_rec_d = d_rec_d_t;
       ka.d_temporal_p = b.d_temporal_p; ka.d_prior_p = b.d_prior_p;
       ka.d_new_temporal = b.d_new_t + (size_t)t * R * snh; ka.d_new_prior = b.d_new_p + (size_t)t * R * psnh;
       sq_launch_compact_bwd(ka, po, d, s);
-      sq_zero_fill(d_tau, (int64_t)(d_pprev + (size_t)M * psnh - d_tau), s);  // d_tm[i] and d_pm[i] are carved back to back: one fill
     }
     // ---- G^T. discovery steps
     float* d_pre_d = b.d_pre_d + (size_t)t * R * rw;
@@ -414,7 +419,9 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     }
     // ---- E^T. propagation slots
     float* d_pre = b.d_pre + (size_t)t * M * pre_ld;
-    sq_zero_fill(b.d_mask, align64((int64_t)M * G2), s);
+    // the mask gradient of the frame accumulates in the frame's slice of d_maskpre (cleared with the scratch) and gets the
+    // sigmoid's derivative in place below
+    float* const d_mask_t = b.d_maskpre + (size_t)t * M * G2;
     const float* mask = w.frame(w.mask, (int64_t)M * G2, t);
     for (int k = N - 1; k >= 0; --k) {
       float* d_t1 = slotp(b.d_t1, T1_LD, t, 0, k);
@@ -491,7 +498,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         CropChainBwdArgs ca; memset(&ca, 0, sizeof(ca));
         ca.mode = CROP_PROP2; ca.slot = k; ca.img = img; ca.rec_prev = rec_prev; ca.rec_new = rec_p_t; ca.d_rec_prev = d_rec_prev;
         ca.d_rec_new = d_rec_p_t; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N; ca.mask_row_add = k;
-        ca.d_mask = b.d_mask; ca.g_out = b.d_g; ca.g_row_mul = 1; ca.tp = cslotp(w.tp, TP_LD, t, 0, k); ca.tp_ld = tpl;
+        ca.d_mask = d_mask_t; ca.g_out = b.d_g; ca.g_row_mul = 1; ca.tp = cslotp(w.tp, TP_LD, t, 0, k); ca.tp_ld = tpl;
         ca.d_tp = d_tp; ca.dtp_ld = tpl; ca.noise = nz; ca.flat = flat; ca.flat_grad = flat_grad;
         sq_launch_crop_chain_bwd(ca, po, d, 1, s);
       }
@@ -558,7 +565,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       CropChainBwdArgs ca; memset(&ca, 0, sizeof(ca));
       ca.mode = CROP_PROP1; ca.img = img; ca.rec_prev = rec_prev; ca.d_rec_prev = d_rec_prev; ca.wb = w.frame(w.wb, (int64_t)M * WB_LD, t);
       ca.wb_ld = WB_LD; ca.d_wb = b.d_wb + (size_t)t * M * WB_LD; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N;
-      ca.d_mask = b.d_mask; ca.g_out = b.d_g1; ca.g_row_mul = N; ca.flat = flat; ca.flat_grad = flat_grad;
+      ca.d_mask = d_mask_t; ca.g_out = b.d_g1; ca.g_row_mul = N; ca.flat = flat; ca.flat_grad = flat_grad;
       sq_launch_crop_chain_bwd(ca, po, d, N, s);
     }
     // ---- B^T. mask MLP and where-bias MLP
@@ -567,7 +574,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       float* d_hid1 = b.d_hid1 + (size_t)t * M * 256;
       const float* hid1 = w.frame(w.hid1, (int64_t)M * 256, t);
       if (c.masked_glimpse) {
-        sq_launch_dact2(b.d_mask, G2, mask, G2, d_maskpre, G2, M, G2, ACT_SIGMOID, ACT_SIGMOID, 1 << 30, 0, s);
+        sq_launch_dact2(d_mask_t, G2, mask, G2, d_maskpre, G2, M, G2, ACT_SIGMOID, ACT_SIGMOID, 1 << 30, 0, s);  // in place
         Dx x(d_maskpre, G2); x.to(0, 128, d_hid1 + 128, 256).dact(hid1 + 128, 256, ACT_ELU); CK(rundx(L_MASK2, x, M));
       }
       { Dx x(b.d_wb + (size_t)t * M * WB_LD, WB_LD); x.to(0, 128, d_hid1, 256).dact(hid1, 256, ACT_ELU); CK(rundx(L_WB2, x, M)); }
@@ -620,8 +627,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   if (c.rec_where_prior) sq_launch_colsum(b.d_rn0, 4, T * R, 4, flat_grad + po.rn_init_state, 1, s);
   sq_launch_colsum(b.d_new_t, snh, T * R, snh, flat_grad + po.temporal_init, 1, s);
   sq_launch_colsum(b.d_new_p, psnh, T * R, psnh, flat_grad + po.prior_init, 1, s);
-  sq_launch_colsum(b.d_tm[0], snh, M, snh, flat_grad + po.temporal_init, 1, s);
-  sq_launch_colsum(b.d_pm[0], psnh, M, psnh, flat_grad + po.prior_init, 1, s);
+  sq_launch_colsum(b.d_tm(0), snh, M, snh, flat_grad + po.temporal_init, 1, s);
+  sq_launch_colsum(b.d_pm(0), psnh, M, psnh, flat_grad + po.prior_init, 1, s);
   {
     const int TB = T * B;
     CK(dx(L_PREDISC, b.d_pre_disc, rw, TB, b.tmp, nh, false));
