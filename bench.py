@@ -161,10 +161,22 @@ def main():
         kw = dict(device_id=torch.device("cuda", local_rank)) if backend == "nccl" else {}
         dist.init_process_group(backend=backend, **kw)  # "nccl" = RCCL on ROCm
     # the training step's gradient all-reduce goes through RCCL's C API on the library's own launch stream
-    comm = None
+    comm, comm_error = None, None
     if dist is not None and backend == "nccl":
         from sqair_amd.rccl import RcclComm
-        comm = RcclComm.from_process_group("cuda:{}".format(local_rank))
+        try:
+            comm = RcclComm.from_process_group("cuda:{}".format(local_rank))
+        except Exception as e:  # e.g. the bundled librccl.so cannot be opened a second time through ctypes
+            comm_error = "{}: {}".format(type(e).__name__, e)
+        # all ranks or none: a rank without the native communicator sends everybody to the process group's all-reduce
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda:{}".format(local_rank))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.destroy()
+            comm = None
+        if comm is None and rank == 0:
+            print("bench: native RCCL communicator unavailable ({}); gradient all-reduce through torch.distributed".format(
+                comm_error or "failed on another rank"), file=sys.stderr)
 
     from sqair_amd.data import config_inputs
     from sqair_amd.flags import make_flags

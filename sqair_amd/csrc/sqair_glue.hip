@@ -319,7 +319,9 @@ __global__ __launch_bounds__(256) void k_rnn_tail(const TailArgs ta, const Dims 
   if (m < d.R && n < n_out) out[(size_t)m * out_ld + n] = sq_tanh(red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + p_bias + p_add);
   if (prof_ts != nullptr) {
     __syncthreads();
-    if (tid == 0) {
+    // (stamped by the last column-tile workgroup of every row tile and by workgroup (0, 0) only: one atomic pair per workgroup
+    // serialises thousands of them on one address and made the many-workgroup launches look 2-3x longer than they are)
+    if (tid == 0 && (blockIdx.x == gridDim.x - 1 || (blockIdx.x == 0 && blockIdx.y == 0))) {
       atomicMin(prof_ts, t_start);
       atomicMax(prof_ts + 4096, wall_clock64());
     }

@@ -181,7 +181,9 @@ __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int 
   }
   if (prof_ts != nullptr) {
     __syncthreads();
-    if (tid == 0) {
+    // (stamped by the last column-tile workgroup of every row tile and by workgroup (0, 0) only: one atomic pair per workgroup
+    // serialises thousands of them on one address and made the many-workgroup launches look 2-3x longer than they are)
+    if (tid == 0 && (blockIdx.x == gridDim.x - 1 || (blockIdx.x == 0 && blockIdx.y == 0))) {
       atomicMin(prof_ts, t_start);
       atomicMax(prof_ts + 4096, wall_clock64());
     }
@@ -364,7 +366,9 @@ __global__ __launch_bounds__(256) void k_linear_mt(const LinArgs a, const int kc
   }
   if (prof_ts != nullptr) {
     __syncthreads();
-    if (tid == 0) {
+    // (stamped by the last column-tile workgroup of every row tile and by workgroup (0, 0) only: one atomic pair per workgroup
+    // serialises thousands of them on one address and made the many-workgroup launches look 2-3x longer than they are)
+    if (tid == 0 && (blockIdx.x == gridDim.x - 1 || (blockIdx.x == 0 && blockIdx.y == 0))) {
       atomicMin(prof_ts, t_start);
       atomicMax(prof_ts + 4096, wall_clock64());
     }
@@ -513,7 +517,9 @@ __global__ __launch_bounds__(256) void k_linear_lds(const LinArgs a, const int k
   }
   if (prof_ts != nullptr) {
     __syncthreads();
-    if (tid == 0) {
+    // (stamped by the last column-tile workgroup of every row tile and by workgroup (0, 0) only: one atomic pair per workgroup
+    // serialises thousands of them on one address and made the many-workgroup launches look 2-3x longer than they are)
+    if (tid == 0 && (blockIdx.x == gridDim.x - 1 || (blockIdx.x == 0 && blockIdx.y == 0))) {
       atomicMin(prof_ts, t_start);
       atomicMax(prof_ts + 4096, wall_clock64());
     }
