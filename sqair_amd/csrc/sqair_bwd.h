@@ -52,6 +52,9 @@ struct CropChainBwdArgs {
   const float* tp; int tp_ld;            // saved transform output (loc 0:4, raw 4:8)
   float* d_tp; int dtp_ld;               // out
   const float* noise; const float* flat; float* flat_grad;
+  // optional: the adjoint of the transform's output layer (nh -> 8, fused into the crop on the way forward) in the same launch:
+  // d_t2[r][j] = (sum_o d_tp[r][o] w3[j][o]) * elu'(t2[r][j]); w3 = [nh][8] as the forward crop reads it
+  const float* w3; const float* t2; int t2_ld; float* d_t2; int dt2_ld;
 };
 
 int sq_launch_logprob_bwd(const LogprobBwdArgs& a, POff po, Dims d, int T, hipStream_t s);

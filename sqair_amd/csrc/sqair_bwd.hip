@@ -1276,6 +1276,7 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* img_s = smem;
   __shared__ float red_s[4][4];
+  __shared__ float dtp_s[8];
   // one workgroup per particle row (the K particles of a sequence re-stage the same frame from L2: 10 KB at 50x50)
   const int r = blockIdx.x, b = r / d.K, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int slot = a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot;
@@ -1319,6 +1320,15 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
         for (int j = 0; j < 4; ++j) q_ch[j] = tril4(a.flat + po.cholesky, ci, min(j, ci));
       }
     }
+  }
+  // operands of the fused output-layer adjoint: this thread's row of w3 and its saved activation
+  const bool fuse_t3 = a.d_t2 != nullptr && a.mode != CROP_PROP1;
+  f32x4_b w3a = {0.0f, 0.0f, 0.0f, 0.0f}, w3b = w3a;
+  float t2v = 0.0f;
+  if (fuse_t3 && tid < d.nh) {
+    w3a = *reinterpret_cast<const f32x4_b*>(a.w3 + (size_t)tid * 8);
+    w3b = *reinterpret_cast<const f32x4_b*>(a.w3 + (size_t)tid * 8 + 4);
+    t2v = a.t2[(size_t)r * a.t2_ld + tid];
   }
   for (int i = tid; i < P; i += 256) img_s[i] = img[i];
   __syncthreads();
@@ -1392,9 +1402,24 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
         }
         a.d_tp[(size_t)r * a.dtp_ld + i] = d_loc;
         a.d_tp[(size_t)r * a.dtp_ld + 4 + i] = d_raw;
+        dtp_s[i] = d_loc;
+        dtp_s[4 + i] = d_raw;
         // total gradient of the sample, kept for k_where_param_grads (scale offsets / Cholesky factor: one batched
         // reduction over all uses at the end of the sweep instead of 640-way contended atomics per launch)
         drn[rec::WHERE + i] = dW;
+      }
+    }
+    if (fuse_t3) {  // (wave-uniform) d t2 = d tp W3^T, times elu' from the saved output
+      __syncthreads();
+      for (int j = tid; j < d.nh; j += 256) {
+        if (j >= 256) {
+          w3a = *reinterpret_cast<const f32x4_b*>(a.w3 + (size_t)j * 8);
+          w3b = *reinterpret_cast<const f32x4_b*>(a.w3 + (size_t)j * 8 + 4);
+          t2v = a.t2[(size_t)r * a.t2_ld + j];
+        }
+        const float g = dtp_s[0] * w3a[0] + dtp_s[1] * w3a[1] + dtp_s[2] * w3a[2] + dtp_s[3] * w3a[3] + dtp_s[4] * w3b[0] +
+                        dtp_s[5] * w3b[1] + dtp_s[6] * w3b[2] + dtp_s[7] * w3b[3];
+        a.d_t2[(size_t)r * a.dt2_ld + j] = g * delu_from_out(t2v);
       }
     }
   }

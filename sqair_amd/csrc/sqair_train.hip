@@ -299,6 +299,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     sq_launch_logprob_bwd(la, po, d, T, s);
   }
 
+  // the adjoint of the transform's 8-wide output layer rides in the crop adjoint that produces its input (80 launches fewer)
+  const bool fuse_t3 = getenv("SQAIR_NO_T3_FUSION") == nullptr;
   // ================= reverse sweep over the frames =================
   for (int t = T - 1; t >= 0; --t) {
     const float* img = obs + (size_t)t * B * P_;
@@ -359,9 +361,10 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         ca.mode = CROP_DISC; ca.slot = j; ca.img = img; ca.rec_prev = rec_prev; ca.rec_new = rec_d_t; ca.d_rec_prev = d_rec_prev;
         ca.d_rec_new = d_rec_d_t; ca.g_out = b.d_g; ca.g_row_mul = 1; ca.tp = cslotp(w.tp, TP_LD, t, 1, j); ca.tp_ld = tpl;
         ca.d_tp = d_tp; ca.dtp_ld = tpl; ca.noise = nz; ca.flat = flat; ca.flat_grad = flat_grad;
+        if (fuse_t3) { ca.w3 = w.w3_disc; ca.t2 = t2; ca.t2_ld = rl; ca.d_t2 = d_t2; ca.dt2_ld = rl; }
         sq_launch_crop_chain_bwd(ca, po, d, 1, s);
       }
-      { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_DISC_T3, x, R)); }
+      if (!fuse_t3) { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_DISC_T3, x, R)); }
       { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU); CK(rundx(L_DISC_T2, x, R)); }
       if (c.rnn_cell == RNN_LSTM) {  // d h_j = T1^T + the next slot's RNN; cell adjoint -> gate pre-activation gradients, d c_{j-1}
         Dx x(d_t1, t1l); x.to(0, nh, b.d_hk, nh);
@@ -500,9 +503,10 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         ca.d_rec_new = d_rec_p_t; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N; ca.mask_row_add = k;
         ca.d_mask = d_mask_t; ca.g_out = b.d_g; ca.g_row_mul = 1; ca.tp = cslotp(w.tp, TP_LD, t, 0, k); ca.tp_ld = tpl;
         ca.d_tp = d_tp; ca.dtp_ld = tpl; ca.noise = nz; ca.flat = flat; ca.flat_grad = flat_grad;
+        if (fuse_t3) { ca.w3 = w.w3_prop; ca.t2 = t2; ca.t2_ld = rl; ca.d_t2 = d_t2; ca.dt2_ld = rl; }
         sq_launch_crop_chain_bwd(ca, po, d, 1, s);
       }
-      { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_PROP_T3, x, R)); }
+      if (!fuse_t3) { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_PROP_T3, x, R)); }
       { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU).dup(d_pre_k + rw, pre_rld); CK(rundx(L_PROP_T2, x, R)); }
       if (c.rnn_cell == RNN_LSTM) {  // d h_k total, then the cell adjoint (second copy: this slot's block of d_pre)
         Dx x(d_t1, t1l);
