@@ -1190,9 +1190,21 @@ __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, cons
   extern __shared__ float wt_s[];  // the `what` rows of steps.l0.w, [nw][nsp + 1] (padded: conflict-free row reads)
   const int r = blockIdx.x, tid = threadIdx.x, nw = d.nw, nsp = d.nh / 2, RW = rec::W;
   const int sh = 31 - __clz(nsp);  // nsp = nh / 2 is 64 or 128 (sqair_create): shifts instead of 50 integer divisions per thread
-  for (int e = tid; e < nw * nsp; e += 128) {  // coalesced, independent loads: one round trip
-    const int c = e >> sh, i = e & (nsp - 1);
-    wt_s[c * (nsp + 1) + i] = a.flat[a.wwhat_off + e];
+  {  // coalesced loads, 25 per thread in flight at once (the plain loop compiled to 8 in flight + waits: seven dependent round
+     // trips for the 50 x 128 block of the shipped sizes, two now)
+    constexpr int U = 25;
+    const int total = nw * nsp;
+    const float* __restrict__ wsrc = a.flat + a.wwhat_off;
+    for (int base = 0; base < total; base += 128 * U) {
+      float v[U];
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = wsrc[min(base + tid + 128 * q, total - 1)];
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int e = base + tid + 128 * q;
+        if (e < total) wt_s[(e >> sh) * (nsp + 1) + (e & (nsp - 1))] = v[q];
+      }
+    }
   }
   const float* rn = a.rec_new + ((size_t)r * d.N + a.slot) * RW;
   float* drn = a.d_rec_new + ((size_t)r * d.N + a.slot) * RW;
@@ -1330,7 +1342,20 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
     w3b = *reinterpret_cast<const f32x4_b*>(a.w3 + (size_t)tid * 8 + 4);
     t2v = a.t2[(size_t)r * a.t2_ld + tid];
   }
-  for (int i = tid; i < P; i += 256) img_s[i] = img[i];
+  {  // frame -> LDS in 16-byte units, 4 loads per thread in flight at once (H * W is a multiple of 4: sqair_create checks).  The
+     // plain copy loop compiled to three or four dependent round trips (an unrolled trip + remainder loops waiting per element).
+    const int n4 = P >> 2;
+    const f32x4_b* __restrict__ s4 = reinterpret_cast<const f32x4_b*>(img);
+    f32x4_b* d4 = reinterpret_cast<f32x4_b*>(img_s);
+    for (int base = 0; base < n4; base += 1024) {
+      f32x4_b v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = s4[min(base + tid + 256 * q, n4 - 1)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (base + tid + 256 * q < n4) d4[base + tid + 256 * q] = v[q];
+    }
+  }
   __syncthreads();
   {
     const float s0 = sq_sigmoid(wl[0]), s1 = sq_sigmoid(wl[1]);
