@@ -140,6 +140,12 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
                                  : a.rec_prev + ((size_t)pr * d.N + a.slot) * rec::W + rec::PRES;
   float prev = *prevp;
   if (a.is_disc && a.slot == 0) prev = 1.0f;
+  float whv[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // where sample of the slot (written by its crop launch): requested with the rest,
+  if (FULL_Z && tid < 16) {                  // not behind the last barrier where it cost a memory round trip of its own
+    const float* wh = a.rec_new + ((size_t)pr * d.N + a.slot) * rec::W + rec::WHERE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) whv[q] = wh[q];
+  }
   // ---- what sample for the 16 rows (nw elements each), operands requested in one burst
   constexpr int EPT = 4;
   const int nel = 16 * nw;
@@ -247,9 +253,8 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
     if (FULL_Z) {  // (after the hidden-layer MFMAs have read the tile: they want zeros outside the what columns)
       zt[tid * ZLD + rec::PRES] = pres;
       zt[tid * ZLD + rec::LOGIT] = logit;
-      const float* wh = a.rec_new + ((size_t)pr * d.N + a.slot) * rec::W + rec::WHERE;  // written by this slot's crop launch
 #pragma unroll
-      for (int q = 0; q < 4; ++q) zt[tid * ZLD + rec::WHERE + q] = wh[q];
+      for (int q = 0; q < 4; ++q) zt[tid * ZLD + rec::WHERE + q] = whv[q];
     }
   }
 }

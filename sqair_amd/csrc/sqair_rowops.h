@@ -70,10 +70,35 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
       float part[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       const float* xrow = a.t2 + (size_t)r * a.t2_ld + per * hl;
       const float4* w4 = reinterpret_cast<const float4*>(a.w3) + (size_t)per * hl * 2;
-      sq_f32x4 xv[4];  // per / 4 <= 4 (nh <= 512)
-      for (int q = 0; q < per / 4; ++q) xv[q] = LD::f4(xrow + 4 * q);
-      for (int q = 0; q < per / 4; ++q) {
-        const sq_f32x4 x = xv[q];
+      // Every load of the layer is requested before the first product (compile-time trip counts, clamped addresses): with the
+      // runtime bound per / 4 the two loops below were four dependent memory round trips (activations one by one, then the
+      // weights of each group of 4 inputs) on the critical path of every slot.  nh <= 256 => per / 4 <= 2; sums in the same order.
+      constexpr int QM = 2;
+      const int nq = per / 4;
+      sq_f32x4 xv[QM];
+      float4 wv[QM][4][2];
+#pragma unroll
+      for (int q = 0; q < QM; ++q) {
+        const int qc = min(q, nq - 1);
+        xv[q] = LD::f4(xrow + 4 * qc);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) { wv[q][ii][0] = w4[(qc * 4 + ii) * 2]; wv[q][ii][1] = w4[(qc * 4 + ii) * 2 + 1]; }
+      }
+#pragma unroll
+      for (int q = 0; q < QM; ++q) {
+        if (q < nq) {
+          const sq_f32x4 x = xv[q];
+          const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii) {
+            const float4 wa = wv[q][ii][0], wb2 = wv[q][ii][1];
+            part[0] += xs[ii] * wa.x; part[1] += xs[ii] * wa.y; part[2] += xs[ii] * wa.z; part[3] += xs[ii] * wa.w;
+            part[4] += xs[ii] * wb2.x; part[5] += xs[ii] * wb2.y; part[6] += xs[ii] * wb2.z; part[7] += xs[ii] * wb2.w;
+          }
+        }
+      }
+      for (int q = QM; q < nq; ++q) {  // (wider hidden layers than the library is built for)
+        const sq_f32x4 x = LD::f4(xrow + 4 * q);
         const float xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
