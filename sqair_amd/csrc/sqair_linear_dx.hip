@@ -62,9 +62,14 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
   const int m = tile_m * 16 + (tid >> 4);
   const int n = tile_n * 16 + (tid & 15);
   const int mc = min(m, a.M - 1);
+  // The range of a column is the same for the whole workgroup (range starts are multiples of 16: the launcher checks), so it is
+  // picked from the tile index alone: a WAVE-UNIFORM index into the by-value argument struct becomes scalar loads.  With the
+  // per-lane column in the comparison every field of the range (pointers, leading dimensions, activation codes) was fetched
+  // by a vector load from the argument segment followed by a full wait -- a dozen dependent round trips per launch.
+  const int n_tile0 = tile_n * 16;
   int ri = 0;
-  if (a.nranges > 1 && n >= a.r[1].n0) ri = 1;
-  if (a.nranges > 2 && n >= a.r[2].n0) ri = 2;
+  if (a.nranges > 1 && n_tile0 >= a.r[1].n0) ri = 1;
+  if (a.nranges > 2 && n_tile0 >= a.r[2].n0) ri = 2;
   const DxRange& rg = a.r[ri];
   const bool live = m < a.M && n >= rg.n0 && n < rg.n1;
   const int c = live ? n - rg.n0 : 0;
@@ -72,7 +77,9 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
   const float* pa = (live && rg.add != nullptr) ? rg.add + (size_t)mc * rg.add_ld + c : dummy;
   const float* ps = (live && rg.saved != nullptr) ? rg.saved + (size_t)mc * rg.saved_ld + c : dummy;
   const float p_add = *pa, p_saved = *ps;
-  const float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : dummy);
+  float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : dummy);
+  p_scale = a.scale_ptr != nullptr ? p_scale : 1.0f;  // used unconditionally below: a load that is only used under a condition
+                                                       // is sunk into it, i.e. behind the barrier (one more round trip)
   float q_g0 = 0.0f, q_g1 = 0.0f, q_h = 0.0f, q_dh = 0.0f;
   if (GRU != 0) {  // gate tapes of the GRU adjoint (columns 0 .. nh - 1 of range 0)
     const int cg = min(c, a.gru.nh - 1);
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
   __syncthreads();
   if (live) {
     float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
-    if (a.scale_ptr != nullptr) v *= p_scale;
+    v *= p_scale;
     if (rg.add != nullptr) v += p_add;
     if (rg.saved != nullptr) v = dx_dact(v, p_saved, c < rg.act_split ? rg.act_a : rg.act_b);
     if (GRU == 1) {
@@ -128,6 +135,8 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
 
 int sq_launch_linear_dx(const DxArgs& a, int kc, int nt, hipStream_t s) {
   if ((reinterpret_cast<uintptr_t>(a.dpre) & 15) != 0 || (a.ld & 3) != 0 || a.width < 1 || a.nranges < 1 || a.nranges > 3) return -5;
+  for (int i = 0; i < a.nranges; ++i)
+    if ((a.r[i].n0 & 15) != 0) return -5;  // a column tile belongs to one range
   const dim3 g(nt, (a.M + 15) / 16);
   if (g.x == 0 || g.y == 0) return 0;
   const int per_wave = (kc + 3) / 4;
