@@ -73,13 +73,18 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
   const DxRange& rg = a.r[ri];
   const bool live = m < a.M && n >= rg.n0 && n < rg.n1;
   const int c = live ? n - rg.n0 : 0;
+  // activation codes as scalars NOW: left as `c < split ? rg.act_a : rg.act_b` at the use, the select became a per-lane ADDRESS
+  // into the argument segment and a vector load + full wait behind the barrier
+  const int act_a = __builtin_amdgcn_readfirstlane(rg.act_a), act_b = __builtin_amdgcn_readfirstlane(rg.act_b),
+            act_split = __builtin_amdgcn_readfirstlane(rg.act_split);
   const float* dummy = wzero0;
   const float* pa = (live && rg.add != nullptr) ? rg.add + (size_t)mc * rg.add_ld + c : dummy;
   const float* ps = (live && rg.saved != nullptr) ? rg.saved + (size_t)mc * rg.saved_ld + c : dummy;
   const float p_add = *pa, p_saved = *ps;
-  float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : dummy);
-  p_scale = a.scale_ptr != nullptr ? p_scale : 1.0f;  // used unconditionally below: a load that is only used under a condition
-                                                       // is sunk into it, i.e. behind the barrier (one more round trip)
+  // (per-lane address on purpose: as a wave-uniform load hipcc sinks it to its use behind the barrier, where it costs every
+  // launch a memory round trip of its own)
+  float p_scale = (a.scale_ptr != nullptr ? a.scale_ptr : dummy + (tid & 15))[0];
+  p_scale = a.scale_ptr != nullptr ? p_scale : 1.0f;
   float q_g0 = 0.0f, q_g1 = 0.0f, q_h = 0.0f, q_dh = 0.0f;
   if (GRU != 0) {  // gate tapes of the GRU adjoint (columns 0 .. nh - 1 of range 0)
     const int cg = min(c, a.gru.nh - 1);
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
     float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
     v *= p_scale;
     if (rg.add != nullptr) v += p_add;
-    if (rg.saved != nullptr) v = dx_dact(v, p_saved, c < rg.act_split ? rg.act_a : rg.act_b);
+    if (rg.saved != nullptr) v = dx_dact(v, p_saved, c < act_split ? act_a : act_b);
     if (GRU == 1) {
       const int nh = a.gru.nh;
       const float dz = v * (q_g1 - q_h) * q_g0 * (1.0f - q_g0), dc = v * q_g0 * (1.0f - q_g1 * q_g1);
