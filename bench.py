@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--cfg", type=int, default=2, help="BASELINE.json config id used as the workload (default 2)")
     ap.add_argument("--train-steps", type=int, default=-1,
                     help="steps of the extra training-step leg (default min(steps, 20); 0 = skip)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="extra object \"streams\": forward passes of this many INDEPENDENT batches in flight on their own "
+                         "streams (0 = skip; single GPU only; never part of `value`)")
     ap.add_argument("--batch", type=int, default=0,
                     help="sequences per GPU (default: the configuration's own; other values are batch-scaling experiments, "
                          "not BASELINE's metric)")
@@ -286,6 +289,45 @@ def main():
                           "RMSProp + re-pack; finite={}".format(bool(torch.isfinite(core.flat).all())))
         core.set_params(P)  # back to the benchmark parameters for the parity / roofline legs below
 
+    # ---- independent batches in flight (extra object "streams"): handles share nothing, so n of them replaying their graphs on
+    # n streams overlap their dependent-launch chains.  Throughput of evaluation / serving, NOT the metric's one-pass-at-a-time rate.
+    streams = None
+    if world == 1 and use_graph and args.streams > 1:
+        try:
+            from sqair_amd.data import make_sequences, to_float
+            cores = [core]
+            for i in range(1, args.streams):
+                d_i = make_sequences(B, T=T, canvas=hw, n_objects=(0, nums.shape[-1] - 1), obj_size=28 if hw[0] <= 64 else 72,
+                                     seed=4321 + i)
+                c_i = SqairCore(F, hw, device=device)
+                with c_i.on_stream():
+                    c_i.set_params(P)
+                    Model(to_float(d_i["imgs"]), None, c_i, K, presence=d_i["nums"], outputs="minimal")
+                cores.append(c_i)
+
+            def round_(k):
+                for i, c_i in enumerate(cores):
+                    with c_i.on_stream():
+                        c_i.draw_noise(seed=3000 + i, step=k, global_batch=B, b0=0)
+                        c_i.forward(use_graph=True)
+            for k in range(3):
+                round_(k)
+            torch.cuda.synchronize()
+            n_rounds = max(5, args.steps // 2)
+            t0 = time.perf_counter()
+            for k in range(n_rounds):
+                round_(3 + k)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            streams = dict(passes_in_flight=len(cores), value=len(cores) * B * T * n_rounds / el, unit="frames/s",
+                           ms_per_round=el / n_rounds * 1e3, rounds=n_rounds,
+                           what="{} independent batches of {} sequences (own handle, stream, graph, data, noise) per round; every "
+                                "pass = noise draw + graph replay + ELBO".format(len(cores), B))
+            del cores[1:]
+            torch.cuda.set_stream(core.stream)
+        except Exception as e:  # never take the bench line down
+            streams = dict(error="{}: {}".format(type(e).__name__, e))
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -406,7 +448,7 @@ def main():
             args.cfg, T, hw[0], hw[1], B, K, N, args.transition, args.time_transition, args.prior_transition, use_graph), "global_batch": B * world, "seq_len": T,
             "parallelism": "dp{}".format(world), "graph_nodes": core.graph_nodes()},
         "elbo_iwae_nats_per_seq": elbo, "elbo_vae_nats_per_seq": elbo_vae,
-        "roofline": roofline, "cpu_baseline": cpu, "train": train,
+        "roofline": roofline, "cpu_baseline": cpu, "train": train, "streams": streams,
     }
     if cpu is not None:
         line["speedup_vs_cpu_baseline"] = value / world / cpu["value"]
