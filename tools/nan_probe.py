@@ -1,0 +1,82 @@
+"""Trains with the reference recipe (tools/train_demo.py's setting) and checks the gradient after EVERY step: at the first
+non-finite value prints which parameters are affected and the state of the forward pass that produced it.
+    python tools/nan_probe.py [steps] [flag=value ...]"""
+import sys
+
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+
+from sqair_amd.data import make_sequences, to_float
+from sqair_amd.dataio import MinibatchFeed
+from sqair_amd.flags import make_flags
+from sqair_amd.model import Model, SqairCore
+from sqair_amd.params import init_params
+from sqair_amd.train import Trainer
+
+over = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a)
+args = [a for a in sys.argv[1:] if "=" not in a]
+steps = int(args[0]) if args else 8000
+T, B, K, hw = 10, 32, 5, (50, 50)
+N = int(over.get("n_steps_per_image", 3))
+over_f = {k: v for k, v in over.items() if k != "seed"}
+F = make_flags(**dict(dict(k_particles=K, n_steps_per_image=N, learning_rate=1e-5, train_itr=2000000, disc_step_bias=5), **over_f))
+train = make_sequences(2048, T=T, canvas=hw, n_objects=(0, 2), seed=1)
+feed = MinibatchFeed(dict(imgs=to_float(train["imgs"]), nums=train["nums"], coords=train["coords"]), B, shuffle=True, seed=0)
+mean_img = to_float(train["imgs"]).mean((0, 1))
+core = SqairCore(F, hw)
+core.set_params({k: np.asarray(v, dtype=np.float32) for k, v in init_params(F, hw, seed=0, mean_img=mean_img).items()})
+names = ["log_weights_per_timestep", "discrete_log_prob", "presence", "what_scale", "where_scale", "what", "where", "what_loc", "where_loc",
+         "presence_logit", "presence_prob"]
+model = Model(to_float(train["imgs"][:T, :B]), None, core, K, outputs=names)
+trainer = Trainer(model, F)
+gen = torch.Generator(device="cuda").manual_seed(int(over.get("seed", 0)))
+spec = core.spec
+hist = []
+ch_off = 0
+for entry in spec:
+    if entry[0] == "prop.cholesky_scale":
+        break
+    ch_off += int(np.prod(entry[1]))
+for it in range(steps):
+    batch = feed.next(it)
+    g = trainer.step(obs=batch["imgs"], generator=gen)
+    with core.on_stream():
+        gmax = float(g.abs().max())
+        fin = bool(torch.isfinite(g).all()) and bool(torch.isfinite(core.flat).all())
+        elbo = float(core.scalars[1]) / core.T
+    hist.append((it, gmax, elbo))
+    if gmax > 2e3 and fin:
+        with core.on_stream():
+            i = int(g.abs().argmax())
+        off = 0
+        for entry in spec:
+            n = int(np.prod(entry[1]))
+            if off <= i < off + n:
+                with core.on_stream():
+                    ch = core.flat[ch_off:ch_off + 10].cpu().numpy()
+                    ws = float(core.out["where_scale"].min())
+                # fill_triangular(v) for n = 4: diagonal entries are v[4], v[9], v[0]?? -> print all ten, the diagonal of T is (v[4+0], v[4+5]...) see oracle
+                print("step %d  max|grad| %.3e at %s[%d]  elbo/frame %.2f  min where_scale %.4f  cholesky_scale %s" % (
+                    it, gmax, entry[0], i - off, elbo, ws, np.array2string(ch, precision=3)), flush=True)
+                break
+            off += n
+    if not fin or it % 500 == 0:
+        print("step %d  max|grad| %.3e  elbo/frame %.2f" % (it, gmax, elbo), flush=True)
+    if not fin:
+        print("last 8 steps:", hist[-8:])
+        gg = g.cpu().numpy(); fl = core.flat.cpu().numpy()
+        off = 0
+        for entry in spec:
+            name, shape = entry[0], entry[1]
+            n = int(np.prod(shape))
+            a, p = gg[off:off + n], fl[off:off + n]
+            if not np.isfinite(a).all() or not np.isfinite(p).all():
+                print("  non-finite: %-40s grad nan %d inf %d | param nan %d" % (name, np.isnan(a).sum(), np.isinf(a).sum(), np.isnan(p).sum()))
+            off += n
+        for k in names:
+            v = core.out[k].cpu().numpy()
+            print("  out %-28s finite %s  min %.4g max %.4g" % (k, np.isfinite(v).all(), np.nanmin(v), np.nanmax(v)))
+        break
+else:
+    print("no non-finite value in %d steps; max|grad| over the run %.3e" % (steps, max(h[1] for h in hist)))
