@@ -17,9 +17,9 @@ from sqair_amd.train import Trainer
 over = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a)
 args = [a for a in sys.argv[1:] if "=" not in a]
 steps = int(args[0]) if args else 8000
-T, B, K, hw = 10, 32, 5, (50, 50)
+T, B, K, hw = int(over.get("T", 10)), 32, 5, (50, 50)
 N = int(over.get("n_steps_per_image", 3))
-over_f = {k: v for k, v in over.items() if k != "seed"}
+over_f = {k: v for k, v in over.items() if k not in ("seed", "T")}
 F = make_flags(**dict(dict(k_particles=K, n_steps_per_image=N, learning_rate=1e-5, train_itr=2000000, disc_step_bias=5), **over_f))
 train = make_sequences(2048, T=T, canvas=hw, n_objects=(0, 2), seed=1)
 feed = MinibatchFeed(dict(imgs=to_float(train["imgs"]), nums=train["nums"], coords=train["coords"]), B, shuffle=True, seed=0)
