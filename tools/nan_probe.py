@@ -19,7 +19,7 @@ args = [a for a in sys.argv[1:] if "=" not in a]
 steps = int(args[0]) if args else 8000
 T, B, K, hw = int(over.get("T", 10)), 32, 5, (50, 50)
 N = int(over.get("n_steps_per_image", 3))
-over_f = {k: v for k, v in over.items() if k not in ("seed", "T")}
+over_f = {k: v for k, v in over.items() if k not in ("seed", "T", "spike")}
 F = make_flags(**dict(dict(k_particles=K, n_steps_per_image=N, learning_rate=1e-5, train_itr=2000000, disc_step_bias=5), **over_f))
 train = make_sequences(2048, T=T, canvas=hw, n_objects=(0, 2), seed=1)
 feed = MinibatchFeed(dict(imgs=to_float(train["imgs"]), nums=train["nums"], coords=train["coords"]), B, shuffle=True, seed=0)
@@ -38,14 +38,44 @@ for entry in spec:
     if entry[0] == "prop.cholesky_scale":
         break
     ch_off += int(np.prod(entry[1]))
+spike = float(over.get("spike", 0))   # spike=1e4: at the first finite gradient above it, recompute that gradient with the fp64 oracle
 for it in range(steps):
     batch = feed.next(it)
-    g = trainer.step(obs=batch["imgs"], generator=gen)
+    if spike:
+        with core.on_stream():
+            flat_before = core.flat.clone()
+    g = trainer.step(obs=batch["imgs"][:T], generator=gen)
     with core.on_stream():
         gmax = float(g.abs().max())
         fin = bool(torch.isfinite(g).all()) and bool(torch.isfinite(core.flat).all())
         elbo = float(core.scalars[1]) / core.T
     hist.append((it, gmax, elbo))
+    if spike and fin and gmax > spike:
+        from oracle import sqair_oracle as O
+        from sqair_amd.params import unflatten_params
+        print("step %d: max|grad| %.3e -- recomputing with the fp64 oracle (same parameters, frames, noise)" % (it, gmax), flush=True)
+        with core.on_stream():
+            P0 = unflatten_params(flat_before.cpu().numpy(), spec)
+            noise = core.noise.cpu().numpy().reshape(T, B * K, 2, N, -1)
+            obs = core.obs.cpu().numpy().reshape(T, B, hw[0], hw[1])
+            got = g.cpu().numpy().copy()
+        orc = O.SqairOracle({k: np.asarray(v, dtype=np.float64) for k, v in P0.items()}, O.make_cfg(F, hw), torch.float64, requires_grad=True)
+        ref = orc.model(obs, noise)
+        orc.make_target(ref).backward()
+        pres_same = np.array_equal(core.out["presence"].cpu().numpy().reshape(-1), ref.outputs["presence"].detach().numpy().reshape(-1))
+        print("presence decisions identical: %s" % pres_same)
+        off = 0
+        rows = []
+        for entry in spec:
+            n = int(np.prod(entry[1]))
+            w = orc.P[entry[0]].grad
+            w = np.zeros(n) if w is None else w.numpy().reshape(-1)
+            a = got[off:off + n]
+            rows.append((float(np.abs(a).max()), float(np.abs(w).max()), float(np.abs(a - w).max()), entry[0]))
+            off += n
+        for ga, gw, err, name in sorted(rows, reverse=True)[:12]:
+            print("  %-34s |grad| HIP %.3e  oracle %.3e  max diff %.3e" % (name, ga, gw, err))
+        break
     if gmax > 2e3 and fin:
         with core.on_stream():
             i = int(g.abs().argmax())
