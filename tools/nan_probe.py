@@ -64,6 +64,18 @@ for it in range(steps):
         orc.make_target(ref).backward()
         pres_same = np.array_equal(core.out["presence"].cpu().numpy().reshape(-1), ref.outputs["presence"].detach().numpy().reshape(-1))
         print("presence decisions identical: %s" % pres_same)
+        lw_h = core.log_weights.cpu().numpy().reshape(B, K); lw_o = ref.log_weights.detach().numpy().reshape(B, K)
+        iw_h = core.importance_weights.cpu().numpy().reshape(B, K); iw_o = ref.importance_weights.numpy().reshape(B, K)
+        b_ = int(np.abs(lw_h - lw_o).max(1).argmax())
+        print("log-weights: max |HIP - oracle| %.4g (rel %.3g); worst sequence %d: HIP %s oracle %s" % (
+            np.abs(lw_h - lw_o).max(), np.abs(lw_h - lw_o).max() / np.abs(lw_o).max(), b_, np.array2string(lw_h[b_], precision=2),
+            np.array2string(lw_o[b_], precision=2)))
+        print("importance weights: max |diff| %.4g; that sequence HIP %s oracle %s" % (np.abs(iw_h - iw_o).max(), np.array2string(iw_h[b_], precision=4),
+                                                                                      np.array2string(iw_o[b_], precision=4)))
+        lwt_h = core.out["log_weights_per_timestep"].cpu().numpy().reshape(T, B, K); lwt_o = ref.outputs["log_weights_per_timestep"].detach().numpy().reshape(T, B, K)
+        t_, bb, kk = np.unravel_index(np.abs(lwt_h - lwt_o).argmax(), lwt_h.shape)
+        print("per-frame log-weights: max |diff| %.4g at frame %d seq %d particle %d: HIP %.6g oracle %.6g; most negative oracle %.6g" % (
+            np.abs(lwt_h - lwt_o).max(), t_, bb, kk, lwt_h[t_, bb, kk], lwt_o[t_, bb, kk], lwt_o.min()))
         off = 0
         rows = []
         for entry in spec:
