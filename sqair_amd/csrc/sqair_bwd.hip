@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_crop_bwd(const CropBwdArgs a, const Dim
     const int r = b * d.K + kp;
     const float l0 = a.logits[(size_t)r * 4 + 0], l1 = a.logits[(size_t)r * 4 + 1];
     const float l2 = a.logits[(size_t)r * 4 + 2], l3 = a.logits[(size_t)r * 4 + 3];
-    const float s0 = sq_sigmoid(l0), s1 = sq_sigmoid(l1);
+    const float s0 = sq_sigmoid_geo(l0), s1 = sq_sigmoid_geo(l1);
     const float sx = fmaxf(s0, 1e-4f), sy = fmaxf(s1, 1e-4f), tx = tanhf(l2), ty = tanhf(l3);
     const float hx = 0.5f * (float)(d.W - 1), hy = 0.5f * (float)(d.H - 1);
     float dsx = 0.0f, dsy = 0.0f, dtx = 0.0f, dty = 0.0f;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   if (tid < N * 4) {
     const int k = tid >> 2, c = tid & 3;
     const float l = a.rec ? a.rec[(fs + k) * a.rec_ld + rec::WHERE + c] : a.where[fs * 4 + tid];
-    co_s[tid] = (tid & 2) ? tanhf(l) : fmaxf(sq_sigmoid(l), 1e-4f);
+    co_s[tid] = (tid & 2) ? tanhf(l) : fmaxf(sq_sigmoid_geo(l), 1e-4f);
   }
   if (tid < N) pres_s[tid] = a.rec ? a.rec[(fs + tid) * a.rec_ld + rec::PRES] : a.pres[fs + tid];
   __syncthreads();
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
     const int k = tid >> 2, c = tid & 3;
     const float tot = acc_s[(0 * N + k) * 4 + c] + acc_s[(1 * N + k) * 4 + c] + acc_s[(2 * N + k) * 4 + c] + acc_s[(3 * N + k) * 4 + c];
     const float l = a.rec ? a.rec[(fs + k) * a.rec_ld + rec::WHERE + c] : a.where[fs * 4 + tid];
-    const float sg = sq_sigmoid(l), th = tanhf(l);
+    const float sg = sq_sigmoid_geo(l), th = tanhf(l);
     a.d_where[(fs + k) * a.dw_ld + c] = tot * ((c & 2) ? 1.0f - th * th : sg * (1.0f - sg));
   }
 }
@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
   }
   __syncthreads();
   {
-    const float s0 = sq_sigmoid(wl[0]), s1 = sq_sigmoid(wl[1]);
+    const float s0 = sq_sigmoid_geo(wl[0]), s1 = sq_sigmoid_geo(wl[1]);
     const float sx = fmaxf(s0, 1e-4f), sy = fmaxf(s1, 1e-4f), tx = tanhf(wl[2]), ty = tanhf(wl[3]);
     const float hx = 0.5f * (float)(d.W - 1), hy = 0.5f * (float)(d.H - 1);
     float dsx = 0.0f, dsy = 0.0f, dtx = 0.0f, dty = 0.0f;

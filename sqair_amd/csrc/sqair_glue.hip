@@ -867,7 +867,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const
     const bool is_y = q >= W;
     const int j = is_y ? q - W : q;
     const float* wl = a.rec ? a.rec + (fs + (size_t)r * N + k) * a.rec_ld + rec::WHERE : a.where_plain + ((size_t)r * N + k) * 4;
-    const float sc = fmaxf(sq_sigmoid(wl[is_y ? 1 : 0]), 1e-4f);
+    const float sc = fmaxf(sq_sigmoid_geo(wl[is_y ? 1 : 0]), 1e-4f);
     const float tr = tanhf(wl[is_y ? 3 : 2]);
     const float L = (float)((is_y ? H : W) - 1);
     const float cn = -1.0f + 2.0f * (float)j / L;

@@ -148,7 +148,7 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
         rn[rec::WHERE_SCALE + ci] = sc;
       }
     }
-    if (hl < 4) coord_s[ci] = (ci & 2) ? tanhf(wl) : fmaxf(sq_sigmoid(wl), 1e-4f);
+    if (hl < 4) coord_s[ci] = (ci & 2) ? tanhf(wl) : fmaxf(sq_sigmoid_geo(wl), 1e-4f);
   }
   if (stage_img) {
 #pragma unroll

@@ -27,7 +27,7 @@ mean_img = to_float(train["imgs"]).mean((0, 1))
 core = SqairCore(F, hw)
 core.set_params({k: np.asarray(v, dtype=np.float32) for k, v in init_params(F, hw, seed=0, mean_img=mean_img).items()})
 names = ["log_weights_per_timestep", "discrete_log_prob", "presence", "what_scale", "where_scale", "what", "where", "what_loc", "where_loc",
-         "presence_logit", "presence_prob"]
+         "presence_logit", "presence_prob", "data_ll_per_sample", "log_q_z_given_x_per_sample", "log_p_z_per_sample"]
 model = Model(to_float(train["imgs"][:T, :B]), None, core, K, outputs=names)
 trainer = Trainer(model, F)
 gen = torch.Generator(device="cuda").manual_seed(int(over.get("seed", 0)))
@@ -62,6 +62,9 @@ for it in range(steps):
         orc = O.SqairOracle({k: np.asarray(v, dtype=np.float64) for k, v in P0.items()}, O.make_cfg(F, hw), torch.float64, requires_grad=True)
         ref = orc.model(obs, noise)
         orc.make_target(ref).backward()
+        orc32 = O.SqairOracle({k: np.asarray(v, dtype=np.float32) for k, v in P0.items()}, O.make_cfg(F, hw), torch.float32, requires_grad=True)
+        ref32 = orc32.model(obs, noise)
+        orc32.make_target(ref32).backward()
         pres_same = np.array_equal(core.out["presence"].cpu().numpy().reshape(-1), ref.outputs["presence"].detach().numpy().reshape(-1))
         print("presence decisions identical: %s" % pres_same)
         lw_h = core.log_weights.cpu().numpy().reshape(B, K); lw_o = ref.log_weights.detach().numpy().reshape(B, K)
@@ -76,6 +79,13 @@ for it in range(steps):
         t_, bb, kk = np.unravel_index(np.abs(lwt_h - lwt_o).argmax(), lwt_h.shape)
         print("per-frame log-weights: max |diff| %.4g at frame %d seq %d particle %d: HIP %.6g oracle %.6g; most negative oracle %.6g" % (
             np.abs(lwt_h - lwt_o).max(), t_, bb, kk, lwt_h[t_, bb, kk], lwt_o[t_, bb, kk], lwt_o.min()))
+        for nm in ("data_ll_per_sample", "log_q_z_given_x_per_sample", "log_p_z_per_sample"):
+            h_ = core.out[nm].cpu().numpy().reshape(T, B, K)[t_, bb, kk]; o_ = ref.outputs[nm].detach().numpy().reshape(T, B, K)[t_, bb, kk]
+            print("   %-28s HIP %.6f oracle %.6f" % (nm, h_, o_))
+        r_ = bb * K + kk
+        for nm in ("where", "where_scale", "where_loc", "what_scale", "presence"):
+            print("   %-12s HIP %s" % (nm, np.array2string(core.out[nm].cpu().numpy().reshape(T, B * K, N, -1)[t_, r_].reshape(-1), precision=4)))
+            print("   %-12s orc %s" % ("", np.array2string(ref.outputs[nm].detach().numpy().reshape(T, B * K, N, -1)[t_, r_].reshape(-1), precision=4)))
         off = 0
         rows = []
         for entry in spec:
@@ -83,10 +93,13 @@ for it in range(steps):
             w = orc.P[entry[0]].grad
             w = np.zeros(n) if w is None else w.numpy().reshape(-1)
             a = got[off:off + n]
-            rows.append((float(np.abs(a).max()), float(np.abs(w).max()), float(np.abs(a - w).max()), entry[0]))
+            w32 = orc32.P[entry[0]].grad
+            w32 = np.zeros(n) if w32 is None else w32.numpy().reshape(-1).astype(np.float64)
+            rows.append((float(np.abs(a).max()), float(np.abs(w).max()), float(np.abs(a - w).max()), entry[0], float(np.abs(w32).max()), float(np.abs(w32 - w).max())))
             off += n
-        for ga, gw, err, name in sorted(rows, reverse=True)[:12]:
-            print("  %-34s |grad| HIP %.3e  oracle %.3e  max diff %.3e" % (name, ga, gw, err))
+        print("presence of the fp32 oracle identical to fp64: %s" % np.array_equal(ref32.outputs["presence"].detach().numpy(), ref.outputs["presence"].detach().numpy()))
+        for ga, gw, err, name, g32, e32 in sorted(rows, reverse=True)[:12]:
+            print("  %-30s |grad| HIP %.3e  oracle fp64 %.3e (diff %.3e)  oracle fp32 %.3e (diff to fp64 %.3e)" % (name, ga, gw, err, g32, e32))
         break
     if gmax > 2e3 and fin:
         with core.on_stream():
