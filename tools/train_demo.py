@@ -21,6 +21,7 @@ from sqair_amd.params import init_params
 from sqair_amd.train import Trainer
 
 over = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a)
+n_train = int(over.pop("n_train", 2048))   # n_train=16384: a training set the model cannot memorise
 sys.argv = [a for a in sys.argv if "=" not in a]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 lr = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-5
@@ -30,7 +31,7 @@ seq_len = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 stage_itr = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 N = int(over.get("n_steps_per_image", N))
 F = make_flags(**dict(dict(k_particles=K, n_steps_per_image=N, learning_rate=lr, train_itr=train_itr, seq_len=seq_len, stage_itr=stage_itr), **over))
-train = make_sequences(2048, T=T, canvas=hw, n_objects=(0, 2), seed=1)
+train = make_sequences(n_train, T=T, canvas=hw, n_objects=(0, 2), seed=1)
 valid = make_sequences(256, T=T, canvas=hw, n_objects=(0, 2), seed=2)
 feed = MinibatchFeed(dict(imgs=to_float(train["imgs"]), nums=train["nums"], coords=train["coords"]), B, shuffle=True, seed=0,
                      seq_len=seq_len, stage_itr=stage_itr)
@@ -78,6 +79,6 @@ for it in range(steps + 1):
             e = float(core.scalars[1]) / core.T
         run = e if it == 0 else 0.9 * run + 0.1 * e
 print(json.dumps(dict(config=dict(T=T, B=B, K=K, N=N, hw=hw, steps=steps, train_itr=train_itr, learning_rate=lr, opt=str(F.opt), flag_overrides=over,
-                                  schedule=F.schedule, data="2048 synthetic 2-glyph sequences, 256 held out",
+                                  schedule=F.schedule, data="%d synthetic 2-glyph sequences, 256 held out" % n_train,
                                   true_objects_per_frame=float(valid["nums"].sum(-1).mean())),
                       upper_bound_per_frame=2500 * (-np.log(0.3) - 0.5 * np.log(2 * np.pi)), curve=log)))
