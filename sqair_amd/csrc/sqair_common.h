@@ -117,7 +117,7 @@ __device__ __forceinline__ float sq_sigmoid(float x) { return __builtin_amdgcn_r
 // scale of the spatial transformer (to_coords): libm exponential and an IEEE divide, ~1 ulp.  The compact sigmoid's 1.7e-7
 // is a RELATIVE 1e-6 at a scale of 0.16, which the inverse warp of the decoder amplifies (pixel coordinate = 9.5 ((x - t) / s + 1))
 // into 6e-5 pixels at the glimpse edge and the likelihood sums over ~400 pixels into 0.04 - 0.4 nats per frame: found as a
-// uniform few-percent deviation of whole gradients from the oracle in states with tiny scales (tools/nan_probe.py).
+// uniform few-percent deviation of whole gradients from the oracle in states with tiny scales (tests/nan_probe.py).
 __device__ __forceinline__ float sq_sigmoid_geo(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float sq_tanh(float x) {  // 1 - 2 / (e^{2x} + 1): saturates cleanly (e^{2x} = inf -> 1, 0 -> -1)
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(sq_exp(2.0f * x) + 1.0f);

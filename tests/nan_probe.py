@@ -1,6 +1,6 @@
 """Trains with the reference recipe (tools/train_demo.py's setting) and checks the gradient after EVERY step: at the first
 non-finite value prints which parameters are affected and the state of the forward pass that produced it.
-    python tools/nan_probe.py [steps] [flag=value ...]"""
+    python tests/nan_probe.py [steps] [flag=value ...]"""
 import sys
 
 sys.path.insert(0, ".")
