@@ -174,8 +174,9 @@ def test_cfg2_full_size_properties():
     assert np.array_equal(m2.presence.cpu().numpy(), pres1)
     assert m2.core.graph_nodes() > 100
     # (b) rows are independent: a shard of the batch reproduces its rows (this is what data-parallel sharding relies
-    # on) — bit for bit when the shard is large enough to select the same kernel variants (16 sequences: M = 320
-    # rows in the batched layers), to fp32 round-off otherwise (8 sequences use the split-K variant everywhere)
+    # on) — bit for bit when the shard selects the same kernel variants (16 sequences: the decoder's T B' N = 3200 rows
+    # still run on the macro-tile kernels like the 6400 of the full batch), to fp32 round-off otherwise (8 sequences: 1600
+    # rows, split-K kernel)
     half = slice(16, 32)
     nz_half = noise.reshape(T, B, K, 2, N, 55)[:, half].reshape(T, 16 * K, 2, N, 55)
     mh = run_hip(F, hw, P, obs[:, half], nz_half, nums=nums[:, half])
@@ -185,6 +186,13 @@ def test_cfg2_full_size_properties():
     m3 = run_hip(F, hw, P, obs[:, sub], nz_sub, nums=nums[:, sub])
     if np.array_equal(m3.presence.cpu().numpy(), pres1[:, 8 * K:16 * K]):
         assert np.abs(m3.log_weights.cpu().numpy() - lw1[sub]).max() <= 1e-5 * np.abs(lw1[sub]).max()
+    # (b') ... and a permutation of the sequences permutes the results, bit for bit (rows change their 16-row tiles and their
+    # neighbours; the kernel variant of a launch depends on its row count only, and that is the same here)
+    perm = np.random.default_rng(7).permutation(B)
+    nz_perm = noise.reshape(T, B, K, 2, N, 55)[:, perm].reshape(T, B * K, 2, N, 55)
+    mp = run_hip(F, hw, P, obs[:, perm], nz_perm, nums=nums[:, perm])
+    assert np.array_equal(mp.log_weights.cpu().numpy(), lw1[perm])
+    assert np.array_equal(mp.presence.cpu().numpy(), pres1[:, (perm[:, None] * K + np.arange(K)[None]).reshape(-1)])
     # (c) IWAE bound >= mean single-particle bound (Jensen), importance weights normalised, ids consistent
     assert float(m1.elbo_iwae) >= float(m1.elbo_vae) - 1e-3
     assert np.allclose(m1.importance_weights.cpu().numpy().sum(-1), 1.0, atol=1e-5)
