@@ -268,6 +268,18 @@ int sqair_backward(SqairHandle* h, const float* flat_params, const void* packed,
 int sqair_set_workspace_clearing(SqairHandle* h, int each_pass);
 int sqair_clear_workspace(SqairHandle* h, void* workspace, int64_t workspace_bytes, int T, int B, int train, void* stream);
 
+/* Run-time options of a handle (API calls of the caller; the library reads NO environment variables):
+ *   "tail_fusion" (default 1): compute the tail of slot k inside slot k + 1's VanillaRNN launch; 0 = one launch per
+ *                 operation.  Results are bit-identical either way (tests/test_hip_forward.py); affects the following passes
+ *                 and captures.
+ * Returns -2 for an unknown name. */
+int sqair_set_option(SqairHandle* h, const char* name, int value);
+/* Debug mode of the reference (`debug=True` -> validate_args / allow_nan_stats=False on its distributions,
+ * sqair/core.py:226, :261, sqair/modules.py:318-320; a TF runtime error inside sess.run): checks x[0:n] for NaN / Inf on
+ * `stream`, SYNCHRONISES it, and returns -5 with "non-finite values in <what>: count, first index" in sqair_last_error.
+ * flag_dev: caller-owned device int32[2] scratch. */
+int sqair_check_finite(SqairHandle* h, const float* x, int64_t n, const char* what, int32_t* flag_dev, void* stream);
+
 /* Generation modes (sqair/sqair_modules.py:157-170, :294-302, sqair/seq.py:198-200).  With
  * cfg.sample_from_prior the propagation posterior log-probabilities are evaluated at samples of the propagation PRIOR, and
  * in frames t > cfg.generate_after those samples replace what / where / presence of the propagated objects, discovery's

@@ -82,6 +82,8 @@ _PROTOS = {
                                  C.c_void_p, C.c_int64, C.c_void_p]),
     "sqair_set_workspace_clearing": (C.c_int, [C.c_void_p, C.c_int]),
     "sqair_clear_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sqair_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "sqair_check_finite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_void_p, C.c_void_p]),
     "sqair_lstm_test": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "sqair_lstm_cell_bwd_test": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_void_p]),
     "sqair_get_config": (C.c_int, [C.c_void_p, C.POINTER(SqairConfig)]),

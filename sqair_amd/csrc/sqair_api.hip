@@ -728,7 +728,7 @@ static bool can_fuse_tail(const SqairHandle* h, LayerId id) {
   const PackedLayer& L = h->layers[id];
   const int nh = h->cfg.n_hidden;
   return h->cfg.rnn_cell == RNN_VANILLA && (nh == 128 || nh == 256) && L.seg_width.size() == 2 && L.seg_width[0] == rec::ZW &&
-         L.seg_width[1] == nh && L.kc == 4 + nh / 16 && L.nt == nh / 16 && L.N == nh && getenv("SQAIR_NO_TAIL_FUSION") == nullptr;
+         L.seg_width[1] == nh && L.kc == 4 + nh / 16 && L.nt == nh / 16 && L.N == nh && h->opt_tail_fusion;
 }
 static int run_rnn_tail(SqairHandle* h, const TailArgs& ta, Dims d, LayerId id, const float* hid, int hid_ld, const float* add, int add_ld,
                         float* out, int out_ld, const float* packed, hipStream_t s) {
@@ -811,7 +811,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
 
   // (the fused launch recomputes a slot's tail in each of the layer's nh / 16 column-tile workgroups: free while the pass is
   // latency-bound (-0.2 ms at 160 rows), even at 320 rows, a loss from 640 on -- 20.5 us against 5.9 + 5.5 us at 1280 rows)
-  static const int tail_rows = getenv("SQAIR_TAIL_FUSION_ROWS") ? atoi(getenv("SQAIR_TAIL_FUSION_ROWS")) : 320;
+  static const int tail_rows = SQ_KNOB_INT("SQAIR_TAIL_FUSION_ROWS", 320);
   const bool fuse_prop = d.R <= tail_rows && can_fuse_tail(h, L_PROP_RNN), fuse_disc = d.R <= tail_rows && can_fuse_tail(h, L_DISC_RNN);
   TailArgs pending_tail; memset(&pending_tail, 0, sizeof(pending_tail));
   for (int t = 0; (parts & 2) && t < T; ++t) {
@@ -1148,6 +1148,51 @@ extern "C" int sqair_clear_workspace(SqairHandle* h, void* workspace, int64_t wo
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// documented run-time options (include/sqair_hip.h).  These are API calls of the caller, not environment variables: nothing in
+// the environment can change what a pass computes or launches (the measurement knobs of tools/ exist only in -DSQAIR_KNOBS builds).
+extern "C" int sqair_set_option(SqairHandle* h, const char* name, int value) {
+  if (!h || !name) return -1;
+  const std::string n(name);
+  if (n == "tail_fusion") { h->opt_tail_fusion = value != 0; return 0; }
+  sq_set_error(h, "sqair_set_option: unknown option '" + n + "' (known: tail_fusion)");
+  return -2;
+}
+
+// debug mode of the reference (validate_args / allow_nan_stats=False of its distributions, sqair/core.py:226, :261,
+// sqair/modules.py:318-320): a finite check of a device tensor that fails through the error channel.
+__global__ __launch_bounds__(256) void k_finite_check(const float* __restrict__ x, int64_t n, int* __restrict__ flag) {
+  int bad = 0;
+  int64_t first = n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i];
+    if (!(fabsf(v) <= 3.4028234664e38f)) { ++bad; if (i < first) first = i; }
+  }
+  if (bad) {
+    atomicAdd(&flag[0], bad);
+    atomicMin(&flag[1], (int)(first < 0x7fffffff ? first : 0x7fffffff));
+  }
+}
+extern "C" int sqair_check_finite(SqairHandle* h, const float* x, int64_t n, const char* what, int32_t* flag_dev, void* stream) {
+  if (!h || !x || !flag_dev || n < 0) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const int init[2] = {0, 0x7fffffff};
+  int got[2] = {0, 0};
+  SQ_CHECK_HIP(hipMemcpyAsync(flag_dev, init, sizeof(init), hipMemcpyHostToDevice, s));
+  if (n > 0) {
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_finite_check, dim3(grid), dim3(256), 0, s, x, n, (int*)flag_dev);
+  }
+  SQ_CHECK_HIP(hipMemcpyAsync(got, flag_dev, sizeof(got), hipMemcpyDeviceToHost, s));
+  SQ_CHECK_HIP(hipStreamSynchronize(s));
+  if (got[0] == 0) return 0;
+  char msg[256];
+  snprintf(msg, sizeof(msg), "non-finite values in %s: %d of %lld, first at flat index %d", what ? what : "tensor", got[0],
+           (long long)n, got[1]);
+  sq_set_error(h, msg);
+  return -5;
+}
+
 extern "C" int sqair_forward(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
                              const float* noise, int T, int B, int t_offset, const SqairOutputs* out, void* workspace,
                              int64_t workspace_bytes, void* stream) {
@@ -1194,7 +1239,7 @@ extern "C" int sqair_profile_forward(SqairHandle* h, const float* flat_params, c
   SQ_CHECK_HIP(hipMemcpy(ts.data(), w.prof_ts, 5 * PROF_MAX * 8, hipMemcpyDeviceToHost));
   double ticks = 0.0;
   for (int i = 0; i < h->prof_n; ++i) ticks += (double)(ts[PROF_MAX + i] - ts[i]);
-  if (const char* dump = getenv("SQAIR_PROF_DUMP")) {  // per-launch CSV: layer id, rows, start tick, end tick (10 ns ticks)
+  if (const char* dump = SQ_KNOB_STR("SQAIR_PROF_DUMP")) {  // per-launch CSV: layer id, rows, start tick, end tick (10 ns ticks)
     if (FILE* f = fopen(dump, "w")) {
       fprintf(f, "layer,M,start,end,wg0_setup,wg0_mfma,wg0_end\n");
       for (int i = 0; i < h->prof_n; ++i)
@@ -1224,7 +1269,7 @@ extern "C" int sqair_profile_linear_graph(SqairHandle* h, const float* flat_para
   hipStream_t s = (hipStream_t)stream;
   SQ_CHECK_HIP(hipStreamSynchronize(s));
   h->only_linear = true;
-  h->emit_extra = getenv("SQAIR_EMIT_EXTRA") ? atoi(getenv("SQAIR_EMIT_EXTRA")) : 0;  // measurement knob: 1 = + crop, 2 = + tail, 4 = - dense
+  h->emit_extra = SQ_KNOB_INT("SQAIR_EMIT_EXTRA", 0);  // measurement knob: 1 = + crop, 2 = + tail, 4 = - dense
   SQ_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   const int rc = forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
                               workspace_bytes, s);

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void k_wgrad_group(const WgGroup g) {
 // what the float4 operand loads of wgrad3_body need: 16-byte aligned rows, and a width that is not a multiple of 4 padded
 // inside its row
 static bool wgrad3_operands_ok(const float* A, int lda, const float* dY, int ldy, int Kdim, int Ndim) {
-  static const int use3 = getenv("SQAIR_WGRAD3") ? atoi(getenv("SQAIR_WGRAD3")) : 1;  // measurement knob: 0 = k_wgrad2 everywhere
+  static const int use3 = SQ_KNOB_INT("SQAIR_WGRAD3", 1);  // measurement knob: 0 = k_wgrad2 everywhere
   const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)dY % 16 == 0) && lda % 4 == 0 && ldy % 4 == 0;
   const bool padded = (Kdim % 4 == 0 || ((Kdim + 3) & ~3) <= lda) && (Ndim % 4 == 0 || ((Ndim + 3) & ~3) <= ldy);
   return use3 > 0 && aligned && padded && Kdim >= 1 && Ndim >= 1;
@@ -532,7 +532,7 @@ static bool wgrad3_eligible(const float* A, int lda, const float* dY, int ldy, i
 static const size_t WG3_LDS = (4 * 4096 + 256) * sizeof(float);
 bool WgradBatch::add(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim, const int* rowmap,
                      const float* alpha_ptr, float* db_a, float* db_b) {
-  static const bool grouped = getenv("SQAIR_WGRAD_GROUP") ? atoi(getenv("SQAIR_WGRAD_GROUP")) != 0 : true;
+  static const bool grouped = SQ_KNOB_INT("SQAIR_WGRAD_GROUP", 1) != 0;
   if (!grouped || M < 1 || !wgrad3_operands_ok(A, lda, dY, ldy, Kdim, Ndim)) return false;
   WgDesc e;
   e.A = A; e.dY = dY; e.dW = dW; e.rowmap = rowmap; e.alpha_ptr = alpha_ptr; e.db_a = db_a; e.db_b = db_b;
@@ -542,8 +542,8 @@ bool WgradBatch::add(const float* A, int lda, const float* dY, int ldy, float* d
   return true;
 }
 int WgradBatch::flush(hipStream_t s) {
-  static const int rows = getenv("SQAIR_WGRAD_ROWS") ? atoi(getenv("SQAIR_WGRAD_ROWS")) : 2048;  // target rows of a workgroup
-  static const bool dump = getenv("SQAIR_WGRAD_DUMP") != nullptr;  // print the block table of every flush
+  static const int rows = SQ_KNOB_INT("SQAIR_WGRAD_ROWS", 2048);  // target rows of a workgroup
+  static const bool dump = SQ_KNOB_SET("SQAIR_WGRAD_DUMP");  // print the block table of every flush
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k_wgrad_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG3_LDS);
@@ -578,7 +578,7 @@ int WgradBatch::flush(hipStream_t s) {
 }
 int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim,
                         hipStream_t s, const int* rowmap, const float* alpha_ptr, float* db_a, float* db_b) {
-  static const int skip = getenv("SQAIR_WGRAD3") ? atoi(getenv("SQAIR_WGRAD3")) < 0 : 0;  // measurement knob: no weight gradients at all
+  static const int skip = SQ_KNOB_INT("SQAIR_WGRAD3", 1) < 0;  // measurement knob (knob builds only): no weight gradients at all
   const int wg3_target = 512;
   if (skip) return 0;
   if (wgrad3_eligible(A, lda, dY, ldy, M, Kdim, Ndim)) {
@@ -600,7 +600,7 @@ int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float
     return 0;
   }
   const int kt = (Kdim + 31) / 32, nt = (Ndim + 31) / 32;
-  static const int wg_target = getenv("SQAIR_WGRAD_WGS") ? atoi(getenv("SQAIR_WGRAD_WGS")) : 2048;  // measurement knob
+  static const int wg_target = SQ_KNOB_INT("SQAIR_WGRAD_WGS", 2048);  // measurement knob
   int zc = wg_target / (kt * nt);
   const int max_z = (M + 63) / 64;
   if (zc > max_z) zc = max_z;

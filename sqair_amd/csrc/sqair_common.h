@@ -93,6 +93,19 @@ int sq_launch_pack(const float* flat, float* packed_w, const int* idx, int64_t n
 int sq_launch_pack_bias(const float* flat, float* packed_b, const int* idxa, const int* idxb, int64_t n,
                         hipStream_t s);
 
+// Measurement knobs (tile shapes, fusion switches, dump files) are read from the environment ONLY in a library built with
+// -DSQAIR_KNOBS (tools/: `python sqair_amd/csrc/build.py --knobs` -> tools/bin/libsqair_hip_knobs.so).  The production library
+// compiles every knob to its default, so no environment variable can change -- or remove -- work inside a timed region.
+#ifdef SQAIR_KNOBS
+#define SQ_KNOB_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define SQ_KNOB_SET(name) (getenv(name) != nullptr)
+#define SQ_KNOB_STR(name) getenv(name)
+#else
+#define SQ_KNOB_INT(name, dflt) (dflt)
+#define SQ_KNOB_SET(name) false
+#define SQ_KNOB_STR(name) ((const char*)nullptr)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // device math (exact-ish fp32; no fast-math so that parity with the fp64 oracle holds to ~1e-6)
 // ---------------------------------------------------------------------------------------------
@@ -107,6 +120,10 @@ int sq_launch_pack_bias(const float* flat, float* packed_b, const int* idxa, con
 __device__ __forceinline__ float sq_exp(float x) {
   // e^x = 2^(x log2 e); the product is formed in two parts (t + r) so that its rounding error, which exp2 would amplify to
   // |x| * 6e-8 relative, is put back to first order: 2^(t + r) = 2^t (1 + r ln 2)
+  // x is clamped to [-104, log(FLT_MAX)] (one v_med3): above it exp2 returns +inf and fma(inf, r ln 2, inf) is NaN whenever
+  // r <= 0; far below it x log2 e overflows to -inf and r becomes inf, fma(0, inf, 0) = NaN.  Every user (sigmoid, tanh,
+  // softplus, ELU) wants the saturated value: 1 / (1 + 3.4e38) = 0, 1 - 2 / 3.4e38 = 1, e^-104 = 0 in fp32.
+  x = __builtin_amdgcn_fmed3f(x, -104.0f, 88.72283f);
   const float t = x * 1.44269504088896340736f;
   const float r = fmaf(x, 1.44269504088896340736f, -t) + x * 1.92596299112661746e-8f;
   const float e = __builtin_amdgcn_exp2f(t);

@@ -54,6 +54,7 @@ struct SqairHandle {
   int emit_extra = 0;
   int debug_reps = 0;       // sqair_debug_linear_time
   float debug_us = 0.0f;
+  bool opt_tail_fusion = true;  // sqair_set_option("tail_fusion"): the tail of slot k inside slot k + 1's RNN launch (bit-identical either way)
   bool clear_each_pass = true;  // zero the caller's workspace at the start of every pass (sqair_set_workspace_clearing)
   const float* gen_noise = nullptr;  // sqair_set_generation_noise
   // generic capture slots (sqair_capture_begin / _end / _launch): any sequence of C-ABI calls as one HIP graph

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int 
     if (a.nseg > 2) { cum2 = c; c += (a.seg[2].width + 15) >> 4; rp2 = a.seg[2].p + (size_t)SQ_ROWOF(a.seg[2]) * a.seg[2].ld; lim2 = ((a.seg[2].width + 3) & ~3) - 4; }
     if (a.nseg > 3) { cum3 = c; rp3 = a.seg[3].p + (size_t)SQ_ROWOF(a.seg[3]) * a.seg[3].ld; lim3 = ((a.seg[3].width + 3) & ~3) - 4; }
   }
+#undef SQ_ROWOF
   f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
   const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + ((size_t)tile_n * kc_total) * 64 + lane;
   const f32x4* __restrict__ wz = reinterpret_cast<const f32x4*>(a.wzero) + lane;
@@ -534,7 +535,7 @@ static MtShape pick_mt_shape(int M, int n_tiles, int kc) {
   static int ov_mt = -1, ov_nt = -1, ov_coal = -1;
   if (ov_mt < 0) {
     ov_mt = ov_nt = 0;
-    const char* e = getenv("SQAIR_MT");
+    const char* e = SQ_KNOB_STR("SQAIR_MT");
     if (e != nullptr) sscanf(e, "%d,%d,%d", &ov_mt, &ov_nt, &ov_coal);
   }
   (void)kc;
@@ -599,7 +600,7 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
   // the forward pass at 32 sequences per GPU, 11 % at 64 and at cfg-4 (they were used from 256 rows up until round 2).
   // Also tried for the 2048+ row launches and dropped: the split-K structure with a 32 x 32 and with a 64 x 64 workgroup tile
   // (half / a quarter of the operand bytes per output tile): 22 - 25 us against 16 - 17 us on 5120 x 256 x 256, back to back.
-  static const int mt_rows = getenv("SQAIR_MT_ROWS") ? atoi(getenv("SQAIR_MT_ROWS")) : 2048;  // measurement knob
+  static const int mt_rows = SQ_KNOB_INT("SQAIR_MT_ROWS", 2048);  // measurement knob
   if (a.M >= mt_rows) {
     // (all of them accumulate in the same order: the tile shape never changes a result)
     if (L.kc <= 4) {  // K <= 64: one block of loads, nothing to pipeline
@@ -609,7 +610,7 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
     }
     // the LDS-tiled kernel pays once its 128 x 64 workgroup tiles fill the chip twice over (measured, tools/time_linear.py:
     // 51200 x 256 x 256 118 -> 106 us, 5120 x 362 x 1152 80 -> 67 us; below that the macro-tile kernel's smaller tiles win)
-    static const int lds_wgs = getenv("SQAIR_LDS_WGS") ? atoi(getenv("SQAIR_LDS_WGS")) : 512;  // measurement knob
+    static const int lds_wgs = SQ_KNOB_INT("SQAIR_LDS_WGS", 512);  // measurement knob
     if (((a.M + 127) / 128) * ((L.nt + 3) / 4) >= lds_wgs) {
       hipLaunchKernelGGL((k_linear_lds<2>), dim3((L.nt + 3) / 4, (a.M + 127) / 128), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
       return 0;

@@ -300,7 +300,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   }
 
   // the adjoint of the transform's 8-wide output layer rides in the crop adjoint that produces its input (80 launches fewer)
-  const bool fuse_t3 = getenv("SQAIR_NO_T3_FUSION") == nullptr;
+  const bool fuse_t3 = !SQ_KNOB_SET("SQAIR_NO_T3_FUSION");
   // ================= reverse sweep over the frames =================
   for (int t = T - 1; t >= 0; --t) {
     const float* img = obs + (size_t)t * B * P_;

@@ -398,6 +398,18 @@ class SqairCore(object):
     def graph_nodes(self):
         return self.lib.sqair_graph_nodes(self.handle)
 
+    def check_finite(self, tensor, what):
+        """Debug mode (reference: `debug` -> validate_args / allow_nan_stats=False, sqair/core.py:226, :261,
+        sqair/modules.py:318-320): raises RuntimeError through the library's error channel when `tensor` holds NaN / Inf.
+        Synchronises the core's stream."""
+        if getattr(self, "_finite_flag", None) is None:
+            self._finite_flag = torch.zeros(2, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._join_in()
+            _capi.check(self.handle, self.lib.sqair_check_finite(
+                self.handle, tensor.data_ptr(), tensor.numel(), what.encode(), self._finite_flag.data_ptr(), self._stream()),
+                "sqair_check_finite")
+
 
 class Model(object):
     """Mirror of reference sqair/model.py:33-214 on top of ``SqairCore``."""
@@ -439,10 +451,15 @@ class Model(object):
             self.gt_presence = torch.as_tensor(presence, dtype=torch.float32).to(core.device)
         elif self.gt_presence is not None and tuple(self.gt_presence.shape[:2]) != tuple(obs.shape[:2]):
             self.gt_presence = None   # ground truth of another batch: the accuracy is undefined until a new one is given
+            for name in ("num_step_accuracy_per_example", "raw_num_step_accuracy", "num_step_accuracy"):
+                self.__dict__.pop(name, None)  # (stale values of the previous shape)
         self.n_timesteps, self.batch_size = int(obs.shape[0]), int(obs.shape[1])
         self.tiled_batch_size = self.batch_size * self.k_particles
-        core.bind(self.n_timesteps, self.batch_size, core._shape[2] if core._shape else "all")
+        # the previous step may still be running on the core's stream (Trainer.step is asynchronous): nothing is freed or
+        # re-allocated before it has drained, and the new buffers are created and filled on that same stream
+        core.stream.synchronize()
         with core.on_stream():
+            core.bind(self.n_timesteps, self.batch_size, core._shape[2] if core._shape else "all")
             core.obs.copy_(self.obs)
         self._ran = False
 
@@ -461,10 +478,20 @@ class Model(object):
             else:
                 core.draw_noise(generator)
             core.forward(use_graph=self._use_graph)
+            if self.debug:
+                self._debug_checks()
             self._collect(resample_u)
         core.stream.synchronize()
         self._ran = True
         return self
+
+    def _debug_checks(self):
+        """`debug=True` of the reference turns on argument validation / NaN checks of every distribution inside the graph
+        (sqair/core.py:226, :261, sqair/modules.py:318-320) — a failed check aborts `sess.run`.  Here: the per-frame
+        log-weights (every log-probability of the pass ends up in them) and the sequence log-weights must be finite."""
+        core = self.core
+        core.check_finite(core.out["log_weights_per_timestep"], "log_weights_per_timestep [T, B*K]")
+        core.check_finite(core.log_weights, "log_weights [B, K]")
 
     def _collect(self, resample_u=None):
         core = self.core
@@ -554,6 +581,9 @@ class Model(object):
             if not self._ran:
                 core.draw_noise()
             core.grad_step(use_graph=self._use_graph)
+            if self.debug:
+                self._debug_checks()
+                core.check_finite(core.flat_grad, "flat gradient of the VIMCO target")
             if l2_reg != 0.0:
                 _capi.check(core.handle, core.lib.sqair_add_l2_grad(
                     core.handle, core.flat.data_ptr(), core.flat_grad.data_ptr(), core.n_params, float(l2_reg),

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from sqair_amd import _capi
 from sqair_amd.data import config_inputs, make_sequences, to_float
 from sqair_amd.flags import make_flags
 from sqair_amd.model import Model, SqairCore
@@ -327,7 +328,7 @@ def test_generation_modes_vs_live_oracle(generate_after, prior):
 @pytest.mark.parametrize("K,N,T,B,n_units", [(5, 4, 3, 32, 8), (3, 3, 2, 7, 4)])
 def test_tail_fused_into_the_next_rnn_layer_is_bitwise_identical(K, N, T, B, n_units):
     """k_rnn_tail (the tail of slot k computed inside slot k + 1's VanillaRNN launch) against the launch-per-op sequence
-    (SQAIR_NO_TAIL_FUSION=1, read when the pass is issued): every output bit for bit, inference and training-mode forward."""
+    (`sqair_set_option(h, "tail_fusion", 0)`): every output bit for bit, inference and training-mode forward."""
     hw = (50, 50)
     F = make_flags(k_particles=K, n_steps_per_image=N, n_units=n_units)
     d = make_sequences(B, T=T, canvas=hw, n_objects=(0, 2), seed=5)
@@ -335,8 +336,9 @@ def test_tail_fused_into_the_next_rnn_layer_is_bitwise_identical(K, N, T, B, n_u
     P = params32(F, hw, 3, 0.05, obs.mean((0, 1)))
     noise = draw_noise(np.random.default_rng(1), T, B * K, N, 4 + int(F.n_what) + 1)
 
-    def run(train):
+    def run(train, fusion=True):
         core = SqairCore(F, hw)
+        _capi.check(core.handle, core.lib.sqair_set_option(core.handle, b"tail_fusion", int(fusion)), "sqair_set_option")
         core.set_params(P)
         Model(obs, None, core, K, presence=d["nums"])
         with core.on_stream():
@@ -345,14 +347,9 @@ def test_tail_fused_into_the_next_rnn_layer_is_bitwise_identical(K, N, T, B, n_u
         core.stream.synchronize()
         return {k: v.cpu().numpy().copy() for k, v in core.out.items()}, core.log_weights.cpu().numpy().copy()
 
-    os.environ.pop("SQAIR_NO_TAIL_FUSION", None)
     fused, lw_f = run(False)
     fused_t, lw_ft = run(True)
-    os.environ["SQAIR_NO_TAIL_FUSION"] = "1"
-    try:
-        plain, lw_p = run(False)
-    finally:
-        os.environ.pop("SQAIR_NO_TAIL_FUSION", None)
+    plain, lw_p = run(False, fusion=False)
     assert np.array_equal(lw_f, lw_p) and np.array_equal(lw_f, lw_ft)
     for k in plain:
         assert np.array_equal(fused[k], plain[k]), k

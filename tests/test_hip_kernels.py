@@ -63,6 +63,39 @@ def test_linear_identity_asymmetric(handle):
     assert np.array_equal(y.cpu().numpy(), w)
 
 
+@pytest.mark.parametrize("M", [16, 2048])  # split-K kernel / macro-tile kernel (rolled epilogue)
+def test_activations_saturate_cleanly(handle, M):
+    """Large finite pre-activations must saturate (tanh -> +-1, sigmoid -> 0 / 1, softplus -> x / 0.01, ELU -> x / -1) and never
+    produce NaN: the hardware-exp2 based exponential overflowed to inf * r = NaN beyond |x| ~ 88 (round-2 advisor finding)."""
+    lib, h, _ = handle
+    vals = np.array([0.0, 1.0, -1.0, 44.0, -44.0, 50.0, -50.0, 88.7, -88.7, 89.0, -89.0, 100.0, -100.0, 1e4, -1e4, 3e38, -3e38],
+                    dtype=np.float32)
+    N = 32
+    pre = np.resize(vals, N).astype(np.float32)
+    x = np.zeros((M, 16), np.float32)
+    w = np.zeros((16, N), np.float32)
+    scratch = torch.empty(1 << 20, dtype=torch.float32, device="cuda")
+    dx, dw, db = dev(x), dev(w), dev(pre)
+    with np.errstate(over="ignore"):
+        p64 = pre.astype(np.float64)
+        want = {1: np.where(p64 > 0, p64, np.expm1(np.minimum(p64, 0))), 2: np.tanh(p64), 3: 1.0 / (1.0 + np.exp(-p64)),
+                4: np.maximum(p64, 0) + np.log1p(np.exp(-np.abs(p64))) + 1e-2}
+    for act in (1, 2, 3, 4):
+        y = torch.full((M, N), float("nan"), device="cuda")
+        rc = lib.sqair_linear_test(h, dx.data_ptr(), dw.data_ptr(), db.data_ptr(), y.data_ptr(), M, 16, N, act,
+                                   scratch.data_ptr(), scratch.numel() * 4, stream())
+        assert rc == 0, lib.sqair_last_error(h)
+        got = y.cpu().numpy()
+        assert np.isfinite(got).all(), (act, pre[~np.isfinite(got[0])])
+        err = np.abs(got.astype(np.float64) - want[act][None, :]) / np.maximum(1.0, np.abs(want[act][None, :]))
+        assert err.max() < 5e-7, (act, pre[err[0].argmax()], got[0, err[0].argmax()])
+        if act == 2:
+            assert np.array_equal(got[0, np.abs(pre) >= 44.0], np.sign(pre[np.abs(pre) >= 44.0]))
+        if act == 3:
+            assert np.array_equal(got[0, pre >= 50.0], np.ones((pre >= 50.0).sum(), np.float32))
+            assert (got[0, pre <= -89.0] <= 1e-38).all()
+
+
 @pytest.mark.parametrize("M,Kx", [(160, 360), (640, 54), (7, 17), (2304, 360), (2050, 54)])
 def test_gru_step(handle, M, Kx):
     lib, h, _ = handle
