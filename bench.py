@@ -11,16 +11,25 @@ K=5 IWAE particles, 4 object slots ("cfg2"); with N > 1 every rank processes its
 shard (weak scaling, the sharding of configs[2]; no collective on the data path of the forward pass).
 frames/step = B * T per rank (all K particles of a frame count as one frame).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel family k_linear (fp32 MFMA dense layers): achieved = algorithmic FLOPs per
-                 launch (135.4 MFLOP/frame at cfg-2, as the reference graph computes
-                 them, / dense launches per step) / average launch duration, measured live with one
-                 HIP-event pair around replays of a graph of the pass's dense launches (boundary
-                 included); frac_device_clock (in-kernel only) and frac_rocprof (profiles/, recomputable
-                 with tools/roofline_from_rocprof.py) are reported beside it; peak = 157.3 TFLOP/s.
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline     — dominant kernel family (the fp32-MFMA dense layers k_linear* / k_rnn_tail) from a PER-DISPATCH
+                 TIMELINE of one step measured live, without a profiler: the same step replayed on
+                 libsqair_hip_timeline.so (the library compiled with -DSQAIR_TIMELINE: every wave stamps its start
+                 and end on the device wall clock, sqair_amd/timeline.py).  achieved = algorithmic FLOPs per launch
+                 (135.4 MFLOP/frame at cfg-2, as the reference graph computes them, / dense
+                 launches per step) / average SLOT of a dense launch (its busy time + the dependent-launch gap up to
+                 the next dispatch: the slots of all dispatches sum to the step); frac_busy_only and
+                 frac_whole_step beside it; peak = 157.3 TFLOP/s.  The committed profiles/r03_timeline_*.csv
+                 are the same measurement (tools/timeline.py; `--recompute` recomputes the fractions from them).
+  roofline_hbm — the gather / scatter / reduce class (k_crop_row, k_insert_loglik, k_compact, k_logprob): busy time
+                 from the same timeline, algorithmic bytes from the shapes (sqair_amd/timeline.py), PMC traffic
+                 from profiles/ when it was measured on this build; peak = 8 TB/s.
   cpu_baseline — the oracle (PyTorch-CPU fp32 restatement at the reference's op granularity,
                  kind "port": the TF1 reference cannot run here) timed on the host cores on a bounded
                  sample of the same workload; only this leg imports oracle/.
+  train        — the full training step on the same workload (reported separately), with the
+                 collective that ran (`rccl_ranks`, `allreduce_on_launch_stream`, its measured time).
+  single_gpu_at_global_batch — N > 1 only: rank 0 alone on B * N sequences (outside `value`), the strong-scaling reference.
 """
 from __future__ import annotations
 
@@ -38,7 +47,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense f32-in matrix peak (= vector peak)
-FLOP_PER_FRAME_CFG2 = 2 * 5 * 13543744  # 2 * K * MACs per frame-particle (SURVEY.md 8(d), Appendix D, N=4)
+MACS_PER_FRAME_PARTICLE = {1: 10166288, 2: 13543744, 3: 13543744, 4: 20298656, 5: 27760960}
 
 
 def cpu_baseline(F, hw, P, obs, noise, hip_ref, budget_s=25.0):
@@ -106,6 +115,116 @@ def cpu_baseline(F, hw, P, obs, noise, hip_ref, budget_s=25.0):
                             elbo_iwae_oracle=float(m.elbo_iwae), elbo_iwae_hip=hip_ref["elbo_iwae"]))
 
 
+def timed_steps(step_fn, n, dist, device):
+    """The contract's timed region: barrier + synchronize on both sides, EXACTLY n steps, MAX over ranks."""
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step_fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    return el
+
+
+def timeline_roofline(F, Ftr, hw, P, obs, nums, algo_flops_step, ms_fwd, ms_train, cfg_id, batch_override, bid):
+    """Per-dispatch timeline of one forward and one training step on the timeline build of the library (sqair_amd/timeline.py)
+    -> the `roofline` / `roofline_hbm` objects and a busy / gap summary of the training step."""
+    from sqair_amd import timeline as TL
+    from sqair_amd.train import Trainer
+    T, B = int(obs.shape[0]), int(obs.shape[1])
+    K, N = int(F.k_particles), int(F.n_steps_per_image)
+    core_t, model_t = TL.make_model(F, hw, P, obs, nums, timeline=True, device="cuda:{}".format(torch.cuda.current_device()))
+    tl = TL.Timeline(core_t)
+    n = [0]
+
+    def fwd():
+        core_t.draw_noise(seed=1000, step=n[0], global_batch=B, b0=0)
+        n[0] += 1
+        core_t.forward(use_graph=True)
+    ms_t = TL.time_steps(core_t, fwd, steps=10)
+    rows, ev_ms = tl.measure(fwd, warm=2)
+    s, d = TL.summarise(rows, ev_ms), TL.dense_stats(rows)
+    alg = TL.algorithmic_hbm_bytes(T, B, K, N, hw[0], hw[1], G=int(F.glimpse_size), nh=core_t.nh, nw=core_t.nw, snh=core_t.snh,
+                                   psnh=core_t.psnh, masked=bool(F.masked_glimpse), train=False)
+    # PMC traffic measured by rocprofv3 on this build, if committed (tools/profile_round.sh)
+    traffic, traffic_note, fam_traffic = None, None, None
+    tpath = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+    if os.path.exists(tpath) and cfg_id == 2 and not batch_override:
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("build_id") == bid:
+                traffic = tj.get("dominant_bytes_per_launch")
+                fam_traffic = tj.get("family_bytes_per_step")
+                traffic_note = "PMC FETCH_SIZE / WRITE_SIZE of {} on this build (profiles/r03_hbm_traffic.json, two separate --pmc passes)".format(tj.get("dominant"))
+            else:
+                traffic_note = "profiles/r03_hbm_traffic.json was measured on build {} != this build {}: not quoted".format(tj.get("build_id"), bid)
+        except Exception as e:  # a broken profile file must not take the bench line down
+            traffic_note = "profiles unreadable: {}".format(e)
+    per = algo_flops_step / max(d["launches"], 1)
+
+    def frac(us):
+        return per / (us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS
+    committed = None
+    cpath = os.path.join(ROOT, "profiles", "r03_timeline.json")
+    if os.path.exists(cpath) and cfg_id == 2 and not batch_override:
+        try:
+            cj = json.load(open(cpath))
+            committed = dict(file="profiles/r03_timeline.json (+ r03_timeline_fwd.csv, r03_timeline_train.csv)",
+                             same_build_as_this_run=cj.get("build_id") == bid, build_id=cj.get("build_id"),
+                             frac_slot=cj["fwd"]["dense_frac"]["frac_slot"], frac_busy_only=cj["fwd"]["dense_frac"]["frac_busy_only"],
+                             recompute="python tools/timeline.py --recompute profiles/r03_timeline_fwd.csv")
+        except Exception as e:
+            committed = dict(error=str(e))
+    roofline = dict(
+        kernel="fp32-MFMA dense layers (k_linear*, k_rnn_tail; {} launches/step)".format(d["launches"]),
+        bound="mfma", achieved=per / (d["avg_slot_us"] * 1e-6) / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+        frac=frac(d["avg_slot_us"]), traffic=traffic, traffic_note=traffic_note,
+        frac_is="frac_slot: algorithmic FLOPs per dense launch / average slot of a dense launch (first-wave start to the next "
+                "dispatch's first-wave start = busy + dependent-launch gap), from the per-dispatch timeline of one step stamped "
+                "by the kernels themselves (no profiler)",
+        frac_slot=frac(d["avg_slot_us"]), frac_busy_only=frac(d["avg_busy_us"]),
+        frac_whole_step=algo_flops_step / (ms_fwd * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        avg_slot_us=d["avg_slot_us"], avg_busy_us=d["avg_busy_us"], algorithmic_flops_per_launch=per,
+        timeline=dict(dispatches=s["dispatches"], span_us=s["span_us"], busy_us=s["busy_us"], gap_us=s["gap_us"],
+                      overlap_us=s["overlap_us"], this_step_hip_event_ms=ev_ms, timeline_build_ms_per_step=ms_t,
+                      product_ms_per_step=ms_fwd, stamp_overhead=ms_t / ms_fwd - 1.0,
+                      span_over_product_step=s["span_us"] / (ms_fwd * 1e3),
+                      dense_share_of_step=d["slot_us"] / max(s["slot_sum_us"], 1e-9),
+                      families={k: dict(launches=v["launches"], slot_us=round(v["slot_us"], 1), busy_us=round(v["busy_us"], 1))
+                                for k, v in sorted(s["families"].items(), key=lambda kv: -kv[1]["slot_us"])}),
+        committed_profile=committed, build_id=bid,
+        note="algorithmic = as-reference FLOPs of the step (SURVEY.md 8(d): input encoder counted N times, mask MLP twice, as the "
+             "reference graph computes them) / dense launches of the step; slots of ALL dispatches sum to the step (span); the "
+             "stamped build runs the step `stamp_overhead` slower than the product library.")
+    roofline_hbm = TL.hbm_class(rows, alg, fam_traffic)
+    train_tl = None
+    if ms_train is not None:
+        tr = Trainer(model_t, Ftr, use_graph=True)
+        step_t = lambda: tr.step(seed=2000, global_batch=B, b0=0)  # noqa: E731
+        ms_tt = TL.time_steps(core_t, step_t, steps=5)
+        rows_t, ev_t = tl.measure(step_t, warm=2)
+        st = TL.summarise(rows_t, ev_t)
+        algt = TL.algorithmic_hbm_bytes(T, B, K, N, hw[0], hw[1], G=int(F.glimpse_size), nh=core_t.nh, nw=core_t.nw,
+                                        snh=core_t.snh, psnh=core_t.psnh, masked=bool(F.masked_glimpse), train=True)
+        train_tl = dict(dispatches=st["dispatches"], span_us=st["span_us"], busy_us=st["busy_us"], gap_us=st["gap_us"],
+                        timeline_build_ms_per_step=ms_tt, stamp_overhead=ms_tt / ms_train - 1.0,
+                        families={k: dict(launches=v["launches"], slot_us=round(v["slot_us"], 1), busy_us=round(v["busy_us"], 1))
+                                  for k, v in sorted(st["families"].items(), key=lambda kv: -kv[1]["slot_us"])[:12]},
+                        hbm_class=[e for e in TL.hbm_class(rows_t, algt) if e["kernel"].endswith("_bwd")])
+    tl.close()
+    return roofline, roofline_hbm, train_tl
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +232,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-timeline", action="store_true", help="skip the per-dispatch timeline (roofline objects become null)")
     ap.add_argument("--cfg", type=int, default=2, help="BASELINE.json config id used as the workload (default 2)")
     ap.add_argument("--train-steps", type=int, default=-1,
                     help="steps of the extra training-step leg (default min(steps, 20); 0 = skip)")
@@ -122,6 +242,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="sequences per GPU (default: the configuration's own; other values are batch-scaling experiments, "
                          "not BASELINE's metric)")
+    ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"],
+                    help="process-group backend (default: nccl = RCCL when every rank has its own device, gloo when ranks share "
+                         "devices, e.g. a 2-rank functional check on a 1-GPU box)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise a 1-rank process group + RCCL communicator at N = 1")
     ap.add_argument("--time-transition", default="GRU", choices=["GRU", "LSTM"],
                     help="propagation temporal cell (the shipped config and BASELINE's metric use GRU)")
     ap.add_argument("--prior-transition", default="GRU", choices=["GRU", "LSTM"], help="propagation prior cell (shipped: GRU)")
@@ -148,15 +272,17 @@ def main():
     if args.gpus != world:
         raise SystemExit("--gpus {} but WORLD_SIZE {} (launch one rank per GPU, or run without WORLD_SIZE)".format(args.gpus, world))
     n_dev = torch.cuda.device_count()
-    # RCCL wants one device per rank.  With fewer visible devices than ranks (the 1-GPU test box) the ranks share devices
-    # and the process group falls back to gloo — a functional check of the N > 1 code path, reported as such
-    # ("rccl_ranks": 0); SQAIR_DIST_BACKEND overrides.
-    backend = os.environ.get("SQAIR_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")
+    # RCCL wants one device per rank.  With fewer visible devices than ranks (a 2-rank functional check on a 1-GPU box) the
+    # ranks share devices and the process group is gloo — reported as such ("rccl_ranks": 0).  With a device per rank the
+    # native RCCL communicator is REQUIRED: failing to build it is an error (non-zero exit), never a silent fallback.
+    own_device = n_dev >= world
+    backend = args.dist_backend or ("nccl" if own_device else "gloo")
     local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
+    device = "cuda:{}".format(local_rank)
     dist = None
-    if world > 1 or os.environ.get("SQAIR_FORCE_DIST") == "1":  # (the env knob: single-rank RCCL group, to measure what
-        import torch.distributed as dist                            #  a communicator in the process costs the graph replays)
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
@@ -164,51 +290,56 @@ def main():
         kw = dict(device_id=torch.device("cuda", local_rank)) if backend == "nccl" else {}
         dist.init_process_group(backend=backend, **kw)  # "nccl" = RCCL on ROCm
     # the training step's gradient all-reduce goes through RCCL's C API on the library's own launch stream
-    comm, comm_error = None, None
+    comm = None
     if dist is not None and backend == "nccl":
         from sqair_amd.rccl import RcclComm
+        comm_error = None
         try:
-            comm = RcclComm.from_process_group("cuda:{}".format(local_rank))
-        except Exception as e:  # e.g. the bundled librccl.so cannot be opened a second time through ctypes
+            comm = RcclComm.from_process_group(device)
+        except Exception as e:
             comm_error = "{}: {}".format(type(e).__name__, e)
-        # all ranks or none: a rank without the native communicator sends everybody to the process group's all-reduce
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda:{}".format(local_rank))
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and comm is not None:
-            comm.destroy()
-            comm = None
-        if comm is None and rank == 0:
-            print("bench: native RCCL communicator unavailable ({}); gradient all-reduce through torch.distributed".format(
-                comm_error or "failed on another rank"), file=sys.stderr)
+        if int(ok.item()) == 0:
+            print("bench: rank {}: the native RCCL communicator could not be built ({}); refusing to fall back".format(
+                rank, comm_error or "failed on another rank"), file=sys.stderr, flush=True)
+            if comm is not None:
+                comm.destroy()
+            dist.destroy_process_group()
+            raise SystemExit(3)
+        assert comm.n_ranks == world
 
-    from sqair_amd.data import config_inputs
+    from sqair_amd._capi import build_id
+    from sqair_amd.data import config_inputs, make_sequences, to_float
     from sqair_amd.flags import make_flags
     from sqair_amd.model import Model, SqairCore
     from sqair_amd.params import init_params
+    from sqair_amd.train import Trainer
 
     # every rank synthesises its own shard of the global batch (seeded by rank), weights are replicated
     ov, obs, nums, _ = config_inputs(args.cfg, B=args.batch or None)
+
+    def shard_data(n_seq, seed):
+        d = make_sequences(n_seq, T=obs.shape[0], canvas=obs.shape[2:], n_objects=(0, nums.shape[-1] - 1),
+                           obj_size=28 if obs.shape[2] <= 64 else 72, seed=seed)
+        return to_float(d["imgs"]), d["nums"]
     if rank > 0:
-        from sqair_amd.data import make_sequences, to_float
-        d = make_sequences(obs.shape[1], T=obs.shape[0], canvas=obs.shape[2:], n_objects=(0, nums.shape[-1] - 1),
-                           obj_size=28 if obs.shape[2] <= 64 else 72, seed=1234 + args.cfg + 1000 * rank)
-        obs, nums = to_float(d["imgs"]), d["nums"]
+        obs, nums = shard_data(obs.shape[1], 1234 + args.cfg + 1000 * rank)
     ov.update(time_transition=args.time_transition, prior_transition=args.prior_transition, transition=args.transition)
     F = make_flags(**ov)
+    Ftr = make_flags(**dict(ov, learning_rate=1e-5, train_itr=1000000))
     hw = tuple(int(v) for v in obs.shape[2:])
     T, B = int(obs.shape[0]), int(obs.shape[1])
     K, N = int(F.k_particles), int(F.n_steps_per_image)
     P = {k: np.asarray(v, dtype=np.float32) for k, v in
          init_params(F, hw, seed=0, mean_img=obs.mean((0, 1)), jitter=0.02).items()}
-    device = "cuda:{}".format(local_rank)
     core = SqairCore(F, hw, device=device)
     # one stream for everything (noise draw, graph replays, optimiser, reductions): see SqairCore.on_stream
     torch.cuda.set_stream(core.stream)
     core.set_params(P)
     model = Model(obs, None, core, K, presence=nums, outputs="minimal")
-    gen = torch.Generator(device=device)
-    gen.manual_seed(1000 + rank)
     use_graph = not args.no_graph
+    bid = build_id()
 
     step_no = [0]
 
@@ -220,26 +351,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
     if dist is not None:
+        torch.cuda.synchronize()
         dist.barrier()
         # RCCL writes its start-up banner (NCCL_DEBUG=VERSION on the GPU boxes) to the C stdout buffer at communicator
         # creation: push it out now, on every rank, so that rank 0's JSON line is the LAST thing on stdout
         import ctypes
         ctypes.CDLL(None).fflush(None)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = timed_steps(step, args.steps, dist, device)
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_step = B * T * world
     value = frames_per_step / (elapsed / args.steps)
@@ -258,43 +377,83 @@ def main():
     train = None
     n_train = min(args.steps, 20) if args.train_steps < 0 else args.train_steps
     if n_train > 0:
-        from sqair_amd.train import Trainer
-        Ftr = make_flags(**dict(ov, learning_rate=1e-5, train_itr=1000000))
         trainer = Trainer(model, Ftr, use_graph=use_graph, comm=comm)
+        tstep = lambda: trainer.step(seed=2000, global_batch=B * world, b0=rank * B)  # noqa: E731
         for _ in range(max(2, min(args.warmup, 3))):
-            trainer.step(seed=2000, global_batch=B * world, b0=rank * B)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n_train):
-            trainer.step(seed=2000, global_batch=B * world, b0=rank * B)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([el], dtype=torch.float64, device=device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
+            tstep()
+        el = timed_steps(tstep, n_train, dist, device)
+        allreduce_ms = None
+        if world > 1:  # the collective alone, same buffer, same stream (20 back to back between one event pair)
+            with core.on_stream():
+                from sqair_amd.dist import allreduce_flat_grads
+                g = core.flat_grad.clone()
+                for _ in range(3):
+                    allreduce_flat_grads(g, comm=comm, stream=core.stream)
+                torch.cuda.synchronize()
+                dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(core.stream)
+                for _ in range(20):
+                    allreduce_flat_grads(g, comm=comm, stream=core.stream)
+                e1.record(core.stream)
+                torch.cuda.synchronize()
+                allreduce_ms = e0.elapsed_time(e1) / 20
         train = dict(value=frames_per_step / (el / n_train), unit="frames/s", ms_per_step=el / n_train * 1e3, steps=n_train,
                      scaling="weak", graph_nodes=getattr(core, "train_graph_nodes", None),
+                     rccl_ranks=comm.n_ranks if comm is not None else 0,
+                     allreduce_on_launch_stream=bool(comm is not None) if world > 1 else None,
+                     allreduce_ms=allreduce_ms,
                      collective="all-reduce(sum) of {} fp32 gradients ({:.1f} MB) per step, {}; 1/world folded into the fused "
                                 "RMSProp kernel".format(core.n_params, core.n_params * 4 / 1e6,
                                                         "ncclAllReduce (RCCL C API) on the launch stream" if comm is not None
-                                                        else "torch.distributed " + backend) if world > 1 else "none (1 rank)",
+                                                        else "torch.distributed " + backend + " (ranks share devices: functional "
+                                                        "check only)") if world > 1 else "none (1 rank)",
                      what="draw noise + forward(train) + VIMCO target + backward (one HIP-graph replay) + all-reduce + "
                           "RMSProp + re-pack; finite={}".format(bool(torch.isfinite(core.flat).all())))
         core.set_params(P)  # back to the benchmark parameters for the parity / roofline legs below
+
+    # ---- N > 1: the strong-scaling reference.  Rank 0 alone processes the GLOBAL batch (B * world sequences) on its GPU, after
+    # the timed regions and outside `value`: weak scaling says N GPUs do N x the work in the same time; this says what ONE GPU
+    # needs for the same N x work (the small-batch step is latency-bound, so one GPU is far better than 1/N of the job).
+    single = None
+    if world > 1:
+        if rank == 0:
+            try:
+                obs_g, nums_g = shard_data(B * world, 99)
+                core_g = SqairCore(F, hw, device=device)
+                with core_g.on_stream():
+                    core_g.set_params(P)
+                    model_g = Model(obs_g, None, core_g, K, presence=nums_g, outputs="minimal")
+                    k = [0]
+
+                    def gstep():
+                        core_g.draw_noise(seed=1000, step=k[0], global_batch=B * world, b0=0)
+                        k[0] += 1
+                        core_g.forward(use_graph=use_graph)
+                    from sqair_amd.timeline import time_steps
+                    ms_g = time_steps(core_g, gstep, steps=max(5, args.steps // 4), warm=3)
+                    single = dict(sequences=B * world, forward_ms_per_step=ms_g, forward_value=B * world * T / (ms_g * 1e-3), unit="frames/s")
+                    if n_train > 0:
+                        tr_g = Trainer(model_g, Ftr, use_graph=use_graph, comm=None)
+                        ms_gt = time_steps(core_g, lambda: tr_g.step(seed=2000, global_batch=B * world, b0=0), steps=max(3, n_train // 4), warm=2)
+                        single.update(train_ms_per_step=ms_gt, train_value=B * world * T / (ms_gt * 1e-3))
+                        del tr_g
+                    single["speedup_of_{}_gpus_over_one_gpu_same_global_batch".format(world)] = dict(
+                        forward=value / single["forward_value"],
+                        train=(train["value"] / single["train_value"]) if train and "train_value" in single else None)
+                del model_g, core_g
+                torch.cuda.empty_cache()
+                torch.cuda.set_stream(core.stream)
+            except Exception as e:  # never take the bench line down
+                single = dict(error="{}: {}".format(type(e).__name__, e))
+        torch.cuda.synchronize()
+        dist.barrier()
 
     # ---- independent batches in flight (extra object "streams"): handles share nothing, so n of them replaying their graphs on
     # n streams overlap their dependent-launch chains.  Throughput of evaluation / serving, NOT the metric's one-pass-at-a-time rate.
     streams = None
     if world == 1 and use_graph and args.streams > 1:
         try:
-            from sqair_amd.data import make_sequences, to_float
             cores = [core]
             for i in range(1, args.streams):
                 d_i = make_sequences(B, T=T, canvas=hw, n_objects=(0, nums.shape[-1] - 1), obj_size=28 if hw[0] <= 64 else 72,
@@ -336,98 +495,38 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (the fp32-MFMA dense layers) ----
-    # Three measurements of "average dense-launch duration", all reported; `frac` uses (1):
-    #  (1) HIP events, live: a graph holding ONLY the dense launches of the pass (same kernels / arguments / order) replayed
-    #      between one event pair on the launch stream -> duration per launch INCLUDING the dependent kernel boundary, i.e. what
-    #      a per-dispatch profiler sees, without a profiler attached;
-    #  (2) device clock, live: first-workgroup-start -> last-workgroup-end per launch (s_memrealtime, stamped by the kernels in
-    #      one eager pass) -> in-kernel time only, no boundary;
-    #  (3) rocprofv3 --kernel-trace --stats of this command, committed under profiles/ for THIS build (build_id must match):
-    #      per-dispatch duration under the profiler (its floor for a trivial dependent kernel is ~4.2-4.5 us on this stack).
-    from sqair_amd._capi import build_id
-    bid = build_id()
-    prof = None
-    for _ in range(3):
-        prof = core.profile_linear()
-    torch.cuda.synchronize()
-    core.forward(use_graph=use_graph)          # a real pass: finite activations in the workspace for the dense-only replay
-    if use_graph:
-        lg = core.profile_linear_graph(replays=20)
-    else:  # (--no-graph is what the PMC passes use: rocprofv3's counter collection crashes on graph launches)
-        lg = dict(ms_per_replay=float("nan"), launches=prof["launches"], avg_launch_us=float("nan"))
-    torch.cuda.synchronize()
-    lin_ms = prof["linear_ms"]
+    # ---- roofline: per-dispatch timeline of one step, stamped by the kernels (module docstring; sqair_amd/timeline.py) ----
+    algo_flops_step = float(B * T) * 2.0 * K * MACS_PER_FRAME_PARTICLE[args.cfg]
     nh_in = 256 + 4 + 2 * int(F.n_what)
-    algo_flops_step = float(B * T) * (FLOP_PER_FRAME_CFG2 if (args.cfg in (2, 3)) else
-                                     2.0 * K * {1: 10166288, 4: 20298656, 5: 27760960}[args.cfg])
     if args.time_transition == "LSTM":  # a 4th gate over the same [x 360 | h 256] -> 256 input: + (360 + 256) * 256 MACs / slot
         algo_flops_step += float(B * T) * 2.0 * K * N * (nh_in + 256) * 256
     if args.prior_transition == "LSTM":  # likewise over [what, where 54 | h 256]
         algo_flops_step += float(B * T) * 2.0 * K * N * (int(F.n_what) + 4 + 256) * 256
     gates = {"VanillaRNN": 1, "GRU": 3, "LSTM": 4}[args.transition] - 1   # extra gate blocks of the two slot RNNs
     algo_flops_step += float(B * T) * 2.0 * K * N * gates * ((416 + 256) + (256 + 256 + int(F.n_what) + 5 + 256)) * 256
-    n_launch = prof["launches"]
-    algo_per_launch = algo_flops_step / n_launch
-    exec_per_launch = prof["executed_flops"] / n_launch
-    us_events = lg["avg_launch_us"]
-    us_clock = lin_ms * 1e3 / n_launch
-
-    def tf(flop, us):
-        return flop / (us * 1e-6) / 1e12
-
-    rocprof = None
-    stats_path = os.path.join(ROOT, "profiles", "r02_kernel_stats.csv")
-    meta_path = os.path.join(ROOT, "profiles", "r02_profile_meta.json")
-    traffic = traffic_note = None
-    if os.path.exists(meta_path):
+    roofline = roofline_hbm = None
+    if use_graph and not args.no_timeline:
         try:
-            meta = json.load(open(meta_path))
-            same_build = meta.get("build_id") == bid
-            if os.path.exists(stats_path) and args.cfg == 2 and not args.batch:
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
-                from roofline_from_rocprof import dense_average_ns
-                avg_ns, per = dense_average_ns(stats_path)
-                dom = max(per, key=lambda k: per[k][0])
-                rocprof = dict(avg_launch_us=avg_ns / 1e3, dominant=dom, dominant_avg_launch_us=per[dom][1] / 1e3,
-                               frac=tf(algo_per_launch, avg_ns / 1e3) / PEAK_FP32_MFMA_TFLOPS,
-                               frac_dominant=tf(algo_per_launch, per[dom][1] / 1e3) / PEAK_FP32_MFMA_TFLOPS,
-                               same_build_as_this_run=same_build, profile_build_id=meta.get("build_id"),
-                               recompute="python tools/roofline_from_rocprof.py profiles/r02_kernel_stats.csv")
-            tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if tj.get("build_id") == bid:
-                    traffic = tj.get("dominant_bytes_per_launch")
-                    traffic_note = "PMC FETCH_SIZE / WRITE_SIZE of {} on this build (profiles/r02_hbm_traffic.json, two separate --pmc passes)".format(tj.get("dominant"))
-                else:
-                    traffic_note = "profiles/r02_hbm_traffic.json was measured on build {} != this build {}: not quoted".format(tj.get("build_id"), bid)
-        except Exception as e:  # a broken profile file must not take the bench line down
-            traffic_note = "profiles unreadable: {}".format(e)
-    roofline = dict(
-        kernel="k_linear family (fp32 MFMA 16x16x4 dense layers, {} launches/step)".format(n_launch),
-        bound="mfma", achieved=tf(algo_per_launch, us_events), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-        frac=tf(algo_per_launch, us_events) / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_note=traffic_note,
-        frac_is="frac_hip_events: algorithmic FLOPs per launch / average launch duration incl. the dependent kernel boundary, one "
-                "HIP-event pair around 20 replays of a graph of the pass's dense launches only",
-        frac_hip_events=tf(algo_per_launch, us_events) / PEAK_FP32_MFMA_TFLOPS,
-        frac_device_clock=tf(algo_per_launch, us_clock) / PEAK_FP32_MFMA_TFLOPS,
-        frac_rocprof=(rocprof or {}).get("frac"),
-        frac_executed_hip_events=tf(exec_per_launch, us_events) / PEAK_FP32_MFMA_TFLOPS,
-        frac_executed_device_clock=tf(exec_per_launch, us_clock) / PEAK_FP32_MFMA_TFLOPS,
-        avg_launch_us=us_events, avg_launch_us_device_clock=us_clock, rocprof=rocprof,
-        algorithmic_flops_per_launch=algo_per_launch, executed_flops_per_launch=exec_per_launch,
-        dense_only_graph_ms=lg["ms_per_replay"], dense_share_of_step=lg["ms_per_replay"] / ms_per_step,
-        step_ms_hip_events_eager=prof["forward_ms_events"], build_id=bid,
-        note="algorithmic = as-reference FLOPs of the step (SURVEY.md 8(d): input encoder counted N times, mask MLP twice, as the "
-             "reference graph computes them); executed = what the hoisted launch sequence runs.  Per-launch HIP events cannot "
-             "resolve 2-5 us kernels (an empty pair costs ~8 us here), hence the dense-only graph.",
-    )
+            roofline, roofline_hbm, train_tl = timeline_roofline(
+                F, Ftr, hw, P, obs, nums, algo_flops_step, ms_per_step, train["ms_per_step"] if train else None, args.cfg,
+                args.batch, bid)
+            if train is not None:
+                train["timeline"] = train_tl
+            torch.cuda.set_stream(core.stream)
+        except Exception as e:  # the timeline library missing / failing must not take the bench line down, but it must show
+            roofline = dict(error="{}: {}".format(type(e).__name__, e), bound="mfma", achieved=None, peak=PEAK_FP32_MFMA_TFLOPS,
+                            unit="TFLOP/s", frac=None, traffic=None)
+    # the whole-step figure needs no instrumentation at all: algorithmic FLOPs of the step / the timed step
+    whole = algo_flops_step / (ms_per_step * 1e-3) / 1e12
+    if roofline is None:
+        roofline = dict(kernel="whole step (no timeline requested)", bound="mfma", achieved=whole, peak=PEAK_FP32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=whole / PEAK_FP32_MFMA_TFLOPS, traffic=None)
 
     cpu = None
     if not args.no_cpu_baseline:
         # parity + timing on the same frames / parameters / noise as one GPU step
         full = Model(obs, None, core, K, presence=nums, outputs=["log_weights_per_timestep", "discrete_log_prob", "presence"])
+        gen = torch.Generator(device=device)
         gen.manual_seed(4242)
         full.core.draw_noise(gen)
         noise = full.core.noise.cpu().numpy().copy()
@@ -439,7 +538,7 @@ def main():
         cpu = cpu_baseline(F, hw, P, obs, noise, hip_ref)
 
     line = {
-        "metric": "frames/sec (forward IWAE ELBO, 10-step 50x50 moving glyphs, K=5)",
+        "metric": "frames/sec (forward IWAE ELBO, {}-step {}x{} moving glyphs, K={})".format(T, hw[0], hw[1], K),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -448,7 +547,8 @@ def main():
             args.cfg, T, hw[0], hw[1], B, K, N, args.transition, args.time_transition, args.prior_transition, use_graph), "global_batch": B * world, "seq_len": T,
             "parallelism": "dp{}".format(world), "graph_nodes": core.graph_nodes()},
         "elbo_iwae_nats_per_seq": elbo, "elbo_vae_nats_per_seq": elbo_vae,
-        "roofline": roofline, "cpu_baseline": cpu, "train": train, "streams": streams,
+        "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu, "train": train,
+        "single_gpu_at_global_batch": single, "streams": streams, "build_id": bid,
     }
     if cpu is not None:
         line["speedup_vs_cpu_baseline"] = value / world / cpu["value"]

@@ -280,6 +280,22 @@ int sqair_set_option(SqairHandle* h, const char* name, int value);
  * flag_dev: caller-owned device int32[2] scratch. */
 int sqair_check_finite(SqairHandle* h, const float* x, int64_t n, const char* what, int32_t* flag_dev, void* stream);
 
+/* ---- per-dispatch timeline (measurement; bench.py's roofline, tools/timeline.py) -----------------------------------------
+ * libsqair_hip_timeline.so is THIS library compiled with -DSQAIR_TIMELINE: every kernel takes one more argument and every
+ * wave stores {start, end} of its life on the 100 MHz device wall clock (s_memrealtime) into its own 16-byte slot of `buf`.
+ * Between _begin and _end every launch issued through the library (eagerly or into a capture) is assigned the next slot
+ * range (an eager launch a fresh one every time); replaying a graph captured in between re-stamps the same slots.  _count /
+ * _end return the number of records; _record(i)
+ * gives kernel name, offset of the range in 8-byte words, waves (= pairs) and workgroups.  Reduce min(start) / max(end) over
+ * the pairs of a record for first-wave-start / last-wave-end of that dispatch (zero pairs = padding).  A stamped step runs
+ * ~3 % slower than the product library's (measured).  The production library returns -3 from
+ * _begin (sqair_timeline_available() == 0) and carries none of this in its kernels. */
+int sqair_timeline_available(void);
+int sqair_timeline_begin(SqairHandle* h, void* buf, int64_t bytes);
+int sqair_timeline_count(const SqairHandle* h);  /* records so far (recording continues) */
+int sqair_timeline_end(SqairHandle* h);
+int sqair_timeline_record(const SqairHandle* h, int i, const char** kernel, int64_t* offset_u64, int* waves, int* workgroups);
+
 /* Generation modes (sqair/sqair_modules.py:157-170, :294-302, sqair/seq.py:198-200).  With
  * cfg.sample_from_prior the propagation posterior log-probabilities are evaluated at samples of the propagation PRIOR, and
  * in frames t > cfg.generate_after those samples replace what / where / presence of the propagated objects, discovery's

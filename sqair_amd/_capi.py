@@ -84,6 +84,12 @@ _PROTOS = {
     "sqair_clear_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sqair_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "sqair_check_finite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_void_p, C.c_void_p]),
+    "sqair_timeline_available": (C.c_int, []),
+    "sqair_timeline_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "sqair_timeline_count": (C.c_int, [C.c_void_p]),
+    "sqair_timeline_end": (C.c_int, [C.c_void_p]),
+    "sqair_timeline_record": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]),
     "sqair_lstm_test": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "sqair_lstm_cell_bwd_test": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_void_p]),
     "sqair_get_config": (C.c_int, [C.c_void_p, C.POINTER(SqairConfig)]),
@@ -117,29 +123,33 @@ _PROTOS = {
 
 EXPORTED_SYMBOLS = [n for n in _PROTOS if not n.startswith("sqair_debug")]
 
-_lib = None
+TIMELINE_LIB_PATH = os.path.join(_HERE, "libsqair_hip_timeline.so")
+
+_libs = {}
 
 
-def lib():
-    """Loads the shared library (once).  Raises ImportError with the build hint if it is absent."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def lib(path=None):
+    """Loads the shared library (once per path).  Raises ImportError with the build hint if it is absent.  `path` selects a
+    build VARIANT of the same sources (TIMELINE_LIB_PATH: every wave stamps its start / end, measurement only); the default is
+    the product library.  There is no environment override."""
+    path = path or LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
             raise ImportError(
-                "libsqair_hip.so is missing ({}): build it with `python -c 'import __graft_entry__ as g; "
-                "g.build()'` or `python sqair_amd/csrc/build.py`; sqair_amd has no CPU fallback".format(LIB_PATH))
+                "{} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`python sqair_amd/csrc/build.py [--timeline]`; sqair_amd has no CPU fallback".format(path))
         # torch first: its wheel bundles its own HIP runtime; loading ours before it would put two runtimes into the
         # process (the second one then reports "no ROCm-capable device")
         import torch  # noqa: F401
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
         if l.sqair_abi_version() != 1:
-            raise ImportError("libsqair_hip.so ABI version mismatch")
-        _lib = l
-    return _lib
+            raise ImportError("{} ABI version mismatch".format(os.path.basename(path)))
+        _libs[path] = l
+    return _libs[path]
 
 
 def build_id():
@@ -156,7 +166,7 @@ def build_id():
     return hsh.hexdigest()[:16]
 
 
-def check(handle, rc, what):
+def check(handle, rc, what, library=None):
     if rc != 0:
-        msg = lib().sqair_last_error(handle)
+        msg = (library or lib()).sqair_last_error(handle)
         raise RuntimeError("{} failed (rc={}): {}".format(what, rc, msg.decode() if msg else ""))

@@ -1149,6 +1149,63 @@ extern "C" int sqair_clear_workspace(SqairHandle* h, void* workspace, int64_t wo
 }
 
 // ------------------------------------------------------------------------------------------------
+// per-dispatch timeline (sqair_common.h: SQ_TLP / SQ_TL_SCOPE / SQ_LAUNCH; only libsqair_hip_timeline.so records anything)
+#ifdef SQAIR_TIMELINE
+namespace {
+struct TlRecord { std::string kernel; int64_t off; int waves, wgs; };
+struct TlState { unsigned long long* buf = nullptr; int64_t cap = 0, used = 0; bool on = false, overflow = false; std::vector<TlRecord> rec; };
+TlState g_tl;
+}  // namespace
+SqTl sq_tl_next(const char* kernel, dim3 grid, dim3 block) {
+  if (!g_tl.on) return SqTl{nullptr, 0, 0, 0, 0};
+  if (block.y != 1 || block.z != 1) { g_tl.overflow = true; return SqTl{nullptr, 0, 0, 0, 0}; }  // (1-D workgroups only)
+  const int64_t wgs = (int64_t)grid.x * grid.y * grid.z;
+  // one {start, end} pair per wave; a workgroup's pairs are padded to whole 128-byte lines, so that workgroups on different
+  // XCDs (whose L2s are not coherent with each other) never write parts of the same line
+  const int64_t nw = (((int64_t)block.x * block.y * block.z + 63) / 64 + 7) / 8 * 8;
+  const int64_t need = 2 * wgs * nw;
+  if (g_tl.used + need > g_tl.cap) { g_tl.overflow = true; return SqTl{nullptr, 0, 0, 0, 0}; }
+  TlRecord r;
+  r.kernel = kernel; r.off = g_tl.used; r.waves = (int)(wgs * nw); r.wgs = (int)wgs;
+  g_tl.rec.push_back(r);
+  SqTl t{g_tl.buf + g_tl.used, grid.x, grid.y, (unsigned)nw, 0};
+  g_tl.used += need;
+  return t;
+}
+extern "C" int sqair_timeline_available(void) { return 1; }
+extern "C" int sqair_timeline_begin(SqairHandle* h, void* buf, int64_t bytes) {
+  if (!h || !buf || bytes < 16 || ((uintptr_t)buf & 15)) return -1;
+  g_tl = TlState();
+  g_tl.buf = (unsigned long long*)buf; g_tl.cap = bytes / 8; g_tl.on = true;
+  return 0;
+}
+extern "C" int sqair_timeline_count(const SqairHandle* h) { return h ? (int)g_tl.rec.size() : -1; }
+extern "C" int sqair_timeline_end(SqairHandle* h) {
+  if (!h) return -1;
+  g_tl.on = false;
+  if (g_tl.overflow) { sq_set_error(h, "sqair_timeline_end: the stamp buffer was too small"); return -4; }
+  return (int)g_tl.rec.size();
+}
+extern "C" int sqair_timeline_record(const SqairHandle* h, int i, const char** kernel, int64_t* offset_u64, int* waves, int* workgroups) {
+  if (!h || i < 0 || i >= (int)g_tl.rec.size()) return -1;
+  if (kernel) *kernel = g_tl.rec[i].kernel.c_str();
+  if (offset_u64) *offset_u64 = g_tl.rec[i].off;
+  if (waves) *waves = g_tl.rec[i].waves;
+  if (workgroups) *workgroups = g_tl.rec[i].wgs;
+  return 0;
+}
+#else
+extern "C" int sqair_timeline_available(void) { return 0; }
+extern "C" int sqair_timeline_begin(SqairHandle* h, void*, int64_t) {
+  if (h) sq_set_error(h, "sqair_timeline_begin: this library was built without -DSQAIR_TIMELINE (use libsqair_hip_timeline.so)");
+  return -3;
+}
+extern "C" int sqair_timeline_count(const SqairHandle*) { return -3; }
+extern "C" int sqair_timeline_end(SqairHandle*) { return -3; }
+extern "C" int sqair_timeline_record(const SqairHandle*, int, const char**, int64_t*, int*, int*) { return -3; }
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // documented run-time options (include/sqair_hip.h).  These are API calls of the caller, not environment variables: nothing in
 // the environment can change what a pass computes or launches (the measurement knobs of tools/ exist only in -DSQAIR_KNOBS builds).
 extern "C" int sqair_set_option(SqairHandle* h, const char* name, int value) {
@@ -1161,7 +1218,8 @@ extern "C" int sqair_set_option(SqairHandle* h, const char* name, int value) {
 
 // debug mode of the reference (validate_args / allow_nan_stats=False of its distributions, sqair/core.py:226, :261,
 // sqair/modules.py:318-320): a finite check of a device tensor that fails through the error channel.
-__global__ __launch_bounds__(256) void k_finite_check(const float* __restrict__ x, int64_t n, int* __restrict__ flag) {
+__global__ __launch_bounds__(256) void k_finite_check(const float* __restrict__ x, int64_t n, int* __restrict__ flag SQ_TLP) {
+  SQ_TL_SCOPE;
   int bad = 0;
   int64_t first = n;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -1181,7 +1239,7 @@ extern "C" int sqair_check_finite(SqairHandle* h, const float* x, int64_t n, con
   SQ_CHECK_HIP(hipMemcpyAsync(flag_dev, init, sizeof(init), hipMemcpyHostToDevice, s));
   if (n > 0) {
     const int grid = (int)std::min<int64_t>((n + 255) / 256, 1024);
-    hipLaunchKernelGGL(k_finite_check, dim3(grid), dim3(256), 0, s, x, n, (int*)flag_dev);
+    SQ_LAUNCH(k_finite_check, dim3(grid), dim3(256), 0, s, x, n, (int*)flag_dev);
   }
   SQ_CHECK_HIP(hipMemcpyAsync(got, flag_dev, sizeof(got), hipMemcpyDeviceToHost, s));
   SQ_CHECK_HIP(hipStreamSynchronize(s));

@@ -33,7 +33,8 @@ struct CropBwdArgs {
   float* d_mask;         // optional [R,G*G]
 };
 
-__global__ __launch_bounds__(256) void k_crop_bwd(const CropBwdArgs a, const Dims d) {
+__global__ __launch_bounds__(256) void k_crop_bwd(const CropBwdArgs a, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* img_s = smem;  // H*W
   __shared__ float red_s[4][4];
@@ -107,7 +108,7 @@ extern "C" int sqair_st_crop_bwd(SqairHandle* h, const float* img, const float* 
     (void)hipGetLastError();
     big = true;
   }
-  hipLaunchKernelGGL(k_crop_bwd, dim3(B), dim3(256), shm, (hipStream_t)stream, a, d);
+  SQ_LAUNCH(k_crop_bwd, dim3(B), dim3(256), shm, (hipStream_t)stream, a, d);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -134,7 +135,8 @@ struct InsertBwdArgs {
   int dw_ld;                 // leading dimension of d_where rows (4 = plain, 64 = gradient records)
 };
 
-__global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a, const Dims d) {
+__global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.N, G = d.G, G2 = d.G * d.G, H = d.H, W = d.W, P = d.H * d.W;
   float* gl_s = smem;                 // N * G2   glimpses
@@ -270,7 +272,8 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   }
 }
 
-__global__ void k_reduce_rows(const float* __restrict__ rows, float* __restrict__ out, int R, int P, int accumulate) {
+__global__ void k_reduce_rows(const float* __restrict__ rows, float* __restrict__ out, int R, int P, int accumulate SQ_TLP) {
+  SQ_TL_SCOPE;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   float acc = accumulate ? out[p] : 0.0f;
@@ -278,7 +281,8 @@ __global__ void k_reduce_rows(const float* __restrict__ rows, float* __restrict_
   out[p] = acc;
 }
 // row-chunked variant for the training step: out[p] += sum over this block's rows (float atomics, out pre-zeroed)
-__global__ void k_reduce_rows_atomic(const float* __restrict__ rows, float* __restrict__ out, int R, int P, int rows_per_block) {
+__global__ void k_reduce_rows_atomic(const float* __restrict__ rows, float* __restrict__ out, int R, int P, int rows_per_block SQ_TLP) {
+  SQ_TL_SCOPE;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
@@ -302,8 +306,8 @@ extern "C" int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, 
   InsertBwdArgs a{glimpse, where_logits, presence, img, mean_img, g_data_ll, d_glimpse, d_where_logits, (float*)scratch,
                   c.output_std, c.background_std, nullptr, 0, 4};
   const size_t shm = ((size_t)2 * d.N * d.G * d.G + (size_t)d.N * (d.W + d.H) + d.N + d.N * 4 + 4 * d.N * 4) * sizeof(float);
-  hipLaunchKernelGGL(k_insert_loglik_bwd, dim3(d.R, 1), dim3(256), shm, (hipStream_t)stream, a, d);
-  hipLaunchKernelGGL(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch,
+  SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, 1), dim3(256), shm, (hipStream_t)stream, a, d);
+  SQ_LAUNCH(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch,
                      d_mean_img, d.R, P, 0);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -313,7 +317,8 @@ extern "C" int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, 
 // sig a stop-gradient  =>  dL/d log_w[t, b, k] = -softmax_k(log_w_b)[k] / (B T),  dL/d disc_lp[t, b, k] = -sig_bk / (B K T)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_elbo_bwd(const float* __restrict__ iw, const float* __restrict__ sig, int T, int B, int K,
-                           float* __restrict__ g_log_w_t, float* __restrict__ g_disc_lp_t) {
+                           float* __restrict__ g_log_w_t, float* __restrict__ g_disc_lp_t SQ_TLP) {
+  SQ_TL_SCOPE;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int R = B * K;
   if (i >= T * R) return;
@@ -328,7 +333,7 @@ extern "C" int sqair_elbo_bwd(SqairHandle* h, const float* importance_weights, c
   SqairConfig c;
   if (sqair_get_config(h, &c) != 0) return -1;
   const int n = T * B * c.k_particles;
-  hipLaunchKernelGGL(k_elbo_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, importance_weights,
+  SQ_LAUNCH(k_elbo_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, importance_weights,
                      vimco_signal, T, B, c.k_particles, g_log_w_t, g_disc_lp_t);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -344,7 +349,8 @@ extern "C" int sqair_elbo_bwd(SqairHandle* h, const float* importance_weights, c
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int lda, const float* __restrict__ dY, int ldy,
                                                float* __restrict__ dW, int ldw, float* __restrict__ db, int M, int Kdim,
                                                int Ndim, int accumulate, const int* __restrict__ rowmap,
-                                               const float* __restrict__ alpha_ptr) {
+                                               const float* __restrict__ alpha_ptr SQ_TLP) {
+  SQ_TL_SCOPE;
   __shared__ float red[4 * 256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int k0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
 
 int sq_launch_wgrad(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int Kdim,
                     int Ndim, int accumulate, hipStream_t s, const int* rowmap, const float* alpha_ptr) {
-  hipLaunchKernelGGL(k_wgrad, dim3((Kdim + 15) / 16, (Ndim + 15) / 16), dim3(256), 0, s, A, lda, dY, ldy, dW, ldw, db, M,
+  SQ_LAUNCH(k_wgrad, dim3((Kdim + 15) / 16, (Ndim + 15) / 16), dim3(256), 0, s, A, lda, dY, ldy, dW, ldw, db, M,
                      Kdim, Ndim, accumulate, rowmap, alpha_ptr);
   return 0;
 }
@@ -414,7 +420,8 @@ int sq_launch_wgrad(const float* A, int lda, const float* dY, int ldy, float* dW
 __global__ __launch_bounds__(256) void k_wgrad2(const float* __restrict__ A, int lda, const float* __restrict__ dY, int ldy,
                                                 float* __restrict__ dW, int ldw, int M, int Kdim, int Ndim,
                                                 const int* __restrict__ rowmap, const float* __restrict__ alpha_ptr,
-                                                float* __restrict__ db_a, float* __restrict__ db_b, int m_per_wg) {
+                                                float* __restrict__ db_a, float* __restrict__ db_b, int m_per_wg SQ_TLP) {
+  SQ_TL_SCOPE;
   __shared__ float red[4 * 1024];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, mq = lane >> 4;
   const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
@@ -506,7 +513,8 @@ __global__ __launch_bounds__(256) void k_wgrad2(const float* __restrict__ A, int
 // grid of workgroups (a 64 x 64 tile x ~m_per_wg rows each) they overlap each other's fixed parts: 0.44 ms for the same
 // 62 blocks (32 GFLOP, 73 TFLOP/s); 100 TFLOP/s at 256 sequences per GPU.  The table of blocks travels in the kernel
 // arguments (<= 32 blocks a launch); a workgroup finds its block by a scalar walk.
-__global__ __launch_bounds__(256) void k_wgrad_group(const WgGroup g) {
+__global__ __launch_bounds__(256) void k_wgrad_group(const WgGroup g SQ_TLP) {
+  SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float red3[];
   int i = 0;
   while (i + 1 < g.nd && (int)blockIdx.x >= g.d[i + 1].wg_begin) ++i;
@@ -571,7 +579,7 @@ int WgradBatch::flush(hipStream_t s) {
         fprintf(stderr, "wgrad block %2d: M %6d K %4d N %4d  tiles %3d  workgroups %5d  useful %.2f\n", (int)(i0 + i), g.d[i].M, g.d[i].Kdim,
                 g.d[i].Ndim, g.d[i].n_tiles, g.d[i].n_tiles * g.d[i].zc,
                 (double)g.d[i].Kdim * g.d[i].Ndim / (4096.0 * g.d[i].n_tiles));
-    hipLaunchKernelGGL(k_wgrad_group, dim3(total), dim3(256), WG3_LDS, s, g);
+    SQ_LAUNCH(k_wgrad_group, dim3(total), dim3(256), WG3_LDS, s, g);
   }
   blocks.clear();
   return 0;
@@ -595,7 +603,7 @@ int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float
       (void)hipGetLastError();
       attr_done = true;
     }
-    hipLaunchKernelGGL(k_wgrad3, dim3(kt * nt * zc), dim3(256), WG3_LDS, s, A, lda, dY, ldy, dW, ldw, M, Kdim, Ndim, rowmap, alpha_ptr, db_a,
+    SQ_LAUNCH(k_wgrad3, dim3(kt * nt * zc), dim3(256), WG3_LDS, s, A, lda, dY, ldy, dW, ldw, M, Kdim, Ndim, rowmap, alpha_ptr, db_a,
                        db_b, m_per_wg, kt, kt * nt);
     return 0;
   }
@@ -607,7 +615,7 @@ int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float
   if (zc < 1) zc = 1;
   int m_per_wg = ((M + zc - 1) / zc + 63) / 64 * 64;
   zc = (M + m_per_wg - 1) / m_per_wg;
-  hipLaunchKernelGGL(k_wgrad2, dim3(kt, nt, zc), dim3(256), 0, s, A, lda, dY, ldy, dW, ldw, M, Kdim, Ndim, rowmap, alpha_ptr,
+  SQ_LAUNCH(k_wgrad2, dim3(kt, nt, zc), dim3(256), 0, s, A, lda, dY, ldy, dW, ldw, M, Kdim, Ndim, rowmap, alpha_ptr,
                      db_a, db_b, m_per_wg);
   return 0;
 }
@@ -619,27 +627,28 @@ int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_
   InsertBwdArgs a{glimpse, nullptr, nullptr, img, mean_img, g_ll, d_glimpse, d_rec, d_mean_rows, std_fg, std_bg, rec, rec_ld,
                   d_rec_ld};
   const size_t shm = ((size_t)2 * d.N * d.G * d.G + (size_t)d.N * (d.W + d.H) + d.N + d.N * 4 + 4 * d.N * 4) * sizeof(float);
-  hipLaunchKernelGGL(k_insert_loglik_bwd, dim3(d.R, T), dim3(256), shm, s, a, d);
+  SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, T), dim3(256), shm, s, a, d);
   return 0;
 }
 int sq_launch_reduce_rows(const float* rows, float* out, int R, int P, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, s, rows, out, R, P, accumulate);
+  SQ_LAUNCH(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, s, rows, out, R, P, accumulate);
   return 0;
 }
 int sq_launch_reduce_rows_atomic(const float* rows, float* out, int R, int P, hipStream_t s) {
   const int rpb = 32;
-  hipLaunchKernelGGL(k_reduce_rows_atomic, dim3((P + 255) / 256, (R + rpb - 1) / rpb), dim3(256), 0, s, rows, out, R, P, rpb);
+  SQ_LAUNCH(k_reduce_rows_atomic, dim3((P + 255) / 256, (R + rpb - 1) / rpb), dim3(256), 0, s, rows, out, R, P, rpb);
   return 0;
 }
 int sq_launch_elbo_bwd(const float* iw, const float* sig, int T, int B, int K, float* g_lw, float* g_dl, hipStream_t s) {
   const int n = T * B * K;
-  hipLaunchKernelGGL(k_elbo_bwd, dim3((n + 255) / 256), dim3(256), 0, s, iw, sig, T, B, K, g_lw, g_dl);
+  SQ_LAUNCH(k_elbo_bwd, dim3((n + 255) / 256), dim3(256), 0, s, iw, sig, T, B, K, g_lw, g_dl);
   return 0;
 }
 
 // d(output_scale) = sum(d_glimpse * glimpse) / scale   (glimpse = scale * raw; modules.py:144-147)
 __global__ void k_dot_scale(const float* __restrict__ a, const float* __restrict__ b, int64_t n, const float* __restrict__ scale,
-                            float* __restrict__ out) {
+                            float* __restrict__ out SQ_TLP) {
+  SQ_TL_SCOPE;
   __shared__ float red[16];
   float acc = 0.0f;
   for (int64_t i = threadIdx.x; i < n; i += 1024) acc += a[i] * b[i];
@@ -653,7 +662,8 @@ __global__ void k_dot_scale(const float* __restrict__ a, const float* __restrict
   }
 }
 __global__ void k_dot_scale_atomic(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
-                                   const float* __restrict__ scale, float* __restrict__ out) {
+                                   const float* __restrict__ scale, float* __restrict__ out SQ_TLP) {
+  SQ_TL_SCOPE;
   __shared__ float red[4];
   float acc = 0.0f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += a[i] * b[i];
@@ -663,18 +673,19 @@ __global__ void k_dot_scale_atomic(const float* __restrict__ a, const float* __r
   if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1] + red[2] + red[3]) / scale[0]);
 }
 int sq_launch_dot_scale_atomic(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_dot_scale_atomic, dim3(512), dim3(256), 0, s, a, b, n, scale, out);
+  SQ_LAUNCH(k_dot_scale_atomic, dim3(512), dim3(256), 0, s, a, b, n, scale, out);
   return 0;
 }
 int sq_launch_dot_scale(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_dot_scale, dim3(1), dim3(1024), 0, s, a, b, n, scale, out);
+  SQ_LAUNCH(k_dot_scale, dim3(1), dim3(1024), 0, s, a, b, n, scale, out);
   return 0;
 }
 
 // Elementwise adjoint of the fused activation epilogue: dPre = dOut * act'(.) expressed through the saved OUTPUT
 // (elu: out > 0 ? 1 : out + 1; tanh: 1 - out^2; sigmoid: out (1 - out); softplus(x) + c: 1 - exp(-(out - c))).
 __global__ void k_dact(const float* __restrict__ d_out, const float* __restrict__ out, float* __restrict__ d_pre, int64_t n,
-                       int act) {
+                       int act SQ_TLP) {
+  SQ_TL_SCOPE;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float o = out[i];
@@ -690,7 +701,7 @@ __global__ void k_dact(const float* __restrict__ d_out, const float* __restrict_
 }
 
 int sq_launch_dact(const float* d_out, const float* out, float* d_pre, int64_t n, int act, hipStream_t s) {
-  hipLaunchKernelGGL(k_dact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_out, out, d_pre, n, act);
+  SQ_LAUNCH(k_dact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_out, out, d_pre, n, act);
   return 0;
 }
 
@@ -703,7 +714,8 @@ int sq_launch_dact(const float* d_out, const float* out, float* d_pre, int64_t n
 // ------------------------------------------------------------------------------------------------
 __global__ void k_rmsprop(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ ms,
                           float* __restrict__ mom, int64_t n, float lr, float rho, float momentum, float eps,
-                          float grad_scale) {
+                          float grad_scale SQ_TLP) {
+  SQ_TL_SCOPE;
   const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 + 3 < n && ((reinterpret_cast<uintptr_t>(theta) | reinterpret_cast<uintptr_t>(grad) |
                       reinterpret_cast<uintptr_t>(ms) | reinterpret_cast<uintptr_t>(mom)) & 15) == 0) {
@@ -737,7 +749,7 @@ extern "C" int sqair_rmsprop_step(SqairHandle* h, float* flat_params, const floa
                                   void* stream) {
   if (!h || !flat_params || !flat_grad || !ms || !mom || n < 1) return -1;
   const int64_t nthreads = (n + 3) / 4;
-  hipLaunchKernelGGL(k_rmsprop, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat_params,
+  SQ_LAUNCH(k_rmsprop, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat_params,
                      flat_grad, ms, mom, n, lr, decay, momentum, epsilon, grad_scale);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -763,7 +775,8 @@ __device__ __forceinline__ float delu_from_out(float o) { return o > 0.0f ? 1.0f
 constexpr int SQ_SMALL_MAX = 1024;
 struct SmallParamTab { int n; int src[16]; int len[16]; int dst[16]; };
 
-__global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, const POff pc, const SmallParamTab tab, const Dims d) {
+__global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, const POff pc, const SmallParamTab tab, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   // The ~800 small parameters this kernel reads (where-prior RNN, step-prior MLP, Cholesky factor) are staged in LDS
   // and their gradients accumulated there (`pc` holds COMPACT offsets into these arrays): reads from the flat buffer
   // interleaved with atomics on the gradient buffer cannot be hoisted by the compiler and serialised the kernel on
@@ -1081,7 +1094,7 @@ int sq_launch_logprob_bwd(const LogprobBwdArgs& a, POff po, Dims d, int T, hipSt
   cp.step_prior_tbias = seg(po.step_prior_tbias, N1);
   cp.cholesky = seg(po.cholesky, 10);
   if (o > SQ_SMALL_MAX) return -1;
-  hipLaunchKernelGGL(k_logprob_bwd, dim3(d.R, T), dim3(64), 0, s, a, cp, tab, d);
+  SQ_LAUNCH(k_logprob_bwd, dim3(d.R, T), dim3(64), 0, s, a, cp, tab, d);
   return 0;
 }
 
@@ -1093,7 +1106,8 @@ __global__ __launch_bounds__(256) void k_lstm_cell_bwd(const float* __restrict__
                                                        int c_ld, const float* __restrict__ d_h, int dh_ld,
                                                        const float* __restrict__ d_c, int dc_ld, float* __restrict__ d_gates,
                                                        int dg_ld, float* __restrict__ d_cprev, int dcp_ld, int rows, int nh,
-                                                       float* __restrict__ d_gates2, int dg2_ld) {
+                                                       float* __restrict__ d_gates2, int dg2_ld SQ_TLP) {
+  SQ_TL_SCOPE;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= rows * nh) return;
   const int r = e / nh, q = e - r * nh;
@@ -1116,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_lstm_cell_bwd(const float* __restrict__
 int sq_launch_lstm_cell_bwd(const float* gates, int g_ld, const float* c_prev, int c_ld, const float* d_h, int dh_ld, const float* d_c,
                             int dc_ld, float* d_gates, int dg_ld, float* d_cprev, int dcp_ld, int rows, int nh, hipStream_t s,
                             float* d_gates2, int dg2_ld) {
-  hipLaunchKernelGGL(k_lstm_cell_bwd, dim3((rows * nh + 255) / 256), dim3(256), 0, s, gates, g_ld, c_prev, c_ld, d_h, dh_ld, d_c, dc_ld,
+  SQ_LAUNCH(k_lstm_cell_bwd, dim3((rows * nh + 255) / 256), dim3(256), 0, s, gates, g_ld, c_prev, c_ld, d_h, dh_ld, d_c, dc_ld,
                      d_gates, dg_ld, d_cprev, dcp_ld, rows, nh, d_gates2, dg2_ld);
   return 0;
 }
@@ -1124,7 +1138,8 @@ int sq_launch_lstm_cell_bwd(const float* gates, int g_ld, const float* c_prev, i
 // ------------------------------------------------------------------------------------------------
 // compaction adjoint: route the gradients of the merged slots of frame t+1 back to their source slots
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, const POff po, const Dims d) {
+__global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, const POff po, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   const int r = blockIdx.x, tid = threadIdx.x, N = d.N, nh = d.nh, RW = rec::W;
   __shared__ int inv_s[2 * SQ_MAXN];  // source slot -> destination (or -1)
   if (tid < 2 * N) inv_s[tid] = -1;
@@ -1177,7 +1192,7 @@ __global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, con
   }
 }
 int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_compact_bwd, dim3(d.R), dim3(256), 0, s, a, po, d);
+  SQ_LAUNCH(k_compact_bwd, dim3(d.R), dim3(256), 0, s, a, po, d);
   return 0;
 }
 
@@ -1185,7 +1200,8 @@ int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t 
 // slot-tail adjoint (mirror of k_slot_tail): presence logit -> steps-predictor output / hidden layer -> what,
 // then the what-sample adjoint (gated mixture for propagation).  One workgroup (128 threads) per row.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, const Dims d) {
+__global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   __shared__ float ds_s[128];
   extern __shared__ float wt_s[];  // the `what` rows of steps.l0.w, [nw][nsp + 1] (padded: conflict-free row reads)
   const int r = blockIdx.x, tid = threadIdx.x, nw = d.nw, nsp = d.nh / 2, RW = rec::W;
@@ -1275,7 +1291,7 @@ __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, cons
   }
 }
 int sq_launch_slot_tail_bwd(const TailBwdArgs& a, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_slot_tail_bwd, dim3(d.R), dim3(128), (size_t)d.nw * (d.nh / 2 + 1) * sizeof(float), s, a, d);
+  SQ_LAUNCH(k_slot_tail_bwd, dim3(d.R), dim3(128), (size_t)d.nw * (d.nh / 2 + 1) * sizeof(float), s, a, d);
   return 0;
 }
 
@@ -1284,7 +1300,8 @@ int sq_launch_slot_tail_bwd(const TailBwdArgs& a, Dims d, hipStream_t s) {
 // record) -> adjoint of the where sample -> d(transform output) [R][8], d(previous where), d(mask).
 // modes as CropMode.  One workgroup per sequence.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a, const POff po, const Dims d) {
+__global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a, const POff po, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* img_s = smem;
   __shared__ float red_s[4][4];
@@ -1453,7 +1470,8 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
 // (frame, row, slot) uses: rows of the tapes [T][R][N]; d_tp [2 phases][rows][ld], gradient records hold the total d where
 __global__ __launch_bounds__(256) void k_where_param_grads(const float* __restrict__ d_tp, int tp_ld, const float* __restrict__ d_rec_p,
                                                            const float* __restrict__ rec_p, const float* __restrict__ noise, int rows,
-                                                           int RN, int N, int nzw, float* __restrict__ flat_grad, POff po) {
+                                                           int RN, int N, int nzw, float* __restrict__ flat_grad, POff po SQ_TLP) {
+  SQ_TL_SCOPE;
   __shared__ float red[4][12];
   float acc[12];
 #pragma unroll
@@ -1492,7 +1510,7 @@ __global__ __launch_bounds__(256) void k_where_param_grads(const float* __restri
 int sq_launch_where_param_grads(const float* d_tp, int tp_ld, const float* d_rec_p, const float* rec_p, const float* noise, int T,
                                 Dims d, float* flat_grad, POff po, hipStream_t s) {
   const int rows = T * d.R * d.N;
-  hipLaunchKernelGGL(k_where_param_grads, dim3(32), dim3(256), 0, s, d_tp, tp_ld, d_rec_p, rec_p, noise, rows, d.R * d.N, d.N, d.nzw,
+  SQ_LAUNCH(k_where_param_grads, dim3(32), dim3(256), 0, s, d_tp, tp_ld, d_rec_p, rec_p, noise, rows, d.R * d.N, d.N, d.nzw,
                      flat_grad, po);
   return 0;
 }
@@ -1504,7 +1522,7 @@ int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nsl
     (void)hipGetLastError();
     big = true;
   }
-  hipLaunchKernelGGL(k_crop_chain_bwd, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
+  SQ_LAUNCH(k_crop_chain_bwd, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
   return 0;
 }
 
@@ -1517,7 +1535,8 @@ int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nsl
 __global__ void k_gru_bwd_a(const float* __restrict__ d_hn, int dhn_ld, const float* __restrict__ z, int z_ld,
                             const float* __restrict__ hc, int hc_ld, const float* __restrict__ hprev, int h_ld,
                             float* __restrict__ dpre1, int dp_ld, float* __restrict__ d_h, int dh_ld, int rows, int nh,
-                            int accumulate_dh, float* __restrict__ dup_z, int dup_ld, int dup_h_off) {
+                            int accumulate_dh, float* __restrict__ dup_z, int dup_ld, int dup_h_off SQ_TLP) {
+  SQ_TL_SCOPE;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * nh) return;
   const int m = i / nh, n = i - m * nh;
@@ -1534,7 +1553,8 @@ __global__ void k_gru_bwd_a(const float* __restrict__ d_hn, int dhn_ld, const fl
 }
 __global__ void k_gru_bwd_b(const float* __restrict__ d_rh, int drh_ld, const float* __restrict__ rg, int r_ld,
                             const float* __restrict__ hprev, int h_ld, float* __restrict__ dpre1, int dp_ld,
-                            float* __restrict__ d_h, int dh_ld, int rows, int nh, float* __restrict__ dup_r, int dup_ld) {
+                            float* __restrict__ d_h, int dh_ld, int rows, int nh, float* __restrict__ dup_r, int dup_ld SQ_TLP) {
+  SQ_TL_SCOPE;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * nh) return;
   const int m = i / nh, n = i - m * nh;
@@ -1547,13 +1567,13 @@ __global__ void k_gru_bwd_b(const float* __restrict__ d_rh, int drh_ld, const fl
 int sq_launch_gru_bwd_a(const float* d_hn, int dhn_ld, const float* z, int z_ld, const float* hc, int hc_ld,
                         const float* hprev, int h_ld, float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh,
                         int accumulate_dh, hipStream_t s, float* dup_z, int dup_ld, int dup_h_off) {
-  hipLaunchKernelGGL(k_gru_bwd_a, dim3((rows * nh + 255) / 256), dim3(256), 0, s, d_hn, dhn_ld, z, z_ld, hc, hc_ld, hprev,
+  SQ_LAUNCH(k_gru_bwd_a, dim3((rows * nh + 255) / 256), dim3(256), 0, s, d_hn, dhn_ld, z, z_ld, hc, hc_ld, hprev,
                      h_ld, dpre1, dp_ld, d_h, dh_ld, rows, nh, accumulate_dh, dup_z, dup_ld, dup_h_off);
   return 0;
 }
 int sq_launch_gru_bwd_b(const float* d_rh, int drh_ld, const float* rg, int r_ld, const float* hprev, int h_ld,
                         float* dpre1, int dp_ld, float* d_h, int dh_ld, int rows, int nh, hipStream_t s, float* dup_r, int dup_ld) {
-  hipLaunchKernelGGL(k_gru_bwd_b, dim3((rows * nh + 255) / 256), dim3(256), 0, s, d_rh, drh_ld, rg, r_ld, hprev, h_ld,
+  SQ_LAUNCH(k_gru_bwd_b, dim3((rows * nh + 255) / 256), dim3(256), 0, s, d_rh, drh_ld, rg, r_ld, hprev, h_ld,
                      dpre1, dp_ld, d_h, dh_ld, rows, nh, dup_r, dup_ld);
   return 0;
 }
@@ -1563,7 +1583,8 @@ int sq_launch_gru_bwd_b(const float* d_rh, int drh_ld, const float* rg, int r_ld
 // ------------------------------------------------------------------------------------------------
 // out[m][n] = (acc ? out : 0) + in[m][n] * act'(saved[m][n])   with per-column-range activations (act_a below split)
 __global__ void k_dact2(const float* din, int in_ld, const float* __restrict__ saved, int s_ld,
-                        float* dout, int out_ld, int rows, int cols, int act_a, int act_b, int split, int acc) {
+                        float* dout, int out_ld, int rows, int cols, int act_a, int act_b, int split, int acc SQ_TLP) {
+  SQ_TL_SCOPE;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * cols) return;
   const int m = i / cols, n = i - m * cols;
@@ -1581,12 +1602,13 @@ __global__ void k_dact2(const float* din, int in_ld, const float* __restrict__ s
 }
 int sq_launch_dact2(const float* din, int in_ld, const float* saved, int s_ld, float* dout, int out_ld, int rows, int cols,
                     int act_a, int act_b, int split, int acc, hipStream_t s) {
-  hipLaunchKernelGGL(k_dact2, dim3((rows * cols + 255) / 256), dim3(256), 0, s, din, in_ld, saved, s_ld, dout, out_ld, rows,
+  SQ_LAUNCH(k_dact2, dim3((rows * cols + 255) / 256), dim3(256), 0, s, din, in_ld, saved, s_ld, dout, out_ld, rows,
                      cols, act_a, act_b, split, acc);
   return 0;
 }
 // column sums of dY[rows][cols] (+)= into out[cols] (bias gradients)
-__global__ void k_colsum(const float* __restrict__ dy, int ld, int rows, int cols, float* __restrict__ out, int rows_per_block) {
+__global__ void k_colsum(const float* __restrict__ dy, int ld, int rows, int cols, float* __restrict__ out, int rows_per_block SQ_TLP) {
+  SQ_TL_SCOPE;
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;  // 4 row partitions
   __shared__ float red[4][64];
@@ -1601,24 +1623,26 @@ __global__ void k_colsum(const float* __restrict__ dy, int ld, int rows, int col
 int sq_launch_colsum(const float* dy, int ld, int rows, int cols, float* out, int acc, hipStream_t s) {
   (void)acc;  // always accumulates (float atomics)
   const int rpb = 64;
-  hipLaunchKernelGGL(k_colsum, dim3((cols + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, s, dy, ld, rows, cols, out, rpb);
+  SQ_LAUNCH(k_colsum, dim3((cols + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, s, dy, ld, rows, cols, out, rpb);
   return 0;
 }
 // latent-summary adjoint: d f[(r,k)][n] = d c[r][n] * presence_k ; particle sum: d pre_disc[b][n] = sum_kp d pre_d[b K + kp][n]
 __global__ void k_latent_sum_bwd(const float* __restrict__ d_c, const float* __restrict__ rec_p, const float* __restrict__ f_out,
-                                 float* __restrict__ d_f, Dims d) {
+                                 float* __restrict__ d_f, Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   const int rk = blockIdx.x;  // r * N + k;  f_out = elu(.) output of the summed feature: its derivative is applied here
   const float pres = rec_p[(size_t)rk * rec::W + rec::PRES];
   for (int n = threadIdx.x; n < d.nh; n += blockDim.x)
     d_f[(size_t)rk * d.nh + n] = d_c[(size_t)(rk / d.N) * d.nh + n] * pres * delu_from_out(f_out[(size_t)rk * d.nh + n]);
 }
 int sq_launch_latent_sum_bwd(const float* d_c, const float* rec_p, const float* f_out, float* d_f, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_latent_sum_bwd, dim3(d.R * d.N), dim3(256), 0, s, d_c, rec_p, f_out, d_f, d);
+  SQ_LAUNCH(k_latent_sum_bwd, dim3(d.R * d.N), dim3(256), 0, s, d_c, rec_p, f_out, d_f, d);
   return 0;
 }
 // d pre_d[r][n] = sum over the N discovery slots of the RNN pre-activation gradients [R][N][nh]; then over particles
 __global__ void k_sum_slots(const float* __restrict__ d_rnn, float* __restrict__ d_pre_d, float* __restrict__ d_pre_disc, int B, int K,
-                            int N, int nh) {
+                            int N, int nh SQ_TLP) {
+  SQ_TL_SCOPE;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nh) return;
   const int b = i / nh, n = i - b * nh;
@@ -1633,10 +1657,11 @@ __global__ void k_sum_slots(const float* __restrict__ d_rnn, float* __restrict__
   d_pre_disc[i] = tot;
 }
 int sq_launch_sum_slots(const float* d_rnn, float* d_pre_d, float* d_pre_disc, int B, int K, int N, int nh, hipStream_t s) {
-  hipLaunchKernelGGL(k_sum_slots, dim3((B * nh + 255) / 256), dim3(256), 0, s, d_rnn, d_pre_d, d_pre_disc, B, K, N, nh);
+  SQ_LAUNCH(k_sum_slots, dim3((B * nh + 255) / 256), dim3(256), 0, s, d_rnn, d_pre_d, d_pre_disc, B, K, N, nh);
   return 0;
 }
-__global__ void k_particle_sum(const float* __restrict__ in, float* __restrict__ out, int B, int K, int nh) {
+__global__ void k_particle_sum(const float* __restrict__ in, float* __restrict__ out, int B, int K, int nh SQ_TLP) {
+  SQ_TL_SCOPE;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nh) return;
   const int b = i / nh, n = i - b * nh;
@@ -1645,11 +1670,12 @@ __global__ void k_particle_sum(const float* __restrict__ in, float* __restrict__
   out[i] = acc;
 }
 int sq_launch_particle_sum(const float* in, float* out, int B, int K, int nh, hipStream_t s) {
-  hipLaunchKernelGGL(k_particle_sum, dim3((B * nh + 255) / 256), dim3(256), 0, s, in, out, B, K, nh);
+  SQ_LAUNCH(k_particle_sum, dim3((B * nh + 255) / 256), dim3(256), 0, s, in, out, B, K, nh);
   return 0;
 }
 // y[m][n] (+)= x[m][n] over a strided sub-block
-__global__ void k_axpy2d(const float* __restrict__ x, int x_ld, float* __restrict__ y, int y_ld, int rows, int cols, int acc) {
+__global__ void k_axpy2d(const float* __restrict__ x, int x_ld, float* __restrict__ y, int y_ld, int rows, int cols, int acc SQ_TLP) {
+  SQ_TL_SCOPE;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * cols) return;
   const int m = i / cols, n = i - m * cols;
@@ -1657,6 +1683,6 @@ __global__ void k_axpy2d(const float* __restrict__ x, int x_ld, float* __restric
   *p = (acc ? *p : 0.0f) + x[(size_t)m * x_ld + n];
 }
 int sq_launch_axpy2d(const float* x, int x_ld, float* y, int y_ld, int rows, int cols, int acc, hipStream_t s) {
-  hipLaunchKernelGGL(k_axpy2d, dim3((rows * cols + 255) / 256), dim3(256), 0, s, x, x_ld, y, y_ld, rows, cols, acc);
+  SQ_LAUNCH(k_axpy2d, dim3((rows * cols + 255) / 256), dim3(256), 0, s, x, x_ld, y, y_ld, rows, cols, acc);
   return 0;
 }

@@ -93,6 +93,64 @@ int sq_launch_pack(const float* flat, float* packed_w, const int* idx, int64_t n
 int sq_launch_pack_bias(const float* flat, float* packed_b, const int* idxa, const int* idxb, int64_t n,
                         hipStream_t s);
 
+// ---------------------------------------------------------------------------------------------
+// Per-dispatch timeline (libsqair_hip_timeline.so = this source with -DSQAIR_TIMELINE; bench.py's roofline, tools/timeline.py).
+// In that build EVERY kernel carries one more argument (SQ_TLP) and every wave stamps {start, end} on the 100 MHz device wall
+// clock (s_memrealtime, chip-wide) into ITS OWN 16-byte slot of a caller-provided buffer -- plain stores, no atomics, nothing
+// shared between waves -- so that a replayed graph yields, per node, first-wave start and last-wave end: busy time per kernel,
+// gap (dependent launch boundary) between kernels, and their sum = the step.  In the production build the three macros expand to
+// nothing and the binary is unchanged.  Kernels are launched through SQ_LAUNCH everywhere.
+// ---------------------------------------------------------------------------------------------
+#ifdef SQAIR_TIMELINE
+struct SqTl { unsigned long long* slot; unsigned gx, gy, nw, pad; };  // slot range + launch geometry
+SqTl sq_tl_next(const char* kernel, dim3 grid, dim3 block);  // sqair_api.hip: next slot range of the active recording (or null)
+#define SQ_TLP , const SqTl sq_tl
+#define SQ_TL_SCOPE SqTlScope sq_tl_scope(sq_tl)
+#define SQ_LAUNCH(kern, grid, block, lds, s, ...) \
+  hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__, sq_tl_next(#kern, grid, block))
+#ifdef __HIPCC__
+struct SqTlScope {
+  // What keeps the stamped step within ~3 % of the product library's (each item measured on the cfg-2 forward pass, 3.51 ms):
+  //  * the end of the wave must not touch memory before its stamp store: grid / block dimensions read through the HIP built-ins
+  //    are scalar loads from the dispatch packet which the compiler places at their use -- a memory round trip between the
+  //    wave's last instruction and the store when used at the end (3.94 ms), a round trip ahead of the kernel's first operand
+  //    loads when used at the start (3.86 ms).  The launch geometry therefore travels in the kernel argument (SqTl, filled by
+  //    sq_tl_next on the host) and arrives with the kernel's other arguments (3.70 ms);
+  //  * the flat thread id of a multi-dimensional workgroup (threadIdx.x + bdx * ...) made the compiler wait for the kernel's
+  //    output stores (s_waitcnt vmcnt(0)) ahead of the stamp code; all kernels use 1-D workgroups, threadIdx.x it is (3.60 ms);
+  //  * not the clock reads: the one at the start overlaps the argument loads (+0.03 ms), the one at the end is free next to the
+  //    store; nor the number of stores (wave 0 only: -0.01 ms), their cache policy, or lines shared between workgroups.
+  const SqTl tl;
+  const unsigned long long t0;
+  static __device__ __forceinline__ unsigned long long clock() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+    return t;
+  }
+  __device__ __forceinline__ explicit SqTlScope(const SqTl tl_) : tl(tl_), t0(__builtin_amdgcn_s_memrealtime()) {}
+  __device__ __forceinline__ ~SqTlScope() {
+    const uintptr_t b = (uintptr_t)tl.slot;
+    if (b == 0) return;
+    const unsigned tid = threadIdx.x;   // every kernel of the library uses 1-D workgroups (checked by sq_tl_next)
+    if ((tid & 63u) != 0u) return;
+    const unsigned wg = blockIdx.x + tl.gx * (blockIdx.y + tl.gy * blockIdx.z);
+    // tl.nw = slots per workgroup (its waves, padded to a whole 128-byte line)
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) u64x2 gvec;
+    gvec* p = (gvec*)b + ((size_t)wg * tl.nw + (tid >> 6));
+    u64x2 v;
+    v.x = t0;
+    v.y = clock();
+    *p = v;
+  }
+};
+#endif
+#else
+#define SQ_TLP
+#define SQ_TL_SCOPE
+#define SQ_LAUNCH(kern, grid, block, lds, s, ...) hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__)
+#endif
+
 // Measurement knobs (tile shapes, fusion switches, dump files) are read from the environment ONLY in a library built with
 // -DSQAIR_KNOBS (tools/: `python sqair_amd/csrc/build.py --knobs` -> tools/bin/libsqair_hip_knobs.so).  The production library
 // compiles every knob to its default, so no environment variable can change -- or remove -- work inside a timed region.

@@ -12,7 +12,8 @@ __global__ void k_init_state(float* __restrict__ rec_m, float* __restrict__ temp
                              float* __restrict__ prop_rnn_init, float* __restrict__ disc_rnn_init,
                              float* __restrict__ rn_init_state, float* __restrict__ w3_prop,
                              float* __restrict__ w3_disc, int w3p_off, int w3d_off,
-                             const float* __restrict__ flat, POff po, Dims d) {
+                             const float* __restrict__ flat, POff po, Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   const int rs = blockIdx.x;  // row*N + slot
   const int tid = threadIdx.x;
   for (int i = tid; i < rec::W; i += blockDim.x) rec_m[(size_t)rs * rec::W + i] = (i == rec::ID) ? -1.0f : 0.0f;
@@ -43,7 +44,8 @@ __global__ void k_init_state(float* __restrict__ rec_m, float* __restrict__ temp
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lstm_cell(const float* __restrict__ gates, int g_ld, const float* __restrict__ c_prev,
                                                    int c_ld, float* __restrict__ h_out, int h_ld, float* __restrict__ c_out,
-                                                   int co_ld, int rows, int nh) {
+                                                   int co_ld, int rows, int nh SQ_TLP) {
+  SQ_TL_SCOPE;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= rows * nh) return;
   const int r = e / nh, q = e - r * nh;
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void k_lstm_cell(const float* __restrict__ gat
 // c_ld = 0 broadcasts one initial cell row; hidden and cell may live in different buffers (slot RNN) or side by side
 int sq_launch_lstm_cell2(const float* gates, int g_ld, const float* c_prev, int c_ld, float* h_out, int h_ld, float* c_out, int co_ld,
                          int rows, int nh, hipStream_t s) {
-  hipLaunchKernelGGL(k_lstm_cell, dim3((rows * nh + 255) / 256), dim3(256), 0, s, gates, g_ld, c_prev, c_ld, h_out, h_ld, c_out, co_ld,
+  SQ_LAUNCH(k_lstm_cell, dim3((rows * nh + 255) / 256), dim3(256), 0, s, gates, g_ld, c_prev, c_ld, h_out, h_ld, c_out, co_ld,
                      rows, nh);
   return 0;
 }
@@ -68,7 +70,7 @@ int sq_launch_lstm_cell(const float* gates, int g_ld, const float* c_prev, int c
 int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float* last_id, float* disc_init_rec,
                          float* prop_rnn_init, float* disc_rnn_init, float* rn_init_state, float* w3_prop, float* w3_disc,
                          int w3p_off, int w3d_off, const float* flat, POff po, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_init_state, dim3(d.R * d.N), dim3(256), 0, s, rec_m, temporal_m, prior_m, last_id, disc_init_rec,
+  SQ_LAUNCH(k_init_state, dim3(d.R * d.N), dim3(256), 0, s, rec_m, temporal_m, prior_m, last_id, disc_init_rec,
                      prop_rnn_init, disc_rnn_init, rn_init_state, w3_prop, w3_disc, w3p_off, w3d_off, flat, po, d);
   return 0;
 }
@@ -82,7 +84,8 @@ int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float*
 
 // one workgroup per particle row (a per-sequence kernel staging the frame in LDS for its K particles had only B = 32
 // workgroups at the headline config and measured 10.3 us; this one 5-6 us with the frame served by L1 / L2)
-__global__ __launch_bounds__(256) void k_crop_row(const CropArgs a, const POff po, const Dims d) {
+__global__ __launch_bounds__(256) void k_crop_row(const CropArgs a, const POff po, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   x_crop_row<LdPlain>(a, po, d, blockIdx.x, a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot, smem, true);
 }
@@ -95,7 +98,7 @@ int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s
     (void)hipGetLastError();
     big_lds = true;
   }
-  hipLaunchKernelGGL(k_crop_row, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
+  SQ_LAUNCH(k_crop_row, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
   return 0;
 }
 
@@ -259,7 +262,8 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
   }
 }
 
-__global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims d) {
+__global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   __shared__ __attribute__((aligned(16))) float zt[16 * ZLD];
   __shared__ float rs[4][16];
   tail_body<false>(a, d, blockIdx.x * 16, true, zt, rs);
@@ -278,7 +282,8 @@ template <int NH>  // hidden-state chunks per wave = nh / 64
 __global__ __launch_bounds__(256) void k_rnn_tail(const TailArgs ta, const Dims d, const float* __restrict__ hid, const int hid_ld,
                                                   const float* __restrict__ wp0, const float* __restrict__ bias,
                                                   const float* __restrict__ add, const int add_ld, float* __restrict__ out,
-                                                  const int out_ld, const int n_out, unsigned long long* __restrict__ prof_ts) {
+                                                  const int out_ld, const int n_out, unsigned long long* __restrict__ prof_ts SQ_TLP) {
+  SQ_TL_SCOPE;
   __shared__ __attribute__((aligned(16))) float zt[16 * ZLD];
   __shared__ float rs[4][16];
   __shared__ float red[4 * 256];
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256) void k_rnn_tail(const TailArgs ta, const Dims 
 }
 
 int sq_launch_slot_tail(const TailArgs& a, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_slot_tail, dim3((d.R + 15) / 16), dim3(256), 0, s, a, d);
+  SQ_LAUNCH(k_slot_tail, dim3((d.R + 15) / 16), dim3(256), 0, s, a, d);
   return 0;
 }
 // tail of slot `ta.slot` + the VanillaRNN layer of the next slot: out = tanh([z-record | hid] W + bias + add); wp / bias point at
@@ -342,8 +347,8 @@ int sq_launch_slot_tail(const TailArgs& a, Dims d, hipStream_t s) {
 int sq_launch_rnn_tail(const TailArgs& ta, Dims d, const float* hid, int hid_ld, const float* wp, const float* bias, const float* add,
                        int add_ld, float* out, int out_ld, int n_out, hipStream_t s, unsigned long long* prof_ts) {
   const dim3 g((n_out + 15) / 16, (d.R + 15) / 16);
-  if (d.nh == 256) hipLaunchKernelGGL(k_rnn_tail<4>, g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
-  else if (d.nh == 128) hipLaunchKernelGGL(k_rnn_tail<2>, g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
+  if (d.nh == 256) SQ_LAUNCH(k_rnn_tail<4>, g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
+  else if (d.nh == 128) SQ_LAUNCH(k_rnn_tail<2>, g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
   else return -1;
   return 0;
 }
@@ -351,7 +356,8 @@ int sq_launch_rnn_tail(const TailArgs& ta, Dims d, const float* hid, int hid_ld,
 // ------------------------------------------------------------------------------------------------
 // DeepSets summary of the propagated latents (reference: sqair/sqair_modules.py:368-385)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_latent_sum(const float* __restrict__ f, const float* __restrict__ rec_p, float* __restrict__ c, Dims d) {
+__global__ void k_latent_sum(const float* __restrict__ f, const float* __restrict__ rec_p, float* __restrict__ c, Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   const int r = blockIdx.x;
   for (int n = threadIdx.x; n < d.nh; n += blockDim.x) {
     float acc = 0.0f;
@@ -361,7 +367,7 @@ __global__ void k_latent_sum(const float* __restrict__ f, const float* __restric
   }
 }
 int sq_launch_latent_sum(const float* f, const float* rec_p, float* c, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_latent_sum, dim3(d.R), dim3(256), 0, s, f, rec_p, c, d);
+  SQ_LAUNCH(k_latent_sum, dim3(d.R), dim3(256), 0, s, f, rec_p, c, d);
   return 0;
 }
 
@@ -373,7 +379,8 @@ int sq_launch_latent_sum(const float* f, const float* rec_p, float* c, Dims d, h
 // RecurrentNormalImpl modules.py:548-611, SQAIRTimestep sums :483-485, :505-507.
 // One wavefront per row b'.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff po, const Dims d) {
+__global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff po, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   // Everything a row needs (3N slot records, N prior-stat rows, the conditioning state and ~1k small-layer
   // parameters) is pulled into LDS by all 256 threads in one burst of independent loads; wavefront 0 then
   // evaluates the densities from LDS.  (A direct global-memory walk was ~20 dependent round trips = 27 us.)
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
 int sq_launch_logprob(const LogprobArgs& a, POff po, Dims d, hipStream_t s) {
   const size_t shm = ((size_t)3 * d.N * rec::W + (size_t)d.N * a.ps_ld + 128 + 128 + 516 + 20 + 40 + 4 + 20 +
                       11 * (d.N + 1) + 2 * (d.N + 1) + 16) * sizeof(float);
-  hipLaunchKernelGGL(k_logprob, dim3(d.R, a.n_frames), dim3(256), shm, s, a, po, d);
+  SQ_LAUNCH(k_logprob, dim3(d.R, a.n_frames), dim3(256), shm, s, a, po, d);
   return 0;
 }
 
@@ -632,7 +639,8 @@ __device__ __forceinline__ float gen_prior_logit(const GenArgs& a, const float* 
   return pl;
 }
 // propagation: samples of the prior for every slot -> generation record; replaces the hidden outputs when generating
-__global__ __launch_bounds__(64) void k_generate_prop(const GenArgs a, const Dims d) {
+__global__ __launch_bounds__(64) void k_generate_prop(const GenArgs a, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   const int r = blockIdx.x, lane = threadIdx.x, N = d.N, nw = d.nw;
   for (int k = 0; k < N; ++k) {
     const size_t rk = (size_t)r * N + k;
@@ -666,7 +674,8 @@ __global__ __launch_bounds__(64) void k_generate_prop(const GenArgs a, const Dim
   }
 }
 // discovery (generated frames only): what ~ N(0, I), where ~ the where prior, presence = 0; keeps the original presence
-__global__ __launch_bounds__(64) void k_generate_disc(const GenArgs a, const POff po, const Dims d) {
+__global__ __launch_bounds__(64) void k_generate_disc(const GenArgs a, const POff po, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   const int r = blockIdx.x, lane = threadIdx.x, N = d.N, nw = d.nw;
   const float* flat = a.flat;
   float hs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -720,11 +729,11 @@ __global__ __launch_bounds__(64) void k_generate_disc(const GenArgs a, const POf
 }
 int sq_launch_generate_prop(const GenArgs& a, POff po, Dims d, hipStream_t s) {
   (void)po;
-  hipLaunchKernelGGL(k_generate_prop, dim3(d.R), dim3(64), 0, s, a, d);
+  SQ_LAUNCH(k_generate_prop, dim3(d.R), dim3(64), 0, s, a, d);
   return 0;
 }
 int sq_launch_generate_disc(const GenArgs& a, POff po, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_generate_disc, dim3(d.R), dim3(64), 0, s, a, po, d);
+  SQ_LAUNCH(k_generate_disc, dim3(d.R), dim3(64), 0, s, a, po, d);
   return 0;
 }
 
@@ -734,7 +743,8 @@ int sq_launch_generate_disc(const GenArgs& a, POff po, Dims d, hipStream_t s) {
 // One workgroup per row: 2N presence bits -> stable present-first permutation -> copy the N
 // survivors (record + prior state + temporal state) into the next frame's state.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff po, const Dims d) {
+__global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff po, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   __shared__ int src_s[SQ_MAXN];
   __shared__ float id_s[SQ_MAXN];
   const int r = blockIdx.x, tid = threadIdx.x;
@@ -837,7 +847,7 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff
   }
 }
 int sq_launch_compact(const CompactArgs& a, POff po, Dims d, hipStream_t s) {
-  hipLaunchKernelGGL(k_compact, dim3(d.R), dim3(256), 0, s, a, po, d);
+  SQ_LAUNCH(k_compact, dim3(d.R), dim3(256), 0, s, a, po, d);
   return 0;
 }
 
@@ -849,7 +859,8 @@ int sq_launch_compact(const CompactArgs& a, POff po, Dims d, hipStream_t s) {
 // glimpses sit in LDS, every thread owns canvas pixels and gathers (inverse map) from them, so the
 // canvas is written at most once and the frame is read once.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const Dims d) {
+__global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.N, G = d.G, G2 = d.G * d.G, H = d.H, W = d.W, P = d.H * d.W;
   float* gl_s = smem;                 // N * G2
@@ -950,7 +961,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const
 }
 int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s) {
   const size_t shm = ((size_t)d.N * d.G * d.G + (size_t)d.N * (d.W + d.H) + d.N) * sizeof(float);
-  hipLaunchKernelGGL(k_insert_loglik, dim3(d.R, a.n_frames > 0 ? a.n_frames : 1), dim3(256), shm, s, a, d);
+  SQ_LAUNCH(k_insert_loglik, dim3(d.R, a.n_frames > 0 ? a.n_frames : 1), dim3(256), shm, s, a, d);
   return 0;
 }
 
@@ -970,7 +981,8 @@ __device__ __forceinline__ float wave_max(float v) {
 __global__ __launch_bounds__(1024) void k_elbo(const float* __restrict__ log_w_t, const float* __restrict__ disc_lp_t,
                                               int T, int B, int K, float* log_weights, float* elbo_per_ex, float* iw_out,
                                               float* signal_out, float* scalars, ElboMeans means, int n_means,
-                                              float* means_out) {
+                                              float* means_out SQ_TLP) {
+  SQ_TL_SCOPE;
   __shared__ float acc_s[16][4 + 8];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int R = B * K;
@@ -1059,7 +1071,7 @@ int sq_launch_elbo(const float* log_w_t, const float* disc_lp_t, int T, int B, i
                    int n_means, float* means_out, hipStream_t s) {
   ElboMeans m;
   for (int i = 0; i < 8; ++i) m.p[i] = (means_in != nullptr && i < n_means) ? means_in[i] : nullptr;
-  hipLaunchKernelGGL(k_elbo, dim3(1), dim3(1024), 0, s, log_w_t, disc_lp_t, T, B, K, log_weights, elbo_per_ex, iw,
+  SQ_LAUNCH(k_elbo, dim3(1), dim3(1024), 0, s, log_w_t, disc_lp_t, T, B, K, log_weights, elbo_per_ex, iw,
                      signal, scalars, m, n_means, means_out);
   return 0;
 }

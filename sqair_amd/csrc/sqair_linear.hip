@@ -27,7 +27,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void k_pack(const float* __restrict__ flat, float* __restrict__ packed, const int* __restrict__ idx,
-                       int64_t n) {
+                       int64_t n SQ_TLP) {
+  SQ_TL_SCOPE;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -37,7 +38,8 @@ __global__ void k_pack(const float* __restrict__ flat, float* __restrict__ packe
 }
 
 __global__ void k_pack_bias(const float* __restrict__ flat, float* __restrict__ packed,
-                            const int* __restrict__ idxa, const int* __restrict__ idxb, int64_t n) {
+                            const int* __restrict__ idxa, const int* __restrict__ idxb, int64_t n SQ_TLP) {
+  SQ_TL_SCOPE;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const int a = idxa[i], b = idxb[i];
@@ -49,13 +51,13 @@ int sq_launch_pack(const float* flat, float* packed_w, const int* idx, int64_t n
   if (n <= 0) return 0;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, s, flat, packed_w, idx, n);
+  SQ_LAUNCH(k_pack, dim3(blocks), dim3(256), 0, s, flat, packed_w, idx, n);
   return 0;
 }
 int sq_launch_pack_bias(const float* flat, float* packed_b, const int* idxa, const int* idxb, int64_t n,
                         hipStream_t s) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_pack_bias, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flat, packed_b, idxa, idxb, n);
+  SQ_LAUNCH(k_pack_bias, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flat, packed_b, idxa, idxb, n);
   return 0;
 }
 
@@ -82,7 +84,8 @@ int sq_launch_pack_bias(const float* flat, float* packed_b, const int* idxa, con
 // ---------------------------------------------------------------------------------------------------
 template <int NCH>
 __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int kc_total, const int n_tiles,
-                                                     unsigned long long* __restrict__ prof_ts) {
+                                                     unsigned long long* __restrict__ prof_ts SQ_TLP) {
+  SQ_TL_SCOPE;
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int 
 // ---------------------------------------------------------------------------------------------------
 template <int NCH, int MT, int NT, bool COAL = false>
 __global__ __launch_bounds__(256) void k_linear_mt(const LinArgs a, const int kc_total, const int n_tiles,
-                                                   unsigned long long* __restrict__ prof_ts) {
+                                                   unsigned long long* __restrict__ prof_ts SQ_TLP) {
+  SQ_TL_SCOPE;
   static_assert(MT == 1 || MT == 2, "row tiles per wave");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
   // COAL: the A fragment is LOADED with 4 consecutive lanes on the 64 contiguous bytes of one row's chunk (16 row segments
@@ -388,7 +392,8 @@ __global__ __launch_bounds__(256) void k_linear_mt(const LinArgs a, const int kc
 // ---------------------------------------------------------------------------------------------------
 template <int TN>
 __global__ __launch_bounds__(256) void k_linear_lds(const LinArgs a, const int kc_total, const int n_tiles,
-                                                    unsigned long long* __restrict__ prof_ts) {
+                                                    unsigned long long* __restrict__ prof_ts SQ_TLP) {
+  SQ_TL_SCOPE;
   constexpr int LDA = 36;  // 32 floats of a K step + 4 of padding: the 16 rows of a fragment read land on distinct 16-byte slots
   __shared__ __attribute__((aligned(16))) float lds[2 * 128 * LDA];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
@@ -552,8 +557,8 @@ static MtShape pick_mt_shape(int M, int n_tiles, int kc) {
 template <int NCH, int MT, int NT>
 static void launch_mt(const LinArgs& a, const PackedLayer& L, int mt, bool coal, hipStream_t s, unsigned long long* prof_ts) {
   const dim3 g((L.nt + NT - 1) / NT, (mt + 4 * MT - 1) / (4 * MT));
-  if (coal) hipLaunchKernelGGL((k_linear_mt<NCH, MT, NT, true>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
-  else hipLaunchKernelGGL((k_linear_mt<NCH, MT, NT, false>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+  if (coal) SQ_LAUNCH((k_linear_mt<NCH, MT, NT, true>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+  else SQ_LAUNCH((k_linear_mt<NCH, MT, NT, false>), g, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
 }
 
 template <int NCH, int NSEG>
@@ -561,7 +566,7 @@ static void launch_seg(const LinArgs& a, const PackedLayer& L, hipStream_t s, un
   const dim3 g(L.nt, (a.M + 15) / 16);
   // the GRU gate epilogues are compiled out of the instantiation the plain layers use (the slot loop rotates through ~10 code
   // objects; the smaller they are, the more of them stay in the instruction cache)
-#define SQ_LAUNCH_KL(G, P) hipLaunchKernelGGL((k_linear<NCH, NSEG, G, P>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a.wzero, a, prof_ts)
+#define SQ_LAUNCH_KL(G, P) SQ_LAUNCH((k_linear<NCH, NSEG, G, P>), g, dim3(256), 0, s, a.seg[0].p, a.wp, a.seg[0].ld, a.seg[0].width, a.seg[0].rmul, a.M, L.kc, L.nt, a.wzero, a, prof_ts)
   // (likewise the device-clock stamps of the profiling pass exist only in the instantiations that pass launches)
   if (prof_ts == nullptr) {
     if (a.epi == EPI_ACT) SQ_LAUNCH_KL(false, false); else SQ_LAUNCH_KL(true, false);
@@ -605,14 +610,14 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
     // (all of them accumulate in the same order: the tile shape never changes a result)
     if (L.kc <= 4) {  // K <= 64: one block of loads, nothing to pipeline
       const dim3 grid_r(L.nt, (mt + 3) / 4);
-      hipLaunchKernelGGL(k_linear_rows<4>, grid_r, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+      SQ_LAUNCH(k_linear_rows<4>, grid_r, dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
       return 0;
     }
     // the LDS-tiled kernel pays once its 128 x 64 workgroup tiles fill the chip twice over (measured, tools/time_linear.py:
     // 51200 x 256 x 256 118 -> 106 us, 5120 x 362 x 1152 80 -> 67 us; below that the macro-tile kernel's smaller tiles win)
     static const int lds_wgs = SQ_KNOB_INT("SQAIR_LDS_WGS", 512);  // measurement knob
     if (((a.M + 127) / 128) * ((L.nt + 3) / 4) >= lds_wgs) {
-      hipLaunchKernelGGL((k_linear_lds<2>), dim3((L.nt + 3) / 4, (a.M + 127) / 128), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
+      SQ_LAUNCH((k_linear_lds<2>), dim3((L.nt + 3) / 4, (a.M + 127) / 128), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);
       return 0;
     }
     const MtShape sh = pick_mt_shape(a.M, L.nt, L.kc);

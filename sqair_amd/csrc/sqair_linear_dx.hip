@@ -26,7 +26,8 @@ __device__ __forceinline__ float dx_dact(float g, float o, int act) {
 template <int NCH, int GRU = 0>
 __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpre0, const float* __restrict__ wp0, const int ld0,
                                                    const int width0, const int M0, const int kc_total,
-                                                   const float* __restrict__ wzero0, const DxArgs a) {
+                                                   const float* __restrict__ wzero0, const DxArgs a SQ_TLP) {
+  SQ_TL_SCOPE;
   // leading scalars (copies of a.dpre / a.wp / a.ld / a.width / a.M / a.wzero): preloaded into SGPRs with the launch, so the
   // operand loads are issued before the s_load of the struct has returned; the epilogue operands, which need the struct, are
   // requested right behind them and still ahead of the MFMAs (see sqair_linear_kernel.inc)
@@ -147,25 +148,25 @@ int sq_launch_linear_dx(const DxArgs& a, int kc, int nt, hipStream_t s) {
   const int per_wave = (kc + 3) / 4;
   if (a.gru.mode != 0) {  // GRU gate adjoints in the epilogue: one range [0, nh), K = nh or the what-head width (<= 16 chunks)
     if (a.nranges != 1 || a.r[0].n0 != 0 || a.r[0].n1 != a.gru.nh || per_wave > 4 || a.r[0].saved != nullptr) return -6;
-#define SQ_DXG(G) hipLaunchKernelGGL((k_linear_dx<4, G>), g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a)
+#define SQ_DXG(G) SQ_LAUNCH((k_linear_dx<4, G>), g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a)
     if (a.gru.mode == 1) SQ_DXG(1); else SQ_DXG(2);
 #undef SQ_DXG
     return 0;
   }
   switch (per_wave) {
-    case 1: hipLaunchKernelGGL(k_linear_dx<1>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
-    case 2: hipLaunchKernelGGL(k_linear_dx<2>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
-    case 3: hipLaunchKernelGGL(k_linear_dx<3>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
-    case 4: hipLaunchKernelGGL(k_linear_dx<4>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
-    case 5: hipLaunchKernelGGL(k_linear_dx<5>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
-    case 6: hipLaunchKernelGGL(k_linear_dx<6>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
-    case 7: hipLaunchKernelGGL(k_linear_dx<7>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
-    case 8: hipLaunchKernelGGL(k_linear_dx<8>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
-    case 9: hipLaunchKernelGGL(k_linear_dx<9>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 1: SQ_LAUNCH(k_linear_dx<1>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 2: SQ_LAUNCH(k_linear_dx<2>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 3: SQ_LAUNCH(k_linear_dx<3>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 4: SQ_LAUNCH(k_linear_dx<4>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 5: SQ_LAUNCH(k_linear_dx<5>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 6: SQ_LAUNCH(k_linear_dx<6>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 7: SQ_LAUNCH(k_linear_dx<7>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 8: SQ_LAUNCH(k_linear_dx<8>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+    case 9: SQ_LAUNCH(k_linear_dx<9>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
     case 10: case 11: case 12:  // K = 768: the GRU gate GEMMs' transposes, all 24 operand loads of a wave in flight at once
-      hipLaunchKernelGGL(k_linear_dx<12>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+      SQ_LAUNCH(k_linear_dx<12>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
     default:                    // K = 1152 (the loop-invariant pre-activation GEMM's transpose) and deeper (looped)
-      hipLaunchKernelGGL(k_linear_dx<18>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
+      SQ_LAUNCH(k_linear_dx<18>, g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a); break;
   }
   return 0;
 }

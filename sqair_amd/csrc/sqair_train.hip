@@ -17,7 +17,8 @@
 
 // a few elementwise helpers local to the driver
 __global__ void k_mul2d(const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld, float* __restrict__ out,
-                        int o_ld, int rows, int cols) {
+                        int o_ld, int rows, int cols SQ_TLP) {
+  SQ_TL_SCOPE;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * cols) return;
   const int m = i / cols, n = i - m * cols;
@@ -25,7 +26,8 @@ __global__ void k_mul2d(const float* __restrict__ a, int a_ld, const float* __re
 }
 // zero fill as a kernel node: memset nodes in the middle of a long captured chain proved unreliable on replay
 // (ROCm 7.2: the second replay of the training graph read stale scratch), a plain kernel keeps the chain uniform
-__global__ void k_zero(float* __restrict__ p, int64_t n) {
+__global__ void k_zero(float* __restrict__ p, int64_t n SQ_TLP) {
+  SQ_TL_SCOPE;
   const int64_t n4 = n / 4;
   float4* p4 = reinterpret_cast<float4*>(p);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
@@ -36,21 +38,23 @@ void sq_zero_fill(float* p, int64_t n, hipStream_t s) {  // p 16-byte aligned
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  if (n > 0) hipLaunchKernelGGL(k_zero, dim3((unsigned)blocks), dim3(256), 0, s, p, n);
+  if (n > 0) SQ_LAUNCH(k_zero, dim3((unsigned)blocks), dim3(256), 0, s, p, n);
 }
-__global__ void k_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+__global__ void k_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t n SQ_TLP) {
+  SQ_TL_SCOPE;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 void sq_copy(float* dst, const float* src, int64_t n, hipStream_t s) {
   int64_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  if (n > 0) hipLaunchKernelGGL(k_copy, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n);
+  if (n > 0) SQ_LAUNCH(k_copy, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n);
 }
 // shifted z-record / RNN-state inputs of the slot RNNs as dense matrices for the batched weight gradient:
 //   zs[(t,r,k)] = z-record of slot k-1 (k > 0) or `init_rec` (k = 0);  rs[(t,r,k)] = r tape of slot k-1 or rnn_init
 __global__ void k_shift_inputs(const float* __restrict__ rec_all, const float* __restrict__ r_tape, const float* __restrict__ init_rec,
                                const float* __restrict__ rnn_init, float* __restrict__ zs, float* __restrict__ rs, int rows,
-                               int N, int nh) {
+                               int N, int nh SQ_TLP) {
+  SQ_TL_SCOPE;
   const int row = blockIdx.x;  // (t, r, k) flattened
   if (row >= rows) return;
   const int k = row % N;
@@ -651,7 +655,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     // prior GRU
     wgrad(L_PRIOR_GRU1, {{w.rec_m_all, RW}, {pm_all, psnh}}, b.d_pgru1, pgw, MT);
     if (c.prior_cell == CELL_GRU) {
-      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.pgr, nh, pm_all, nh, b.rh[0], nh, MT, nh);
+      SQ_LAUNCH(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.pgr, nh, pm_all, nh, b.rh[0], nh, MT, nh);
       wgrad(L_PRIOR_GRU2, {{b.rh[0], nh}}, b.d_pgru1 + 2 * nh, 3 * nh, MT);
     }
     wgrad(L_PRIOR_LIN, {{w.prior_p, psnh}}, b.d_pstats, PS_LD, MT);
@@ -669,10 +673,10 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     // loop-invariant pre-activations
     wgrad(L_PRE, {{w.m1, M1_LD}, {w.rec_m_all, RW}, {tau_all, snh}}, b.d_pre, pre_ld, MT);
     // propagation slot chain (phase 0 of the tapes)
-    hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_p_all, w.r, w.zero_rec, w.prop_rnn_init, b.zs[0], b.rs[0], MT, N, nh);
+    SQ_LAUNCH(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_p_all, w.r, w.zero_rec, w.prop_rnn_init, b.zs[0], b.rs[0], MT, N, nh);
     wgrad(L_PROP_RNN, {{b.zs[0], 64}, {b.rs[0], nh}}, b.d_rnn, rw, MT);
     if (c.rnn_cell == RNN_GRU) {  // candidate's recurrent matrix: A = r * h_{k-1}
-      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.rgates + nh, 3 * nh, b.rs[0], nh, b.rh[1], nh, MT, nh);
+      SQ_LAUNCH(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.rgates + nh, 3 * nh, b.rs[0], nh, b.rh[1], nh, MT, nh);
       wgrad(L_PROP_RNN2, {{b.rh[1], nh}}, b.d_rnn + 2 * nh, rw, MT);
     }
     wgrad(L_PROP_T1, {{w.r, nh}}, b.d_t1, T1_LD, MT);
@@ -682,7 +686,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     if (c.time_cell == CELL_LSTM) {
       wgrad(L_PROP_GRU2, {{tm_all, snh}}, b.d_gru1, gw, MT);   // recurrent rows + b_gates: A = h_{t-1}
     } else if (c.time_cell == CELL_GRU) {
-      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.gr, nh, tm_all, nh, b.rh[2], nh, MT, nh);
+      SQ_LAUNCH(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.gr, nh, tm_all, nh, b.rh[2], nh, MT, nh);
       wgrad(L_PROP_GRU2, {{b.rh[2], nh}}, b.d_gru1 + 2 * nh, 3 * nh, MT);
     }
     wgrad(L_PROP_HEADS, {{w.temporal_p, snh}}, b.d_hraw, HRAW_LD, MT);
@@ -694,11 +698,11 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     if (c.rec_where_prior) wgrad(L_RNCOND, {{w.rn_init_state, 0}, {w.c, nh}}, b.d_spre, 128, T * R);
     // discovery slot chain (phase 1 of the tapes)
     const size_t ph1 = (size_t)MT;
-    hipLaunchKernelGGL(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_d_all, w.r + ph1 * nh, w.disc_init_rec, w.disc_rnn_init, b.zs[1],
+    SQ_LAUNCH(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_d_all, w.r + ph1 * nh, w.disc_init_rec, w.disc_rnn_init, b.zs[1],
                        b.rs[1], MT, N, nh);
     wgrad(L_DISC_RNN, {{b.zs[1], 64}, {b.rs[1], nh}}, b.d_rnn + ph1 * rw, rw, MT);
     if (c.rnn_cell == RNN_GRU) {
-      hipLaunchKernelGGL(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.rgates + ph1 * 3 * nh + nh, 3 * nh, b.rs[1], nh, b.rh[3], nh, MT, nh);
+      SQ_LAUNCH(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.rgates + ph1 * 3 * nh + nh, 3 * nh, b.rs[1], nh, b.rh[3], nh, MT, nh);
       wgrad(L_DISC_RNN2, {{b.rh[3], nh}}, b.d_rnn + ph1 * rw + 2 * nh, rw, MT);
     }
     wgrad(L_DISC_T1, {{w.r + ph1 * nh, nh}}, b.d_t1 + ph1 * T1_LD, T1_LD, MT);
@@ -748,14 +752,15 @@ extern "C" int sqair_capture_launch(SqairHandle* h, int slot, void* stream) {
   return 0;
 }
 // grad += l2 * theta  (targets.l2_reg, sqair/targets.py:31-35: weight * sum_v l2_loss(v) over ALL trainable variables)
-__global__ void k_add_l2(const float* __restrict__ theta, float* __restrict__ grad, int64_t n, float l2) {
+__global__ void k_add_l2(const float* __restrict__ theta, float* __restrict__ grad, int64_t n, float l2 SQ_TLP) {
+  SQ_TL_SCOPE;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) grad[i] += l2 * theta[i];
 }
 extern "C" int sqair_add_l2_grad(SqairHandle* h, const float* flat_params, float* flat_grad, int64_t n, float l2, void* stream) {
   if (!h || !flat_params || !flat_grad || n < 0) return -1;
   if (n == 0 || l2 == 0.0f) return 0;
-  hipLaunchKernelGGL(k_add_l2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat_params, flat_grad, n, l2);
+  SQ_LAUNCH(k_add_l2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat_params, flat_grad, n, l2);
   SQ_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -779,7 +784,8 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 __global__ void k_fill_noise(float* __restrict__ noise, int64_t n_local, int64_t per_frame_local, int64_t per_frame_global,
-                             int64_t row0_elems, int nzw, unsigned long long seed, unsigned long long step) {
+                             int64_t row0_elems, int nzw, unsigned long long seed, unsigned long long step SQ_TLP) {
+  SQ_TL_SCOPE;
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // quad of 4 consecutive LOCAL elements
   if (q * 4 >= n_local) return;
 #pragma unroll
@@ -809,7 +815,7 @@ extern "C" int sqair_fill_noise(SqairHandle* h, float* noise, int T, int B, int 
   const int64_t per_frame_local = (int64_t)B * c.k_particles * per_row, per_frame_global = (int64_t)global_B * c.k_particles * per_row;
   const int64_t n_local = (int64_t)T * per_frame_local;
   const int64_t quads = (n_local + 3) / 4;
-  hipLaunchKernelGGL(k_fill_noise, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, noise, n_local,
+  SQ_LAUNCH(k_fill_noise, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, noise, n_local,
                      per_frame_local, per_frame_global, (int64_t)b0 * c.k_particles * per_row, nzw, (unsigned long long)seed,
                      (unsigned long long)step);
   SQ_CHECK_HIP(hipGetLastError());

@@ -62,11 +62,11 @@ class SqairCore(object):
     """Thin owner of a library handle + the device buffers it needs (parameters, packed parameters,
     workspace, noise, outputs) for one (T, B) shape on one device / stream."""
 
-    def __init__(self, F, img_hw, device="cuda:0"):
+    def __init__(self, F, img_hw, device="cuda:0", lib_path=None):
         if not torch.cuda.is_available():
             raise RuntimeError("sqair_amd needs a HIP device (no CPU fallback)")
         self.F = F
-        self.lib = _capi.lib()
+        self.lib = _capi.lib(lib_path)  # lib_path: a build variant (sqair_amd.timeline); default = the product library
         self.device = torch.device(device)
         self.cfg = make_config(F, img_hw)
         self.handle = C.c_void_p()
