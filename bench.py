@@ -164,7 +164,7 @@ def timeline_roofline(F, Ftr, hw, P, obs, nums, algo_flops_step, ms_fwd, ms_trai
             tj = json.load(open(tpath))
             if tj.get("build_id") == bid:
                 traffic = tj.get("dominant_bytes_per_launch")
-                fam_traffic = tj.get("family_bytes_per_step")
+                fam_traffic = tj.get("family_bytes_per_launch")
                 traffic_note = "PMC FETCH_SIZE / WRITE_SIZE of {} on this build (profiles/r03_hbm_traffic.json, two separate --pmc passes)".format(tj.get("dominant"))
             else:
                 traffic_note = "profiles/r03_hbm_traffic.json was measured on build {} != this build {}: not quoted".format(tj.get("build_id"), bid)

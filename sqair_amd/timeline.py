@@ -201,9 +201,10 @@ def algorithmic_hbm_bytes(T, B, K, N, H, W, G=20, nh=256, nw=50, snh=None, psnh=
     return out
 
 
-def hbm_class(rows, alg_bytes, traffic=None):
+def hbm_class(rows, alg_bytes, traffic_per_launch=None):
     """Per family: launches, busy time, algorithmic bytes per step -> achieved TB/s and fraction of the 8 TB/s HBM peak.
-    `traffic`: optional {family: PMC bytes per step} measured by rocprofv3 --pmc (profiles/), quoted beside it."""
+    `traffic_per_launch`: optional {family: PMC bytes per launch} measured by rocprofv3 --pmc (profiles/rNN_hbm_traffic.json,
+    `family_bytes_per_launch`), quoted beside it as bytes per step."""
     s = summarise(rows)["families"]
     out = []
     for fam, b in alg_bytes.items():
@@ -213,9 +214,9 @@ def hbm_class(rows, alg_bytes, traffic=None):
         e = dict(kernel=fam, launches=s[fam]["launches"], busy_us=busy, avg_busy_us=s[fam]["avg_busy_us"],
                  algorithmic_bytes_per_step=b, achieved=b / (busy * 1e-6) / 1e12, peak=HBM_PEAK_TBS, unit="TB/s")
         e["frac"] = e["achieved"] / HBM_PEAK_TBS
-        if traffic and fam in traffic:
-            e["traffic_bytes_per_step"] = traffic[fam]
-            e["traffic_over_algorithmic"] = traffic[fam] / b
+        if traffic_per_launch and fam in traffic_per_launch:
+            e["traffic_bytes_per_step"] = traffic_per_launch[fam] * s[fam]["launches"]
+            e["traffic_over_algorithmic"] = e["traffic_bytes_per_step"] / b
         out.append(e)
     return out
 

@@ -44,7 +44,13 @@ def main():
     dense = {k: v for k, v in out.items() if k.startswith(("k_linear<", "k_linear_rows", "k_linear_mt"))}
     tot_n = sum(v["launches"] for v in dense.values())
     dom = max(dense, key=lambda k: dense[k]["launches"]) if dense else None
+    fam = collections.defaultdict(lambda: [0, 0.0])
+    for k, v in out.items():
+        f = k.split("<")[0].strip()
+        fam[f][0] += v["launches"]
+        fam[f][1] += v["hbm_bytes_per_launch"] * v["launches"]
     blob = dict(build_id=build_id(),
+                family_bytes_per_launch={f: b / max(n, 1) for f, (n, b) in sorted(fam.items())},
                 dominant=dom, dominant_bytes_per_launch=dense[dom]["hbm_bytes_per_launch"] if dom else None,
                 dense_family_bytes_per_launch=sum(v["hbm_bytes_per_launch"] * v["launches"] for v in dense.values()) / max(tot_n, 1),
                 method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (python bench.py --steps 3 --warmup 1 "
