@@ -209,7 +209,7 @@ def timeline_roofline(F, Ftr, hw, P, obs, nums, algo_flops_step, ms_fwd, ms_trai
     roofline_hbm = TL.hbm_class(rows, alg, fam_traffic)
     train_tl = None
     if ms_train is not None:
-        tr = Trainer(model_t, Ftr, use_graph=True)
+        tr = Trainer(model_t, Ftr, use_graph=True, collective=False)
         step_t = lambda: tr.step(seed=2000, global_batch=B, b0=0)  # noqa: E731
         ms_tt = TL.time_steps(core_t, step_t, steps=5)
         rows_t, ev_t = tl.measure(step_t, warm=2)
@@ -434,7 +434,7 @@ def main():
                     ms_g = time_steps(core_g, gstep, steps=max(5, args.steps // 4), warm=3)
                     single = dict(sequences=B * world, forward_ms_per_step=ms_g, forward_value=B * world * T / (ms_g * 1e-3), unit="frames/s")
                     if n_train > 0:
-                        tr_g = Trainer(model_g, Ftr, use_graph=use_graph, comm=None)
+                        tr_g = Trainer(model_g, Ftr, use_graph=use_graph, comm=None, collective=False)
                         ms_gt = time_steps(core_g, lambda: tr_g.step(seed=2000, global_batch=B * world, b0=0), steps=max(3, n_train // 4), warm=2)
                         single.update(train_ms_per_step=ms_gt, train_value=B * world * T / (ms_gt * 1e-3))
                         del tr_g

@@ -768,6 +768,9 @@ class SqairOracle(object):
             write("_prop_presence_prob", prop["presence_prob"])
             write("_disc_presence_prob", disc["presence_prob"])
             write("_prop_prev_presence", z[2])
+            # probability of the Bernoulli the generation modes draw from the propagation PRIOR (sqair_modules.py:294-302):
+            # lets the tests measure how far those decisions are from flipping, like the two posterior ones above
+            write("_prop_prior_presence_prob", torch.sigmoid(prop["prior_stats"][4]))
             z, temporal, prior = z_t, o["temporal_state"], o["prior_state"]
             prev_ids, last_id = o["obj_ids"], o["last_used_id"]
         out = OrderedDict((k, torch.stack(v, 0)) for k, v in tas.items())

@@ -85,7 +85,7 @@ def save_checkpoint(path, core, optimizer=None, global_step=None, trainer=None):
         if optimizer.kind == "adam":
             blob["beta1_power"] = np.asarray(0.9 ** optimizer.t, dtype=np.float64)
             blob["beta2_power"] = np.asarray(0.999 ** optimizer.t, dtype=np.float64)
-            blob["optimizer_step"] = np.asarray(int(optimizer.t), dtype=np.int64)
+        blob["optimizer_step"] = np.asarray(int(optimizer.t), dtype=np.int64)
     blob["global_step"] = np.asarray(int(global_step or 0), dtype=np.int64)
     np.savez(path, **blob)
 
@@ -110,11 +110,17 @@ def load_checkpoint(path, core, optimizer=None, strict=True, trainer=None):
             if slot and all((tf_name + "/" + slot) in tf_vars for _, _, _, tf_name in spec):
                 vals = {name: np.asarray(tf_vars[tf_name + "/" + slot]).reshape(shape) for name, shape, _, tf_name in spec}
                 buf.copy_(torch.from_numpy(flatten_params(vals, spec)))
-        if optimizer.kind == "adam":
-            if "optimizer_step" in tf_vars:
-                optimizer.t = int(tf_vars["optimizer_step"])
-            elif "beta1_power" in tf_vars:   # a TF dump: recover the count from beta1^t
-                optimizer.t = int(round(np.log(float(tf_vars["beta1_power"])) / np.log(0.9)))
+        # number of updates applied so far: drives Adam's bias correction and, for every kind, the default learning-rate
+        # schedule of apply_gradients(lr=None).  Our own files store it; a TF dump has global_step (one update per step in the
+        # reference's loop, experiment.py:150-155) and, for Adam, beta1_power = 0.9^t — which TF keeps in fp32 and which
+        # underflows to 0 after ~1000 steps, so it is only used while it is still a usable number.
+        if "optimizer_step" in tf_vars:
+            optimizer.t = int(tf_vars["optimizer_step"])
+        else:
+            optimizer.t = step
+            b1p = float(tf_vars["beta1_power"]) if (optimizer.kind == "adam" and "beta1_power" in tf_vars) else 0.0
+            if step == 0 and np.isfinite(b1p) and 1e-30 < b1p < 1.0:
+                optimizer.t = int(round(np.log(b1p) / np.log(0.9)))
     if trainer is not None:
         trainer.step_no = step
     return step

@@ -113,18 +113,24 @@ class Trainer(object):
     buffer over the ranks (the single collective of the step, RCCL over xGMI), apply the optimiser.
     ``model`` is a ``sqair_amd.model.Model`` bound to this rank's shard."""
 
-    def __init__(self, model, F, use_graph=True, comm=None):
+    def __init__(self, model, F, use_graph=True, comm=None, collective=True):
         """comm: a ``sqair_amd.rccl.RcclComm`` — the gradient all-reduce is then enqueued on the core's own stream
-        (``ncclAllReduce``); None = the default ``torch.distributed`` group, if one is initialised."""
+        (``ncclAllReduce``); None = the default ``torch.distributed`` group, if one is initialised.  ``collective=False``: a
+        trainer that belongs to ONE rank of a running job (bench.py's single-GPU reference and timeline legs) and must not
+        enter the job's collective."""
         self.model, self.core, self.F = model, model.core, F
         self.comm = comm
+        self.collective = bool(collective)
         self.opt = Optimizer(self.core, getattr(F, "opt", "rmsprop"))
         self.step_no = 0
         self.use_graph = bool(use_graph)
 
     def step(self, obs=None, noise=None, generator=None, seed=None, global_batch=None, b0=0, presence=None):
         """One training step, asynchronous on the core's stream (``core.stream.synchronize()`` or read metrics inside
-        ``core.on_stream()`` to observe results)."""
+        ``core.on_stream()`` to observe results).  Returns the flat gradient buffer: on a multi-rank job it holds the SUM over
+        the ranks of the shard gradients (the all-reduce's result); the 1 / world that makes it the reference's ``reduce_mean``
+        over the global batch is applied inside the optimiser kernel (``grad_scale``), so a caller that logs or clips these
+        values must scale them by ``1 / world`` itself."""
         import torch
         from . import _capi
         from .dist import allreduce_flat_grads
@@ -157,7 +163,7 @@ class Trainer(object):
             if l2 != 0.0:
                 _capi.check(core.handle, core.lib.sqair_add_l2_grad(
                     core.handle, core.flat.data_ptr(), g.data_ptr(), core.n_params, l2, core._stream()), "sqair_add_l2_grad")
-            scale = allreduce_flat_grads(g, comm=self.comm, stream=core.stream)
+            scale = allreduce_flat_grads(g, comm=self.comm, stream=core.stream) if self.collective else 1.0
             self.opt.apply_gradients(g, learning_rate(F, self.step_no), grad_scale=scale)
         self.step_no += 1
         return g

@@ -105,7 +105,43 @@ def make_fixture(name, F, hw, T, B, data_seed, param_seed, jitter, n_objects=(0,
         os.path.getsize(path) / 1024.0))
 
 
+def grad_digest(g):
+    """What the gradient fixture keeps of one parameter's gradient (fp64): every element of small tensors, 256 evenly strided
+    elements of large ones, plus sum / sum of absolute values / L2 norm / max of absolute values over ALL elements."""
+    g = np.asarray(g, dtype=np.float64).reshape(-1)
+    idx = np.arange(g.size) if g.size <= 4096 else np.linspace(0, g.size - 1, 256).astype(np.int64)
+    return idx, g[idx], np.array([g.sum(), np.abs(g).sum(), np.sqrt((g * g).sum()), np.abs(g).max()])
+
+
+def make_grad_fixture(name):
+    """Gradients of the VIMCO target (model.py:150-168) w.r.t. every trainable variable for an EXISTING forward fixture (same
+    frames, parameters, noise), by autograd through the fp64 oracle -> <name>_grads.npz (digest form, see grad_digest)."""
+    z = np.load(os.path.join(HERE, name + ".npz"))
+    T, B, K, N, H, W, pseed, _ = [int(v) for v in z["meta"]]
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    spec = param_spec(F, (H, W))
+    P = params32(F, (H, W), pseed, float(z["jitter"]), z["mean_img"])
+    assert checksum(P, spec) == str(z["params_sha256"]), "parameters regenerated from (seed, jitter) differ from the fixture's"
+    orc = O.SqairOracle(P, O.make_cfg(F, (H, W)), torch.float64, requires_grad=True)
+    m = orc.model(z["obs"], z["noise"], num=z["nums"], resample_u=z["resample_u"])
+    assert np.array_equal(m.presence.detach().numpy(), z["out_presence"])
+    target = orc.make_target(m)
+    target.backward()
+    out = dict(params_sha256=z["params_sha256"], vimco_target=np.float64(target.item()))
+    for pname in (e[0] for e in spec):
+        g = orc.P[pname].grad
+        g = np.zeros(orc.P[pname].shape) if g is None else g.numpy()
+        idx, vals, stats = grad_digest(g)
+        out["idx/" + pname], out["val/" + pname], out["stat/" + pname] = idx, vals, stats
+    path = os.path.join(HERE, name + "_grads.npz")
+    np.savez_compressed(path, **out)
+    print("{}_grads: target {:.6f}, {} parameters, {:.0f} KB".format(name, float(target), len(spec), os.path.getsize(path) / 1024.0))
+
+
 if __name__ == "__main__":
+    if "--grads-only" in sys.argv:   # the forward fixtures stay as committed; only the gradient digest is (re)generated
+        make_grad_fixture("k5_iwae_vimco")
+        sys.exit(0)
     # cfg-1 (BASELINE.json configs[0]): T=3, B=4, K=1, N=3, 50x50 — full 38-output dump
     make_fixture("cfg1_plumbing", make_flags(k_particles=1, n_steps_per_image=3), (50, 50), T=3, B=4, data_seed=1235,
                  param_seed=0, jitter=0.05)
@@ -115,3 +151,4 @@ if __name__ == "__main__":
     # 128x128 frames (cfg-5 shape family): stresses the LDS-staged crop / insert path
     make_fixture("hw128_small", make_flags(k_particles=2, n_steps_per_image=4), (128, 128), T=2, B=2, data_seed=5,
                  param_seed=2, jitter=0.05, n_objects=(1, 2), obj_size=72, full=False)
+    make_grad_fixture("k5_iwae_vimco")

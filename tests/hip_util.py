@@ -70,6 +70,17 @@ def presence_margins(o, noise):
     return d.min((0, 2, 3))
 
 
+def prior_presence_margins(o, gen_noise):
+    """The same for the Bernoullis the generation modes draw from the propagation PRIOR (`sample_from_prior`,
+    sqair_modules.py:294-302): min |u_gen - sigmoid(prior logit)| per row over the slots that were present at t - 1 (an absent
+    slot's prior logit is -88: its draw cannot flip)."""
+    g = lambda k: o[k].detach().numpy() if hasattr(o[k], "detach") else np.asarray(o[k])
+    shp = gen_noise.shape[:2] + (gen_noise.shape[3],)
+    live = g("_prop_prev_presence")[..., :shp[-1]].reshape(shp) > 0.5
+    d = np.where(live, np.abs(gen_noise[:, :, 0, :, -1] - g("_prop_prior_presence_prob").reshape(shp)), 1.0)
+    return d.min((0, 2))
+
+
 # A draw whose closest live Bernoulli sits nearer than this to its threshold is not used: the HIP path's probabilities agree
 # with the fp64 oracle to ~1e-6 (test_forward_matches_golden_fixture), so 1e-4 is a 100x safety factor, and with ~10^3 live
 # Bernoullis per case a draw passes with probability ~0.8 (a wider margin would reject nearly every draw of the larger cases).

@@ -248,12 +248,22 @@ def _full_backward_case(K, N, T, B, hw, seed, flags=None):
     return report, ref, core
 
 
-def _check_report(report, tol=3e-3):
+# Gradient bar: 5e-4 of the parameter's largest gradient (measured: <= ~1e-4 in the regular regime).  The parameters below get
+# 3e-3: `*.transform.scale_offset` is ONE scalar added to the four raw scales of every where posterior, so its gradient is the
+# sum over all rows, frames, slots and the 4 scale columns of the gradient of `*.transform.l2.b` -- terms of both signs of size
+# ~50 that cancel to ~0.3 (measured below: |grad| 0.29 against 49 for l2.b), which amplifies the fp32 rounding of the
+# individual terms (each good to ~1e-4) by two orders of magnitude relative to the result.  Everything else holds the tight bar.
+TIGHT, LOOSE = 5e-4, 3e-3
+ILL_CONDITIONED = ("disc.transform.scale_offset", "prop.transform.scale_offset")
+
+
+def _check_report(report, tol=TIGHT, loose=ILL_CONDITIONED):
     gmax = max(s for _, _, s in report)
-    bad = [(n, e, s) for n, e, s in report if not np.isfinite(e) or e > tol * max(s, 1e-4 * gmax)]
-    for n, e, s in report:
-        print("%-34s err %.3e  |grad|max %.3e %s" % (n, e, s, "<-- BAD" if (n, e, s) in bad else ""))
-    assert not bad, bad
+    rel = lambda e, s: e / max(s, 1e-4 * gmax)
+    bad = [(n, e, s) for n, e, s in report if not np.isfinite(e) or rel(e, s) > (LOOSE if n in loose else tol)]
+    for n, e, s in sorted(report, key=lambda r: -rel(r[1], r[2]))[:8]:
+        print("%-34s err %.3e  |grad|max %.3e  rel %.2e %s" % (n, e, s, rel(e, s), "<-- BAD" if (n, e, s) in bad else ""))
+    assert not bad, [(n, "%.2e" % rel(e, s)) for n, e, s in bad]
 
 
 def test_full_backward_single_frame_discovery_only():
@@ -591,3 +601,66 @@ def test_rccl_all_reduce_on_the_gradient_buffer_single_rank():
         assert float((again - before).abs().max()) <= 1e-5 * float(before.abs().max())
     finally:
         dist.destroy_process_group()
+
+
+def test_gradients_match_the_golden_fixture():
+    """tests/golden/k5_iwae_vimco_grads.npz (autograd through the fp64 oracle on the k5_iwae_vimco fixture; digest per
+    parameter: sampled elements + sum / sum|.| / L2 / max|.|): the HIP backward pass on the same frames, parameters, noise."""
+    import os
+    from sqair_amd.model import Model, SqairCore
+    from tests.hip_util_cpu import GOLDEN, fixture_params
+    z = np.load(os.path.join(GOLDEN, "k5_iwae_vimco.npz"))
+    g = np.load(os.path.join(GOLDEN, "k5_iwae_vimco_grads.npz"))
+    assert str(g["params_sha256"]) == str(z["params_sha256"])
+    T, B, K, N, H, W, _, _ = [int(v) for v in z["meta"]]
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    P = fixture_params(z, F, (H, W))
+    core = SqairCore(F, (H, W))
+    core.set_params(P)
+    m = Model(z["obs"], None, core, K, presence=z["nums"], outputs=["log_weights_per_timestep", "discrete_log_prob", "presence"])
+    with core.on_stream():
+        core.noise.copy_(torch.as_tensor(z["noise"]).reshape(core.noise.shape))
+        core.forward(train=True)
+        core.backward()
+    core.stream.synchronize()
+    assert np.array_equal(core.out["presence"].cpu().numpy(), z["out_presence"].astype(np.float32))
+    assert abs(float(core.scalars[2]) - float(g["vimco_target"])) <= 1e-4 * abs(float(g["vimco_target"]))
+    report = []
+    gmax = max(float(g[k][3]) for k in g.files if k.startswith("stat/"))
+    for name, got in core.grads_by_name().items():
+        got = got.cpu().numpy().astype(np.float64).reshape(-1)
+        stat = g["stat/" + name]
+        scale = max(float(stat[3]), 1e-4 * gmax)
+        report.append((name, float(np.abs(got[g["idx/" + name]] - g["val/" + name]).max()), float(stat[3])))
+        # whole-tensor digests: the L2 norm to the same relative bar
+        assert abs(np.sqrt((got * got).sum()) - stat[2]) <= LOOSE * max(stat[2], scale), name
+    _check_report(report)
+
+
+def test_l2_term_of_the_target_and_its_gradient():
+    """targets.l2_reg (sqair/targets.py:31-35): weight * sum_v tf.nn.l2_loss(v) = weight * 0.5 * sum theta^2 over ALL
+    trainable variables, added to the VIMCO target (model.py:160); its gradient is weight * theta (sqair_add_l2_grad)."""
+    from sqair_amd.data import make_sequences, to_float
+    from sqair_amd.model import Model, SqairCore
+    from sqair_amd.train import Optimizer
+    from tests.hip_util import draw_noise, params32
+    K, N, T, B, hw = 2, 2, 2, 2, (50, 50)
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    obs = to_float(make_sequences(B, T=T, canvas=hw, seed=3)["imgs"])
+    core = SqairCore(F, hw)
+    core.set_params(params32(F, hw, 2, 0.05, obs.mean((0, 1))))
+    m = Model(obs, None, core, K, outputs="minimal")
+    noise = draw_noise(np.random.default_rng(1), T, B * K, N, 55)
+    opt = Optimizer(core)
+    with core.on_stream():
+        core.noise.copy_(torch.as_tensor(noise).reshape(core.noise.shape))
+    m._ran = True    # keep this noise
+    t0, gv0 = m.make_target(opt, l2_reg=0.0)
+    g0 = core.flat_grad.clone()
+    l2 = 0.37
+    t1, gv1 = m.make_target(opt, l2_reg=l2)
+    theta = core.flat.cpu().numpy().astype(np.float64)
+    assert abs(float(t1) - (float(t0) + l2 * 0.5 * float((theta * theta).sum()))) <= 1e-5 * abs(float(t1))
+    want = g0.cpu().numpy().astype(np.float64) + l2 * theta
+    assert np.abs(core.flat_grad.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+    assert len(gv1) == len(core.spec)

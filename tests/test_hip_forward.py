@@ -12,7 +12,9 @@ from sqair_amd import _capi
 from sqair_amd.data import config_inputs, make_sequences, to_float
 from sqair_amd.flags import make_flags
 from sqair_amd.model import Model, SqairCore
-from tests.hip_util import GOLDEN, MARGIN, draw_noise, params32, presence_margins, rel_err, run_hip, run_oracle, stable_noise
+from tests.hip_util_cpu import fixture_params
+from tests.hip_util import (GOLDEN, MARGIN, MAX_DRAWS, draw_noise, params32, presence_margins, prior_presence_margins, rel_err,
+                            run_hip, run_oracle, stable_noise)
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +48,7 @@ def test_forward_matches_golden_fixture(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     T, B, K, N, H, W, pseed, _ = [int(v) for v in z["meta"]]
     F = make_flags(k_particles=K, n_steps_per_image=N)
-    P = params32(F, (H, W), pseed, float(z["jitter"]), z["mean_img"])
+    P = fixture_params(z, F, (H, W))   # regenerated from (seed, jitter); asserts the stored params_sha256
     ref_out = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
     ref_model = {k[6:]: z[k] for k in z.files if k.startswith("model_")}
     m = run_hip(F, (H, W), P, z["obs"], z["noise"], nums=z["nums"], resample_u=z["resample_u"])
@@ -298,17 +300,22 @@ def test_generation_modes_vs_live_oracle(generate_after, prior):
     core.set_params(P)
     m = Model(obs, None, core, K, presence=d["nums"])
     orc = O.SqairOracle(P, O.make_cfg(F, hw), torch.float64)
-    for attempt in range(3):   # (Bernoullis drawn from the PRIOR in these modes are outside presence_margins' reach)
+    # the draw is chosen on the ORACLE's margins alone — the posterior Bernoullis and the ones these modes draw from the
+    # propagation prior — and the HIP path then runs ONCE; a disagreement in any discrete decision is a failure
+    for attempt in range(MAX_DRAWS):
         rng = np.random.default_rng(400 + attempt)
         noise, gen_noise = draw_noise(rng, T, B * K, N, 55), draw_noise(rng, T, B * K, N, 55)
         with torch.no_grad():
             ref = orc.model(obs, noise, num=d["nums"], gen_noise=gen_noise)
-        m.run(noise=noise, gen_noise=gen_noise)
-        if all(np.array_equal(getattr(m, k).cpu().numpy(), getattr(ref, k).numpy()) for k in ("prop_pres", "disc_pres", "presence")):
-            print("generation mode: identical discrete decisions on draw", attempt + 1)
+        mg = min(float(presence_margins(ref.outputs, noise).min()), float(prior_presence_margins(ref.outputs, gen_noise).min()))
+        if mg >= MARGIN:
+            print("generation mode: draw {} of <= {}, oracle margin {:.4f}".format(attempt + 1, MAX_DRAWS, mg))
             break
     else:
-        pytest.fail("no noise draw with identical discrete decisions")
+        pytest.fail("no decision-stable noise draw within {} attempts (last margin {:.2e})".format(MAX_DRAWS, mg))
+    m.run(noise=noise, gen_noise=gen_noise)
+    for k in ("prop_pres", "disc_pres", "presence", "obj_id"):
+        assert np.array_equal(getattr(m, k).cpu().numpy(), getattr(ref, k).numpy().astype(np.float32)), k
     if generate_after > 0:
         assert float(m.disc_pres[generate_after + 1:].abs().sum()) == 0.0
         assert float(m.num_disc_steps_per_sample[:generate_after + 1].sum()) > 0
@@ -355,3 +362,87 @@ def test_tail_fused_into_the_next_rnn_layer_is_bitwise_identical(K, N, T, B, n_u
         assert np.array_equal(fused[k], plain[k]), k
         assert np.array_equal(fused_t[k], plain[k]), k
     assert float(plain["presence"].sum()) > 0
+
+
+def test_cfg2_full_batch_against_the_fp32_oracle():
+    """BASELINE configs[1] at FULL size (all 32 sequences x 5 particles x 10 frames) against the oracle in fp32 — the
+    comparison bench.py's cpu_baseline leg prints, as a test: every particle row whose Bernoullis are decision-stable on the
+    oracle's margin must decide identically, and the sequence log-weights / ELBO agree to the north-star 1e-4 relative."""
+    ov, obs, nums, _ = config_inputs(2)
+    F = make_flags(**ov)
+    hw = tuple(obs.shape[2:])
+    T, B, K, N = obs.shape[0], obs.shape[1], int(F.k_particles), int(F.n_steps_per_image)
+    P = params32(F, hw, 0, 0.02, obs.mean((0, 1)))
+    noise = draw_noise(np.random.default_rng(4242), T, B * K, N, 55)
+    ref = run_oracle(F, hw, P, obs, noise, nums=nums, dtype=torch.float32)
+    m = run_hip(F, hw, P, obs, noise, nums=nums, outputs=["log_weights_per_timestep", "discrete_log_prob", "presence"])
+    stable = presence_margins(ref.outputs, noise) >= MARGIN
+    agree = (m.presence.cpu().numpy() == ref.presence.numpy()).all((0, 2))
+    print("cfg-2 full batch: {} of {} rows decision-stable, {} agree".format(int(stable.sum()), stable.size, int(agree.sum())))
+    assert stable.mean() > 0.8 and agree[stable].all()
+    a = m.log_weights.cpu().numpy().astype(np.float64).reshape(-1)[stable]
+    b = ref.log_weights.numpy().astype(np.float64).reshape(-1)[stable]
+    # fp32 oracle vs fp32 kernels: both carry ~1e-6 of rounding through a 10-frame recurrence
+    assert np.abs(a - b).max() <= REL * np.abs(b).max()
+    if agree.all():
+        assert abs(float(m.elbo_iwae) - float(ref.elbo_iwae)) <= REL * abs(float(ref.elbo_iwae))
+
+
+def test_resample_and_image_summaries_match_the_reference_semantics():
+    """Model.resample / resampled_* / img_summaries (reference: sqair/model.py:170-214): tensors gathered along the tiled-batch
+    axis at b * K + iw_resampling_idx[b]; summaries = uint8 reconstruction (resampled canvas) and input of the first frame."""
+    K, N, T, B, hw = 4, 3, 3, 5, (50, 50)
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), seed=21)
+    obs = to_float(d["imgs"])
+    P = params32(F, hw, 3, 0.05, obs.mean((0, 1)))
+    noise = draw_noise(np.random.default_rng(5), T, B * K, N, 55)
+    ru = np.random.default_rng(6).uniform(size=B).astype(np.float32)
+    m = run_hip(F, hw, P, obs, noise, nums=d["nums"], resample_u=ru)
+    iw = m.importance_weights.cpu().numpy()
+    idx = m.iw_resampling_idx.cpu().numpy()
+    # inverse-CDF draw of Categorical(importance weights) at u (the reference samples tfd.Categorical, model.py:102-103)
+    want_idx = np.minimum((np.cumsum(iw, -1) <= ru[:, None]).sum(-1), K - 1)
+    assert np.array_equal(idx, want_idx) and (iw[np.arange(B), idx] > 0).all()
+    rows = np.arange(B) * K + idx
+    for name in "obj_id canvas glimpse presence_prob presence presence_logit where".split():
+        full = getattr(m, name).cpu().numpy()
+        got = getattr(m, "resampled_" + name).cpu().numpy()
+        assert got.shape == (T, B) + full.shape[2:] and np.array_equal(got, full[:, rows]), name
+    # resample(*args, axis): several tensors at once, any axis, K = 1 is the identity (model.py:170-192)
+    a, b = m.resample(m.what, m.where, axis=1)
+    assert np.array_equal(a.cpu().numpy(), m.what.cpu().numpy()[:, rows]) and np.array_equal(b.cpu().numpy(), m.where.cpu().numpy()[:, rows])
+    lw = m.log_weights.reshape(-1)
+    assert np.array_equal(m.resample(lw, axis=-1).cpu().numpy(), lw.cpu().numpy()[rows])
+    s = m.img_summaries()
+    assert s["reconstructions"].dtype == torch.uint8 and s["inputs"].dtype == torch.uint8
+    assert tuple(s["reconstructions"].shape) == (B,) + hw and tuple(s["inputs"].shape) == (B,) + hw
+    rec = np.round(np.clip(m.canvas.cpu().numpy()[0, rows], 0.0, 1.0) * 255.0).astype(np.uint8)
+    assert np.array_equal(s["reconstructions"].cpu().numpy(), rec)
+    assert np.array_equal(s["inputs"].cpu().numpy(), np.round(obs[0] * 255.0).astype(np.uint8))
+    # importance-weighted means are what the per-frame metrics are (model.py:202-205)
+    dl = m.data_ll_per_sample.cpu().numpy().reshape(T, B, K).mean(0)
+    assert abs(float(m.data_ll) - float((iw * dl * K).mean())) <= 1e-4 * abs(float(m.data_ll))
+    m1 = run_hip(make_flags(k_particles=1, n_steps_per_image=N), hw, P, obs, noise[:, ::K], nums=d["nums"])
+    assert np.array_equal(m1.resampled_canvas.cpu().numpy(), m1.canvas.cpu().numpy())
+
+
+def test_debug_mode_raises_on_non_finite_log_weights():
+    """`debug=True` (reference: validate_args / allow_nan_stats=False, core.py:226, :261, modules.py:318-320): a pass whose
+    log-weights are not finite fails through the library's error channel; a healthy pass does not."""
+    K, N, T, B, hw = 2, 2, 2, 2, (50, 50)
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    d = make_sequences(B, T=T, canvas=hw, seed=2)
+    obs = to_float(d["imgs"])
+    P = params32(F, hw, 1, 0.05, obs.mean((0, 1)))
+    core = SqairCore(F, hw)
+    core.set_params(P)
+    m = Model(obs, None, core, K, presence=d["nums"], debug=True)
+    m.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))
+    assert np.isfinite(float(m.elbo_iwae))
+    bad = dict(P)
+    bad["dec.l2.b"] = np.full_like(P["dec.l2.b"], np.nan)
+    core.set_params(bad)
+    with pytest.raises(RuntimeError, match="non-finite values in log_weights"):
+        m.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))
+    assert core.lib.sqair_set_option(core.handle, b"no_such_option", 1) == -2
