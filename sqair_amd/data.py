@@ -4,7 +4,7 @@ glyphs standing in for the MNIST digits (MNIST is not available offline).  SURVE
 Reference pipeline (sqair/data/create_seq_mnist.py:89-131) and where each stage lives here:
 
   * static frame — ``create_mnist`` (sqair/data/data.py:64-186): ``nums ~ randint(n_min, n_max + 1)`` objects per sample;
-    each template is tight-cropped to its non-zero bounding box (``template_dimensions`` / ``dim_coords``, data.py:47-60);
+    each template is tight-cropped to its non-zero bounding box (``template_dimensions``, data.py:47-60);
     its top-left corner is ``round(rand(2) * (canvas - size))`` (``make_coord`` with ``fraction_outside_canvas = 0``),
     re-drawn while the box overlaps an occupied region, at most 5 draws in total per SAMPLE, after which the whole sample
     is started again                                                   -> ``place_templates``
@@ -13,7 +13,7 @@ Reference pipeline (sqair/data/create_seq_mnist.py:89-131) and where each stage 
     ``[-overlap * template, canvas - overlap * template]`` = ``[0, canvas]`` for ``overlap = 0``
     (create_seq_mnist.py:43-56, :98)                                   -> ``NoisyAccelerationTrajectory``, ``position_bounds``
   * rendering — ``TemplateDataset._blend`` (sqair/data/template.py:69-104): positions rounded to integers, templates
-    clipped to the canvas and merged with ``np.maximum``              -> ``blend``, ``constrain_dims``
+    clipped to the canvas and merged with ``np.maximum``              -> ``blend``, ``_visible_span``
   * ``convert_img_dtype`` (template.py:38-42): ``(imgs - min) / (max / 255)`` then a TRUNCATING cast to uint8
                                                                        -> ``convert_img_dtype``
   * fed as ``float32 / 255`` (data.py:199)                             -> ``to_float``
@@ -96,35 +96,36 @@ class NoisyAccelerationTrajectory(object):
 
 
 # ---------------------------------------------------------------------------------------------------- rendering
-def constrain_dims(a, b, dim):
-    """Slice [ai, bi) of a template spanning canvas rows a..b that falls inside a canvas of ``dim`` rows (template.py:31-35)."""
-    ai = 0 if a >= 0 else -a
-    d = min(dim - b, 0)
-    bi = b - a + d
-    return ai, max(bi, 0)
+def _visible_span(first, extent, limit):
+    """Intersection of the interval [first, first + extent) with a canvas axis [0, limit): returns (canvas_lo, canvas_hi,
+    template_lo) — the canvas slice that is covered and the template index it starts from.  An object entirely off the canvas
+    gives an empty slice.  (Same result as the reference's clip / slice arithmetic, template.py:31-35, :85-89, expressed as an
+    interval intersection; pinned bit for bit by tests/golden/generator_ref.npz.)"""
+    lo = min(max(first, 0), limit)
+    hi = max(min(max(first + extent, 0), limit), lo)
+    return lo, hi, lo - first
 
 
 def blend(canvas, template, pos):
     """Max-blends ``template`` into ``canvas`` (in place) with its top-left corner at ``round(pos)``; parts outside the
     canvas are cut off (template.py:69-104)."""
-    th, tw = template.shape[:2]
-    height, width = canvas.shape[:2]
-    pos = np.round(pos)
-    y0, x0 = int(pos[0]), int(pos[1])
-    y1, x1 = int(pos[0] + th), int(pos[1] + tw)
-    yt0, yt1 = constrain_dims(y0, y1, height)
-    xt0, xt1 = constrain_dims(x0, x1, width)
-    y0, y1 = min(max(y0, 0), height), max(min(y1, height), 0)
-    x0, x1 = min(max(x0, 0), width), max(min(x1, width), 0)
-    canvas[y0:y1, x0:x1] = np.maximum(canvas[y0:y1, x0:x1], template[yt0:yt1, xt0:xt1])
+    corner = np.round(pos).astype(np.int64)
+    rows = _visible_span(int(corner[0]), template.shape[0], canvas.shape[0])
+    cols = _visible_span(int(corner[1]), template.shape[1], canvas.shape[1])
+    (r0, r1, tr), (c0, c1, tc) = rows, cols
+    if r1 <= r0 or c1 <= c0:
+        return
+    patch = canvas[r0:r1, c0:c1]
+    np.maximum(patch, template[tr:tr + (r1 - r0), tc:tc + (c1 - c0)], out=patch)
 
 
 def convert_img_dtype(imgs, dtype=np.uint8):
-    """template.py:38-42 — note: divides by ``max / 255`` (not by the range) and the cast truncates."""
-    if dtype == np.uint8:
-        imgs = (imgs - imgs.min()) / (imgs.max() / 255.)
-        imgs = imgs.astype(np.uint8)
-    return imgs
+    """Whole-dataset rescale to uint8 (template.py:38-42).  Quirks kept on purpose: the offset is the global minimum but the
+    scale is ``max / 255`` (not the range), and the float -> uint8 cast truncates instead of rounding."""
+    if dtype != np.uint8:
+        return imgs
+    shifted = imgs - imgs.min()
+    return (shifted / (imgs.max() / 255.)).astype(np.uint8)
 
 
 def to_float(imgs_u8):
@@ -133,27 +134,27 @@ def to_float(imgs_u8):
 
 
 # ---------------------------------------------------------------------------------------------------- static frame
-def dim_coords(proj):
-    """(start, size) of the non-zero run of a projection (data.py:47-51; size = number of non-zero entries)."""
-    proj = np.greater(proj, 0.)
-    size = int(proj.sum())
-    start = int(np.argmax(np.arange(len(proj)) * proj)) - size + 1
-    return start, size
-
-
 def template_dimensions(template):
-    """data.py:55-60."""
-    y_start, y_size = dim_coords(template.sum(1))
-    x_start, x_size = dim_coords(template.sum(0))
-    return (y_start, x_start), (y_size, x_size)
+    """Tight bounding box of the non-zero pixels of a template as ((y, x), (height, width)) (data.py:47-60).  Like the
+    reference, the size along an axis is the NUMBER of non-empty rows / columns (not last - first + 1) and the start is the
+    last non-empty index minus that count plus one — identical for the solid glyphs used here and for MNIST digits."""
+    out = []
+    for axis in (1, 0):
+        occupied = np.flatnonzero(template.sum(axis) > 0.)
+        count = int(occupied.size)
+        last = int(occupied[-1]) if count else 0
+        out.append((last - count + 1, count))
+    (y, h), (x, w) = out
+    return (y, x), (h, w)
 
 
 def make_coord(size, canvas_size, rng, fraction_outside_canvas=0.0):
-    """Top-left corner of a template of ``size`` (data.py:98-115): ``round(rand(2) * (canvas + (2 f - 1) size) - f size)``."""
-    size = np.asarray(size)
-    position_range = np.asarray(canvas_size) + (2. * fraction_outside_canvas - 1.) * size
-    pos = rng.rand(2) * position_range - fraction_outside_canvas * size
-    return np.round(pos).astype(np.int32)
+    """Random top-left corner for a template of ``size`` (data.py:98-115): uniform over the positions that keep at most
+    ``fraction_outside_canvas`` of the template off the canvas, rounded to whole pixels.  Consumes ``rng.rand(2)``."""
+    f = float(fraction_outside_canvas)
+    extent = np.asarray(size, dtype=np.float64)
+    free = np.asarray(canvas_size, dtype=np.float64) - (1.0 - 2.0 * f) * extent
+    return np.round(rng.rand(2) * free - f * extent).astype(np.int32)
 
 
 def place_templates(templates, canvas_size, rng, with_overlap=False, n_tries=5):
