@@ -532,6 +532,229 @@ __global__ __launch_bounds__(256) void k_linear_lds(const LinArgs a, const int k
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Large-row throughput kernel (launches with thousands of rows whose tiles fill the chip: the once-per-frame layers from ~128
+// sequences per GPU up, the decoder, cfg-4): BOTH operands through LDS.
+//   * workgroup tile 128 rows x (2 TNW) 16-column tiles (TNW = 4: 128 x 128), 2 x 2 waves, wave tile 64 x 16 TNW: per 16-deep
+//     K chunk a wave reads 4 A and TNW B fragments (ds_read_b128) for 16 TNW MFMAs (16x16x4 fp32): with TNW = 4 that is
+//     8 KB of LDS reads per 2048 matrix-core cycles and 16 KB of global traffic per workgroup and chunk (8 B/clk/CU; the
+//     128 x 64 tile of k_linear_lds with weights straight from global memory needs twice that, which is what capped it at
+//     0.40 of the fp32 matrix peak);
+//   * global -> LDS without registers (global_load_lds_dwordx4, 1 KB per wave instruction, LDS image = lane order): a weight
+//     fragment block of the packed buffer IS lane order; an activation block (16 rows x 64 bytes) is fetched with 4 lanes on
+//     each row's 64 contiguous bytes and the 16-byte unit q of row r goes to slot q ^ ((r >> 1) & 3) -- the swizzle is applied
+//     to the SOURCE address -- so that the fragment read (16 rows, same q) spreads over all banks;
+//   * two LDS stages: the loads of chunk c + 1 are issued before the MFMAs of chunk c and retired by the barrier that ends it
+//     (one chunk = ~0.9 us of matrix-core work per wave hides an L2 / MALL round trip);
+//   * blockIdx -> tile is XCD-aware: XCD x (= blockIdx % 8) owns a contiguous run of tiles in row-block-major order, i.e. a few
+//     row blocks with ALL their column blocks: every activation row is pulled into ONE L2 (the weights, small, into all 8);
+//     with the column block fastest across XCDs every L2 would fetch the whole activation matrix;
+//   * accumulation order = the other throughput kernels' (chunks in order, components x, y, z, w per accumulator): bit-identical
+//     results; the four components are issued as four sweeps over the 4 TNW independent accumulators (a dependent MFMA every
+//     16 TNW issues instead of back to back: 40-cycle latency against 32-cycle issue);
+//   * epilogue: the rolled loop over LDS-parked sums of k_linear_lds (small code).
+// ---------------------------------------------------------------------------------------------------
+#ifdef SQAIR_KNOBS
+__device__ unsigned long long sq_big_phase[8];   // knob builds: phase stamps of workgroup 0 / wave 0 (tools/time_linear.py prints them)
+#define SQ_BIG_STAMP(i) if (blockIdx.x == 8 && threadIdx.x == 0) sq_big_phase[i] = wall_clock64();
+#else
+#define SQ_BIG_STAMP(i)
+#endif
+template <int TNW>
+__global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int kc_total, const int n_tiles, const int n_colblk,
+                                                    const int n_tiles_total, const int vec_ok SQ_TLP) {
+  SQ_TL_SCOPE;
+  SQ_BIG_STAMP(0)
+  constexpr int A_BYTES = 128 * 16 * 4, B_BYTES = 2 * TNW * 1024, STAGE = A_BYTES + B_BYTES;
+  constexpr int PARK = 4 * (3 * TNW) * 1024;   // epilogue: per wave 2 TNW parked accumulators + TNW biases, 16 bytes per lane each
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE > PARK ? 2 * STAGE : PARK];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  // XCD-aware tile order (bijective also when the tile count is not a multiple of 8)
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, qn = n_tiles_total >> 3, rn = n_tiles_total & 7;
+  if (j >= qn + (xcd < rn ? 1 : 0)) return;
+  const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + j;
+  const int rowblk = tile / n_colblk, colblk = tile - rowblk * n_colblk;
+  const int row0 = rowblk * 128;
+  const int tile_n0 = colblk * (2 * TNW);
+  // segment table in named locals (see k_linear_mt)
+  const float* sp0 = a.seg[0].p; const float* sp1 = a.seg[1].p; const float* sp2 = a.seg[2].p; const float* sp3 = a.seg[3].p;
+  const int sl0 = a.seg[0].ld, sl1 = a.seg[1].ld, sl2 = a.seg[2].ld, sl3 = a.seg[3].ld;
+  const unsigned sm0 = a.seg[0].rmul, sm1 = a.seg[1].rmul, sm2 = a.seg[2].rmul, sm3 = a.seg[3].rmul;
+  const int w0 = a.seg[0].width, w1 = a.seg[1].width, w2 = a.seg[2].width, w3 = a.seg[3].width;
+  const int c1 = (w0 + 15) >> 4;
+  const int c2 = c1 + (a.nseg > 1 ? (w1 + 15) >> 4 : 0);
+  const int c3 = c2 + (a.nseg > 2 ? (w2 + 15) >> 4 : 0);
+  const int cum1 = a.nseg > 1 ? c1 : 0x7fffffff, cum2 = a.nseg > 2 ? c2 : 0x7fffffff, cum3 = a.nseg > 3 ? c3 : 0x7fffffff;
+  const int lim0 = ((w0 + 3) & ~3) - 4, lim1 = ((w1 + 3) & ~3) - 4, lim2 = ((w2 + 3) & ~3) - 4, lim3 = ((w3 + 3) & ~3) - 4;
+  // staging map of the activations: wave w issues the two 16-row pieces 2 w and 2 w + 1 of a chunk; lane -> row (lane >> 2) of
+  // the piece, LDS slot lane & 3, which holds the 16-byte unit q = slot ^ ((row >> 1) & 3) of the row's 64 bytes.
+  // The per-chunk address work is kept to a handful of instructions (one wave per SIMD issues an instruction every ~4-5 cycles:
+  // ~70 instructions of segment selection and 64-bit arithmetic per chunk were 0.3 us of every 1.2 us chunk): the row pointers
+  // of the CURRENT segment live in registers and are re-derived only when a chunk crosses a segment boundary (a scalar branch),
+  // the weight pointers advance by one fragment block.
+  const int srow = lane >> 2;
+  const int sq4 = ((lane & 3) ^ ((srow >> 1) & 3)) * 4;
+  const int arow_a = min(row0 + 32 * wave + srow, a.M - 1), arow_b = min(row0 + 32 * wave + 16 + srow, a.M - 1);
+  const float *pa = nullptr, *pb = nullptr;   // row pointers into the current segment
+  int seg_c0 = 0, seg_end = 0, seg_lim = 0, seg_i = -1;     // its first chunk, one past its last chunk, clamp of the k offset
+  const float* wpt[(2 * TNW + 3) / 4];        // this wave's weight tiles t = wave, wave + 4, ...: pointer to the block of the NEXT chunk
+#pragma unroll
+  for (int q = 0; q < (2 * TNW + 3) / 4; ++q)
+    wpt[q] = a.wp + ((size_t)min(tile_n0 + wave + 4 * q, n_tiles - 1) * kc_total) * 256 + (size_t)lane * 4;
+#define SQ_BIG_STAGE(G, BUF)                                                                                         \
+  {                                                                                                                  \
+    const int g = (G);                                                                                               \
+    if (g >= seg_end) { /* next segment (wave-uniform) */                                                            \
+      ++seg_i;                                                                                                       \
+      const float* sp = seg_i == 0 ? sp0 : (seg_i == 1 ? sp1 : (seg_i == 2 ? sp2 : sp3));                             \
+      const int sl = seg_i == 0 ? sl0 : (seg_i == 1 ? sl1 : (seg_i == 2 ? sl2 : sl3));                                \
+      const unsigned sm = seg_i == 0 ? sm0 : (seg_i == 1 ? sm1 : (seg_i == 2 ? sm2 : sm3));                           \
+      const int sw = seg_i == 0 ? w0 : (seg_i == 1 ? w1 : (seg_i == 2 ? w2 : w3));                                    \
+      seg_c0 = seg_end; seg_end += (sw + 15) >> 4; seg_lim = ((sw + 3) & ~3) - 4;                                     \
+      pa = sp + (size_t)(sm ? (int)__umulhi((unsigned)arow_a, sm) : arow_a) * sl;                                     \
+      pb = sp + (size_t)(sm ? (int)__umulhi((unsigned)arow_b, sm) : arow_b) * sl;                                     \
+    }                                                                                                                \
+    const int kk = min((g - seg_c0) * 16 + sq4, seg_lim);                                                            \
+    char* st = lds + (BUF) * STAGE;                                                                                   \
+    __builtin_amdgcn_global_load_lds((glb_ptr)(pa + kk), (lds_ptr)(st + (2 * wave) * 1024), 16, 0, 0);               \
+    __builtin_amdgcn_global_load_lds((glb_ptr)(pb + kk), (lds_ptr)(st + (2 * wave + 1) * 1024), 16, 0, 0);           \
+    _Pragma("unroll") for (int q = 0; q < (2 * TNW + 3) / 4; ++q)                                                     \
+      if (wave + 4 * q < 2 * TNW) {                                                                                   \
+        __builtin_amdgcn_global_load_lds((glb_ptr)wpt[q], (lds_ptr)(st + A_BYTES + (wave + 4 * q) * 1024), 16, 0, 0); \
+        wpt[q] += 256;                                                                                                \
+      }                                                                                                               \
+  }
+
+  f32x4 acc[4][TNW];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) acc[i][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  // fragment read offsets (bytes inside a stage): activation row (64 wave_m + 16 i + l15), slot kq ^ ((l15 >> 1) & 3)
+  const int a_off = (64 * wave_m + l15) * 64 + ((kq ^ ((l15 >> 1) & 3)) * 16);
+  const int b_off = A_BYTES + wave_n * TNW * 1024 + lane * 16;
+  SQ_BIG_STAMP(1)
+  SQ_BIG_STAGE(0, 0)
+  __syncthreads();
+  SQ_BIG_STAMP(2)
+#pragma unroll 1
+  for (int c = 0; c < kc_total; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < kc_total) SQ_BIG_STAGE(c + 1, buf ^ 1)
+    const char* st = lds + buf * STAGE;
+    f32x4 af[4], bv[TNW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + a_off + i * 1024);
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) bv[t] = *reinterpret_cast<const f32x4*>(st + b_off + t * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < TNW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].x, af[i].x, acc[i][t], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < TNW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].y, af[i].y, acc[i][t], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < TNW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].z, af[i].z, acc[i][t], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < TNW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].w, af[i].w, acc[i][t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise hoists the barrier into the middle of the chunk's MFMAs: half the time for the loads)
+    __syncthreads();   // retires the loads of chunk c + 1 (vmcnt(0) precedes the barrier) and the reads of chunk c
+  }
+#undef SQ_BIG_STAGE
+  SQ_BIG_STAMP(3)
+  // Epilogue.  The MFMAs above take the WEIGHT fragment as their first operand and the activation fragment as the second, i.e.
+  // they compute the transposed tile: lane (kq, l15) of accumulator (i, t) holds C[row 16 i + l15][columns 16 t + 4 kq .. + 3]
+  // -- four CONSECUTIVE COLUMNS of one row (the products commute and k is summed in the same order: bit-identical sums).  So
+  // every lane owns whole 16-byte pieces of output rows: 16-byte bias / addend loads and output stores, no transposition.
+  // What remains is code size: a kernel starts with a cold instruction cache (~1.5 ns per byte of
+  // straight-line code executed once), and 16 unrolled copies of the epilogue of one accumulator are ~6 KB.  The accumulators
+  // of two row tiles at a time are therefore parked in LDS -- each lane its own 16 bytes per accumulator, read back by the
+  // same lane: an indexable register file, no conflicts, no barrier -- and ONE rolled loop body handles all of them.
+  sq_f32x4* park = reinterpret_cast<sq_f32x4*>(lds) + wave * ((2 * TNW + TNW) * 64) + lane;   // [2 TNW sums + TNW biases][64 lanes]
+  float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : a.bias);
+  p_scale = a.scale_ptr != nullptr ? p_scale : 1.0f;
+  const int wtile_n0 = tile_n0 + wave_n * TNW;
+  const int nq = wtile_n0 * 16 + 4 * kq;            // column of this lane's float4 in column tile 0 of the wave
+#pragma unroll
+  for (int t = 0; t < TNW; ++t)                     // (the packed bias is padded to whole tiles)
+    park[(2 * TNW + t) * 64] = *reinterpret_cast<const sq_f32x4*>(a.bias + (size_t)min(wtile_n0 + t, n_tiles - 1) * 16 + 4 * kq);
+  // fast path (wave-uniform): plain activation layer, one activation code, every float4 inside the tensor, 16-byte aligned rows
+  const bool fast = a.epi == EPI_ACT && vec_ok != 0 && a.act_split >= a.N && (a.N & 3) == 0 &&
+                    (a.add == nullptr || ((a.add_n & 3) == 0 && a.add_rmul == 0));
+  const float sc = a.scale * p_scale;
+  const int act = a.act_a;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int t = 0; t < TNW; ++t) park[(ii * TNW + t) * 64] = acc[2 * half + ii][t];
+    if (half == 0) { SQ_BIG_STAMP(5) }
+    if (half == 1) { SQ_BIG_STAMP(6) }
+    const int mh = row0 + wave_m * 64 + half * 32 + l15;
+    // (TNW accumulators per trip: a lone wave stalls on every LDS / address / store latency of a one-accumulator body --
+    // measured 0.23 us per accumulator with an identity activation -- so the trip carries TNW independent chains)
+#pragma unroll 1
+    for (int ii = 0; ii < 2; ++ii) {
+      const int m = mh + ii * 16;
+      sq_f32x4 v[TNW], b4[TNW];
+#pragma unroll
+      for (int t = 0; t < TNW; ++t) { v[t] = park[(ii * TNW + t) * 64]; b4[t] = park[(2 * TNW + t) * 64]; }
+      if (m < a.M) {
+        if (fast) {
+          float* orow = a.out + (size_t)m * a.out_ld;
+          const float* arow = a.add + (size_t)m * a.add_ld;
+          sq_f32x4 x[TNW];
+#pragma unroll
+          for (int t = 0; t < TNW; ++t) {
+            x[t] = v[t] + b4[t];
+            if (a.add != nullptr && nq + t * 16 < a.add_n) x[t] += *reinterpret_cast<const sq_f32x4*>(arow + nq + t * 16);
+          }
+          switch (act) {   // scalar branch on a kernel argument
+            case ACT_ELU: _Pragma("unroll") for (int t = 0; t < TNW; ++t) x[t] = sq_f32x4{sq_elu(x[t].x), sq_elu(x[t].y), sq_elu(x[t].z), sq_elu(x[t].w)}; break;
+            case ACT_TANH: _Pragma("unroll") for (int t = 0; t < TNW; ++t) x[t] = sq_f32x4{sq_tanh(x[t].x), sq_tanh(x[t].y), sq_tanh(x[t].z), sq_tanh(x[t].w)}; break;
+            case ACT_SIGMOID: _Pragma("unroll") for (int t = 0; t < TNW; ++t) x[t] = sq_f32x4{sq_sigmoid(x[t].x), sq_sigmoid(x[t].y), sq_sigmoid(x[t].z), sq_sigmoid(x[t].w)}; break;
+            case ACT_SOFTPLUS_MIN: _Pragma("unroll") for (int t = 0; t < TNW; ++t) x[t] = sq_f32x4{sq_softplus(x[t].x), sq_softplus(x[t].y), sq_softplus(x[t].z), sq_softplus(x[t].w)} + 1e-2f; break;
+            default: break;
+          }
+#pragma unroll
+          for (int t = 0; t < TNW; ++t)
+            if (nq + t * 16 < a.N) *reinterpret_cast<sq_f32x4*>(orow + nq + t * 16) = x[t] * sc;
+        } else {
+#pragma unroll 1
+          for (int t = 0; t < TNW; ++t)
+            if (nq + t * 16 < a.N) x_epilogue4(a, m, nq + t * 16, park[(ii * TNW + t) * 64], park[(2 * TNW + t) * 64], p_scale, vec_ok != 0);
+        }
+      }
+    }
+  }
+  SQ_BIG_STAMP(4)
+}
+#ifdef SQAIR_KNOBS
+extern "C" int sqair_debug_big_phases(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sq_big_phase), sizeof(unsigned long long) * 8);
+}
+#endif
+template <int TNW>
+static void launch_big(const LinArgs& a, const PackedLayer& L, hipStream_t s) {
+  const int n_colblk = (L.nt + 2 * TNW - 1) / (2 * TNW), n_rowblk = (a.M + 127) / 128;
+  const int total = n_colblk * n_rowblk;
+  // 16-byte epilogue accesses need 16-byte aligned rows in every tensor the epilogue touches
+  auto al = [](const void* p, int ld) { return p == nullptr || (((uintptr_t)p & 15) == 0 && (ld & 3) == 0); };
+  const int vec = al(a.out, a.out_ld) && al(a.add, a.add_ld) && al(a.e0, a.e0_ld) && al(a.e1, a.e1_ld) && al(a.o1, a.o1_ld) &&
+                  al(a.o2, a.o2_ld) && al(a.o3, a.o3_ld) && (a.epi == EPI_ACT || (a.nh & 3) == 0);
+  SQ_LAUNCH((k_linear_big<TNW>), dim3(8 * ((total + 7) / 8)), dim3(256), 0, s, a, L.kc, L.nt, n_colblk, total, vec);
+}
+
 // Tile shape of the throughput variants, from measurements of the layer shapes of the pass (tools/time_linear.py, MI355X):
 // slabs per wave (1 or 2; two ROW tiles per wave -- template parameter MT = 2 -- measured slower on every shape of the pass and is
 // not instantiated) and whether the A fragment is loaded row-contiguously (COAL).  SQAIR_MT="1,NT[,COAL]" overrides.
@@ -615,6 +838,15 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
     }
     // the LDS-tiled kernel pays once its 128 x 64 workgroup tiles fill the chip twice over (measured, tools/time_linear.py:
     // 51200 x 256 x 256 118 -> 106 us, 5120 x 362 x 1152 80 -> 67 us; below that the macro-tile kernel's smaller tiles win)
+    // both operands through LDS (k_linear_big): ahead of the two kernels below on every shape of the pass with >= 4 column
+    // tiles (tools/time_linear.py, back to back: 5120 x 362 x 1152 70 -> 52 us, 51200 x 256 x 256 113 -> 88, 6400 x 256 x 400
+    // 28 -> 25, 5120 x 256 x 256 18 -> 17.4); the 128 x 64 tile (TNW = 2) beats 128 x 128 wherever the tile count is what
+    // limits (all of these shapes: 80 - 1600 tiles on 256 CUs)
+    static const int big = SQ_KNOB_INT("SQAIR_BIG", 2);  // measurement knob: 0 = off, 2 / 4 = forced TNW
+    if (big > 0 && prof_ts == nullptr && L.nt >= 4) {
+      if (big == 4) launch_big<4>(a, L, s); else launch_big<2>(a, L, s);
+      return 0;
+    }
     static const int lds_wgs = SQ_KNOB_INT("SQAIR_LDS_WGS", 512);  // measurement knob
     if (((a.M + 127) / 128) * ((L.nt + 3) / 4) >= lds_wgs) {
       SQ_LAUNCH((k_linear_lds<2>), dim3((L.nt + 3) / 4, (a.M + 127) / 128), dim3(256), 0, s, a, L.kc, L.nt, prof_ts);

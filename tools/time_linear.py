@@ -18,7 +18,7 @@ SHAPES = [(640, 362, 1152, 0), (640, 312, 768, 0), (640, 400, 256, 1), (6400, 56
 
 def main():
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or SHAPES
-    lib = _capi.lib()
+    lib = _capi.lib(__import__('os').environ.get('SQAIR_TOOL_LIB'))  # tools may point at the -DSQAIR_KNOBS build (tools/bin/libsqair_hip_knobs.so)
     h = C.c_void_p()
     cfg = make_config(make_flags(), (50, 50))
     assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
@@ -41,6 +41,13 @@ def main():
         fl = 2.0 * M * K * N
         print("M=%-6d K=%-5d N=%-5d act=%d : %8.2f us  %6.1f TFLOP/s (%.2f of 157.3)  max err %.1e" % (
             M, K, N, act, us.value, fl / us.value / 1e6, fl / us.value / 1e6 / 157.3, err))
+        if hasattr(lib, "sqair_debug_big_phases"):   # knob builds: phase stamps of one workgroup of k_linear_big (10 ns ticks)
+            ph = (C.c_uint64 * 8)()
+            torch.cuda.synchronize()
+            if lib.sqair_debug_big_phases(ph) == 0 and ph[4] > ph[0]:
+                t = [ph[i] - ph[0] for i in range(5)]
+                print("   k_linear_big phases of one workgroup [us]: setup %.2f | first loads %.2f | K loop %.2f | epilogue %.2f (park tile 0 at +%.2f, tile 1 at +%.2f)" % (
+                    t[1] * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (ph[5] - ph[3]) * 0.01, (ph[6] - ph[3]) * 0.01))
     lib.sqair_destroy(h)
 
 
