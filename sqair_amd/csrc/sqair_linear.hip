@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
   SQ_TL_SCOPE;
   SQ_BIG_STAMP(0)
   constexpr int A_BYTES = 128 * 16 * 4, B_BYTES = 2 * TNW * 1024, STAGE = A_BYTES + B_BYTES;
-  constexpr int PARK = 4 * (3 * TNW) * 1024;   // epilogue: per wave 2 TNW parked accumulators + TNW biases, 16 bytes per lane each
+  constexpr int PARK = 4 * (2 * TNW) * 1024;   // epilogue: per wave 2 TNW parked accumulators, 16 bytes per lane each
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE > PARK ? 2 * STAGE : PARK];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -679,14 +679,14 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
   // straight-line code executed once), and 16 unrolled copies of the epilogue of one accumulator are ~6 KB.  The accumulators
   // of two row tiles at a time are therefore parked in LDS -- each lane its own 16 bytes per accumulator, read back by the
   // same lane: an indexable register file, no conflicts, no barrier -- and ONE rolled loop body handles all of them.
-  sq_f32x4* park = reinterpret_cast<sq_f32x4*>(lds) + wave * ((2 * TNW + TNW) * 64) + lane;   // [2 TNW sums + TNW biases][64 lanes]
+  sq_f32x4* park = reinterpret_cast<sq_f32x4*>(lds) + wave * (2 * TNW * 64) + lane;   // [2 TNW sums][64 lanes]
   float p_scale = *(a.scale_ptr != nullptr ? a.scale_ptr : a.bias);
   p_scale = a.scale_ptr != nullptr ? p_scale : 1.0f;
   const int wtile_n0 = tile_n0 + wave_n * TNW;
   const int nq = wtile_n0 * 16 + 4 * kq;            // column of this lane's float4 in column tile 0 of the wave
+  sq_f32x4 b4[TNW];                                 // this lane's biases (the packed bias is padded to whole tiles)
 #pragma unroll
-  for (int t = 0; t < TNW; ++t)                     // (the packed bias is padded to whole tiles)
-    park[(2 * TNW + t) * 64] = *reinterpret_cast<const sq_f32x4*>(a.bias + (size_t)min(wtile_n0 + t, n_tiles - 1) * 16 + 4 * kq);
+  for (int t = 0; t < TNW; ++t) b4[t] = *reinterpret_cast<const sq_f32x4*>(a.bias + (size_t)min(wtile_n0 + t, n_tiles - 1) * 16 + 4 * kq);
   // fast path (wave-uniform): plain activation layer, one activation code, every float4 inside the tensor, 16-byte aligned rows
   const bool fast = a.epi == EPI_ACT && vec_ok != 0 && a.act_split >= a.N && (a.N & 3) == 0 &&
                     (a.add == nullptr || ((a.add_n & 3) == 0 && a.add_rmul == 0));
@@ -706,9 +706,9 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
 #pragma unroll 1
     for (int ii = 0; ii < 2; ++ii) {
       const int m = mh + ii * 16;
-      sq_f32x4 v[TNW], b4[TNW];
+      sq_f32x4 v[TNW];
 #pragma unroll
-      for (int t = 0; t < TNW; ++t) { v[t] = park[(ii * TNW + t) * 64]; b4[t] = park[(2 * TNW + t) * 64]; }
+      for (int t = 0; t < TNW; ++t) v[t] = park[(ii * TNW + t) * 64];
       if (m < a.M) {
         if (fast) {
           float* orow = a.out + (size_t)m * a.out_ld;
@@ -730,9 +730,9 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
           for (int t = 0; t < TNW; ++t)
             if (nq + t * 16 < a.N) *reinterpret_cast<sq_f32x4*>(orow + nq + t * 16) = x[t] * sc;
         } else {
-#pragma unroll 1
+#pragma unroll
           for (int t = 0; t < TNW; ++t)
-            if (nq + t * 16 < a.N) x_epilogue4(a, m, nq + t * 16, park[(ii * TNW + t) * 64], park[(2 * TNW + t) * 64], p_scale, vec_ok != 0);
+            if (nq + t * 16 < a.N) x_epilogue4(a, m, nq + t * 16, v[t], b4[t], p_scale, vec_ok != 0);
         }
       }
     }
@@ -752,6 +752,9 @@ static void launch_big(const LinArgs& a, const PackedLayer& L, hipStream_t s) {
   auto al = [](const void* p, int ld) { return p == nullptr || (((uintptr_t)p & 15) == 0 && (ld & 3) == 0); };
   const int vec = al(a.out, a.out_ld) && al(a.add, a.add_ld) && al(a.e0, a.e0_ld) && al(a.e1, a.e1_ld) && al(a.o1, a.o1_ld) &&
                   al(a.o2, a.o2_ld) && al(a.o3, a.o3_ld) && (a.epi == EPI_ACT || (a.nh & 3) == 0);
+  // (measured and dropped: starting the workgroups in odd hardware wave slots half a CU-load of matrix work late, so that their
+  // K loops cover the others' epilogues -- 51200 x 256 x 256: 91 -> 84 us at half the computed delay with the 128 x 64 tile,
+  // slower in every other combination tried)
   SQ_LAUNCH((k_linear_big<TNW>), dim3(8 * ((total + 7) / 8)), dim3(256), 0, s, a, L.kc, L.nt, n_colblk, total, vec);
 }
 
