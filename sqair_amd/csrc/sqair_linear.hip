@@ -532,6 +532,20 @@ __global__ __launch_bounds__(256) void k_linear_lds(const LinArgs a, const int k
   }
 }
 
+#define SQ_T2_NAME k_linear_t2
+#include "sqair_linear_t2.inc"
+#undef SQ_T2_NAME
+template <int NB>
+static void launch_t2(const LinArgs& a, const PackedLayer& L, hipStream_t s) {
+  const dim3 g((L.nt + 1) / 2, (a.M + 31) / 32);
+  switch (a.nseg) {
+    case 1: SQ_LAUNCH((k_linear_t2<NB, 1>), g, dim3(256), 0, s, a, L.kc, L.nt); break;
+    case 2: SQ_LAUNCH((k_linear_t2<NB, 2>), g, dim3(256), 0, s, a, L.kc, L.nt); break;
+    case 3: SQ_LAUNCH((k_linear_t2<NB, 3>), g, dim3(256), 0, s, a, L.kc, L.nt); break;
+    default: SQ_LAUNCH((k_linear_t2<NB, 4>), g, dim3(256), 0, s, a, L.kc, L.nt); break;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Large-row throughput kernel (launches with thousands of rows whose tiles fill the chip: the once-per-frame layers from ~128
 // sequences per GPU up, the decoder, cfg-4): BOTH operands through LDS.
@@ -861,6 +875,15 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
     return 0;
   }
   const int per_wave = (L.kc + 3) / 4;
+  // hundreds of rows, several column tiles and a DEEP K (>= 640: the input encoder; in the backward pass the transposes of the
+  // wide once-per-frame layers): 32 x 32 tiles with two blocks of operand loads in flight (sqair_linear_t2.inc).  Measured
+  // back to back (tools/time_linear.py): 640 x 1152 x 384 17.9 -> 12.1 us, 640 x 768 x 320 17.3 -> 8.8; at K <= 400 the
+  // 16 x 16 tile is as fast or faster (640 x 362 x 1152 13.6 / 13.2, 640 x 312 x 768 8.6 / 9.5) and keeps those layers
+  static const int t2_rows = SQ_KNOB_INT("SQAIR_T2_ROWS", 512), t2_kc = SQ_KNOB_INT("SQAIR_T2_KC", 40);  // measurement knobs
+  if (a.M >= t2_rows && L.nt >= 4 && L.kc >= t2_kc && prof_ts == nullptr) {
+    if (per_wave <= 2) launch_t2<2>(a, L, s); else if (per_wave <= 3 || per_wave == 5 || per_wave == 6) launch_t2<3>(a, L, s); else launch_t2<4>(a, L, s);
+    return 0;
+  }
   switch (per_wave) {
     case 1: launch_nch<1>(a, L, grid, s, prof_ts); break;
     case 2: launch_nch<2>(a, L, grid, s, prof_ts); break;

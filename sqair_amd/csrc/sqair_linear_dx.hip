@@ -139,6 +139,12 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
   }
 }
 
+#define SQ_T2_NAME k_linear_dx_t2
+#define SQ_T2_DX 1
+#include "sqair_linear_t2.inc"
+#undef SQ_T2_DX
+#undef SQ_T2_NAME
+
 int sq_launch_linear_dx(const DxArgs& a, int kc, int nt, hipStream_t s) {
   if ((reinterpret_cast<uintptr_t>(a.dpre) & 15) != 0 || (a.ld & 3) != 0 || a.width < 1 || a.nranges < 1 || a.nranges > 3) return -5;
   for (int i = 0; i < a.nranges; ++i)
@@ -151,6 +157,15 @@ int sq_launch_linear_dx(const DxArgs& a, int kc, int nt, hipStream_t s) {
 #define SQ_DXG(G) SQ_LAUNCH((k_linear_dx<4, G>), g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a)
     if (a.gru.mode == 1) SQ_DXG(1); else SQ_DXG(2);
 #undef SQ_DXG
+    return 0;
+  }
+  // hundreds of rows and several column tiles (the transposes of the once-per-frame layers): 32 x 32 tiles (sqair_linear_t2.inc)
+  static const int t2_rows = SQ_KNOB_INT("SQAIR_T2_ROWS", 512), t2_kc = SQ_KNOB_INT("SQAIR_T2_KC", 40);  // measurement knobs
+  if (a.M >= t2_rows && nt >= 4 && kc >= t2_kc) {
+    const dim3 g2((nt + 1) / 2, (a.M + 31) / 32);
+    if (per_wave <= 2) SQ_LAUNCH((k_linear_dx_t2<2>), g2, dim3(256), 0, s, a, kc, nt);
+    else if (per_wave <= 3 || per_wave == 5 || per_wave == 6) SQ_LAUNCH((k_linear_dx_t2<3>), g2, dim3(256), 0, s, a, kc, nt);
+    else SQ_LAUNCH((k_linear_dx_t2<4>), g2, dim3(256), 0, s, a, kc, nt);
     return 0;
   }
   switch (per_wave) {
