@@ -115,9 +115,12 @@ extern "C" int sqair_st_crop_bwd(SqairHandle* h, const float* img, const float* 
 // ------------------------------------------------------------------------------------------------
 // insert + log-likelihood backward.  One workgroup per row b'.  Pass over the canvas pixels exactly like
 // the forward kernel; per pixel the scalar adjoints g_cv (canvas) and g_ms (written-to mask sum) are pushed
-// back into (a) the N glimpses — LDS float atomics on a tile that is written out once, (b) the inverse-warp
-// coordinates -> 4 reductions per slot, (c) the mean image (per-row contribution, summed over rows by a
-// second tiny kernel so that the result is deterministic).
+// back into (a) the inverse-warp coordinates -> 4 reductions per slot, (b) the mean image (per-row contribution,
+// summed over rows by a second tiny kernel), and g_cv is kept in LDS; (c) the N glimpses are then GATHERED:
+// texel (gy, gx) of slot k sums g_cv over the canvas pixels whose bilinear footprint contains it,
+// |xg(X) - gx| < 1 and |yg(Y) - gy| < 1, with weight (1 - |xg - gx|)(1 - |yg - gy|) -- the transpose of the
+// forward's two-tap interpolation, separable, deterministic.  (Until round 3 the pixels SCATTERED into an LDS
+// tile with float atomics: neighbouring pixels hit the same texel, the atomics serialised -- 108 us per step.)
 // ------------------------------------------------------------------------------------------------
 struct InsertBwdArgs {
   const float* glimpse;      // [R,N,G2]
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.N, G = d.G, G2 = d.G * d.G, H = d.H, W = d.W, P = d.H * d.W;
   float* gl_s = smem;                 // N * G2   glimpses
-  float* dg_s = gl_s + N * G2;        // N * G2   glimpse gradients
-  float* xt_s = dg_s + N * G2;        // N * W
+  float* gcv_s = gl_s + N * G2;       // P        canvas adjoint per pixel
+  float* xt_s = gcv_s + P;            // N * W
   float* yt_s = xt_s + N * W;         // N * H
   float* pres_s = yt_s + N * H;       // N
   float* co_s = pres_s + N;           // N * 4  (sx, sy, tx, ty)
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   const int b = r / d.K;
   const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot-row of this (frame, row)
   const size_t frr = (size_t)fr * d.R + r;
-  for (int i = tid; i < N * G2; i += 256) { gl_s[i] = a.glimpse[fs * G2 + i]; dg_s[i] = 0.0f; }
+  for (int i = tid; i < N * G2; i += 256) gl_s[i] = a.glimpse[fs * G2 + i];
   if (tid < N * 4) {
     const int k = tid >> 2, c = tid & 3;
     const float l = a.rec ? a.rec[(fs + k) * a.rec_ld + rec::WHERE + c] : a.where[fs * 4 + tid];
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
     const float g_m = g_cv * mean + g_sd * (a.std_fg - a.std_bg);
     const float g_ms = g_m * 20.0f * m * (1.0f - m);
     a.d_mean_rows[frr * P + pix] = g_cv * m;
+    gcv_s[pix] = g_cv;
     for (int k = 0; k < N; ++k) {
       const float pk = pres_s[k];
       if (pk == 0.0f) continue;
@@ -236,10 +240,6 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
           const bool ok = yy >= 0 && yy < G && xx >= 0 && xx < G;
           vl[dy][dx] = ok ? 1.0f : 0.0f;
           t[dy][dx] = ok ? gk[yy * G + xx] : 0.0f;
-          if (ok) {
-            const float w = (dy ? wy1 : 1.0f - wy1) * (dx ? wx1 : 1.0f - wx1);
-            atomicAdd(&dg_s[k * G2 + yy * G + xx], g_cv * pk * w);
-          }
         }
       // d/d xg, d/d yg of (g_cv * bilinear(glimpse) + g_ms * bilinear(ones))
       const float dvdx = (1.0f - wy1) * (t[0][1] - t[0][0]) + wy1 * (t[1][1] - t[1][0]);
@@ -262,7 +262,36 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
       if (lane == 0) acc_s[(wave * N + k) * 4 + c] = v;
     }
   __syncthreads();
-  for (int i = tid; i < N * G2; i += 256) a.d_glimpse[fs * G2 + i] = dg_s[i];
+  // ---- glimpse gradient by gathering (see the header): texel i = (k, gy, gx)
+  {
+    const float fw = 0.5f * (float)(W - 1), fh = 0.5f * (float)(H - 1);
+    for (int i = tid; i < N * G2; i += 256) {
+      const int k = i / G2, q = i - k * G2, gy = q / G, gx = q - gy * G;
+      const float pk = pres_s[k];
+      float acc = 0.0f;
+      if (pk != 0.0f) {
+        const float sx = co_s[k * 4 + 0], sy = co_s[k * 4 + 1], tx = co_s[k * 4 + 2], ty = co_s[k * 4 + 3];
+        // pixel range whose glimpse coordinate lies within one texel of (gx, gy): xg is increasing in X (sx > 0); one pixel of
+        // slack either side, the exact test |xg - gx| < 1 decides on the same table values the per-pixel pass used
+        const int X0 = max(0, (int)floorf(fw * (sx * (((float)gx - 1.0f) / hg - 1.0f) + tx + 1.0f)) - 1);
+        const int X1 = min(W - 1, (int)ceilf(fw * (sx * (((float)gx + 1.0f) / hg - 1.0f) + tx + 1.0f)) + 1);
+        const int Y0 = max(0, (int)floorf(fh * (sy * (((float)gy - 1.0f) / hg - 1.0f) + ty + 1.0f)) - 1);
+        const int Y1 = min(H - 1, (int)ceilf(fh * (sy * (((float)gy + 1.0f) / hg - 1.0f) + ty + 1.0f)) + 1);
+        for (int Y = Y0; Y <= Y1; ++Y) {
+          const float wy = 1.0f - fabsf(yt_s[k * H + Y] - (float)gy);
+          if (!(wy > 0.0f)) continue;
+          float rowsum = 0.0f;
+          for (int X = X0; X <= X1; ++X) {
+            const float wx = 1.0f - fabsf(xt_s[k * W + X] - (float)gx);
+            if (wx > 0.0f) rowsum += wx * gcv_s[Y * W + X];
+          }
+          acc += wy * rowsum;
+        }
+        acc *= pk;
+      }
+      a.d_glimpse[fs * G2 + i] = acc;
+    }
+  }
   if (tid < N * 4) {
     const int k = tid >> 2, c = tid & 3;
     const float tot = acc_s[(0 * N + k) * 4 + c] + acc_s[(1 * N + k) * 4 + c] + acc_s[(2 * N + k) * 4 + c] + acc_s[(3 * N + k) * 4 + c];
@@ -272,6 +301,17 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   }
 }
 
+// dynamic LDS of k_insert_loglik_bwd: glimpses, the canvas adjoint, coordinate tables, presences, coordinates, wave partials
+static size_t insert_bwd_lds(const Dims& d) {
+  const size_t bytes = ((size_t)d.N * d.G * d.G + (size_t)d.H * d.W + (size_t)d.N * (d.W + d.H) + d.N + d.N * 4 + 4 * d.N * 4) * sizeof(float);
+  static bool big = false;
+  if (bytes > 48 * 1024 && !big) {
+    (void)hipFuncSetAttribute((const void*)k_insert_loglik_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipGetLastError();
+    big = true;
+  }
+  return bytes;
+}
 __global__ void k_reduce_rows(const float* __restrict__ rows, float* __restrict__ out, int R, int P, int accumulate SQ_TLP) {
   SQ_TL_SCOPE;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -305,7 +345,7 @@ extern "C" int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, 
   if (scratch_bytes < (int64_t)d.R * P * 4) return -1;
   InsertBwdArgs a{glimpse, where_logits, presence, img, mean_img, g_data_ll, d_glimpse, d_where_logits, (float*)scratch,
                   c.output_std, c.background_std, nullptr, 0, 4};
-  const size_t shm = ((size_t)2 * d.N * d.G * d.G + (size_t)d.N * (d.W + d.H) + d.N + d.N * 4 + 4 * d.N * 4) * sizeof(float);
+  const size_t shm = insert_bwd_lds(d);
   SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, 1), dim3(256), shm, (hipStream_t)stream, a, d);
   SQ_LAUNCH(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch,
                      d_mean_img, d.R, P, 0);
@@ -626,7 +666,7 @@ int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_
                                 float std_fg, float std_bg, int T, Dims d, hipStream_t s) {
   InsertBwdArgs a{glimpse, nullptr, nullptr, img, mean_img, g_ll, d_glimpse, d_rec, d_mean_rows, std_fg, std_bg, rec, rec_ld,
                   d_rec_ld};
-  const size_t shm = ((size_t)2 * d.N * d.G * d.G + (size_t)d.N * (d.W + d.H) + d.N + d.N * 4 + 4 * d.N * 4) * sizeof(float);
+  const size_t shm = insert_bwd_lds(d);
   SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, T), dim3(256), shm, s, a, d);
   return 0;
 }
