@@ -535,15 +535,22 @@ __global__ __launch_bounds__(256) void k_linear_lds(const LinArgs a, const int k
 #define SQ_T2_NAME k_linear_t2
 #include "sqair_linear_t2.inc"
 #undef SQ_T2_NAME
-template <int NB>
+template <int NB, int NW>
 static void launch_t2(const LinArgs& a, const PackedLayer& L, hipStream_t s) {
   const dim3 g((L.nt + 1) / 2, (a.M + 31) / 32);
   switch (a.nseg) {
-    case 1: SQ_LAUNCH((k_linear_t2<NB, 1>), g, dim3(256), 0, s, a, L.kc, L.nt); break;
-    case 2: SQ_LAUNCH((k_linear_t2<NB, 2>), g, dim3(256), 0, s, a, L.kc, L.nt); break;
-    case 3: SQ_LAUNCH((k_linear_t2<NB, 3>), g, dim3(256), 0, s, a, L.kc, L.nt); break;
-    default: SQ_LAUNCH((k_linear_t2<NB, 4>), g, dim3(256), 0, s, a, L.kc, L.nt); break;
+    case 1: SQ_LAUNCH((k_linear_t2<NB, 1, NW>), g, dim3(64 * NW), 0, s, a, L.kc, L.nt); break;
+    case 2: SQ_LAUNCH((k_linear_t2<NB, 2, NW>), g, dim3(64 * NW), 0, s, a, L.kc, L.nt); break;
+    case 3: SQ_LAUNCH((k_linear_t2<NB, 3, NW>), g, dim3(64 * NW), 0, s, a, L.kc, L.nt); break;
+    default: SQ_LAUNCH((k_linear_t2<NB, 4, NW>), g, dim3(64 * NW), 0, s, a, L.kc, L.nt); break;
   }
+}
+// 4 waves per tile; operand blocks of NB chunks, two in flight.  (NW = 8 / 16 waves per tile -- one block per wave, no serial
+// chain of round trips -- measured SLOWER: 640 x 1152 x 384 12.1 -> 30.9 us with 16 waves.  The launch is bound by what the
+// memory system delivers to scattered 64-byte row pieces, and more waves in flight only lengthen every round trip.)
+static void launch_t2_any(const LinArgs& a, const PackedLayer& L, hipStream_t s) {
+  const int per = (L.kc + 3) / 4;
+  if (per <= 2) launch_t2<2, 4>(a, L, s); else if (per <= 3 || per == 5 || per == 6) launch_t2<3, 4>(a, L, s); else launch_t2<4, 4>(a, L, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -881,7 +888,7 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
   // 16 x 16 tile is as fast or faster (640 x 362 x 1152 13.6 / 13.2, 640 x 312 x 768 8.6 / 9.5) and keeps those layers
   static const int t2_rows = SQ_KNOB_INT("SQAIR_T2_ROWS", 512), t2_kc = SQ_KNOB_INT("SQAIR_T2_KC", 40);  // measurement knobs
   if (a.M >= t2_rows && L.nt >= 4 && L.kc >= t2_kc && prof_ts == nullptr) {
-    if (per_wave <= 2) launch_t2<2>(a, L, s); else if (per_wave <= 3 || per_wave == 5 || per_wave == 6) launch_t2<3>(a, L, s); else launch_t2<4>(a, L, s);
+    launch_t2_any(a, L, s);
     return 0;
   }
   switch (per_wave) {

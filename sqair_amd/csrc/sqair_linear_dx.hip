@@ -163,9 +163,9 @@ int sq_launch_linear_dx(const DxArgs& a, int kc, int nt, hipStream_t s) {
   static const int t2_rows = SQ_KNOB_INT("SQAIR_T2_ROWS", 512), t2_kc = SQ_KNOB_INT("SQAIR_T2_KC", 40);  // measurement knobs
   if (a.M >= t2_rows && nt >= 4 && kc >= t2_kc) {
     const dim3 g2((nt + 1) / 2, (a.M + 31) / 32);
-    if (per_wave <= 2) SQ_LAUNCH((k_linear_dx_t2<2>), g2, dim3(256), 0, s, a, kc, nt);
-    else if (per_wave <= 3 || per_wave == 5 || per_wave == 6) SQ_LAUNCH((k_linear_dx_t2<3>), g2, dim3(256), 0, s, a, kc, nt);
-    else SQ_LAUNCH((k_linear_dx_t2<4>), g2, dim3(256), 0, s, a, kc, nt);
+#define SQ_DXT2(NB, NW) SQ_LAUNCH((k_linear_dx_t2<NB, NW>), g2, dim3(64 * NW), 0, s, a, kc, nt)
+    if (per_wave <= 2) SQ_DXT2(2, 4); else if (per_wave <= 3 || per_wave == 5 || per_wave == 6) SQ_DXT2(3, 4); else SQ_DXT2(4, 4);
+#undef SQ_DXT2
     return 0;
   }
   switch (per_wave) {
