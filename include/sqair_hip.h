@@ -164,23 +164,6 @@ int sqair_graph_capture(SqairHandle* h, const float* flat_params, const void* pa
 int sqair_graph_launch(SqairHandle* h, void* stream);
 int sqair_graph_nodes(const SqairHandle* h); /* kernel nodes in the captured graph */
 
-/* Eager forward in which every dense-layer launch (k_linear, the dominant kernel) stamps its first-workgroup
- * start and last-workgroup end with the 100 MHz device wall clock; one HIP-event pair brackets the pass.
- * Outputs: summed k_linear time [ms], number of launches, FLOPs those launches executed (2 M K N, true dims),
- * and the HIP-event time of the whole eager pass [ms].  bench.py's roofline line. */
-int sqair_profile_forward(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
-                          const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
-                          void* workspace, int64_t workspace_bytes, void* stream, double* linear_ms,
-                          int* linear_launches, double* linear_flops, double* forward_ms_events);
-
-/* The dense launches of one pass, and only they, captured as a HIP graph and replayed `replays` times between two HIP
- * events on `stream`: *ms_per_replay / *launches is the average dense-launch duration including the dependent kernel
- * boundary (what a per-dispatch profiler reports), measured without a profiler attached.  The workspace must have been
- * used by a real pass of the same shape before (the dense kernels read what that pass left behind). */
-int sqair_profile_linear_graph(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
-                               const float* noise, int T, int B, int t_offset, const SqairOutputs* out, void* workspace,
-                               int64_t workspace_bytes, void* stream, int replays, double* ms_per_replay, int* launches);
-
 /* ---- objective ---------------------------------------------------------------------------------
  * Fused IWAE / VIMCO reductions over [T,B,K] (reference: Model._build sqair/model.py:88-103,
  * targets.iwae / vimco_control_variate / vimco sqair/targets.py:38-75, make_target model.py:150-158,

@@ -62,13 +62,6 @@ _PROTOS = {
     "sqair_graph_capture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_int, C.c_int, C.POINTER(SqairOutputs), C.c_void_p, C.c_int64,
                                       C.c_void_p]),
-    "sqair_profile_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                        C.c_int, C.c_int, C.POINTER(SqairOutputs), C.c_void_p, C.c_int64,
-                                        C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
-                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "sqair_profile_linear_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                             C.POINTER(SqairOutputs), C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
-                                             C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "sqair_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sqair_graph_nodes": (C.c_int, [C.c_void_p]),
     "sqair_elbo": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -708,15 +708,6 @@ int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipSt
   l.a.bias = packed + pl.b + L.b_off;
   l.a.M = M;
   l.a.N = L.N;
-  if (h->only_linear && (h->emit_extra & 4)) return 0;  // (measurement: the dense launches left OUT of the graph)
-  if (h->prof && h->prof_n < PROF_MAX) {
-    int ksum = 0;
-    for (int w : L.seg_width) ksum += w;
-    h->prof_flops += 2.0 * (double)M * (double)ksum * (double)L.N;
-    h->prof_layer.push_back((int)id);
-    h->prof_m.push_back(M);
-    return sq_launch_linear(l.a, L, s, h->prof_ts + h->prof_n++);
-  }
   const int rc = sq_launch_linear(l.a, L, s);
   if (rc != 0) sq_set_error(h, "internal: A-operand contract (16-byte aligned, ld % 4 == 0) violated in layer " + std::to_string((int)id));
   return rc;
@@ -734,15 +725,7 @@ static int run_rnn_tail(SqairHandle* h, const TailArgs& ta, Dims d, LayerId id, 
                         float* out, int out_ld, const float* packed, hipStream_t s) {
   const PackedLayer& L = h->layers[id];
   const PackedLayout pl = packed_layout(h);
-  if (h->only_linear && (h->emit_extra & 4)) return 0;
-  unsigned long long* pts = nullptr;
-  if (h->prof && h->prof_n < PROF_MAX) {
-    h->prof_flops += 2.0 * (double)d.R * (double)(rec::ZW + d.nh) * (double)L.N;
-    h->prof_layer.push_back((int)id);
-    h->prof_m.push_back(d.R);
-    pts = h->prof_ts + h->prof_n++;
-  }
-  const int rc = sq_launch_rnn_tail(ta, d, hid, hid_ld, packed + pl.w + L.w_off, packed + pl.b + L.b_off, add, add_ld, out, out_ld, L.N, s, pts);
+  const int rc = sq_launch_rnn_tail(ta, d, hid, hid_ld, packed + pl.w + L.w_off, packed + pl.b + L.b_off, add, add_ld, out, out_ld, L.N, s, nullptr);
   if (rc != 0) sq_set_error(h, "internal: k_rnn_tail launch rejected");
   return rc;
 }
@@ -756,10 +739,10 @@ static int run_rnn_tail(SqairHandle* h, const TailArgs& ta, Dims d, LayerId id, 
     RUN(l2, id2, M);                              \
   } while (0)
 
-static int emit_crop(SqairHandle* h, const CropArgs& ca, POff po, Dims d, int nslots, hipStream_t s) { return (h->only_linear && !(h->emit_extra & 1)) ? 0 : sq_launch_crop(ca, po, d, nslots, s); }
-static int emit_tail(SqairHandle* h, const TailArgs& ta, Dims d, hipStream_t s) { return (h->only_linear && !(h->emit_extra & 2)) ? 0 : sq_launch_slot_tail(ta, d, s); }
-static int emit_latsum(SqairHandle* h, const float* f, const float* rec_p, float* c, Dims d, hipStream_t s) { return h->only_linear ? 0 : sq_launch_latent_sum(f, rec_p, c, d, s); }
-static int emit_compact(SqairHandle* h, const CompactArgs& ka, POff po, Dims d, hipStream_t s) { return h->only_linear ? 0 : sq_launch_compact(ka, po, d, s); }
+static int emit_crop(SqairHandle* h, const CropArgs& ca, POff po, Dims d, int nslots, hipStream_t s) { (void)h; return sq_launch_crop(ca, po, d, nslots, s); }
+static int emit_tail(SqairHandle* h, const TailArgs& ta, Dims d, hipStream_t s) { (void)h; return sq_launch_slot_tail(ta, d, s); }
+static int emit_latsum(SqairHandle* h, const float* f, const float* rec_p, float* c, Dims d, hipStream_t s) { (void)h; return sq_launch_latent_sum(f, rec_p, c, d, s); }
+static int emit_compact(SqairHandle* h, const CompactArgs& ka, POff po, Dims d, hipStream_t s) { (void)h; return sq_launch_compact(ka, po, d, s); }
 
 // parts: 1 = prologue (workspace clear, initial state, input encoder), 2 = the frame loop, 4 = epilogue (log-probabilities,
 // decoder, final state copies).
@@ -800,7 +783,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     //  same T and B -- every buffer is then either rewritten by the pass or holds finite values / zeros it never overwrites)
     if (h->clear_each_pass) sq_zero_fill(wsbase, (int64_t)((float*)w.prof_ts - wsbase), s);
     // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
-    if (!h->only_linear) sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0, w.snh), w.state(w.prior_m, 0, w.psnh), w.last_id[0], w.disc_init_rec,
+    sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0, w.snh), w.state(w.prior_m, 0, w.psnh), w.last_id[0], w.disc_init_rec,
                          w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc,
                          (int)P(h, "prop.transform.l2.w"), (int)P(h, "disc.transform.l2.w"), flat, po, d, s);
     // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
@@ -845,7 +828,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     if (c.prior_cell == CELL_LSTM) {
       float* pg = w.frame(w.pgz, (int64_t)M * 4 * nh, t);
       Lin g; g.seg(rec_prev, RW, rec::ZW).seg(prior_prev, psnh, nh).out(pg, 4 * nh); RUN(g, L_PRIOR_GRU1, M);
-      if (!h->only_linear) sq_launch_lstm_cell(pg, 4 * nh, prior_prev + nh, psnh, prior_p, psnh, M, nh, s);
+      sq_launch_lstm_cell(pg, 4 * nh, prior_prev + nh, psnh, prior_p, psnh, M, nh, s);
       Lin pll; pll.seg(prior_p, psnh, nh).out(pstats_t, PS_LD); RUN(pll, L_PRIOR_LIN, M);
     } else if (c.prior_cell == CELL_VANILLA) {
       Lin g; g.seg(rec_prev, RW, rec::ZW).seg(prior_prev, nh, nh).out(prior_p, nh).act(ACT_TANH); RUN(g, L_PRIOR_GRU1, M);
@@ -907,7 +890,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
           float* gates = train ? w.slot(w.rgates, 4 * nh, t, 0, k) : w.rgates;
           a.add(pre_k, pre_rld, rw).out(gates, w.sld(4 * nh));
           RUN(a, L_PROP_RNN, R);
-          if (!h->only_linear) sq_launch_lstm_cell2(gates, w.sld(4 * nh), k == 0 ? w.prop_rnn_init + nh : w.cslot(t, 0, k - 1), k == 0 ? 0 : rl, r_k, rl,
+          sq_launch_lstm_cell2(gates, w.sld(4 * nh), k == 0 ? w.prop_rnn_init + nh : w.cslot(t, 0, k - 1), k == 0 ? 0 : rl, r_k, rl,
                                w.cslot(t, 0, k), rl, R, nh, s);
         } else if (c.rnn_cell == RNN_GRU) {  // snt.GRU in two launches, [z | r | tanh candidate] kept for the backward pass
           float* g3 = train ? w.slot(w.rgates, 3 * nh, t, 0, k) : w.rgates;
@@ -954,7 +937,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         Lin gl; gl.seg(r_k, rl, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(enc, el, 2 * nw)
                   .add(w.lpre + (size_t)k * 4 * nh, N * 4 * nh, 4 * nh).out(gates, gld);
         RUN(gl, L_PROP_GRU1, R);
-        if (!h->only_linear) sq_launch_lstm_cell(gates, gld, tau_prev + (size_t)k * snh, N * snh, temporal_p + (size_t)k * snh, N * snh, R, nh, s);
+        sq_launch_lstm_cell(gates, gld, tau_prev + (size_t)k * snh, N * snh, temporal_p + (size_t)k * snh, N * snh, R, nh, s);
         Lin hd; hd.seg(temporal_p + (size_t)k * snh, N * snh, nh).out(hraw, hl); RUN(hd, L_PROP_HEADS, R);
       } else if (c.time_cell == CELL_VANILLA) {  // tau' = tanh(x W_i + [tau W_h + b, hoisted into `pre`]) in one launch
         Lin g; g.seg(r_k, rl, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(enc, el, 2 * nw)
@@ -992,7 +975,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
       ga.rec_p = rec_p_t; ga.rec_d = rec_d_t; ga.rec_prev = rec_prev; ga.pstats = pstats_t; ga.ps_ld = PS_LD; ga.spre = spre_t;
       ga.gen_noise = h->gen_noise + (size_t)t * R * 2 * N * nzw; ga.gen = w.gen + (size_t)t * M * gen::W; ga.flat = flat;
       ga.do_generate = do_generate ? 1 : 0; ga.cfg = c;
-      if (!h->only_linear) sq_launch_generate_prop(ga, po, d, s);
+      sq_launch_generate_prop(ga, po, d, s);
     }
     // ---- F. summary of propagated latents -> discovery conditioning (sqair_modules.py:368-385, :501) ----
     {
@@ -1022,7 +1005,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
           float* gates = train ? w.slot(w.rgates, 4 * nh, t, 1, j) : w.rgates;
           a.add(w.pre_d, rw, rw).out(gates, w.sld(4 * nh));
           RUN(a, L_DISC_RNN, R);
-          if (!h->only_linear) sq_launch_lstm_cell2(gates, w.sld(4 * nh), j == 0 ? w.disc_rnn_init + nh : w.cslot(t, 1, j - 1), j == 0 ? 0 : rl, r_j, rl,
+          sq_launch_lstm_cell2(gates, w.sld(4 * nh), j == 0 ? w.disc_rnn_init + nh : w.cslot(t, 1, j - 1), j == 0 ? 0 : rl, r_j, rl,
                                w.cslot(t, 1, j), rl, R, nh, s);
         } else if (c.rnn_cell == RNN_GRU) {
           float* g3 = train ? w.slot(w.rgates, 3 * nh, t, 1, j) : w.rgates;
@@ -1067,7 +1050,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         else emit_tail(h, ta, d, s);
       }
     }
-    if (do_generate && !h->only_linear) sq_launch_generate_disc(ga, po, d, s);  // sqair_modules.py:157-170
+    if (do_generate) sq_launch_generate_disc(ga, po, d, s);  // sqair_modules.py:157-170
     // ---- I. merge / compaction (the log-probabilities H and the decoder J are off the recurrence's critical path:
     //      they run once for all T frames after the loop)
     {
@@ -1087,7 +1070,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     la.rec_p = w.rec_p_all; la.rec_d = w.rec_d_all; la.rec_prev = w.rec_m_all; la.pstats = w.pstats; la.ps_ld = PS_LD;
     la.spre = w.spre; la.flat = flat; la.t_global = t_offset; la.t = 0; la.n_frames = T; la.qz = w.qz; la.pz = w.pz;
     la.disc_lp = w.dlp; la.out = out; la.cfg = c; la.gen = c.sample_from_prior ? w.gen : nullptr;
-    if (!h->only_linear) sq_launch_logprob(la, po, d, s);
+    sq_launch_logprob(la, po, d, s);
   }
   // ---- J. decoder of all T frames as three M = T*B'*N row GEMMs + one insert / log-likelihood launch
   //      (modules.py:435-467, seq.py:271-276) ----
@@ -1098,20 +1081,20 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     Lin a; a.seg(rec_all, RW, rec::ZW).out(w.dec_a, nh).act(ACT_ELU); RUN(a, L_DEC0, MT);
     Lin b; b.seg(w.dec_a, nh, nh).out(w.dec_b, nh).act(ACT_ELU); RUN(b, L_DEC1, MT);
     Lin g; g.seg(w.dec_b, nh, nh).out(gl, G2); g.a.scale_ptr = flat + po.dec_output_scale; RUN(g, L_DEC2, MT);
-    if (out.glimpse && train && !h->only_linear) sq_copy(out.glimpse, gl, (int64_t)MT * G2, s);
+    if (out.glimpse && train) sq_copy(out.glimpse, gl, (int64_t)MT * G2, s);
     InsertArgs ia; memset(&ia, 0, sizeof(ia));
     ia.glimpse = gl; ia.rec = rec_all; ia.rec_ld = RW; ia.img = obs; ia.mean_img = flat + po.dec_mean_img;
     ia.canvas = out.canvas; ia.data_ll = w.dll; ia.qz = w.qz; ia.pz = w.pz; ia.t = 0; ia.n_frames = T; ia.out = out;
     ia.std_fg = c.output_std; ia.std_bg = c.background_std;
-    if (!h->only_linear) sq_launch_insert_loglik(ia, d, s);
+    sq_launch_insert_loglik(ia, d, s);
   }
   // final recurrent state (for state-level parity checks)
   if (out.final_temporal_state)
-    if (!h->only_linear) sq_copy(out.final_temporal_state, w.state(w.temporal_m, T, w.snh), (int64_t)M * snh, s);
+    sq_copy(out.final_temporal_state, w.state(w.temporal_m, T, w.snh), (int64_t)M * snh, s);
   if (out.final_prior_state)
-    if (!h->only_linear) sq_copy(out.final_prior_state, w.state(w.prior_m, T, w.psnh), (int64_t)M * psnh, s);
+    sq_copy(out.final_prior_state, w.state(w.prior_m, T, w.psnh), (int64_t)M * psnh, s);
   if (out.final_last_used_id)
-    if (!h->only_linear) sq_copy(out.final_last_used_id, w.last_id[T & 1], (int64_t)R, s);
+    sq_copy(out.final_last_used_id, w.last_id[T & 1], (int64_t)R, s);
   SQ_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1257,109 +1240,6 @@ extern "C" int sqair_forward(SqairHandle* h, const float* flat_params, const voi
   if (!h) return -1;
   return forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
                       workspace_bytes, (hipStream_t)stream);
-}
-
-// Eager forward in which every dense-layer launch (k_linear, the dominant kernel) stamps {first workgroup start,
-// last workgroup end} with the 100 MHz device wall clock (s_memrealtime) into its own slot; one HIP-event pair
-// brackets the whole pass on the launch stream.  Per-launch HIP events cannot resolve these kernels: an empty event
-// pair costs ~7.8 us on this stack, more than the kernels themselves (measured, profiles/README.md).
-extern "C" int sqair_profile_forward(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
-                                     const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
-                                     void* workspace, int64_t workspace_bytes, void* stream, double* linear_ms,
-                                     int* linear_launches, double* linear_flops, double* forward_ms_events) {
-  if (!h) return -1;
-  hipStream_t s = (hipStream_t)stream;
-  if (workspace_bytes < sqair_workspace_bytes(h, T, B)) { sq_set_error(h, "workspace too small"); return -1; }
-  Workspace w = carve(h, T, B, (float*)workspace);
-  SQ_CHECK_HIP(hipMemsetAsync(w.prof_ts, 0xFF, PROF_MAX * 8, s));
-  SQ_CHECK_HIP(hipMemsetAsync(w.prof_ts + PROF_MAX, 0, PROF_MAX * 8, s));
-  hipEvent_t ea, eb;
-  SQ_CHECK_HIP(hipEventCreate(&ea));
-  SQ_CHECK_HIP(hipEventCreate(&eb));
-  h->prof = true;
-  h->prof_ts = w.prof_ts;
-  h->prof_n = 0;
-  h->prof_flops = 0.0;
-  h->prof_layer.clear();
-  h->prof_m.clear();
-  (void)hipEventRecord(ea, s);
-  int rc = forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
-                        workspace_bytes, s);
-  (void)hipEventRecord(eb, s);
-  h->prof = false;
-  if (rc != 0) return rc;
-  SQ_CHECK_HIP(hipStreamSynchronize(s));
-  float fms = 0.0f;
-  SQ_CHECK_HIP(hipEventElapsedTime(&fms, ea, eb));
-  (void)hipEventDestroy(ea);
-  (void)hipEventDestroy(eb);
-  std::vector<unsigned long long> ts(5 * PROF_MAX);
-  SQ_CHECK_HIP(hipMemcpy(ts.data(), w.prof_ts, 5 * PROF_MAX * 8, hipMemcpyDeviceToHost));
-  double ticks = 0.0;
-  for (int i = 0; i < h->prof_n; ++i) ticks += (double)(ts[PROF_MAX + i] - ts[i]);
-  if (const char* dump = SQ_KNOB_STR("SQAIR_PROF_DUMP")) {  // per-launch CSV: layer id, rows, start tick, end tick (10 ns ticks)
-    if (FILE* f = fopen(dump, "w")) {
-      fprintf(f, "layer,M,start,end,wg0_setup,wg0_mfma,wg0_end\n");
-      for (int i = 0; i < h->prof_n; ++i)
-        fprintf(f, "%d,%d,%llu,%llu,%llu,%llu,%llu\n", h->prof_layer[i], h->prof_m[i], ts[i] - ts[0], ts[PROF_MAX + i] - ts[0],
-                ts[2 * PROF_MAX + i], ts[3 * PROF_MAX + i], ts[4 * PROF_MAX + i]);
-      fclose(f);
-    }
-  }
-  if (linear_ms) *linear_ms = ticks * 1e-5;  // 100 MHz ticks -> ms
-  if (linear_launches) *linear_launches = h->prof_n;
-  if (linear_flops) *linear_flops = h->prof_flops;
-  if (forward_ms_events) *forward_ms_events = fms;
-  return 0;
-}
-
-// Roofline measurement of the dominant kernel with HIP events (bench.py): the dense launches of one pass -- and nothing else --
-// are captured as a graph (same kernels, same arguments, same order; the crop / tail / compaction / log-probability launches
-// between them are left out, so the dense kernels read whatever the last real pass left in the workspace: finite values, and
-// their run time does not depend on data) and replayed `replays` times between two events on the launch stream.  The average
-// per launch therefore contains the dependent kernel boundary, like the per-dispatch durations rocprofv3 reports (per-launch
-// event pairs cannot resolve 2-5 us kernels: an empty pair costs ~8 us here).
-extern "C" int sqair_profile_linear_graph(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
-                                          const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
-                                          void* workspace, int64_t workspace_bytes, void* stream, int replays,
-                                          double* ms_per_replay, int* launches) {
-  if (!h || replays < 1 || !ms_per_replay) return -1;
-  hipStream_t s = (hipStream_t)stream;
-  SQ_CHECK_HIP(hipStreamSynchronize(s));
-  h->only_linear = true;
-  h->emit_extra = SQ_KNOB_INT("SQAIR_EMIT_EXTRA", 0);  // measurement knob: 1 = + crop, 2 = + tail, 4 = - dense
-  SQ_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-  const int rc = forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
-                              workspace_bytes, s);
-  hipGraph_t g = nullptr;
-  const hipError_t e = hipStreamEndCapture(s, &g);
-  h->only_linear = false;
-  if (rc != 0 || e != hipSuccess) {
-    if (g) (void)hipGraphDestroy(g);
-    if (rc == 0) sq_set_error(h, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    return rc != 0 ? rc : -2;
-  }
-  size_t nn = 0;
-  SQ_CHECK_HIP(hipGraphGetNodes(g, nullptr, &nn));
-  hipGraphExec_t ge = nullptr;
-  SQ_CHECK_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-  hipEvent_t ea, eb;
-  SQ_CHECK_HIP(hipEventCreate(&ea));
-  SQ_CHECK_HIP(hipEventCreate(&eb));
-  for (int i = 0; i < 3; ++i) SQ_CHECK_HIP(hipGraphLaunch(ge, s));
-  SQ_CHECK_HIP(hipEventRecord(ea, s));
-  for (int i = 0; i < replays; ++i) SQ_CHECK_HIP(hipGraphLaunch(ge, s));
-  SQ_CHECK_HIP(hipEventRecord(eb, s));
-  SQ_CHECK_HIP(hipStreamSynchronize(s));
-  float ms = 0.0f;
-  SQ_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb));
-  (void)hipEventDestroy(ea);
-  (void)hipEventDestroy(eb);
-  (void)hipGraphExecDestroy(ge);
-  (void)hipGraphDestroy(g);
-  *ms_per_replay = (double)ms / replays;
-  if (launches) *launches = (int)nn;
-  return 0;
 }
 
 extern "C" int sqair_graph_capture(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,

@@ -40,18 +40,10 @@ struct SqairHandle {
   int64_t packed_w = 0, packed_b = 0;
   bool plan_uploaded_to = false;
   const void* plan_uploaded_ptr = nullptr;
-  // live profiling of the dominant kernel (sqair_profile_forward)
-  bool prof = false;
-  unsigned long long* prof_ts = nullptr;
-  int prof_n = 0;
-  double prof_flops = 0.0;
-  std::vector<int> prof_layer, prof_m;
   // graph
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int graph_nodes = 0;
-  bool only_linear = false; // sqair_profile_linear_graph: emit the dense launches only
-  int emit_extra = 0;
   int debug_reps = 0;       // sqair_debug_linear_time
   float debug_us = 0.0f;
   bool opt_tail_fusion = true;  // sqair_set_option("tail_fusion"): the tail of slot k inside slot k + 1's RNN launch (bit-identical either way)

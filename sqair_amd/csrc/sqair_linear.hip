@@ -868,7 +868,10 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
     // limits (all of these shapes: 80 - 1600 tiles on 256 CUs)
     static const int big = SQ_KNOB_INT("SQAIR_BIG", 2);  // measurement knob: 0 = off, 2 / 4 = forced TNW
     if (big > 0 && prof_ts == nullptr && L.nt >= 4) {
-      if (big == 4) launch_big<4>(a, L, s); else launch_big<2>(a, L, s);
+#ifdef SQAIR_KNOBS
+      if (big == 4) { launch_big<4>(a, L, s); return 0; }   // (the 128 x 128 tile exists in the knob build only)
+#endif
+      launch_big<2>(a, L, s);
       return 0;
     }
     static const int lds_wgs = SQ_KNOB_INT("SQAIR_LDS_WGS", 512);  // measurement knob

@@ -372,29 +372,6 @@ class SqairCore(object):
                 grads[name] = flat_grad[o:o + n].reshape(shape).clone()
         return grads, d_rec
 
-    def profile_linear(self, t_offset=0):
-        """Eager forward with HIP events around every dense-layer launch; returns a dict (see
-        sqair_profile_forward in include/sqair_hip.h)."""
-        ms, n, fl, empty = C.c_double(), C.c_int(), C.c_double(), C.c_double()
-        with torch.cuda.device(self.device):
-            self._join_in()
-            _capi.check(self.handle, self.lib.sqair_profile_forward(*(self._args(t_offset) + (
-                C.byref(ms), C.byref(n), C.byref(fl), C.byref(empty)))), "sqair_profile_forward")
-            self._join_out()
-        return dict(linear_ms=ms.value, launches=n.value, executed_flops=fl.value, forward_ms_events=empty.value)
-
-    def profile_linear_graph(self, replays=20, t_offset=0):
-        """Average duration of a dense-layer launch INCLUDING the dependent kernel boundary, measured with one HIP-event
-        pair around `replays` replays of a graph that holds only the dense launches of the pass (sqair_profile_linear_graph).
-        Returns dict(ms_per_replay, launches, avg_launch_us)."""
-        ms, n = C.c_double(), C.c_int()
-        with torch.cuda.device(self.device):
-            self._join_in()
-            _capi.check(self.handle, self.lib.sqair_profile_linear_graph(*(self._args(t_offset) + (
-                int(replays), C.byref(ms), C.byref(n)))), "sqair_profile_linear_graph")
-            self._join_out()
-        return dict(ms_per_replay=ms.value, launches=n.value, avg_launch_us=ms.value * 1e3 / max(n.value, 1))
-
     def graph_nodes(self):
         return self.lib.sqair_graph_nodes(self.handle)
 

@@ -1,4 +1,4 @@
-"""Recomputes bench.py's `roofline.frac_rocprof` from the committed rocprofv3 summary:
+"""Recomputes the rocprofv3-side dense-family fraction from the committed summary (cross-check only: bench.py's roofline comes from the in-kernel timeline, tools/timeline.py):
 
     python tools/roofline_from_rocprof.py profiles/r02_kernel_stats.csv [launches_per_step] [algorithmic_gflop_per_step]
 
