@@ -773,6 +773,9 @@ static void launch_big(const LinArgs& a, const PackedLayer& L, hipStream_t s) {
   auto al = [](const void* p, int ld) { return p == nullptr || (((uintptr_t)p & 15) == 0 && (ld & 3) == 0); };
   const int vec = al(a.out, a.out_ld) && al(a.add, a.add_ld) && al(a.e0, a.e0_ld) && al(a.e1, a.e1_ld) && al(a.o1, a.o1_ld) &&
                   al(a.o2, a.o2_ld) && al(a.o3, a.o3_ld) && (a.epi == EPI_ACT || (a.nh & 3) == 0);
+  // (measured and dropped: two chunks per stage and barrier, with all fragments of the stage requested before its first MFMA
+  // -- the K loop of a lone workgroup stays at 0.66 us per chunk against 0.435 us of MFMAs: what remains is the ISSUE cost of
+  // the LDS-DMA loads in the MFMA waves' own instruction streams, ~100+ cycles apiece, not the barrier or the LDS latency)
   // (measured and dropped: starting the workgroups in odd hardware wave slots half a CU-load of matrix work late, so that their
   // K loops cover the others' epilogues -- 51200 x 256 x 256: 91 -> 84 us at half the computed delay with the 128 x 64 tile,
   // slower in every other combination tried)
