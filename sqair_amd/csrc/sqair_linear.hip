@@ -774,8 +774,11 @@ static void launch_big(const LinArgs& a, const PackedLayer& L, hipStream_t s) {
   const int vec = al(a.out, a.out_ld) && al(a.add, a.add_ld) && al(a.e0, a.e0_ld) && al(a.e1, a.e1_ld) && al(a.o1, a.o1_ld) &&
                   al(a.o2, a.o2_ld) && al(a.o3, a.o3_ld) && (a.epi == EPI_ACT || (a.nh & 3) == 0);
   // (measured and dropped: two chunks per stage and barrier, with all fragments of the stage requested before its first MFMA
-  // -- the K loop of a lone workgroup stays at 0.66 us per chunk against 0.435 us of MFMAs: what remains is the ISSUE cost of
-  // the LDS-DMA loads in the MFMA waves' own instruction streams, ~100+ cycles apiece, not the barrier or the LDS latency)
+  // -- the K loop of a lone workgroup stays at 0.66 us per chunk against 0.435 us of MFMAs: so neither the barrier nor the LDS latency
+  // ahead of the first MFMA is what it pays)
+  // (measured and dropped: four extra LOADER waves per workgroup, one per SIMD, issuing every LDS-DMA load so that the multiply
+  // waves only read fragments and issue MFMAs -- a lone workgroup's K loop 10.8 -> 11.4 us, i.e. the load ISSUE is not what
+  // it pays either; the 0.23 us per chunk beyond the MFMAs are still unexplained)
   // (measured and dropped: starting the workgroups in odd hardware wave slots half a CU-load of matrix work late, so that their
   // K loops cover the others' epilogues -- 51200 x 256 x 256: 91 -> 84 us at half the computed delay with the 128 x 64 tile,
   // slower in every other combination tried)
