@@ -12,6 +12,7 @@
 //                         [in, out] layout straight into the flat gradient buffer
 #include "sqair_glue.h"
 #include "sqair_bwd.h"
+#include "sqair_canvas.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -113,14 +114,16 @@ extern "C" int sqair_st_crop_bwd(SqairHandle* h, const float* img, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// insert + log-likelihood backward.  One workgroup per row b'.  Pass over the canvas pixels exactly like
-// the forward kernel; per pixel the scalar adjoints g_cv (canvas) and g_ms (written-to mask sum) are pushed
-// back into (a) the inverse-warp coordinates -> 4 reductions per slot, (b) the mean image (per-row contribution,
-// summed over rows by a second tiny kernel), and g_cv is kept in LDS; (c) the N glimpses are then GATHERED:
+// insert + log-likelihood backward.  One workgroup per (row b', frame), band by band like the forward kernel
+// (sqair_canvas.h): (1) the canvas / mask sum of the band are rebuilt over the slots' boxes; (2) per pixel the
+// scalar adjoints g_cv (canvas) and g_ms (written-to mask sum) replace them in LDS and the row's contribution
+// to d mean_img is written (summed over rows by a second tiny kernel); (3) per slot, over its box, the adjoints
+// are pushed back into the inverse-warp coordinates -> 4 sums per slot; (4) the N glimpses are GATHERED:
 // texel (gy, gx) of slot k sums g_cv over the canvas pixels whose bilinear footprint contains it,
 // |xg(X) - gx| < 1 and |yg(Y) - gy| < 1, with weight (1 - |xg - gx|)(1 - |yg - gy|) -- the transpose of the
-// forward's two-tap interpolation, separable, deterministic.  (Until round 3 the pixels SCATTERED into an LDS
-// tile with float atomics: neighbouring pixels hit the same texel, the atomics serialised -- 108 us per step.)
+// forward's two-tap interpolation, separable, deterministic; the pixel runs per texel column / row are found
+// once per workgroup.  (Rounds 1-2: the pixels SCATTERED into an LDS tile with float atomics, 108 us per step;
+// round 3 until the box formulation: every pixel walked every slot, 101 us, and 697 us at 128 x 128.)
 // ------------------------------------------------------------------------------------------------
 struct InsertBwdArgs {
   const float* glimpse;      // [R,N,G2]
@@ -138,172 +141,157 @@ struct InsertBwdArgs {
   int dw_ld;                 // leading dimension of d_where rows (4 = plain, 64 = gradient records)
 };
 
-__global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a, const Dims d SQ_TLP) {
+// LDS past the canvas block: glimpse gradient [N][G2], pixel runs per texel column / row [N][G] x 2 (first | last << 16),
+// per-wave partial sums of the four coordinate gradients [4][N][4]
+static inline size_t insert_bwd_lds_floats(const Dims& d, int band_rows) {
+  return sq_canvas_lds_floats(d.N, d.G, d.H, d.W, band_rows) + (size_t)d.N * d.G * d.G + 2 * (size_t)d.N * d.G + 16 * (size_t)d.N;
+}
+
+__global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a, const Dims d, const int band_rows SQ_TLP) {
   SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.N, G = d.G, G2 = d.G * d.G, H = d.H, W = d.W, P = d.H * d.W;
-  float* gl_s = smem;                 // N * G2   glimpses
-  float* gcv_s = gl_s + N * G2;       // P        canvas adjoint per pixel
-  float* xt_s = gcv_s + P;            // N * W
-  float* yt_s = xt_s + N * W;         // N * H
-  float* pres_s = yt_s + N * H;       // N
-  float* co_s = pres_s + N;           // N * 4  (sx, sy, tx, ty)
-  float* acc_s = co_s + N * 4;        // 4 waves * N * 4
-  const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const CanvasLds c = sq_canvas_carve(smem, N, G, H, W, band_rows);
+  float* dgl_s = c.end;                               // N * G2
+  int* xr_s = reinterpret_cast<int*>(dgl_s + N * G2); // N * G
+  int* yr_s = xr_s + N * G;                           // N * G
+  float* acc_s = reinterpret_cast<float*>(yr_s + N * G);  // 4 waves * N * 4
+  const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, tx = tid & 31, ty = tid >> 5;
   const int fr = blockIdx.y;  // frame
   const int b = r / d.K;
   const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot-row of this (frame, row)
   const size_t frr = (size_t)fr * d.R + r;
-  for (int i = tid; i < N * G2; i += 256) gl_s[i] = a.glimpse[fs * G2 + i];
-  if (tid < N * 4) {
-    const int k = tid >> 2, c = tid & 3;
-    const float l = a.rec ? a.rec[(fs + k) * a.rec_ld + rec::WHERE + c] : a.where[fs * 4 + tid];
-    co_s[tid] = (tid & 2) ? tanhf(l) : fmaxf(sq_sigmoid_geo(l), 1e-4f);
-  }
-  if (tid < N) pres_s[tid] = a.rec ? a.rec[(fs + tid) * a.rec_ld + rec::PRES] : a.pres[fs + tid];
-  __syncthreads();
-  for (int i = tid; i < N * (W + H); i += 256) {
-    const int k = i / (W + H), q = i % (W + H);
-    const bool is_y = q >= W;
-    const int j = is_y ? q - W : q;
-    const float sc = co_s[k * 4 + (is_y ? 1 : 0)], tr = co_s[k * 4 + (is_y ? 3 : 2)];
-    const float L = (float)((is_y ? H : W) - 1);
-    const float cn = -1.0f + 2.0f * (float)j / L;
-    const float g = 0.5f * (float)(G - 1) * ((cn - tr) / sc + 1.0f);
-    if (is_y) yt_s[k * H + j] = g; else xt_s[k * W + j] = g;
-  }
-  __syncthreads();
   const float gll = a.g_ll[frr];
-  const float* img = a.img + ((size_t)fr * d.B + b) * P;
-  float dco[SQ_MAXN][4];
-#pragma unroll
-  for (int k = 0; k < SQ_MAXN; ++k) dco[k][0] = dco[k][1] = dco[k][2] = dco[k][3] = 0.0f;
+  const float* __restrict__ img = a.img + ((size_t)fr * d.B + b) * P;
+  if (a.rec) sq_canvas_prologue(c, a.glimpse + fs * G2, a.rec + fs * a.rec_ld + rec::WHERE, a.rec_ld, a.rec + fs * a.rec_ld + rec::PRES, a.rec_ld, N, G, H, W);
+  else sq_canvas_prologue(c, a.glimpse + fs * G2, a.where + fs * 4, 4, a.pres + fs, 1, N, G, H, W);
+  for (int i = tid; i < N * G2; i += 256) dgl_s[i] = 0.0f;
+  for (int i = tid; i < 16 * N; i += 256) acc_s[i] = 0.0f;
+  // pixel run of texel column gx of slot k: the columns of the box with |xt - gx| < 1 (xt grows with the column); rows alike
+  for (int i = tid; i < 2 * N * G; i += 256) {
+    const bool is_y = i >= N * G;
+    const int q = is_y ? i - N * G : i, k = q / G, g = q - k * G;
+    const float* t = is_y ? c.yt + k * H : c.xt + k * W;
+    const int lo = c.box[k * 4 + (is_y ? 2 : 0)], hi = c.box[k * 4 + (is_y ? 3 : 1)];
+    int below = 0, above = 0;
+    for (int j = lo; j <= hi; ++j) {
+      const float v = t[j] - (float)g;
+      below += v <= -1.0f;
+      above += v >= 1.0f;
+    }
+    (is_y ? yr_s : xr_s)[q] = (lo + below) | ((hi - above) << 16);   // (empty: last < first)
+  }
+  __syncthreads();
   const float hg = 0.5f * (float)(G - 1);
-  for (int pix = tid; pix < P; pix += 256) {
-    const int Y = pix / W, X = pix - Y * W;
-    // ---- forward recompute of canvas / mask sum at this pixel
-    float cv = 0.0f, ms = 0.0f;
+  for (int yb0 = 0; yb0 < H; yb0 += band_rows) {
+    const int yb1 = min(H, yb0 + band_rows) - 1, n = (yb1 - yb0 + 1) * W, pix0 = yb0 * W;
+    float xv[SQ_CANVAS_PF], mv[SQ_CANVAS_PF];
+#pragma unroll
+    for (int q = 0; q < SQ_CANVAS_PF; ++q) {
+      const int p = tid + q * 256;
+      xv[q] = p < n ? img[pix0 + p] : 0.0f;
+      mv[q] = p < n ? a.mean_img[pix0 + p] : 0.0f;
+    }
+    sq_canvas_band(c, yb0, yb1, N, G, H, W);
+    // ---- (2) adjoints of the band's pixels
+#pragma unroll
+    for (int q = 0; q < SQ_CANVAS_PF; ++q) {
+      const int p = tid + q * 256;
+      if (p < n) {
+        const float m = sq_sigmoid(-10.0f + c.ms[p] * 20.0f);
+        const float mean = mv[q];
+        const float cv = c.cv[p] + mean * m;
+        const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
+        const float diff = xv[q] - cv;
+        const float g_cv = gll * diff / (sd * sd);
+        const float g_sd = gll * (diff * diff / (sd * sd * sd) - 1.0f / sd);
+        const float g_m = g_cv * mean + g_sd * (a.std_fg - a.std_bg);
+        a.d_mean_rows[frr * P + pix0 + p] = g_cv * m;
+        c.cv[p] = g_cv;
+        c.ms[p] = g_m * 20.0f * m * (1.0f - m);
+      }
+    }
+    __syncthreads();
+    // ---- (3) d/d (sx, sy, tx, ty) of every slot, over its box
     for (int k = 0; k < N; ++k) {
-      const float pk = pres_s[k];
-      if (pk == 0.0f) continue;
-      const float xg = xt_s[k * W + X], yg = yt_s[k * H + Y];
-      if (!(xg > -1.0f && xg < (float)G && yg > -1.0f && yg < (float)G)) continue;
-      const float x0f = floorf(xg), y0f = floorf(yg);
-      const int x0 = (int)x0f, y0 = (int)y0f;
-      const float wx1 = xg - x0f, wy1 = yg - y0f;
-      const float* gk = gl_s + k * G2;
-      float v = 0.0f, on = 0.0f;
+      CanvasSlot s;
+      if (!sq_canvas_slot(c, k, yb0, yb1, s)) continue;
+      const float* gk = c.gl + k * G2;
+      const float sx = c.co[k * 4 + 0], sy = c.co[k * 4 + 1], tcx = c.co[k * 4 + 2], tcy = c.co[k * 4 + 3];
+      float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
+      for (int Y = s.y0 + ty; Y <= s.y1; Y += 8) {
+        const float yg = c.yt[k * H + Y];
+        const float y0f = floorf(yg);
+        const int y0 = (int)y0f;
+        const float wy1 = yg - y0f;
+        const float Yn = -1.0f + 2.0f * (float)Y / (float)(H - 1);
+        for (int X = s.x0 + tx; X <= s.x1; X += 32) {
+          const float xg = c.xt[k * W + X];
+          const float x0f = floorf(xg);
+          const int x0 = (int)x0f;
+          const float wx1 = xg - x0f;
+          float t[2][2], vl[2][2];
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {
-        const int yy = y0 + dy;
-        if (yy < 0 || yy >= G) continue;
-        const float wy = dy ? wy1 : 1.0f - wy1;
+          for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          const int xx = x0 + dx;
-          if (xx < 0 || xx >= G) continue;
-          const float w = wy * (dx ? wx1 : 1.0f - wx1);
-          v += w * gk[yy * G + xx];
-          on += w;
+            for (int dx = 0; dx < 2; ++dx) {
+              const int yy = y0 + dy, xx = x0 + dx;
+              const bool ok = yy >= 0 && yy < G && xx >= 0 && xx < G;
+              vl[dy][dx] = ok ? 1.0f : 0.0f;
+              t[dy][dx] = ok ? gk[yy * G + xx] : 0.0f;
+            }
+          // d/d xg, d/d yg of (g_cv * bilinear(glimpse) + g_ms * bilinear(ones))
+          const float dvdx = (1.0f - wy1) * (t[0][1] - t[0][0]) + wy1 * (t[1][1] - t[1][0]);
+          const float dvdy = (1.0f - wx1) * (t[1][0] - t[0][0]) + wx1 * (t[1][1] - t[0][1]);
+          const float dodx = (1.0f - wy1) * (vl[0][1] - vl[0][0]) + wy1 * (vl[1][1] - vl[1][0]);
+          const float dody = (1.0f - wx1) * (vl[1][0] - vl[0][0]) + wx1 * (vl[1][1] - vl[0][1]);
+          const int o = (Y - yb0) * W + X;
+          const float g_cv = c.cv[o], g_ms = c.ms[o];
+          const float gx = s.pk * (g_cv * dvdx + g_ms * dodx), gy = s.pk * (g_cv * dvdy + g_ms * dody);
+          const float Xn = -1.0f + 2.0f * (float)X / (float)(W - 1);
+          d0 += gx * (-hg * (Xn - tcx) / (sx * sx));
+          d1 += gy * (-hg * (Yn - tcy) / (sy * sy));
+          d2 += gx * (-hg / sx);
+          d3 += gy * (-hg / sy);
         }
       }
-      cv += v * pk;
-      ms += on * pk;
+      d0 = sq_wave_sum(d0); d1 = sq_wave_sum(d1); d2 = sq_wave_sum(d2); d3 = sq_wave_sum(d3);
+      if (lane == 0) {   // one writer per (wave, slot)
+        float* ac = acc_s + (wave * N + k) * 4;
+        ac[0] += d0; ac[1] += d1; ac[2] += d2; ac[3] += d3;
+      }
     }
-    const float m = sq_sigmoid(-10.0f + ms * 20.0f);
-    const float mean = a.mean_img[pix];
-    cv += mean * m;
-    const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
-    const float diff = img[pix] - cv;
-    // ---- adjoints
-    const float g_cv = gll * diff / (sd * sd);
-    const float g_sd = gll * (diff * diff / (sd * sd * sd) - 1.0f / sd);
-    const float g_m = g_cv * mean + g_sd * (a.std_fg - a.std_bg);
-    const float g_ms = g_m * 20.0f * m * (1.0f - m);
-    a.d_mean_rows[frr * P + pix] = g_cv * m;
-    gcv_s[pix] = g_cv;
-    for (int k = 0; k < N; ++k) {
-      const float pk = pres_s[k];
-      if (pk == 0.0f) continue;
-      const float xg = xt_s[k * W + X], yg = yt_s[k * H + Y];
-      if (!(xg > -1.0f && xg < (float)G && yg > -1.0f && yg < (float)G)) continue;
-      const float x0f = floorf(xg), y0f = floorf(yg);
-      const int x0 = (int)x0f, y0 = (int)y0f;
-      const float wx1 = xg - x0f, wy1 = yg - y0f;
-      const float* gk = gl_s + k * G2;
-      float t[2][2], vl[2][2];
-#pragma unroll
-      for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          const int yy = y0 + dy, xx = x0 + dx;
-          const bool ok = yy >= 0 && yy < G && xx >= 0 && xx < G;
-          vl[dy][dx] = ok ? 1.0f : 0.0f;
-          t[dy][dx] = ok ? gk[yy * G + xx] : 0.0f;
-        }
-      // d/d xg, d/d yg of (g_cv * bilinear(glimpse) + g_ms * bilinear(ones))
-      const float dvdx = (1.0f - wy1) * (t[0][1] - t[0][0]) + wy1 * (t[1][1] - t[1][0]);
-      const float dvdy = (1.0f - wx1) * (t[1][0] - t[0][0]) + wx1 * (t[1][1] - t[0][1]);
-      const float dodx = (1.0f - wy1) * (vl[0][1] - vl[0][0]) + wy1 * (vl[1][1] - vl[1][0]);
-      const float dody = (1.0f - wx1) * (vl[1][0] - vl[0][0]) + wx1 * (vl[1][1] - vl[0][1]);
-      const float gx = pk * (g_cv * dvdx + g_ms * dodx), gy = pk * (g_cv * dvdy + g_ms * dody);
-      const float sx = co_s[k * 4 + 0], sy = co_s[k * 4 + 1], tx = co_s[k * 4 + 2], ty = co_s[k * 4 + 3];
-      const float Xn = -1.0f + 2.0f * (float)X / (float)(W - 1), Yn = -1.0f + 2.0f * (float)Y / (float)(H - 1);
-      dco[k][0] += gx * (-hg * (Xn - tx) / (sx * sx));
-      dco[k][1] += gy * (-hg * (Yn - ty) / (sy * sy));
-      dco[k][2] += gx * (-hg / sx);
-      dco[k][3] += gy * (-hg / sy);
-    }
-  }
-  for (int k = 0; k < N; ++k)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float v = sq_wave_sum(dco[k][c]);
-      if (lane == 0) acc_s[(wave * N + k) * 4 + c] = v;
-    }
-  __syncthreads();
-  // ---- glimpse gradient by gathering (see the header): texel i = (k, gy, gx)
-  {
-    const float fw = 0.5f * (float)(W - 1), fh = 0.5f * (float)(H - 1);
+    // ---- (4) glimpse gradient by gathering (see the header): texel i = (k, gy, gx), rows of this band
     for (int i = tid; i < N * G2; i += 256) {
       const int k = i / G2, q = i - k * G2, gy = q / G, gx = q - gy * G;
-      const float pk = pres_s[k];
-      float acc = 0.0f;
-      if (pk != 0.0f) {
-        const float sx = co_s[k * 4 + 0], sy = co_s[k * 4 + 1], tx = co_s[k * 4 + 2], ty = co_s[k * 4 + 3];
-        // pixel range whose glimpse coordinate lies within one texel of (gx, gy): xg is increasing in X (sx > 0); one pixel of
-        // slack either side, the exact test |xg - gx| < 1 decides on the same table values the per-pixel pass used
-        const int X0 = max(0, (int)floorf(fw * (sx * (((float)gx - 1.0f) / hg - 1.0f) + tx + 1.0f)) - 1);
-        const int X1 = min(W - 1, (int)ceilf(fw * (sx * (((float)gx + 1.0f) / hg - 1.0f) + tx + 1.0f)) + 1);
-        const int Y0 = max(0, (int)floorf(fh * (sy * (((float)gy - 1.0f) / hg - 1.0f) + ty + 1.0f)) - 1);
-        const int Y1 = min(H - 1, (int)ceilf(fh * (sy * (((float)gy + 1.0f) / hg - 1.0f) + ty + 1.0f)) + 1);
-        for (int Y = Y0; Y <= Y1; ++Y) {
-          const float wy = 1.0f - fabsf(yt_s[k * H + Y] - (float)gy);
-          if (!(wy > 0.0f)) continue;
-          float rowsum = 0.0f;
-          for (int X = X0; X <= X1; ++X) {
-            const float wx = 1.0f - fabsf(xt_s[k * W + X] - (float)gx);
-            if (wx > 0.0f) rowsum += wx * gcv_s[Y * W + X];
-          }
-          acc += wy * rowsum;
-        }
-        acc *= pk;
+      if (c.pres[k] == 0.0f) continue;
+      const int xr = xr_s[k * G + gx], yr = yr_s[k * G + gy];
+      const int X0 = xr & 0xffff, X1 = xr >> 16, Y0 = max(yr & 0xffff, yb0), Y1 = min(yr >> 16, yb1);
+      float acc = dgl_s[i];
+      for (int Y = Y0; Y <= Y1; ++Y) {
+        const float wy = 1.0f - fabsf(c.yt[k * H + Y] - (float)gy);
+        float rowsum = 0.0f;
+        for (int X = X0; X <= X1; ++X) rowsum += (1.0f - fabsf(c.xt[k * W + X] - (float)gx)) * c.cv[(Y - yb0) * W + X];
+        acc += wy * rowsum;
       }
-      a.d_glimpse[fs * G2 + i] = acc;
+      dgl_s[i] = acc;
     }
+    __syncthreads();  // the next band clears c.cv / c.ms; after the last one: dgl_s / acc_s complete
   }
+  for (int i = tid; i < N * G2; i += 256) a.d_glimpse[fs * G2 + i] = dgl_s[i] * c.pres[i / G2];
   if (tid < N * 4) {
-    const int k = tid >> 2, c = tid & 3;
-    const float tot = acc_s[(0 * N + k) * 4 + c] + acc_s[(1 * N + k) * 4 + c] + acc_s[(2 * N + k) * 4 + c] + acc_s[(3 * N + k) * 4 + c];
-    const float l = a.rec ? a.rec[(fs + k) * a.rec_ld + rec::WHERE + c] : a.where[fs * 4 + tid];
+    const int k = tid >> 2, q = tid & 3;
+    const float tot = acc_s[(0 * N + k) * 4 + q] + acc_s[(1 * N + k) * 4 + q] + acc_s[(2 * N + k) * 4 + q] + acc_s[(3 * N + k) * 4 + q];
+    const float l = a.rec ? a.rec[(fs + k) * a.rec_ld + rec::WHERE + q] : a.where[fs * 4 + tid];
     const float sg = sq_sigmoid_geo(l), th = tanhf(l);
-    a.d_where[(fs + k) * a.dw_ld + c] = tot * ((c & 2) ? 1.0f - th * th : sg * (1.0f - sg));
+    a.d_where[(fs + k) * a.dw_ld + q] = tot * ((q & 2) ? 1.0f - th * th : sg * (1.0f - sg));
   }
 }
 
-// dynamic LDS of k_insert_loglik_bwd: glimpses, the canvas adjoint, coordinate tables, presences, coordinates, wave partials
-static size_t insert_bwd_lds(const Dims& d) {
-  const size_t bytes = ((size_t)d.N * d.G * d.G + (size_t)d.H * d.W + (size_t)d.N * (d.W + d.H) + d.N + d.N * 4 + 4 * d.N * 4) * sizeof(float);
+// band height and dynamic LDS of k_insert_loglik_bwd
+static size_t insert_bwd_lds(const Dims& d, int& band_rows) {
+  band_rows = sq_canvas_band_rows(d.H, d.W);
+  const size_t bytes = insert_bwd_lds_floats(d, band_rows) * sizeof(float);
   static bool big = false;
   if (bytes > 48 * 1024 && !big) {
     (void)hipFuncSetAttribute((const void*)k_insert_loglik_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -345,8 +333,9 @@ extern "C" int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, 
   if (scratch_bytes < (int64_t)d.R * P * 4) return -1;
   InsertBwdArgs a{glimpse, where_logits, presence, img, mean_img, g_data_ll, d_glimpse, d_where_logits, (float*)scratch,
                   c.output_std, c.background_std, nullptr, 0, 4};
-  const size_t shm = insert_bwd_lds(d);
-  SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, 1), dim3(256), shm, (hipStream_t)stream, a, d);
+  int band_rows;
+  const size_t shm = insert_bwd_lds(d, band_rows);
+  SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, 1), dim3(256), shm, (hipStream_t)stream, a, d, band_rows);
   SQ_LAUNCH(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch,
                      d_mean_img, d.R, P, 0);
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -666,8 +655,9 @@ int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_
                                 float std_fg, float std_bg, int T, Dims d, hipStream_t s) {
   InsertBwdArgs a{glimpse, nullptr, nullptr, img, mean_img, g_ll, d_glimpse, d_rec, d_mean_rows, std_fg, std_bg, rec, rec_ld,
                   d_rec_ld};
-  const size_t shm = insert_bwd_lds(d);
-  SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, T), dim3(256), shm, s, a, d);
+  int band_rows;
+  const size_t shm = insert_bwd_lds(d, band_rows);
+  SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, T), dim3(256), shm, s, a, d, band_rows);
   return 0;
 }
 int sq_launch_reduce_rows(const float* rows, float* out, int R, int P, int accumulate, hipStream_t s) {
@@ -813,46 +803,77 @@ __device__ __forceinline__ float delu_from_out(float o) { return o > 0.0f ? 1.0f
 // ------------------------------------------------------------------------------------------------
 
 constexpr int SQ_SMALL_MAX = 1024;
-struct SmallParamTab { int n; int src[16]; int len[16]; int dst[16]; };
+struct SmallParamTab { int n; int src[16]; int len[16]; int dst[16]; int total; };
 
-__global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, const POff pc, const SmallParamTab tab, const Dims d SQ_TLP) {
+__global__ __launch_bounds__(256) void k_logprob_bwd(const LogprobBwdArgs a, const POff pc, const SmallParamTab tab, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
-  // The ~800 small parameters this kernel reads (where-prior RNN, step-prior MLP, Cholesky factor) are staged in LDS
-  // and their gradients accumulated there (`pc` holds COMPACT offsets into these arrays): reads from the flat buffer
-  // interleaved with atomics on the gradient buffer cannot be hoisted by the compiler and serialised the kernel on
-  // L2 latency (1.1 ms); one coalesced flush of float atomics per workgroup at the end instead.
-  __shared__ float fl[SQ_SMALL_MAX], gl[SQ_SMALL_MAX];
-  for (int sgi = 0; sgi < tab.n; ++sgi)
-    for (int i = threadIdx.x; i < tab.len[sgi]; i += 64) {
-      fl[tab.dst[sgi] + i] = a.flat[tab.src[sgi] + i];
-      gl[tab.dst[sgi] + i] = 0.0f;
-    }
-  __syncthreads();
-  const int r = blockIdx.x, fr = blockIdx.y, lane = threadIdx.x;
-  const int N = d.N, nw = d.nw, RW = rec::W;
+  // One workgroup of four wavefronts per (row b', frame).  Four things keep its serial chain short:
+  // * the ~800 small parameters this kernel reads (where-prior RNN, step-prior MLP, Cholesky factor) are staged in LDS and
+  //   their gradients accumulated there (`pc` holds COMPACT offsets into these arrays): reads from the flat buffer
+  //   interleaved with atomics on the gradient buffer cannot be hoisted by the compiler and serialised the kernel on L2
+  //   latency (1.1 ms in round 1); one coalesced flush of float atomics per workgroup at the end instead;
+  // * the row's own inputs -- its N discovery / propagation / merged records and prior statistics -- are staged in LDS too, all
+  //   requested in ONE batch, and the record gradients are summed in LDS and flushed at the end (until round 3: read from
+  //   global memory where needed, between float atomics on the gradient records the reads have to be ordered against);
+  // * everything that is per slot runs on a lane (or a group of four lanes) PER SLOT instead of in a loop over the slots on
+  //   lane 0: the where-prior RNN steps (independent given the conditioning), the Cholesky solves, the number-of-steps terms
+  //   and the step-prior MLP were ~7000 dependent instructions of one wave, 84 us for a kernel that moves 5 MB;
+  // * the independent parts run on different wavefronts: wave 0 the where-prior RNN and the discovery where terms, wave 1 the
+  //   step prior and the number-of-steps terms, wave 2 the propagation where terms and Cholesky solves, and all four share
+  //   the what terms slot by slot.  Every LDS accumulator has ONE writing wave, so the sums keep a fixed order (the
+  //   gradient is bit-reproducible); the two pieces of d e_sum meet in LDS before the prior-logit terms.
+  extern __shared__ __attribute__((aligned(16))) float row_s[];
+  __shared__ float hid_s[16], gv_s[SQ_MAXN + 1], de_s[2];
+  const int r = blockIdx.x, fr = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = d.N, nw = d.nw, RW = rec::W, MW = rec::ZW;
   const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;
   const size_t frr = (size_t)fr * d.R + r;
+  float* rd_s = row_s;              // [N][RW] discovery records
+  float* rp_s = rd_s + N * RW;      // [N][RW] propagation records
+  float* drd_s = rp_s + N * RW;     // the same two as gradients
+  float* drp_s = drd_s + N * RW;
+  float* rm_s = drp_s + N * RW;     // [N][MW] merged records of the previous frame (z part: all that is used of them), gradient
+  float* drm_s = rm_s + N * MW;
+  float* ps_s = drm_s + N * MW;     // [N][ps_ld] prior statistics, gradient
+  float* dps_s = ps_s + N * a.ps_ld;
+  float* fl = dps_s + N * a.ps_ld;  // [tab.total] small parameters, gradient
+  float* gl = fl + tab.total;
+  sq_wave_stage(rd_s, a.rec_d + fs * RW, N * RW, lane, wave, 4);
+  sq_wave_stage(rp_s, a.rec_p + fs * RW, N * RW, lane, wave, 4);
+  for (int k = wave; k < N; k += 4) sq_wave_stage(rm_s + k * MW, a.rec_m + (fs + k) * RW, MW, lane);
+  sq_wave_stage(ps_s, a.pstats + fs * a.ps_ld, N * a.ps_ld, lane, wave, 4);
+#pragma unroll   // (constant indices: the table entries are read from the kernel arguments in one batch, not one dependent scalar load per trip)
+  for (int sgi = 0; sgi < 16; ++sgi)
+    if (sgi < tab.n) sq_wave_stage(fl + tab.dst[sgi], a.flat + tab.src[sgi], tab.len[sgi], lane, wave, 4);
+  for (int i = tid; i < 2 * N * RW; i += 256) drd_s[i] = 0.0f;          // drd_s | drp_s
+  for (int i = tid; i < N * MW; i += 256) drm_s[i] = 0.0f;
+  for (int i = tid; i < N * a.ps_ld; i += 256) dps_s[i] = 0.0f;
+  for (int i = tid; i < tab.total; i += 256) gl[i] = 0.0f;
+  const float gw = a.g_lw[frr], gd = a.g_dl[frr];
+  __syncthreads();
   const float* flat = fl;
   float* fg = gl;
-  const float gw = a.g_lw[frr], gd = a.g_dl[frr];
   const int t_global = a.t_global0 + fr;
-  // ---------------- forward quantities needed below: prior logits, e_sum
-  float pl[SQ_MAXN], e_sum = 0.0f;
-  for (int k = 0; k < N; ++k) {
-    const float* rm = a.rec_m + (fs + k) * RW;
-    const float* ps = a.pstats + (fs + k) * a.ps_ld;
-    const float pres_tm1 = rm[rec::PRES];
-    float v = ps[0] + a.cfg.prop_prior_step_bias;
-    v = pres_tm1 * v + (pres_tm1 - 1.0f) * 88.0f;
-    if (a.cfg.prop_prior_type != 0) v = rm[rec::LOGIT] + 0.1f * v;
-    pl[k] = v;
-    e_sum += (sq_sigmoid(v) - 0.5f) / (float)N;
+  // ---------------- forward quantities needed below: lane k holds the prior logit of slot k; e_sum
+  float pl_k = 0.0f, e_sum;
+  {
+    float e = 0.0f;
+    if (lane < N) {
+      const float* rm = rm_s + lane * MW;
+      const float pres_tm1 = rm[rec::PRES];
+      float v = ps_s[lane * a.ps_ld] + a.cfg.prop_prior_step_bias;
+      v = pres_tm1 * v + (pres_tm1 - 1.0f) * 88.0f;
+      if (a.cfg.prop_prior_type != 0) v = rm[rec::LOGIT] + 0.1f * v;
+      pl_k = v;
+      e = (sq_sigmoid(v) - 0.5f) / (float)N;
+    }
+    e_sum = sq_wave_sum(e);
   }
-  float d_e = 0.0f;
-  // ---------------- discovery: recurrent where prior
-  float n_disc = 0.0f;
-  for (int j = 0; j < N; ++j) n_disc += a.rec_d[(fs + j) * RW + rec::PRES];
+  const float n_disc = sq_wave_sum(lane < N ? rd_s[lane * RW + rec::PRES] : 0.0f);
   const int n = (int)(n_disc + 0.5f);
+  // ---------------- wave 0: discovery, recurrent where prior
+  if (wave == 0) {
+  float d_e = 0.0f;
   if (a.cfg.rec_where_prior) {
     // s = elu(spre + e ce), hs = s h2h + b_h2h + b_i2h  (lanes own s_i for i = lane, lane + 64)
     float sv[2], part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -862,55 +883,57 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
       sv[q] = sq_elu(a.spre[frr * 128 + i] + e_sum * flat[pc.rn_cond_w + (4 + d.nh) * 128 + i]);
       for (int jj = 0; jj < 4; ++jj) part[jj] += sv[q] * flat[pc.rn_h2h_w + i * 4 + jj];
     }
-    float hs[4], d_hs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float hs[4], d_hs[4];
     for (int jj = 0; jj < 4; ++jj) hs[jj] = sq_wave_sum(part[jj]) + flat[pc.rn_h2h_b + jj] + flat[pc.rn_i2h_b + jj];
-    for (int j = 0; j < N; ++j) {
-      const float* rd = a.rec_d + (fs + j) * RW;
-      const float pres = rd[rec::PRES];
-      const float* xp = j == 0 ? flat + pc.rn_init_sample : a.rec_d + (fs + j - 1) * RW + rec::WHERE;
-      float o[4], pre;
+    // the N steps of the RNN only share hs (step j reads the SAMPLED where of step j - 1): lanes 4 j + i work on step j,
+    // component i; sums over the components are butterflies inside the group of four
+    {
+      const int j = min(lane >> 2, N - 1), ci = lane & 3;
+      const bool on = lane < 4 * N;
+      const float* rd = rd_s + j * RW;
+      const float* xp = j == 0 ? flat + pc.rn_init_sample : rd_s + (j - 1) * RW + rec::WHERE;
+      float o[4];
       for (int mm = 0; mm < 4; ++mm) {
-        pre = hs[mm];
+        float pre = hs[mm];
         for (int i = 0; i < 4; ++i) pre += xp[i] * flat[pc.rn_i2h_w + i * 4 + mm];
         o[mm] = tanhf(pre);
       }
-      // lanes 0..3: component i
-      float g_loc = 0.0f, g_raw = 0.0f;
-      if (lane < 4) {
-        float loc = flat[pc.rn_readout_b + lane], raw = flat[pc.rn_readout_b + 4 + lane];
+      float loc = flat[pc.rn_readout_b + ci], raw = flat[pc.rn_readout_b + 4 + ci];
+      for (int mm = 0; mm < 4; ++mm) {
+        loc += o[mm] * flat[pc.rn_readout_w + mm * 8 + ci];
+        raw += o[mm] * flat[pc.rn_readout_w + mm * 8 + 4 + ci];
+      }
+      const float psc = sq_softplus(raw) + 1e-2f;
+      const float x = rd[rec::WHERE + ci];
+      const float coef = on ? gw * rd[rec::PRES] : 0.0f;
+      const float g_loc = coef * (-dnormal_dx(x, loc, psc));
+      const float g_raw = coef * dnormal_dsc(x, loc, psc) * sq_sigmoid(raw);
+      if (on) {
+        atomicAdd(&drd_s[j * RW + rec::WHERE + ci], coef * dnormal_dx(x, loc, psc));
+        atomicAdd(&fg[pc.rn_readout_b + ci], g_loc);
+        atomicAdd(&fg[pc.rn_readout_b + 4 + ci], g_raw);
         for (int mm = 0; mm < 4; ++mm) {
-          loc += o[mm] * flat[pc.rn_readout_w + mm * 8 + lane];
-          raw += o[mm] * flat[pc.rn_readout_w + mm * 8 + 4 + lane];
-        }
-        const float psc = sq_softplus(raw) + 1e-2f;
-        const float x = rd[rec::WHERE + lane];
-        const float coef = gw * pres;
-        g_loc = coef * (-dnormal_dx(x, loc, psc));
-        g_raw = coef * dnormal_dsc(x, loc, psc) * sq_sigmoid(raw);
-        unsafeAtomicAdd(&a.d_rec_d[(fs + j) * RW + rec::WHERE + lane], coef * dnormal_dx(x, loc, psc));
-        atomicAdd(&fg[pc.rn_readout_b + lane], g_loc);
-        atomicAdd(&fg[pc.rn_readout_b + 4 + lane], g_raw);
-        for (int mm = 0; mm < 4; ++mm) {
-          atomicAdd(&fg[pc.rn_readout_w + mm * 8 + lane], o[mm] * g_loc);
-          atomicAdd(&fg[pc.rn_readout_w + mm * 8 + 4 + lane], o[mm] * g_raw);
+          atomicAdd(&fg[pc.rn_readout_w + mm * 8 + ci], o[mm] * g_loc);
+          atomicAdd(&fg[pc.rn_readout_w + mm * 8 + 4 + ci], o[mm] * g_raw);
         }
       }
-      // g_o[m] = sum_i ro_w[m][i] g_loc_i + ro_w[m][4+i] g_raw_i  (reduce over lanes 0..3)
+      // g_o[m] = sum_i ro_w[m][i] g_loc_i + ro_w[m][4+i] g_raw_i  (over the four lanes of the step)
       float g_pre[4];
       for (int mm = 0; mm < 4; ++mm) {
-        float v = lane < 4 ? flat[pc.rn_readout_w + mm * 8 + lane] * g_loc + flat[pc.rn_readout_w + mm * 8 + 4 + lane] * g_raw : 0.0f;
-        v = sq_wave_sum(v);
+        float v = flat[pc.rn_readout_w + mm * 8 + ci] * g_loc + flat[pc.rn_readout_w + mm * 8 + 4 + ci] * g_raw;
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
         g_pre[mm] = v * (1.0f - o[mm] * o[mm]);
-        d_hs[mm] += g_pre[mm];
+        d_hs[mm] = sq_wave_sum(on && ci == 0 ? g_pre[mm] : 0.0f);
       }
-      if (lane < 4) {  // lane = input index i of i2h
+      if (on) {  // ci = input index i of i2h
         float dx = 0.0f;
         for (int mm = 0; mm < 4; ++mm) {
-          atomicAdd(&fg[pc.rn_i2h_w + lane * 4 + mm], xp[lane] * g_pre[mm]);
-          dx += flat[pc.rn_i2h_w + lane * 4 + mm] * g_pre[mm];
+          atomicAdd(&fg[pc.rn_i2h_w + ci * 4 + mm], xp[ci] * g_pre[mm]);
+          dx += flat[pc.rn_i2h_w + ci * 4 + mm] * g_pre[mm];
         }
-        if (j == 0) atomicAdd(&fg[pc.rn_init_sample + lane], dx);
-        else unsafeAtomicAdd(&a.d_rec_d[(fs + j - 1) * RW + rec::WHERE + lane], dx);
+        if (j == 0) atomicAdd(&fg[pc.rn_init_sample + ci], dx);
+        else atomicAdd(&drd_s[(j - 1) * RW + rec::WHERE + ci], dx);
       }
     }
     if (lane < 4) {
@@ -935,87 +958,101 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
   } else {
     a.d_spre[frr * 128 + lane] = 0.0f;
     a.d_spre[frr * 128 + 64 + lane] = 0.0f;
-    for (int j = 0; j < N; ++j)
-      if (lane < 4) {
-        const float* rd = a.rec_d + (fs + j) * RW;
-        unsafeAtomicAdd(&a.d_rec_d[(fs + j) * RW + rec::WHERE + lane],
-                  gw * rd[rec::PRES] * dnormal_dx(rd[rec::WHERE + lane], a.cfg.where_prior_mean[lane], 1.0f));
-      }
+    if (lane < 4 * N) {
+      const int j = lane >> 2, ci = lane & 3;
+      const float* rd = rd_s + j * RW;
+      atomicAdd(&drd_s[j * RW + rec::WHERE + ci], gw * rd[rec::PRES] * dnormal_dx(rd[rec::WHERE + ci], a.cfg.where_prior_mean[ci], 1.0f));
+    }
   }
-  // ---------------- discovery: q what / where, p what, number of steps
-  for (int j = 0; j < N; ++j) {
-    const float* rd = a.rec_d + (fs + j) * RW;
-    float* dr = a.d_rec_d + (fs + j) * RW;
+  if (lane == 0) de_s[0] = d_e;
+  // q where of the discovery slots (same gradient elements as the prior above: same wave)
+  if (lane < 4 * N) {
+    const int j = lane >> 2, ci = lane & 3;
+    const float* rd = rd_s + j * RW;
+    float* dr = drd_s + j * RW;
+    const float cq = -gw * rd[rec::PRES];
+    const float x = rd[rec::WHERE + ci], loc = rd[rec::WHERE_LOC + ci], sc = rd[rec::WHERE_SCALE + ci];
+    atomicAdd(&dr[rec::WHERE + ci], cq * dnormal_dx(x, loc, sc));
+    atomicAdd(&dr[rec::WHERE_LOC + ci], -cq * dnormal_dx(x, loc, sc));
+    atomicAdd(&dr[rec::WHERE_SCALE + ci], cq * dnormal_dsc(x, loc, sc));
+  }
+  }  // wave 0
+  // ---------------- all waves: q what, p what of the discovery slots
+  for (int j = wave; j < N; j += 4) {
+    const float* rd = rd_s + j * RW;
+    float* dr = drd_s + j * RW;
     const float pres = rd[rec::PRES];
     const float cq = -gw * pres, cp = gw * pres;
     if (lane < nw) {
       const float x = rd[rec::WHAT + lane], loc = rd[rec::WHAT_LOC + lane], sc = rd[rec::WHAT_SCALE + lane];
-      unsafeAtomicAdd(&dr[rec::WHAT + lane], cq * dnormal_dx(x, loc, sc) + cp * (-x));
-      unsafeAtomicAdd(&dr[rec::WHAT_LOC + lane], -cq * dnormal_dx(x, loc, sc));
-      unsafeAtomicAdd(&dr[rec::WHAT_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
-    }
-    if (lane < 4) {
-      const float x = rd[rec::WHERE + lane], loc = rd[rec::WHERE_LOC + lane], sc = rd[rec::WHERE_SCALE + lane];
-      unsafeAtomicAdd(&dr[rec::WHERE + lane], cq * dnormal_dx(x, loc, sc));
-      unsafeAtomicAdd(&dr[rec::WHERE_LOC + lane], -cq * dnormal_dx(x, loc, sc));
-      unsafeAtomicAdd(&dr[rec::WHERE_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
-    }
-    if (lane == 0) {
-      // q_num = log J_n, J from p_j = sigmoid(logit_j): d log J_n / d logit_j = (1 - p_j) for j < n, -p_n for j = n < N
-      const float coef = -gw + gd;
-      const float pj = rd[rec::PROB];
-      float g = 0.0f;
-      if (j < n) g = coef * (1.0f - pj);
-      else if (j == n) g = coef * (-pj);
-      unsafeAtomicAdd(&dr[rec::LOGIT], g);
+      atomicAdd(&dr[rec::WHAT + lane], cq * dnormal_dx(x, loc, sc) + cp * (-x));
+      atomicAdd(&dr[rec::WHAT_LOC + lane], -cq * dnormal_dx(x, loc, sc));
+      atomicAdd(&dr[rec::WHAT_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
     }
   }
-  // categorical / geometric prior of the number of steps
-  if (a.cfg.disc_prior_type == 0 && lane == 0) {
-    float hid[10], lg[SQ_MAXN + 1], gv[SQ_MAXN + 1];
-    for (int i = 0; i < 10; ++i) hid[i] = sq_elu(e_sum * flat[pc.sp_l0_w + i] + flat[pc.sp_l0_b + i]);
-    float mx = -1e30f;
-    for (int c = 0; c <= N; ++c) {
-      float v = flat[pc.step_prior_bias + c] + (t_global > 0 ? flat[pc.step_prior_tbias + c] : 0.0f) + flat[pc.sp_l1_b + c];
-      for (int i = 0; i < 10; ++i) v += hid[i] * flat[pc.sp_l1_w + i * (N + 1) + c];
-      lg[c] = sq_elu(v);
-      mx = fmaxf(mx, lg[c]);
+  // ---------------- wave 1: number of steps
+  if (wave == 1) {
+  float d_e = 0.0f;
+  if (lane < N) {
+    // q_num = log J_n, J from p_j = sigmoid(logit_j): d log J_n / d logit_j = (1 - p_j) for j < n, -p_n for j = n < N
+    const int j = lane;
+    const float coef = -gw + gd;
+    const float pj = rd_s[j * RW + rec::PROB];
+    float g = 0.0f;
+    if (j < n) g = coef * (1.0f - pj);
+    else if (j == n) g = coef * (-pj);
+    atomicAdd(&drd_s[j * RW + rec::LOGIT], g);
+  }
+  // categorical / geometric prior of the number of steps: hidden unit i on lane i, class c on lane c
+  if (a.cfg.disc_prior_type == 0) {
+    const int N1 = N + 1;
+    const float hid = lane < 10 ? sq_elu(e_sum * flat[pc.sp_l0_w + lane] + flat[pc.sp_l0_b + lane]) : 0.0f;
+    if (lane < 10) hid_s[lane] = hid;
+    __builtin_amdgcn_wave_barrier();   // (one wave: its LDS operations complete in order)
+    float lg = -1e30f;
+    if (lane < N1) {
+      float v = flat[pc.step_prior_bias + lane] + (t_global > 0 ? flat[pc.step_prior_tbias + lane] : 0.0f) + flat[pc.sp_l1_b + lane];
+      for (int i = 0; i < 10; ++i) v += hid_s[i] * flat[pc.sp_l1_w + i * N1 + lane];
+      lg = sq_elu(v);
     }
-    float se = 0.0f;
-    for (int c = 0; c <= N; ++c) se += expf(lg[c] - mx);
-    for (int c = 0; c <= N; ++c) {
-      const float sm = expf(lg[c] - mx) / se;
-      gv[c] = gw * ((c == n ? 1.0f : 0.0f) - sm) * delu_from_out(lg[c]);
-      atomicAdd(&fg[pc.step_prior_bias + c], gv[c]);
-      if (t_global > 0) atomicAdd(&fg[pc.step_prior_tbias + c], gv[c]);
-      atomicAdd(&fg[pc.sp_l1_b + c], gv[c]);
+    float mx = lg;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));   // classes sit on lanes 0 .. N <= 8
+    const float ex = lane < N1 ? expf(lg - mx) : 0.0f;
+    const float se = sq_wave_sum(ex);
+    if (lane < N1) {
+      const float gv = gw * ((lane == n ? 1.0f : 0.0f) - ex / se) * delu_from_out(lg);
+      gv_s[lane] = gv;
+      atomicAdd(&fg[pc.step_prior_bias + lane], gv);
+      if (t_global > 0) atomicAdd(&fg[pc.step_prior_tbias + lane], gv);
+      atomicAdd(&fg[pc.sp_l1_b + lane], gv);
     }
-    for (int i = 0; i < 10; ++i) {
+    __builtin_amdgcn_wave_barrier();
+    for (int q = lane; q < 10 * N1; q += 64) atomicAdd(&fg[pc.sp_l1_w + q], hid_s[q / N1] * gv_s[q % N1]);
+    float de = 0.0f;
+    if (lane < 10) {
       float gh = 0.0f;
-      for (int c = 0; c <= N; ++c) {
-        atomicAdd(&fg[pc.sp_l1_w + i * (N + 1) + c], hid[i] * gv[c]);
-        gh += flat[pc.sp_l1_w + i * (N + 1) + c] * gv[c];
-      }
-      const float ghp = gh * delu_from_out(hid[i]);
-      atomicAdd(&fg[pc.sp_l0_w + i], e_sum * ghp);
-      atomicAdd(&fg[pc.sp_l0_b + i], ghp);
-      d_e += flat[pc.sp_l0_w + i] * ghp;
+      for (int c = 0; c < N1; ++c) gh += flat[pc.sp_l1_w + lane * N1 + c] * gv_s[c];
+      const float ghp = gh * delu_from_out(hid);
+      atomicAdd(&fg[pc.sp_l0_w + lane], e_sum * ghp);
+      atomicAdd(&fg[pc.sp_l0_b + lane], ghp);
+      de = flat[pc.sp_l0_w + lane] * ghp;
     }
+    d_e += sq_wave_sum(de);
   }
-  d_e = __shfl(d_e, 0, 64);
-  // ---------------- propagation
-  for (int k = 0; k < N; ++k) {
-    const float* rp = a.rec_p + (fs + k) * RW;
-    const float* rm = a.rec_m + (fs + k) * RW;
-    const float* ps = a.pstats + (fs + k) * a.ps_ld;
-    float* drp = a.d_rec_p + (fs + k) * RW;
-    float* drm = a.d_rec_m + (fs + k) * RW;
-    float* dps = a.d_pstats + (fs + k) * a.ps_ld;
+  if (lane == 0) de_s[1] = d_e;
+  }  // wave 1
+  // ---------------- all waves: q what, p what of the propagated slots
+  for (int k = wave; k < N; k += 4) {
+    const float* rp = rp_s + k * RW;
+    const float* rm = rm_s + k * MW;
+    const float* ps = ps_s + k * a.ps_ld;
+    float* drp = drp_s + k * RW;
+    float* drm = drm_s + k * MW;
+    float* dps = dps_s + k * a.ps_ld;
     const float pres = rp[rec::PRES], pres_tm1 = rm[rec::PRES];
     const float m = pres_tm1 * pres;
     const float cq = -gw * m, cp = gw * m;
-    for (int i = lane; i < a.ps_ld; i += 64) dps[i] = 0.0f;
-    __syncthreads();
     if (lane < nw) {
       const float x = rp[rec::WHAT + lane];
       const float loc = rp[rec::WHAT_LOC + lane], sc = rp[rec::WHAT_SCALE + lane];
@@ -1024,85 +1061,119 @@ __global__ __launch_bounds__(64) void k_logprob_bwd(const LogprobBwdArgs a, cons
       else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHAT + lane] + 0.1f * ploc;
       const float praw = ps[9 + nw + lane];
       const float psc = sq_softplus(praw) + 1e-2f;
-      unsafeAtomicAdd(&drp[rec::WHAT + lane], cq * dnormal_dx(x, loc, sc) + cp * dnormal_dx(x, ploc, psc));
-      unsafeAtomicAdd(&drp[rec::WHAT_LOC + lane], -cq * dnormal_dx(x, loc, sc));
-      unsafeAtomicAdd(&drp[rec::WHAT_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
+      atomicAdd(&drp[rec::WHAT + lane], cq * dnormal_dx(x, loc, sc) + cp * dnormal_dx(x, ploc, psc));
+      atomicAdd(&drp[rec::WHAT_LOC + lane], -cq * dnormal_dx(x, loc, sc));
+      atomicAdd(&drp[rec::WHAT_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
       const float g_ploc = -cp * dnormal_dx(x, ploc, psc);
       if (a.cfg.prop_prior_type == 0) dps[5 + lane] = g_ploc;
       else {
-        unsafeAtomicAdd(&drm[rec::WHAT + lane], g_ploc);
+        atomicAdd(&drm[rec::WHAT + lane], g_ploc);
         if (a.cfg.prop_prior_type == 2) dps[5 + lane] = 0.1f * g_ploc;
       }
       dps[9 + nw + lane] = cp * dnormal_dsc(x, ploc, psc) * sq_sigmoid(praw);
     }
-    if (lane < 4) {
-      const float x = rp[rec::WHERE + lane];
-      float ploc = ps[1 + lane];
-      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHERE + lane];
-      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHERE + lane] + 0.1f * ploc;
-      const float praw = ps[5 + nw + lane];
-      const float psc = sq_softplus(praw) + 1e-2f;
-      unsafeAtomicAdd(&drp[rec::WHERE + lane], cp * dnormal_dx(x, ploc, psc));
-      const float g_ploc = -cp * dnormal_dx(x, ploc, psc);
-      if (a.cfg.prop_prior_type == 0) dps[1 + lane] = g_ploc;
-      else {
-        unsafeAtomicAdd(&drm[rec::WHERE + lane], g_ploc);
-        if (a.cfg.prop_prior_type == 2) dps[1 + lane] = 0.1f * g_ploc;
-      }
-      dps[5 + nw + lane] = cp * dnormal_dsc(x, ploc, psc) * sq_sigmoid(praw);
+  }
+  // ---------------- wave 2: p where and the MultivariateNormalTriL posterior of where
+  if (wave == 2 && lane < 4 * N) {
+    const int k = lane >> 2, ci = lane & 3;
+    const float* rp = rp_s + k * RW;
+    const float* rm = rm_s + k * MW;
+    const float* ps = ps_s + k * a.ps_ld;
+    float* dps = dps_s + k * a.ps_ld;
+    const float cp = gw * rm[rec::PRES] * rp[rec::PRES];
+    const float x = rp[rec::WHERE + ci];
+    float ploc = ps[1 + ci];
+    if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHERE + ci];
+    else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHERE + ci] + 0.1f * ploc;
+    const float praw = ps[5 + nw + ci];
+    const float psc = sq_softplus(praw) + 1e-2f;
+    atomicAdd(&drp_s[k * RW + rec::WHERE + ci], cp * dnormal_dx(x, ploc, psc));
+    const float g_ploc = -cp * dnormal_dx(x, ploc, psc);
+    if (a.cfg.prop_prior_type == 0) dps[1 + ci] = g_ploc;
+    else {
+      atomicAdd(&drm_s[k * MW + rec::WHERE + ci], g_ploc);
+      if (a.cfg.prop_prior_type == 2) dps[1 + ci] = 0.1f * g_ploc;
     }
-    if (lane == 0) {
-      // MultivariateNormalTriL posterior of where: L = T * sc[:,None] + diag(sc)
-      const float* ch = flat + pc.cholesky;
-      float L[4][4], y[4], u[4], dd[4];
-      for (int i = 0; i < 4; ++i) {
-        const float sci = rp[rec::WHERE_SCALE + i];
-        for (int j = 0; j < 4; ++j) L[i][j] = j <= i ? tril4(ch, i, j) * sci + (i == j ? sci : 0.0f) : 0.0f;
-        dd[i] = rp[rec::WHERE + i] - rp[rec::WHERE_LOC + i];
-      }
-      for (int i = 0; i < 4; ++i) {
-        float acc = dd[i];
-        for (int j = 0; j < i; ++j) acc -= L[i][j] * y[j];
-        y[i] = acc / L[i][i];
-      }
-      for (int i = 3; i >= 0; --i) {  // L^T u = y
-        float acc = y[i];
-        for (int j = i + 1; j < 4; ++j) acc -= L[j][i] * u[j];
-        u[i] = acc / L[i][i];
-      }
-      for (int i = 0; i < 4; ++i) {
-        unsafeAtomicAdd(&drp[rec::WHERE + i], cq * (-u[i]));
-        unsafeAtomicAdd(&drp[rec::WHERE_LOC + i], cq * u[i]);
-        const float sci = rp[rec::WHERE_SCALE + i];
-        float dsc = 0.0f;
-        for (int j = 0; j <= i; ++j) {
-          const float dL = u[i] * y[j] - (i == j ? 1.0f / L[i][i] : 0.0f);
-          const float tij = tril4(ch, i, j);
-          dsc += dL * (tij + (i == j ? 1.0f : 0.0f));
-          const int q = i * 4 + j;  // fill_triangular index -> cholesky_scale element
-          atomicAdd(&fg[pc.cholesky + (q < 6 ? 4 + q : 15 - q)], cq * dL * sci);
-        }
-        unsafeAtomicAdd(&drp[rec::WHERE_SCALE + i], cq * dsc);
-      }
-      // presence Bernoullis and the prior logit (incl. its path through e_sum)
-      const float logit = rp[rec::LOGIT];
-      unsafeAtomicAdd(&drp[rec::LOGIT], (-gw + gd) * pres_tm1 * (pres - sq_sigmoid(logit)));
-      const float spl = sq_sigmoid(pl[k]);
-      float g_pl = gw * pres_tm1 * (pres - spl) + d_e * spl * (1.0f - spl) / (float)N;
-      if (a.cfg.prop_prior_type != 0) {
-        unsafeAtomicAdd(&drm[rec::LOGIT], g_pl);
-        g_pl *= 0.1f;
-      }
-      dps[0] = g_pl * pres_tm1;
+    dps[5 + nw + ci] = cp * dnormal_dsc(x, ploc, psc) * sq_sigmoid(praw);
+  }
+  if (wave == 2 && lane < N) {
+    const int k = lane;
+    const float* rp = rp_s + k * RW;
+    const float* rm = rm_s + k * MW;
+    float* drp = drp_s + k * RW;
+    const float pres = rp[rec::PRES], pres_tm1 = rm[rec::PRES];
+    const float cq = -gw * pres_tm1 * pres;
+    // L = T * sc[:,None] + diag(sc)
+    const float* ch = flat + pc.cholesky;
+    float L[4][4], y[4], u[4], dd[4];
+    for (int i = 0; i < 4; ++i) {
+      const float sci = rp[rec::WHERE_SCALE + i];
+      for (int j = 0; j < 4; ++j) L[i][j] = j <= i ? tril4(ch, i, j) * sci + (i == j ? sci : 0.0f) : 0.0f;
+      dd[i] = rp[rec::WHERE + i] - rp[rec::WHERE_LOC + i];
     }
-    __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+      float acc = dd[i];
+      for (int j = 0; j < i; ++j) acc -= L[i][j] * y[j];
+      y[i] = acc / L[i][i];
+    }
+    for (int i = 3; i >= 0; --i) {  // L^T u = y
+      float acc = y[i];
+      for (int j = i + 1; j < 4; ++j) acc -= L[j][i] * u[j];
+      u[i] = acc / L[i][i];
+    }
+    for (int i = 0; i < 4; ++i) {
+      atomicAdd(&drp[rec::WHERE + i], cq * (-u[i]));
+      atomicAdd(&drp[rec::WHERE_LOC + i], cq * u[i]);
+      const float sci = rp[rec::WHERE_SCALE + i];
+      float dsc = 0.0f;
+      for (int j = 0; j <= i; ++j) {
+        const float dL = u[i] * y[j] - (i == j ? 1.0f / L[i][i] : 0.0f);
+        const float tij = tril4(ch, i, j);
+        dsc += dL * (tij + (i == j ? 1.0f : 0.0f));
+        const int q = i * 4 + j;  // fill_triangular index -> cholesky_scale element
+        atomicAdd(&fg[pc.cholesky + (q < 6 ? 4 + q : 15 - q)], cq * dL * sci);
+      }
+      atomicAdd(&drp[rec::WHERE_SCALE + i], cq * dsc);
+    }
   }
   __syncthreads();
-  for (int sgi = 0; sgi < tab.n; ++sgi)
-    for (int i = threadIdx.x; i < tab.len[sgi]; i += 64) {
-      const float g = gl[tab.dst[sgi] + i];
-      if (g != 0.0f) unsafeAtomicAdd(a.flat_grad + tab.src[sgi] + i, g);
+  if (wave == 2 && lane < N) {
+    // presence Bernoullis and the prior logit (incl. its path through e_sum: both pieces of d e_sum are in LDS now)
+    const int k = lane;
+    const float* rp = rp_s + k * RW;
+    const float* rm = rm_s + k * MW;
+    float* drp = drp_s + k * RW;
+    const float pres = rp[rec::PRES], pres_tm1 = rm[rec::PRES];
+    const float d_e = (a.cfg.rec_where_prior ? de_s[0] : 0.0f) + (a.cfg.disc_prior_type == 0 ? de_s[1] : 0.0f);
+    const float logit = rp[rec::LOGIT];
+    atomicAdd(&drp[rec::LOGIT], (-gw + gd) * pres_tm1 * (pres - sq_sigmoid(logit)));
+    const float spl = sq_sigmoid(pl_k);
+    float g_pl = gw * pres_tm1 * (pres - spl) + d_e * spl * (1.0f - spl) / (float)N;
+    if (a.cfg.prop_prior_type != 0) {
+      atomicAdd(&drm_s[k * MW + rec::LOGIT], g_pl);
+      g_pl *= 0.1f;
     }
+    dps_s[k * a.ps_ld] = g_pl * pres_tm1;
+  }
+  __syncthreads();
+  for (int i = tid; i < N * RW; i += 256) {   // (the gradient records are accumulated into: the dX launches add to them too)
+    const float gd_ = drd_s[i], gp_ = drp_s[i];
+    if (gd_ != 0.0f) unsafeAtomicAdd(a.d_rec_d + fs * RW + i, gd_);
+    if (gp_ != 0.0f) unsafeAtomicAdd(a.d_rec_p + fs * RW + i, gp_);
+  }
+  for (int i = tid; i < N * MW; i += 256) {
+    const int k = i / MW, q = i - k * MW;
+    const float gm_ = drm_s[i];
+    if (gm_ != 0.0f) unsafeAtomicAdd(a.d_rec_m + (fs + k) * RW + q, gm_);
+  }
+  for (int i = tid; i < N * a.ps_ld; i += 256) a.d_pstats[fs * a.ps_ld + i] = dps_s[i];
+#pragma unroll
+  for (int sgi = 0; sgi < 16; ++sgi)
+    if (sgi < tab.n)
+      for (int i = tid; i < tab.len[sgi]; i += 256) {
+        const float g = gl[tab.dst[sgi] + i];
+        if (g != 0.0f) unsafeAtomicAdd(a.flat_grad + tab.src[sgi] + i, g);
+      }
 }
 
 int sq_launch_logprob_bwd(const LogprobBwdArgs& a, POff po, Dims d, int T, hipStream_t s) {
@@ -1134,7 +1205,9 @@ int sq_launch_logprob_bwd(const LogprobBwdArgs& a, POff po, Dims d, int T, hipSt
   cp.step_prior_tbias = seg(po.step_prior_tbias, N1);
   cp.cholesky = seg(po.cholesky, 10);
   if (o > SQ_SMALL_MAX) return -1;
-  SQ_LAUNCH(k_logprob_bwd, dim3(d.R, T), dim3(64), 0, s, a, cp, tab, d);
+  tab.total = o;
+  const size_t shm = (4 * (size_t)d.N * rec::W + 2 * (size_t)d.N * rec::ZW + 2 * (size_t)d.N * a.ps_ld + 2 * (size_t)o) * sizeof(float);
+  SQ_LAUNCH(k_logprob_bwd, dim3(d.R, T), dim3(256), shm, s, a, cp, tab, d);
   return 0;
 }
 

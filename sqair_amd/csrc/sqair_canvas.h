@@ -1,0 +1,152 @@
+// Decoder canvas building blocks shared by k_insert_loglik (sqair_glue.hip) and its adjoint k_insert_loglik_bwd
+// (sqair_bwd.hip).  reference: AIRDecoder._decode sqair/modules.py:435-467 (inverse spatial transformer of the N
+// decoded glimpses onto the canvas + the written-to mask).
+//
+// A glimpse covers a small axis-aligned BOX of the canvas (the inverse warp is separable and monotone per axis), so the
+// canvas is built slot by slot over each slot's box, 256 threads as a 32 x 8 patch, into an LDS band of at most
+// SQ_CANVAS_BAND_PIXELS pixels (whole rows; the 50 x 50 frame is one band, a 128 x 128 frame eight).  Until round 3
+// every pixel walked all N slots: with consecutive pixels on a wavefront's lanes a wave ran a slot's bilinear body
+// whenever ANY of its 64 pixels was inside that box -- 2.7x the useful work at 50 x 50, far more at 128 x 128.
+#pragma once
+#include "sqair_common.h"
+
+constexpr int SQ_CANVAS_PF = 10;                               // frame / mean-image values a thread holds per band
+constexpr int SQ_CANVAS_BAND_PIXELS = 256 * SQ_CANVAS_PF;
+
+// rows per band for a W-wide frame: as many whole rows as fit SQ_CANVAS_BAND_PIXELS (host + device agree through the argument)
+static inline int sq_canvas_band_rows(int H, int W) {
+  int rows = SQ_CANVAS_BAND_PIXELS / W;
+  if (rows < 1) rows = 1;
+  return rows < H ? rows : H;
+}
+
+struct CanvasLds {
+  float* gl;    // [N][G2]  glimpses
+  float* xt;    // [N][W]   glimpse x coordinate of every canvas column
+  float* yt;    // [N][H]   glimpse y coordinate of every canvas row
+  float* pres;  // [N]
+  float* co;    // [N][4]   sx, sy, tx, ty
+  int* box;     // [N][4]   first / last column, first / last row with a coordinate in (-1, G); empty: last < first
+  float* cv;    // [band]   canvas (adjoint kernel: then its gradient)
+  float* ms;    // [band]   written-to mask sum (adjoint kernel: then its gradient)
+  float* end;
+};
+__host__ __device__ static inline size_t sq_canvas_lds_floats(int N, int G, int H, int W, int band_rows) {
+  return (size_t)N * G * G + (size_t)N * (W + H) + N + 4 * N + 4 * N + 2 * (size_t)band_rows * W;
+}
+__device__ __forceinline__ CanvasLds sq_canvas_carve(float* smem, int N, int G, int H, int W, int band_rows) {
+  CanvasLds c;
+  c.gl = smem;
+  c.xt = c.gl + N * G * G;
+  c.yt = c.xt + N * W;
+  c.pres = c.yt + N * H;
+  c.co = c.pres + N;
+  c.box = reinterpret_cast<int*>(c.co + 4 * N);
+  c.cv = reinterpret_cast<float*>(c.box + 4 * N);
+  c.ms = c.cv + band_rows * W;
+  c.end = c.ms + band_rows * W;
+  return c;
+}
+
+__device__ __forceinline__ bool sq_canvas_inside(float g, int G) { return g > -1.0f && g < (float)G; }
+
+// glimpses, presences, transform coefficients, the two coordinate tables and the boxes of one row; ends on a barrier.
+// where0 / pres0 point at slot 0's four where logits / presence, *_ld floats between slots.
+__device__ __forceinline__ void sq_canvas_prologue(const CanvasLds& c, const float* __restrict__ glimpse, const float* __restrict__ where0,
+                                                   int where_ld, const float* __restrict__ pres0, int pres_ld, int N, int G, int H, int W) {
+  const int tid = threadIdx.x, G2 = G * G;
+  for (int i = tid; i < N * G2; i += 256) c.gl[i] = glimpse[i];
+  if (tid < N * 4) {
+    const int k = tid >> 2, q = tid & 3;
+    const float l = where0[(size_t)k * where_ld + q];
+    c.co[tid] = (q & 2) ? tanhf(l) : fmaxf(sq_sigmoid_geo(l), 1e-4f);
+    c.box[tid] = (q & 1) ? -1 : 0;
+  }
+  if (tid < N) c.pres[tid] = pres0[(size_t)tid * pres_ld];
+  __syncthreads();
+  for (int i = tid; i < N * (W + H); i += 256) {
+    const int k = i / (W + H), q = i - k * (W + H);
+    const bool is_y = q >= W;
+    const int j = is_y ? q - W : q;
+    const float sc = c.co[k * 4 + (is_y ? 1 : 0)], tr = c.co[k * 4 + (is_y ? 3 : 2)];
+    const float L = (float)((is_y ? H : W) - 1);
+    const float cn = -1.0f + 2.0f * (float)j / L;
+    const float g = 0.5f * (float)(G - 1) * ((cn - tr) / sc + 1.0f);
+    if (is_y) c.yt[k * H + j] = g; else c.xt[k * W + j] = g;
+  }
+  __syncthreads();
+  // the coordinate grows with the pixel index (scale > 0), so the pixels inside are one run: its two ends have one writer each
+  for (int i = tid; i < N * (W + H); i += 256) {
+    const int k = i / (W + H), q = i - k * (W + H);
+    const bool is_y = q >= W;
+    const int j = is_y ? q - W : q, L = is_y ? H : W;
+    const float* t = is_y ? c.yt + k * H : c.xt + k * W;
+    if (sq_canvas_inside(t[j], G)) {
+      if (j == 0 || !sq_canvas_inside(t[j - 1], G)) c.box[k * 4 + (is_y ? 2 : 0)] = j;
+      if (j == L - 1 || !sq_canvas_inside(t[j + 1], G)) c.box[k * 4 + (is_y ? 3 : 1)] = j;
+    }
+  }
+  __syncthreads();
+}
+
+// bilinear value of glimpse gk and of a glimpse of ones at (xg, yg), both coordinates inside (-1, G): taps outside the glimpse are zero
+__device__ __forceinline__ void sq_canvas_tap(const float* __restrict__ gk, float xg, float yg, int G, float& v, float& on) {
+  const float x0f = floorf(xg), y0f = floorf(yg);
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const float wx1 = xg - x0f, wy1 = yg - y0f;
+  v = 0.0f;
+  on = 0.0f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    const int yy = y0 + dy;
+    if (yy < 0 || yy >= G) continue;
+    const float wy = dy ? wy1 : 1.0f - wy1;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int xx = x0 + dx;
+      if (xx < 0 || xx >= G) continue;
+      const float w = wy * (dx ? wx1 : 1.0f - wx1);
+      v += w * gk[yy * G + xx];
+      on += w;
+    }
+  }
+}
+
+// wave-uniform copies of slot k's presence and of its box clipped to rows [yb0, yb1]; false: nothing of the slot in the band
+struct CanvasSlot { float pk; int x0, x1, y0, y1; };
+__device__ __forceinline__ bool sq_canvas_slot(const CanvasLds& c, int k, int yb0, int yb1, CanvasSlot& s) {
+  s.pk = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, c.pres[k])));
+  s.x0 = __builtin_amdgcn_readfirstlane(c.box[k * 4 + 0]);
+  s.x1 = __builtin_amdgcn_readfirstlane(c.box[k * 4 + 1]);
+  s.y0 = max(__builtin_amdgcn_readfirstlane(c.box[k * 4 + 2]), yb0);
+  s.y1 = min(__builtin_amdgcn_readfirstlane(c.box[k * 4 + 3]), yb1);
+  return s.pk != 0.0f && s.x1 >= s.x0 && s.y1 >= s.y0;
+}
+
+// canvas and mask sum of rows [yb0, yb1] into c.cv / c.ms (slots added in index order, as the reference's sum over objects);
+// ends on a barrier
+__device__ __forceinline__ void sq_canvas_band(const CanvasLds& c, int yb0, int yb1, int N, int G, int H, int W) {
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const int n = (yb1 - yb0 + 1) * W;
+  for (int i = tid; i < n; i += 256) {
+    c.cv[i] = 0.0f;
+    c.ms[i] = 0.0f;
+  }
+  __syncthreads();
+  for (int k = 0; k < N; ++k) {
+    CanvasSlot s;
+    if (!sq_canvas_slot(c, k, yb0, yb1, s)) continue;
+    const float* gk = c.gl + k * G * G;
+    for (int Y = s.y0 + ty; Y <= s.y1; Y += 8) {
+      const float yg = c.yt[k * H + Y];
+      for (int X = s.x0 + tx; X <= s.x1; X += 32) {
+        float v, on;
+        sq_canvas_tap(gk, c.xt[k * W + X], yg, G, v, on);
+        const int o = (Y - yb0) * W + X;
+        c.cv[o] += v * s.pk;
+        c.ms[o] += on * s.pk;
+      }
+    }
+    __syncthreads();
+  }
+}

@@ -224,6 +224,16 @@ __device__ __forceinline__ float tril4(const float* __restrict__ v, int i, int j
   const int q = i * 4 + j;
   return q < 6 ? v[4 + q] : v[15 - q];
 }
+// n floats from global memory into LDS on the LDS-DMA path (global_load_lds_dword: no registers, nothing waits until the
+// barrier ahead of the first reader, so every trip of every array staged this way is in flight together).  Wave `wave` of
+// `n_waves` takes the 64-element trips wave, wave + n_waves, ...; lane l of a trip moves element base + l, the trip's LDS
+// destination is wave-uniform + 4 l bytes; lanes past n are masked off.
+__device__ __forceinline__ void sq_wave_stage(float* lds_dst, const float* __restrict__ src, int n, int lane, int wave = 0, int n_waves = 1) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  for (int base = 64 * wave; base < n; base += 64 * n_waves)
+    if (base + lane < n) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + base + lane), (lds_ptr_t)(lds_dst + base), 4, 0, 0);
+}
 __device__ __forceinline__ float sq_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

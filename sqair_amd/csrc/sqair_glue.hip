@@ -3,6 +3,7 @@
 // reductions.  All HBM-bound gather / scatter / reduce work (class 2).
 #include "sqair_glue.h"
 #include "sqair_rowops.h"
+#include "sqair_canvas.h"
 
 // ------------------------------------------------------------------------------------------------
 // initial recurrent state (reference: sqair/seq.py:86-100, sqair_modules.py:352-366, core.py:156-162)
@@ -382,8 +383,11 @@ int sq_launch_latent_sum(const float* f, const float* rec_p, float* c, Dims d, h
 __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff po, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
   // Everything a row needs (3N slot records, N prior-stat rows, the conditioning state and ~1k small-layer
-  // parameters) is pulled into LDS by all 256 threads in one burst of independent loads; wavefront 0 then
-  // evaluates the densities from LDS.  (A direct global-memory walk was ~20 dependent round trips = 27 us.)
+  // parameters) is pulled into LDS by all 256 threads in one burst of independent loads (a direct global-memory
+  // walk was ~20 dependent round trips = 27 us); the four wavefronts then share the slots -- wave w evaluates
+  // propagation slots w, w + 4, ... and, once e_sum is known, discovery slots w, w + 4, ... -- and leave the per-slot
+  // terms in LDS, which thread 0 sums in slot order (the order the single wave of rounds 1-2 summed them in, whose
+  // ~3500 dependent instructions were 26 of the kernel's 29 us).
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int r = blockIdx.x;
   const int fr = blockIdx.y;               // frame (the launch covers all T frames of the pass)
@@ -406,12 +410,10 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
   float* spb_s = sp1_s + 11 * (N + 1);     // 2*(N+1)
   float* ch_s = spb_s + 2 * (N + 1);       // 10
   const float* __restrict__ flat = a.flat;
-  for (int i = tid; i < N * RW; i += 256) {
-    recp_s[i] = a.rec_p[(fs + (size_t)r * N) * RW + i];
-    recd_s[i] = a.rec_d[(fs + (size_t)r * N) * RW + i];
-    recm_s[i] = a.rec_prev[(fs + (size_t)r * N) * RW + i];
-  }
-  for (int i = tid; i < N * a.ps_ld; i += 256) ps_s[i] = a.pstats[(fs + (size_t)r * N) * a.ps_ld + i];
+  sq_wave_stage(recp_s, a.rec_p + (fs + (size_t)r * N) * RW, N * RW, tid & 63, tid >> 6, 4);
+  sq_wave_stage(recd_s, a.rec_d + (fs + (size_t)r * N) * RW, N * RW, tid & 63, tid >> 6, 4);
+  sq_wave_stage(recm_s, a.rec_prev + (fs + (size_t)r * N) * RW, N * RW, tid & 63, tid >> 6, 4);
+  sq_wave_stage(ps_s, a.pstats + (fs + (size_t)r * N) * a.ps_ld, N * a.ps_ld, tid & 63, tid >> 6, 4);
   if (a.cfg.rec_where_prior) {
     if (tid < 128) {
       spre_s[tid] = a.spre[((size_t)fr * d.R + r) * 128 + tid];
@@ -430,15 +432,14 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
     spb_s[tid] = flat[po.step_prior_bias + tid];
     spb_s[N + 1 + tid] = flat[po.step_prior_tbias + tid];
   }
+  __shared__ float prop_s[SQ_MAXN][6], disc_s[SQ_MAXN][3];
   __syncthreads();
-  if (tid >= 64) return;
-  const int lane = tid;
+  const int lane = tid & 63, wave = tid >> 6;
   const size_t tr = (size_t)(a.t + fr) * d.R + r;
   const int t_global = a.t_global + fr;
   const float LOG2PI = 1.83787706640934548356f;
 
-  float e_sum = 0.0f, q_prop = 0.0f, p_prop = 0.0f, q_pres_sum = 0.0f, p_pres_sum = 0.0f, n_prop = 0.0f;
-  for (int k = 0; k < N; ++k) {
+  for (int k = wave; k < N; k += 4) {
     const float* rp = recp_s + k * RW;
     const float* rm = recm_s + k * RW;
     const float* ps = ps_s + k * a.ps_ld;
@@ -498,14 +499,17 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
       if (a.out.prop_where_prior_log_prob) a.out.prop_where_prior_log_prob[o] = p_where * m;
       if (a.out.prop_prob) a.out.prop_prob[o] = expf(q_pres) * pres_tm1;
       if (a.out.prop_pres) a.out.prop_pres[o] = pres_hidden;
+      prop_s[k][0] = (q_what + q_where) * m;
+      prop_s[k][1] = (p_what + p_where) * m;
+      prop_s[k][2] = q_pres * pres_tm1;
+      prop_s[k][3] = p_pres * pres_tm1;
+      prop_s[k][4] = (sq_sigmoid(pl) - 0.5f) / (float)N;
+      prop_s[k][5] = pres;
     }
-    q_prop += (q_what + q_where) * m;
-    p_prop += (p_what + p_where) * m;
-    q_pres_sum += q_pres * pres_tm1;
-    p_pres_sum += p_pres * pres_tm1;
-    e_sum += (sq_sigmoid(pl) - 0.5f) / (float)N;
-    n_prop += pres;
   }
+  __syncthreads();
+  float e_sum = 0.0f;
+  for (int k = 0; k < N; ++k) e_sum += prop_s[k][4];
 
   // ---- discovery
   float hs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -517,12 +521,9 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
     }
     for (int jj = 0; jj < 4; ++jj) hs[jj] = sq_wave_sum(part[jj]) + h2h_s[512 + jj] + i2h_s[16 + jj];
   }
-  float q_disc = 0.0f, p_disc = 0.0f, n_disc = 0.0f;
-  double probs[SQ_MAXN];
-  for (int j = 0; j < N; ++j) {
+  for (int j = wave; j < N; j += 4) {
     const float* rd = recd_s + j * RW;
     const float pres = rd[rec::PRES];
-    probs[j] = (double)rd[rec::PROB];
     float qw = 0.0f, pw = 0.0f;
     if (lane < nw) {
       const float x = rd[rec::WHAT + lane];
@@ -560,15 +561,30 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
       if (a.out.disc_what_prior_log_prob) a.out.disc_what_prior_log_prob[o] = p_what * pres;
       if (a.out.disc_where_prior_log_prob) a.out.disc_where_prior_log_prob[o] = p_where * pres;
       if (a.out.disc_pres) a.out.disc_pres[o] = pres;
+      disc_s[j][0] = (q_what + q_where) * pres;
+      disc_s[j][1] = (p_what + p_where) * pres;
+      // num_steps is what discovery itself inferred (sqair_modules.py:146), also when the frame is generated and the
+      // hidden presence has been zeroed
+      const bool generated = a.gen != nullptr && a.cfg.generate_after > 0 && t_global > a.cfg.generate_after;
+      disc_s[j][2] = generated ? a.gen[(fs + (size_t)r * N + j) * gen::W + gen::ORIG_DPRES] : pres;
     }
-    q_disc += (q_what + q_where) * pres;
-    p_disc += (p_what + p_where) * pres;
-    // num_steps is what discovery itself inferred (sqair_modules.py:146), also when the frame is generated and the
-    // hidden presence has been zeroed
-    const bool generated = a.gen != nullptr && a.cfg.generate_after > 0 && t_global > a.cfg.generate_after;
-    n_disc += generated ? a.gen[(fs + (size_t)r * N + j) * gen::W + gen::ORIG_DPRES] : pres;
   }
-  if (lane != 0) return;
+  __syncthreads();
+  if (tid != 0) return;
+  float q_prop = 0.0f, p_prop = 0.0f, q_pres_sum = 0.0f, p_pres_sum = 0.0f, n_prop = 0.0f;
+  float q_disc = 0.0f, p_disc = 0.0f, n_disc = 0.0f;
+  double probs[SQ_MAXN];
+  for (int k = 0; k < N; ++k) {
+    q_prop += prop_s[k][0];
+    p_prop += prop_s[k][1];
+    q_pres_sum += prop_s[k][2];
+    p_pres_sum += prop_s[k][3];
+    n_prop += prop_s[k][5];
+    q_disc += disc_s[k][0];
+    p_disc += disc_s[k][1];
+    n_disc += disc_s[k][2];
+    probs[k] = (double)recd_s[k * RW + rec::PROB];
+  }
   // NumStepsDistribution (float64 inside, prior.py:61-67)
   const int n = (int)(n_disc + 0.5f);
   double joint[SQ_MAXN + 1];
@@ -855,91 +871,48 @@ int sq_launch_compact(const CompactArgs& a, POff po, Dims d, hipStream_t s) {
 // Decoder back end: inverse spatial transformer of the N decoded glimpses onto the canvas, the
 // written-to mask, mean image, Gaussian log-likelihood and the frame log-weight, fused.
 // reference: AIRDecoder._decode/_add_mean_image/_build sqair/modules.py:435-467,
-// SequentialAIR._compute_log_weights sqair/seq.py:271-276.  One workgroup per row b'; the N
-// glimpses sit in LDS, every thread owns canvas pixels and gathers (inverse map) from them, so the
-// canvas is written at most once and the frame is read once.
+// SequentialAIR._compute_log_weights sqair/seq.py:271-276.  One workgroup per (row b', frame); the N
+// glimpses sit in LDS, the canvas is built band by band over the slots' boxes (sqair_canvas.h), then
+// every thread finishes its pixels of the band: the canvas is written at most once, the frame read once.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const Dims d SQ_TLP) {
+__global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const Dims d, const int band_rows SQ_TLP) {
   SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.N, G = d.G, G2 = d.G * d.G, H = d.H, W = d.W, P = d.H * d.W;
-  float* gl_s = smem;                 // N * G2
-  float* xt_s = gl_s + N * G2;        // N * W  glimpse x coordinate per canvas column
-  float* yt_s = xt_s + N * W;         // N * H
-  float* pres_s = yt_s + N * H;       // N
+  const CanvasLds c = sq_canvas_carve(smem, N, G, H, W, band_rows);
   __shared__ float red_s[4];
   const int r = blockIdx.x, tid = threadIdx.x;
   const int fr = blockIdx.y;  // frame
   const int b = r / d.K;
-  const size_t fs = (size_t)fr * d.R * N;
-  for (int i = tid; i < N * G2; i += 256) gl_s[i] = a.glimpse[(fs + (size_t)r * N) * G2 + i];
-  for (int i = tid; i < N * (W + H); i += 256) {
-    const int k = i / (W + H), q = i % (W + H);
-    const bool is_y = q >= W;
-    const int j = is_y ? q - W : q;
-    const float* wl = a.rec ? a.rec + (fs + (size_t)r * N + k) * a.rec_ld + rec::WHERE : a.where_plain + ((size_t)r * N + k) * 4;
-    const float sc = fmaxf(sq_sigmoid_geo(wl[is_y ? 1 : 0]), 1e-4f);
-    const float tr = tanhf(wl[is_y ? 3 : 2]);
-    const float L = (float)((is_y ? H : W) - 1);
-    const float cn = -1.0f + 2.0f * (float)j / L;
-    const float g = 0.5f * (float)(G - 1) * ((cn - tr) / sc + 1.0f);
-    if (is_y) yt_s[k * H + j] = g; else xt_s[k * W + j] = g;
-  }
-  if (tid < N) pres_s[tid] = a.rec ? a.rec[(fs + (size_t)r * N + tid) * a.rec_ld + rec::PRES] : a.pres_plain[(size_t)r * N + tid];
-  __syncthreads();
+  const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot of this (frame, row)
   const float* __restrict__ img = a.img + ((size_t)fr * d.B + b) * P;
   const size_t frr = (size_t)fr * d.R + r;
   const float qv = a.qz != nullptr ? a.qz[frr] : 0.0f, pv = a.qz != nullptr ? a.pz[frr] : 0.0f;  // requested early
+  if (a.rec) sq_canvas_prologue(c, a.glimpse + fs * G2, a.rec + fs * a.rec_ld + rec::WHERE, a.rec_ld, a.rec + fs * a.rec_ld + rec::PRES, a.rec_ld, N, G, H, W);
+  else sq_canvas_prologue(c, a.glimpse + fs * G2, a.where_plain + (size_t)r * N * 4, 4, a.pres_plain + (size_t)r * N, 1, N, G, H, W);
   float ll = 0.0f;
-  constexpr int PF = 10;  // pixels per thread whose frame / mean-image values are requested together
-  for (int pix0 = tid; pix0 < P; pix0 += 256 * PF) {
-    float xv[PF], mv[PF];
+  for (int yb0 = 0; yb0 < H; yb0 += band_rows) {
+    const int yb1 = min(H, yb0 + band_rows) - 1, n = (yb1 - yb0 + 1) * W, pix0 = yb0 * W;
+    float xv[SQ_CANVAS_PF], mv[SQ_CANVAS_PF];  // the band's frame / mean-image values: in flight while the canvas is built
 #pragma unroll
-    for (int q = 0; q < PF; ++q) {
-      const int pix = pix0 + q * 256;
-      xv[q] = pix < P ? img[pix] : 0.0f;
-      mv[q] = pix < P ? a.mean_img[pix] : 0.0f;
+    for (int q = 0; q < SQ_CANVAS_PF; ++q) {
+      const int p = tid + q * 256;
+      xv[q] = p < n ? img[pix0 + p] : 0.0f;
+      mv[q] = p < n ? a.mean_img[pix0 + p] : 0.0f;
     }
+    sq_canvas_band(c, yb0, yb1, N, G, H, W);
 #pragma unroll
-    for (int q = 0; q < PF; ++q) {
-      const int pix = pix0 + q * 256;
-      if (pix >= P) break;
-      const int Y = pix / W, X = pix % W;
-      float cv = 0.0f, ms = 0.0f;
-      for (int k = 0; k < N; ++k) {
-        const float pk = pres_s[k];
-        if (pk == 0.0f) continue;
-        const float xg = xt_s[k * W + X], yg = yt_s[k * H + Y];
-        // fully outside the glimpse: both taps invalid on one axis
-        if (!(xg > -1.0f && xg < (float)G && yg > -1.0f && yg < (float)G)) continue;
-        const float x0f = floorf(xg), y0f = floorf(yg);
-        const int x0 = (int)x0f, y0 = (int)y0f;
-        const float wx1 = xg - x0f, wy1 = yg - y0f;
-        const float* gk = gl_s + k * G2;
-        float v = 0.0f, on = 0.0f;
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-          const int yy = y0 + dy;
-          if (yy < 0 || yy >= G) continue;
-          const float wy = dy ? wy1 : 1.0f - wy1;
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            const int xx = x0 + dx;
-            if (xx < 0 || xx >= G) continue;
-            const float w = wy * (dx ? wx1 : 1.0f - wx1);
-            v += w * gk[yy * G + xx];
-            on += w;
-          }
-        }
-        cv += v * pk;
-        ms += on * pk;
+    for (int q = 0; q < SQ_CANVAS_PF; ++q) {
+      const int p = tid + q * 256;
+      if (p < n) {
+        const float m = sq_sigmoid(-10.0f + c.ms[p] * 20.0f);
+        const float cv = c.cv[p] + mv[q] * m;
+        const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
+        ll += sq_normal_lp(xv[q], cv, sd);
+        if (a.canvas) a.canvas[frr * P + pix0 + p] = cv;
       }
-      const float m = sq_sigmoid(-10.0f + ms * 20.0f);
-      cv += mv[q] * m;
-      const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
-      ll += sq_normal_lp(xv[q], cv, sd);
-      if (a.canvas) a.canvas[frr * P + pix] = cv;
     }
+    if (yb1 + 1 < H) __syncthreads();  // the next band clears c.cv / c.ms
   }
   ll = sq_wave_sum(ll);
   if ((tid & 63) == 0) red_s[tid >> 6] = ll;
@@ -960,8 +933,15 @@ __global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const
   }
 }
 int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s) {
-  const size_t shm = ((size_t)d.N * d.G * d.G + (size_t)d.N * (d.W + d.H) + d.N) * sizeof(float);
-  SQ_LAUNCH(k_insert_loglik, dim3(d.R, a.n_frames > 0 ? a.n_frames : 1), dim3(256), shm, s, a, d);
+  const int band_rows = sq_canvas_band_rows(d.H, d.W);
+  const size_t shm = sq_canvas_lds_floats(d.N, d.G, d.H, d.W, band_rows) * sizeof(float);
+  static bool big = false;
+  if (shm > 48 * 1024 && !big) {
+    (void)hipFuncSetAttribute((const void*)k_insert_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipGetLastError();
+    big = true;
+  }
+  SQ_LAUNCH(k_insert_loglik, dim3(d.R, a.n_frames > 0 ? a.n_frames : 1), dim3(256), shm, s, a, d, band_rows);
   return 0;
 }
 

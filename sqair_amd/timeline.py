@@ -85,8 +85,13 @@ class Timeline(object):
             live = pairs[:, 0] != 0
             if not live.any():
                 continue
+            life = (pairs[live, 1] - pairs[live, 0]).astype(np.float64) * TICK_US
             rows.append(dict(kernel=kernel.strip("() "), family=family(kernel), start=int(pairs[live, 0].min()),
-                             end=int(pairs[live, 1].max()), workgroups=wgs, waves=waves))
+                             end=int(pairs[live, 1].max()), workgroups=wgs, waves=waves,
+                             # (not in the CSV) lifetimes of the waves and the spread of their starts: lifetimes ~ busy = one
+                             # latency-bound round of waves; lifetimes << busy = several rounds / throughput-bound
+                             wave_life_p50_us=float(np.median(life)), wave_life_max_us=float(life.max()),
+                             wave_start_spread_us=float((pairs[live, 0].max() - pairs[live, 0].min()) * TICK_US)))
         t_last = max(r["end"] for r in rows)
         lo = t_last - int((event_ms * 1e3 + 1500.0) / TICK_US)
         rows = [r for r in rows if r["start"] >= lo]

@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--recompute", default=None)
     ap.add_argument("--flops", type=float, default=2 * 5 * 13543744 * 320.0)
+    ap.add_argument("--waves", default=None, help="also print wave lifetimes of the dispatches whose kernel name contains this")
     args = ap.parse_args()
     if args.recompute:
         return recompute(args.recompute, args.flops)
@@ -124,6 +125,12 @@ def main():
                 frac_busy_only=per / (d["avg_busy_us"] * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 frac_whole_step=algo_flops / (ms_p[name] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS)
         res[name] = out
+        if args.waves:
+            for r in rows:
+                if args.waves in r["kernel"]:
+                    print("  {} [{}]: busy {:.2f} us, {} workgroups / {} waves, wave lifetime p50 {:.2f} max {:.2f} us, starts spread "
+                          "over {:.2f} us".format(r["kernel"], name, r["busy_us"], r["workgroups"], r["waves"], r["wave_life_p50_us"],
+                                                  r["wave_life_max_us"], r["wave_start_spread_us"]))
         TL.write_csv(rows, path, "per-dispatch timeline of one {} step, cfg-{} (T={} B={} K={} N={} {}x{}), build {}\n"
                      "stamped by the kernels (100 MHz device wall clock): start = first wave's start, end = last wave's end, "
                      "gap_before = start - previous end, slot = next start - start\n"
