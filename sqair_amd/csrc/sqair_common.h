@@ -234,9 +234,33 @@ __device__ __forceinline__ void sq_wave_stage(float* lds_dst, const float* __res
   for (int base = 64 * wave; base < n; base += 64 * n_waves)
     if (base + lane < n) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + base + lane), (lds_ptr_t)(lds_dst + base), 4, 0, 0);
 }
-__device__ __forceinline__ float sq_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane sums on the VALU (every lane of the wave active; the result in every lane of the group).  __shfl_xor is a
+// ds_bpermute_b32 -- an LDS-crossbar round trip of ~100 cycles, six of them in a row for one wave sum -- and the small
+// per-row kernels of the chain are chains of exactly such sums.  Inside a row of 16 lanes: two quad permutes, the row's half
+// mirror and mirror (DPP modifiers on the add's operand); across rows: gfx950's v_permlane16_swap / v_permlane32_swap, which
+// with both operands the same value leave [r0 r0 r2 r2] | [r1 r1 r3 r3] resp. [lo lo] | [hi hi] (hipcc pads the
+// VALU-write -> permlane hazard itself).  A different summation order than the xor butterfly's, just as fixed.
+template <int CTRL>
+__device__ __forceinline__ float sq_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sq_row_sum(float v) {   // over the 16 lanes of a DPP row
+  v += sq_dpp<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += sq_dpp<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += sq_dpp<0x141>(v);   // row_half_mirror
+  v += sq_dpp<0x140>(v);   // row_mirror
   return v;
+}
+__device__ __forceinline__ float sq_half_sum(float v) {  // over lanes 0..31 / 32..63
+  v = sq_row_sum(v);
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float sq_wave_sum(float v) {
+  v = sq_half_sum(v);
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 #endif

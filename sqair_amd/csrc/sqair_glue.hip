@@ -232,11 +232,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
         if (STORE && a.s1h_out != nullptr && row0 + 4 * kq + i < d.R)
           a.s1h_out[(size_t)(row0 + 4 * kq + i) * a.s1h_ld + (wave + 4 * t) * 16 + (lane & 15)] = hv;
       }
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    part[i] = v;
+    part[i] = sq_row_sum(v);
   }
   if ((lane & 15) == 0) {
 #pragma unroll
@@ -380,18 +376,20 @@ int sq_launch_latent_sum(const float* f, const float* rec_p, float* c, Dims d, h
 // RecurrentNormalImpl modules.py:548-611, SQAIRTimestep sums :483-485, :505-507.
 // One wavefront per row b'.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff po, const Dims d SQ_TLP) {
+constexpr int SQ_LOGPROB_WAVES = 2;   // (four waves per workgroup did not all fit the chip at once: two rounds of workgroups)
+__global__ __launch_bounds__(64 * SQ_LOGPROB_WAVES) void k_logprob(const LogprobArgs a, const POff po, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
   // Everything a row needs (3N slot records, N prior-stat rows, the conditioning state and ~1k small-layer
   // parameters) is pulled into LDS by all 256 threads in one burst of independent loads (a direct global-memory
-  // walk was ~20 dependent round trips = 27 us); the four wavefronts then share the slots -- wave w evaluates
-  // propagation slots w, w + 4, ... and, once e_sum is known, discovery slots w, w + 4, ... -- and leave the per-slot
-  // terms in LDS, which thread 0 sums in slot order (the order the single wave of rounds 1-2 summed them in, whose
+  // walk was ~20 dependent round trips = 27 us); the wavefronts then share the slots -- wave w evaluates
+  // propagation slots w, w + NWV, ... and, once e_sum is known, discovery slots w, w + NWV, ... -- and leave the per-slot
+  // terms in LDS, which wave 0 sums in slot order (the order the single wave of rounds 1-2 summed them in, whose
   // ~3500 dependent instructions were 26 of the kernel's 29 us).
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int r = blockIdx.x;
   const int fr = blockIdx.y;               // frame (the launch covers all T frames of the pass)
   const int tid = threadIdx.x;
+  constexpr int NWV = SQ_LOGPROB_WAVES, NT = 64 * NWV;
   const int N = d.N, nw = d.nw;
   const int RW = rec::W;
   const size_t fs = (size_t)fr * d.R * N;  // slot-rows per frame
@@ -410,16 +408,16 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
   float* spb_s = sp1_s + 11 * (N + 1);     // 2*(N+1)
   float* ch_s = spb_s + 2 * (N + 1);       // 10
   const float* __restrict__ flat = a.flat;
-  sq_wave_stage(recp_s, a.rec_p + (fs + (size_t)r * N) * RW, N * RW, tid & 63, tid >> 6, 4);
-  sq_wave_stage(recd_s, a.rec_d + (fs + (size_t)r * N) * RW, N * RW, tid & 63, tid >> 6, 4);
-  sq_wave_stage(recm_s, a.rec_prev + (fs + (size_t)r * N) * RW, N * RW, tid & 63, tid >> 6, 4);
-  sq_wave_stage(ps_s, a.pstats + (fs + (size_t)r * N) * a.ps_ld, N * a.ps_ld, tid & 63, tid >> 6, 4);
+  sq_wave_stage(recp_s, a.rec_p + (fs + (size_t)r * N) * RW, N * RW, tid & 63, tid >> 6, NWV);
+  sq_wave_stage(recd_s, a.rec_d + (fs + (size_t)r * N) * RW, N * RW, tid & 63, tid >> 6, NWV);
+  sq_wave_stage(recm_s, a.rec_prev + (fs + (size_t)r * N) * RW, N * RW, tid & 63, tid >> 6, NWV);
+  sq_wave_stage(ps_s, a.pstats + (fs + (size_t)r * N) * a.ps_ld, N * a.ps_ld, tid & 63, tid >> 6, NWV);
   if (a.cfg.rec_where_prior) {
     if (tid < 128) {
       spre_s[tid] = a.spre[((size_t)fr * d.R + r) * 128 + tid];
       ce_s[tid] = flat[po.rn_cond_w + (4 + d.nh) * 128 + tid];
     }
-    for (int i = tid; i < 512; i += 256) h2h_s[i] = flat[po.rn_h2h_w + i];
+    for (int i = tid; i < 512; i += NT) h2h_s[i] = flat[po.rn_h2h_w + i];
     if (tid < 4) { h2h_s[512 + tid] = flat[po.rn_h2h_b + tid]; i2h_s[16 + tid] = flat[po.rn_i2h_b + tid]; isamp_s[tid] = flat[po.rn_init_sample + tid]; }
     if (tid < 16) i2h_s[tid] = flat[po.rn_i2h_w + tid];
     if (tid < 32) ro_s[tid] = flat[po.rn_readout_w + tid];
@@ -439,7 +437,7 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
   const int t_global = a.t_global + fr;
   const float LOG2PI = 1.83787706640934548356f;
 
-  for (int k = wave; k < N; k += 4) {
+  for (int k = wave; k < N; k += NWV) {
     const float* rp = recp_s + k * RW;
     const float* rm = recm_s + k * RW;
     const float* ps = ps_s + k * a.ps_ld;
@@ -521,7 +519,7 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
     }
     for (int jj = 0; jj < 4; ++jj) hs[jj] = sq_wave_sum(part[jj]) + h2h_s[512 + jj] + i2h_s[16 + jj];
   }
-  for (int j = wave; j < N; j += 4) {
+  for (int j = wave; j < N; j += NWV) {
     const float* rd = recd_s + j * RW;
     const float pres = rd[rec::PRES];
     float qw = 0.0f, pw = 0.0f;
@@ -570,10 +568,10 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
     }
   }
   __syncthreads();
-  if (tid != 0) return;
+  if (wave != 0) return;
+  // wave 0: the sums in slot order (every lane the same), then class c of the number-of-steps distributions on lane c <= N
   float q_prop = 0.0f, p_prop = 0.0f, q_pres_sum = 0.0f, p_pres_sum = 0.0f, n_prop = 0.0f;
   float q_disc = 0.0f, p_disc = 0.0f, n_disc = 0.0f;
-  double probs[SQ_MAXN];
   for (int k = 0; k < N; ++k) {
     q_prop += prop_s[k][0];
     p_prop += prop_s[k][1];
@@ -583,43 +581,42 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
     q_disc += disc_s[k][0];
     p_disc += disc_s[k][1];
     n_disc += disc_s[k][2];
-    probs[k] = (double)recd_s[k * RW + rec::PROB];
   }
-  // NumStepsDistribution (float64 inside, prior.py:61-67)
+  // NumStepsDistribution (float64 inside, prior.py:61-67): joint_c = (1 - p_c) prod_{i < c} p_i, joint_N = prod p_i, normalised
   const int n = (int)(n_disc + 0.5f);
-  double joint[SQ_MAXN + 1];
+  double mine = 0.0, at_n = 0.0, tot = 0.0;
   {
-    double cum = 1.0, tot = 0.0;
-    for (int j = 0; j < N; ++j) {
-      joint[j] = (1.0 - probs[j]) * cum;
-      cum *= probs[j];
-      tot += joint[j];
+    double cum = 1.0;
+    for (int j = 0; j <= N; ++j) {
+      const double pj = j < N ? (double)recd_s[j * RW + rec::PROB] : 0.0;
+      const double jc = (1.0 - pj) * cum;
+      cum *= pj;
+      tot += jc;
+      mine = j == lane ? jc : mine;
+      at_n = j == n ? jc : at_n;
     }
-    joint[N] = cum;
-    tot += cum;
-    for (int j = 0; j <= N; ++j) joint[j] /= tot;
   }
-  const float jn = (float)joint[n];
+  const float jn = (float)(at_n / tot);
   const float q_num = logf(fminf(fmaxf(jn, 1e-16f), 1.0f));
   float p_num;
   if (a.cfg.disc_prior_type == 1) {
     const float pr = 1.0f - a.cfg.step_success_prob;
     p_num = (float)n * log1pf(-pr) + logf(pr);
   } else {
-    float hid[10];
-    for (int i = 0; i < 10; ++i) hid[i] = sq_elu(e_sum * sp0_s[i] + sp0_s[10 + i]);
-    float lg[SQ_MAXN + 1];
-    float mx = -1e30f;
-    for (int c = 0; c <= N; ++c) {
-      float v = spb_s[c] + (t_global > 0 ? spb_s[N + 1 + c] : 0.0f) + sp1_s[10 * (N + 1) + c];
-      for (int i = 0; i < 10; ++i) v += hid[i] * sp1_s[i * (N + 1) + c];
-      lg[c] = sq_elu(v);
-      mx = fmaxf(mx, lg[c]);
-    }
-    float se = 0.0f;
-    for (int c = 0; c <= N; ++c) se += expf(lg[c] - mx);
-    p_num = lg[n] - (mx + logf(se));
+    const int c = min(lane, N);
+    float v = spb_s[c] + (t_global > 0 ? spb_s[N + 1 + c] : 0.0f) + sp1_s[10 * (N + 1) + c];
+    for (int i = 0; i < 10; ++i) v += sq_elu(e_sum * sp0_s[i] + sp0_s[10 + i]) * sp1_s[i * (N + 1) + c];
+    const float lg = lane <= N ? sq_elu(v) : -1e30f;
+    float mx = lg;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));   // N + 1 <= 9 classes on lanes 0 .. 15
+    float se = lane <= N ? expf(lg - mx) : 0.0f;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o, 64);
+    p_num = __shfl(lg, n, 64) - (mx + logf(se));
   }
+  if (a.out.disc_prob && lane <= N) a.out.disc_prob[tr * (N + 1) + lane] = (float)(mine / tot);
+  if (lane != 0) return;
   const float q_prop_tot = q_prop + q_pres_sum, p_prop_tot = p_prop + p_pres_sum;
   const float q_disc_tot = q_disc + q_num, p_disc_tot = p_disc + p_num;
   a.qz[(size_t)fr * d.R + r] = q_disc_tot + q_prop_tot;
@@ -633,13 +630,11 @@ __global__ __launch_bounds__(256) void k_logprob(const LogprobArgs a, const POff
   if (a.out.discrete_log_prob) a.out.discrete_log_prob[tr] = q_pres_sum + q_num;
   if (a.out.num_prop_steps_per_sample) a.out.num_prop_steps_per_sample[tr] = n_prop;
   if (a.out.num_disc_steps_per_sample) a.out.num_disc_steps_per_sample[tr] = n_disc;
-  if (a.out.disc_prob)
-    for (int c = 0; c <= N; ++c) a.out.disc_prob[tr * (N + 1) + c] = (float)joint[c];
 }
 int sq_launch_logprob(const LogprobArgs& a, POff po, Dims d, hipStream_t s) {
   const size_t shm = ((size_t)3 * d.N * rec::W + (size_t)d.N * a.ps_ld + 128 + 128 + 516 + 20 + 40 + 4 + 20 +
                       11 * (d.N + 1) + 2 * (d.N + 1) + 16) * sizeof(float);
-  SQ_LAUNCH(k_logprob, dim3(d.R, a.n_frames), dim3(256), shm, s, a, po, d);
+  SQ_LAUNCH(k_logprob, dim3(d.R, a.n_frames), dim3(64 * SQ_LOGPROB_WAVES), shm, s, a, po, d);
   return 0;
 }
 

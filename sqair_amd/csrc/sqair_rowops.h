@@ -109,10 +109,7 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
       }
 #pragma unroll
       for (int o = 0; o < 8; ++o) {
-        float v = part[o];
-        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-        part[o] = v + a.w3[d.nh * 8 + o];
+        part[o] = sq_half_sum(part[o]) + a.w3[d.nh * 8 + o];
       }
       tp_loc = ci == 0 ? part[0] : (ci == 1 ? part[1] : (ci == 2 ? part[2] : part[3]));
       tp_raw = ci == 0 ? part[4] : (ci == 1 ? part[5] : (ci == 2 ? part[6] : part[7]));
