@@ -1753,24 +1753,39 @@ int sq_launch_latent_sum_bwd(const float* d_c, const float* rec_p, const float* 
   return 0;
 }
 // d pre_d[r][n] = sum over the N discovery slots of the RNN pre-activation gradients [R][N][nh]; then over particles
-__global__ void k_sum_slots(const float* __restrict__ d_rnn, float* __restrict__ d_pre_d, float* __restrict__ d_pre_disc, int B, int K,
-                            int N, int nh SQ_TLP) {
+// d_pre_d[r] = sum over the N slots of d_rnn[r][j], d_pre_disc[b] = sum over the K particles of d_pre_d: workgroup = (sequence,
+// 64 columns), one wave per particle (K > 16: strided), every load of the pass in flight at once (a thread per (b, column)
+// walking its K x N values was K x N dependent round trips: 4.6 us)
+__global__ __launch_bounds__(1024) void k_sum_slots(const float* __restrict__ d_rnn, float* __restrict__ d_pre_d, float* __restrict__ d_pre_disc,
+                                                   int B, int K, int N, int nh SQ_TLP) {
   SQ_TL_SCOPE;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * nh) return;
-  const int b = i / nh, n = i - b * nh;
+  __shared__ float part_s[16][64];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const int n = blockIdx.y * 64 + lane;
+  const bool ok = n < nh;
   float tot = 0.0f;
-  for (int kp = 0; kp < K; ++kp) {
+  for (int kp = wave; kp < K; kp += n_waves) {
     const int r = b * K + kp;
+    float v[SQ_MAXN];
+#pragma unroll
+    for (int j = 0; j < SQ_MAXN; ++j) v[j] = ok && j < N ? d_rnn[((size_t)r * N + j) * nh + n] : 0.0f;
     float acc = 0.0f;
-    for (int j = 0; j < N; ++j) acc += d_rnn[((size_t)r * N + j) * nh + n];
-    d_pre_d[(size_t)r * nh + n] = acc;
+#pragma unroll
+    for (int j = 0; j < SQ_MAXN; ++j) acc += v[j];
+    if (ok) d_pre_d[(size_t)r * nh + n] = acc;
     tot += acc;
   }
-  d_pre_disc[i] = tot;
+  part_s[wave][lane] = tot;
+  __syncthreads();
+  if (wave == 0 && ok) {
+    float t = 0.0f;
+    for (int w = 0; w < n_waves; ++w) t += part_s[w][lane];
+    d_pre_disc[(size_t)b * nh + n] = t;
+  }
 }
 int sq_launch_sum_slots(const float* d_rnn, float* d_pre_d, float* d_pre_disc, int B, int K, int N, int nh, hipStream_t s) {
-  SQ_LAUNCH(k_sum_slots, dim3((B * nh + 255) / 256), dim3(256), 0, s, d_rnn, d_pre_d, d_pre_disc, B, K, N, nh);
+  const int n_waves = K < 16 ? K : 16;
+  SQ_LAUNCH(k_sum_slots, dim3(B, (nh + 63) / 64), dim3(64 * n_waves), 0, s, d_rnn, d_pre_d, d_pre_disc, B, K, N, nh);
   return 0;
 }
 __global__ void k_particle_sum(const float* __restrict__ in, float* __restrict__ out, int B, int K, int nh SQ_TLP) {

@@ -55,7 +55,7 @@ __device__ __forceinline__ bool sq_canvas_inside(float g, int G) { return g > -1
 __device__ __forceinline__ void sq_canvas_prologue(const CanvasLds& c, const float* __restrict__ glimpse, const float* __restrict__ where0,
                                                    int where_ld, const float* __restrict__ pres0, int pres_ld, int N, int G, int H, int W) {
   const int tid = threadIdx.x, G2 = G * G;
-  for (int i = tid; i < N * G2; i += 256) c.gl[i] = glimpse[i];
+  sq_wave_stage(c.gl, glimpse, N * G2, tid & 63, tid >> 6, 4);   // (LDS-DMA: lands by the first barrier below)
   if (tid < N * 4) {
     const int k = tid >> 2, q = tid & 3;
     const float l = where0[(size_t)k * where_ld + q];
@@ -89,27 +89,19 @@ __device__ __forceinline__ void sq_canvas_prologue(const CanvasLds& c, const flo
   __syncthreads();
 }
 
-// bilinear value of glimpse gk and of a glimpse of ones at (xg, yg), both coordinates inside (-1, G): taps outside the glimpse are zero
+// bilinear value of glimpse gk and of a glimpse of ones at (xg, yg), both coordinates inside (-1, G): taps outside the glimpse
+// are zero.  Branch-free (clamped addresses, zeroed weights): four of these are in flight per thread in sq_canvas_band.
 __device__ __forceinline__ void sq_canvas_tap(const float* __restrict__ gk, float xg, float yg, int G, float& v, float& on) {
   const float x0f = floorf(xg), y0f = floorf(yg);
   const int x0 = (int)x0f, y0 = (int)y0f;
-  const float wx1 = xg - x0f, wy1 = yg - y0f;
-  v = 0.0f;
-  on = 0.0f;
-#pragma unroll
-  for (int dy = 0; dy < 2; ++dy) {
-    const int yy = y0 + dy;
-    if (yy < 0 || yy >= G) continue;
-    const float wy = dy ? wy1 : 1.0f - wy1;
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int xx = x0 + dx;
-      if (xx < 0 || xx >= G) continue;
-      const float w = wy * (dx ? wx1 : 1.0f - wx1);
-      v += w * gk[yy * G + xx];
-      on += w;
-    }
-  }
+  const float fx = xg - x0f, fy = yg - y0f;
+  const float wx0 = x0 >= 0 ? 1.0f - fx : 0.0f, wx1 = x0 + 1 < G ? fx : 0.0f;
+  const float wy0 = y0 >= 0 ? 1.0f - fy : 0.0f, wy1 = y0 + 1 < G ? fy : 0.0f;
+  const int xa = max(x0, 0), xb = min(x0 + 1, G - 1);
+  const float* ra = gk + max(y0, 0) * G;
+  const float* rb = gk + min(y0 + 1, G - 1) * G;
+  v = wy0 * (wx0 * ra[xa] + wx1 * ra[xb]) + wy1 * (wx0 * rb[xa] + wx1 * rb[xb]);
+  on = (wy0 + wy1) * (wx0 + wx1);
 }
 
 // wave-uniform copies of slot k's presence and of its box clipped to rows [yb0, yb1]; false: nothing of the slot in the band
@@ -137,16 +129,22 @@ __device__ __forceinline__ void sq_canvas_band(const CanvasLds& c, int yb0, int 
     CanvasSlot s;
     if (!sq_canvas_slot(c, k, yb0, yb1, s)) continue;
     const float* gk = c.gl + k * G * G;
-    for (int Y = s.y0 + ty; Y <= s.y1; Y += 8) {
-      const float yg = c.yt[k * H + Y];
+    // four rows of the patch per trip: all their table / glimpse reads first, the read-modify-writes of the band after them (one
+    // pixel at a time the reads of a pixel queued behind the writes of the one before: ~6 dependent LDS round trips per pixel)
+    for (int Y0 = s.y0 + ty; Y0 <= s.y1; Y0 += 32)
       for (int X = s.x0 + tx; X <= s.x1; X += 32) {
-        float v, on;
-        sq_canvas_tap(gk, c.xt[k * W + X], yg, G, v, on);
-        const int o = (Y - yb0) * W + X;
-        c.cv[o] += v * s.pk;
-        c.ms[o] += on * s.pk;
+        const float xg = c.xt[k * W + X];
+        float v[4], on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sq_canvas_tap(gk, xg, c.yt[k * H + min(Y0 + 8 * u, s.y1)], G, v[u], on[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (Y0 + 8 * u <= s.y1) {
+            const int o = (Y0 + 8 * u - yb0) * W + X;
+            c.cv[o] += v[u] * s.pk;
+            c.ms[o] += on[u] * s.pk;
+          }
       }
-    }
     __syncthreads();
   }
 }

@@ -251,6 +251,21 @@ __device__ __forceinline__ float sq_row_sum(float v) {   // over the 16 lanes of
   v += sq_dpp<0x140>(v);   // row_mirror
   return v;
 }
+__device__ __forceinline__ float sq_wave_max(float v) {   // (same network as sq_wave_sum; v of inactive slots: pass -3e38)
+  v = fmaxf(v, sq_dpp<0xB1>(v));
+  v = fmaxf(v, sq_dpp<0x4E>(v));
+  v = fmaxf(v, sq_dpp<0x141>(v));
+  v = fmaxf(v, sq_dpp<0x140>(v));
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+  const unsigned u2 = __builtin_bit_cast(unsigned, v);
+  const auto r2 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)r2[0]), __builtin_bit_cast(float, (unsigned)r2[1]));
+}
+__device__ __forceinline__ float sq_read_lane(float v, int lane_uniform) {   // lane index wave-uniform
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_uniform));
+}
 __device__ __forceinline__ float sq_half_sum(float v) {  // over lanes 0..31 / 32..63
   v = sq_row_sum(v);
   const unsigned u = __builtin_bit_cast(unsigned, v);

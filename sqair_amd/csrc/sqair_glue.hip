@@ -947,77 +947,113 @@ int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 struct ElboMeans { const float* p[8]; };
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
 __global__ __launch_bounds__(1024) void k_elbo(const float* __restrict__ log_w_t, const float* __restrict__ disc_lp_t,
                                               int T, int B, int K, float* log_weights, float* elbo_per_ex, float* iw_out,
                                               float* signal_out, float* scalars, ElboMeans means, int n_means,
                                               float* means_out SQ_TLP) {
   SQ_TL_SCOPE;
   __shared__ float acc_s[16][4 + 8];
+  __shared__ float stage_s[16][10][64];   // per wave: one strip of 64 (frame, particle) values per array
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int R = B * K;
+  const int fpi = 64 / K, tl = min(lane / K, fpi - 1), kl = lane - (lane / K) * K;   // frames per load instruction (K <= 64)
   float a_vae = 0.0f, a_iwae = 0.0f, a_vimco = 0.0f, a_ess = 0.0f;
   float a_means[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int b = wave; b < B; b += 16) {
-    const bool act = lane < K;
-    float lw = 0.0f, dl = 0.0f;
-    if (act) {
-#pragma unroll 10
-      for (int t = 0; t < T; ++t) lw += log_w_t[(size_t)t * R + b * K + lane];
-      if (disc_lp_t != nullptr) {
-#pragma unroll 10
-        for (int t = 0; t < T; ++t) dl += disc_lp_t[(size_t)t * R + b * K + lane];
+  // Two sequences per trip (b0 and b0 + 16), and EVERYTHING both need from memory -- T log-weights, T discrete log-probs and
+  // T values of each importance-weighted mean per particle -- requested before the first reduction, without branches between
+  // the loads: the values were just written by workgroups all over the chip, a round trip to them is ~2 us, and the kernel used
+  // to make ~20 of them one after the other (17 us for 64 KB).
+  for (int b0 = wave; b0 < B; b0 += 32) {
+    float lw2[2], dl2[2], xm2[2][8];
+    {
+      const float* src[10];
+      src[0] = log_w_t;
+      src[1] = disc_lp_t != nullptr ? disc_lp_t : log_w_t;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) src[2 + q] = q < n_means ? means.p[q] : log_w_t;
+      float acc[2][10];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[s2][i] = 0.0f;
+      // lane = (frame in the chunk, particle): ONE load instruction per array fetches 64 / K frames of a sequence (all T = 10
+      // of the benchmark), so a trip's 2 x 10 loads cover both sequences; the frames then meet through a wave-private LDS
+      // strip, where lane k adds its particle's values in frame order
+      float* strip = &stage_s[wave][0][0];
+      for (int t0 = 0; t0 < T; t0 += fpi) {
+        const int tt = t0 + tl;
+        const bool ld = lane < fpi * K && tt < T;
+        float v[2][10];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const size_t o = (size_t)min(tt, T - 1) * R + (size_t)min(b0 + 16 * s2, B - 1) * K + kl;
+#pragma unroll
+          for (int i = 0; i < 10; ++i) v[s2][i] = src[i][o];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+          for (int i = 0; i < 10; ++i) strip[i * 64 + lane] = ld ? v[s2][i] : 0.0f;
+          __builtin_amdgcn_wave_barrier();   // (one wave: its LDS operations complete in order)
+          if (lane < K)
+            for (int f = 0; f < fpi && t0 + f < T; ++f)
+#pragma unroll
+              for (int i = 0; i < 10; ++i) acc[s2][i] += strip[i * 64 + f * K + lane];
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        lw2[s2] = acc[s2][0];
+        dl2[s2] = disc_lp_t != nullptr ? acc[s2][1] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xm2[s2][q] = acc[s2][2 + q] / (float)T;
       }
     }
-    const float mx = wave_max(act ? lw : -3.0e38f);
-    const float ex = act ? expf(lw - mx) : 0.0f;
-    const float se = sq_wave_sum(ex);
-    const float lse = mx + logf(se);
-    const float elbo = lse - logf((float)K);
-    const float w = act ? ex / se : 0.0f;
-    // VIMCO control variate (targets.py:46-59): replace w_k by the mean of the others, logmeanexp
-    const float sum_lw = sq_wave_sum(act ? lw : 0.0f);
-    float cv = 0.0f;
-    {  // K == 1 gives 0/0 = NaN exactly like the reference's (k_particles - 1.) division (targets.py:55)
-      const float abo = (sum_lw - lw) / ((float)K - 1.0f);
-      float m2 = abo;  // max over the K terms of the leave-one-out sum (own weight replaced by abo)
-      for (int j = 0; j < K; ++j) {
-        const float lj = __shfl(lw, j, 64);
-        if (j != lane) m2 = fmaxf(m2, lj);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int b = b0 + 16 * s2;
+      const bool act = lane < K && b < B;   // (b >= B, wave-uniform: contributes zeros, stores nothing)
+      const float lw = act ? lw2[s2] : 0.0f, dl = act ? dl2[s2] : 0.0f;
+      const float mx = sq_wave_max(act ? lw : -3.0e38f);
+      const float ex = act ? expf(lw - mx) : 0.0f;
+      const float se = sq_wave_sum(ex);
+      const float lse = mx + logf(se);
+      const float elbo = lse - logf((float)K);
+      const float w = act ? ex / se : 0.0f;
+      // VIMCO control variate (targets.py:46-59): replace w_k by the mean of the others, logmeanexp
+      const float sum_lw = sq_wave_sum(act ? lw : 0.0f);
+      float cv = 0.0f;
+      {  // K == 1 gives 0/0 = NaN exactly like the reference's (k_particles - 1.) division (targets.py:55)
+        const float abo = (sum_lw - lw) / ((float)K - 1.0f);
+        float m2 = abo;  // max over the K terms of the leave-one-out sum (own weight replaced by abo)
+        for (int j = 0; j < K; ++j) {
+          const float lj = sq_read_lane(lw, j);
+          if (j != lane) m2 = fmaxf(m2, lj);
+        }
+        float rest = 0.0f;  // sum_{j != k} exp(lw_j - m2), exact (no cancellation)
+        for (int j = 0; j < K; ++j) {
+          const float lj = sq_read_lane(lw, j);
+          if (j != lane) rest += expf(lj - m2);
+        }
+        cv = m2 + logf(rest + expf(abo - m2)) - logf((float)K);
       }
-      float rest = 0.0f;  // sum_{j != k} exp(lw_j - m2), exact (no cancellation)
-      for (int j = 0; j < K; ++j) {
-        const float lj = __shfl(lw, j, 64);
-        if (j != lane) rest += expf(lj - m2);
-      }
-      cv = m2 + logf(rest + expf(abo - m2)) - logf((float)K);
-    }
-    const float sig = act ? lw - cv : 0.0f;
-    const float loss = act ? (-elbo - sig * dl) : 0.0f;
-    a_vae += sq_wave_sum(act ? lw : 0.0f);
-    a_vimco += sq_wave_sum(loss);
-    const float sw = sq_wave_sum(w), sw2 = sq_wave_sum(w * w);
-    a_iwae += elbo;
-    a_ess += sw * sw / sw2;
-    if (act) {
-      if (log_weights) log_weights[b * K + lane] = lw;
-      if (iw_out) iw_out[b * K + lane] = w;
-      if (signal_out) signal_out[b * K + lane] = sig;
-    }
-    if (lane == 0 && elbo_per_ex) elbo_per_ex[b] = elbo;
-    for (int q = 0; q < n_means; ++q) {
-      float xm = 0.0f;
+      const float sig = act ? lw - cv : 0.0f;
+      const float loss = act ? (-elbo - sig * dl) : 0.0f;
+      a_vae += sq_wave_sum(act ? lw : 0.0f);
+      a_vimco += sq_wave_sum(loss);
+      const float sw = sq_wave_sum(w), sw2 = sq_wave_sum(w * w);
+      a_iwae += b < B ? elbo : 0.0f;
+      a_ess += b < B ? sw * sw / sw2 : 0.0f;
       if (act) {
-#pragma unroll 10
-        for (int t = 0; t < T; ++t) xm += means.p[q][(size_t)t * R + b * K + lane];
-        xm /= (float)T;
+        if (log_weights) log_weights[b * K + lane] = lw;
+        if (iw_out) iw_out[b * K + lane] = w;
+        if (signal_out) signal_out[b * K + lane] = sig;
       }
-      a_means[q] += sq_wave_sum(w * xm);  // mean over (B,K) of iw * x * K == mean_b sum_k iw x
+      if (lane == 0 && b < B && elbo_per_ex) elbo_per_ex[b] = elbo;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (q < n_means) a_means[q] += sq_wave_sum(w * (act ? xm2[s2][q] : 0.0f));  // mean over (B,K) of iw * x * K == mean_b sum_k iw x
     }
   }
   if (lane == 0) {
@@ -1025,19 +1061,15 @@ __global__ __launch_bounds__(1024) void k_elbo(const float* __restrict__ log_w_t
     for (int q = 0; q < 8; ++q) acc_s[wave][4 + q] = a_means[q];
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float s[12];
-    for (int i = 0; i < 12; ++i) {
-      s[i] = 0.0f;
-      for (int wv = 0; wv < 16; ++wv) s[i] += acc_s[wv][i];
+  if (threadIdx.x < 12) {   // column i of the per-wave partial sums on thread i, waves in order
+    const int i = threadIdx.x;
+    float t = 0.0f;
+    for (int wv = 0; wv < 16; ++wv) t += acc_s[wv][i];
+    if (i < 4) {
+      if (scalars) scalars[i] = i == 0 ? t / (float)(B * K) : (i == 2 ? t / (float)(B * K) / (float)T : t / (float)B);
+    } else if (i - 4 < n_means) {
+      means_out[i - 4] = t / (float)B;
     }
-    if (scalars) {
-      scalars[0] = s[0] / (float)(B * K);
-      scalars[1] = s[1] / (float)B;
-      scalars[2] = s[2] / (float)(B * K) / (float)T;
-      scalars[3] = s[3] / (float)B;
-    }
-    for (int q = 0; q < n_means; ++q) means_out[q] = s[4 + q] / (float)B;
   }
 }
 
