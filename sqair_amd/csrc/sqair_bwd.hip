@@ -1313,28 +1313,22 @@ int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t 
 // slot-tail adjoint (mirror of k_slot_tail): presence logit -> steps-predictor output / hidden layer -> what,
 // then the what-sample adjoint (gated mixture for propagation).  One workgroup (128 threads) per row.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, const Dims d SQ_TLP) {
+__global__ __launch_bounds__(256) void k_slot_tail_bwd(const TailBwdArgs a, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
   __shared__ float ds_s[128];
   extern __shared__ float wt_s[];  // the `what` rows of steps.l0.w, [nw][nsp + 1] (padded: conflict-free row reads)
   const int r = blockIdx.x, tid = threadIdx.x, nw = d.nw, nsp = d.nh / 2, RW = rec::W;
-  const int sh = 31 - __clz(nsp);  // nsp = nh / 2 is 64 or 128 (sqair_create): shifts instead of 50 integer divisions per thread
-  {  // coalesced loads, 25 per thread in flight at once (the plain loop compiled to 8 in flight + waits: seven dependent round
-     // trips for the 50 x 128 block of the shipped sizes, two now)
-    constexpr int U = 25;
-    const int total = nw * nsp;
-    const float* __restrict__ wsrc = a.flat + a.wwhat_off;
-    for (int base = 0; base < total; base += 128 * U) {
-      float v[U];
+  // the weight block: 16-byte loads, all of a thread's requests (7 for the 50 x 128 block of the shipped sizes) issued here and
+  // written to LDS only AFTER the per-row operands below have been requested too -- one memory round trip for the whole kernel.
+  // (Rounds 1-2: the plain copy loop, seven dependent round trips; round 3 at first: 2 x 25 dword loads per thread, whose LDS
+  // stores waited for the weights before the per-row operands were even requested: 5.8 us.  LDS-DMA dwords were slower still.)
+  typedef float sq_f32x4 __attribute__((ext_vector_type(4), aligned(4)));   // (flat parameter offsets are only 4-byte aligned)
+  constexpr int WU = 8;
+  const int total4 = (nw * nsp) >> 2;   // nsp is a multiple of 64
+  const sq_f32x4* __restrict__ wsrc4 = reinterpret_cast<const sq_f32x4*>(a.flat + a.wwhat_off);
+  sq_f32x4 wv[WU];
 #pragma unroll
-      for (int q = 0; q < U; ++q) v[q] = wsrc[min(base + tid + 128 * q, total - 1)];
-#pragma unroll
-      for (int q = 0; q < U; ++q) {
-        const int e = base + tid + 128 * q;
-        if (e < total) wt_s[(e >> sh) * (nsp + 1) + (e & (nsp - 1))] = v[q];
-      }
-    }
-  }
+  for (int q = 0; q < WU; ++q) wv[q] = wsrc4[min(tid + 256 * q, total4 - 1)];
   const float* rn = a.rec_new + ((size_t)r * d.N + a.slot) * RW;
   float* drn = a.d_rec_new + ((size_t)r * d.N + a.slot) * RW;
   (void)rn;
@@ -1357,9 +1351,29 @@ __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, cons
     wtm1 = a.rec_prev[((size_t)r * d.N + a.slot) * RW + rec::WHAT + c];
     q_dprev = a.d_rec_prev[((size_t)r * d.N + a.slot) * RW + rec::WHAT + c];
   }
+  float hv_ = 0.0f, w2_ = 0.0f;
   if (tid < nsp) {
-    const float hv = a.s1h[(size_t)r * a.s1h_ld + tid];
-    const float w2 = a.flat[a.w2_off + tid];
+    hv_ = a.s1h[(size_t)r * a.s1h_ld + tid];
+    w2_ = a.flat[a.w2_off + tid];
+  }
+  {
+    const int sh = 31 - __clz(nsp);   // nsp = nh / 2 is 64 or 128 (sqair_create)
+#pragma unroll
+    for (int q = 0; q < WU; ++q) {
+      const int e = 4 * (tid + 256 * q);
+      if (e < 4 * total4) {
+        float* dst = wt_s + (e >> sh) * (nsp + 1) + (e & (nsp - 1));   // (padded rows: conflict-free row reads, scalar stores)
+        dst[0] = wv[q].x; dst[1] = wv[q].y; dst[2] = wv[q].z; dst[3] = wv[q].w;
+      }
+    }
+    for (int e4 = tid + 256 * WU; e4 < total4; e4 += 256) {   // (wider layers than the library is built for)
+      const sq_f32x4 x = wsrc4[e4];
+      float* dst = wt_s + ((4 * e4) >> sh) * (nsp + 1) + ((4 * e4) & (nsp - 1));
+      dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
+    }
+  }
+  if (tid < nsp) {
+    const float hv = hv_, w2 = w2_;
     const float g = d_raw * w2 * delu_from_out(hv);
     ds_s[tid] = g;
     a.d_s1pre[(size_t)r * a.ds_ld + tid] = g;
@@ -1404,7 +1418,7 @@ __global__ __launch_bounds__(128) void k_slot_tail_bwd(const TailBwdArgs a, cons
   }
 }
 int sq_launch_slot_tail_bwd(const TailBwdArgs& a, Dims d, hipStream_t s) {
-  SQ_LAUNCH(k_slot_tail_bwd, dim3(d.R), dim3(128), (size_t)d.nw * (d.nh / 2 + 1) * sizeof(float), s, a, d);
+  SQ_LAUNCH(k_slot_tail_bwd, dim3(d.R), dim3(256), (size_t)d.nw * (d.nh / 2 + 1) * sizeof(float), s, a, d);
   return 0;
 }
 
