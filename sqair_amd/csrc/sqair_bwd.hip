@@ -1253,55 +1253,86 @@ int sq_launch_lstm_cell_bwd(const float* gates, int g_ld, const float* c_prev, i
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, const POff po, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
-  const int r = blockIdx.x, tid = threadIdx.x, N = d.N, nh = d.nh, RW = rec::W;
+  const int r = blockIdx.x, tid = threadIdx.x, N = d.N, RW = rec::W;
   __shared__ int inv_s[2 * SQ_MAXN];  // source slot -> destination (or -1)
   if (tid < 2 * N) inv_s[tid] = -1;
   __syncthreads();
   if (tid < N) inv_s[a.src[(size_t)r * N + tid]] = tid;
   __syncthreads();
   typedef float cf4 __attribute__((ext_vector_type(4)));   // all gradient rows are 16-byte aligned: 16-byte units throughout
-  const int r4 = RW / 4;
-  for (int e = tid; e < 2 * N * r4; e += 256) {
-    const int sl = e / r4, i = e - sl * r4;
-    const int dst = inv_s[sl];
-    if (dst < 0) continue;
-    const cf4 g = reinterpret_cast<const cf4*>(a.d_rec_next + ((size_t)r * N + dst) * RW)[i];
-    cf4* tgt = reinterpret_cast<cf4*>(sl < N ? a.d_rec_p + ((size_t)r * N + sl) * RW : a.d_rec_d + ((size_t)r * N + (sl - N)) * RW) + i;
-    *tgt += g;
-  }
-  // recurrent states: propagated slots get the gradient of the merged slot they became; newly discovered objects started
-  // from the trainable initial states -- their gradients are summed per row here and over rows / frames after the sweep
-  // (atomics on the 2 x nh parameter words from every row serialise in L2)
   const cf4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-  const int snh = d.snh, t4 = snh / 4;
-  for (int e = tid; e < N * t4; e += 256) {
-    const int sl = e / t4, i = e - sl * t4;
-    const int dst = inv_s[sl];
-    reinterpret_cast<cf4*>(a.d_temporal_p + ((size_t)r * N + sl) * snh)[i] =
-        dst >= 0 ? reinterpret_cast<const cf4*>(a.d_temporal_next + ((size_t)r * N + dst) * snh)[i] : zero4;
-  }
-  for (int i = tid; i < t4; i += 256) {
-    cf4 acc = zero4;
-    for (int sl = N; sl < 2 * N; ++sl) {
+  // Three jobs -- (1) gradient records: add the merged slot's record onto the source slot's; (2) recurrent states of the
+  // propagated slots: the gradient of the merged slot they became (or zero); (3) newly discovered objects started from the
+  // trainable initial states: their gradients summed per row here, over rows / frames after the sweep (atomics on the 2 x nh
+  // parameter words from every row serialise in L2) -- and every one of their loads is requested before the first store, so
+  // the kernel is two memory round trips (the permutation, then everything) and the write.  (Measured: 5.4 us either way --
+  // the per-unit loops it replaces overlapped well enough; what is left is those two cold round trips themselves.)
+  constexpr int Q1 = 3, Q2 = 4;   // units per thread: 2 N RW / 4 <= 3 x 256 records, N snh / 4 <= 4 x 256 state words (N <= 8, snh <= 512)
+  const int r4 = RW / 4;
+  cf4 g1[Q1], t1[Q1];
+  cf4* tg1[Q1];
+#pragma unroll
+  for (int q = 0; q < Q1; ++q) {
+    const int e = tid + 256 * q;
+    tg1[q] = nullptr;
+    g1[q] = zero4;
+    t1[q] = zero4;
+    if (e < 2 * N * r4) {
+      const int sl = e / r4, i = e - sl * r4;
       const int dst = inv_s[sl];
-      if (dst >= 0) acc += reinterpret_cast<const cf4*>(a.d_temporal_next + ((size_t)r * N + dst) * snh)[i];
+      if (dst >= 0) {
+        tg1[q] = reinterpret_cast<cf4*>(sl < N ? a.d_rec_p + ((size_t)r * N + sl) * RW : a.d_rec_d + ((size_t)r * N + (sl - N)) * RW) + i;
+        g1[q] = reinterpret_cast<const cf4*>(a.d_rec_next + ((size_t)r * N + dst) * RW)[i];
+        t1[q] = *tg1[q];
+      }
     }
-    reinterpret_cast<cf4*>(a.d_new_temporal + (size_t)r * snh)[i] = acc;
   }
-  const int psnh = d.psnh, p4 = psnh / 4;
-  for (int e = tid; e < N * p4; e += 256) {
-    const int sl = e / p4, i = e - sl * p4;
-    const int dst = inv_s[sl];
-    reinterpret_cast<cf4*>(a.d_prior_p + ((size_t)r * N + sl) * psnh)[i] =
-        dst >= 0 ? reinterpret_cast<const cf4*>(a.d_prior_next + ((size_t)r * N + dst) * psnh)[i] : zero4;
-  }
-  for (int i = tid; i < p4; i += 256) {
-    cf4 acc = zero4;
-    for (int sl = N; sl < 2 * N; ++sl) {
-      const int dst = inv_s[sl];
-      if (dst >= 0) acc += reinterpret_cast<const cf4*>(a.d_prior_next + ((size_t)r * N + dst) * psnh)[i];
+  const int snh = d.snh, psnh = d.psnh;
+  cf4 v2[2][Q2], acc3[2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {   // temporal state, prior state
+    const int w = st == 0 ? snh : psnh, w4 = w / 4;
+    const float* next = st == 0 ? a.d_temporal_next : a.d_prior_next;
+#pragma unroll
+    for (int q = 0; q < Q2; ++q) {
+      const int e = tid + 256 * q;
+      v2[st][q] = zero4;
+      if (e < N * w4) {
+        const int sl = e / w4, i = e - sl * w4;
+        const int dst = inv_s[sl];
+        if (dst >= 0) v2[st][q] = reinterpret_cast<const cf4*>(next + ((size_t)r * N + dst) * w)[i];
+      }
     }
-    reinterpret_cast<cf4*>(a.d_new_prior + (size_t)r * psnh)[i] = acc;
+    cf4 x3[SQ_MAXN];
+#pragma unroll
+    for (int j = 0; j < SQ_MAXN; ++j) {
+      x3[j] = zero4;
+      if (j < N && tid < w4) {
+        const int dst = inv_s[N + j];
+        if (dst >= 0) x3[j] = reinterpret_cast<const cf4*>(next + ((size_t)r * N + dst) * w)[tid];
+      }
+    }
+    acc3[st] = zero4;
+#pragma unroll
+    for (int j = 0; j < SQ_MAXN; ++j) acc3[st] += x3[j];
+  }
+  // ---- stores
+#pragma unroll
+  for (int q = 0; q < Q1; ++q)
+    if (tg1[q] != nullptr) *tg1[q] = t1[q] + g1[q];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const int w = st == 0 ? snh : psnh, w4 = w / 4;
+    float* outp = st == 0 ? a.d_temporal_p : a.d_prior_p;
+#pragma unroll
+    for (int q = 0; q < Q2; ++q) {
+      const int e = tid + 256 * q;
+      if (e < N * w4) {
+        const int sl = e / w4, i = e - sl * w4;
+        reinterpret_cast<cf4*>(outp + ((size_t)r * N + sl) * w)[i] = v2[st][q];
+      }
+    }
+    if (tid < w4) reinterpret_cast<cf4*>((st == 0 ? a.d_new_temporal : a.d_new_prior) + (size_t)r * w)[tid] = acc3[st];
   }
 }
 int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t s) {

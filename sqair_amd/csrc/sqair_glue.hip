@@ -797,33 +797,43 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff
   // copy the N survivors: record (168) + temporal state + prior state, as 16-byte units (all rows are 16-byte aligned;
   // only the trainable initial states of newly discovered objects come from the unaligned flat parameter buffer)
   typedef float cf4 __attribute__((ext_vector_type(4)));
+  typedef float cf4u __attribute__((ext_vector_type(4), aligned(4)));   // (flat parameter offsets are only 4-byte aligned)
   const int snh = d.snh, psnh = d.psnh;
   const int r4 = rec::W / 4, t4 = snh / 4, per4 = r4 + t4 + psnh / 4;
-  for (int e = tid; e < N * per4; e += 256) {
-    const int dst = e / per4, i = e - dst * per4;
-    const int sidx = src_s[dst];
-    const bool prop = sidx < N;
-    const int ss = prop ? sidx : sidx - N;
-    if (i < r4) {
-      const float* rs = (prop ? a.rec_p : a.rec_d) + ((size_t)r * N + ss) * rec::W;
-      cf4 v = reinterpret_cast<const cf4*>(rs)[i];
-      if (i == rec::ID / 4) v[rec::ID % 4] = id_s[dst];
-      reinterpret_cast<cf4*>(a.rec_next + ((size_t)r * N + dst) * rec::W)[i] = v;
-    } else {
-      const bool tmp = i < r4 + t4;
-      const int q = tmp ? i - r4 : i - r4 - t4;
-      const int w = tmp ? snh : psnh;
-      const float* sp = tmp ? a.temporal_p : a.prior_p;
-      float* dp = tmp ? a.temporal_next : a.prior_next;
-      cf4 v;
-      if (prop) {
-        v = reinterpret_cast<const cf4*>(sp + ((size_t)r * N + ss) * w)[q];
-      } else {
-        const float* ip = a.flat + (tmp ? po.temporal_init : po.prior_init) + 4 * q;
-        v = cf4{ip[0], ip[1], ip[2], ip[3]};
+  // four units per thread and trip, every load of a trip ahead of its stores.  The kernel stays at two cold memory round trips
+  // (presences -> permutation, then the survivors' rows) plus the write, ~4.8 us
+  constexpr int CU = 4;
+  for (int e0 = tid; e0 < N * per4; e0 += 256 * CU) {
+    cf4 v[CU];
+    cf4* dp[CU];
+#pragma unroll
+    for (int u = 0; u < CU; ++u) {
+      const int e = e0 + 256 * u;
+      dp[u] = nullptr;
+      if (e < N * per4) {
+        const int dst = e / per4, i = e - dst * per4;
+        const int sidx = src_s[dst];
+        const bool prop = sidx < N;
+        const int ss = prop ? sidx : sidx - N;
+        if (i < r4) {
+          const float* rs = (prop ? a.rec_p : a.rec_d) + ((size_t)r * N + ss) * rec::W;
+          v[u] = reinterpret_cast<const cf4*>(rs)[i];
+          if (i == rec::ID / 4) v[u][rec::ID % 4] = id_s[dst];
+          dp[u] = reinterpret_cast<cf4*>(a.rec_next + ((size_t)r * N + dst) * rec::W) + i;
+        } else {
+          const bool tmp = i < r4 + t4;
+          const int q = tmp ? i - r4 : i - r4 - t4;
+          const int w = tmp ? snh : psnh;
+          const float* sp = prop ? (tmp ? a.temporal_p : a.prior_p) + ((size_t)r * N + ss) * w + 4 * q
+                                 : a.flat + (tmp ? po.temporal_init : po.prior_init) + 4 * q;
+          v[u] = *reinterpret_cast<const cf4u*>(sp);
+          dp[u] = reinterpret_cast<cf4*>((tmp ? a.temporal_next : a.prior_next) + ((size_t)r * N + dst) * w) + q;
+        }
       }
-      reinterpret_cast<cf4*>(dp + ((size_t)r * N + dst) * w)[q] = v;
     }
+#pragma unroll
+    for (int u = 0; u < CU; ++u)
+      if (dp[u] != nullptr) *dp[u] = v[u];
   }
   // the 9 hidden outputs + object id (seq.py:121-134)
   for (int e = tid; e < N * 64; e += 256) {
