@@ -185,17 +185,17 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   const float hg = 0.5f * (float)(G - 1);
   for (int yb0 = 0; yb0 < H; yb0 += band_rows) {
     const int yb1 = min(H, yb0 + band_rows) - 1, n = (yb1 - yb0 + 1) * W, pix0 = yb0 * W;
-    float xv[SQ_CANVAS_PF], mv[SQ_CANVAS_PF];
+    float xv[SQ_CANVAS_PF_BWD], mv[SQ_CANVAS_PF_BWD];
 #pragma unroll
-    for (int q = 0; q < SQ_CANVAS_PF; ++q) {
+    for (int q = 0; q < SQ_CANVAS_PF_BWD; ++q) {
       const int p = tid + q * 256;
       xv[q] = p < n ? img[pix0 + p] : 0.0f;
       mv[q] = p < n ? a.mean_img[pix0 + p] : 0.0f;
     }
-    sq_canvas_band(c, yb0, yb1, N, G, H, W);
+    sq_canvas_band<SQ_CANVAS_ROWS_BWD>(c, yb0, yb1, N, G, H, W);
     // ---- (2) adjoints of the band's pixels
 #pragma unroll
-    for (int q = 0; q < SQ_CANVAS_PF; ++q) {
+    for (int q = 0; q < SQ_CANVAS_PF_BWD; ++q) {
       const int p = tid + q * 256;
       if (p < n) {
         const float m = sq_sigmoid(-10.0f + c.ms[p] * 20.0f);
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
 
 // band height and dynamic LDS of k_insert_loglik_bwd
 static size_t insert_bwd_lds(const Dims& d, int& band_rows) {
-  band_rows = sq_canvas_band_rows(d.H, d.W);
+  band_rows = sq_canvas_band_rows(d.H, d.W, SQ_CANVAS_PF_BWD);
   const size_t bytes = insert_bwd_lds_floats(d, band_rows) * sizeof(float);
   static bool big = false;
   if (bytes > 48 * 1024 && !big) {

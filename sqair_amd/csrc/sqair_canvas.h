@@ -4,18 +4,22 @@
 //
 // A glimpse covers a small axis-aligned BOX of the canvas (the inverse warp is separable and monotone per axis), so the
 // canvas is built slot by slot over each slot's box, 256 threads as a 32 x 8 patch, into an LDS band of at most
-// SQ_CANVAS_BAND_PIXELS pixels (whole rows; the 50 x 50 frame is one band, a 128 x 128 frame eight).  Until round 3
+// 256 PF pixels (whole rows; with PF = 10 the 50 x 50 frame is one band, a 128 x 128 frame eight).  Until round 3
 // every pixel walked all N slots: with consecutive pixels on a wavefront's lanes a wave ran a slot's bilinear body
 // whenever ANY of its 64 pixels was inside that box -- 2.7x the useful work at 50 x 50, far more at 128 x 128.
 #pragma once
 #include "sqair_common.h"
 
-constexpr int SQ_CANVAS_PF = 10;                               // frame / mean-image values a thread holds per band
-constexpr int SQ_CANVAS_BAND_PIXELS = 256 * SQ_CANVAS_PF;
+// Two tunings (template parameters PF = frame / mean-image values a thread holds per band, so a band has at most 256 PF
+// pixels, and ROWS = patch rows a thread has in flight in sq_canvas_band).  Forward: PF 5, ROWS 2 -- 65 VGPRs and 18 KB of LDS
+// at 50 x 50 let all of the pass's 1600 workgroups be resident at once (25 -> 21 us; PF 10 / ROWS 4: 108 VGPRs, two rounds).
+// Adjoint: PF 10, ROWS 4 -- it holds the glimpse gradient in LDS as well and is resident in two rounds either way, where
+// fewer, larger bands win (64 us against 71; 243 against 306 at 128 x 128).
+constexpr int SQ_CANVAS_PF_FWD = 5, SQ_CANVAS_ROWS_FWD = 2, SQ_CANVAS_PF_BWD = 10, SQ_CANVAS_ROWS_BWD = 4;
 
-// rows per band for a W-wide frame: as many whole rows as fit SQ_CANVAS_BAND_PIXELS (host + device agree through the argument)
-static inline int sq_canvas_band_rows(int H, int W) {
-  int rows = SQ_CANVAS_BAND_PIXELS / W;
+// rows per band for a W-wide frame: as many whole rows as fit 256 PF pixels (host + device agree through the argument)
+static inline int sq_canvas_band_rows(int H, int W, int pf) {
+  int rows = 256 * pf / W;
   if (rows < 1) rows = 1;
   return rows < H ? rows : H;
 }
@@ -117,6 +121,7 @@ __device__ __forceinline__ bool sq_canvas_slot(const CanvasLds& c, int k, int yb
 
 // canvas and mask sum of rows [yb0, yb1] into c.cv / c.ms (slots added in index order, as the reference's sum over objects);
 // ends on a barrier
+template <int ROWS>
 __device__ __forceinline__ void sq_canvas_band(const CanvasLds& c, int yb0, int yb1, int N, int G, int H, int W) {
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
   const int n = (yb1 - yb0 + 1) * W;
@@ -129,16 +134,17 @@ __device__ __forceinline__ void sq_canvas_band(const CanvasLds& c, int yb0, int 
     CanvasSlot s;
     if (!sq_canvas_slot(c, k, yb0, yb1, s)) continue;
     const float* gk = c.gl + k * G * G;
-    // four rows of the patch per trip: all their table / glimpse reads first, the read-modify-writes of the band after them (one
-    // pixel at a time the reads of a pixel queued behind the writes of the one before: ~6 dependent LDS round trips per pixel)
-    for (int Y0 = s.y0 + ty; Y0 <= s.y1; Y0 += 32)
+    // ROWS rows of the patch per trip: all their table / glimpse reads first, the read-modify-writes of the band after
+    // them (one pixel at a time the reads of a pixel queued behind the writes of the one before: ~6 dependent LDS round trips
+    // per pixel)
+    for (int Y0 = s.y0 + ty; Y0 <= s.y1; Y0 += 8 * ROWS)
       for (int X = s.x0 + tx; X <= s.x1; X += 32) {
         const float xg = c.xt[k * W + X];
-        float v[4], on[4];
+        float v[ROWS], on[ROWS];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) sq_canvas_tap(gk, xg, c.yt[k * H + min(Y0 + 8 * u, s.y1)], G, v[u], on[u]);
+        for (int u = 0; u < ROWS; ++u) sq_canvas_tap(gk, xg, c.yt[k * H + min(Y0 + 8 * u, s.y1)], G, v[u], on[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < ROWS; ++u)
           if (Y0 + 8 * u <= s.y1) {
             const int o = (Y0 + 8 * u - yb0) * W + X;
             c.cv[o] += v[u] * s.pk;

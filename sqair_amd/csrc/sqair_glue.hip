@@ -880,7 +880,7 @@ int sq_launch_compact(const CompactArgs& a, POff po, Dims d, hipStream_t s) {
 // glimpses sit in LDS, the canvas is built band by band over the slots' boxes (sqair_canvas.h), then
 // every thread finishes its pixels of the band: the canvas is written at most once, the frame read once.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const Dims d, const int band_rows SQ_TLP) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_insert_loglik(const InsertArgs a, const Dims d, const int band_rows SQ_TLP) {
   SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.N, G = d.G, G2 = d.G * d.G, H = d.H, W = d.W, P = d.H * d.W;
@@ -898,16 +898,16 @@ __global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const
   float ll = 0.0f;
   for (int yb0 = 0; yb0 < H; yb0 += band_rows) {
     const int yb1 = min(H, yb0 + band_rows) - 1, n = (yb1 - yb0 + 1) * W, pix0 = yb0 * W;
-    float xv[SQ_CANVAS_PF], mv[SQ_CANVAS_PF];  // the band's frame / mean-image values: in flight while the canvas is built
+    float xv[SQ_CANVAS_PF_FWD], mv[SQ_CANVAS_PF_FWD];  // the band's frame / mean-image values: in flight while the canvas is built
 #pragma unroll
-    for (int q = 0; q < SQ_CANVAS_PF; ++q) {
+    for (int q = 0; q < SQ_CANVAS_PF_FWD; ++q) {
       const int p = tid + q * 256;
       xv[q] = p < n ? img[pix0 + p] : 0.0f;
       mv[q] = p < n ? a.mean_img[pix0 + p] : 0.0f;
     }
-    sq_canvas_band(c, yb0, yb1, N, G, H, W);
+    sq_canvas_band<SQ_CANVAS_ROWS_FWD>(c, yb0, yb1, N, G, H, W);
 #pragma unroll
-    for (int q = 0; q < SQ_CANVAS_PF; ++q) {
+    for (int q = 0; q < SQ_CANVAS_PF_FWD; ++q) {
       const int p = tid + q * 256;
       if (p < n) {
         const float m = sq_sigmoid(-10.0f + c.ms[p] * 20.0f);
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik(const InsertArgs a, const
   }
 }
 int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s) {
-  const int band_rows = sq_canvas_band_rows(d.H, d.W);
+  const int band_rows = sq_canvas_band_rows(d.H, d.W, SQ_CANVAS_PF_FWD);
   const size_t shm = sq_canvas_lds_floats(d.N, d.G, d.H, d.W, band_rows) * sizeof(float);
   static bool big = false;
   if (shm > 48 * 1024 && !big) {
