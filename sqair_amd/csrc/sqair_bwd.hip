@@ -212,53 +212,68 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
       }
     }
     __syncthreads();
-    // ---- (3) d/d (sx, sy, tx, ty) of every slot, over its box
-    for (int k = 0; k < N; ++k) {
-      CanvasSlot s;
-      if (!sq_canvas_slot(c, k, yb0, yb1, s)) continue;
-      const float* gk = c.gl + k * G2;
-      const float sx = c.co[k * 4 + 0], sy = c.co[k * 4 + 1], tcx = c.co[k * 4 + 2], tcy = c.co[k * 4 + 3];
-      float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
-      for (int Y = s.y0 + ty; Y <= s.y1; Y += 8) {
-        const float yg = c.yt[k * H + Y];
-        const float y0f = floorf(yg);
-        const int y0 = (int)y0f;
-        const float wy1 = yg - y0f;
-        const float Yn = -1.0f + 2.0f * (float)Y / (float)(H - 1);
-        for (int X = s.x0 + tx; X <= s.x1; X += 32) {
-          const float xg = c.xt[k * W + X];
-          const float x0f = floorf(xg);
-          const int x0 = (int)x0f;
-          const float wx1 = xg - x0f;
-          float t[2][2], vl[2][2];
+    // ---- (3) d/d (sx, sy, tx, ty) of every slot, over its box.  With gx / gy the adjoints of a pixel's glimpse coordinates,
+    // d sx = -hg / sx^2 sum gx (Xn - tx), d tx = -hg / sx sum gx (y alike): four running sums per thread, no division
+    // per pixel; WG_ROWS patch rows in flight, taps at clamped addresses under validity masks (one pixel at a time
+    // with four divisions each this phase was 24 of the kernel's 64 us)
+    {
+      constexpr int WG_ROWS = 2;   // (4 rows in flight: 123 VGPRs, a workgroup fewer per CU, slower)
+      const float inv_w = 2.0f / (float)(W - 1), inv_h = 2.0f / (float)(H - 1);
+      for (int k = 0; k < N; ++k) {
+        CanvasSlot s;
+        if (!sq_canvas_slot(c, k, yb0, yb1, s)) continue;
+        const float* gk = c.gl + k * G2;
+        const float sx = c.co[k * 4 + 0], sy = c.co[k * 4 + 1], tcx = c.co[k * 4 + 2], tcy = c.co[k * 4 + 3];
+        float sgx = 0.0f, sgxx = 0.0f, sgy = 0.0f, sgyy = 0.0f;
+        for (int Y0 = s.y0 + ty; Y0 <= s.y1; Y0 += 8 * WG_ROWS)
+          for (int X = s.x0 + tx; X <= s.x1; X += 32) {
+            const float xg = c.xt[k * W + X];
+            const float x0f = floorf(xg);
+            const int x0 = (int)x0f;
+            const float wx1 = xg - x0f;
+            const bool xa_ok = x0 >= 0, xb_ok = x0 + 1 < G;
+            const int xa = max(x0, 0), xb = min(x0 + 1, G - 1);
+            const float Xn = -1.0f + (float)X * inv_w;
+            float gxs[WG_ROWS], gys[WG_ROWS], yns[WG_ROWS];
 #pragma unroll
-          for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-              const int yy = y0 + dy, xx = x0 + dx;
-              const bool ok = yy >= 0 && yy < G && xx >= 0 && xx < G;
-              vl[dy][dx] = ok ? 1.0f : 0.0f;
-              t[dy][dx] = ok ? gk[yy * G + xx] : 0.0f;
+            for (int u = 0; u < WG_ROWS; ++u) {
+              const int Y = min(Y0 + 8 * u, s.y1);
+              const float yg = c.yt[k * H + Y];
+              const float y0f = floorf(yg);
+              const int y0 = (int)y0f;
+              const float wy1 = yg - y0f;
+              const bool ya_ok = y0 >= 0, yb_ok = y0 + 1 < G;
+              const float* ra = gk + max(y0, 0) * G;
+              const float* rb = gk + min(y0 + 1, G - 1) * G;
+              const float v00 = ya_ok && xa_ok ? 1.0f : 0.0f, v01 = ya_ok && xb_ok ? 1.0f : 0.0f;
+              const float v10 = yb_ok && xa_ok ? 1.0f : 0.0f, v11 = yb_ok && xb_ok ? 1.0f : 0.0f;
+              const float t00 = ra[xa] * v00, t01 = ra[xb] * v01, t10 = rb[xa] * v10, t11 = rb[xb] * v11;
+              // d/d xg, d/d yg of (g_cv * bilinear(glimpse) + g_ms * bilinear(ones))
+              const float dvdx = (1.0f - wy1) * (t01 - t00) + wy1 * (t11 - t10);
+              const float dvdy = (1.0f - wx1) * (t10 - t00) + wx1 * (t11 - t01);
+              const float dodx = (1.0f - wy1) * (v01 - v00) + wy1 * (v11 - v10);
+              const float dody = (1.0f - wx1) * (v10 - v00) + wx1 * (v11 - v01);
+              const int o = (Y - yb0) * W + X;
+              const float on = Y0 + 8 * u <= s.y1 ? s.pk : 0.0f;   // (rows past the box: clamped reads, no contribution)
+              gxs[u] = on * (c.cv[o] * dvdx + c.ms[o] * dodx);
+              gys[u] = on * (c.cv[o] * dvdy + c.ms[o] * dody);
+              yns[u] = -1.0f + (float)Y * inv_h;
             }
-          // d/d xg, d/d yg of (g_cv * bilinear(glimpse) + g_ms * bilinear(ones))
-          const float dvdx = (1.0f - wy1) * (t[0][1] - t[0][0]) + wy1 * (t[1][1] - t[1][0]);
-          const float dvdy = (1.0f - wx1) * (t[1][0] - t[0][0]) + wx1 * (t[1][1] - t[0][1]);
-          const float dodx = (1.0f - wy1) * (vl[0][1] - vl[0][0]) + wy1 * (vl[1][1] - vl[1][0]);
-          const float dody = (1.0f - wx1) * (vl[1][0] - vl[0][0]) + wx1 * (vl[1][1] - vl[0][1]);
-          const int o = (Y - yb0) * W + X;
-          const float g_cv = c.cv[o], g_ms = c.ms[o];
-          const float gx = s.pk * (g_cv * dvdx + g_ms * dodx), gy = s.pk * (g_cv * dvdy + g_ms * dody);
-          const float Xn = -1.0f + 2.0f * (float)X / (float)(W - 1);
-          d0 += gx * (-hg * (Xn - tcx) / (sx * sx));
-          d1 += gy * (-hg * (Yn - tcy) / (sy * sy));
-          d2 += gx * (-hg / sx);
-          d3 += gy * (-hg / sy);
+#pragma unroll
+            for (int u = 0; u < WG_ROWS; ++u) {
+              sgx += gxs[u];
+              sgxx += gxs[u] * (Xn - tcx);
+              sgy += gys[u];
+              sgyy += gys[u] * (yns[u] - tcy);
+            }
+          }
+        float d0 = -hg / (sx * sx) * sgxx, d1 = -hg / (sy * sy) * sgyy;
+        float d2 = -hg / sx * sgx, d3 = -hg / sy * sgy;
+        d0 = sq_wave_sum(d0); d1 = sq_wave_sum(d1); d2 = sq_wave_sum(d2); d3 = sq_wave_sum(d3);
+        if (lane == 0) {   // one writer per (wave, slot)
+          float* ac = acc_s + (wave * N + k) * 4;
+          ac[0] += d0; ac[1] += d1; ac[2] += d2; ac[3] += d3;
         }
-      }
-      d0 = sq_wave_sum(d0); d1 = sq_wave_sum(d1); d2 = sq_wave_sum(d2); d3 = sq_wave_sum(d3);
-      if (lane == 0) {   // one writer per (wave, slot)
-        float* ac = acc_s + (wave * N + k) * 4;
-        ac[0] += d0; ac[1] += d1; ac[2] += d2; ac[3] += d3;
       }
     }
     // ---- (4) glimpse gradient by gathering (see the header): texel i = (k, gy, gx), rows of this band
