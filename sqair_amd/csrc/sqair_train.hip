@@ -34,6 +34,12 @@ __global__ void k_zero(float* __restrict__ p, int64_t n SQ_TLP) {
     p4[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = 0.0f;
 }
+#ifdef SQAIR_KNOBS
+__global__ void k_fill_value(float* __restrict__ p, int64_t n, float v SQ_TLP) {
+  SQ_TL_SCOPE;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+#endif
 void sq_zero_fill(float* p, int64_t n, hipStream_t s) {  // p 16-byte aligned
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -133,42 +139,51 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   const int64_t pre_ld = h->layers[L_PRE].nt * 16;
   BwdSpace b;
   memset(&b, 0, sizeof(b));
+  // Two groups: buffers the pass accumulates into or reads before it has written all of them come first and are cleared at the
+  // start of every pass (zero_total floats); buffers that are WRITTEN IN FULL before anything reads them -- the decoder's
+  // temporaries, the per-row mean-image terms, the A operands built for the batched weight gradients -- follow and are not.
+  // The knob build can fill the second group with NaNs ahead of a pass (SQAIR_SCRATCH_POISON): the gradient tests pass on that
+  // library, which is what "written in full" rests on.  (The per-layer pre-activation gradients do NOT qualify: with them
+  // poisoned, NaNs reach enc.what_head / enc.mask / disc.* -- padded columns behind zero weights, and the paths a flag
+  // disables, whose weight gradients are still taken from the zeroed buffers.)
   int64_t o = 0;
-  auto take = [&](int64_t n) {
-    float* p = base ? base + o : nullptr;
+  for (int pass = 0; pass < 2; ++pass) {
+  auto T_ = [&](float*& dst, int64_t n, bool written_in_full = false) {
+    if ((int)written_in_full != pass) return;
+    dst = base ? base + o : nullptr;
     o += align64(n);
-    return p;
   };
-  b.g_lw = take(T * R); b.g_dl = take(T * R);
-  b.d_rec_m = take((T + 1) * M * rec::W); b.d_rec_p = take(MT * rec::W); b.d_rec_d = take(MT * rec::W);
+  T_(b.g_lw, T * R); T_(b.g_dl, T * R);
+  T_(b.d_rec_m, (T + 1) * M * rec::W); T_(b.d_rec_p, MT * rec::W); T_(b.d_rec_d, MT * rec::W);
   const int64_t snh = c.time_cell == CELL_LSTM ? 2 * nh : nh, gw = sq_gate_width(c, c.time_cell);  // temporal state / gate widths
   const int64_t psnh = c.prior_cell == CELL_LSTM ? 2 * nh : nh, pgw = sq_gate_width(c, c.prior_cell);
   const int64_t rw = sq_rnn_width(c);  // slot-RNN pre-activation width
   b.tm_stride = align64(M * snh); b.pm_stride = align64(M * psnh);
-  b.d_tm0 = take((T + 1) * b.tm_stride); b.d_pm0 = take((T + 1) * b.pm_stride);
-  b.d_temporal_p = take(M * snh); b.d_prior_p = take(M * psnh);
-  b.d_pstats = take(MT * PS_LD); b.d_spre = take(T * R * 128); b.d_raw = take(2 * MT);
-  b.d_pgru1 = take(MT * pgw); b.d_hid1 = take(MT * 256); b.d_wb = take(MT * WB_LD); b.d_maskpre = take(MT * G2);
-  b.d_pea = take(MT * nh); b.d_peb = take(MT * nh); b.d_m1 = take(MT * M1_LD); b.d_pre = take(MT * pre_ld);
-  b.d_lea = take(MT * nh); b.d_leb = take(MT * nh); b.d_pre_d = take(T * R * rw); b.d_pre_disc = take((int64_t)T * B * rw);
+  T_(b.d_tm0, (T + 1) * b.tm_stride); T_(b.d_pm0, (T + 1) * b.pm_stride);
+  T_(b.d_temporal_p, M * snh); T_(b.d_prior_p, M * psnh);
+  T_(b.d_pstats, MT * PS_LD); T_(b.d_spre, T * R * 128); T_(b.d_raw, 2 * MT);
+  T_(b.d_pgru1, MT * pgw); T_(b.d_hid1, MT * 256); T_(b.d_wb, MT * WB_LD); T_(b.d_maskpre, MT * G2);
+  T_(b.d_pea, MT * nh); T_(b.d_peb, MT * nh); T_(b.d_m1, MT * M1_LD); T_(b.d_pre, MT * pre_ld);
+  T_(b.d_lea, MT * nh); T_(b.d_leb, MT * nh); T_(b.d_pre_d, T * R * rw); T_(b.d_pre_disc, (int64_t)T * B * rw);
   const int64_t S = 2 * MT;
-  b.d_rnn = take(S * rw); b.d_t1 = take(S * T1_LD); b.d_t2 = take(S * nh); b.d_tp = take(S * TP_LD);
-  b.d_e1 = take(S * nh); b.d_e2 = take(S * nh); b.d_enc3 = take(S * ENC_LD); b.d_gru1 = take(MT * gw);
-  b.d_hraw = take(MT * HRAW_LD);
-  b.d_g = take(R * G2); b.d_g1 = take(M * G2); b.d_c = take(R * nh);
-  b.tmp = take(M * 512);
-  b.d_new_t = take(T * R * snh); b.d_new_p = take(T * R * psnh);
-  b.d_init_p = take(T * R * nh); b.d_init_d = take(T * R * nh); b.d_rn0 = take(T * R * 4);
-  b.d_r[0] = take(R * nh); b.d_r[1] = take(R * nh); b.dhn = take(M * nh); b.d_rh = take(M * nh);
-  b.d_enc = take(R * ENC_LD);
-  b.d_cs[0] = take(R * nh); b.d_cs[1] = take(R * nh); b.d_hk = take(R * nh);
+  T_(b.d_rnn, S * rw); T_(b.d_t1, S * T1_LD); T_(b.d_t2, S * nh); T_(b.d_tp, S * TP_LD);
+  T_(b.d_e1, S * nh); T_(b.d_e2, S * nh); T_(b.d_enc3, S * ENC_LD); T_(b.d_gru1, MT * gw);
+  T_(b.d_hraw, MT * HRAW_LD);
+  T_(b.d_g, R * G2); T_(b.d_g1, M * G2); T_(b.d_c, R * nh);
+  T_(b.tmp, M * 512);
+  T_(b.d_new_t, T * R * snh); T_(b.d_new_p, T * R * psnh);
+  T_(b.d_init_p, T * R * nh); T_(b.d_init_d, T * R * nh); T_(b.d_rn0, T * R * 4);
+  T_(b.d_r[0], R * nh); T_(b.d_r[1], R * nh); T_(b.dhn, M * nh); T_(b.d_rh, M * nh);
+  T_(b.d_enc, R * ENC_LD);
+  T_(b.d_cs[0], R * nh); T_(b.d_cs[1], R * nh); T_(b.d_hk, R * nh);
   const int64_t big = MT * (nh > G2 ? nh : G2);
-  b.d_gl = take(MT * G2); b.d_mean_rows = take(T * R * P_); b.bufa = take(big); b.bufb = take(big);
-  b.d_ia = take((int64_t)T * B * nh); b.d_ib = take((int64_t)T * B * nh);
-  b.zero_total = o;
-  b.bufc = take(MT * nh);
-  for (int i = 0; i < 2; ++i) { b.zs[i] = take(MT * 64); b.rs[i] = take(MT * nh); }
-  for (int i = 0; i < 4; ++i) b.rh[i] = take(MT * nh);
+  T_(b.d_gl, MT * G2, true); T_(b.d_mean_rows, T * R * P_, true); T_(b.bufa, big, true); T_(b.bufb, big, true);
+  T_(b.d_ia, (int64_t)T * B * nh); T_(b.d_ib, (int64_t)T * B * nh);
+  T_(b.bufc, MT * nh, true);
+  for (int i = 0; i < 2; ++i) { T_(b.zs[i], MT * 64, true); T_(b.rs[i], MT * nh, true); }
+  for (int i = 0; i < 4; ++i) T_(b.rh[i], MT * nh, true);
+  if (pass == 0) b.zero_total = o;
+  }
   b.total = o;
   return b;
 }
@@ -212,6 +227,12 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   }
   sq_zero_fill(flat_grad, h->n_params, s);
   sq_zero_fill((float*)scratch, b.zero_total, s);
+#ifdef SQAIR_KNOBS
+  {  // measurement / test knob: NaNs into everything the pass claims to write in full before reading (carve_bwd)
+    static const bool poison = SQ_KNOB_SET("SQAIR_SCRATCH_POISON");
+    if (poison) SQ_LAUNCH(k_fill_value, dim3(2048), dim3(256), 0, s, (float*)scratch + b.zero_total, b.total - b.zero_total, __builtin_nanf(""));
+  }
+#endif
 
   // dX through the transposed pack: out[M][K of the forward layer] (+)= dpre[M][N] W^T.  Single-segment layers write
   // exactly their true input width; multi-segment layers write all 16 * kc padded columns (the caller splits them).

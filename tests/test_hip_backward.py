@@ -1,5 +1,6 @@
 """-m gpu: adjoint kernels (building blocks of the training step) against autograd on the CPU oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -172,7 +173,7 @@ def test_backward_decoder_branch_matches_autograd(K, N, T, B, hw):
     d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=min(28, hw[0] // 2), seed=11)
     obs = to_float(d["imgs"])
     P = params32(F, hw, 4, 0.05, obs.mean((0, 1)))
-    core = SqairCore(F, hw)
+    core = SqairCore(F, hw, lib_path=lib_path)
     core.set_params(P)
     names = ["log_weights_per_timestep", "discrete_log_prob", "presence", "prop_pres", "disc_pres"]
     m = Model(obs, None, core, K, outputs=names)
@@ -215,7 +216,7 @@ def test_rmsprop_step_matches_tf_semantics():
         lib.sqair_destroy(h)
 
 
-def _full_backward_case(K, N, T, B, hw, seed, flags=None):
+def _full_backward_case(K, N, T, B, hw, seed, flags=None, lib_path=None):
     from sqair_amd.data import make_sequences, to_float
     from sqair_amd.model import Model, SqairCore
     from tests.hip_util import draw_noise, params32
@@ -223,7 +224,7 @@ def _full_backward_case(K, N, T, B, hw, seed, flags=None):
     d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=min(28, hw[0] // 2), seed=seed)
     obs = to_float(d["imgs"])
     P = params32(F, hw, 4, 0.05, obs.mean((0, 1)))
-    core = SqairCore(F, hw)
+    core = SqairCore(F, hw, lib_path=lib_path)
     core.set_params(P)
     names = ["log_weights_per_timestep", "discrete_log_prob", "presence", "prop_pres", "disc_pres"]
     m = Model(obs, None, core, K, outputs=names)
@@ -451,6 +452,22 @@ def test_full_backward_flag_variants(flags):
     feed back into z_{t-1}), geometric step prior, fixed where prior, unmasked glimpses, the LSTM temporal / prior / slot-RNN cells."""
     report, ref, _ = _full_backward_case(K=3, N=3, T=3, B=3, hw=(50, 50), seed=11, flags=flags)
     assert float(ref.prop_pres.detach().sum()) > 0
+    _check_report(report)
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(prop_prior_type="guided", masked_glimpse=False), dict(transition="LSTM", time_transition="LSTM"),
+                                   dict(disc_prior_type="geom", rec_where_prior=False)])
+def test_scratch_the_backward_pass_does_not_clear_is_written_in_full(flags, monkeypatch):
+    """`sqair_backward` clears only part of its scratch (carve_bwd, sqair_train.hip): the rest it claims to write in full before
+    reading it.  The knob build of the library fills that rest with NaNs ahead of the pass (SQAIR_SCRATCH_POISON); every
+    gradient must come out as on the product library."""
+    knob_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin", "libsqair_hip_knobs.so")
+    if not os.path.exists(knob_lib):
+        pytest.skip("knob build of the library not present (python sqair_amd/csrc/build.py --knobs)")
+    monkeypatch.setenv("SQAIR_SCRATCH_POISON", "1")
+    report, _, _ = _full_backward_case(K=3, N=3, T=3, B=3, hw=(50, 50), seed=11, flags=flags, lib_path=knob_lib)
+    _check_report(report)
+    report, _, _ = _full_backward_case(K=2, N=3, T=1, B=2, hw=(50, 50), seed=5, flags=flags, lib_path=knob_lib)
     _check_report(report)
 
 
