@@ -173,7 +173,7 @@ def test_backward_decoder_branch_matches_autograd(K, N, T, B, hw):
     d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=min(28, hw[0] // 2), seed=11)
     obs = to_float(d["imgs"])
     P = params32(F, hw, 4, 0.05, obs.mean((0, 1)))
-    core = SqairCore(F, hw, lib_path=lib_path)
+    core = SqairCore(F, hw)
     core.set_params(P)
     names = ["log_weights_per_timestep", "discrete_log_prob", "presence", "prop_pres", "disc_pres"]
     m = Model(obs, None, core, K, outputs=names)
