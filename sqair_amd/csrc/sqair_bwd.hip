@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_crop_bwd(const CropBwdArgs a, const Dim
     const float hx = 0.5f * (float)(d.W - 1), hy = 0.5f * (float)(d.H - 1);
     float dsx = 0.0f, dsy = 0.0f, dtx = 0.0f, dty = 0.0f;
     for (int pix = tid; pix < G2; pix += 256) {
-      const int i = pix / G, j = pix - i * G;
+      const int i = sq_div(pix, d.g_mul), j = pix - i * G;
       const float gx = -1.0f + 2.0f * (float)j / (float)(G - 1), gy = -1.0f + 2.0f * (float)i / (float)(G - 1);
       const float x = hx * (sx * gx + tx + 1.0f), y = hy * (sy * gy + ty + 1.0f);
       const float x0f = floorf(x), y0f = floorf(y);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   float* acc_s = reinterpret_cast<float*>(yr_s + N * G);  // 4 waves * N * 4
   const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, tx = tid & 31, ty = tid >> 5;
   const int fr = blockIdx.y;  // frame
-  const int b = r / d.K;
+  const int b = sq_div(r, d.k_mul);
   const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot-row of this (frame, row)
   const size_t frr = (size_t)fr * d.R + r;
   const float gll = a.g_ll[frr];
@@ -1480,7 +1480,7 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
   __shared__ float red_s[4][4];
   __shared__ float dtp_s[8];
   // one workgroup per particle row (the K particles of a sequence re-stage the same frame from L2: 10 KB at 50x50)
-  const int r = blockIdx.x, b = r / d.K, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = blockIdx.x, b = sq_div(r, d.k_mul), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int slot = a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot;
   const int P = d.H * d.W, G = d.G, G2 = d.G * d.G, RW = rec::W;
   const float* img = a.img + (size_t)b * P;
@@ -1553,7 +1553,7 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
     const float hx = 0.5f * (float)(d.W - 1), hy = 0.5f * (float)(d.H - 1);
     float dsx = 0.0f, dsy = 0.0f, dtx = 0.0f, dty = 0.0f;
     auto pixel = [&](const int pix, float g, const float mk, const float dmk) {
-      const int i = pix / G, j = pix - i * G;
+      const int i = sq_div(pix, d.g_mul), j = pix - i * G;
       const float gx = -1.0f + 2.0f * (float)j / (float)(G - 1), gy = -1.0f + 2.0f * (float)i / (float)(G - 1);
       const float x = hx * (sx * gx + tx + 1.0f), y = hy * (sy * gy + ty + 1.0f);
       const float x0f = floorf(x), y0f = floorf(y);

@@ -157,7 +157,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
 #pragma unroll
   for (int q = 0; q < EPT; ++q) {
     const int e = min(tid + 256 * q, nel - 1);
-    const int rr = e / nw, c = e - rr * nw;
+    const int rr = sq_div(e, d.nw_mul), c = e - rr * nw;
     const int r = min(row0 + rr, d.R - 1);
     v_loc[q] = a.enc[(size_t)r * a.enc_ld + c];
     v_sc[q] = a.enc[(size_t)r * a.enc_ld + nw + c];
@@ -181,7 +181,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
   for (int q = 0; q < EPT; ++q) {
     const int e = tid + 256 * q;
     if (e < nel) {
-      const int rr = e / nw, c = e - rr * nw;
+      const int rr = sq_div(e, d.nw_mul), c = e - rr * nw;
       float loc, sc;
       if (a.is_disc) {
         loc = v_loc[q];
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   __shared__ float red_s[4];
   const int r = blockIdx.x, tid = threadIdx.x;
   const int fr = blockIdx.y;  // frame
-  const int b = r / d.K;
+  const int b = sq_div(r, d.k_mul);
   const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot of this (frame, row)
   const float* __restrict__ img = a.img + ((size_t)fr * d.B + b) * P;
   const size_t frr = (size_t)fr * d.R + r;

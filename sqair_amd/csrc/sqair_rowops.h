@@ -21,7 +21,7 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
   float* tab_s = smem + 4;      // 2 * 2G
   float* img_s = smem + 4 + 4 * d.G;  // H*W when stage_img: the frame is pulled into LDS WHILE wave 0 computes `where`, so
                                       // the gather below does not start a second memory round trip after it
-  const int tid = threadIdx.x, b = r / d.K;
+  const int tid = threadIdx.x, b = sq_div(r, d.k_mul);
   const int P = d.H * d.W, G = d.G, G2 = d.G * d.G;
   const int mrow_add = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
   const int orow_add = a.out_row_add + (a.mode == CROP_PROP1 ? slot : 0);
@@ -171,7 +171,7 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
   __syncthreads();
   for (int pix = tid, q = 0; pix < G2; pix += 256, ++q) {
     const float mk = q < MPT ? mk0[q < MPT ? q : 0] : (has_mask ? LD::f(a.mask + ((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix) : 1.0f);
-    const int i = pix / G, j = pix - i * G;
+    const int i = sq_div(pix, d.g_mul), j = pix - i * G;
     const float x0f = tab_s[j * 2], wx1 = tab_s[j * 2 + 1];
     const float y0f = tab_s[(G + i) * 2], wy1 = tab_s[(G + i) * 2 + 1];
     const int x0 = (int)x0f, y0 = (int)y0f;
