@@ -1487,7 +1487,15 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
   const int madd = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
   const int gadd = a.g_row_add + (a.mode == CROP_PROP1 ? slot : 0);
   // everything the later phases read from memory is requested up front, next to the frame: the kernel then makes ONE memory
-  // round trip (it used to make three: frame | glimpse gradient + mask | the operands of the where-sample adjoint)
+  // round trip (it used to make three: frame | glimpse gradient + mask | the operands of the where-sample adjoint).  The
+  // frame's first 1024 16-byte units go out FIRST -- they still have to pass through LDS once they are here -- and the fences keep
+  // hipcc from computing every address of the kernel before it issues the first request.
+  const int n4 = P >> 2;   // (H * W is a multiple of 4: sqair_create checks)
+  const f32x4_b* __restrict__ s4 = reinterpret_cast<const f32x4_b*>(img);
+  f32x4_b fv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) fv[q] = s4[min(tid + 256 * q, n4 - 1)];
+  __builtin_amdgcn_sched_barrier(0);
   constexpr int PPT = 4;  // pixels per thread prefetched (covers G * G <= 1024)
   float g_v[PPT], m_v[PPT], dm_v[PPT];
 #pragma unroll
@@ -1532,12 +1540,13 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
     w3b = *reinterpret_cast<const f32x4_b*>(a.w3 + (size_t)tid * 8 + 4);
     t2v = a.t2[(size_t)r * a.t2_ld + tid];
   }
-  {  // frame -> LDS in 16-byte units, 4 loads per thread in flight at once (H * W is a multiple of 4: sqair_create checks).  The
-     // plain copy loop compiled to three or four dependent round trips (an unrolled trip + remainder loops waiting per element).
-    const int n4 = P >> 2;
-    const f32x4_b* __restrict__ s4 = reinterpret_cast<const f32x4_b*>(img);
+  {  // frame -> LDS in 16-byte units, 4 loads per thread in flight at once.  The plain copy loop compiled to three or four
+     // dependent round trips (an unrolled trip + remainder loops waiting per element).
     f32x4_b* d4 = reinterpret_cast<f32x4_b*>(img_s);
-    for (int base = 0; base < n4; base += 1024) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (tid + 256 * q < n4) d4[tid + 256 * q] = fv[q];
+    for (int base = 1024; base < n4; base += 1024) {   // frames beyond 4096 pixels
       f32x4_b v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = s4[min(base + tid + 256 * q, n4 - 1)];

@@ -137,6 +137,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
     for (int i = 0; i < 4; ++i) sp[t][i] = a.s1p[(size_t)min(row0 + 4 * kq + i, d.R - 1) * a.s1p_ld + col];
     w2v[t] = a.flat[a.w2_off + col];
   }
+  __builtin_amdgcn_sched_barrier(0);   // (see k_rnn_tail: issue this group's loads before the next group's address arithmetic)
   const int pr = min(row0 + (tid & 15), d.R - 1);
   const float b2 = a.flat[a.b2_off];
   const float u = a.noise[(((size_t)pr * 2 + (a.is_disc ? 1 : 0)) * d.N + a.slot) * d.nzw + 4 + nw];
@@ -150,6 +151,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
 #pragma unroll
     for (int q = 0; q < 4; ++q) whv[q] = wh[q];
   }
+  __builtin_amdgcn_sched_barrier(0);
   // ---- what sample for the 16 rows (nw elements each), operands requested in one burst
   constexpr int EPT = 4;
   const int nel = 16 * nw;
@@ -299,9 +301,13 @@ __global__ __launch_bounds__(256) void k_rnn_tail(const TailArgs ta, const Dims 
     bh[i] = wp[(size_t)g * 64];
     ah[i] = *reinterpret_cast<const f32x4_t*>(hrow + (g - 4) * 16 + kq * 4);
   }
+  // (fences: hipcc otherwise computes the addresses of ALL ~70 loads of the kernel -- 180 instructions of 64-bit address
+  // arithmetic -- before it issues the first one; each group of requests goes out as soon as its own addresses are known)
+  __builtin_amdgcn_sched_barrier(0);
   const int m = row0 + (tid >> 4), n = tile_n * 16 + (tid & 15);
   const int mc = min(m, d.R - 1), nc = min(n, n_out - 1);
   const float p_bias = bias[nc], p_add = add[(size_t)mc * add_ld + nc];
+  __builtin_amdgcn_sched_barrier(0);
   tail_body<true>(ta, d, row0, tile_n == 0, zt, rs);
   __syncthreads();
   const f32x4_t az = *reinterpret_cast<const f32x4_t*>(&zt[l15 * ZLD + 16 * wave + 4 * kq]);

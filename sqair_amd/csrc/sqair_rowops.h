@@ -28,22 +28,23 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
   const float* __restrict__ img = a.img + (size_t)b * P;
   const bool has_mask = a.mask != nullptr;
   const bool fused_tp = a.t2 != nullptr && (a.mode == CROP_PROP2 || a.mode == CROP_DISC);
-  constexpr int IPT = 10;  // first 2560 frame pixels: requested before anything else, stored after the where computation
+  // Requests in the order of the kernel's critical path: the operands of the where sample (32 threads: the fused output layer
+  // of the transform, the noise, the previous where) go out FIRST, the frame and the mask -- needed only after the where
+  // computation -- behind them.  (The frame used to be requested first: the where operands' loads then sat ~400 instructions of
+  // address arithmetic into the kernel.)
+  constexpr int IPT = 10;  // first 2560 frame pixels: stored to LDS after the where computation
   float v0[IPT];
-  if (stage_img) {
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) v0[q] = img[min(q * 256 + tid, P - 1)];
-  }
-  constexpr int MPT = 2;  // mask values of this thread's first pixels, requested up front as well
+  constexpr int MPT = 2;   // mask values of this thread's first pixels, requested up front as well
   float mk0[MPT];
-#pragma unroll
-  for (int q = 0; q < MPT; ++q)
-    mk0[q] = has_mask ? LD::f(a.mask + ((size_t)r * a.mask_row_mul + mrow_add) * G2 + min(tid + 256 * q, G2 - 1)) : 1.0f;
+  const int hl = tid, ci = hl & 3;
+  const int per = d.nh / 32;
+  float tp_loc = 0.0f, tp_raw = 0.0f;
+  float e[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zp = 0.0f, off = 0.0f, chv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wbv = 0.0f, lg = 0.0f;
+  constexpr int QM = 2;
+  const int nq = per / 4;
+  sq_f32x4 xv[QM];
+  float4 wv[QM][4][2];
   if (tid < 32) {
-    const int hl = tid, ci = hl & 3;
-    const int per = d.nh / 32;
-    float tp_loc = 0.0f, tp_raw = 0.0f;
-    float e[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zp = 0.0f, off = 0.0f, chv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wbv = 0.0f, lg = 0.0f;
     if (a.mode == CROP_PLAIN) {
       lg = LD::f(a.logits + (size_t)r * 4 + ci);
     } else if (a.mode == CROP_PROP1) {
@@ -67,16 +68,11 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
       }
     }
     if (fused_tp) {
-      float part[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       const float* xrow = a.t2 + (size_t)r * a.t2_ld + per * hl;
       const float4* w4 = reinterpret_cast<const float4*>(a.w3) + (size_t)per * hl * 2;
       // Every load of the layer is requested before the first product (compile-time trip counts, clamped addresses): with the
       // runtime bound per / 4 the two loops below were four dependent memory round trips (activations one by one, then the
       // weights of each group of 4 inputs) on the critical path of every slot.  nh <= 256 => per / 4 <= 2; sums in the same order.
-      constexpr int QM = 2;
-      const int nq = per / 4;
-      sq_f32x4 xv[QM];
-      float4 wv[QM][4][2];
 #pragma unroll
       for (int q = 0; q < QM; ++q) {
         const int qc = min(q, nq - 1);
@@ -84,6 +80,22 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) { wv[q][ii][0] = w4[(qc * 4 + ii) * 2]; wv[q][ii][1] = w4[(qc * 4 + ii) * 2 + 1]; }
       }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (stage_img) {
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) v0[q] = img[min(q * 256 + tid, P - 1)];
+  }
+#pragma unroll
+  for (int q = 0; q < MPT; ++q)
+    mk0[q] = has_mask ? LD::f(a.mask + ((size_t)r * a.mask_row_mul + mrow_add) * G2 + min(tid + 256 * q, G2 - 1)) : 1.0f;
+  __builtin_amdgcn_sched_barrier(0);
+  if (tid < 32) {
+    if (fused_tp) {
+      float part[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      const float* xrow = a.t2 + (size_t)r * a.t2_ld + per * hl;
+      const float4* w4 = reinterpret_cast<const float4*>(a.w3) + (size_t)per * hl * 2;
 #pragma unroll
       for (int q = 0; q < QM; ++q) {
         if (q < nq) {
