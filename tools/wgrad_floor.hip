@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include "sqair_common.h"   // SQ_TLP / SQ_TL_SCOPE (nothing in the product build)
 typedef float f32x4_b __attribute__((ext_vector_type(4)));
 #define SQ_KWGRAD_NAME k_full
 #define SQ_KWGRAD_BODY b_full
