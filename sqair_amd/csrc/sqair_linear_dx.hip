@@ -68,10 +68,14 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
   // per-lane column in the comparison every field of the range (pointers, leading dimensions, activation codes) was fetched
   // by a vector load from the argument segment followed by a full wait -- a dozen dependent round trips per launch.
   const int n_tile0 = tile_n * 16;
-  int ri = 0;
-  if (a.nranges > 1 && n_tile0 >= a.r[1].n0) ri = 1;
-  if (a.nranges > 2 && n_tile0 >= a.r[2].n0) ri = 2;
-  const DxRange& rg = a.r[ri];
+  int ri_ = 0;
+  if (a.nranges > 1 && n_tile0 >= a.r[1].n0) ri_ = 1;
+  if (a.nranges > 2 && n_tile0 >= a.r[2].n0) ri_ = 2;
+  // the range as a by-value copy from a SCALAR index: every field arrives in one batch of scalar loads.  (As a reference through
+  // a per-lane-looking index hipcc kept the struct's address in VGPRs and fetched each field when first used -- readfirstlane,
+  // s_load_dword, wait -- under the `live` masks: eight dependent scalar round trips ahead of the epilogue operands' requests.)
+  const int ri = __builtin_amdgcn_readfirstlane(ri_);
+  const DxRange rg = a.r[ri];
   const bool live = m < a.M && n >= rg.n0 && n < rg.n1;
   const int c = live ? n - rg.n0 : 0;
   // activation codes as scalars NOW: left as `c < split ? rg.act_a : rg.act_b` at the use, the select became a per-lane ADDRESS
