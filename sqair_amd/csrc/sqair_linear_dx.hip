@@ -90,13 +90,15 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
   // launch a memory round trip of its own)
   float p_scale = (a.scale_ptr != nullptr ? a.scale_ptr : dummy + (tid & 15))[0];
   p_scale = a.scale_ptr != nullptr ? p_scale : 1.0f;
+  const DxGru gr = a.gru;   // (by value: one batch of scalar loads; field by field they were fetched where first used, the last
+                            // ones between the barrier and the stores)
   float q_g0 = 0.0f, q_g1 = 0.0f, q_h = 0.0f, q_dh = 0.0f;
   if (GRU != 0) {  // gate tapes of the GRU adjoint (columns 0 .. nh - 1 of range 0)
-    const int cg = min(c, a.gru.nh - 1);
-    q_g0 = a.gru.g0[(size_t)mc * a.gru.g0_ld + cg];
-    if (GRU == 1) q_g1 = a.gru.g1[(size_t)mc * a.gru.g1_ld + cg];
-    q_h = a.gru.hprev[(size_t)mc * a.gru.h_ld + cg];
-    if (GRU == 2 || a.gru.acc_dh) q_dh = a.gru.d_h[(size_t)mc * a.gru.dh_ld + cg];
+    const int cg = min(c, gr.nh - 1);
+    q_g0 = gr.g0[(size_t)mc * gr.g0_ld + cg];
+    if (GRU == 1) q_g1 = gr.g1[(size_t)mc * gr.g1_ld + cg];
+    q_h = gr.hprev[(size_t)mc * gr.h_ld + cg];
+    if (GRU == 2 || gr.acc_dh) q_dh = gr.d_h[(size_t)mc * gr.dh_ld + cg];
   }
   __builtin_amdgcn_sched_barrier(0);
   SQ_DX_MFMA()
@@ -122,20 +124,20 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dpr
     if (rg.add != nullptr) v += p_add;
     if (rg.saved != nullptr) v = dx_dact(v, p_saved, c < act_split ? act_a : act_b);
     if (GRU == 1) {
-      const int nh = a.gru.nh;
+      const int nh = gr.nh;
       const float dz = v * (q_g1 - q_h) * q_g0 * (1.0f - q_g0), dc = v * q_g0 * (1.0f - q_g1 * q_g1);
-      a.gru.dpre1[(size_t)m * a.gru.dp_ld + c] = dz;
-      a.gru.dpre1[(size_t)m * a.gru.dp_ld + 2 * nh + c] = dc;
-      if (a.gru.dup != nullptr) {
-        a.gru.dup[(size_t)m * a.gru.dup_ld + c] = dz;
-        if (a.gru.dup_h_off >= 0) a.gru.dup[(size_t)m * a.gru.dup_ld + a.gru.dup_h_off + c] = dc;
+      gr.dpre1[(size_t)m * gr.dp_ld + c] = dz;
+      gr.dpre1[(size_t)m * gr.dp_ld + 2 * nh + c] = dc;
+      if (gr.dup != nullptr) {
+        gr.dup[(size_t)m * gr.dup_ld + c] = dz;
+        if (gr.dup_h_off >= 0) gr.dup[(size_t)m * gr.dup_ld + gr.dup_h_off + c] = dc;
       }
-      a.gru.d_h[(size_t)m * a.gru.dh_ld + c] = (a.gru.acc_dh ? q_dh : 0.0f) + v * (1.0f - q_g0);
+      gr.d_h[(size_t)m * gr.dh_ld + c] = (gr.acc_dh ? q_dh : 0.0f) + v * (1.0f - q_g0);
     } else if (GRU == 2) {
       const float dr = v * q_h * q_g0 * (1.0f - q_g0);
-      a.gru.dpre1[(size_t)m * a.gru.dp_ld + a.gru.nh + c] = dr;
-      if (a.gru.dup != nullptr) a.gru.dup[(size_t)m * a.gru.dup_ld + c] = dr;
-      a.gru.d_h[(size_t)m * a.gru.dh_ld + c] = q_dh + v * q_g0;
+      gr.dpre1[(size_t)m * gr.dp_ld + gr.nh + c] = dr;
+      if (gr.dup != nullptr) gr.dup[(size_t)m * gr.dup_ld + c] = dr;
+      gr.d_h[(size_t)m * gr.dh_ld + c] = q_dh + v * q_g0;
     } else {
       rg.dst[(size_t)m * rg.dst_ld + c] = v;
       if (rg.dst2 != nullptr) rg.dst2[(size_t)m * rg.dst2_ld + c] = v;
