@@ -1361,6 +1361,8 @@ int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_slot_tail_bwd(const TailBwdArgs a, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
+  SQ_PIN8(a.is_disc, a.slot, a.rec_prev, a.rec_new, a.d_rec_new, a.d_rec_prev, a.s1h, a.s1h_ld);
+  SQ_PIN8(a.hraw, a.h_ld, a.enc, a.enc_ld, a.noise, a.flat, a.w2_off, a.wwhat_off);
   __shared__ float ds_s[128];
   extern __shared__ float wt_s[];  // the `what` rows of steps.l0.w, [nw][nsp + 1] (padded: conflict-free row reads)
   const int r = blockIdx.x, tid = threadIdx.x, nw = d.nw, nsp = d.nh / 2, RW = rec::W;
@@ -1378,9 +1380,12 @@ __global__ __launch_bounds__(256) void k_slot_tail_bwd(const TailBwdArgs a, cons
   const float* rn = a.rec_new + ((size_t)r * d.N + a.slot) * RW;
   float* drn = a.d_rec_new + ((size_t)r * d.N + a.slot) * RW;
   (void)rn;
-  float prev;
-  if (a.is_disc) prev = a.slot == 0 ? 1.0f : a.rec_new[((size_t)r * d.N + a.slot - 1) * RW + rec::PRES];
-  else prev = a.rec_prev[((size_t)r * d.N + a.slot) * RW + rec::PRES];
+  // (one unconditional load from a selected, always valid address: as a guarded load hipcc put a full wait behind it -- the
+  // weight block's round trip -- ahead of the per-row requests below)
+  const float* prevp = a.is_disc ? (a.slot == 0 ? a.flat : a.rec_new + ((size_t)r * d.N + a.slot - 1) * RW + rec::PRES)
+                                 : a.rec_prev + ((size_t)r * d.N + a.slot) * RW + rec::PRES;
+  float prev = *prevp;
+  if (a.is_disc && a.slot == 0) prev = 1.0f;
   const float d_raw = prev * drn[rec::LOGIT];
   // two threads per what element (c = tid >> 1, each sums half of the hidden units); everything the second phase reads from
   // memory is requested HERE, ahead of the barrier, so that the kernel makes one memory round trip instead of two
@@ -1479,6 +1484,9 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
   float* img_s = smem;
   __shared__ float red_s[4][4];
   __shared__ float dtp_s[8];
+  SQ_PIN8(a.mode, a.slot, a.img, a.rec_prev, a.rec_new, a.d_rec_prev, a.d_rec_new, a.wb);
+  SQ_PIN8(a.wb_ld, a.mask, a.mask_row_mul, a.mask_row_add, a.d_mask, a.g_out, a.g_row_mul, a.g_row_add);
+  SQ_PIN8(a.tp, a.tp_ld, a.noise, a.flat, a.w3, a.t2, a.t2_ld, a.d_t2);
   // one workgroup per particle row (the K particles of a sequence re-stage the same frame from L2: 10 KB at 50x50)
   const int r = blockIdx.x, b = sq_div(r, d.k_mul), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int slot = a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot;
@@ -1510,7 +1518,15 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
   {
     const float* wsrc = a.mode == CROP_PROP1 ? a.rec_prev + ((size_t)r * d.N + slot) * RW + rec::WHERE
                                              : a.rec_new + ((size_t)r * d.N + slot) * RW + rec::WHERE;
-    for (int i = 0; i < 4; ++i) wl[i] = wsrc[i] + (a.mode == CROP_PROP1 ? 0.1f * a.wb[((size_t)r * d.N + slot) * a.wb_ld + i] : 0.0f);
+    // (unconditional loads from a valid address, then the select: behind the ternary each element was a guarded load with a
+    // full wait of its own)
+    const bool p1 = a.mode == CROP_PROP1;
+    const float* wbp = p1 ? a.wb + ((size_t)r * d.N + slot) * a.wb_ld : wsrc;
+    float w0[4], w1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w0[i] = wsrc[i]; w1[i] = wbp[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wl[i] = w0[i] + (p1 ? 0.1f * w1[i] : 0.0f);
   }
   // operands of the four where coordinates' adjoint (threads 0..3)
   const int ci = tid & 3;

@@ -224,6 +224,12 @@ __device__ __forceinline__ float tril4(const float* __restrict__ v, int i, int j
   const int q = i * 4 + j;
   return q < 6 ? v[4 + q] : v[15 - q];
 }
+// Pins the scalar loads of by-value kernel-argument fields HERE: hipcc otherwise fetches each field where it is first used --
+// one s_load + wait at a time along the kernel's control flow, i.e. a chain of scalar round trips in front of the global loads
+// whose addresses they feed.  Listing the fields of a kernel in two or three of these at its top makes them one batch.
+#define SQ_PIN1(x) asm volatile("" ::"s"(x))
+#define SQ_PIN4(a_, b_, c_, d_) asm volatile("" ::"s"(a_), "s"(b_), "s"(c_), "s"(d_))
+#define SQ_PIN8(a_, b_, c_, d_, e_, f_, g_, h_) asm volatile("" ::"s"(a_), "s"(b_), "s"(c_), "s"(d_), "s"(e_), "s"(f_), "s"(g_), "s"(h_))
 // n floats from global memory into LDS on the LDS-DMA path (global_load_lds_dword: no registers, nothing waits until the
 // barrier ahead of the first reader, so every trip of every array staged this way is in flight together).  Wave `wave` of
 // `n_waves` takes the 64-element trips wave, wave + n_waves, ...; lane l of a trip moves element base + l, the trip's LDS
