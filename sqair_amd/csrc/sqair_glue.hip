@@ -146,7 +146,9 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
   float prev = *prevp;
   if (a.is_disc && a.slot == 0) prev = 1.0f;
   float whv[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // where sample of the slot (written by its crop launch): requested with the rest,
-  if (FULL_Z && tid < 16) {                  // not behind the last barrier where it cost a memory round trip of its own
+  if (FULL_Z) {                              // not behind the last barrier where it cost a memory round trip of its own; by EVERY
+    // thread (only 16 use it): as a guarded load (`tid < 16`) hipcc put a wait for all earlier requests behind it, and the
+    // what-sample operands below went out a memory round trip late
     const float* wh = a.rec_new + ((size_t)pr * d.N + a.slot) * rec::W + rec::WHERE;
 #pragma unroll
     for (int q = 0; q < 4; ++q) whv[q] = wh[q];
