@@ -106,5 +106,18 @@ struct WgradBatch {
   int flush(hipStream_t s);
 };
 
+// Column sums collected at the end of the backward pass and issued as ONE launch (k_colsum_group): out[n] += sum_m dy[m][n] wt[m]
+// (wt null: plain bias / initial-state gradients; with wt a one-column weight gradient, d w2 = A^T d_raw of the steps predictors).
+// Seven to eleven such sums close the chain: as launches of their own each paid the dependent-launch gap and a cold round trip.
+struct ColsumEntry { const float* dy; const float* wt; float* out; int ld, wld, rows, cols, first, nbx; };
+constexpr int SQ_CS_MAXE = 12;
+struct ColsumGroup { ColsumEntry e[SQ_CS_MAXE]; int n; };
+struct ColsumBatch {
+  ColsumGroup g{};
+  int total = 0;
+  void add(const float* dy, int ld, int rows, int cols, float* out, hipStream_t s, const float* wt = nullptr, int wld = 0);
+  int flush(hipStream_t s);
+};
+
 int sq_launch_where_param_grads(const float* d_tp, int tp_ld, const float* d_rec_p, const float* rec_p, const float* noise, int T,
                                 Dims d, float* flat_grad, POff po, hipStream_t s);

@@ -1824,6 +1824,43 @@ int sq_launch_colsum(const float* dy, int ld, int rows, int cols, float* out, in
   SQ_LAUNCH(k_colsum, dim3((cols + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, s, dy, ld, rows, cols, out, rpb);
   return 0;
 }
+// the same for up to SQ_CS_MAXE independent sums in one launch (ColsumBatch, sqair_bwd.h): a workgroup finds its entry from
+// its index (wave-uniform) and runs k_colsum's body on 64 rows x 64 columns of it, each row optionally weighted
+__global__ __launch_bounds__(256) void k_colsum_group(const ColsumGroup g SQ_TLP) {
+  SQ_TL_SCOPE;
+  int ei = 0;
+  for (int i = 1; i < g.n; ++i) ei = (int)blockIdx.x >= g.e[i].first ? i : ei;
+  const ColsumEntry e = g.e[__builtin_amdgcn_readfirstlane(ei)];
+  const int bl = (int)blockIdx.x - e.first, by = bl / e.nbx, bx = bl - by * e.nbx;
+  const int n = bx * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;  // 4 row partitions
+  __shared__ float red[4][64];
+  const int r0 = by * 64, r1 = min(e.rows, r0 + 64);
+  float sacc = 0.0f;
+  if (n < e.cols) {
+    if (e.wt != nullptr)
+      for (int m = r0 + part; m < r1; m += 4) sacc += e.dy[(size_t)m * e.ld + n] * e.wt[(size_t)m * e.wld];
+    else
+      for (int m = r0 + part; m < r1; m += 4) sacc += e.dy[(size_t)m * e.ld + n];
+  }
+  red[part][threadIdx.x & 63] = sacc;
+  __syncthreads();
+  if (part == 0 && n < e.cols) unsafeAtomicAdd(e.out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+void ColsumBatch::add(const float* dy, int ld, int rows, int cols, float* out, hipStream_t s, const float* wt, int wld) {
+  if (rows <= 0 || cols <= 0) return;
+  if (g.n == SQ_CS_MAXE) (void)flush(s);
+  ColsumEntry& e = g.e[g.n++];
+  e.dy = dy; e.wt = wt; e.out = out; e.ld = ld; e.wld = wld; e.rows = rows; e.cols = cols;
+  e.first = total; e.nbx = (cols + 63) / 64;
+  total += e.nbx * ((rows + 63) / 64);
+}
+int ColsumBatch::flush(hipStream_t s) {
+  if (g.n > 0) SQ_LAUNCH(k_colsum_group, dim3(total), dim3(256), 0, s, g);
+  g.n = 0;
+  total = 0;
+  return 0;
+}
 // latent-summary adjoint: d f[(r,k)][n] = d c[r][n] * presence_k ; particle sum: d pre_disc[b][n] = sum_kp d pre_d[b K + kp][n]
 __global__ void k_latent_sum_bwd(const float* __restrict__ d_c, const float* __restrict__ rec_p, const float* __restrict__ f_out,
                                  float* __restrict__ d_f, Dims d SQ_TLP) {

@@ -651,13 +651,23 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     }
   }
   // ================= initial states, input encoder =================
-  sq_launch_colsum(b.d_init_p, nh, T * R, nh, flat_grad + po.prop_rnn_init, 1, s);
-  sq_launch_colsum(b.d_init_d, nh, T * R, nh, flat_grad + po.disc_rnn_init, 1, s);
-  if (c.rec_where_prior) sq_launch_colsum(b.d_rn0, 4, T * R, 4, flat_grad + po.rn_init_state, 1, s);
-  sq_launch_colsum(b.d_new_t, snh, T * R, snh, flat_grad + po.temporal_init, 1, s);
-  sq_launch_colsum(b.d_new_p, psnh, T * R, psnh, flat_grad + po.prior_init, 1, s);
-  sq_launch_colsum(b.d_tm(0), snh, M, snh, flat_grad + po.temporal_init, 1, s);
-  sq_launch_colsum(b.d_pm(0), psnh, M, psnh, flat_grad + po.prior_init, 1, s);
+  {  // one launch (they were seven to nine, each a dependent node of the chain)
+    ColsumBatch cs;
+    cs.add(b.d_init_p, nh, T * R, nh, flat_grad + po.prop_rnn_init, s);
+    cs.add(b.d_init_d, nh, T * R, nh, flat_grad + po.disc_rnn_init, s);
+    if (c.rec_where_prior) cs.add(b.d_rn0, 4, T * R, 4, flat_grad + po.rn_init_state, s);
+    cs.add(b.d_new_t, snh, T * R, snh, flat_grad + po.temporal_init, s);
+    cs.add(b.d_new_p, psnh, T * R, psnh, flat_grad + po.prior_init, s);
+    cs.add(b.d_tm(0), snh, M, snh, flat_grad + po.temporal_init, s);
+    cs.add(b.d_pm(0), psnh, M, psnh, flat_grad + po.prior_init, s);
+    // output layer of the steps predictors (nh/2 -> 1): d w2 = s1h^T d_raw, d b2 = sum d_raw, all uses at once
+    const size_t ph1 = (size_t)T * R * N;
+    cs.add(w.s1h, S1_LD, (int)ph1, nsp, flat_grad + po.prop_steps_l1_w, s, b.d_raw, 1);
+    cs.add(b.d_raw, 1, (int)ph1, 1, flat_grad + po.prop_steps_l1_b, s);
+    cs.add(w.s1h + ph1 * S1_LD, S1_LD, (int)ph1, nsp, flat_grad + po.disc_steps_l1_w, s, b.d_raw + ph1, 1);
+    cs.add(b.d_raw + ph1, 1, (int)ph1, 1, flat_grad + po.disc_steps_l1_b, s);
+    cs.flush(s);
+  }
   {
     const int TB = T * B;
     CK(dx(L_PREDISC, b.d_pre_disc, rw, TB, b.tmp, nh, false));
@@ -731,11 +741,6 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     wgrad(L_DISC_T3, {{w.t2 + ph1 * nh, nh}}, b.d_tp + ph1 * TP_LD, TP_LD, MT);
     wgrad(L_DISC_S1, {{w.rec_d_all, RW}}, b.d_t1 + ph1 * T1_LD + nh, T1_LD, MT);
     sq_launch_where_param_grads(b.d_tp, TP_LD, b.d_rec_p, w.rec_p_all, noise, T, d, flat_grad, po, s);
-    // output layer of the steps predictors (nh/2 -> 1): d w2 = s1h^T d_raw, d b2 = sum d_raw, all uses at once
-    sq_launch_wgrad_acc(w.s1h, S1_LD, b.d_raw, 1, flat_grad + po.prop_steps_l1_w, 1, MT, nsp, 1, s, nullptr, nullptr,
-                        flat_grad + po.prop_steps_l1_b, nullptr);
-    sq_launch_wgrad_acc(w.s1h + ph1 * S1_LD, S1_LD, b.d_raw + ph1, 1, flat_grad + po.disc_steps_l1_w, 1, MT, nsp, 1, s, nullptr, nullptr,
-                        flat_grad + po.disc_steps_l1_b, nullptr);
   }
   wbatch.flush(s);
   SQ_CHECK_HIP(hipGetLastError());
