@@ -56,18 +56,24 @@ void sq_copy(float* dst, const float* src, int64_t n, hipStream_t s) {
   if (n > 0) SQ_LAUNCH(k_copy, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n);
 }
 // shifted z-record / RNN-state inputs of the slot RNNs as dense matrices for the batched weight gradient:
-//   zs[(t,r,k)] = z-record of slot k-1 (k > 0) or `init_rec` (k = 0);  rs[(t,r,k)] = r tape of slot k-1 or rnn_init
-__global__ void k_shift_inputs(const float* __restrict__ rec_all, const float* __restrict__ r_tape, const float* __restrict__ init_rec,
-                               const float* __restrict__ rnn_init, float* __restrict__ zs, float* __restrict__ rs, int rows,
-                               int N, int nh SQ_TLP) {
+//   zs[(t,r,k)] = z-record of slot k-1 (k > 0) or `init_rec` (k = 0);  rs[(t,r,k)] = r tape of slot k-1 or rnn_init;
+//   with a GRU slot RNN also the candidate's recurrent input rh = reset gate * rs.  Both phases (blockIdx.y: propagation,
+//   discovery) in one launch -- they were four nodes at the end of the chain.
+struct ShiftPhase { const float *rec_all, *r_tape, *init_rec, *rnn_init, *gate; float *zs, *rs, *rh; };
+struct ShiftArgs { ShiftPhase p[2]; int rows, N, nh, gate_ld; };
+__global__ void k_shift_inputs(const ShiftArgs a SQ_TLP) {
   SQ_TL_SCOPE;
   const int row = blockIdx.x;  // (t, r, k) flattened
-  if (row >= rows) return;
-  const int k = row % N;
+  if (row >= a.rows) return;
+  const ShiftPhase p = a.p[blockIdx.y];
+  const int k = row % a.N, nh = a.nh;
   for (int i = threadIdx.x; i < 64; i += blockDim.x)
-    zs[(size_t)row * 64 + i] = i < rec::ZW ? (k > 0 ? rec_all[(size_t)(row - 1) * rec::W + i] : init_rec[i]) : 0.0f;
-  for (int i = threadIdx.x; i < nh; i += blockDim.x)
-    rs[(size_t)row * nh + i] = k > 0 ? r_tape[(size_t)(row - 1) * nh + i] : rnn_init[i];
+    p.zs[(size_t)row * 64 + i] = i < rec::ZW ? (k > 0 ? p.rec_all[(size_t)(row - 1) * rec::W + i] : p.init_rec[i]) : 0.0f;
+  for (int i = threadIdx.x; i < nh; i += blockDim.x) {
+    const float v = k > 0 ? p.r_tape[(size_t)(row - 1) * nh + i] : p.rnn_init[i];
+    p.rs[(size_t)row * nh + i] = v;
+    if (p.gate != nullptr) p.rh[(size_t)row * nh + i] = p.gate[(size_t)row * a.gate_ld + i] * v;
+  }
 }
 
 // builder for the routed dX GEMM
@@ -670,10 +676,9 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   }
   {
     const int TB = T * B;
-    CK(dx(L_PREDISC, b.d_pre_disc, rw, TB, b.tmp, nh, false));
-    sq_launch_dact2(b.tmp, nh, w.ienc_b, nh, b.d_ib, nh, TB, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
-    CK(dx(L_IENC1, b.d_ib, nh, TB, b.tmp, nh, false));
-    sq_launch_dact2(b.tmp, nh, w.ienc_a, nh, b.d_ia, nh, TB, nh, ACT_ELU, ACT_ELU, 1 << 30, 0, s);
+    // (the activation adjoints in the dX launches' epilogues, as in the slot chain)
+    { Dx x(b.d_pre_disc, rw); x.to(0, nh, b.d_ib, nh).dact(w.ienc_b, nh, ACT_ELU); CK(rundx(L_PREDISC, x, TB)); }
+    { Dx x(b.d_ib, nh); x.to(0, nh, b.d_ia, nh).dact(w.ienc_a, nh, ACT_ELU); CK(rundx(L_IENC1, x, TB)); }
     wgrad(L_PREDISC, {{w.ienc_b, nh}}, b.d_pre_disc, rw, TB);
     wgrad(L_IENC1, {{w.ienc_a, nh}}, b.d_ib, nh, TB);
     wgrad(L_IENC0, {{obs, P_}}, b.d_ia, nh, TB);
@@ -704,12 +709,18 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     // loop-invariant pre-activations
     wgrad(L_PRE, {{w.m1, M1_LD}, {w.rec_m_all, RW}, {tau_all, snh}}, b.d_pre, pre_ld, MT);
     // propagation slot chain (phase 0 of the tapes)
-    SQ_LAUNCH(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_p_all, w.r, w.zero_rec, w.prop_rnn_init, b.zs[0], b.rs[0], MT, N, nh);
-    wgrad(L_PROP_RNN, {{b.zs[0], 64}, {b.rs[0], nh}}, b.d_rnn, rw, MT);
-    if (c.rnn_cell == RNN_GRU) {  // candidate's recurrent matrix: A = r * h_{k-1}
-      SQ_LAUNCH(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.rgates + nh, 3 * nh, b.rs[0], nh, b.rh[1], nh, MT, nh);
-      wgrad(L_PROP_RNN2, {{b.rh[1], nh}}, b.d_rnn + 2 * nh, rw, MT);
+    const size_t ph1 = (size_t)MT;
+    {
+      const bool gru = c.rnn_cell == RNN_GRU;  // candidate's recurrent matrix: A = r * h_{k-1}
+      ShiftArgs sa;
+      sa.p[0] = ShiftPhase{w.rec_p_all, w.r, w.zero_rec, w.prop_rnn_init, gru ? w.rgates + nh : nullptr, b.zs[0], b.rs[0], b.rh[1]};
+      sa.p[1] = ShiftPhase{w.rec_d_all, w.r + ph1 * nh, w.disc_init_rec, w.disc_rnn_init, gru ? w.rgates + ph1 * 3 * nh + nh : nullptr,
+                           b.zs[1], b.rs[1], b.rh[3]};
+      sa.rows = MT; sa.N = N; sa.nh = nh; sa.gate_ld = 3 * nh;
+      SQ_LAUNCH(k_shift_inputs, dim3(MT, 2), dim3(64), 0, s, sa);
     }
+    wgrad(L_PROP_RNN, {{b.zs[0], 64}, {b.rs[0], nh}}, b.d_rnn, rw, MT);
+    if (c.rnn_cell == RNN_GRU) wgrad(L_PROP_RNN2, {{b.rh[1], nh}}, b.d_rnn + 2 * nh, rw, MT);
     wgrad(L_PROP_T1, {{w.r, nh}}, b.d_t1, T1_LD, MT);
     wgrad(L_PROP_T2, {{w.t1, T1_LD}}, b.d_t2, nh, MT);
     wgrad(L_PROP_T3, {{w.t2, nh}}, b.d_tp, TP_LD, MT);
@@ -728,14 +739,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     wgrad(L_PRED, {{w.c, nh}}, b.d_pre_d, rw, T * R);
     if (c.rec_where_prior) wgrad(L_RNCOND, {{w.rn_init_state, 0}, {w.c, nh}}, b.d_spre, 128, T * R);
     // discovery slot chain (phase 1 of the tapes)
-    const size_t ph1 = (size_t)MT;
-    SQ_LAUNCH(k_shift_inputs, dim3(MT), dim3(64), 0, s, w.rec_d_all, w.r + ph1 * nh, w.disc_init_rec, w.disc_rnn_init, b.zs[1],
-                       b.rs[1], MT, N, nh);
     wgrad(L_DISC_RNN, {{b.zs[1], 64}, {b.rs[1], nh}}, b.d_rnn + ph1 * rw, rw, MT);
-    if (c.rnn_cell == RNN_GRU) {
-      SQ_LAUNCH(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.rgates + ph1 * 3 * nh + nh, 3 * nh, b.rs[1], nh, b.rh[3], nh, MT, nh);
-      wgrad(L_DISC_RNN2, {{b.rh[3], nh}}, b.d_rnn + ph1 * rw + 2 * nh, rw, MT);
-    }
+    if (c.rnn_cell == RNN_GRU) wgrad(L_DISC_RNN2, {{b.rh[3], nh}}, b.d_rnn + ph1 * rw + 2 * nh, rw, MT);
     wgrad(L_DISC_T1, {{w.r + ph1 * nh, nh}}, b.d_t1 + ph1 * T1_LD, T1_LD, MT);
     wgrad(L_DISC_T2, {{w.t1 + ph1 * T1_LD, T1_LD}}, b.d_t2 + ph1 * nh, nh, MT);
     wgrad(L_DISC_T3, {{w.t2 + ph1 * nh, nh}}, b.d_tp + ph1 * TP_LD, TP_LD, MT);
