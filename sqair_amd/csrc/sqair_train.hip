@@ -16,14 +16,6 @@
 #include "sqair_bwd.h"
 
 // a few elementwise helpers local to the driver
-__global__ void k_mul2d(const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld, float* __restrict__ out,
-                        int o_ld, int rows, int cols SQ_TLP) {
-  SQ_TL_SCOPE;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * cols) return;
-  const int m = i / cols, n = i - m * cols;
-  out[(size_t)m * o_ld + n] = a[(size_t)m * a_ld + n] * b[(size_t)m * b_ld + n];
-}
 // zero fill as a kernel node: memset nodes in the middle of a long captured chain proved unreliable on replay
 // (ROCm 7.2: the second replay of the training graph read stale scratch), a plain kernel keeps the chain uniform
 __global__ void k_zero(float* __restrict__ p, int64_t n SQ_TLP) {
@@ -60,13 +52,22 @@ void sq_copy(float* dst, const float* src, int64_t n, hipStream_t s) {
 //   with a GRU slot RNN also the candidate's recurrent input rh = reset gate * rs.  Both phases (blockIdx.y: propagation,
 //   discovery) in one launch -- they were four nodes at the end of the chain.
 struct ShiftPhase { const float *rec_all, *r_tape, *init_rec, *rnn_init, *gate; float *zs, *rs, *rh; };
-struct ShiftArgs { ShiftPhase p[2]; int rows, N, nh, gate_ld; };
+struct MulJob { const float *a, *b; float* out; };   // out[row][i] = a[row][i] b[row][i], all three [rows][nh]
+struct ShiftArgs { ShiftPhase p[2]; MulJob m[2]; int rows, N, nh, gate_ld; };
+// blockIdx.y: 0 / 1 = the phases, 2 / 3 = the element-wise products of the prior / temporal GRU candidates' recurrent inputs
+// (reset gate * previous state), which need the same launch shape
 __global__ void k_shift_inputs(const ShiftArgs a SQ_TLP) {
   SQ_TL_SCOPE;
   const int row = blockIdx.x;  // (t, r, k) flattened
   if (row >= a.rows) return;
+  const int nh = a.nh;
+  if (blockIdx.y >= 2) {
+    const MulJob m = a.m[blockIdx.y - 2];
+    for (int i = threadIdx.x; i < nh; i += blockDim.x) m.out[(size_t)row * nh + i] = m.a[(size_t)row * nh + i] * m.b[(size_t)row * nh + i];
+    return;
+  }
   const ShiftPhase p = a.p[blockIdx.y];
-  const int k = row % a.N, nh = a.nh;
+  const int k = row % a.N;
   for (int i = threadIdx.x; i < 64; i += blockDim.x)
     p.zs[(size_t)row * 64 + i] = i < rec::ZW ? (k > 0 ? p.rec_all[(size_t)(row - 1) * rec::W + i] : p.init_rec[i]) : 0.0f;
   for (int i = threadIdx.x; i < nh; i += blockDim.x) {
@@ -688,12 +689,24 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     const float* tm_all = w.temporal_m;  // [T+1][M][snh]; frames 0..T-1 are the inputs
     const float* tau_all = tm_all + d.toff;
     const float* pm_all = w.prior_m;
+    // shifted / gated operand matrices of the recurrent layers' weight gradients, one launch
+    const size_t ph1 = (size_t)MT;
+    {
+      const bool gru = c.rnn_cell == RNN_GRU;  // candidate's recurrent matrix: A = r * h_{k-1}
+      ShiftArgs sa;
+      sa.p[0] = ShiftPhase{w.rec_p_all, w.r, w.zero_rec, w.prop_rnn_init, gru ? w.rgates + nh : nullptr, b.zs[0], b.rs[0], b.rh[1]};
+      sa.p[1] = ShiftPhase{w.rec_d_all, w.r + ph1 * nh, w.disc_init_rec, w.disc_rnn_init, gru ? w.rgates + ph1 * 3 * nh + nh : nullptr,
+                           b.zs[1], b.rs[1], b.rh[3]};
+      sa.rows = MT; sa.N = N; sa.nh = nh; sa.gate_ld = 3 * nh;
+      int ny = 2;
+      sa.m[0] = sa.m[1] = MulJob{nullptr, nullptr, nullptr};
+      if (c.prior_cell == CELL_GRU) sa.m[ny++ - 2] = MulJob{w.pgr, pm_all, b.rh[0]};
+      if (c.time_cell == CELL_GRU) sa.m[ny++ - 2] = MulJob{w.gr, tm_all, b.rh[2]};
+      SQ_LAUNCH(k_shift_inputs, dim3(MT, ny), dim3(64), 0, s, sa);
+    }
     // prior GRU
     wgrad(L_PRIOR_GRU1, {{w.rec_m_all, RW}, {pm_all, psnh}}, b.d_pgru1, pgw, MT);
-    if (c.prior_cell == CELL_GRU) {
-      SQ_LAUNCH(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.pgr, nh, pm_all, nh, b.rh[0], nh, MT, nh);
-      wgrad(L_PRIOR_GRU2, {{b.rh[0], nh}}, b.d_pgru1 + 2 * nh, 3 * nh, MT);
-    }
+    if (c.prior_cell == CELL_GRU) wgrad(L_PRIOR_GRU2, {{b.rh[0], nh}}, b.d_pgru1 + 2 * nh, 3 * nh, MT);   // (b.rh: k_shift_inputs below)
     wgrad(L_PRIOR_LIN, {{w.prior_p, psnh}}, b.d_pstats, PS_LD, MT);
     // where-bias / mask MLPs
     wgrad(L_TAU1, {{tau_all, snh}}, b.d_hid1, 256, MT);
@@ -709,16 +722,6 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     // loop-invariant pre-activations
     wgrad(L_PRE, {{w.m1, M1_LD}, {w.rec_m_all, RW}, {tau_all, snh}}, b.d_pre, pre_ld, MT);
     // propagation slot chain (phase 0 of the tapes)
-    const size_t ph1 = (size_t)MT;
-    {
-      const bool gru = c.rnn_cell == RNN_GRU;  // candidate's recurrent matrix: A = r * h_{k-1}
-      ShiftArgs sa;
-      sa.p[0] = ShiftPhase{w.rec_p_all, w.r, w.zero_rec, w.prop_rnn_init, gru ? w.rgates + nh : nullptr, b.zs[0], b.rs[0], b.rh[1]};
-      sa.p[1] = ShiftPhase{w.rec_d_all, w.r + ph1 * nh, w.disc_init_rec, w.disc_rnn_init, gru ? w.rgates + ph1 * 3 * nh + nh : nullptr,
-                           b.zs[1], b.rs[1], b.rh[3]};
-      sa.rows = MT; sa.N = N; sa.nh = nh; sa.gate_ld = 3 * nh;
-      SQ_LAUNCH(k_shift_inputs, dim3(MT, 2), dim3(64), 0, s, sa);
-    }
     wgrad(L_PROP_RNN, {{b.zs[0], 64}, {b.rs[0], nh}}, b.d_rnn, rw, MT);
     if (c.rnn_cell == RNN_GRU) wgrad(L_PROP_RNN2, {{b.rh[1], nh}}, b.d_rnn + 2 * nh, rw, MT);
     wgrad(L_PROP_T1, {{w.r, nh}}, b.d_t1, T1_LD, MT);
@@ -728,7 +731,6 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     if (c.time_cell == CELL_LSTM) {
       wgrad(L_PROP_GRU2, {{tm_all, snh}}, b.d_gru1, gw, MT);   // recurrent rows + b_gates: A = h_{t-1}
     } else if (c.time_cell == CELL_GRU) {
-      SQ_LAUNCH(k_mul2d, dim3((MT * nh + 255) / 256), dim3(256), 0, s, w.gr, nh, tm_all, nh, b.rh[2], nh, MT, nh);
       wgrad(L_PROP_GRU2, {{b.rh[2], nh}}, b.d_gru1 + 2 * nh, 3 * nh, MT);
     }
     wgrad(L_PROP_HEADS, {{w.temporal_p, snh}}, b.d_hraw, HRAW_LD, MT);
