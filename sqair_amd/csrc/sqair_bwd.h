@@ -48,6 +48,8 @@ struct CropChainBwdArgs {
   const float* wb; int wb_ld;            // PROP1: raw where-bias output
   float* d_wb;                           // PROP1 out: [M][wb_ld]
   const float* mask; int mask_row_mul, mask_row_add; float* d_mask;  // optional; d_mask accumulated (+=)
+  int mask_dact;                         // 1: this launch is the last to add to d_mask -- it writes the gradient of the mask
+                                         // layer's PRE-activation (x mask (1 - mask)) instead of the sum (was an element-wise launch per frame)
   const float* g_out; int g_row_mul, g_row_add;                       // d glimpse [rows][G2]
   const float* tp; int tp_ld;            // saved transform output (loc 0:4, raw 4:8)
   float* d_tp; int dtp_ld;               // out

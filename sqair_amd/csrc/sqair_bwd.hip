@@ -1596,7 +1596,8 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
       const float dvdx = (1.0f - wy1) * (t[0][1] - t[0][0]) + wy1 * (t[1][1] - t[1][0]);
       const float dvdy = (1.0f - wx1) * (t[1][0] - t[0][0]) + wx1 * (t[1][1] - t[0][1]);
       if (a.mask != nullptr) {
-        a.d_mask[((size_t)r * a.mask_row_mul + madd) * G2 + pix] = dmk + g * v;
+        const float dm = dmk + g * v;
+        a.d_mask[((size_t)r * a.mask_row_mul + madd) * G2 + pix] = a.mask_dact ? dm * (mk * (1.0f - mk)) : dm;
         g *= mk;
       }
       dsx += g * dvdx * hx * gx;

@@ -602,6 +602,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       ca.mode = CROP_PROP1; ca.img = img; ca.rec_prev = rec_prev; ca.d_rec_prev = d_rec_prev; ca.wb = w.frame(w.wb, (int64_t)M * WB_LD, t);
       ca.wb_ld = WB_LD; ca.d_wb = b.d_wb + (size_t)t * M * WB_LD; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N;
       ca.d_mask = d_mask_t; ca.g_out = b.d_g1; ca.g_row_mul = N; ca.flat = flat; ca.flat_grad = flat_grad;
+      ca.mask_dact = 1;  // the frame's last contribution to d mask: the sigmoid's adjoint rides on its write (d_mask_t IS d_maskpre)
       sq_launch_crop_chain_bwd(ca, po, d, N, s);
     }
     // ---- B^T. mask MLP and where-bias MLP
@@ -610,7 +611,6 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       float* d_hid1 = b.d_hid1 + (size_t)t * M * 256;
       const float* hid1 = w.frame(w.hid1, (int64_t)M * 256, t);
       if (c.masked_glimpse) {
-        sq_launch_dact2(d_mask_t, G2, mask, G2, d_maskpre, G2, M, G2, ACT_SIGMOID, ACT_SIGMOID, 1 << 30, 0, s);  // in place
         Dx x(d_maskpre, G2); x.to(0, 128, d_hid1 + 128, 256).dact(hid1 + 128, 256, ACT_ELU); CK(rundx(L_MASK2, x, M));
       }
       { Dx x(b.d_wb + (size_t)t * M * WB_LD, WB_LD); x.to(0, 128, d_hid1, 256).dact(hid1, 256, ACT_ELU); CK(rundx(L_WB2, x, M)); }
