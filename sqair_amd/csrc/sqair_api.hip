@@ -1561,7 +1561,8 @@ int sq_launch_wgrad(const float* A, int lda, const float* dY, int ldy, float* dW
                     int Ndim, int accumulate, hipStream_t s, const int* rowmap = nullptr, const float* alpha_ptr = nullptr);
 int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_ld, const float* img, const float* mean_img,
                                 const float* g_ll, float* d_glimpse, float* d_rec, int d_rec_ld, float* d_mean_rows,
-                                float std_fg, float std_bg, int T, Dims d, hipStream_t s);
+                                float std_fg, float std_bg, int T, Dims d, hipStream_t s, const float* scale = nullptr,
+                                float* d_scale = nullptr);
 int sq_launch_reduce_rows(const float* rows, float* out, int R, int P, int accumulate, hipStream_t s);
 int sq_launch_elbo_bwd(const float* iw, const float* sig, int T, int B, int K, float* g_lw, float* g_dl, hipStream_t s);
 int sq_launch_dot_scale(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s);

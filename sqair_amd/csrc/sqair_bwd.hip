@@ -139,6 +139,8 @@ struct InsertBwdArgs {
   const float* rec;          // alternatively: merged slot records [.., rec_ld] (where at +0, presence at +54)
   int rec_ld;
   int dw_ld;                 // leading dimension of d_where rows (4 = plain, 64 = gradient records)
+  const float* scale;        // optional (training step): the decoder's output scale and its gradient,
+  float* d_scale;            //   d scale += sum(d_glimpse * glimpse) / scale (modules.py:144-147) -- both factors are in LDS here
 };
 
 // LDS past the canvas block: glimpse gradient [N][G2], pixel runs per texel column / row [N][G] x 2 (first | last << 16),
@@ -293,7 +295,19 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
     }
     __syncthreads();  // the next band clears c.cv / c.ms; after the last one: dgl_s / acc_s complete
   }
-  for (int i = tid; i < N * G2; i += 256) a.d_glimpse[fs * G2 + i] = dgl_s[i] * c.pres[i / G2];
+  float dsc = 0.0f;
+  for (int i = tid; i < N * G2; i += 256) {
+    const float v = dgl_s[i] * c.pres[i / G2];
+    a.d_glimpse[fs * G2 + i] = v;
+    dsc += v * c.gl[i];
+  }
+  if (a.d_scale != nullptr) {  // (was a launch of its own over all of d_glimpse and glimpse: 14 us)
+    __shared__ float dsc_s[4];
+    dsc = sq_wave_sum(dsc);
+    if ((tid & 63) == 0) dsc_s[tid >> 6] = dsc;
+    __syncthreads();
+    if (tid == 0) unsafeAtomicAdd(a.d_scale, (dsc_s[0] + dsc_s[1] + dsc_s[2] + dsc_s[3]) / a.scale[0]);
+  }
   if (tid < N * 4) {
     const int k = tid >> 2, q = tid & 3;
     const float tot = acc_s[(0 * N + k) * 4 + q] + acc_s[(1 * N + k) * 4 + q] + acc_s[(2 * N + k) * 4 + q] + acc_s[(3 * N + k) * 4 + q];
@@ -667,9 +681,9 @@ int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float
 // batched insert/log-likelihood adjoint over T frames on merged slot records (decoder branch of sqair_backward)
 int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_ld, const float* img, const float* mean_img,
                                 const float* g_ll, float* d_glimpse, float* d_rec, int d_rec_ld, float* d_mean_rows,
-                                float std_fg, float std_bg, int T, Dims d, hipStream_t s) {
+                                float std_fg, float std_bg, int T, Dims d, hipStream_t s, const float* scale, float* d_scale) {
   InsertBwdArgs a{glimpse, nullptr, nullptr, img, mean_img, g_ll, d_glimpse, d_rec, d_mean_rows, std_fg, std_bg, rec, rec_ld,
-                  d_rec_ld};
+                  d_rec_ld, scale, d_scale};
   int band_rows;
   const size_t shm = insert_bwd_lds(d, band_rows);
   SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, T), dim3(256), shm, s, a, d, band_rows);
