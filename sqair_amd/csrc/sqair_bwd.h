@@ -88,7 +88,6 @@ int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_
 int sq_launch_reduce_rows(const float* rows, float* out, int R, int P, int accumulate, hipStream_t s);
 int sq_launch_elbo_bwd(const float* iw, const float* sig, int T, int B, int K, float* g_lw, float* g_dl, hipStream_t s);
 int sq_launch_dot_scale(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s);
-int sq_launch_dot_scale_atomic(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s);
 int sq_launch_reduce_rows_atomic(const float* rows, float* out, int R, int P, hipStream_t s);
 int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim,
                         hipStream_t s, const int* rowmap, const float* alpha_ptr, float* db_a, float* db_b);

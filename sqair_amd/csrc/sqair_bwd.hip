@@ -720,21 +720,6 @@ __global__ void k_dot_scale(const float* __restrict__ a, const float* __restrict
     out[0] = t / scale[0];
   }
 }
-__global__ void k_dot_scale_atomic(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
-                                   const float* __restrict__ scale, float* __restrict__ out SQ_TLP) {
-  SQ_TL_SCOPE;
-  __shared__ float red[4];
-  float acc = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += a[i] * b[i];
-  acc = sq_wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1] + red[2] + red[3]) / scale[0]);
-}
-int sq_launch_dot_scale_atomic(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s) {
-  SQ_LAUNCH(k_dot_scale_atomic, dim3(512), dim3(256), 0, s, a, b, n, scale, out);
-  return 0;
-}
 int sq_launch_dot_scale(const float* a, const float* b, int64_t n, const float* scale, float* out, hipStream_t s) {
   SQ_LAUNCH(k_dot_scale, dim3(1), dim3(1024), 0, s, a, b, n, scale, out);
   return 0;
