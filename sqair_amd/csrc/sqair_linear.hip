@@ -870,7 +870,12 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
   // Also tried for the 2048+ row launches and dropped: the split-K structure with a 32 x 32 and with a 64 x 64 workgroup tile
   // (half / a quarter of the operand bytes per output tile): 22 - 25 us against 16 - 17 us on 5120 x 256 x 256, back to back.
   static const int mt_rows = SQ_KNOB_INT("SQAIR_MT_ROWS", 2048);  // measurement knob
-  if (a.M >= mt_rows) {
+  // just below 2048 rows only the WIDE layers go to the LDS-tiled kernel (its 128 x 64 tiles then still number ~200):
+  // tools/time_linear.py, back to back, 1920 x 362 x 1152 35.7 -> 33.2 us, 1920 x 312 x 768 21.2 -> 19.2 (every 256 / 400-column
+  // layer would be twice as slow; at 1280 rows 362 x 1152 gains back to back, 24.3 -> 21.1, but not in the pass, and
+  // 312 x 768 loses, 14.7 -> 18.4).  cfg-4 (1920 rows per frame): forward 6.13 -> 6.07 ms, training 14.16 -> 14.12.
+  const bool mid_wide = prof_ts == nullptr && L.kc > 4 && a.M >= 1792 && L.nt >= 48;
+  if (a.M >= mt_rows || mid_wide) {
     // (all of them accumulate in the same order: the tile shape never changes a result)
     if (L.kc <= 4) {  // K <= 64: one block of loads, nothing to pipeline
       const dim3 grid_r(L.nt, (mt + 3) / 4);
