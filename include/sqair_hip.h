@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SQAIR_ABI_VERSION 1
+#define SQAIR_ABI_VERSION 2   /* 2: sqair_build_id / sqair_build_flags added, sqair_profile_* removed */
 
 /* Hyper-parameters of the path.  Field names follow the reference flags
  * (reference: sqair/common_model_flags.py:32-56, sqair/configs/mlp_mnist_model.py:42-52). */
@@ -63,6 +63,12 @@ typedef struct SqairHandle SqairHandle;
 
 /* ---- lifetime / introspection (host only: usable without a GPU) -------------------------------- */
 int sqair_abi_version(void);
+/* Identity of the loaded binary: 16 hex digits = sha256 over the sources it was compiled from (sqair_amd/csrc/ + this header +
+ * compiler flags; sqair_amd/csrc/build.py computes the same hash over the files on disk), and the build variant
+ * ("product" | "timeline" | "knobs").  Measurements are quoted next to this id, and the Python binding refuses a binary whose
+ * id is not the id of the sources beside it. */
+const char* sqair_build_id(void);
+const char* sqair_build_flags(void);
 int sqair_create(const SqairConfig* cfg, SqairHandle** out);
 int sqair_destroy(SqairHandle* h);
 const char* sqair_last_error(const SqairHandle* h);

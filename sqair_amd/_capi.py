@@ -43,6 +43,8 @@ class SqairOutputs(C.Structure):
 
 _PROTOS = {
     "sqair_abi_version": (C.c_int, []),
+    "sqair_build_id": (C.c_char_p, []),
+    "sqair_build_flags": (C.c_char_p, []),
     "sqair_create": (C.c_int, [C.POINTER(SqairConfig), C.POINTER(C.c_void_p)]),
     "sqair_destroy": (C.c_int, [C.c_void_p]),
     "sqair_last_error": (C.c_char_p, [C.c_void_p]),
@@ -118,13 +120,29 @@ EXPORTED_SYMBOLS = [n for n in _PROTOS if not n.startswith("sqair_debug")]
 
 TIMELINE_LIB_PATH = os.path.join(_HERE, "libsqair_hip_timeline.so")
 
+ABI_VERSION = 2
+_VARIANT_OF = {"libsqair_hip.so": "product", "libsqair_hip_timeline.so": "timeline", "libsqair_hip_knobs.so": "knobs"}
+
 _libs = {}
 
 
-def lib(path=None):
-    """Loads the shared library (once per path).  Raises ImportError with the build hint if it is absent.  `path` selects a
-    build VARIANT of the same sources (TIMELINE_LIB_PATH: every wave stamps its start / end, measurement only); the default is
-    the product library.  There is no environment override."""
+class StaleLibraryError(ImportError):
+    """The shared object was not compiled from the sources beside it."""
+
+
+def source_id():
+    """Hash of the kernel sources ON DISK (sqair_amd/csrc/ + include/sqair_hip.h + compiler flags): what a fresh build of any
+    variant would report as its `sqair_build_id()`."""
+    from .csrc.build import source_id as _sid
+    return _sid()
+
+
+def lib(path=None, allow_stale=False):
+    """Loads the shared library (once per path).  Raises ImportError with the build hint if it is absent, if its ABI version is
+    not this binding's, or (StaleLibraryError) if the build id compiled into it is not the hash of the sources on disk -- a
+    binary is git-ignored and travels beside the sources, so nothing else ties the two together.  `path` selects a build
+    VARIANT of the same sources (TIMELINE_LIB_PATH: every wave stamps its start / end, measurement only); the default is the
+    product library.  There is no environment override."""
     path = path or LIB_PATH
     if path not in _libs:
         if not os.path.exists(path):
@@ -135,31 +153,39 @@ def lib(path=None):
         # process (the second one then reports "no ROCm-capable device")
         import torch  # noqa: F401
         l = C.CDLL(path)
+        # the version first, through the one symbol every version has: a binding that has drifted fails HERE, not in a getattr
+        l.sqair_abi_version.restype = C.c_int
+        if l.sqair_abi_version() != ABI_VERSION:
+            raise ImportError("{}: ABI version {} but this binding speaks {}; rebuild (python sqair_amd/csrc/build.py)".format(
+                os.path.basename(path), l.sqair_abi_version(), ABI_VERSION))
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.sqair_abi_version() != 1:
-            raise ImportError("{} ABI version mismatch".format(os.path.basename(path)))
+        got, want = l.sqair_build_id().decode(), source_id()
+        if got != want and not allow_stale:
+            raise StaleLibraryError(
+                "{} was compiled from sources {} but the sources on disk are {}: rebuild (python sqair_amd/csrc/build.py "
+                "--force [--timeline] [--knobs]); numbers measured on a stale binary would be attributed to the wrong "
+                "code".format(os.path.basename(path), got, want))
+        variant = _VARIANT_OF.get(os.path.basename(path))
+        if variant is not None and l.sqair_build_flags().decode() != variant:
+            raise ImportError("{} reports build variant '{}', expected '{}'".format(
+                os.path.basename(path), l.sqair_build_flags().decode(), variant))
         _libs[path] = l
     return _libs[path]
 
 
-def build_id():
-    """Short hash of the kernel sources libsqair_hip.so is built from (csrc/ + include/sqair_hip.h): profiles carry it so that a
-    number is only ever quoted next to the build it was measured on."""
-    import hashlib
-    hsh = hashlib.sha256()
-    src = os.path.join(_HERE, "csrc")
-    files = sorted(f for f in os.listdir(src) if f.endswith((".hip", ".h", ".inc")))
-    for f in files:
-        hsh.update(f.encode())
-        hsh.update(open(os.path.join(src, f), "rb").read())
-    hsh.update(open(os.path.join(os.path.dirname(_HERE), "include", "sqair_hip.h"), "rb").read())
-    return hsh.hexdigest()[:16]
+def build_id(path=None):
+    """The build id COMPILED INTO the loaded library (`sqair_build_id()`: the hash of the sources that binary was built from).
+    Profiles carry it so that a number is only ever quoted next to the binary it was measured on; `lib()` has already checked
+    that it equals `source_id()`."""
+    return lib(path).sqair_build_id().decode()
 
 
 def check(handle, rc, what, library=None):
+    """Raises RuntimeError with the handle's error text.  `library` must be the shared object the handle came from (a handle of
+    the timeline / knob variant is not the product library's to read): SqairCore.check passes its own."""
     if rc != 0:
         msg = (library or lib()).sqair_last_error(handle)
         raise RuntimeError("{} failed (rc={}): {}".format(what, rc, msg.decode() if msg else ""))

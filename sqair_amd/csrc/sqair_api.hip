@@ -14,6 +14,10 @@
 //     pre-activations, the prior GRU) is batched over the N slots up front (M = B'*N rows);
 //   * only the truly sequential part (explaining away: slot k needs slot k-1's sample) remains in
 //     the per-slot chain.
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "sqair_internal.h"
 
 void sq_set_error(SqairHandle* h, const std::string& msg) {
@@ -503,7 +507,34 @@ static void build_plan_T(SqairHandle* h) {
 // ------------------------------------------------------------------------------------------------
 // C-ABI: lifetime / introspection
 // ------------------------------------------------------------------------------------------------
+int sq_allow_big_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -2;
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count({kernel, dev})) return 0;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    fprintf(stderr, "sqair: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed on device %d\n", bytes, dev);
+    (void)hipGetLastError();
+    return -2;
+  }
+  done.insert({kernel, dev});
+  return 0;
+}
+
 extern "C" int sqair_abi_version(void) { return SQAIR_ABI_VERSION; }
+// identity of this binary: the hash of the sources it was compiled from (csrc/build.py passes it in) and the build variant.
+// The marker string makes the id readable from the file without loading it.
+#ifndef SQAIR_BUILD_ID
+#define SQAIR_BUILD_ID "0000000000000000"
+#endif
+#ifndef SQAIR_BUILD_VARIANT
+#define SQAIR_BUILD_VARIANT "unknown"
+#endif
+__attribute__((used)) static const char sq_build_marker[] = "SQAIR_BUILD_ID=" SQAIR_BUILD_ID ";";
+extern "C" const char* sqair_build_id(void) { return SQAIR_BUILD_ID; }
+extern "C" const char* sqair_build_flags(void) { return SQAIR_BUILD_VARIANT; }
 
 extern "C" int sqair_create(const SqairConfig* cfg, SqairHandle** out) {
   if (cfg == nullptr || out == nullptr) return -1;
@@ -530,8 +561,14 @@ extern "C" int sqair_create(const SqairConfig* cfg, SqairHandle** out) {
   return 0;
 }
 
+#ifdef SQAIR_TIMELINE
+void sq_tl_forget(const SqairHandle* h);
+#endif
 extern "C" int sqair_destroy(SqairHandle* h) {
   if (h == nullptr) return 0;
+#ifdef SQAIR_TIMELINE
+  sq_tl_forget(h);
+#endif
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
   for (int i = 0; i < 4; ++i) {
@@ -1134,14 +1171,31 @@ extern "C" int sqair_clear_workspace(SqairHandle* h, void* workspace, int64_t wo
 // ------------------------------------------------------------------------------------------------
 // per-dispatch timeline (sqair_common.h: SQ_TLP / SQ_TL_SCOPE / SQ_LAUNCH; only libsqair_hip_timeline.so records anything)
 #ifdef SQAIR_TIMELINE
+// Launches reach sq_tl_next through SQ_LAUNCH without a handle, so the ACTIVE recording is one per process -- but it is OWNED by
+// the handle that began it: a second handle cannot reset it (-6), its records stay readable by the owner after _end, and the
+// owner's captured graphs (whose nodes carry slot addresses frozen at capture time) are dropped whenever a recording begins or
+// ends, so that no replay can stamp into a buffer of another recording or one the caller has released.
 namespace {
 struct TlRecord { std::string kernel; int64_t off; int waves, wgs; };
-struct TlState { unsigned long long* buf = nullptr; int64_t cap = 0, used = 0; bool on = false, overflow = false; std::vector<TlRecord> rec; };
+struct TlState {
+  const SqairHandle* owner = nullptr;
+  unsigned long long* buf = nullptr; int64_t cap = 0, used = 0; bool on = false, overflow = false, bad_block = false;
+  std::vector<TlRecord> rec;
+};
 TlState g_tl;
+void tl_drop_graphs(SqairHandle* h) {
+  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+  h->graph_nodes = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (h->cap_exec[i]) { (void)hipGraphExecDestroy(h->cap_exec[i]); h->cap_exec[i] = nullptr; }
+    if (h->cap_graph[i]) { (void)hipGraphDestroy(h->cap_graph[i]); h->cap_graph[i] = nullptr; }
+  }
+}
 }  // namespace
 SqTl sq_tl_next(const char* kernel, dim3 grid, dim3 block) {
   if (!g_tl.on) return SqTl{nullptr, 0, 0, 0, 0};
-  if (block.y != 1 || block.z != 1) { g_tl.overflow = true; return SqTl{nullptr, 0, 0, 0, 0}; }  // (1-D workgroups only)
+  if (block.y != 1 || block.z != 1) { g_tl.bad_block = true; return SqTl{nullptr, 0, 0, 0, 0}; }  // (1-D workgroups only)
   const int64_t wgs = (int64_t)grid.x * grid.y * grid.z;
   // one {start, end} pair per wave; a workgroup's pairs are padded to whole 128-byte lines, so that workgroups on different
   // XCDs (whose L2s are not coherent with each other) never write parts of the same line
@@ -1155,22 +1209,31 @@ SqTl sq_tl_next(const char* kernel, dim3 grid, dim3 block) {
   g_tl.used += need;
   return t;
 }
+void sq_tl_forget(const SqairHandle* h) { if (g_tl.owner == h) g_tl = TlState(); }
 extern "C" int sqair_timeline_available(void) { return 1; }
 extern "C" int sqair_timeline_begin(SqairHandle* h, void* buf, int64_t bytes) {
   if (!h || !buf || bytes < 16 || ((uintptr_t)buf & 15)) return -1;
+  if (g_tl.on && g_tl.owner != h) {
+    sq_set_error(h, "sqair_timeline_begin: a recording is active on another handle (one recording per process; end it first)");
+    return -6;
+  }
+  tl_drop_graphs(h);
   g_tl = TlState();
-  g_tl.buf = (unsigned long long*)buf; g_tl.cap = bytes / 8; g_tl.on = true;
+  g_tl.owner = h; g_tl.buf = (unsigned long long*)buf; g_tl.cap = bytes / 8; g_tl.on = true;
   return 0;
 }
-extern "C" int sqair_timeline_count(const SqairHandle* h) { return h ? (int)g_tl.rec.size() : -1; }
+extern "C" int sqair_timeline_count(const SqairHandle* h) { return (h && g_tl.owner == h) ? (int)g_tl.rec.size() : -1; }
 extern "C" int sqair_timeline_end(SqairHandle* h) {
   if (!h) return -1;
+  if (g_tl.owner != h) { sq_set_error(h, "sqair_timeline_end: this handle owns no recording"); return -6; }
   g_tl.on = false;
+  tl_drop_graphs(h);
+  if (g_tl.bad_block) { sq_set_error(h, "sqair_timeline_end: a kernel was launched with a multi-dimensional workgroup (the stamps need 1-D workgroups)"); return -4; }
   if (g_tl.overflow) { sq_set_error(h, "sqair_timeline_end: the stamp buffer was too small"); return -4; }
   return (int)g_tl.rec.size();
 }
 extern "C" int sqair_timeline_record(const SqairHandle* h, int i, const char** kernel, int64_t* offset_u64, int* waves, int* workgroups) {
-  if (!h || i < 0 || i >= (int)g_tl.rec.size()) return -1;
+  if (!h || g_tl.owner != h || i < 0 || i >= (int)g_tl.rec.size()) return -1;
   if (kernel) *kernel = g_tl.rec[i].kernel.c_str();
   if (offset_u64) *offset_u64 = g_tl.rec[i].off;
   if (waves) *waves = g_tl.rec[i].waves;

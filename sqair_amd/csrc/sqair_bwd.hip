@@ -103,12 +103,7 @@ extern "C" int sqair_st_crop_bwd(SqairHandle* h, const float* img, const float* 
   Dims d = make_dims(c, B);
   CropBwdArgs a{img, where_logits, mask, g_out, d_where_logits, d_mask};
   const size_t shm = (size_t)d.H * d.W * sizeof(float);
-  static bool big = false;
-  if (shm > 48 * 1024 && !big) {
-    (void)hipFuncSetAttribute((const void*)k_crop_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipGetLastError();
-    big = true;
-  }
+  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_crop_bwd, 150 * 1024) != 0) return -2;
   SQ_LAUNCH(k_crop_bwd, dim3(B), dim3(256), shm, (hipStream_t)stream, a, d);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -321,12 +316,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
 static size_t insert_bwd_lds(const Dims& d, int& band_rows) {
   band_rows = sq_canvas_band_rows(d.H, d.W, SQ_CANVAS_PF_BWD);
   const size_t bytes = insert_bwd_lds_floats(d, band_rows) * sizeof(float);
-  static bool big = false;
-  if (bytes > 48 * 1024 && !big) {
-    (void)hipFuncSetAttribute((const void*)k_insert_loglik_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipGetLastError();
-    big = true;
-  }
+  if (bytes > 48 * 1024 && sq_allow_big_lds((const void*)k_insert_loglik_bwd, 150 * 1024) != 0) return 0;  // 0 = failed
   return bytes;
 }
 __global__ void k_reduce_rows(const float* __restrict__ rows, float* __restrict__ out, int R, int P, int accumulate SQ_TLP) {
@@ -364,6 +354,7 @@ extern "C" int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, 
                   c.output_std, c.background_std, nullptr, 0, 4};
   int band_rows;
   const size_t shm = insert_bwd_lds(d, band_rows);
+  if (shm == 0) return -2;
   SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, 1), dim3(256), shm, (hipStream_t)stream, a, d, band_rows);
   SQ_LAUNCH(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch,
                      d_mean_img, d.R, P, 0);
@@ -610,12 +601,7 @@ bool WgradBatch::add(const float* A, int lda, const float* dY, int ldy, float* d
 int WgradBatch::flush(hipStream_t s) {
   static const int rows = SQ_KNOB_INT("SQAIR_WGRAD_ROWS", 2048);  // target rows of a workgroup
   static const bool dump = SQ_KNOB_SET("SQAIR_WGRAD_DUMP");  // print the block table of every flush
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_wgrad_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG3_LDS);
-    (void)hipGetLastError();
-    attr_done = true;
-  }
+  if (sq_allow_big_lds((const void*)k_wgrad_group, (int)WG3_LDS) != 0) return -2;
   for (size_t i0 = 0; i0 < blocks.size(); i0 += SQ_WG_MAXD) {
     WgGroup g;
     memset(&g, 0, sizeof(g));
@@ -655,12 +641,7 @@ int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float
     if (zc < 1) zc = 1;
     const int m_per_wg = ((M + zc - 1) / zc + 63) / 64 * 64;   // 4 waves x a multiple of 16 rows
     zc = (M + m_per_wg - 1) / m_per_wg;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)k_wgrad3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG3_LDS);
-      (void)hipGetLastError();
-      attr_done = true;
-    }
+    if (sq_allow_big_lds((const void*)k_wgrad3, (int)WG3_LDS) != 0) return -2;
     SQ_LAUNCH(k_wgrad3, dim3(kt * nt * zc), dim3(256), WG3_LDS, s, A, lda, dY, ldy, dW, ldw, M, Kdim, Ndim, rowmap, alpha_ptr, db_a,
                        db_b, m_per_wg, kt, kt * nt);
     return 0;
@@ -686,6 +667,7 @@ int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_
                   d_rec_ld, scale, d_scale};
   int band_rows;
   const size_t shm = insert_bwd_lds(d, band_rows);
+  if (shm == 0) return -2;
   SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, T), dim3(256), shm, s, a, d, band_rows);
   return 0;
 }
@@ -1714,12 +1696,7 @@ int sq_launch_where_param_grads(const float* d_tp, int tp_ld, const float* d_rec
 }
 int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
   const size_t shm = (size_t)d.H * d.W * sizeof(float);
-  static bool big = false;
-  if (shm > 48 * 1024 && !big) {
-    (void)hipFuncSetAttribute((const void*)k_crop_chain_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipGetLastError();
-    big = true;
-  }
+  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_crop_chain_bwd, 150 * 1024) != 0) return -2;
   SQ_LAUNCH(k_crop_chain_bwd, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
   return 0;
 }

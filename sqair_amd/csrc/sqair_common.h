@@ -85,6 +85,10 @@ struct PackedLayer {
 
 struct SqairHandle;
 void sq_set_error(SqairHandle* h, const std::string& msg);
+// Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) on the CURRENT device, once per
+// (kernel, device): the attribute belongs to the device's copy of the kernel, so a process that drives several devices (one
+// handle each) has to set it on each of them.  Returns 0 or -2; the HIP error is not swallowed.
+int sq_allow_big_lds(const void* kernel, int bytes);
 
 // launchers (sqair_linear.hip)
 // prof_ts (optional): device slot {min start, max end} of the launch in 100 MHz wall-clock ticks
@@ -181,11 +185,15 @@ __device__ __forceinline__ float sq_exp(float x) {
   // x is clamped to [-104, log(FLT_MAX)] (one v_med3): above it exp2 returns +inf and fma(inf, r ln 2, inf) is NaN whenever
   // r <= 0; far below it x log2 e overflows to -inf and r becomes inf, fma(0, inf, 0) = NaN.  Every user (sigmoid, tanh,
   // softplus, ELU) wants the saturated value: 1 / (1 + 3.4e38) = 0, 1 - 2 / 3.4e38 = 1, e^-104 = 0 in fp32.
+  // A NaN argument stays NaN (v_med3 would return the smaller of the two bounds for it, i.e. e^-104: a NaN pre-activation would
+  // leave every activation as a finite number and never reach the log-weights, which is what debug mode checks): one compare +
+  // select on the way out.
+  const float x0 = x;
   x = __builtin_amdgcn_fmed3f(x, -104.0f, 88.72283f);
   const float t = x * 1.44269504088896340736f;
   const float r = fmaf(x, 1.44269504088896340736f, -t) + x * 1.92596299112661746e-8f;
   const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, r * 0.69314718055994530942f, e);
+  return x0 != x0 ? x0 : fmaf(e, r * 0.69314718055994530942f, e);
 }
 __device__ __forceinline__ float sq_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
 __device__ __forceinline__ float sq_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + sq_exp(-x)); }

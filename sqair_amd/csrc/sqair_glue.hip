@@ -93,12 +93,7 @@ __global__ __launch_bounds__(256) void k_crop_row(const CropArgs a, const POff p
 
 int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
   const size_t shm = (4 + (size_t)4 * d.G + (size_t)d.H * d.W) * sizeof(float);
-  static bool big_lds = false;
-  if (shm > 48 * 1024 && !big_lds) {  // 128x128 frames: 64 KiB + tables, CDNA4 has 160 KiB of LDS per CU
-    (void)hipFuncSetAttribute((const void*)k_crop_row, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipGetLastError();
-    big_lds = true;
-  }
+  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_crop_row, 150 * 1024) != 0) return -2;
   SQ_LAUNCH(k_crop_row, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
   return 0;
 }
@@ -948,12 +943,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s) {
   const int band_rows = sq_canvas_band_rows(d.H, d.W, SQ_CANVAS_PF_FWD);
   const size_t shm = sq_canvas_lds_floats(d.N, d.G, d.H, d.W, band_rows) * sizeof(float);
-  static bool big = false;
-  if (shm > 48 * 1024 && !big) {
-    (void)hipFuncSetAttribute((const void*)k_insert_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipGetLastError();
-    big = true;
-  }
+  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_insert_loglik, 150 * 1024) != 0) return -2;
   SQ_LAUNCH(k_insert_loglik, dim3(d.R, a.n_frames > 0 ? a.n_frames : 1), dim3(256), shm, s, a, d, band_rows);
   return 0;
 }

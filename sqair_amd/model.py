@@ -93,12 +93,12 @@ class SqairCore(object):
             self.stream = torch.cuda.Stream(device=self.device)
         self._shape = None
         self._graph_ready = False
-        _capi.check(self.handle, self.lib.sqair_set_workspace_clearing(self.handle, 0), "sqair_set_workspace_clearing")
+        self.check(self.lib.sqair_set_workspace_clearing(self.handle, 0), "sqair_set_workspace_clearing")
 
     def _clear_ws(self, ws, train):
         """One workspace per (T, B, inference | training) is cleared ONCE here; the per-pass zero fill of the library is
         switched off for this handle (include/sqair_hip.h: sqair_set_workspace_clearing)."""
-        _capi.check(self.handle, self.lib.sqair_clear_workspace(self.handle, ws.data_ptr(), ws.numel() * 4, self.T_bind, self.B_bind,
+        self.check(self.lib.sqair_clear_workspace(self.handle, ws.data_ptr(), ws.numel() * 4, self.T_bind, self.B_bind,
                                                                  int(train), self._stream()), "sqair_clear_workspace")
         self.stream.synchronize()
 
@@ -147,7 +147,7 @@ class SqairCore(object):
     def pack(self):
         with torch.cuda.device(self.device):
             self._join_in()
-            _capi.check(self.handle, self.lib.sqair_pack_params(self.handle, self.flat.data_ptr(),
+            self.check(self.lib.sqair_pack_params(self.handle, self.flat.data_ptr(),
                                                                 self.packed.data_ptr(), self._stream()),
                         "sqair_pack_params")
             self._join_out()
@@ -189,7 +189,7 @@ class SqairCore(object):
             self.gen_noise = None
             if self.cfg.sample_from_prior:  # second set of draws: the prior samples of the generation modes
                 self.gen_noise = torch.zeros(T, R, 2, N, self.nzw, dtype=torch.float32, device=self.device)
-                _capi.check(self.handle, self.lib.sqair_set_generation_noise(self.handle, self.gen_noise.data_ptr()),
+                self.check(self.lib.sqair_set_generation_noise(self.handle, self.gen_noise.data_ptr()),
                             "sqair_set_generation_noise")
             self.ws_bytes = self.lib.sqair_workspace_bytes(self.handle, T, B)
             self.workspace = torch.empty(self.ws_bytes // 4, dtype=torch.float32, device=self.device)
@@ -228,11 +228,11 @@ class SqairCore(object):
             return
         with torch.cuda.device(self.device):
             self._join_in()
-            _capi.check(self.handle, self.lib.sqair_fill_noise(
+            self.check(self.lib.sqair_fill_noise(
                 self.handle, self.noise.data_ptr(), self.T, self.B, int(global_batch or self.B), int(b0), int(seed), int(step),
                 self._stream()), "sqair_fill_noise")
             if self.gen_noise is not None:  # the prior samples of the generation modes: an independent Philox key
-                _capi.check(self.handle, self.lib.sqair_fill_noise(
+                self.check(self.lib.sqair_fill_noise(
                     self.handle, self.gen_noise.data_ptr(), self.T, self.B, int(global_batch or self.B), int(b0),
                     int(seed) ^ 0x9E3779B97F4A7C15, int(step), self._stream()), "sqair_fill_noise")
             self._join_out()
@@ -255,17 +255,17 @@ class SqairCore(object):
                     self._clear_ws(self.train_ws, True)
                 args = list(self._args(t_offset))
                 args[9], args[10] = self.train_ws.data_ptr(), nb
-                _capi.check(self.handle, self.lib.sqair_forward_train(*args), "sqair_forward_train")
+                self.check(self.lib.sqair_forward_train(*args), "sqair_forward_train")
             elif use_graph:
                 if not self._graph_ready:
                     torch.cuda.synchronize(self.device)
-                    _capi.check(self.handle, self.lib.sqair_graph_capture(*self._args(t_offset)), "sqair_graph_capture")
+                    self.check(self.lib.sqair_graph_capture(*self._args(t_offset)), "sqair_graph_capture")
                     self._graph_ready = True
-                _capi.check(self.handle, self.lib.sqair_graph_launch(self.handle, self._stream()), "sqair_graph_launch")
+                self.check(self.lib.sqair_graph_launch(self.handle, self._stream()), "sqair_graph_launch")
             else:
-                _capi.check(self.handle, self.lib.sqair_forward(*self._args(t_offset)), "sqair_forward")
+                self.check(self.lib.sqair_forward(*self._args(t_offset)), "sqair_forward")
             dlp = self.out["discrete_log_prob"].data_ptr() if "discrete_log_prob" in self.out else None
-            _capi.check(self.handle, self.lib.sqair_elbo(
+            self.check(self.lib.sqair_elbo(
                 self.handle, self.out["log_weights_per_timestep"].data_ptr(), dlp, self.T, self.B,
                 self.log_weights.data_ptr(), self.elbo_iwae_per_example.data_ptr(),
                 self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.scalars.data_ptr(),
@@ -283,7 +283,7 @@ class SqairCore(object):
             if getattr(self, "flat_grad", None) is None:
                 self.flat_grad = torch.zeros_like(self.flat)
             self._join_in()
-            _capi.check(self.handle, self.lib.sqair_backward(
+            self.check(self.lib.sqair_backward(
                 self.handle, self.flat.data_ptr(), self.packed.data_ptr(), self.obs.data_ptr(), self.noise.data_ptr(),
                 self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.T, self.B, int(t_offset),
                 self.train_ws.data_ptr(), self.train_ws.numel() * 4, self.bwd_scratch.data_ptr(), nb,
@@ -304,19 +304,19 @@ class SqairCore(object):
             self.backward(t_offset=t_offset)
             torch.cuda.synchronize(self.device)
             with torch.cuda.device(self.device):
-                _capi.check(self.handle, self.lib.sqair_capture_begin(self.handle, self._stream()), "sqair_capture_begin")
+                self.check(self.lib.sqair_capture_begin(self.handle, self._stream()), "sqair_capture_begin")
                 try:
                     self._issue_train(t_offset)
                 finally:
                     n = self.lib.sqair_capture_end(self.handle, self._stream(), 1)
                 if n < 0:
-                    _capi.check(self.handle, n, "sqair_capture_end")
+                    self.check(n, "sqair_capture_end")
             self.train_graph_nodes = n
             self._train_graph_ready = True
             self._train_graph_key = (self._shape, int(t_offset))
         with torch.cuda.device(self.device):
             self._join_in()
-            _capi.check(self.handle, self.lib.sqair_capture_launch(self.handle, 1, self._stream()), "sqair_capture_launch")
+            self.check(self.lib.sqair_capture_launch(self.handle, 1, self._stream()), "sqair_capture_launch")
             self._join_out()
         return self.flat_grad
 
@@ -325,14 +325,14 @@ class SqairCore(object):
         nb = self.train_ws.numel() * 4
         args = list(self._args(t_offset))
         args[9], args[10] = self.train_ws.data_ptr(), nb
-        _capi.check(self.handle, self.lib.sqair_forward_train(*args), "sqair_forward_train")
+        self.check(self.lib.sqair_forward_train(*args), "sqair_forward_train")
         dlp = self.out["discrete_log_prob"].data_ptr() if "discrete_log_prob" in self.out else None
-        _capi.check(self.handle, self.lib.sqair_elbo(
+        self.check(self.lib.sqair_elbo(
             self.handle, self.out["log_weights_per_timestep"].data_ptr(), dlp, self.T, self.B,
             self.log_weights.data_ptr(), self.elbo_iwae_per_example.data_ptr(),
             self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.scalars.data_ptr(),
             self.c_means, len(self.mean_names), self.iw_means.data_ptr(), self._stream()), "sqair_elbo")
-        _capi.check(self.handle, self.lib.sqair_backward(
+        self.check(self.lib.sqair_backward(
             self.handle, self.flat.data_ptr(), self.packed.data_ptr(), self.obs.data_ptr(), self.noise.data_ptr(),
             self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.T, self.B, int(t_offset),
             self.train_ws.data_ptr(), nb, self.bwd_scratch.data_ptr(), self.bwd_scratch.numel() * 4,
@@ -358,7 +358,7 @@ class SqairCore(object):
             flat_grad = torch.zeros_like(self.flat)
             d_rec = torch.zeros(self.T, M, 64, dtype=torch.float32, device=self.device)
             self._join_in()
-            _capi.check(self.handle, self.lib.sqair_backward_decoder(
+            self.check(self.lib.sqair_backward_decoder(
                 self.handle, self.flat.data_ptr(), self.packed.data_ptr(), self.obs.data_ptr(),
                 self.importance_weights.data_ptr(), self.vimco_signal.data_ptr(), self.T, self.B,
                 self.workspace.data_ptr(), self.ws_bytes, scratch.data_ptr(), nb, flat_grad.data_ptr(), d_rec.data_ptr(),
@@ -375,6 +375,10 @@ class SqairCore(object):
     def graph_nodes(self):
         return self.lib.sqair_graph_nodes(self.handle)
 
+    def check(self, rc, what):
+        """Raises RuntimeError with this handle's error text, read through the library the handle came from."""
+        _capi.check(self.handle, rc, what, library=self.lib)
+
     def check_finite(self, tensor, what):
         """Debug mode (reference: `debug` -> validate_args / allow_nan_stats=False, sqair/core.py:226, :261,
         sqair/modules.py:318-320): raises RuntimeError through the library's error channel when `tensor` holds NaN / Inf.
@@ -383,7 +387,7 @@ class SqairCore(object):
             self._finite_flag = torch.zeros(2, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             self._join_in()
-            _capi.check(self.handle, self.lib.sqair_check_finite(
+            self.check(self.lib.sqair_check_finite(
                 self.handle, tensor.data_ptr(), tensor.numel(), what.encode(), self._finite_flag.data_ptr(), self._stream()),
                 "sqair_check_finite")
 
@@ -562,7 +566,7 @@ class Model(object):
                 self._debug_checks()
                 core.check_finite(core.flat_grad, "flat gradient of the VIMCO target")
             if l2_reg != 0.0:
-                _capi.check(core.handle, core.lib.sqair_add_l2_grad(
+                core.check(core.lib.sqair_add_l2_grad(
                     core.handle, core.flat.data_ptr(), core.flat_grad.data_ptr(), core.n_params, float(l2_reg),
                     core._stream()), "sqair_add_l2_grad")
             self._collect()

@@ -41,7 +41,7 @@ class Timeline(object):
         self.core = core
         with torch.cuda.device(core.device):
             self.buf = torch.zeros((mbytes << 20) // 8, dtype=torch.int64, device=core.device)
-        _capi.check(core.handle, core.lib.sqair_timeline_begin(core.handle, self.buf.data_ptr(), self.buf.numel() * 8),
+        core.check(core.lib.sqair_timeline_begin(core.handle, self.buf.data_ptr(), self.buf.numel() * 8),
                     "sqair_timeline_begin")
 
     def close(self):

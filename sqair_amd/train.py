@@ -87,7 +87,7 @@ class Optimizer(object):
         self.t += 1
         if self.kind == "rmsprop":
             with torch.cuda.device(core.device):
-                _capi.check(core.handle, core.lib.sqair_rmsprop_step(
+                core.check(core.lib.sqair_rmsprop_step(
                     core.handle, core.flat.data_ptr(), flat_grad.data_ptr(), self.ms.data_ptr(), self.mom.data_ptr(),
                     core.n_params, float(lr), self.decay, self.momentum, self.epsilon, float(grad_scale),
                     C.c_void_p(torch.cuda.current_stream(core.device).cuda_stream)), "sqair_rmsprop_step")
@@ -161,7 +161,7 @@ class Trainer(object):
             g = core.grad_step(use_graph=self.use_graph)
             l2 = float(getattr(F, "l2", 0.0))
             if l2 != 0.0:
-                _capi.check(core.handle, core.lib.sqair_add_l2_grad(
+                core.check(core.lib.sqair_add_l2_grad(
                     core.handle, core.flat.data_ptr(), g.data_ptr(), core.n_params, l2, core._stream()), "sqair_add_l2_grad")
             scale = allreduce_flat_grads(g, comm=self.comm, stream=core.stream) if self.collective else 1.0
             self.opt.apply_gradients(g, learning_rate(F, self.step_no), grad_scale=scale)

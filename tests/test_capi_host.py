@@ -26,7 +26,30 @@ def test_library_loads_and_exports_header_symbols(repo_root):
     for n in names:
         assert hasattr(lib, n), "missing export " + n
     assert set(names) == set(_capi.EXPORTED_SYMBOLS), "ctypes prototypes and header disagree"
-    assert lib.sqair_abi_version() == 1
+    assert lib.sqair_abi_version() == _capi.ABI_VERSION == 2
+    assert lib.sqair_build_flags() == b"product"
+
+
+def test_build_id_is_compiled_in_and_a_stale_binary_is_refused(tmp_path):
+    """The id a library reports is the hash of the sources IT was compiled from (csrc/build.py passes it to hipcc), not a hash
+    taken from disk at run time: a binary that does not belong to the sources beside it is refused by the binding, and the
+    measurement tools (bench.py, tools/timeline.py) get their `build_id` from the loaded library."""
+    from sqair_amd.csrc import build as B
+    assert _capi.build_id() == _capi.source_id() == B.binary_id(_capi.LIB_PATH)
+    assert re.fullmatch(r"[0-9a-f]{16}", _capi.build_id())
+    # a deliberately stale copy: same code, another id compiled in (both occurrences: the marker and the exported string)
+    blob = open(_capi.LIB_PATH, "rb").read()
+    good = _capi.build_id().encode()
+    assert blob.count(good) >= 2
+    stale = tmp_path / "libsqair_hip.so"
+    stale.write_bytes(blob.replace(good, b"0123456789abcdef"))
+    assert B.binary_id(str(stale)) == "0123456789abcdef"
+    with pytest.raises(_capi.StaleLibraryError, match="compiled from sources 0123456789abcdef but the sources on disk are " + good.decode()):
+        _capi.lib(str(stale))
+    assert _capi.lib(str(stale), allow_stale=True).sqair_build_id() == b"0123456789abcdef"
+    assert _capi.build_id(str(stale)) == "0123456789abcdef"   # the LIBRARY's value, whatever the disk says
+    # csrc/build.py rebuilds on an id mismatch, not on modification times
+    assert B.binary_id(str(tmp_path / "absent.so")) is None
 
 
 @pytest.mark.parametrize("N,hw,cell", [(3, (50, 50), "GRU"), (4, (50, 50), "GRU"), (6, (50, 50), "GRU"), (4, (128, 128), "GRU"),

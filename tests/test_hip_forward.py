@@ -345,7 +345,7 @@ def test_tail_fused_into_the_next_rnn_layer_is_bitwise_identical(K, N, T, B, n_u
 
     def run(train, fusion=True):
         core = SqairCore(F, hw)
-        _capi.check(core.handle, core.lib.sqair_set_option(core.handle, b"tail_fusion", int(fusion)), "sqair_set_option")
+        core.check(core.lib.sqair_set_option(core.handle, b"tail_fusion", int(fusion)), "sqair_set_option")
         core.set_params(P)
         Model(obs, None, core, K, presence=d["nums"])
         with core.on_stream():
@@ -446,3 +446,20 @@ def test_debug_mode_raises_on_non_finite_log_weights():
     with pytest.raises(RuntimeError, match="non-finite values in log_weights"):
         m.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))
     assert core.lib.sqair_set_option(core.handle, b"no_such_option", 1) == -2
+    # a NaN that enters AHEAD of an activation must survive it (the compact exponential clamps its argument with v_med3, which
+    # maps NaN to a bound: sigmoid / tanh / ELU / softplus would turn a NaN pre-activation into a finite value): hidden-layer
+    # weights of ELU, tanh (discovery RNN) and softplus (what scale) layers that every frame's log-weight depends on, and a NaN
+    # pixel in the observation
+    for name in ("enc.glimpse.l0.w", "disc.rnn.i2h.w", "enc.what_head.w", "dec.l0.w"):
+        bad = dict(P)
+        bad[name] = np.full_like(P[name], np.nan)
+        core.set_params(bad)
+        with pytest.raises(RuntimeError, match="non-finite values in log_weights"):
+            m.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))
+    core.set_params(P)
+    m.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))   # healthy again
+    obs_bad = obs.copy()
+    obs_bad[1, 0, 20, 20] = np.nan
+    mb = Model(obs_bad, None, core, K, presence=d["nums"], debug=True)
+    with pytest.raises(RuntimeError, match="non-finite values in log_weights"):
+        mb.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))
