@@ -19,7 +19,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
                  (135.4 MFLOP/frame at cfg-2, as the reference graph computes them, / dense
                  launches per step) / average SLOT of a dense launch (its busy time + the dependent-launch gap up to
                  the next dispatch: the slots of all dispatches sum to the step); frac_busy_only and
-                 frac_whole_step beside it; peak = 157.3 TFLOP/s.  The committed profiles/r03_timeline_*.csv
+                 frac_whole_step beside it; peak = 157.3 TFLOP/s.  The committed profiles/r04_timeline_*.csv
                  are the same measurement (tools/timeline.py; `--recompute` recomputes the fractions from them).
   roofline_hbm — the gather / scatter / reduce class (k_crop_row, k_insert_loglik, k_compact, k_logprob): busy time
                  from the same timeline, algorithmic bytes from the shapes (sqair_amd/timeline.py), PMC traffic
@@ -48,6 +48,10 @@ import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense f32-in matrix peak (= vector peak)
 MACS_PER_FRAME_PARTICLE = {1: 10166288, 2: 13543744, 3: 13543744, 4: 20298656, 5: 27760960}
+# ... and what the path EXECUTES per frame (the loop-invariant input encoder hoisted out of the N slot steps, the
+# mask MLP evaluated once): MFLOP per frame, all K particles included.  `roofline.frac_executed` is quoted on this figure.
+EXECUTED_MFLOP_PER_FRAME = {1: 17.5, 2: 114.3, 3: 114.3, 4: 167.7, 5: 149.8}
+PROFILE_TAG = "r04"                    # profiles/<tag>_*.json|csv: the committed files of this round (tools/profile_round.sh)
 
 
 def cpu_baseline(F, hw, P, obs, noise, hip_ref, budget_s=25.0):
@@ -158,31 +162,32 @@ def timeline_roofline(F, Ftr, hw, P, obs, nums, algo_flops_step, ms_fwd, ms_trai
                                    psnh=core_t.psnh, masked=bool(F.masked_glimpse), train=False)
     # PMC traffic measured by rocprofv3 on this build, if committed (tools/profile_round.sh)
     traffic, traffic_note, fam_traffic = None, None, None
-    tpath = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_hbm_traffic.json")
     if os.path.exists(tpath) and cfg_id == 2 and not batch_override:
         try:
             tj = json.load(open(tpath))
             if tj.get("build_id") == bid:
                 traffic = tj.get("dominant_bytes_per_launch")
                 fam_traffic = tj.get("family_bytes_per_launch")
-                traffic_note = "PMC FETCH_SIZE / WRITE_SIZE of {} on this build (profiles/r03_hbm_traffic.json, two separate --pmc passes)".format(tj.get("dominant"))
+                traffic_note = "PMC FETCH_SIZE / WRITE_SIZE of {} on this build (profiles/{}_hbm_traffic.json, two separate --pmc passes)".format(tj.get("dominant"), PROFILE_TAG)
             else:
-                traffic_note = "profiles/r03_hbm_traffic.json was measured on build {} != this build {}: not quoted".format(tj.get("build_id"), bid)
+                traffic_note = "profiles/{}_hbm_traffic.json was measured on build {} != this build {}: not quoted".format(PROFILE_TAG, tj.get("build_id"), bid)
         except Exception as e:  # a broken profile file must not take the bench line down
             traffic_note = "profiles unreadable: {}".format(e)
     per = algo_flops_step / max(d["launches"], 1)
+    exec_ratio = EXECUTED_MFLOP_PER_FRAME[cfg_id] * 1e6 / (2.0 * K * MACS_PER_FRAME_PARTICLE[cfg_id])
 
     def frac(us):
         return per / (us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS
     committed = None
-    cpath = os.path.join(ROOT, "profiles", "r03_timeline.json")
+    cpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_timeline.json")
     if os.path.exists(cpath) and cfg_id == 2 and not batch_override:
         try:
             cj = json.load(open(cpath))
-            committed = dict(file="profiles/r03_timeline.json (+ r03_timeline_fwd.csv, r03_timeline_train.csv)",
+            committed = dict(file="profiles/{0}_timeline.json (+ {0}_timeline_fwd.csv, {0}_timeline_train.csv)".format(PROFILE_TAG),
                              same_build_as_this_run=cj.get("build_id") == bid, build_id=cj.get("build_id"),
                              frac_slot=cj["fwd"]["dense_frac"]["frac_slot"], frac_busy_only=cj["fwd"]["dense_frac"]["frac_busy_only"],
-                             recompute="python tools/timeline.py --recompute profiles/r03_timeline_fwd.csv")
+                             recompute="python tools/timeline.py --recompute profiles/{}_timeline_fwd.csv".format(PROFILE_TAG))
         except Exception as e:
             committed = dict(error=str(e))
     roofline = dict(
@@ -193,6 +198,9 @@ def timeline_roofline(F, Ftr, hw, P, obs, nums, algo_flops_step, ms_fwd, ms_trai
                 "dispatch's first-wave start = busy + dependent-launch gap), from the per-dispatch timeline of one step stamped "
                 "by the kernels themselves (no profiler)",
         frac_slot=frac(d["avg_slot_us"]), frac_busy_only=frac(d["avg_busy_us"]),
+        # the same slot fraction on the FLOPs the path executes (input encoder hoisted, mask MLP once): what the matrix cores
+        # are really asked to do per launch; `frac` stays on the as-reference count, which is the contract
+        frac_executed=frac(d["avg_slot_us"]) * exec_ratio, executed_over_algorithmic_flops=exec_ratio,
         frac_whole_step=algo_flops_step / (ms_fwd * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
         avg_slot_us=d["avg_slot_us"], avg_busy_us=d["avg_busy_us"], algorithmic_flops_per_launch=per,
         timeline=dict(dispatches=s["dispatches"], span_us=s["span_us"], busy_us=s["busy_us"], gap_us=s["gap_us"],
@@ -412,6 +420,51 @@ def main():
                           "RMSProp + re-pack; finite={}".format(bool(torch.isfinite(core.flat).all())))
         core.set_params(P)  # back to the benchmark parameters for the parity / roofline legs below
 
+    # ---- what the evaluation path costs: the same forward step with ALL 38 per-frame outputs of SequentialAIR requested (canvases,
+    # glimpses, every log-probability: reference sqair/seq.py:121-177 writes them all, scripts/eval.py:191-224 and the notebook read
+    # them); the timed region above asks for `elbo_iwae` only (outputs="minimal", what `sess.run(model.elbo_iwae)` evaluates).
+    all_out = None
+    if rank == 0 and use_graph:
+        try:
+            from sqair_amd.timeline import time_steps
+            core_a = SqairCore(F, hw, device=device)
+            with core_a.on_stream():
+                core_a.set_params(P)
+                Model(obs, None, core_a, K, presence=nums, outputs="all")
+                ka = [0]
+
+                def astep():
+                    core_a.draw_noise(seed=1000, step=ka[0], global_batch=B * world, b0=rank * B)
+                    ka[0] += 1
+                    core_a.forward(use_graph=True)
+                ms_a = time_steps(core_a, astep, steps=max(5, args.steps // 2), warm=3)
+            all_out = dict(ms_per_step=ms_a, value=B * T / (ms_a * 1e-3), unit="frames/s (this rank)", graph_nodes=core_a.graph_nodes(),
+                           outputs=len(core_a.out), what="noise draw + graph replay + ELBO with every SqairOutputs field written")
+            del core_a
+            torch.cuda.empty_cache()
+            torch.cuda.set_stream(core.stream)
+        except Exception as e:  # never take the bench line down
+            all_out = dict(error="{}: {}".format(type(e).__name__, e))
+    # ---- N > 1: what the training step SHOULD take = this rank's step without the collective + the collective alone; the ratio
+    # flags a degraded all-reduce (or a stream / queue problem) in the driver's scaling curve by itself
+    if train is not None and world > 1:
+        if rank == 0:
+            try:
+                from sqair_amd.timeline import time_steps
+                tr1 = Trainer(model, Ftr, use_graph=use_graph, comm=None, collective=False)
+                with core.on_stream():
+                    ms_1 = time_steps(core, lambda: tr1.step(seed=2000, global_batch=B * world, b0=rank * B), steps=max(3, n_train // 2), warm=2)
+                del tr1
+                core.set_params(P)
+                train["single_rank_ms_per_step_no_collective"] = ms_1
+                if train.get("allreduce_ms") is not None:
+                    train["expected_ms"] = ms_1 + train["allreduce_ms"]
+                    train["measured_over_expected"] = train["ms_per_step"] / train["expected_ms"]
+            except Exception as e:
+                train["expected_ms_error"] = "{}: {}".format(type(e).__name__, e)
+        torch.cuda.synchronize()
+        dist.barrier()
+
     # ---- N > 1: the strong-scaling reference.  Rank 0 alone processes the GLOBAL batch (B * world sequences) on its GPU, after
     # the timed regions and outside `value`: weak scaling says N GPUs do N x the work in the same time; this says what ONE GPU
     # needs for the same N x work (the small-batch step is latency-bound, so one GPU is far better than 1/N of the job).
@@ -548,6 +601,7 @@ def main():
             "parallelism": "dp{}".format(world), "graph_nodes": core.graph_nodes()},
         "elbo_iwae_nats_per_seq": elbo, "elbo_vae_nats_per_seq": elbo_vae,
         "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu, "train": train,
+        "forward_all_outputs": all_out, "forward_all_outputs_ms": (all_out or {}).get("ms_per_step"),
         "single_gpu_at_global_batch": single, "streams": streams, "build_id": bid,
     }
     if cpu is not None:

@@ -110,6 +110,7 @@ _PROTOS = {
     "sqair_debug_linear_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "sqair_debug_layers": (C.c_int, [C.c_void_p]),
+    "sqair_debug_padded_count": (C.c_int64, [C.c_void_p, C.POINTER(C.c_int)]),
     "sqair_debug_layer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sqair_debug_plan": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),

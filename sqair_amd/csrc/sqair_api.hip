@@ -14,6 +14,7 @@
 //     pre-activations, the prior GRU) is batched over the N slots up front (M = B'*N rows);
 //   * only the truly sequential part (explaining away: slot k needs slot k-1's sample) remains in
 //     the per-slot chain.
+#include <algorithm>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -27,22 +28,55 @@ void sq_set_error(SqairHandle* h, const std::string& msg) {
 // ------------------------------------------------------------------------------------------------
 // parameter inventory — order of SURVEY.md Appendix C (reference: notebooks/play.ipynb:239-362)
 // ------------------------------------------------------------------------------------------------
-static void add_param(SqairHandle* h, const std::string& name, int rows, int cols) {
+// A dimension of a parameter as a concatenation of segments, each with its size in the caller's (reference) shapes and in the
+// padded shapes the kernels run on.  Integer expressions over it (`4 + nh + 1`, `2 * nh + nw`, `4 * nh`) keep the segment
+// structure, so the inventory below reads like the reference's shape arithmetic and still knows where the padding sits.
+struct PDim {
+  std::vector<std::pair<int, int>> seg;  // (true size, padded size)
+  PDim(int n) { seg.push_back({n, n}); }   // NOLINT: implicit on purpose
+  PDim(int t, int p) { seg.push_back({t, p}); }
+  int t() const { int n = 0; for (auto& s : seg) n += s.first; return n; }
+  int p() const { int n = 0; for (auto& s : seg) n += s.second; return n; }
+  // position in the padded dimension of every true index
+  std::vector<int> map() const {
+    std::vector<int> m;
+    int base = 0;
+    for (auto& s : seg) { for (int i = 0; i < s.first; ++i) m.push_back(base + i); base += s.second; }
+    return m;
+  }
+};
+static PDim operator+(PDim a, const PDim& b) { a.seg.insert(a.seg.end(), b.seg.begin(), b.seg.end()); return a; }
+static PDim operator+(PDim a, int b) { return a + PDim(b); }
+static PDim operator+(int a, const PDim& b) { return PDim(a) + b; }
+static PDim operator*(int k, const PDim& a) { PDim r = a; for (int i = 1; i < k; ++i) r = r + a; return r; }
+
+static void add_param(SqairHandle* h, const std::string& name, const PDim& rows, const PDim& cols) {
   ParamEntry e;
   e.name = name;
   e.off = h->n_params;
-  e.rows = rows;
-  e.cols = cols;
-  e.numel = (int64_t)rows * cols;
+  e.rows = rows.p();
+  e.cols = cols.p();
+  e.numel = (int64_t)e.rows * e.cols;
   h->pidx[name] = (int)h->params.size();
   h->params.push_back(e);
   h->n_params += e.numel;
+  ParamEntry u;   // the caller's view of the same variable
+  u.name = name;
+  u.off = h->n_uparams;
+  u.rows = rows.t();
+  u.cols = cols.t();
+  u.numel = (int64_t)u.rows * u.cols;
+  h->uparams.push_back(u);
+  h->n_uparams += u.numel;
+  const std::vector<int> rm = rows.map(), cm = cols.map();
+  for (int r : rm)
+    for (int c : cm) h->u2i.push_back((int)(e.off + (int64_t)r * e.cols + c));
 }
-static void add_lin(SqairHandle* h, const std::string& name, int fin, int fout) {
+static void add_lin(SqairHandle* h, const std::string& name, const PDim& fin, const PDim& fout) {
   add_param(h, name + ".w", fin, fout);
   add_param(h, name + ".b", 1, fout);
 }
-static void add_gru(SqairHandle* h, const std::string& name, int fin, int nh) {
+static void add_gru(SqairHandle* h, const std::string& name, const PDim& fin, const PDim& nh) {
   const char* g[3] = {"z", "r", "h"};
   for (int i = 0; i < 3; ++i) {
     add_param(h, name + ".w" + g[i], fin, nh);
@@ -62,8 +96,10 @@ int PC(const SqairHandle* h, const std::string& name) { return h->params[h->pidx
 
 static void build_inventory(SqairHandle* h) {
   const SqairConfig& c = h->cfg;
-  const int P_ = c.img_h * c.img_w, nh = c.n_hidden, nw = c.n_what, N = c.n_steps_per_image;
-  const int G2 = c.glimpse_size * c.glimpse_size, nsp = nh / 2;
+  const int P_ = c.img_h * c.img_w, nw = c.n_what, N = c.n_steps_per_image;
+  const int G2 = c.glimpse_size * c.glimpse_size;
+  // (true, padded): n_hidden and the steps predictor's hidden width n_hidden // 2 (common_model_flags.py:59-71)
+  const PDim nh(h->ucfg.n_hidden, c.n_hidden), nsp(h->ucfg.n_hidden / 2, c.n_hidden / 2);
   add_param(h, "dec.mean_img", c.img_h, c.img_w);
   add_lin(h, "dec.l0", nw, nh);
   add_lin(h, "dec.l1", nh, nh);
@@ -116,7 +152,7 @@ static void build_inventory(SqairHandle* h) {
   add_lin(h, "prop.where_bias.l1", 128, 4);
   add_lin(h, "prop.steps.l0", 2 * nh + nw, nsp);
   add_lin(h, "prop.steps.l1", nsp, 1);
-  add_lin(h, "prop.transform.l0", 2 * nh + 4, nh);
+  add_lin(h, "prop.transform.l0", nh + 4 + nh, nh);   // [hidden | where_{t-1} | temporal] (core.py:325-326): the ORDER matters to the padding
   add_lin(h, "prop.transform.l1", nh, nh);
   add_lin(h, "prop.transform.l2", nh, 8);
   add_param(h, "prop.transform.scale_offset", 1, 1);
@@ -169,6 +205,7 @@ static void build_inventory(SqairHandle* h) {
   o.prop_rnn_init = (int)P(h, "prop.rnn_init");
   o.prior_init = (int)P(h, "seq.prior_init");
   o.temporal_init = (int)P(h, "seq.temporal_init");
+  h->padded = h->n_params != h->n_uparams;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -539,14 +576,18 @@ extern "C" const char* sqair_build_flags(void) { return SQAIR_BUILD_VARIANT; }
 extern "C" int sqair_create(const SqairConfig* cfg, SqairHandle** out) {
   if (cfg == nullptr || out == nullptr) return -1;
   *out = nullptr;
-  if (cfg->n_what < 1 || cfg->n_what > 50 || cfg->n_steps_per_image < 1 || cfg->n_steps_per_image > SQ_MAXN ||
-      (cfg->n_hidden != 128 && cfg->n_hidden != 256) ||  // n_units 4 / 8 (row kernels read nh / 32 floats per lane as float4;
-      cfg->glimpse_size < 2 ||                           //  slot buffers are laid out for nh <= 256)
-      cfg->img_h < 2 || cfg->img_w < 2 || ((cfg->img_h * cfg->img_w) % 4) != 0 ||  // frame rows are float4 GEMM operands
-      cfg->k_particles < 1 || cfg->k_particles > 64)
+  // The limits of this build (sqair_limits below).  Inside them every value of the reference's flags is accepted
+  // (common_model_flags.py:32-56, configs/mlp_mnist_model.py:42-52 take any integer): n_hidden = 32 n_units is padded to the next
+  // multiple of 128 with inert units (SqairHandle), frames of any H x W (rows that are not 16-byte multiples are staged through a
+  // padded copy), any number of particles.
+  if (cfg->n_what < 1 || cfg->n_what > SQ_MAX_NWHAT || cfg->n_steps_per_image < 1 || cfg->n_steps_per_image > SQ_MAXN ||
+      cfg->n_hidden < 16 || cfg->n_hidden > SQ_MAX_NHIDDEN || (cfg->n_hidden % 16) != 0 ||  // (n_hidden // 2 is a whole number of units)
+      cfg->glimpse_size < 2 || cfg->img_h < 2 || cfg->img_w < 2 || cfg->k_particles < 1 || cfg->k_particles > SQ_MAX_K)
     return -1;
   SqairHandle* h = new SqairHandle();
+  h->ucfg = *cfg;
   h->cfg = *cfg;
+  h->cfg.n_hidden = (cfg->n_hidden + 127) / 128 * 128;
   build_inventory(h);
   // GRU candidate matrices are bare [nh, nh] parameters: give build_plan's simple() a ".w" alias
   if (cfg->prior_cell == CELL_GRU) h->pidx["prop.prior_gru.uh.w"] = h->pidx["prop.prior_gru.uh"];
@@ -580,18 +621,19 @@ extern "C" int sqair_destroy(SqairHandle* h) {
 }
 
 extern "C" const char* sqair_last_error(const SqairHandle* h) { return h ? h->err.c_str() : "null handle"; }
-extern "C" int64_t sqair_param_count(const SqairHandle* h) { return h ? h->n_params : -1; }
-extern "C" int sqair_param_entries(const SqairHandle* h) { return h ? (int)h->params.size() : -1; }
+// (the caller's inventory: reference shapes, whatever the kernels pad internally)
+extern "C" int64_t sqair_param_count(const SqairHandle* h) { return h ? h->n_uparams : -1; }
+extern "C" int sqair_param_entries(const SqairHandle* h) { return h ? (int)h->uparams.size() : -1; }
 extern "C" int sqair_param_entry(const SqairHandle* h, int i, const char** name, int64_t* offset, int64_t* numel) {
-  if (!h || i < 0 || i >= (int)h->params.size()) return -1;
-  if (name) *name = h->params[i].name.c_str();
-  if (offset) *offset = h->params[i].off;
-  if (numel) *numel = h->params[i].numel;
+  if (!h || i < 0 || i >= (int)h->uparams.size()) return -1;
+  if (name) *name = h->uparams[i].name.c_str();
+  if (offset) *offset = h->uparams[i].off;
+  if (numel) *numel = h->uparams[i].numel;
   return 0;
 }
 extern "C" int sqair_get_config(const SqairHandle* h, SqairConfig* out) {
   if (!h || !out) return -1;
-  *out = h->cfg;
+  *out = h->ucfg;
   return 0;
 }
 extern "C" int sqair_noise_width(const SqairHandle* h) { return h ? 4 + h->cfg.n_what + 1 : -1; }
@@ -599,12 +641,30 @@ extern "C" int sqair_noise_width(const SqairHandle* h) { return h ? 4 + h->cfg.n
 
 extern "C" int64_t sqair_packed_bytes(const SqairHandle* h) { return h ? packed_layout(h).total * 4 : -1; }
 
+// caller's flat buffer <-> the padded one (padded configurations only): element j of the caller's lives at u2i[j]
+__global__ void k_flat_scatter(const float* __restrict__ user, float* __restrict__ padded, const int* __restrict__ u2i, int64_t n SQ_TLP) {
+  SQ_TL_SCOPE;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) padded[u2i[i]] = user[i];
+}
+__global__ void k_flat_gather(const float* __restrict__ padded, float* __restrict__ user, const int* __restrict__ u2i, int64_t n SQ_TLP) {
+  SQ_TL_SCOPE;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) user[i] = padded[u2i[i]];
+}
+// gradient in the padded shapes -> the caller's flat gradient buffer (the padding's entries are dropped)
+void sq_flat_gather(const SqairHandle* h, const float* padded_grad, float* user_grad, const void* packed, hipStream_t s) {
+  const PackedLayout pl = packed_layout(h);
+  SQ_LAUNCH(k_flat_gather, dim3((unsigned)std::min<int64_t>(2048, (h->n_uparams + 255) / 256)), dim3(256), 0, s, padded_grad, user_grad,
+            (const int*)packed + pl.um, h->n_uparams);
+}
+
 extern "C" int sqair_pack_params(SqairHandle* h, const float* flat, void* packed, void* stream) {
   if (!h || !flat || !packed) return -1;
   hipStream_t s = (hipStream_t)stream;
   const PackedLayout pl = packed_layout(h);
   float* base = (float*)packed;
   int* ibase = (int*)packed;
+  if (h->padded && h->plan_uploaded_ptr != packed)
+    SQ_CHECK_HIP(hipMemcpyAsync(ibase + pl.um, h->u2i.data(), h->u2i.size() * 4, hipMemcpyHostToDevice, s));
   if (h->plan_uploaded_ptr != packed) {
     SQ_CHECK_HIP(hipMemcpyAsync(ibase + pl.wi, h->widx.data(), h->packed_w * 4, hipMemcpyHostToDevice, s));
     SQ_CHECK_HIP(hipMemcpyAsync(ibase + pl.ba, h->bidx_a.data(), h->packed_b * 4, hipMemcpyHostToDevice, s));
@@ -612,6 +672,12 @@ extern "C" int sqair_pack_params(SqairHandle* h, const float* flat, void* packed
     SQ_CHECK_HIP(hipMemcpyAsync(ibase + pl.rm, h->rm_pool.data(), h->rm_pool.size() * 4, hipMemcpyHostToDevice, s));
     SQ_CHECK_HIP(hipStreamSynchronize(s));
     h->plan_uploaded_ptr = packed;
+  }
+  if (h->padded) {  // the padded copy of the flat parameters: zeros + the caller's values in their padded places
+    sq_zero_fill(base + pl.fi, h->n_params, s);
+    SQ_LAUNCH(k_flat_scatter, dim3((unsigned)std::min<int64_t>(2048, (h->n_uparams + 255) / 256)), dim3(256), 0, s, flat, base + pl.fi,
+              (const int*)(ibase + pl.um), h->n_uparams);
+    flat = base + pl.fi;
   }
   sq_launch_pack(flat, base + pl.w, ibase + pl.wi, h->packed_w, s);
   sq_launch_pack_bias(flat, base + pl.b, ibase + pl.ba, ibase + pl.bb, h->packed_b, s);
@@ -710,6 +776,10 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.dec_a = take((int64_t)T * M * nh);
   w.dec_b = take((int64_t)T * M * nh);
   w.gen = take(c.sample_from_prior ? (int64_t)T * M * gen::W : 64);
+  {
+    const int64_t P_ = (int64_t)c.img_h * c.img_w, P4 = (P_ + 3) / 4 * 4;
+    w.obs_p = take(P4 != P_ ? (int64_t)T * B * P4 + 16 : 64);   // (+16: the last K chunk of the input encoder may read past the row)
+  }
   w.prof_ts = (unsigned long long*)take(5 * PROF_MAX * 2);
   w.total = o;
   return w;
@@ -781,6 +851,22 @@ static int emit_tail(SqairHandle* h, const TailArgs& ta, Dims d, hipStream_t s) 
 static int emit_latsum(SqairHandle* h, const float* f, const float* rec_p, float* c, Dims d, hipStream_t s) { (void)h; return sq_launch_latent_sum(f, rec_p, c, d, s); }
 static int emit_compact(SqairHandle* h, const CompactArgs& ka, POff po, Dims d, hipStream_t s) { (void)h; return sq_launch_compact(ka, po, d, s); }
 
+// rows of n floats -> rows of pitch p4 >= n, zero padded
+__global__ void k_pad_rows(const float* __restrict__ src, float* __restrict__ dst, int n, int p4 SQ_TLP) {
+  SQ_TL_SCOPE;
+  const size_t r = blockIdx.x;
+  for (int i = threadIdx.x; i < p4; i += blockDim.x) dst[r * p4 + i] = i < n ? src[r * n + i] : 0.0f;
+}
+// row r: nseg segments of `padw` floats -> nseg segments of their first `truew` floats, packed
+__global__ void k_copy_cols(const float* __restrict__ src, float* __restrict__ dst, int nseg, int truew, int padw SQ_TLP) {
+  SQ_TL_SCOPE;
+  const size_t r = blockIdx.x;
+  for (int i = threadIdx.x; i < nseg * truew; i += blockDim.x) {
+    const int sg = i / truew, c = i - sg * truew;
+    dst[r * nseg * truew + i] = src[r * nseg * padw + sg * padw + c];
+  }
+}
+
 // parts: 1 = prologue (workspace clear, initial state, input encoder), 2 = the frame loop, 4 = epilogue (log-probabilities,
 // decoder, final state copies).
 int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, const float* obs, const float* noise,
@@ -799,6 +885,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     sq_set_error(h, "sample_from_prior: inference through sqair_forward / sqair_graph_capture only, after sqair_set_generation_noise");
     return -1;
   }
+  flat = sq_flat(h, flat, packed);   // (padded configurations: the copy sqair_pack_params keeps in the packed buffer)
   const SqairOutputs out = *outp;
   const int nh = c.n_hidden, nw = c.n_what, N = c.n_steps_per_image, K = c.k_particles;
   const int R = B * K, M = R * N, G2 = c.glimpse_size * c.glimpse_size, P_ = c.img_h * c.img_w;
@@ -806,6 +893,12 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   Dims d = make_dims(c, B);
   const POff po = h->po;
   const Workspace w = sq_carve(h, T, B, wsbase, train);
+  // Frames are GEMM A operands (the input encoder) and 16-byte staging units (crop adjoint): their rows must start 16-byte
+  // aligned.  H * W not a multiple of 4 (the reference takes any frame size): the pass works on a zero-padded copy with pitch
+  // P4 = H * W rounded up to 4, made once in the prologue; otherwise on the caller's buffer as it is.
+  const float* const obs_user = obs;
+  if ((P_ & 3) != 0) { d.P4 = (P_ + 3) / 4 * 4; obs = w.obs_p; }
+  const int PL = d.P4;
   const int pre_ld = h->layers[L_PRE].nt * 16;
   const int RW = rec::W, snh = d.snh, psnh = d.psnh;
   const int rw = sq_rnn_width(c);  // slot-RNN pre-activation width; pre columns: [rnn rw | T1 nh | S1 nh/2 | GRU z, r]
@@ -823,8 +916,9 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0, w.snh), w.state(w.prior_m, 0, w.psnh), w.last_id[0], w.disc_init_rec,
                          w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc,
                          (int)P(h, "prop.transform.l2.w"), (int)P(h, "disc.transform.l2.w"), flat, po, d, s);
+    if (obs != obs_user) SQ_LAUNCH(k_pad_rows, dim3(T * B), dim3(256), 0, s, obs_user, w.obs_p, P_, PL);
     // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
-    Lin a; a.seg(obs, P_, P_).out(w.ienc_a, nh).act(ACT_ELU); RUN(a, L_IENC0, T * B);
+    Lin a; a.seg(obs, PL, P_).out(w.ienc_a, nh).act(ACT_ELU); RUN(a, L_IENC0, T * B);
     Lin b; b.seg(w.ienc_a, nh, nh).out(w.ienc_b, nh).act(ACT_ELU); RUN(b, L_IENC1, T * B);
     Lin p; p.seg(w.ienc_b, nh, nh).out(w.pre_disc, rw); RUN(p, L_PREDISC, T * B);
   }
@@ -836,7 +930,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   TailArgs pending_tail; memset(&pending_tail, 0, sizeof(pending_tail));
   for (int t = 0; (parts & 2) && t < T; ++t) {
     const int pp = t & 1, pn = pp ^ 1;
-    const float* img = obs + (size_t)t * B * P_;
+    const float* img = obs + (size_t)t * B * PL;
     const float* nz = noise + (size_t)t * R * 2 * N * nzw;
     const float* rec_prev = w.rec_m_all + (size_t)t * M * RW;
     float* rec_next = w.rec_m_all + (size_t)(t + 1) * M * RW;
@@ -1125,11 +1219,16 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     ia.std_fg = c.output_std; ia.std_bg = c.background_std;
     sq_launch_insert_loglik(ia, d, s);
   }
-  // final recurrent state (for state-level parity checks)
-  if (out.final_temporal_state)
-    sq_copy(out.final_temporal_state, w.state(w.temporal_m, T, w.snh), (int64_t)M * snh, s);
-  if (out.final_prior_state)
-    sq_copy(out.final_prior_state, w.state(w.prior_m, T, w.psnh), (int64_t)M * psnh, s);
+  // final recurrent state (for state-level parity checks), in the caller's widths: [hidden | cell] halves without their padding
+  const int unh = h->ucfg.n_hidden;
+  if (out.final_temporal_state) {
+    if (!h->padded) sq_copy(out.final_temporal_state, w.state(w.temporal_m, T, w.snh), (int64_t)M * snh, s);
+    else SQ_LAUNCH(k_copy_cols, dim3(M), dim3(256), 0, s, (const float*)w.state(w.temporal_m, T, w.snh), out.final_temporal_state, snh / nh, unh, nh);
+  }
+  if (out.final_prior_state) {
+    if (!h->padded) sq_copy(out.final_prior_state, w.state(w.prior_m, T, w.psnh), (int64_t)M * psnh, s);
+    else SQ_LAUNCH(k_copy_cols, dim3(M), dim3(256), 0, s, (const float*)w.state(w.prior_m, T, w.psnh), out.final_prior_state, psnh / nh, unh, nh);
+  }
   if (out.final_last_used_id)
     sq_copy(out.final_last_used_id, w.last_id[T & 1], (int64_t)R, s);
   SQ_CHECK_HIP(hipGetLastError());
@@ -1599,6 +1698,13 @@ extern "C" int sqair_lstm_cell_bwd_test(SqairHandle* h, const float* gates, cons
 // the CPU from these tables to check the row / column maps without a GPU)
 // ------------------------------------------------------------------------------------------------
 extern "C" int sqair_debug_layers(const SqairHandle* h) { return h ? (int)L_COUNT : -1; }
+// padded inventory: total floats of the padded flat buffer; u2i (optional, n = sqair_param_count entries): where element j of the
+// caller's flat buffer lives in it
+extern "C" int64_t sqair_debug_padded_count(const SqairHandle* h, int* u2i) {
+  if (!h) return -1;
+  if (u2i) memcpy(u2i, h->u2i.data(), h->u2i.size() * sizeof(int));
+  return h->n_params;
+}
 extern "C" int sqair_debug_layer(const SqairHandle* h, int id, int* kc, int* nt, int* n, int* nseg, int* seg_widths) {
   if (!h || id < 0 || id >= L_COUNT) return -1;
   const PackedLayer& L = h->layers[id];
@@ -1703,6 +1809,10 @@ extern "C" int sqair_backward_decoder(SqairHandle* h, const float* flat, const v
   if (!h || !flat || !packedv || !obs || !importance_weights || !vimco_signal || !workspace || !scratch || !flat_grad) return -1;
   if (workspace_bytes < sqair_workspace_bytes(h, T, B) || scratch_bytes < sqair_backward_scratch_bytes(h, T, B)) {
     sq_set_error(h, "sqair_backward_decoder: workspace / scratch too small");
+    return -1;
+  }
+  if (h->padded) {
+    sq_set_error(h, "sqair_backward_decoder (a partial adjoint kept for unit tests) writes in the kernels' own shapes: use sqair_backward for an n_hidden that is not a multiple of 128");
     return -1;
   }
   hipStream_t s = (hipStream_t)stream;

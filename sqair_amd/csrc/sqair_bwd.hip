@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_crop_bwd(const CropBwdArgs a, const Dim
   __shared__ float red_s[4][4];
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int P = d.H * d.W, G = d.G, G2 = d.G * d.G;
-  const float* img = a.img + (size_t)b * P;
+  const float* img = a.img + (size_t)b * d.P4;
   for (int i = tid; i < P; i += 256) img_s[i] = img[i];
   __syncthreads();
   for (int kp = 0; kp < d.K; ++kp) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot-row of this (frame, row)
   const size_t frr = (size_t)fr * d.R + r;
   const float gll = a.g_ll[frr];
-  const float* __restrict__ img = a.img + ((size_t)fr * d.B + b) * P;
+  const float* __restrict__ img = a.img + ((size_t)fr * d.B + b) * d.P4;
   if (a.rec) sq_canvas_prologue(c, a.glimpse + fs * G2, a.rec + fs * a.rec_ld + rec::WHERE, a.rec_ld, a.rec + fs * a.rec_ld + rec::PRES, a.rec_ld, N, G, H, W);
   else sq_canvas_prologue(c, a.glimpse + fs * G2, a.where + fs * 4, 4, a.pres + fs, 1, N, G, H, W);
   for (int i = tid; i < N * G2; i += 256) dgl_s[i] = 0.0f;
@@ -1472,14 +1472,14 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
   const int r = blockIdx.x, b = sq_div(r, d.k_mul), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int slot = a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot;
   const int P = d.H * d.W, G = d.G, G2 = d.G * d.G, RW = rec::W;
-  const float* img = a.img + (size_t)b * P;
+  const float* img = a.img + (size_t)b * d.P4;
   const int madd = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
   const int gadd = a.g_row_add + (a.mode == CROP_PROP1 ? slot : 0);
   // everything the later phases read from memory is requested up front, next to the frame: the kernel then makes ONE memory
   // round trip (it used to make three: frame | glimpse gradient + mask | the operands of the where-sample adjoint).  The
   // frame's first 1024 16-byte units go out FIRST -- they still have to pass through LDS once they are here -- and the fences keep
   // hipcc from computing every address of the kernel before it issues the first request.
-  const int n4 = P >> 2;   // (H * W is a multiple of 4: sqair_create checks)
+  const int n4 = d.P4 >> 2;   // (frames are 16-byte aligned and padded to a multiple of 4 floats: Dims.P4)
   const f32x4_b* __restrict__ s4 = reinterpret_cast<const f32x4_b*>(img);
   f32x4_b fv[4];
 #pragma unroll
@@ -1695,7 +1695,8 @@ int sq_launch_where_param_grads(const float* d_tp, int tp_ld, const float* d_rec
   return 0;
 }
 int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
-  const size_t shm = (size_t)d.H * d.W * sizeof(float);
+  if ((d.P4 & 3) != 0) return -1;   // (the frame is staged in 16-byte units: callers pass the padded copy, Dims.P4)
+  const size_t shm = (size_t)d.P4 * sizeof(float);
   if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_crop_chain_bwd, 150 * 1024) != 0) return -2;
   SQ_LAUNCH(k_crop_chain_bwd, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
   return 0;

@@ -2,7 +2,20 @@
 #pragma once
 #include "sqair_common.h"
 
-constexpr int SQ_MAXN = 8;  // max object slots supported by the small per-row kernels
+// Limits of a build.  The product library is laid out for the shipped model family (slot record with 50 `what` entries, 8 slots,
+// hidden layers up to 256 wide); libsqair_hip_wide.so is the same source compiled with -DSQAIR_WIDE for the rest of the range the
+// reference's flags span: larger records, more slots, wider layers -- slower kernels (more registers / LDS per workgroup), same
+// results, same C-ABI.  sqair_amd picks the library from the flags.
+#ifdef SQAIR_WIDE
+constexpr int SQ_MAXN = 16;          // n_steps_per_image
+constexpr int SQ_MAX_NWHAT = 128;    // n_what
+constexpr int SQ_MAX_NHIDDEN = 512;  // 32 * n_units (after padding to a multiple of 128)
+#else
+constexpr int SQ_MAXN = 8;           // max object slots supported by the small per-row kernels
+constexpr int SQ_MAX_NWHAT = 50;
+constexpr int SQ_MAX_NHIDDEN = 256;
+#endif
+constexpr int SQ_MAX_K = 256;        // k_particles
 
 // Offsets (in floats) into the flat parameter buffer of the small layers the per-row kernels read
 // straight from the unpacked parameters.
@@ -30,6 +43,9 @@ struct Dims {
   SqMagic nw_mul, g_mul, k_mul;     // sq_magic(nw), sq_magic(G), sq_magic(K): e / x == sq_div(e, x_mul).  A runtime integer division is
                                     // ~25 instructions; in the slot tail and the crops it stood ahead of the operand loads of every
                                     // launch of the slot loop (forward step 3.44 -> 3.39 ms, training 7.90 -> 7.84)
+  int P4;                           // floats between consecutive frames in the buffer the kernels read frames from: H * W, or --
+                                    // inside a pass over frames whose H * W is not a multiple of 4 -- H * W rounded up to 4 (the
+                                    // pass stages such frames through a zero-padded copy so that every frame starts 16-byte aligned)
 };
 #ifdef __HIPCC__
 __device__ __forceinline__ int sq_div(int e, SqMagic m) { return (int)(__umulhi((unsigned)e, m.mul) + ((unsigned)e & m.one)); }
@@ -45,7 +61,7 @@ inline Dims make_dims(const SqairConfig& c, int B) {
   return Dims{c.img_h, c.img_w, c.glimpse_size, c.n_steps_per_image, c.n_what, c.n_hidden, c.k_particles, B * c.k_particles, B,
               4 + c.n_what + 1, lstm ? 2 * c.n_hidden : c.n_hidden, lstm ? c.n_hidden : 0,
               (c.prior_cell == CELL_LSTM) ? 2 * c.n_hidden : c.n_hidden, c.rnn_cell == RNN_LSTM ? 2 * c.n_hidden : c.n_hidden,
-              sq_magic(c.n_what), sq_magic(c.glimpse_size), sq_magic(c.k_particles)};
+              sq_magic(c.n_what), sq_magic(c.glimpse_size), sq_magic(c.k_particles), c.img_h * c.img_w};
 }
 
 enum CropMode { CROP_PLAIN = 0, CROP_PROP1 = 1, CROP_PROP2 = 2, CROP_DISC = 3 };

@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   const int fr = blockIdx.y;  // frame
   const int b = sq_div(r, d.k_mul);
   const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot of this (frame, row)
-  const float* __restrict__ img = a.img + ((size_t)fr * d.B + b) * P;
+  const float* __restrict__ img = a.img + ((size_t)fr * d.B + b) * d.P4;
   const size_t frr = (size_t)fr * d.R + r;
   const float qv = a.qz != nullptr ? a.qz[frr] : 0.0f, pv = a.qz != nullptr ? a.pz[frr] : 0.0f;  // requested early
   if (a.rec) sq_canvas_prologue(c, a.glimpse + fs * G2, a.rec + fs * a.rec_ld + rec::WHERE, a.rec_ld, a.rec + fs * a.rec_ld + rec::PRES, a.rec_ld, N, G, H, W);
@@ -1081,11 +1081,86 @@ __global__ __launch_bounds__(1024) void k_elbo(const float* __restrict__ log_w_t
   }
 }
 
+// The same reductions for K > 64 particles (the lane-per-particle kernel above covers the shipped K = 5 and anything up to a
+// wavefront): one workgroup, particle k of the current sequence on thread k (K <= 1024), sequences one after the other, the
+// sums of a sequence through LDS in a fixed order.  A slow path by design -- a few hundred KB of input -- with the formulas of
+// k_elbo term by term (model.py:88-103, :150-158, :202-205; targets.py:38-75; ops.py:52-59).
+__global__ __launch_bounds__(1024) void k_elbo_wide(const float* __restrict__ log_w_t, const float* __restrict__ disc_lp_t,
+                                                   int T, int B, int K, float* log_weights, float* elbo_per_ex, float* iw_out,
+                                                   float* signal_out, float* scalars, ElboMeans means, int n_means,
+                                                   float* means_out SQ_TLP) {
+  SQ_TL_SCOPE;
+  __shared__ float lw_s[1024], red_s[1024];
+  const int k = threadIdx.x, R = B * K;
+  const bool act = k < K;
+  // block-wide max / sum of one value per thread, result in every thread (tree over LDS: the same order on every run)
+  auto bmax = [&](float v) { red_s[k] = v; __syncthreads(); for (int o = 512; o > 0; o >>= 1) { if (k < o) red_s[k] = fmaxf(red_s[k], red_s[k + o]); __syncthreads(); } const float r = red_s[0]; __syncthreads(); return r; };
+  auto bsum = [&](float v) { red_s[k] = v; __syncthreads(); for (int o = 512; o > 0; o >>= 1) { if (k < o) red_s[k] += red_s[k + o]; __syncthreads(); } const float r = red_s[0]; __syncthreads(); return r; };
+  float a_vae = 0.0f, a_iwae = 0.0f, a_vimco = 0.0f, a_ess = 0.0f, a_means[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < B; ++b) {
+    float lw = 0.0f, dl = 0.0f, xm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (act)
+      for (int t = 0; t < T; ++t) {
+        const size_t o = (size_t)t * R + (size_t)b * K + k;
+        lw += log_w_t[o];
+        if (disc_lp_t != nullptr) dl += disc_lp_t[o];
+        for (int q = 0; q < n_means; ++q) xm[q] += means.p[q][o];
+      }
+    for (int q = 0; q < n_means; ++q) xm[q] /= (float)T;
+    lw_s[k] = act ? lw : -3.0e38f;
+    const float mx = bmax(act ? lw : -3.0e38f);
+    const float ex = act ? expf(lw - mx) : 0.0f;
+    const float se = bsum(ex);
+    const float elbo = mx + logf(se) - logf((float)K);
+    const float w = act ? ex / se : 0.0f;
+    const float sum_lw = bsum(act ? lw : 0.0f);
+    float cv = 0.0f;
+    if (act) {   // VIMCO control variate (targets.py:46-59): own weight replaced by the mean of the others, logmeanexp
+      const float abo = (sum_lw - lw) / ((float)K - 1.0f);
+      float m2 = abo;
+      for (int j = 0; j < K; ++j)
+        if (j != k) m2 = fmaxf(m2, lw_s[j]);
+      float rest = 0.0f;
+      for (int j = 0; j < K; ++j)
+        if (j != k) rest += expf(lw_s[j] - m2);
+      cv = m2 + logf(rest + expf(abo - m2)) - logf((float)K);
+    }
+    const float sig = act ? lw - cv : 0.0f;
+    const float loss = act ? (-elbo - sig * dl) : 0.0f;
+    a_vae += sum_lw;
+    a_vimco += bsum(loss);
+    const float sw = bsum(w), sw2 = bsum(w * w);
+    a_iwae += elbo;
+    a_ess += sw * sw / sw2;
+    if (act) {
+      if (log_weights) log_weights[b * K + k] = lw;
+      if (iw_out) iw_out[b * K + k] = w;
+      if (signal_out) signal_out[b * K + k] = sig;
+    }
+    if (k == 0 && elbo_per_ex) elbo_per_ex[b] = elbo;
+    for (int q = 0; q < n_means; ++q) a_means[q] += bsum(w * (act ? xm[q] : 0.0f));
+  }
+  if (k == 0) {
+    if (scalars) {
+      scalars[0] = a_vae / (float)(B * K);
+      scalars[1] = a_iwae / (float)B;
+      scalars[2] = a_vimco / (float)(B * K) / (float)T;
+      scalars[3] = a_ess / (float)B;
+    }
+    for (int q = 0; q < n_means; ++q) means_out[q] = a_means[q] / (float)B;
+  }
+}
+
 int sq_launch_elbo(const float* log_w_t, const float* disc_lp_t, int T, int B, int K, float* log_weights,
                    float* elbo_per_ex, float* iw, float* signal, float* scalars, const float* const* means_in,
                    int n_means, float* means_out, hipStream_t s) {
   ElboMeans m;
   for (int i = 0; i < 8; ++i) m.p[i] = (means_in != nullptr && i < n_means) ? means_in[i] : nullptr;
+  if (K > 64) {
+    SQ_LAUNCH(k_elbo_wide, dim3(1), dim3(1024), 0, s, log_w_t, disc_lp_t, T, B, K, log_weights, elbo_per_ex, iw, signal, scalars, m,
+              n_means, means_out);
+    return 0;
+  }
   SQ_LAUNCH(k_elbo, dim3(1), dim3(1024), 0, s, log_w_t, disc_lp_t, T, B, K, log_weights, elbo_per_ex, iw,
                      signal, scalars, m, n_means, means_out);
   return 0;

@@ -20,11 +20,23 @@ enum LayerId {
 };
 
 struct SqairHandle {
+  // cfg is what the kernels run on: n_hidden rounded up to a width the row kernels are written for (a multiple of 128).  The extra
+  // hidden units are inert by construction -- zero weights and biases in, zero weights out, zero initial states: ELU(0) = tanh(0)
+  // = 0, a GRU / LSTM unit that starts at 0 with zero pre-activations stays at 0 -- so results equal the unpadded model's.  ucfg
+  // is the caller's configuration.  `params` is the inventory in the PADDED shapes (everything downstream -- packing plan, POff,
+  // the kernels that read small layers straight from the flat buffer -- sees only these); `uparams` is the caller's inventory
+  // (reference shapes, what crosses the ABI) and u2i maps each of its elements to its place in the padded flat buffer.  When
+  // nothing is padded (`padded` false: n_hidden 128 / 256 / ...) the two coincide and the caller's buffers are used as they are.
   SqairConfig cfg;
+  SqairConfig ucfg;
   std::string err;
   std::vector<ParamEntry> params;
   std::map<std::string, int> pidx;
   int64_t n_params = 0;
+  std::vector<ParamEntry> uparams;
+  int64_t n_uparams = 0;
+  std::vector<int> u2i;
+  bool padded = false;
   POff po;
   // packing plan
   PackedLayer layers[L_COUNT];
@@ -59,9 +71,10 @@ inline int64_t align64(int64_t x) { return (x + 63) / 64 * 64; }
 int64_t P(const SqairHandle* h, const std::string& name);  // flat offset of a parameter (aborts on unknown names)
 int PC(const SqairHandle* h, const std::string& name);      // its number of columns
 
-// packed buffer = [weights fp32 | biases fp32 | widx int32 | bidx_a | bidx_b], each 256-byte aligned
+// packed buffer = [weights fp32 | biases fp32 | widx int32 | bidx_a | bidx_b | row maps | (padded configurations only:) the flat
+// parameters in the padded shapes fp32 | u2i int32], each 256-byte aligned
 struct PackedLayout {
-  int64_t w, b, wi, ba, bb, rm, total;  // offsets in 4-byte words
+  int64_t w, b, wi, ba, bb, rm, fi, um, total;  // offsets in 4-byte words
 };
 inline PackedLayout packed_layout(const SqairHandle* h) {
   PackedLayout p;
@@ -71,7 +84,9 @@ inline PackedLayout packed_layout(const SqairHandle* h) {
   p.ba = align64(p.wi + h->packed_w);
   p.bb = align64(p.ba + h->packed_b);
   p.rm = align64(p.bb + h->packed_b);
-  p.total = align64(p.rm + (int64_t)h->rm_pool.size());
+  p.fi = align64(p.rm + (int64_t)h->rm_pool.size());
+  p.um = align64(p.fi + (h->padded ? h->n_params : 0));
+  p.total = align64(p.um + (h->padded ? h->n_uparams : 0));
   return p;
 }
 
@@ -131,6 +146,7 @@ struct Workspace {
   int* src;                                      // train: compaction source slot [T][R][N]
   float *qz, *pz, *dlp, *dll, *glimpse, *dec_a, *dec_b;
   float* gen;                                    // sample_from_prior: [T][M][64] prior samples + original presences
+  float* obs_p;                                  // frames whose H * W is not a multiple of 4: zero-padded copy [T*B][P4] (else unused)
   unsigned long long* prof_ts;
   int64_t total;  // floats
 
@@ -152,6 +168,12 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train);
 void sq_zero_fill(float* p, int64_t n, hipStream_t s);
 void sq_copy(float* dst, const float* src, int64_t n, hipStream_t s);
 
+// the flat parameter buffer the kernels read: the caller's, or (padded configurations) the padded copy sqair_pack_params keeps
+// inside the packed buffer
+inline const float* sq_flat(const SqairHandle* h, const float* user_flat, const void* packed) {
+  return h->padded ? (const float*)packed + packed_layout(h).fi : user_flat;
+}
+void sq_flat_gather(const SqairHandle* h, const float* padded_grad, float* user_grad, const void* packed, hipStream_t s);
 int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipStream_t s);
 #define RUN(l, id, M)                                   \
   do {                                                  \

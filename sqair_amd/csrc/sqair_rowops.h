@@ -25,7 +25,7 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
   const int P = d.H * d.W, G = d.G, G2 = d.G * d.G;
   const int mrow_add = a.mask_row_add + (a.mode == CROP_PROP1 ? slot : 0);
   const int orow_add = a.out_row_add + (a.mode == CROP_PROP1 ? slot : 0);
-  const float* __restrict__ img = a.img + (size_t)b * P;
+  const float* __restrict__ img = a.img + (size_t)b * d.P4;
   const bool has_mask = a.mask != nullptr;
   const bool fused_tp = a.t2 != nullptr && (a.mode == CROP_PROP2 || a.mode == CROP_DISC);
   // Requests in the order of the kernel's critical path: the operands of the where sample (32 threads: the fused output layer

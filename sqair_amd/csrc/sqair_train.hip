@@ -135,6 +135,7 @@ struct BwdSpace {
   // A operands built for the batched weight gradients (fully written before they are read: outside the zero-filled part).
   // One copy per use -- the grouped launch at the end of the pass reads them all
   float *zs[2], *rs[2], *rh[4];
+  float* grad_padded;  // padded configurations only: flat gradient in the padded shapes
   int64_t zero_total;  // floats from the base that the pass expects zeroed
   int64_t total;
 };
@@ -191,6 +192,9 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   for (int i = 0; i < 4; ++i) T_(b.rh[i], MT * nh, true);
   if (pass == 0) b.zero_total = o;
   }
+  // padded configurations: the gradient in the padded shapes (gathered into the caller's buffer at the end of the pass)
+  b.grad_padded = base ? base + o : nullptr;
+  if (h->padded) o += align64(h->n_params);
   b.total = o;
   return b;
 }
@@ -225,6 +229,9 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   const Workspace w = sq_carve(h, T, B, (float*)train_workspace, true);
   const BwdSpace b = carve_bwd(h, T, B, (float*)scratch);
   const PackedLayout pl = packed_layout(h);
+  // (frames whose H * W is not a multiple of 4: the zero-padded copy the forward pass left in the training workspace)
+  if ((P_ & 3) != 0) { d.P4 = (P_ + 3) / 4 * 4; obs = w.obs_p; }
+  const int PL = d.P4;
   const int pre_ld = h->layers[L_PRE].nt * 16;
   const int* rm_dev = (const int*)packed + pl.rm;
 
@@ -232,6 +239,11 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     sq_set_error(h, "sqair_backward: flat_grad must be 16-byte aligned");
     return -1;
   }
+  // padded configurations (SqairHandle): parameters are read from the padded copy inside the packed buffer, the gradient is
+  // accumulated in the padded shapes and gathered into the caller's buffer at the end
+  float* const user_grad = flat_grad;
+  flat = sq_flat(h, flat, packedv);
+  if (h->padded) flat_grad = b.grad_padded;
   sq_zero_fill(flat_grad, h->n_params, s);
   sq_zero_fill((float*)scratch, b.zero_total, s);
 #ifdef SQAIR_KNOBS
@@ -334,7 +346,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
   const bool fuse_t3 = !SQ_KNOB_SET("SQAIR_NO_T3_FUSION");
   // ================= reverse sweep over the frames =================
   for (int t = T - 1; t >= 0; --t) {
-    const float* img = obs + (size_t)t * B * P_;
+    const float* img = obs + (size_t)t * B * PL;
     const float* nz = noise + (size_t)t * R * 2 * N * nzw;
     const float* rec_prev = w.rec_m_all + (size_t)t * M * RW;
     const float* rec_p_t = w.rec_p_all + (size_t)t * M * RW;
@@ -681,7 +693,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     { Dx x(b.d_ib, nh); x.to(0, nh, b.d_ia, nh).dact(w.ienc_a, nh, ACT_ELU); CK(rundx(L_IENC1, x, TB)); }
     wgrad(L_PREDISC, {{w.ienc_b, nh}}, b.d_pre_disc, rw, TB);
     wgrad(L_IENC1, {{w.ienc_a, nh}}, b.d_ib, nh, TB);
-    wgrad(L_IENC0, {{obs, P_}}, b.d_ia, nh, TB);
+    wgrad(L_IENC0, {{obs, PL}}, b.d_ia, nh, TB);
   }
   // ================= batched weight gradients =================
   {
@@ -749,6 +761,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     sq_launch_where_param_grads(b.d_tp, TP_LD, b.d_rec_p, w.rec_p_all, noise, T, d, flat_grad, po, s);
   }
   wbatch.flush(s);
+  if (h->padded) sq_flat_gather(h, flat_grad, user_grad, packedv, s);
   SQ_CHECK_HIP(hipGetLastError());
   return 0;
 }

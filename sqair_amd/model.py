@@ -42,11 +42,8 @@ def make_config(F, img_hw):
             "(configs/mlp_mnist_model.py:86-87,125 pick Sonnet cells by name); got {}/{}/{}".format(
                 F.transition, F.time_transition, F.prior_transition))
     p = get_params(F)
-    if (int(img_hw[0]) * int(img_hw[1])) % 4 != 0:
-        raise NotImplementedError("HIP path needs H * W to be a multiple of 4 (flattened frames are float4 GEMM operands); "
-                                  "got {}x{}".format(img_hw[0], img_hw[1]))
-    if p.n_hidden not in (128, 256):
-        raise NotImplementedError("HIP path supports n_units 4 or 8 (n_hidden 128 / 256); got n_units={}".format(F.n_units))
+    if int(F.n_units) < 1:
+        raise ValueError("n_units must be >= 1; got {}".format(F.n_units))
     sp = parse_string_flag(F.scale_prior, num_elements=2)
     std = float(np.float32(np.float32(np.sqrt(F.output_std)) ** np.float32(2.0)))  # modules.py:419-422
     return _capi.SqairConfig(

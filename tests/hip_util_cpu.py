@@ -18,3 +18,10 @@ def fixture_params(z, F, hw):
     got = hashlib.sha256(flatten_params(P, param_spec(F, hw)).tobytes()).hexdigest()
     assert got == str(z["params_sha256"]), "fixture parameters changed: sha256 {} != stored {}".format(got, z["params_sha256"])
     return P
+
+
+def draw_noise(rng, T, R, N, nzw):
+    """eps ~ N(0, 1) for the Normals, u ~ U[0, 1) in the last entry of every slot: the noise tensor of one pass [T, R, 2, N, nzw]."""
+    nz = rng.standard_normal((T, R, 2, N, nzw)).astype(np.float32)
+    nz[..., -1] = rng.uniform(size=nz.shape[:-1]).astype(np.float32)
+    return nz

@@ -92,12 +92,13 @@ def test_create_rejects_bad_config():
     h = C.c_void_p()
     assert lib.sqair_create(C.byref(cfg), C.byref(h)) != 0
     cfg = make_config(F, (50, 50))
-    cfg.n_hidden = 64          # n_units = 2: the row kernels are written for n_hidden 128 / 256
+    cfg.n_hidden = 72          # not 32 * n_units: n_hidden // 2 must be a whole number of 16-column tiles' worth of units
     assert lib.sqair_create(C.byref(cfg), C.byref(h)) != 0
-    with pytest.raises(NotImplementedError):
-        make_config(make_flags(n_units=2), (50, 50))
-    with pytest.raises(NotImplementedError):
-        make_config(F, (37, 41))   # H * W must be a multiple of 4
+    with pytest.raises(ValueError):
+        make_config(make_flags(n_units=0), (50, 50))
+    cfg = make_config(F, (37, 41))   # any frame size (H * W not a multiple of 4 goes through a padded copy)
+    assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
+    lib.sqair_destroy(h)
 
 
 def test_flag_errors_mirror_reference():

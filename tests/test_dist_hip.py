@@ -200,3 +200,38 @@ def test_bench_launches_its_own_ranks():
         assert line["rccl_ranks"] == 2 and line["train"]["rccl_ranks"] == 2 and line["train"]["allreduce_on_launch_stream"] is True
     else:
         assert line["dist_backend"] == "gloo" and line["rccl_ranks"] == 0 and line["train"]["allreduce_on_launch_stream"] is False
+
+
+def test_bench_eight_ranks_functional_check_on_one_node():
+    """The driver's 8-GPU command line, runnable on whatever the box has: `bench.py --gpus 8` launching its own eight ranks.  On a
+    1-GPU box the ranks share the device and the process group is gloo (RCCL refuses two ranks on one device) -- a FUNCTIONAL
+    check of everything around the collective that world size 2 cannot reach: rank-indexed data seeding and Philox offsets for
+    ranks 2..7, eight rendezvous clients on one port, the barrier order of the extra legs (training, expected-step, one GPU at the
+    global batch), eight contexts' worth of memory.  No scaling number is taken from it."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # (cfg-2's model at 3 sequences per rank: cfg-1 has K = 1, whose VIMCO target is NaN by the reference's own formula)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--cfg", "2", "--batch", "3", "--steps", "2", "--warmup", "1",
+           "--train-steps", "2", "--no-cpu-baseline", "--no-timeline"]
+    if torch.cuda.device_count() < 8:
+        cmd += ["--dist-backend", "gloo"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["parallelism"] == "dp8" and line["scaling"] == "weak"
+    B = line["config"]["global_batch"] // 8
+    assert line["config"]["global_batch"] == 8 * B and B >= 1
+    assert np.isfinite(line["value"]) and line["value"] > 0 and np.isfinite(line["elbo_iwae_nats_per_seq"])
+    tr = line["train"]
+    assert np.isfinite(tr["value"]) and tr["value"] > 0 and "finite=True" in tr["what"]
+    assert tr["allreduce_ms"] > 0 and tr["single_rank_ms_per_step_no_collective"] > 0
+    assert abs(tr["expected_ms"] - (tr["single_rank_ms_per_step_no_collective"] + tr["allreduce_ms"])) < 1e-9
+    assert tr["measured_over_expected"] > 0
+    sg = line["single_gpu_at_global_batch"]
+    assert sg["sequences"] == 8 * B and sg["forward_value"] > 0 and sg["train_value"] > 0
+    assert line["forward_all_outputs_ms"] > 0
+    if torch.cuda.device_count() >= 8:
+        assert line["rccl_ranks"] == 8 and tr["allreduce_on_launch_stream"] is True
+    else:
+        assert line["dist_backend"] == "gloo" and line["rccl_ranks"] == 0 and tr["allreduce_on_launch_stream"] is False

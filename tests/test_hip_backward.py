@@ -472,10 +472,14 @@ def test_scratch_the_backward_pass_does_not_clear_is_written_in_full(flags, monk
 
 
 @pytest.mark.parametrize("flags", [dict(n_units=4), dict(n_what=20), dict(n_what=7), dict(glimpse_size=12), dict(glimpse_size=28),
-                                   dict(n_units=4, n_what=7, glimpse_size=12)])
+                                   dict(n_units=4, n_what=7, glimpse_size=12), dict(n_units=2), dict(n_units=3), dict(n_units=6),
+                                   dict(n_units=7, transition="LSTM", time_transition="LSTM", prior_transition="LSTM"),
+                                   dict(n_units=2, transition="GRU")])
 def test_model_size_flags_forward_and_backward(flags):
     """n_units (n_hidden = 32 * n_units; the reference's own --test_run uses n_units = 4, scripts/experiment.py:95), n_what and
-    glimpse_size other than the shipped 8 / 50 / 20: all outputs feeding the objective and every gradient against the oracle."""
+    glimpse_size other than the shipped 8 / 50 / 20: all outputs feeding the objective and every gradient against the oracle.
+    n_hidden values that are not a multiple of 128 run on layers padded with inert units (csrc/sqair_internal.h: SqairHandle); the
+    parameters, their gradients and the final recurrent states cross the ABI in the reference's own shapes."""
     report, ref, core = _full_backward_case(K=3, N=3, T=3, B=3, hw=(50, 50), seed=11, flags=flags)
     assert float(ref.prop_pres.detach().sum()) > 0
     lw = core.out["log_weights_per_timestep"].cpu().numpy()
@@ -496,10 +500,12 @@ def test_scalar_hyper_parameter_flags_reach_the_kernels():
     _check_report(report)
 
 
-@pytest.mark.parametrize("K,N,T,B,hw", [(2, 6, 2, 2, (50, 50)), (2, 3, 2, 2, (128, 128)), (4, 2, 3, 5, (40, 56)), (3, 3, 2, 3, (37, 44))])
+@pytest.mark.parametrize("K,N,T,B,hw", [(2, 6, 2, 2, (50, 50)), (2, 3, 2, 2, (128, 128)), (4, 2, 3, 5, (40, 56)), (3, 3, 2, 3, (37, 44)),
+                                        (2, 3, 2, 3, (51, 49)), (2, 2, 2, 2, (37, 41)), (128, 2, 2, 1, (50, 50)), (70, 3, 2, 2, (40, 40))])
 def test_full_backward_other_shapes(K, N, T, B, hw):
     """N = 6 slots (BASELINE configs[3]), 128x128 frames (configs[4]: the frame no longer fits the default LDS window),
-    a non-square frame with B*K not a multiple of the 16-row MFMA tile."""
+    a non-square frame with B*K not a multiple of the 16-row MFMA tile, frames whose H * W is not a multiple of 4 (they
+    pass through a zero-padded copy), more particles than a wavefront has lanes (K = 70, 128: the generic ELBO kernel)."""
     report, _, _ = _full_backward_case(K, N, T, B, hw, seed=21)
     _check_report(report)
 

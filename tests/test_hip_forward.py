@@ -211,7 +211,9 @@ def test_cfg2_full_size_properties():
     stable = (presence_margins(ref.outputs, nz_sub) >= MARGIN)
     agree = (m3.presence.cpu().numpy() == ref.presence.numpy()).all((0, 2))
     print("cfg-2 sub-batch: {} of {} rows decision-stable, {} rows agree".format(int(stable.sum()), stable.size, int(agree.sum())))
-    assert stable.mean() > 0.8
+    # (MARGIN 1e-4 and ~80 live Bernoullis per row: ~1-2 % of the rows are expected inside the margin; more than 5 % would mean
+    #  the probabilities themselves have moved)
+    assert stable.mean() > 0.95
     assert agree[stable].all()
     a, b = m3.log_weights.cpu().numpy().reshape(-1)[stable], ref.log_weights.numpy().reshape(-1)[stable]
     assert np.abs(a - b).max() <= REL * np.abs(b).max()
@@ -379,7 +381,7 @@ def test_cfg2_full_batch_against_the_fp32_oracle():
     stable = presence_margins(ref.outputs, noise) >= MARGIN
     agree = (m.presence.cpu().numpy() == ref.presence.numpy()).all((0, 2))
     print("cfg-2 full batch: {} of {} rows decision-stable, {} agree".format(int(stable.sum()), stable.size, int(agree.sum())))
-    assert stable.mean() > 0.8 and agree[stable].all()
+    assert stable.mean() > 0.95 and agree[stable].all()
     a = m.log_weights.cpu().numpy().astype(np.float64).reshape(-1)[stable]
     b = ref.log_weights.numpy().astype(np.float64).reshape(-1)[stable]
     # fp32 oracle vs fp32 kernels: both carry ~1e-6 of rounding through a 10-frame recurrence
@@ -463,3 +465,17 @@ def test_debug_mode_raises_on_non_finite_log_weights():
     mb = Model(obs_bad, None, core, K, presence=d["nums"], debug=True)
     with pytest.raises(RuntimeError, match="non-finite values in log_weights"):
         mb.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))
+
+
+@pytest.mark.parametrize("n_units,cells", [(2, ("GRU", "GRU")), (5, ("LSTM", "LSTM")), (6, ("GRU", "LSTM"))])
+def test_forward_padded_hidden_width_final_states_in_reference_shapes(n_units, cells):
+    """n_hidden = 64 / 160 / 192 run on 128- / 256-wide layers with inert padding units; all 38 outputs against the oracle and
+    the final recurrent states come back in the caller's widths ([hidden | cell] halves of n_hidden each)."""
+    F = make_flags(k_particles=2, n_steps_per_image=3, n_units=n_units, time_transition=cells[0], prior_transition=cells[1])
+    m, ref = _live_oracle_case(F, T=3, B=3)
+    assert float(ref.prop_pres.sum()) > 0
+    nh = 32 * n_units
+    for name, mult in (("final_temporal_state", 2 if cells[0] == "LSTM" else 1), ("final_prior_state", 2 if cells[1] == "LSTM" else 1)):
+        got, want = m.outputs[name].cpu().numpy(), ref.outputs["_" + name].numpy()
+        assert got.shape == want.shape and got.shape[-1] == mult * nh
+        assert np.abs(got - want).max() < 5e-4 * max(1.0, np.abs(want).max())
