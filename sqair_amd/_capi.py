@@ -120,9 +120,23 @@ _PROTOS = {
 EXPORTED_SYMBOLS = [n for n in _PROTOS if not n.startswith("sqair_debug")]
 
 TIMELINE_LIB_PATH = os.path.join(_HERE, "libsqair_hip_timeline.so")
+# the same sources compiled with -DSQAIR_WIDE: the rest of the reference's flag range (n_what up to 128, up to 16 object slots,
+# n_units up to 16) on a larger slot record and plain-loop per-row kernels; same C-ABI, slower
+WIDE_LIB_PATH = os.path.join(_HERE, "libsqair_hip_wide.so")
+# what the product library is laid out for (csrc/sqair_glue.h: SQ_MAXN, SQ_MAX_NWHAT, SQ_MAX_NHIDDEN)
+PRODUCT_LIMITS = dict(n_what=50, n_steps_per_image=8, n_hidden=256)
+WIDE_LIMITS = dict(n_what=128, n_steps_per_image=16, n_hidden=512)
+
+
+def lib_path_for(n_what, n_steps_per_image, n_hidden):
+    """The library a configuration runs on: the product library inside its limits, the wide build beyond them."""
+    inside = (n_what <= PRODUCT_LIMITS["n_what"] and n_steps_per_image <= PRODUCT_LIMITS["n_steps_per_image"] and
+              n_hidden <= PRODUCT_LIMITS["n_hidden"])
+    return LIB_PATH if inside else WIDE_LIB_PATH
 
 ABI_VERSION = 2
-_VARIANT_OF = {"libsqair_hip.so": "product", "libsqair_hip_timeline.so": "timeline", "libsqair_hip_knobs.so": "knobs"}
+_VARIANT_OF = {"libsqair_hip.so": "product", "libsqair_hip_timeline.so": "timeline", "libsqair_hip_knobs.so": "knobs",
+               "libsqair_hip_wide.so": "wide"}
 
 _libs = {}
 

@@ -1,10 +1,13 @@
 """Builds libsqair_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
 
-Variants of the SAME sources (python sqair_amd/csrc/build.py [--force] [--timeline] [--knobs]):
+Variants of the SAME sources (python sqair_amd/csrc/build.py [--force] [--timeline] [--knobs] [--wide]):
   libsqair_hip.so            the product: no environment knobs, no timing code in any kernel
   libsqair_hip_timeline.so   -DSQAIR_TIMELINE: every wave stamps its start / end on the device wall clock (sqair_common.h);
                              what bench.py's roofline and tools/timeline.py measure the per-dispatch timeline with
   tools/bin/libsqair_hip_knobs.so  -DSQAIR_KNOBS: the measurement knobs of tools/ (tile shapes, fusion switches, dumps)
+  libsqair_hip_wide.so       -DSQAIR_WIDE: the same C-ABI for the rest of the reference's flag range (n_what up to 128, up to 16
+                             object slots, n_units up to 16): a larger slot record and plain-loop variants of the per-row kernels;
+                             sqair_amd picks it from the flags when the product library's limits are exceeded
 
 Every binary carries the hash of the sources it was compiled from (`-DSQAIR_BUILD_ID`, exported as `sqair_build_id()`, also
 greppable in the file as `SQAIR_BUILD_ID=<16 hex>;`) and its variant (`sqair_build_flags()`).  A binary is rebuilt when that id
@@ -23,7 +26,9 @@ SOURCES = ["sqair_api.hip", "sqair_linear.hip", "sqair_glue.hip", "sqair_bwd.hip
 OUT = os.path.join(os.path.dirname(HERE), "libsqair_hip.so")
 OUT_TIMELINE = os.path.join(os.path.dirname(HERE), "libsqair_hip_timeline.so")
 OUT_KNOBS = os.path.join(ROOT, "tools", "bin", "libsqair_hip_knobs.so")
-VARIANTS = {"product": (OUT, []), "timeline": (OUT_TIMELINE, ["-DSQAIR_TIMELINE"]), "knobs": (OUT_KNOBS, ["-DSQAIR_KNOBS"])}
+OUT_WIDE = os.path.join(os.path.dirname(HERE), "libsqair_hip_wide.so")
+VARIANTS = {"product": (OUT, []), "timeline": (OUT_TIMELINE, ["-DSQAIR_TIMELINE"]), "knobs": (OUT_KNOBS, ["-DSQAIR_KNOBS"]),
+            "wide": (OUT_WIDE, ["-DSQAIR_WIDE"])}
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
                "-mllvm", "-amdgpu-kernarg-preload-count=16", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 _ID_MARK = re.compile(rb"SQAIR_BUILD_ID=([0-9a-f]{16});")

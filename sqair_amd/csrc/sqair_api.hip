@@ -587,7 +587,13 @@ extern "C" int sqair_create(const SqairConfig* cfg, SqairHandle** out) {
   SqairHandle* h = new SqairHandle();
   h->ucfg = *cfg;
   h->cfg = *cfg;
-  h->cfg.n_hidden = (cfg->n_hidden + 127) / 128 * 128;
+  // (128, 256 or 512: the slot-tail adjoint indexes its LDS copy of steps.l0 with shifts -- n_hidden / 2 a power of two)
+  h->cfg.n_hidden = cfg->n_hidden <= 128 ? 128 : (cfg->n_hidden <= 256 ? 256 : 512);
+  {  // the log-probability adjoint stages a row's 2N records, their gradients and the prior statistics in LDS (k_logprob_bwd)
+    const int64_t N = cfg->n_steps_per_image;
+    const int64_t lds = (4 * N * rec::W + 2 * N * rec::ZW + 2 * N * PS_LD + 2 * (800 + 13 * (N + 1))) * 4;
+    if (lds > 150 * 1024) { delete h; return -1; }   // (only the wide build can get here: n_steps_per_image 15, 16 with its 416-float record)
+  }
   build_inventory(h);
   // GRU candidate matrices are bare [nh, nh] parameters: give build_plan's simple() a ".w" alias
   if (cfg->prior_cell == CELL_GRU) h->pidx["prop.prior_gru.uh.w"] = h->pidx["prop.prior_gru.uh"];
@@ -1811,8 +1817,8 @@ extern "C" int sqair_backward_decoder(SqairHandle* h, const float* flat, const v
     sq_set_error(h, "sqair_backward_decoder: workspace / scratch too small");
     return -1;
   }
-  if (h->padded) {
-    sq_set_error(h, "sqair_backward_decoder (a partial adjoint kept for unit tests) writes in the kernels' own shapes: use sqair_backward for an n_hidden that is not a multiple of 128");
+  if (h->padded || rec::ZWP != 64) {
+    sq_set_error(h, "sqair_backward_decoder (a partial adjoint kept for unit tests) writes in the product build's own shapes: use sqair_backward in the wide build or with an n_hidden that is padded");
     return -1;
   }
   hipStream_t s = (hipStream_t)stream;

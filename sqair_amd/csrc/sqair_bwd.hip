@@ -979,11 +979,11 @@ __global__ __launch_bounds__(256) void k_logprob_bwd(const LogprobBwdArgs a, con
     float* dr = drd_s + j * RW;
     const float pres = rd[rec::PRES];
     const float cq = -gw * pres, cp = gw * pres;
-    if (lane < nw) {
-      const float x = rd[rec::WHAT + lane], loc = rd[rec::WHAT_LOC + lane], sc = rd[rec::WHAT_SCALE + lane];
-      atomicAdd(&dr[rec::WHAT + lane], cq * dnormal_dx(x, loc, sc) + cp * (-x));
-      atomicAdd(&dr[rec::WHAT_LOC + lane], -cq * dnormal_dx(x, loc, sc));
-      atomicAdd(&dr[rec::WHAT_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
+    SQ_WHAT_LANES(wc, lane, nw) {
+      const float x = rd[rec::WHAT + wc], loc = rd[rec::WHAT_LOC + wc], sc = rd[rec::WHAT_SCALE + wc];
+      atomicAdd(&dr[rec::WHAT + wc], cq * dnormal_dx(x, loc, sc) + cp * (-x));
+      atomicAdd(&dr[rec::WHAT_LOC + wc], -cq * dnormal_dx(x, loc, sc));
+      atomicAdd(&dr[rec::WHAT_SCALE + wc], cq * dnormal_dsc(x, loc, sc));
     }
   }
   // ---------------- wave 1: number of steps
@@ -1012,8 +1012,9 @@ __global__ __launch_bounds__(256) void k_logprob_bwd(const LogprobBwdArgs a, con
       lg = sq_elu(v);
     }
     float mx = lg;
+    constexpr int CLS = SQ_MAXN + 1 <= 16 ? 16 : 32;   // classes sit on lanes 0 .. N
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));   // classes sit on lanes 0 .. N <= 8
+    for (int o = 1; o < CLS; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     const float ex = lane < N1 ? expf(lg - mx) : 0.0f;
     const float se = sq_wave_sum(ex);
     if (lane < N1) {
@@ -1049,24 +1050,24 @@ __global__ __launch_bounds__(256) void k_logprob_bwd(const LogprobBwdArgs a, con
     const float pres = rp[rec::PRES], pres_tm1 = rm[rec::PRES];
     const float m = pres_tm1 * pres;
     const float cq = -gw * m, cp = gw * m;
-    if (lane < nw) {
-      const float x = rp[rec::WHAT + lane];
-      const float loc = rp[rec::WHAT_LOC + lane], sc = rp[rec::WHAT_SCALE + lane];
-      float ploc = ps[5 + lane];
-      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHAT + lane];
-      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHAT + lane] + 0.1f * ploc;
-      const float praw = ps[9 + nw + lane];
+    SQ_WHAT_LANES(wc, lane, nw) {
+      const float x = rp[rec::WHAT + wc];
+      const float loc = rp[rec::WHAT_LOC + wc], sc = rp[rec::WHAT_SCALE + wc];
+      float ploc = ps[5 + wc];
+      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHAT + wc];
+      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHAT + wc] + 0.1f * ploc;
+      const float praw = ps[9 + nw + wc];
       const float psc = sq_softplus(praw) + 1e-2f;
-      atomicAdd(&drp[rec::WHAT + lane], cq * dnormal_dx(x, loc, sc) + cp * dnormal_dx(x, ploc, psc));
-      atomicAdd(&drp[rec::WHAT_LOC + lane], -cq * dnormal_dx(x, loc, sc));
-      atomicAdd(&drp[rec::WHAT_SCALE + lane], cq * dnormal_dsc(x, loc, sc));
+      atomicAdd(&drp[rec::WHAT + wc], cq * dnormal_dx(x, loc, sc) + cp * dnormal_dx(x, ploc, psc));
+      atomicAdd(&drp[rec::WHAT_LOC + wc], -cq * dnormal_dx(x, loc, sc));
+      atomicAdd(&drp[rec::WHAT_SCALE + wc], cq * dnormal_dsc(x, loc, sc));
       const float g_ploc = -cp * dnormal_dx(x, ploc, psc);
-      if (a.cfg.prop_prior_type == 0) dps[5 + lane] = g_ploc;
+      if (a.cfg.prop_prior_type == 0) dps[5 + wc] = g_ploc;
       else {
-        atomicAdd(&drm[rec::WHAT + lane], g_ploc);
-        if (a.cfg.prop_prior_type == 2) dps[5 + lane] = 0.1f * g_ploc;
+        atomicAdd(&drm[rec::WHAT + wc], g_ploc);
+        if (a.cfg.prop_prior_type == 2) dps[5 + wc] = 0.1f * g_ploc;
       }
-      dps[9 + nw + lane] = cp * dnormal_dsc(x, ploc, psc) * sq_sigmoid(praw);
+      dps[9 + nw + wc] = cp * dnormal_dsc(x, ploc, psc) * sq_sigmoid(praw);
     }
   }
   // ---------------- wave 2: p where and the MultivariateNormalTriL posterior of where
@@ -1203,6 +1204,8 @@ int sq_launch_logprob_bwd(const LogprobBwdArgs& a, POff po, Dims d, int T, hipSt
   if (o > SQ_SMALL_MAX) return -1;
   tab.total = o;
   const size_t shm = (4 * (size_t)d.N * rec::W + 2 * (size_t)d.N * rec::ZW + 2 * (size_t)d.N * a.ps_ld + 2 * (size_t)o) * sizeof(float);
+  if (shm > 150 * 1024) return -1;   // (sqair_create has checked this configuration against sq_logprob_bwd_lds_bytes)
+  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_logprob_bwd, 150 * 1024) != 0) return -2;
   SQ_LAUNCH(k_logprob_bwd, dim3(d.R, T), dim3(256), shm, s, a, cp, tab, d);
   return 0;
 }
@@ -1263,6 +1266,37 @@ __global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, con
   // parameter words from every row serialise in L2) -- and every one of their loads is requested before the first store, so
   // the kernel is two memory round trips (the permutation, then everything) and the write.  (Measured: 5.4 us either way --
   // the per-unit loops it replaces overlapped well enough; what is left is those two cold round trips themselves.)
+#ifdef SQAIR_WIDE
+  // (the wide build: the same three jobs as plain loops -- sources and destinations are different buffers)
+  const int r4 = RW / 4;
+  for (int e = tid; e < 2 * N * r4; e += 256) {
+    const int sl = e / r4, i = e - sl * r4;
+    const int dst = inv_s[sl];
+    if (dst >= 0) {
+      cf4* tg = reinterpret_cast<cf4*>(sl < N ? a.d_rec_p + ((size_t)r * N + sl) * RW : a.d_rec_d + ((size_t)r * N + (sl - N)) * RW) + i;
+      *tg = *tg + reinterpret_cast<const cf4*>(a.d_rec_next + ((size_t)r * N + dst) * RW)[i];
+    }
+  }
+  for (int st = 0; st < 2; ++st) {   // temporal state, prior state
+    const int w = st == 0 ? d.snh : d.psnh, w4 = w / 4;
+    const float* next = st == 0 ? a.d_temporal_next : a.d_prior_next;
+    float* outp = st == 0 ? a.d_temporal_p : a.d_prior_p;
+    for (int e = tid; e < N * w4; e += 256) {
+      const int sl = e / w4, i = e - sl * w4;
+      const int dst = inv_s[sl];
+      reinterpret_cast<cf4*>(outp + ((size_t)r * N + sl) * w)[i] = dst >= 0 ? reinterpret_cast<const cf4*>(next + ((size_t)r * N + dst) * w)[i] : zero4;
+    }
+    for (int i = tid; i < w4; i += 256) {
+      cf4 acc = zero4;
+      for (int j = 0; j < N; ++j) {
+        const int dst = inv_s[N + j];
+        if (dst >= 0) acc += reinterpret_cast<const cf4*>(next + ((size_t)r * N + dst) * w)[i];
+      }
+      reinterpret_cast<cf4*>((st == 0 ? a.d_new_temporal : a.d_new_prior) + (size_t)r * w)[i] = acc;
+    }
+  }
+}
+#else
   constexpr int Q1 = 3, Q2 = 4;   // units per thread: 2 N RW / 4 <= 3 x 256 records, N snh / 4 <= 4 x 256 state words (N <= 8, snh <= 512)
   const int r4 = RW / 4;
   cf4 g1[Q1], t1[Q1];
@@ -1331,6 +1365,7 @@ __global__ __launch_bounds__(256) void k_compact_bwd(const CompactBwdArgs a, con
     if (tid < w4) reinterpret_cast<cf4*>((st == 0 ? a.d_new_temporal : a.d_new_prior) + (size_t)r * w)[tid] = acc3[st];
   }
 }
+#endif
 int sq_launch_compact_bwd(const CompactBwdArgs& a, POff po, Dims d, hipStream_t s) {
   SQ_LAUNCH(k_compact_bwd, dim3(d.R), dim3(256), 0, s, a, po, d);
   return 0;
@@ -1344,7 +1379,7 @@ __global__ __launch_bounds__(256) void k_slot_tail_bwd(const TailBwdArgs a, cons
   SQ_TL_SCOPE;
   SQ_PIN8(a.is_disc, a.slot, a.rec_prev, a.rec_new, a.d_rec_new, a.d_rec_prev, a.s1h, a.s1h_ld);
   SQ_PIN8(a.hraw, a.h_ld, a.enc, a.enc_ld, a.noise, a.flat, a.w2_off, a.wwhat_off);
-  __shared__ float ds_s[128];
+  __shared__ float ds_s[SQ_MAX_NHIDDEN / 2];
   extern __shared__ float wt_s[];  // the `what` rows of steps.l0.w, [nw][nsp + 1] (padded: conflict-free row reads)
   const int r = blockIdx.x, tid = threadIdx.x, nw = d.nw, nsp = d.nh / 2, RW = rec::W;
   // the weight block: 16-byte loads, all of a thread's requests (7 for the 50 x 128 block of the shipped sizes) issued here and
@@ -1450,7 +1485,9 @@ __global__ __launch_bounds__(256) void k_slot_tail_bwd(const TailBwdArgs a, cons
   }
 }
 int sq_launch_slot_tail_bwd(const TailBwdArgs& a, Dims d, hipStream_t s) {
-  SQ_LAUNCH(k_slot_tail_bwd, dim3(d.R), dim3(256), (size_t)d.nw * (d.nh / 2 + 1) * sizeof(float), s, a, d);
+  const size_t shm = (size_t)d.nw * (d.nh / 2 + 1) * sizeof(float);
+  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_slot_tail_bwd, 150 * 1024) != 0) return -2;
+  SQ_LAUNCH(k_slot_tail_bwd, dim3(d.R), dim3(256), shm, s, a, d);
   return 0;
 }
 

@@ -23,11 +23,30 @@
 // concat order.
 // ---------------------------------------------------------------------------------------------
 namespace rec {
+#ifdef SQAIR_WIDE
+// the wide build's record (libsqair_hip_wide.so: n_what up to 128): same fields, same order, room for 128 `what` entries
+constexpr int NWMAX = 128;      // `what` entries the layout has room for
+constexpr int WHERE = 0;        // 4
+constexpr int WHAT = 4;         // n_what
+constexpr int PRES = 132;
+constexpr int LOGIT = 133;
+constexpr int ZW = 134;         // width of the z-record segment (K chunks of 16: ZWP = 144 floats are read)
+constexpr int ZWP = 144;
+constexpr int WHERE_LOC = 144;  // 4
+constexpr int WHERE_SCALE = 148; // 4
+constexpr int WHAT_LOC = 152;   // 128
+constexpr int WHAT_SCALE = 280; // 128
+constexpr int PROB = 408;
+constexpr int ID = 409;
+constexpr int W = 416;
+#else
+constexpr int NWMAX = 50;
 constexpr int WHERE = 0;        // 4
 constexpr int WHAT = 4;         // n_what (<= 50 in this layout)
 constexpr int PRES = 54;
 constexpr int LOGIT = 55;
 constexpr int ZW = 56;          // width of the z-record segment
+constexpr int ZWP = 64;         // ... padded to whole K chunks of 16
 constexpr int WHERE_LOC = 56;   // 4
 constexpr int WHERE_SCALE = 60; // 4
 constexpr int WHAT_LOC = 64;    // 50
@@ -35,6 +54,13 @@ constexpr int WHAT_SCALE = 114; // 50
 constexpr int PROB = 164;
 constexpr int ID = 165;
 constexpr int W = 168;
+#endif
+// lanes over the `what` entries of a record: one pass in the product build (n_what <= 50 < 64 lanes), a loop in the wide one
+#ifdef SQAIR_WIDE
+#define SQ_WHAT_LANES(c, lane, nw) for (int c = (lane); c < (nw); c += 64)
+#else
+#define SQ_WHAT_LANES(c, lane, nw) for (int c = (lane), sq_once_ = 1; sq_once_ != 0 && c < (nw); sq_once_ = 0)
+#endif
 }  // namespace rec
 
 enum Act { ACT_NONE = 0, ACT_ELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3, ACT_SOFTPLUS_MIN = 4 };

@@ -137,7 +137,11 @@ int sq_launch_logprob(const LogprobArgs& a, POff po, Dims d, hipStream_t s);
 //   [0:4] where ~ prior, [4:54] what ~ prior, [54] presence ~ Bernoulli(prior logit), [55] the posterior path's own
 //   propagation presence, [56] the posterior path's own discovery presence of step k
 namespace gen {
+#ifdef SQAIR_WIDE
+constexpr int WHERE = 0, WHAT = 4, PRES = 132, ORIG_PRES = 133, ORIG_DPRES = 134, W = 144;
+#else
 constexpr int WHERE = 0, WHAT = 4, PRES = 54, ORIG_PRES = 55, ORIG_DPRES = 56, W = 64;
+#endif
 }
 struct GenArgs {
   float* rec_p; float* rec_d; const float* rec_prev;   // records of this frame (overwritten when generating)

@@ -109,6 +109,95 @@ int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+#ifdef SQAIR_WIDE
+// The wide build's tail (n_what up to 128, n_hidden up to 512): the same arithmetic in the same order -- what sample, hidden
+// layer = s1p + what W_what on the matrix cores with the A operand from an LDS tile of the fresh sample, output dot, presence --
+// written as plain loops (operands fetched where they are used, no prefetch choreography): a slow path by design.
+constexpr int ZLD = rec::ZWP + 4;
+template <bool FULL_Z>
+__device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, const int row0, const bool STORE, float* zt, float (*rs)[16]) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
+  const int nw = d.nw, nsp = d.nh / 2;
+  const int n_tiles = nsp / 16;          // wave w owns tiles w, w + 4, ...
+  constexpr int ZCH = rec::ZWP / 16;     // K chunks of the z-record tile
+  const f32x4_t* wp4 = reinterpret_cast<const f32x4_t*>(a.wp);
+  const int pr = min(row0 + (tid & 15), d.R - 1);
+  const float b2 = a.flat[a.b2_off];
+  const float u = a.noise[(((size_t)pr * 2 + (a.is_disc ? 1 : 0)) * d.N + a.slot) * d.nzw + 4 + nw];
+  float prev = 1.0f;
+  if (!(a.is_disc && a.slot == 0))
+    prev = a.is_disc ? a.rec_new[((size_t)pr * d.N + a.slot - 1) * rec::W + rec::PRES] : a.rec_prev[((size_t)pr * d.N + a.slot) * rec::W + rec::PRES];
+  for (int i = tid; i < 16 * ZLD; i += 256) zt[i] = 0.0f;
+  __syncthreads();
+  for (int e = tid; e < 16 * nw; e += 256) {
+    const int rr = e / nw, c = e - rr * nw;
+    const int r = min(row0 + rr, d.R - 1);
+    float loc = a.enc[(size_t)r * a.enc_ld + c], sc = a.enc[(size_t)r * a.enc_ld + nw + c];
+    const float eps = a.noise[(((size_t)r * 2 + (a.is_disc ? 1 : 0)) * d.N + a.slot) * d.nzw + 4 + c];
+    if (!a.is_disc) {
+      const float* hr = a.hraw + (size_t)r * a.h_ld;
+      const float tm1 = a.rec_prev[((size_t)r * d.N + a.slot) * rec::W + rec::WHAT + c];
+      const float t_loc = hr[c];
+      const float t_scale = sq_softplus(hr[nw + c]) + 1e-2f;
+      const float fg = sq_sigmoid(hr[2 * nw + c]) * 0.9999f;
+      const float ig = sq_sigmoid(hr[3 * nw + c]) * 0.9999f;
+      const float tg = sq_sigmoid(hr[4 * nw + c]) * 0.9999f;
+      const float l2 = fg * tm1 + (1.0f - ig) * loc + (1.0f - tg) * t_loc;
+      sc = (1.0f - ig) * sc + (1.0f - tg) * t_scale;
+      loc = l2;
+    }
+    const float what = loc + sc * eps;
+    zt[rr * ZLD + rec::WHAT + c] = what;
+    if (STORE && row0 + rr < d.R) {
+      float* rn = a.rec_new + ((size_t)(row0 + rr) * d.N + a.slot) * rec::W;
+      rn[rec::WHAT + c] = what;
+      rn[rec::WHAT_LOC + c] = loc;
+      rn[rec::WHAT_SCALE + c] = sc;
+    }
+  }
+  __syncthreads();
+  float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int tile = wave; tile < n_tiles; tile += 4) {
+    const int col = tile * 16 + (lane & 15);
+    f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c = 0; c < ZCH; ++c) {
+      const f32x4_t av = *reinterpret_cast<const f32x4_t*>(&zt[(lane & 15) * ZLD + 16 * c + 4 * kq]);
+      const f32x4_t bv = wp4[(size_t)(tile * ZCH + c) * 64 + lane];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    const float w2v = a.flat[a.w2_off + col];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float hv = sq_elu(acc[i] + a.s1p[(size_t)min(row0 + 4 * kq + i, d.R - 1) * a.s1p_ld + col]);
+      part[i] += hv * w2v;
+      if (STORE && a.s1h_out != nullptr && row0 + 4 * kq + i < d.R) a.s1h_out[(size_t)(row0 + 4 * kq + i) * a.s1h_ld + col] = hv;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) part[i] = sq_row_sum(part[i]);
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rs[wave][4 * kq + i] = part[i];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const float raw = rs[0][tid] + rs[1][tid] + rs[2][tid] + rs[3][tid] + b2;
+    const float logit = prev * raw + (prev - 1.0f) * 88.0f;
+    const float prob = sq_sigmoid(logit);
+    const float pres = (u < prob ? 1.0f : 0.0f) * prev;
+    if (STORE && row0 + tid < d.R) {
+      float* rn = a.rec_new + ((size_t)(row0 + tid) * d.N + a.slot) * rec::W;
+      rn[rec::PRES] = pres;
+      rn[rec::LOGIT] = logit;
+      rn[rec::PROB] = prob;
+    }
+  }
+  (void)FULL_Z;
+}
+#else
 constexpr int ZLD = 68;
 // Body shared by k_slot_tail (one workgroup per 16 rows, results to memory) and k_rnn_tail (every workgroup of the NEXT slot's RNN
 // layer re-derives the tail of its 16 rows and keeps the z-record in LDS as the layer's first A segment).  FULL_Z: also place
@@ -258,6 +347,8 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
   }
 }
 
+#endif
+
 __global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
   __shared__ __attribute__((aligned(16))) float zt[16 * ZLD];
@@ -265,6 +356,7 @@ __global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims 
   tail_body<false>(a, d, blockIdx.x * 16, true, zt, rs);
 }
 
+#ifndef SQAIR_WIDE
 // ------------------------------------------------------------------------------------------------
 // Slot tail fused INTO the next slot's RNN layer (VanillaRNN slot cell, sqair/core.py:187-189, :304-305): the layer's first A
 // segment is the z-record of the slot that has just been finished, and the tail that completes it (what sample, steps-predictor
@@ -338,6 +430,8 @@ __global__ __launch_bounds__(256) void k_rnn_tail(const TailArgs ta, const Dims 
   }
 }
 
+#endif
+
 int sq_launch_slot_tail(const TailArgs& a, Dims d, hipStream_t s) {
   SQ_LAUNCH(k_slot_tail, dim3((d.R + 15) / 16), dim3(256), 0, s, a, d);
   return 0;
@@ -346,11 +440,16 @@ int sq_launch_slot_tail(const TailArgs& a, Dims d, hipStream_t s) {
 // the layer's packed weights (K chunks: 4 of the z-record, nh / 16 of the hidden state) and packed bias
 int sq_launch_rnn_tail(const TailArgs& ta, Dims d, const float* hid, int hid_ld, const float* wp, const float* bias, const float* add,
                        int add_ld, float* out, int out_ld, int n_out, hipStream_t s, unsigned long long* prof_ts) {
+#ifdef SQAIR_WIDE
+  (void)ta; (void)d; (void)hid; (void)hid_ld; (void)wp; (void)bias; (void)add; (void)add_ld; (void)out; (void)out_ld; (void)n_out; (void)s; (void)prof_ts;
+  return -1;   // (the wide build never fuses the tail: can_fuse_tail, sqair_api.hip)
+#else
   const dim3 g((n_out + 15) / 16, (d.R + 15) / 16);
   if (d.nh == 256) SQ_LAUNCH(k_rnn_tail<4>, g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
   else if (d.nh == 128) SQ_LAUNCH(k_rnn_tail<2>, g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
   else return -1;
   return 0;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,7 +526,11 @@ __global__ __launch_bounds__(64 * SQ_LOGPROB_WAVES) void k_logprob(const Logprob
     if (tid < 8) ro_s[32 + tid] = flat[po.rn_readout_b + tid];
   }
   if (tid < 10) { sp0_s[tid] = flat[po.sp_l0_w + tid]; sp0_s[10 + tid] = flat[po.sp_l0_b + tid]; ch_s[tid] = flat[po.cholesky + tid]; }
+#ifdef SQAIR_WIDE
+  for (int i = tid; i < 10 * (N + 1); i += NT) sp1_s[i] = flat[po.sp_l1_w + i];   // (up to 170 entries: more than the workgroup has threads)
+#else
   if (tid < 10 * (N + 1)) sp1_s[tid] = flat[po.sp_l1_w + tid];
+#endif
   if (tid <= N) {
     sp1_s[10 * (N + 1) + tid] = flat[po.sp_l1_b + tid];
     spb_s[tid] = flat[po.step_prior_bias + tid];
@@ -456,13 +559,13 @@ __global__ __launch_bounds__(64 * SQ_LOGPROB_WAVES) void k_logprob(const Logprob
     pl = pres_tm1 * pl + (pres_tm1 - 1.0f) * 88.0f;
     if (a.cfg.prop_prior_type != 0) pl = logit_tm1 + 0.1f * pl;
     float qw = 0.0f, pw = 0.0f;
-    if (lane < nw) {
-      const float x = rp[rec::WHAT + lane];
-      qw = sq_normal_lp(gr != nullptr ? gr[gen::WHAT + lane] : x, rp[rec::WHAT_LOC + lane], rp[rec::WHAT_SCALE + lane]);
-      float ploc = ps[5 + lane];
-      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHAT + lane];
-      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHAT + lane] + 0.1f * ploc;
-      pw = sq_normal_lp(x, ploc, sq_softplus(ps[9 + nw + lane]) + 1e-2f);
+    SQ_WHAT_LANES(wc, lane, nw) {
+      const float x = rp[rec::WHAT + wc];
+      qw += sq_normal_lp(gr != nullptr ? gr[gen::WHAT + wc] : x, rp[rec::WHAT_LOC + wc], rp[rec::WHAT_SCALE + wc]);
+      float ploc = ps[5 + wc];
+      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHAT + wc];
+      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHAT + wc] + 0.1f * ploc;
+      pw += sq_normal_lp(x, ploc, sq_softplus(ps[9 + nw + wc]) + 1e-2f);
     }
     const float q_what = sq_wave_sum(qw), p_what = sq_wave_sum(pw);
     float pwh = 0.0f;
@@ -526,10 +629,10 @@ __global__ __launch_bounds__(64 * SQ_LOGPROB_WAVES) void k_logprob(const Logprob
     const float* rd = recd_s + j * RW;
     const float pres = rd[rec::PRES];
     float qw = 0.0f, pw = 0.0f;
-    if (lane < nw) {
-      const float x = rd[rec::WHAT + lane];
-      qw = sq_normal_lp(x, rd[rec::WHAT_LOC + lane], rd[rec::WHAT_SCALE + lane]);
-      pw = sq_normal_lp(x, 0.0f, 1.0f);
+    SQ_WHAT_LANES(wc, lane, nw) {
+      const float x = rd[rec::WHAT + wc];
+      qw += sq_normal_lp(x, rd[rec::WHAT_LOC + wc], rd[rec::WHAT_SCALE + wc]);
+      pw += sq_normal_lp(x, 0.0f, 1.0f);
     }
     const float q_what = sq_wave_sum(qw), p_what = sq_wave_sum(pw);
     float qwh = 0.0f, pwh = 0.0f;
@@ -611,11 +714,12 @@ __global__ __launch_bounds__(64 * SQ_LOGPROB_WAVES) void k_logprob(const Logprob
     for (int i = 0; i < 10; ++i) v += sq_elu(e_sum * sp0_s[i] + sp0_s[10 + i]) * sp1_s[i * (N + 1) + c];
     const float lg = lane <= N ? sq_elu(v) : -1e30f;
     float mx = lg;
+    constexpr int CLS = SQ_MAXN + 1 <= 16 ? 16 : 32;   // N + 1 classes on lanes 0 .. CLS - 1
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));   // N + 1 <= 9 classes on lanes 0 .. 15
+    for (int o = 1; o < CLS; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     float se = lane <= N ? expf(lg - mx) : 0.0f;
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o, 64);
+    for (int o = 1; o < CLS; o <<= 1) se += __shfl_xor(se, o, 64);
     p_num = __shfl(lg, n, 64) - (mx + logf(se));
   }
   if (a.out.disc_prob && lane <= N) a.out.disc_prob[tr * (N + 1) + lane] = (float)(mine / tot);
@@ -637,6 +741,7 @@ __global__ __launch_bounds__(64 * SQ_LOGPROB_WAVES) void k_logprob(const Logprob
 int sq_launch_logprob(const LogprobArgs& a, POff po, Dims d, hipStream_t s) {
   const size_t shm = ((size_t)3 * d.N * rec::W + (size_t)d.N * a.ps_ld + 128 + 128 + 516 + 20 + 40 + 4 + 20 +
                       11 * (d.N + 1) + 2 * (d.N + 1) + 16) * sizeof(float);
+  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_logprob, 150 * 1024) != 0) return -2;
   SQ_LAUNCH(k_logprob, dim3(d.R, a.n_frames), dim3(64 * SQ_LOGPROB_WAVES), shm, s, a, po, d);
   return 0;
 }
@@ -663,13 +768,13 @@ __global__ __launch_bounds__(64) void k_generate_prop(const GenArgs a, const Dim
     const float* ps = a.pstats + rk * a.ps_ld;
     const float* gn = a.gen_noise + (((size_t)r * 2 + 0) * N + k) * d.nzw;
     float* g = a.gen + rk * gen::W;
-    if (lane < nw) {
-      float ploc = ps[5 + lane];
-      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHAT + lane];
-      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHAT + lane] + 0.1f * ploc;
-      const float v = ploc + (sq_softplus(ps[9 + nw + lane]) + 1e-2f) * gn[4 + lane];
-      g[gen::WHAT + lane] = v;
-      if (a.do_generate) rp[rec::WHAT + lane] = v;
+    SQ_WHAT_LANES(wc, lane, nw) {
+      float ploc = ps[5 + wc];
+      if (a.cfg.prop_prior_type == 1) ploc = rm[rec::WHAT + wc];
+      else if (a.cfg.prop_prior_type == 2) ploc = rm[rec::WHAT + wc] + 0.1f * ploc;
+      const float v = ploc + (sq_softplus(ps[9 + nw + wc]) + 1e-2f) * gn[4 + wc];
+      g[gen::WHAT + wc] = v;
+      if (a.do_generate) rp[rec::WHAT + wc] = v;
     }
     if (lane < 4) {
       float ploc = ps[1 + lane];
@@ -711,7 +816,7 @@ __global__ __launch_bounds__(64) void k_generate_disc(const GenArgs a, const POf
     float* rd = a.rec_d + rj * rec::W;
     const float* gn = a.gen_noise + (((size_t)r * 2 + 1) * N + j) * d.nzw;
     if (lane == 0) a.gen[rj * gen::W + gen::ORIG_DPRES] = rd[rec::PRES];
-    if (lane < nw) rd[rec::WHAT + lane] = gn[4 + lane];
+    SQ_WHAT_LANES(wc, lane, nw) rd[rec::WHAT + wc] = gn[4 + wc];
     float x[4];
     for (int c = 0; c < 4; ++c) {  // every lane computes the 4 components (tiny), lane 0 stores
       float loc, sc;
@@ -839,8 +944,9 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a, const POff
       if (dp[u] != nullptr) *dp[u] = v[u];
   }
   // the 9 hidden outputs + object id (seq.py:121-134)
-  for (int e = tid; e < N * 64; e += 256) {
-    const int dst = e >> 6, c = e & 63;
+  constexpr int CW = rec::NWMAX <= 64 ? 64 : 128;   // lanes per slot: enough for the `what` entries
+  for (int e = tid; e < N * CW; e += 256) {
+    const int dst = e / CW, c = e & (CW - 1);
     const int sidx = src_s[dst];
     const float* rs = sidx < N ? a.rec_p + ((size_t)r * N + sidx) * rec::W : a.rec_d + ((size_t)r * N + (sidx - N)) * rec::W;
     const size_t o = tr * N + dst;

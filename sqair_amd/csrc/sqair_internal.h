@@ -126,7 +126,14 @@ struct Lin {
 // uses of a layer as one long row range).
 // ------------------------------------------------------------------------------------------------
 constexpr int PROF_MAX = 4096;
+// leading dimensions of the activation buffers: room for the widest layer the build accepts (prior statistics 2 (4 + n_what) + 1,
+// glimpse-encoder Gaussian 2 n_what, loc1 n_what, raw heads 5 n_what, transform hidden | steps hidden 1.5 n_hidden, steps hidden
+// n_hidden / 2), each a multiple of 16
+#ifdef SQAIR_WIDE
+constexpr int PS_LD = 272, ENC_LD = 256, M1_LD = 128, HRAW_LD = 640, WB_LD = 4, TP_LD = 8, T1_LD = 768, S1_LD = 256;
+#else
 constexpr int PS_LD = 112, ENC_LD = 112, M1_LD = 64, HRAW_LD = 256, WB_LD = 4, TP_LD = 8, T1_LD = 384, S1_LD = 128;
+#endif
 
 struct Workspace {
   bool train;

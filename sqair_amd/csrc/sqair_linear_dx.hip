@@ -159,9 +159,16 @@ int sq_launch_linear_dx(const DxArgs& a, int kc, int nt, hipStream_t s) {
   if (g.x == 0 || g.y == 0) return 0;
   const int per_wave = (kc + 3) / 4;
   if (a.gru.mode != 0) {  // GRU gate adjoints in the epilogue: one range [0, nh), K = nh or the what-head width (<= 16 chunks)
-    if (a.nranges != 1 || a.r[0].n0 != 0 || a.r[0].n1 != a.gru.nh || per_wave > 4 || a.r[0].saved != nullptr) return -6;
-#define SQ_DXG(G) SQ_LAUNCH((k_linear_dx<4, G>), g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a)
-    if (a.gru.mode == 1) SQ_DXG(1); else SQ_DXG(2);
+    if (a.nranges != 1 || a.r[0].n0 != 0 || a.r[0].n1 != a.gru.nh || a.r[0].saved != nullptr) return -6;
+#define SQ_DXG(NCH, G) SQ_LAUNCH((k_linear_dx<NCH, G>), g, dim3(256), 0, s, a.dpre, a.wp, a.ld, a.width, a.M, kc, a.wzero, a)
+#ifdef SQAIR_WIDE
+    // (the wide build: K up to 5 x 128 head columns / 512 hidden units -- deeper instantiations of the same kernel)
+    if (per_wave > 8) { if (a.gru.mode == 1) SQ_DXG(18, 1); else SQ_DXG(18, 2); return 0; }
+    if (per_wave > 4) { if (a.gru.mode == 1) SQ_DXG(8, 1); else SQ_DXG(8, 2); return 0; }
+#else
+    if (per_wave > 4) return -6;
+#endif
+    if (a.gru.mode == 1) SQ_DXG(4, 1); else SQ_DXG(4, 2);
 #undef SQ_DXG
     return 0;
   }

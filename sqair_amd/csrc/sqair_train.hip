@@ -68,8 +68,8 @@ __global__ void k_shift_inputs(const ShiftArgs a SQ_TLP) {
   }
   const ShiftPhase p = a.p[blockIdx.y];
   const int k = row % a.N;
-  for (int i = threadIdx.x; i < 64; i += blockDim.x)
-    p.zs[(size_t)row * 64 + i] = i < rec::ZW ? (k > 0 ? p.rec_all[(size_t)(row - 1) * rec::W + i] : p.init_rec[i]) : 0.0f;
+  for (int i = threadIdx.x; i < rec::ZWP; i += blockDim.x)
+    p.zs[(size_t)row * rec::ZWP + i] = i < rec::ZW ? (k > 0 ? p.rec_all[(size_t)(row - 1) * rec::W + i] : p.init_rec[i]) : 0.0f;
   for (int i = threadIdx.x; i < nh; i += blockDim.x) {
     const float v = k > 0 ? p.r_tape[(size_t)(row - 1) * nh + i] : p.rnn_init[i];
     p.rs[(size_t)row * nh + i] = v;
@@ -188,7 +188,7 @@ static BwdSpace carve_bwd(const SqairHandle* h, int T, int B, float* base) {
   T_(b.d_gl, MT * G2, true); T_(b.d_mean_rows, T * R * P_, true); T_(b.bufa, big, true); T_(b.bufb, big, true);
   T_(b.d_ia, (int64_t)T * B * nh); T_(b.d_ib, (int64_t)T * B * nh);
   T_(b.bufc, MT * nh, true);
-  for (int i = 0; i < 2; ++i) { T_(b.zs[i], MT * 64, true); T_(b.rs[i], MT * nh, true); }
+  for (int i = 0; i < 2; ++i) { T_(b.zs[i], MT * rec::ZWP, true); T_(b.rs[i], MT * nh, true); }
   for (int i = 0; i < 4; ++i) T_(b.rh[i], MT * nh, true);
   if (pass == 0) b.zero_total = o;
   }
@@ -435,11 +435,11 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       if (j > 0) {
         Dx x(d_rnn, drl);
         x.to(0, rec::ZW, d_rec_d_t + (size_t)(j - 1) * RW, N * RW).acc();
-        x.to(64, 64 + nh, b.d_r[(j - 1) & 1], nh);
+        x.to(rec::ZWP, rec::ZWP + nh, b.d_r[(j - 1) & 1], nh);
         if (c.rnn_cell == RNN_GRU) x.acc();   // the gate adjoints above already put their direct part there
         CK(rundx(L_DISC_RNN, x, R));
       } else {
-        Dx x(d_rnn, drl); x.to(64, 64 + nh, b.d_init_d + (size_t)t * R * nh, nh);   // d (initial hidden state): column sum after the sweep
+        Dx x(d_rnn, drl); x.to(rec::ZWP, rec::ZWP + nh, b.d_init_d + (size_t)t * R * nh, nh);   // d (initial hidden state): column sum after the sweep
         if (c.rnn_cell == RNN_GRU) x.acc();
         CK(rundx(L_DISC_RNN, x, R));
         if (c.rnn_cell == RNN_LSTM) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.disc_rnn_init + nh, 1, s);
@@ -577,11 +577,11 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       if (k > 0) {
         Dx x(d_rnn, drl);
         x.to(0, rec::ZW, d_rec_p_t + (size_t)(k - 1) * RW, N * RW).acc();
-        x.to(64, 64 + nh, b.d_r[(k - 1) & 1], nh);
+        x.to(rec::ZWP, rec::ZWP + nh, b.d_r[(k - 1) & 1], nh);
         if (c.rnn_cell == RNN_GRU) x.acc();
         CK(rundx(L_PROP_RNN, x, R));
       } else {
-        Dx x(d_rnn, drl); x.to(64, 64 + nh, b.d_init_p + (size_t)t * R * nh, nh);
+        Dx x(d_rnn, drl); x.to(rec::ZWP, rec::ZWP + nh, b.d_init_p + (size_t)t * R * nh, nh);
         if (c.rnn_cell == RNN_GRU) x.acc();
         CK(rundx(L_PROP_RNN, x, R));
         if (c.rnn_cell == RNN_LSTM) sq_launch_colsum(b.d_cs[1], nh, R, nh, flat_grad + po.prop_rnn_init + nh, 1, s);
@@ -595,7 +595,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     {
       Dx x(d_pre, pre_ld);
       x.to(0, nw, d_m1, M1_LD);
-      const int o1 = (nw + 15) / 16 * 16, o2 = o1 + 64;   // padded segment starts: [m1 nw | record 56 | temporal nh]
+      const int o1 = (nw + 15) / 16 * 16, o2 = o1 + rec::ZWP;   // padded segment starts: [m1 nw | record 56 | temporal nh]
       x.to(o1, o1 + rec::ZW, d_rec_prev, RW).acc();
       x.to(o2, o2 + nh, d_tau + d.toff, snh).acc();
       CK(rundx(L_PRE, x, M));
@@ -635,7 +635,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         CK(rundx(L_PRIOR_LIN, x, M)); }
       Dx x(d_pgru1, pgw);   // [z_{t-1} record 56 (pad 64) | previous state nh]
       x.to(0, rec::ZW, d_rec_prev, RW).acc();
-      x.to(64, 64 + nh, d_pprev, nh);
+      x.to(rec::ZWP, rec::ZWP + nh, d_pprev, nh);
       CK(rundx(L_PRIOR_GRU1, x, M));
     } else {
     {
@@ -651,7 +651,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
                               d_pgru1, pgw, d_pprev + nh, psnh, M, nh, s);
       Dx x(d_pgru1, pgw);   // [z_{t-1} record 56 (pad 64) | previous hidden state nh]
       x.to(0, rec::ZW, d_rec_prev, RW).acc();
-      x.to(64, 64 + nh, d_pprev, psnh);
+      x.to(rec::ZWP, rec::ZWP + nh, d_pprev, psnh);
       CK(rundx(L_PRIOR_GRU1, x, M));
     } else {
       {
@@ -662,7 +662,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       {  // [z_{t-1} record 56 (pad 64) | prior state nh]
         Dx x(d_pgru1, 3 * nh);
         x.to(0, rec::ZW, d_rec_prev, RW).acc();
-        x.to(64, 64 + nh, d_pprev, nh).acc();
+        x.to(rec::ZWP, rec::ZWP + nh, d_pprev, nh).acc();
         CK(rundx(L_PRIOR_GRU1, x, M));
       }
     }
@@ -733,7 +733,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     // loop-invariant pre-activations
     wgrad(L_PRE, {{w.m1, M1_LD}, {w.rec_m_all, RW}, {tau_all, snh}}, b.d_pre, pre_ld, MT);
     // propagation slot chain (phase 0 of the tapes)
-    wgrad(L_PROP_RNN, {{b.zs[0], 64}, {b.rs[0], nh}}, b.d_rnn, rw, MT);
+    wgrad(L_PROP_RNN, {{b.zs[0], rec::ZWP}, {b.rs[0], nh}}, b.d_rnn, rw, MT);
     if (c.rnn_cell == RNN_GRU) wgrad(L_PROP_RNN2, {{b.rh[1], nh}}, b.d_rnn + 2 * nh, rw, MT);
     wgrad(L_PROP_T1, {{w.r, nh}}, b.d_t1, T1_LD, MT);
     wgrad(L_PROP_T2, {{w.t1, T1_LD}}, b.d_t2, nh, MT);
@@ -752,7 +752,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     wgrad(L_PRED, {{w.c, nh}}, b.d_pre_d, rw, T * R);
     if (c.rec_where_prior) wgrad(L_RNCOND, {{w.rn_init_state, 0}, {w.c, nh}}, b.d_spre, 128, T * R);
     // discovery slot chain (phase 1 of the tapes)
-    wgrad(L_DISC_RNN, {{b.zs[1], 64}, {b.rs[1], nh}}, b.d_rnn + ph1 * rw, rw, MT);
+    wgrad(L_DISC_RNN, {{b.zs[1], rec::ZWP}, {b.rs[1], nh}}, b.d_rnn + ph1 * rw, rw, MT);
     if (c.rnn_cell == RNN_GRU) wgrad(L_DISC_RNN2, {{b.rh[3], nh}}, b.d_rnn + ph1 * rw + 2 * nh, rw, MT);
     wgrad(L_DISC_T1, {{w.r + ph1 * nh, nh}}, b.d_t1 + ph1 * T1_LD, T1_LD, MT);
     wgrad(L_DISC_T2, {{w.t1 + ph1 * T1_LD, T1_LD}}, b.d_t2 + ph1 * nh, nh, MT);

@@ -63,13 +63,17 @@ class SqairCore(object):
         if not torch.cuda.is_available():
             raise RuntimeError("sqair_amd needs a HIP device (no CPU fallback)")
         self.F = F
-        self.lib = _capi.lib(lib_path)  # lib_path: a build variant (sqair_amd.timeline); default = the product library
-        self.device = torch.device(device)
         self.cfg = make_config(F, img_hw)
+        # lib_path: a build variant (sqair_amd.timeline).  Default: the product library for everything it is laid out for, the
+        # wide build of the same sources for the rest of the flag range (n_what > 50, more than 8 slots, n_units > 8)
+        self.lib = _capi.lib(lib_path or _capi.lib_path_for(self.cfg.n_what, self.cfg.n_steps_per_image, self.cfg.n_hidden))
+        self.device = torch.device(device)
         self.handle = C.c_void_p()
         rc = self.lib.sqair_create(C.byref(self.cfg), C.byref(self.handle))
         if rc != 0:
-            raise ValueError("sqair_create rejected the configuration (rc={})".format(rc))
+            raise ValueError("sqair_create rejected the configuration (rc={}): limits n_what <= {n_what}, n_steps_per_image <= "
+                             "{n_steps_per_image} (<= 14 with the wide record), n_units <= 16, k_particles <= 256".format(
+                                 rc, **_capi.WIDE_LIMITS))
         self.spec = param_spec(F, img_hw)
         self.offsets, self.n_params = param_offsets(self.spec)
         assert self.n_params == self.lib.sqair_param_count(self.handle), "parameter inventory mismatch"

@@ -108,3 +108,50 @@ def test_flag_errors_mirror_reference():
         make_config(make_flags(disc_prior_type="bogus"), (50, 50))   # sqair_modules.py:224
     with pytest.raises(ValueError):
         make_flags(not_a_flag=1)
+
+
+@pytest.mark.parametrize("flags", [dict(n_what=100), dict(n_what=128, n_units=16), dict(n_steps_per_image=12), dict(n_units=10),
+                                   dict(n_units=13, time_transition="LSTM", prior_transition="LSTM", transition="LSTM"),
+                                   dict(n_steps_per_image=14, n_what=128)])
+def test_wide_library_accepts_the_rest_of_the_flag_range(flags):
+    """Beyond what the product library is laid out for (n_what <= 50, 8 slots, n_units <= 8) the SAME sources compiled with
+    -DSQAIR_WIDE serve the configuration through the same C-ABI (reference flags take any value:
+    sqair/common_model_flags.py:32-56, configs/mlp_mnist_model.py:42-52); the product library says no instead of misbehaving."""
+    F = make_flags(**flags)
+    cfg = make_config(F, (50, 50))
+    path = _capi.lib_path_for(cfg.n_what, cfg.n_steps_per_image, cfg.n_hidden)
+    assert path == _capi.WIDE_LIB_PATH
+    h = C.c_void_p()
+    assert _capi.lib().sqair_create(C.byref(cfg), C.byref(h)) != 0
+    lib = _capi.lib(path)
+    assert lib.sqair_build_flags() == b"wide" and lib.sqair_abi_version() == _capi.ABI_VERSION
+    assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
+    try:
+        spec = param_spec(F, (50, 50))
+        off, total = param_offsets(spec)
+        assert lib.sqair_param_count(h) == total and lib.sqair_param_entries(h) == len(spec)
+        for i, (name, shape, _, _) in enumerate(spec):
+            cname, coff, cnum = C.c_char_p(), C.c_int64(), C.c_int64()
+            assert lib.sqair_param_entry(h, i, C.byref(cname), C.byref(coff), C.byref(cnum)) == 0
+            assert (cname.value.decode(), coff.value, cnum.value) == (name, off[name][0], int(np.prod(shape)) if len(shape) else 1)
+        assert lib.sqair_noise_width(h) == 4 + int(F.n_what) + 1
+        assert lib.sqair_workspace_bytes(h, 3, 2) > 0 and lib.sqair_backward_bytes(h, 3, 2) > 0
+    finally:
+        lib.sqair_destroy(h)
+
+
+def test_limits_of_both_builds():
+    lib, wide = _capi.lib(), _capi.lib(_capi.WIDE_LIB_PATH)
+    h = C.c_void_p()
+    for flags, ok_product, ok_wide in [(dict(n_what=50, n_steps_per_image=8, n_units=8), True, True),
+                                       (dict(n_what=51), False, True), (dict(n_steps_per_image=9), False, True),
+                                       (dict(n_units=9), False, True), (dict(n_what=129), False, False),
+                                       (dict(n_steps_per_image=17), False, False), (dict(n_units=17), False, False),
+                                       (dict(k_particles=256), True, True), (dict(k_particles=257), False, False),
+                                       (dict(n_steps_per_image=16, n_what=128), False, False)]:   # (the adjoint's LDS staging)
+        cfg = make_config(make_flags(**flags), (50, 50))
+        for l, ok in ((lib, ok_product), (wide, ok_wide)):
+            rc = l.sqair_create(C.byref(cfg), C.byref(h))
+            assert (rc == 0) == ok, (flags, l.sqair_build_flags(), rc)
+            if rc == 0:
+                l.sqair_destroy(h)

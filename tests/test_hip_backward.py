@@ -258,8 +258,15 @@ TIGHT, LOOSE = 5e-4, 3e-3
 ILL_CONDITIONED = ("disc.transform.scale_offset", "prop.transform.scale_offset")
 
 
-def _check_report(report, tol=TIGHT, loose=ILL_CONDITIONED):
+def _check_report(report, tol=TIGHT, loose=ILL_CONDITIONED, ill_scale=False):
     gmax = max(s for _, _, s in report)
+    if ill_scale:
+        # `*.transform.scale_offset` is the SUM of the four scale columns of `*.transform.l2.b`'s gradient: judge its error on the
+        # size of the terms it is made of (the loose bar above assumes the ~170x cancellation of the shipped sizes; other sizes
+        # cancel harder)
+        by = {n: s for n, _, s in report}
+        report = [(n, e, max(s, by[n.replace("scale_offset", "l2.b")]) if n in loose else s) for n, e, s in report]
+        loose = ()
     rel = lambda e, s: e / max(s, 1e-4 * gmax)
     bad = [(n, e, s) for n, e, s in report if not np.isfinite(e) or rel(e, s) > (LOOSE if n in loose else tol)]
     for n, e, s in sorted(report, key=lambda r: -rel(r[1], r[2]))[:8]:
@@ -486,6 +493,25 @@ def test_model_size_flags_forward_and_backward(flags):
     want = ref.log_weights_per_timestep.detach().numpy()
     assert np.abs(lw - want).max() <= 1e-4 * np.abs(want).max()
     _check_report(report)
+
+
+@pytest.mark.parametrize("K,N,flags", [(3, 3, dict(n_what=64)), (3, 3, dict(n_what=100)), (2, 3, dict(n_what=128, glimpse_size=12)),
+                                       (3, 3, dict(n_units=12)), (2, 3, dict(n_units=16)), (2, 12, {}), (2, 9, dict(n_units=2)),
+                                       (2, 3, dict(n_units=10, n_what=70, transition="LSTM", time_transition="LSTM", prior_transition="LSTM")),
+                                       (2, 3, dict(n_what=60, transition="GRU", prop_prior_type="guided", disc_prior_type="geom"))])
+def test_wide_flag_range_forward_and_backward(K, N, flags):
+    """The rest of the reference's flag range (n_what > 50, more than 8 object slots, n_units > 8:
+    sqair/common_model_flags.py:32-56 and configs/mlp_mnist_model.py:42-52 accept any value) runs on libsqair_hip_wide.so -- the
+    same sources with a larger slot record and plain-loop per-row kernels, picked by SqairCore from the flags: the log-weights and
+    every gradient against the oracle, exactly like the shipped sizes."""
+    from sqair_amd import _capi
+    report, ref, core = _full_backward_case(K=K, N=N, T=3 if N < 9 else 2, B=2, hw=(50, 50), seed=11, flags=flags)
+    assert core.lib is _capi.lib(_capi.WIDE_LIB_PATH)
+    assert float(ref.prop_pres.detach().sum()) > 0
+    lw = core.out["log_weights_per_timestep"].cpu().numpy()
+    want = ref.log_weights_per_timestep.detach().numpy()
+    assert np.abs(lw - want).max() <= 1e-4 * np.abs(want).max()
+    _check_report(report, ill_scale=True)
 
 
 def test_scalar_hyper_parameter_flags_reach_the_kernels():
