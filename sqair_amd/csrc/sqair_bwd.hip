@@ -180,6 +180,8 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   }
   __syncthreads();
   const float hg = 0.5f * (float)(G - 1);
+  const bool one_sd = a.std_fg == a.std_bg;
+  const float gll_isd2 = gll / (a.std_fg * a.std_fg), m_bg = sq_sigmoid(-10.0f);
   for (int yb0 = 0; yb0 < H; yb0 += band_rows) {
     const int yb1 = min(H, yb0 + band_rows) - 1, n = (yb1 - yb0 + 1) * W, pix0 = yb0 * W;
     float xv[SQ_CANVAS_PF_BWD], mv[SQ_CANVAS_PF_BWD];
@@ -190,19 +192,28 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
       mv[q] = p < n ? a.mean_img[pix0 + p] : 0.0f;
     }
     sq_canvas_band<SQ_CANVAS_ROWS_BWD>(c, yb0, yb1, N, G, H, W);
-    // ---- (2) adjoints of the band's pixels
+    // ---- (2) adjoints of the band's pixels.  As in the forward kernel: one likelihood scale when std_fg == std_bg (its powers taken
+    // once), and no exponential for a wavefront whose 64 pixels lie outside every glimpse's box (mask sum exactly 0)
 #pragma unroll
     for (int q = 0; q < SQ_CANVAS_PF_BWD; ++q) {
       const int p = tid + q * 256;
+      const float msv = p < n ? c.ms[p] : 0.0f;
+      const bool any_on = __builtin_amdgcn_ballot_w64(msv != 0.0f) != 0ull;   // (wave-uniform)
       if (p < n) {
-        const float m = sq_sigmoid(-10.0f + c.ms[p] * 20.0f);
+        const float m = any_on ? sq_sigmoid(-10.0f + msv * 20.0f) : m_bg;
         const float mean = mv[q];
         const float cv = c.cv[p] + mean * m;
-        const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
         const float diff = xv[q] - cv;
-        const float g_cv = gll * diff / (sd * sd);
-        const float g_sd = gll * (diff * diff / (sd * sd * sd) - 1.0f / sd);
-        const float g_m = g_cv * mean + g_sd * (a.std_fg - a.std_bg);
+        float g_cv, g_m;
+        if (one_sd) {
+          g_cv = gll_isd2 * diff;
+          g_m = g_cv * mean;
+        } else {
+          const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
+          g_cv = gll * diff / (sd * sd);
+          const float g_sd = gll * (diff * diff / (sd * sd * sd) - 1.0f / sd);
+          g_m = g_cv * mean + g_sd * (a.std_fg - a.std_bg);
+        }
         a.d_mean_rows[frr * P + pix0 + p] = g_cv * m;
         c.cv[p] = g_cv;
         c.ms[p] = g_m * 20.0f * m * (1.0f - m);
@@ -1496,6 +1507,7 @@ int sq_launch_slot_tail_bwd(const TailBwdArgs& a, Dims d, hipStream_t s) {
 // record) -> adjoint of the where sample -> d(transform output) [R][8], d(previous where), d(mask).
 // modes as CropMode.  One workgroup per sequence.
 // ------------------------------------------------------------------------------------------------
+template <bool STAGED>   // the frame staged in LDS through registers (up to SQ_CROP_STAGE_MAX_PIXELS) or by LDS-DMA (larger frames)
 __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a, const POff po, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1516,7 +1528,12 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
   // round trip (it used to make three: frame | glimpse gradient + mask | the operands of the where-sample adjoint).  The
   // frame's first 1024 16-byte units go out FIRST -- they still have to pass through LDS once they are here -- and the fences keep
   // hipcc from computing every address of the kernel before it issues the first request.
-  const int n4 = d.P4 >> 2;   // (frames are 16-byte aligned and padded to a multiple of 4 floats: Dims.P4)
+  // Large frames (SQ_CROP_STAGE_MAX_PIXELS; 128 x 128 = 4096 units): every unit on the LDS-DMA path, requested HERE in one batch
+  // (16 wave instructions of 1 KB each) -- through registers the units beyond the first 1024 were three more dependent round
+  // trips (5.8 us per launch at 128 x 128 against 4.0 at 50 x 50; reading the taps where they lie instead, after the where
+  // logits have arrived, was slower still: 6.3 us -- a second COLD round trip, the frame was last touched a forward pass ago)
+  if (!STAGED) sq_wave_stage16(img_s, img, d.P4 >> 2, lane, wave, 4);
+  const int n4 = STAGED ? d.P4 >> 2 : 1;   // (frames are 16-byte aligned and padded to a multiple of 4 floats: Dims.P4)
   const f32x4_b* __restrict__ s4 = reinterpret_cast<const f32x4_b*>(img);
   f32x4_b fv[4];
 #pragma unroll
@@ -1574,7 +1591,7 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
     w3b = *reinterpret_cast<const f32x4_b*>(a.w3 + (size_t)tid * 8 + 4);
     t2v = a.t2[(size_t)r * a.t2_ld + tid];
   }
-  {  // frame -> LDS in 16-byte units, 4 loads per thread in flight at once.  The plain copy loop compiled to three or four
+  if (STAGED) {  // frame -> LDS in 16-byte units, 4 loads per thread in flight at once.  The plain copy loop compiled to three or four
      // dependent round trips (an unrolled trip + remainder loops waiting per element).
     f32x4_b* d4 = reinterpret_cast<f32x4_b*>(img_s);
 #pragma unroll
@@ -1734,8 +1751,11 @@ int sq_launch_where_param_grads(const float* d_tp, int tp_ld, const float* d_rec
 int sq_launch_crop_chain_bwd(const CropChainBwdArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
   if ((d.P4 & 3) != 0) return -1;   // (the frame is staged in 16-byte units: callers pass the padded copy, Dims.P4)
   const size_t shm = (size_t)d.P4 * sizeof(float);
-  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_crop_chain_bwd, 150 * 1024) != 0) return -2;
-  SQ_LAUNCH(k_crop_chain_bwd, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
+  if (d.H * d.W <= SQ_CROP_STAGE_MAX_PIXELS) SQ_LAUNCH(k_crop_chain_bwd<true>, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
+  else {
+    if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_crop_chain_bwd<false>, 150 * 1024) != 0) return -2;
+    SQ_LAUNCH(k_crop_chain_bwd<false>, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
+  }
   return 0;
 }
 

@@ -274,6 +274,13 @@ __device__ __forceinline__ void sq_wave_stage(float* lds_dst, const float* __res
   for (int base = 64 * wave; base < n; base += 64 * n_waves)
     if (base + lane < n) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + base + lane), (lds_ptr_t)(lds_dst + base), 4, 0, 0);
 }
+// The same in 16-byte units (global_load_lds_dwordx4: 1 KB per wave instruction): n4 units, src and lds_dst 16-byte aligned.
+__device__ __forceinline__ void sq_wave_stage16(float* lds_dst, const float* __restrict__ src, int n4, int lane, int wave = 0, int n_waves = 1) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  for (int base = 64 * wave; base < n4; base += 64 * n_waves)
+    if (base + lane < n4) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 4 * (size_t)(base + lane)), (lds_ptr_t)(lds_dst + 4 * base), 16, 0, 0);
+}
 // Cross-lane sums on the VALU (every lane of the wave active; the result in every lane of the group).  __shfl_xor is a
 // ds_bpermute_b32 -- an LDS-crossbar round trip of ~100 cycles, six of them in a row for one wave sum -- and the small
 // per-row kernels of the chain are chains of exactly such sums.  Inside a row of 16 lanes: two quad permutes, the row's half

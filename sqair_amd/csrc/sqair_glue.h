@@ -65,6 +65,11 @@ inline Dims make_dims(const SqairConfig& c, int B) {
 }
 
 enum CropMode { CROP_PLAIN = 0, CROP_PROP1 = 1, CROP_PROP2 = 2, CROP_DISC = 3 };
+// Frames up to this many pixels are staged in LDS by the crop kernels while the where computation runs (a 50 x 50 frame is
+// 10 KB: the copy hides behind the where sample); larger ones (BASELINE configs[4]: 128 x 128 = 64 KB per workgroup, of which a
+// 20 x 20 glimpse touches at most 1600 pixels) are sampled where they lie -- four taps per glimpse pixel straight from L2, all
+// in flight at once, instead of 54 dependent copy trips per thread
+constexpr int SQ_CROP_STAGE_MAX_PIXELS = 4096;
 
 struct CropArgs {
   int mode;

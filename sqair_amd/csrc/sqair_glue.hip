@@ -85,16 +85,18 @@ int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float*
 
 // one workgroup per particle row (a per-sequence kernel staging the frame in LDS for its K particles had only B = 32
 // workgroups at the headline config and measured 10.3 us; this one 5-6 us with the frame served by L1 / L2)
+template <bool STAGED>
 __global__ __launch_bounds__(256) void k_crop_row(const CropArgs a, const POff po, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  x_crop_row<LdPlain>(a, po, d, blockIdx.x, a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot, smem, true);
+  x_crop_row<LdPlain, STAGED>(a, po, d, blockIdx.x, a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot, smem);
 }
 
 int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
-  const size_t shm = (4 + (size_t)4 * d.G + (size_t)d.H * d.W) * sizeof(float);
-  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_crop_row, 150 * 1024) != 0) return -2;
-  SQ_LAUNCH(k_crop_row, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
+  const bool staged = d.H * d.W <= SQ_CROP_STAGE_MAX_PIXELS;
+  const size_t shm = (4 + (size_t)4 * d.G + (staged ? (size_t)d.H * d.W : 0)) * sizeof(float);
+  if (staged) SQ_LAUNCH(k_crop_row<true>, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
+  else SQ_LAUNCH(k_crop_row<false>, dim3(d.R, nslots), dim3(256), shm, s, a, po, d);
   return 0;
 }
 
@@ -1005,6 +1007,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   if (a.rec) sq_canvas_prologue(c, a.glimpse + fs * G2, a.rec + fs * a.rec_ld + rec::WHERE, a.rec_ld, a.rec + fs * a.rec_ld + rec::PRES, a.rec_ld, N, G, H, W);
   else sq_canvas_prologue(c, a.glimpse + fs * G2, a.where_plain + (size_t)r * N * 4, 4, a.pres_plain + (size_t)r * N, 1, N, G, H, W);
   float ll = 0.0f;
+  // Two things every pixel paid for and few need.  (1) The likelihood's scale m std_fg + (1 - m) std_bg is ONE number when the
+  // two flags agree (bg_std=None -> output_std, the shipped configuration: modules.py:419-422): its logarithm and reciprocal are
+  // taken once, not per pixel.  (2) A pixel no glimpse's box touches has a written-to mask sum of exactly 0, i.e. m = sigmoid(-10):
+  // a wavefront (64 consecutive pixels of a row) whose pixels are all outside every box skips the exponential -- most of a
+  // 128 x 128 frame.  The value is the same sq_sigmoid(-10) either way.  (cfg-5: 111 -> 98 us.)
+  const bool one_sd = a.std_fg == a.std_bg;
+  const float inv_sd = 1.0f / a.std_fg, lp0 = -logf(a.std_fg) - 0.91893853320467274178f;
+  const float m_bg = sq_sigmoid(-10.0f);
   for (int yb0 = 0; yb0 < H; yb0 += band_rows) {
     const int yb1 = min(H, yb0 + band_rows) - 1, n = (yb1 - yb0 + 1) * W, pix0 = yb0 * W;
     float xv[SQ_CANVAS_PF_FWD], mv[SQ_CANVAS_PF_FWD];  // the band's frame / mean-image values: in flight while the canvas is built
@@ -1018,11 +1028,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 #pragma unroll
     for (int q = 0; q < SQ_CANVAS_PF_FWD; ++q) {
       const int p = tid + q * 256;
+      const float msv = p < n ? c.ms[p] : 0.0f;
+      const bool any_on = __builtin_amdgcn_ballot_w64(msv != 0.0f) != 0ull;   // (wave-uniform)
       if (p < n) {
-        const float m = sq_sigmoid(-10.0f + c.ms[p] * 20.0f);
+        const float m = any_on ? sq_sigmoid(-10.0f + msv * 20.0f) : m_bg;
         const float cv = c.cv[p] + mv[q] * m;
-        const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
-        ll += sq_normal_lp(xv[q], cv, sd);
+        if (one_sd) {
+          const float dd = (xv[q] - cv) * inv_sd;
+          ll += fmaf(-0.5f * dd, dd, lp0);
+        } else {
+          const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
+          ll += sq_normal_lp(xv[q], cv, sd);
+        }
         if (a.canvas) a.canvas[frr * P + pix0 + p] = cv;
       }
     }

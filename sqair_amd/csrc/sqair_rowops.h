@@ -15,8 +15,8 @@ struct LdPlain {
   }
 };
 
-template <class LD>
-__device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int r, int slot, float* smem, bool stage_img) {
+template <class LD, bool stage_img>   // stage_img: the frame is copied to LDS (up to SQ_CROP_STAGE_MAX_PIXELS); else its taps are read where they lie
+__device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int r, int slot, float* smem) {
   float* coord_s = smem;        // 4
   float* tab_s = smem + 4;      // 2 * 2G
   float* img_s = smem + 4 + 4 * d.G;  // H*W when stage_img: the frame is pulled into LDS WHILE wave 0 computes `where`, so
@@ -181,6 +181,41 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
     tab_s[i * 2 + 1] = x - x0;
   }
   __syncthreads();
+  if (!stage_img) {
+    // Large frames (SQ_CROP_STAGE_MAX_PIXELS): the four taps of every glimpse pixel straight from memory (L2: the K particles of
+    // a sequence and the slots of a frame keep reading the same 64 KB), PX pixels of a thread in flight at once -- unconditional
+    // loads from clamped addresses, taps outside the frame get weight zero (a guarded load is fenced with a full wait)
+    constexpr int PX = 2;
+    for (int p0 = tid; p0 < G2; p0 += 256 * PX) {
+      float tv[PX][4], tw[PX][4], mk[PX];
+#pragma unroll
+      for (int u = 0; u < PX; ++u) {
+        const int pix = min(p0 + 256 * u, G2 - 1);
+        mk[u] = has_mask ? LD::f(a.mask + ((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix) : 1.0f;
+        const int i = sq_div(pix, d.g_mul), j = pix - i * G;
+        const float x0f = tab_s[j * 2], wx1 = tab_s[j * 2 + 1];
+        const float y0f = tab_s[(G + i) * 2], wy1 = tab_s[(G + i) * 2 + 1];
+        const int x0 = (int)x0f, y0 = (int)y0f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int yy = y0 + dy, xx = x0 + dx;
+            const bool ok = yy >= 0 && yy < d.H && xx >= 0 && xx < d.W;
+            tv[u][dy * 2 + dx] = img[min(max(yy, 0), d.H - 1) * d.W + min(max(xx, 0), d.W - 1)];
+            tw[u][dy * 2 + dx] = ok ? (dy ? wy1 : 1.0f - wy1) * (dx ? wx1 : 1.0f - wx1) : 0.0f;
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < PX; ++u)
+        if (p0 + 256 * u < G2) {
+          float v = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v += tw[u][q] * tv[u][q];
+          a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + p0 + 256 * u] = has_mask ? v * mk[u] : v;
+        }
+    }
+  } else
   for (int pix = tid, q = 0; pix < G2; pix += 256, ++q) {
     const float mk = q < MPT ? mk0[q < MPT ? q : 0] : (has_mask ? LD::f(a.mask + ((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix) : 1.0f);
     const int i = sq_div(pix, d.g_mul), j = pix - i * G;
