@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   int* xr_s = reinterpret_cast<int*>(dgl_s + N * G2); // N * G
   int* yr_s = xr_s + N * G;                           // N * G
   float* acc_s = reinterpret_cast<float*>(yr_s + N * G);  // 4 waves * N * 4
-  const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, tx = tid & 31, ty = tid >> 5;
+  const int r = sq_row_of_wg(blockIdx.x, d), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, tx = tid & 31, ty = tid >> 5;
   const int fr = blockIdx.y;  // frame
   const int b = sq_div(r, d.k_mul);
   const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot-row of this (frame, row)
@@ -1518,7 +1518,7 @@ __global__ __launch_bounds__(256) void k_crop_chain_bwd(const CropChainBwdArgs a
   SQ_PIN8(a.wb_ld, a.mask, a.mask_row_mul, a.mask_row_add, a.d_mask, a.g_out, a.g_row_mul, a.g_row_add);
   SQ_PIN8(a.tp, a.tp_ld, a.noise, a.flat, a.w3, a.t2, a.t2_ld, a.d_t2);
   // one workgroup per particle row (the K particles of a sequence re-stage the same frame from L2: 10 KB at 50x50)
-  const int r = blockIdx.x, b = sq_div(r, d.k_mul), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = sq_row_of_wg(blockIdx.x, d), b = sq_div(r, d.k_mul), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int slot = a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot;
   const int P = d.H * d.W, G = d.G, G2 = d.G * d.G, RW = rec::W;
   const float* img = a.img + (size_t)b * d.P4;

@@ -64,6 +64,20 @@ inline Dims make_dims(const SqairConfig& c, int B) {
               sq_magic(c.n_what), sq_magic(c.glimpse_size), sq_magic(c.k_particles), c.img_h * c.img_w};
 }
 
+#ifdef __HIPCC__
+// Particle row handled by workgroup i of a launch with one workgroup per row (grid.x = R, R a multiple of 8).  Workgroups go to
+// the eight XCDs round-robin (XCD = i % 8), each XCD has its own L2, and the K particles of a sequence read the SAME frame: with
+// rows taken in launch order a frame was fetched into up to K of the eight L2s (PMC: 2.5x the algorithmic bytes of k_crop_row).
+// With the number of sequences a multiple of 8, sequence b's K rows go to XCD b % 8, so a frame enters one L2.
+__device__ __forceinline__ int sq_row_of_wg(int i, const Dims& d) {
+  if ((d.B & 7) != 0) return i;
+  const int xcd = i & 7, j = i >> 3;
+  const int bb = sq_div(j, d.k_mul), k = j - bb * d.K;
+  // (wave-uniform by construction; said so explicitly: the multiply-high of sq_div is a vector instruction, and a row index in a
+  // VGPR turns every address of the kernel into vector arithmetic)
+  return __builtin_amdgcn_readfirstlane((bb * 8 + xcd) * d.K + k);
+}
+#endif
 enum CropMode { CROP_PLAIN = 0, CROP_PROP1 = 1, CROP_PROP2 = 2, CROP_DISC = 3 };
 // Frames up to this many pixels are staged in LDS by the crop kernels while the where computation runs (a 50 x 50 frame is
 // 10 KB: the copy hides behind the where sample); larger ones (BASELINE configs[4]: 128 x 128 = 64 KB per workgroup, of which a

@@ -89,7 +89,7 @@ template <bool STAGED>
 __global__ __launch_bounds__(256) void k_crop_row(const CropArgs a, const POff po, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  x_crop_row<LdPlain, STAGED>(a, po, d, blockIdx.x, a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot, smem);
+  x_crop_row<LdPlain, STAGED>(a, po, d, sq_row_of_wg(blockIdx.x, d), a.mode == CROP_PROP1 ? (int)blockIdx.y : a.slot, smem);
 }
 
 int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s) {
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   const int N = d.N, G = d.G, G2 = d.G * d.G, H = d.H, W = d.W, P = d.H * d.W;
   const CanvasLds c = sq_canvas_carve(smem, N, G, H, W, band_rows);
   __shared__ float red_s[4];
-  const int r = blockIdx.x, tid = threadIdx.x;
+  const int r = sq_row_of_wg(blockIdx.x, d), tid = threadIdx.x;   // (the K particles of a sequence on one XCD: one L2 holds the frame)
   const int fr = blockIdx.y;  // frame
   const int b = sq_div(r, d.k_mul);
   const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot of this (frame, row)
