@@ -162,16 +162,17 @@ def timeline_roofline(F, Ftr, hw, P, obs, nums, algo_flops_step, ms_fwd, ms_trai
                                    psnh=core_t.psnh, masked=bool(F.masked_glimpse), train=False)
     # PMC traffic measured by rocprofv3 on this build, if committed (tools/profile_round.sh)
     traffic, traffic_note, fam_traffic = None, None, None
-    tpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_hbm_traffic.json")
-    if os.path.exists(tpath) and cfg_id == 2 and not batch_override:
+    tname = PROFILE_TAG + "_hbm_traffic" + ("" if cfg_id in (2, 3) else "_cfg{}".format(cfg_id)) + ".json"
+    tpath = os.path.join(ROOT, "profiles", tname)
+    if os.path.exists(tpath) and not batch_override:
         try:
             tj = json.load(open(tpath))
             if tj.get("build_id") == bid:
                 traffic = tj.get("dominant_bytes_per_launch")
                 fam_traffic = tj.get("family_bytes_per_launch")
-                traffic_note = "PMC FETCH_SIZE / WRITE_SIZE of {} on this build (profiles/{}_hbm_traffic.json, two separate --pmc passes)".format(tj.get("dominant"), PROFILE_TAG)
+                traffic_note = "PMC FETCH_SIZE / WRITE_SIZE of {} on this build (profiles/{}, two separate --pmc passes)".format(tj.get("dominant"), tname)
             else:
-                traffic_note = "profiles/{}_hbm_traffic.json was measured on build {} != this build {}: not quoted".format(PROFILE_TAG, tj.get("build_id"), bid)
+                traffic_note = "profiles/{} was measured on build {} != this build {}: not quoted".format(tname, tj.get("build_id"), bid)
         except Exception as e:  # a broken profile file must not take the bench line down
             traffic_note = "profiles unreadable: {}".format(e)
     per = algo_flops_step / max(d["launches"], 1)

@@ -12,8 +12,8 @@
 #                          segfaults inside rocprofv3 when the step is a 2000-node graph replay)
 #   rNN_profile_meta.json  build_id of the library the profiles were taken on + the commands
 #   rNN_bench.json, rNN_bench_cfg{4,5}.json   bench lines of the same build WITH cpu_baseline
-# usage: gpurun --timeout 1500 -- 'bash tools/profile_round.sh r03'
-R=${1:-r03}
+# usage: gpurun --timeout 1800 -- 'bash tools/profile_round.sh r04'
+R=${1:-r04}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$R
 mkdir -p $OUT
@@ -58,6 +58,14 @@ PCMD="python $REPO/bench.py --steps 3 --warmup 1 --train-steps 3 --no-cpu-baseli
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- $PCMD > /tmp/pmc_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- $PCMD > /tmp/pmc_w.log 2>&1
 python $REPO/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $OUT/${R}_hbm_traffic.json > /dev/null
+# the same two counter passes for BASELINE configs 4 and 5 (rNN_hbm_traffic_cfg{4,5}.json)
+for C in 4 5; do
+  PC="python $REPO/bench.py --cfg $C --steps 3 --warmup 1 --train-steps 3 --no-cpu-baseline --no-graph --no-timeline --streams 0"
+  rm -rf /tmp/pmc_f$C /tmp/pmc_w$C
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f$C -- $PC > /tmp/pmc_f$C.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w$C -- $PC > /tmp/pmc_w$C.log 2>&1
+  python $REPO/tools/pmc_traffic.py /tmp/pmc_f$C /tmp/pmc_w$C $OUT/${R}_hbm_traffic_cfg$C.json > /dev/null
+done
 python - <<PY
 import json, sys
 sys.path.insert(0, "$REPO")
@@ -68,7 +76,7 @@ json.dump(dict(build_id=build_id(), stats_command="rocprofv3 --kernel-trace --st
           open("$OUT/${R}_profile_meta.json", "w"), indent=1)
 PY
 # the bench lines themselves, reading the fresh profiles (copied into place for this run)
-cp $OUT/${R}_hbm_traffic.json $OUT/${R}_timeline.json $OUT/${R}_timeline_fwd.csv $OUT/${R}_timeline_train.csv $REPO/profiles/ 2>/dev/null
+cp $OUT/${R}_hbm_traffic*.json $OUT/${R}_timeline*.json $OUT/${R}_timeline_*.csv $REPO/profiles/ 2>/dev/null
 cd $REPO
 python bench.py --steps 50 --warmup 5 > $OUT/${R}_bench.json 2> $OUT/${R}_bench.err
 python bench.py --cfg 4 --steps 30 --warmup 5 > $OUT/${R}_bench_cfg4.json 2> $OUT/${R}_bench_cfg4.err
