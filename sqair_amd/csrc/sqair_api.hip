@@ -732,7 +732,6 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.rn_init_state = take(4);
   w.w3_prop = take(nh * 8 + 8);
   w.w3_disc = take(nh * 8 + 8);
-  w.w3_wb = take(128 * 8 + 8);
   w.temporal_p = take(F * M * snh);
   w.prior_p = take(F * M * psnh);
   w.pgz = take(F * M * ((c.prior_cell == CELL_LSTM) ? 4 * nh : nh));  // GRU: z gate; LSTM: the four gate pre-activations
@@ -921,8 +920,8 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     if (h->clear_each_pass) sq_zero_fill(wsbase, (int64_t)((float*)w.prof_ts - wsbase), s);
     // initial state; discovery starts every frame with presence = 1 (core.py:150) -> disc_init_rec
     sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0, w.snh), w.state(w.prior_m, 0, w.psnh), w.last_id[0], w.disc_init_rec,
-                         w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc, w.w3_wb,
-                         (int)P(h, "prop.transform.l2.w"), (int)P(h, "disc.transform.l2.w"), (int)P(h, "prop.where_bias.l1.w"), flat, po, d, s);
+                         w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc,
+                         (int)P(h, "prop.transform.l2.w"), (int)P(h, "disc.transform.l2.w"), flat, po, d, s);
     if (obs != obs_user) SQ_LAUNCH(k_pad_rows, dim3(T * B), dim3(256), 0, s, obs_user, w.obs_p, P_, PL);
     // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
     Lin a; a.seg(obs, PL, P_).out(w.ienc_a, nh).act(ACT_ELU); RUN(a, L_IENC0, T * B);
@@ -985,8 +984,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     // ---- B. where-bias MLP and glimpse-mask MLP of every slot (core.py:292, modules.py:350-356) ----
     {
       Lin a; a.seg(tau_prev, snh, nh).out(hid1, 256).act(ACT_ELU); RUN(a, L_TAU1, M);
-      // (the where-bias MLP's 128 -> 4 output layer L_WB2 is evaluated inside crop #1 below, like the transform's output layer
-      //  inside the slot crops: one dependent launch per frame less)
+      Lin b; b.seg(hid1, 256, 128).out(wb, WB_LD); RUN(b, L_WB2, M);
       Lin m; m.seg(hid1 + 128, 256, 128).out(mask, G2).act(ACT_SIGMOID); RUN(m, L_MASK2, M);
     }
     // ---- C. crop #1 at where_{t-1} + bias, masked, encoded -> loc1 (core.py:293-294) ----
@@ -994,8 +992,6 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
       CropArgs ca; memset(&ca, 0, sizeof(ca));
       ca.mode = CROP_PROP1; ca.img = img; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N;
       ca.out = g1; ca.out_row_mul = N; ca.rec_prev = rec_prev; ca.wb = wb; ca.wb_ld = WB_LD; ca.flat = flat;
-      ca.t2 = hid1; ca.t2_ld = 256; ca.t2_w = 128; ca.w3 = w.w3_wb;
-      if (train) { ca.tp_out = wb; ca.tp_out_ld = WB_LD; }   // (the adjoint of the crop reads it)
       emit_crop(h, ca, po, d, N, s);
       Lin a; a.seg(g1, G2, G2).out(pea, nh).act(ACT_ELU); RUN(a, L_GENC0, M);
       Lin b; b.seg(pea, nh, nh).out(peb, nh).act(ACT_ELU); RUN(b, L_GENC1, M);

@@ -100,8 +100,7 @@ struct CropArgs {
   const float* tp;         // PROP2 / DISC: transform MLP output [R, tp_ld] (loc 0:4, raw scale 4:8), or
   int tp_ld;
   const float* t2;         // ... its input [R, t2_ld]: the 256 -> 8 output layer is then evaluated in this launch
-  int t2_ld;               //     (PROP1: the where-bias MLP's hidden layer [R*N, t2_ld], its 128 -> 4 output layer likewise)
-  int t2_w;                // width of that input row (0 = n_hidden)
+  int t2_ld;
   const float* w3;         // 16-byte aligned copy of transform.l2 {w [nh,8], b [8]} (workspace, see k_init_state)
   const float* noise;      // noise of frame t, [R,2,N,nzw]
   const float* flat;       // flat parameters
@@ -116,7 +115,7 @@ int sq_launch_lstm_cell(const float* gates, int g_ld, const float* c_prev, int c
                         hipStream_t s);
 int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float* last_id, float* disc_init_rec,
                          float* prop_rnn_init, float* disc_rnn_init, float* rn_init_state, float* w3_prop, float* w3_disc,
-                         float* w3_wb, int w3p_off, int w3d_off, int wb_off, const float* flat,
+                         int w3p_off, int w3d_off, const float* flat,
                          POff po, Dims d, hipStream_t s);
 int sq_launch_crop(const CropArgs& a, POff po, Dims d, int nslots, hipStream_t s);
 // Tail of a propagation / discovery slot in one launch: what-sample, the what-dependent part of the steps

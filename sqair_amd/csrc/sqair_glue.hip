@@ -12,7 +12,7 @@ __global__ void k_init_state(float* __restrict__ rec_m, float* __restrict__ temp
                              float* __restrict__ last_id, float* __restrict__ disc_init_rec,
                              float* __restrict__ prop_rnn_init, float* __restrict__ disc_rnn_init,
                              float* __restrict__ rn_init_state, float* __restrict__ w3_prop,
-                             float* __restrict__ w3_disc, float* __restrict__ w3_wb, int w3p_off, int w3d_off, int wb_off,
+                             float* __restrict__ w3_disc, int w3p_off, int w3d_off,
                              const float* __restrict__ flat, POff po, Dims d SQ_TLP) {
   SQ_TL_SCOPE;
   const int rs = blockIdx.x;  // row*N + slot
@@ -35,8 +35,6 @@ __global__ void k_init_state(float* __restrict__ rec_m, float* __restrict__ temp
       w3_prop[i] = flat[w3p_off + i];
       w3_disc[i] = flat[w3d_off + i];
     }
-    // where_bias.l1 {w [128, 4], b [4]} in the same [inputs][8] layout (columns 4..7 zero): the crop of PROP1 evaluates it
-    for (int i = tid; i < 128 * 8 + 8; i += blockDim.x) w3_wb[i] = (i & 7) < 4 ? flat[wb_off + (i >> 3) * 4 + (i & 3)] : 0.0f;
   }
 }
 
@@ -72,9 +70,9 @@ int sq_launch_lstm_cell(const float* gates, int g_ld, const float* c_prev, int c
 
 int sq_launch_init_state(float* rec_m, float* temporal_m, float* prior_m, float* last_id, float* disc_init_rec,
                          float* prop_rnn_init, float* disc_rnn_init, float* rn_init_state, float* w3_prop, float* w3_disc,
-                         float* w3_wb, int w3p_off, int w3d_off, int wb_off, const float* flat, POff po, Dims d, hipStream_t s) {
+                         int w3p_off, int w3d_off, const float* flat, POff po, Dims d, hipStream_t s) {
   SQ_LAUNCH(k_init_state, dim3(d.R * d.N), dim3(256), 0, s, rec_m, temporal_m, prior_m, last_id, disc_init_rec,
-                     prop_rnn_init, disc_rnn_init, rn_init_state, w3_prop, w3_disc, w3_wb, w3p_off, w3d_off, wb_off, flat, po, d);
+                     prop_rnn_init, disc_rnn_init, rn_init_state, w3_prop, w3_disc, w3p_off, w3d_off, flat, po, d);
   return 0;
 }
 

@@ -142,7 +142,7 @@ struct Workspace {
   float *rec_m_all, *rec_p_all, *rec_d_all;
   float *temporal_m, *prior_m;                   // train: [T+1][M][snh | nh], else [2][M][snh | nh]
   float *last_id[2];
-  float *zero_rec, *disc_init_rec, *prop_rnn_init, *disc_rnn_init, *rn_init_state, *w3_prop, *w3_disc, *w3_wb;
+  float *zero_rec, *disc_init_rec, *prop_rnn_init, *disc_rnn_init, *rn_init_state, *w3_prop, *w3_disc;
   float *temporal_p, *prior_p;                   // per frame
   float *pgz, *pgr, *pghc, *pgrh, *pgxh;         // prior GRU internals, per frame
   float *pstats, *spre;                          // always [T]

@@ -27,11 +27,7 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
   const int orow_add = a.out_row_add + (a.mode == CROP_PROP1 ? slot : 0);
   const float* __restrict__ img = a.img + (size_t)b * d.P4;
   const bool has_mask = a.mask != nullptr;
-  // the small output layer that feeds the where computation, evaluated in this launch from its input row: the transform's
-  // n_hidden -> 8 layer (PROP2 / DISC) or the where-bias MLP's 128 -> 4 layer laid out the same way (PROP1: row per (r, slot))
-  const bool fused_tp = a.t2 != nullptr && a.mode != CROP_PLAIN;
-  const int fw = a.t2_w > 0 ? a.t2_w : d.nh;   // width of that input row
-  const size_t frow = a.mode == CROP_PROP1 ? (size_t)r * d.N + slot : (size_t)r;
+  const bool fused_tp = a.t2 != nullptr && (a.mode == CROP_PROP2 || a.mode == CROP_DISC);
   // Requests in the order of the kernel's critical path: the operands of the where sample (32 threads: the fused output layer
   // of the transform, the noise, the previous where) go out FIRST, the frame and the mask -- needed only after the where
   // computation -- behind them.  (The frame used to be requested first: the where operands' loads then sat ~400 instructions of
@@ -41,7 +37,7 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
   constexpr int MPT = 2;   // mask values of this thread's first pixels, requested up front as well
   float mk0[MPT];
   const int hl = tid, ci = hl & 3;
-  const int per = fw / 32;
+  const int per = d.nh / 32;
   float tp_loc = 0.0f, tp_raw = 0.0f;
   float e[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zp = 0.0f, off = 0.0f, chv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wbv = 0.0f, lg = 0.0f;
   constexpr int QM = 2;
@@ -53,7 +49,7 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
       lg = LD::f(a.logits + (size_t)r * 4 + ci);
     } else if (a.mode == CROP_PROP1) {
       zp = LD::f(a.rec_prev + ((size_t)r * d.N + slot) * rec::W + rec::WHERE + ci);
-      if (!fused_tp) wbv = LD::f(a.wb + ((size_t)r * d.N + slot) * a.wb_ld + ci);
+      wbv = LD::f(a.wb + ((size_t)r * d.N + slot) * a.wb_ld + ci);
     } else {
       const float* eps = a.noise + (((size_t)r * 2 + (a.mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
 #pragma unroll
@@ -72,7 +68,7 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
       }
     }
     if (fused_tp) {
-      const float* xrow = a.t2 + frow * a.t2_ld + per * hl;
+      const float* xrow = a.t2 + (size_t)r * a.t2_ld + per * hl;
       const float4* w4 = reinterpret_cast<const float4*>(a.w3) + (size_t)per * hl * 2;
       // Every load of the layer is requested before the first product (compile-time trip counts, clamped addresses): with the
       // runtime bound per / 4 the two loops below were four dependent memory round trips (activations one by one, then the
@@ -98,7 +94,7 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
   if (tid < 32) {
     if (fused_tp) {
       float part[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-      const float* xrow = a.t2 + frow * a.t2_ld + per * hl;
+      const float* xrow = a.t2 + (size_t)r * a.t2_ld + per * hl;
       const float4* w4 = reinterpret_cast<const float4*>(a.w3) + (size_t)per * hl * 2;
 #pragma unroll
       for (int q = 0; q < QM; ++q) {
@@ -125,15 +121,14 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
       }
 #pragma unroll
       for (int o = 0; o < 8; ++o) {
-        part[o] = sq_half_sum(part[o]) + a.w3[fw * 8 + o];
+        part[o] = sq_half_sum(part[o]) + a.w3[d.nh * 8 + o];
       }
       tp_loc = ci == 0 ? part[0] : (ci == 1 ? part[1] : (ci == 2 ? part[2] : part[3]));
       tp_raw = ci == 0 ? part[4] : (ci == 1 ? part[5] : (ci == 2 ? part[6] : part[7]));
-      if (a.tp_out != nullptr && hl < 4) {   // (training: kept for the adjoint.  PROP1: the where-bias MLP's output [.., 4])
-        a.tp_out[frow * a.tp_out_ld + ci] = tp_loc;
-        if (a.mode != CROP_PROP1) a.tp_out[frow * a.tp_out_ld + 4 + ci] = tp_raw;
+      if (a.tp_out != nullptr && hl < 4) {
+        a.tp_out[(size_t)r * a.tp_out_ld + ci] = tp_loc;
+        a.tp_out[(size_t)r * a.tp_out_ld + 4 + ci] = tp_raw;
       }
-      if (a.mode == CROP_PROP1) wbv = tp_loc;
     }
     float wl;
     if (a.mode == CROP_PLAIN) {
