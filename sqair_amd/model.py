@@ -59,7 +59,7 @@ class SqairCore(object):
     """Thin owner of a library handle + the device buffers it needs (parameters, packed parameters,
     workspace, noise, outputs) for one (T, B) shape on one device / stream."""
 
-    def __init__(self, F, img_hw, device="cuda:0", lib_path=None):
+    def __init__(self, F, img_hw, device="cuda:0", lib_path=None, stream_priority=0):
         if not torch.cuda.is_available():
             raise RuntimeError("sqair_amd needs a HIP device (no CPU fallback)")
         self.F = F
@@ -91,7 +91,7 @@ class SqairCore(object):
             self.packed = torch.zeros(self.lib.sqair_packed_bytes(self.handle) // 4, dtype=torch.float32,
                                       device=self.device)
             # all launches go to one dedicated non-default stream (HIP refuses to capture the legacy stream)
-            self.stream = torch.cuda.Stream(device=self.device)
+            self.stream = torch.cuda.Stream(device=self.device, priority=int(stream_priority))
         self._shape = None
         self._graph_ready = False
         self.check(self.lib.sqair_set_workspace_clearing(self.handle, 0), "sqair_set_workspace_clearing")

@@ -286,15 +286,17 @@ def test_training_mode_forward_is_bitwise_identical():
     assert torch.equal(core.log_weights, lw)
 
 
-@pytest.mark.parametrize("generate_after,prior", [(-1, "rnn"), (1, "rnn"), (1, "guided"), (2, "rw")])
-def test_generation_modes_vs_live_oracle(generate_after, prior):
+@pytest.mark.parametrize("generate_after,prior,n_what", [(-1, "rnn", 50), (1, "rnn", 50), (1, "guided", 50), (2, "rw", 50),
+                                                         (1, "rnn", 70), (2, "guided", 128)])   # (n_what > 50: the wide build)
+def test_generation_modes_vs_live_oracle(generate_after, prior, n_what):
     """`sample_from_prior` (posterior log-probs at prior samples, sqair_modules.py:294-302) and
     generation of the frames t > generate_after from the priors (seq.py:198-200, sqair_modules.py:157-170)."""
     from oracle import sqair_oracle as O
     from sqair_amd.model import Model, SqairCore
     K, N, T, B, hw = 3, 3, 5, 3, (32, 40)
     F = make_flags(k_particles=K, n_steps_per_image=N, sample_from_prior=True, generate_after=generate_after,
-                   prop_prior_type=prior, rec_where_prior=(prior != "rw"))
+                   prop_prior_type=prior, rec_where_prior=(prior != "rw"), n_what=n_what)
+    nzw = 4 + n_what + 1
     d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=20, seed=13)
     obs = to_float(d["imgs"])
     P = params32(F, hw, 6, 0.05, obs.mean((0, 1)))
@@ -306,7 +308,7 @@ def test_generation_modes_vs_live_oracle(generate_after, prior):
     # propagation prior — and the HIP path then runs ONCE; a disagreement in any discrete decision is a failure
     for attempt in range(MAX_DRAWS):
         rng = np.random.default_rng(400 + attempt)
-        noise, gen_noise = draw_noise(rng, T, B * K, N, 55), draw_noise(rng, T, B * K, N, 55)
+        noise, gen_noise = draw_noise(rng, T, B * K, N, nzw), draw_noise(rng, T, B * K, N, nzw)
         with torch.no_grad():
             ref = orc.model(obs, noise, num=d["nums"], gen_noise=gen_noise)
         mg = min(float(presence_margins(ref.outputs, noise).min()), float(prior_presence_margins(ref.outputs, gen_noise).min()))
