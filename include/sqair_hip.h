@@ -69,6 +69,14 @@ int sqair_abi_version(void);
  * id is not the id of the sources beside it. */
 const char* sqair_build_id(void);
 const char* sqair_build_flags(void);
+/* Returns -1 for a configuration outside this BUILD's limits.  libsqair_hip.so (the product) is laid out for the shipped model family:
+ * n_what <= 50, n_steps_per_image <= 8, n_hidden <= 256; libsqair_hip_wide.so -- the same sources compiled with -DSQAIR_WIDE, the
+ * same C-ABI, slower per-row kernels -- takes n_what <= 128, n_steps_per_image <= 16 (15, 16 only while the log-probability
+ * adjoint's LDS staging fits: not with its 416-float slot record), n_hidden <= 512.  Both: n_hidden = 32 * n_units any multiple
+ * of 16 (the kernels run on the next of 128 / 256 / 512 with inert padding units; parameters, gradients and final states cross
+ * this ABI in the reference's shapes), k_particles <= 256, any H x W.  The reference's flags take any value
+ * (sqair/common_model_flags.py:32-56, sqair/configs/mlp_mnist_model.py:42-52); a host picks the library by the flags
+ * (sqair_amd/_capi.py: lib_path_for). */
 int sqair_create(const SqairConfig* cfg, SqairHandle** out);
 int sqair_destroy(SqairHandle* h);
 const char* sqair_last_error(const SqairHandle* h);
