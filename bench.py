@@ -421,31 +421,6 @@ def main():
                           "RMSProp + re-pack; finite={}".format(bool(torch.isfinite(core.flat).all())))
         core.set_params(P)  # back to the benchmark parameters for the parity / roofline legs below
 
-    # ---- what the evaluation path costs: the same forward step with ALL 38 per-frame outputs of SequentialAIR requested (canvases,
-    # glimpses, every log-probability: reference sqair/seq.py:121-177 writes them all, scripts/eval.py:191-224 and the notebook read
-    # them); the timed region above asks for `elbo_iwae` only (outputs="minimal", what `sess.run(model.elbo_iwae)` evaluates).
-    all_out = None
-    if rank == 0 and use_graph:
-        try:
-            from sqair_amd.timeline import time_steps
-            core_a = SqairCore(F, hw, device=device)
-            with core_a.on_stream():
-                core_a.set_params(P)
-                Model(obs, None, core_a, K, presence=nums, outputs="all")
-                ka = [0]
-
-                def astep():
-                    core_a.draw_noise(seed=1000, step=ka[0], global_batch=B * world, b0=rank * B)
-                    ka[0] += 1
-                    core_a.forward(use_graph=True)
-                ms_a = time_steps(core_a, astep, steps=max(5, args.steps // 2), warm=3)
-            all_out = dict(ms_per_step=ms_a, value=B * T / (ms_a * 1e-3), unit="frames/s (this rank)", graph_nodes=core_a.graph_nodes(),
-                           outputs=len(core_a.out), what="noise draw + graph replay + ELBO with every SqairOutputs field written")
-            del core_a
-            torch.cuda.empty_cache()
-            torch.cuda.set_stream(core.stream)
-        except Exception as e:  # never take the bench line down
-            all_out = dict(error="{}: {}".format(type(e).__name__, e))
     # ---- N > 1: what the training step SHOULD take = this rank's step without the collective + the collective alone; the ratio
     # flags a degraded all-reduce (or a stream / queue problem) in the driver's scaling curve by itself
     if train is not None and world > 1:
@@ -541,6 +516,33 @@ def main():
         except Exception as e:  # never take the bench line down
             streams = dict(error="{}: {}".format(type(e).__name__, e))
 
+    # (after the `streams` leg: every stream ever created takes a hardware queue slot round-robin, and an extra one ahead of that leg
+    #  put two of its three streams on one queue: 131 k instead of 206 k frames/s)
+    # ---- what the evaluation path costs: the same forward step with ALL 38 per-frame outputs of SequentialAIR requested (canvases,
+    # glimpses, every log-probability: reference sqair/seq.py:121-177 writes them all, scripts/eval.py:191-224 and the notebook read
+    # them); the timed region above asks for `elbo_iwae` only (outputs="minimal", what `sess.run(model.elbo_iwae)` evaluates).
+    all_out = None
+    if rank == 0 and use_graph:
+        try:
+            from sqair_amd.timeline import time_steps
+            core_a = SqairCore(F, hw, device=device)
+            with core_a.on_stream():
+                core_a.set_params(P)
+                Model(obs, None, core_a, K, presence=nums, outputs="all")
+                ka = [0]
+
+                def astep():
+                    core_a.draw_noise(seed=1000, step=ka[0], global_batch=B * world, b0=rank * B)
+                    ka[0] += 1
+                    core_a.forward(use_graph=True)
+                ms_a = time_steps(core_a, astep, steps=max(5, args.steps // 2), warm=3)
+            all_out = dict(ms_per_step=ms_a, value=B * T / (ms_a * 1e-3), unit="frames/s (this rank)", graph_nodes=core_a.graph_nodes(),
+                           outputs=len(core_a.out), what="noise draw + graph replay + ELBO with every SqairOutputs field written")
+            del core_a
+            torch.cuda.empty_cache()
+            torch.cuda.set_stream(core.stream)
+        except Exception as e:  # never take the bench line down
+            all_out = dict(error="{}: {}".format(type(e).__name__, e))
     if rank != 0:
         if dist is not None:
             dist.barrier()
