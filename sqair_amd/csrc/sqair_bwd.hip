@@ -144,6 +144,7 @@ static inline size_t insert_bwd_lds_floats(const Dims& d, int band_rows) {
   return sq_canvas_lds_floats(d.N, d.G, d.H, d.W, band_rows) + (size_t)d.N * d.G * d.G + 2 * (size_t)d.N * d.G + 16 * (size_t)d.N;
 }
 
+template <int PF, int ROWS>
 __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a, const Dims d, const int band_rows SQ_TLP) {
   SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -184,18 +185,18 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   const float gll_isd2 = gll / (a.std_fg * a.std_fg), m_bg = sq_sigmoid(-10.0f);
   for (int yb0 = 0; yb0 < H; yb0 += band_rows) {
     const int yb1 = min(H, yb0 + band_rows) - 1, n = (yb1 - yb0 + 1) * W, pix0 = yb0 * W;
-    float xv[SQ_CANVAS_PF_BWD], mv[SQ_CANVAS_PF_BWD];
+    float xv[PF], mv[PF];
 #pragma unroll
-    for (int q = 0; q < SQ_CANVAS_PF_BWD; ++q) {
+    for (int q = 0; q < PF; ++q) {
       const int p = tid + q * 256;
       xv[q] = p < n ? img[pix0 + p] : 0.0f;
       mv[q] = p < n ? a.mean_img[pix0 + p] : 0.0f;
     }
-    sq_canvas_band<SQ_CANVAS_ROWS_BWD>(c, yb0, yb1, N, G, H, W);
+    sq_canvas_band<ROWS>(c, yb0, yb1, N, G, H, W);
     // ---- (2) adjoints of the band's pixels.  As in the forward kernel: one likelihood scale when std_fg == std_bg (its powers taken
     // once), and no exponential for a wavefront whose 64 pixels lie outside every glimpse's box (mask sum exactly 0)
 #pragma unroll
-    for (int q = 0; q < SQ_CANVAS_PF_BWD; ++q) {
+    for (int q = 0; q < PF; ++q) {
       const int p = tid + q * 256;
       const float msv = p < n ? c.ms[p] : 0.0f;
       const bool any_on = __builtin_amdgcn_ballot_w64(msv != 0.0f) != 0ull;   // (wave-uniform)
@@ -325,11 +326,18 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
 
 // band height and dynamic LDS of k_insert_loglik_bwd
 static size_t insert_bwd_lds(const Dims& d, int& band_rows) {
-  band_rows = sq_canvas_band_rows(d.H, d.W, SQ_CANVAS_PF_BWD);
+  const bool wide = d.W > SQ_CANVAS_WIDE;
+  band_rows = sq_canvas_band_rows(d.H, d.W, wide ? SQ_CANVAS_PF_BWD_W : SQ_CANVAS_PF_BWD);
   const size_t bytes = insert_bwd_lds_floats(d, band_rows) * sizeof(float);
-  if (bytes > 48 * 1024 && sq_allow_big_lds((const void*)k_insert_loglik_bwd, 150 * 1024) != 0) return 0;  // 0 = failed
+  const void* kern = wide ? (const void*)k_insert_loglik_bwd<SQ_CANVAS_PF_BWD_W, SQ_CANVAS_ROWS_BWD_W> : (const void*)k_insert_loglik_bwd<SQ_CANVAS_PF_BWD, SQ_CANVAS_ROWS_BWD>;
+  if (bytes > 48 * 1024 && sq_allow_big_lds(kern, 150 * 1024) != 0) return 0;  // 0 = failed
   return bytes;
 }
+#define SQ_LAUNCH_INSERT_BWD(grid, shm, s, a, d, band_rows)                                                                         \
+  do {                                                                                                                                \
+    if ((d).W > SQ_CANVAS_WIDE) SQ_LAUNCH((k_insert_loglik_bwd<SQ_CANVAS_PF_BWD_W, SQ_CANVAS_ROWS_BWD_W>), grid, dim3(256), shm, s, a, d, band_rows); \
+    else SQ_LAUNCH((k_insert_loglik_bwd<SQ_CANVAS_PF_BWD, SQ_CANVAS_ROWS_BWD>), grid, dim3(256), shm, s, a, d, band_rows);            \
+  } while (0)
 __global__ void k_reduce_rows(const float* __restrict__ rows, float* __restrict__ out, int R, int P, int accumulate SQ_TLP) {
   SQ_TL_SCOPE;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,7 +374,7 @@ extern "C" int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, 
   int band_rows;
   const size_t shm = insert_bwd_lds(d, band_rows);
   if (shm == 0) return -2;
-  SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, 1), dim3(256), shm, (hipStream_t)stream, a, d, band_rows);
+  SQ_LAUNCH_INSERT_BWD(dim3(d.R, 1), shm, (hipStream_t)stream, a, d, band_rows);
   SQ_LAUNCH(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch,
                      d_mean_img, d.R, P, 0);
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -679,7 +687,7 @@ int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_
   int band_rows;
   const size_t shm = insert_bwd_lds(d, band_rows);
   if (shm == 0) return -2;
-  SQ_LAUNCH(k_insert_loglik_bwd, dim3(d.R, T), dim3(256), shm, s, a, d, band_rows);
+  SQ_LAUNCH_INSERT_BWD(dim3(d.R, T), shm, s, a, d, band_rows);
   return 0;
 }
 int sq_launch_reduce_rows(const float* rows, float* out, int R, int P, int accumulate, hipStream_t s) {

@@ -16,6 +16,11 @@
 // Adjoint: PF 10, ROWS 4 -- it holds the glimpse gradient in LDS as well and is resident in two rounds either way, where
 // fewer, larger bands win (64 us against 71; 243 against 306 at 128 x 128).
 constexpr int SQ_CANVAS_PF_FWD = 5, SQ_CANVAS_ROWS_FWD = 2, SQ_CANVAS_PF_BWD = 10, SQ_CANVAS_ROWS_BWD = 4;
+// Frames wider than 64 pixels (BASELINE configs[4]: 128 x 128): band heights that are whole patch trips.  The 32 x 8-thread patch
+// walks a box in trips of 8 ROWS rows; with PF 5 a 128-wide band is 10 rows, of which a 16-row trip wastes six (ablation at cfg-5,
+// timeline build with early exits: prologue 9 us, pixel phase 25 us, BAND BUILDING 74 of the kernel's 106 us).  PF 4 / ROWS 1:
+// 8-row bands, one exact trip; the adjoint PF 8 / ROWS 2: 16-row bands.
+constexpr int SQ_CANVAS_WIDE = 64, SQ_CANVAS_PF_FWD_W = 4, SQ_CANVAS_ROWS_FWD_W = 1, SQ_CANVAS_PF_BWD_W = 8, SQ_CANVAS_ROWS_BWD_W = 2;
 
 // rows per band for a W-wide frame: as many whole rows as fit 256 PF pixels (host + device agree through the argument)
 static inline int sq_canvas_band_rows(int H, int W, int pf) {

@@ -991,6 +991,7 @@ int sq_launch_compact(const CompactArgs& a, POff po, Dims d, hipStream_t s) {
 // glimpses sit in LDS, the canvas is built band by band over the slots' boxes (sqair_canvas.h), then
 // every thread finishes its pixels of the band: the canvas is written at most once, the frame read once.
 // ------------------------------------------------------------------------------------------------
+template <int PF, int ROWS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_insert_loglik(const InsertArgs a, const Dims d, const int band_rows SQ_TLP) {
   SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1017,16 +1018,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   const float m_bg = sq_sigmoid(-10.0f);
   for (int yb0 = 0; yb0 < H; yb0 += band_rows) {
     const int yb1 = min(H, yb0 + band_rows) - 1, n = (yb1 - yb0 + 1) * W, pix0 = yb0 * W;
-    float xv[SQ_CANVAS_PF_FWD], mv[SQ_CANVAS_PF_FWD];  // the band's frame / mean-image values: in flight while the canvas is built
+    float xv[PF], mv[PF];  // the band's frame / mean-image values: in flight while the canvas is built
 #pragma unroll
-    for (int q = 0; q < SQ_CANVAS_PF_FWD; ++q) {
+    for (int q = 0; q < PF; ++q) {
       const int p = tid + q * 256;
       xv[q] = p < n ? img[pix0 + p] : 0.0f;
       mv[q] = p < n ? a.mean_img[pix0 + p] : 0.0f;
     }
-    sq_canvas_band<SQ_CANVAS_ROWS_FWD>(c, yb0, yb1, N, G, H, W);
+    sq_canvas_band<ROWS>(c, yb0, yb1, N, G, H, W);
 #pragma unroll
-    for (int q = 0; q < SQ_CANVAS_PF_FWD; ++q) {
+    for (int q = 0; q < PF; ++q) {
       const int p = tid + q * 256;
       const float msv = p < n ? c.ms[p] : 0.0f;
       const bool any_on = __builtin_amdgcn_ballot_w64(msv != 0.0f) != 0ull;   // (wave-uniform)
@@ -1064,10 +1065,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   }
 }
 int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s) {
-  const int band_rows = sq_canvas_band_rows(d.H, d.W, SQ_CANVAS_PF_FWD);
+  const bool wide = d.W > SQ_CANVAS_WIDE;
+  const int band_rows = sq_canvas_band_rows(d.H, d.W, wide ? SQ_CANVAS_PF_FWD_W : SQ_CANVAS_PF_FWD);
   const size_t shm = sq_canvas_lds_floats(d.N, d.G, d.H, d.W, band_rows) * sizeof(float);
-  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_insert_loglik, 150 * 1024) != 0) return -2;
-  SQ_LAUNCH(k_insert_loglik, dim3(d.R, a.n_frames > 0 ? a.n_frames : 1), dim3(256), shm, s, a, d, band_rows);
+  const dim3 grid(d.R, a.n_frames > 0 ? a.n_frames : 1);
+  if (wide) {
+    if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_insert_loglik<SQ_CANVAS_PF_FWD_W, SQ_CANVAS_ROWS_FWD_W>, 150 * 1024) != 0) return -2;
+    SQ_LAUNCH((k_insert_loglik<SQ_CANVAS_PF_FWD_W, SQ_CANVAS_ROWS_FWD_W>), grid, dim3(256), shm, s, a, d, band_rows);
+  } else {
+    if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_insert_loglik<SQ_CANVAS_PF_FWD, SQ_CANVAS_ROWS_FWD>, 150 * 1024) != 0) return -2;
+    SQ_LAUNCH((k_insert_loglik<SQ_CANVAS_PF_FWD, SQ_CANVAS_ROWS_FWD>), grid, dim3(256), shm, s, a, d, band_rows);
+  }
   return 0;
 }
 
