@@ -97,10 +97,15 @@ int sq_launch_wgrad_acc(const float* A, int lda, const float* dY, int ldy, float
 struct WgDesc {
   const float* A; const float* dY; float* dW; const int* rowmap; const float* alpha_ptr; float* db_a; float* db_b;
   int lda, ldy, ldw, M, Kdim, Ndim, kt, n_tiles;
-  int wg_begin, m_per_wg, zc, pad_;  // filled by flush(): first workgroup of the block, rows and number of its M-chunks
+  // filled by flush(): rows and number of the block's M-chunks; a chunk's tiles in `tg` groups of `gs` tiles (a group is what
+  // goes to ONE XCD together); qb[x] = the first of the block's zc * tg groups in XCD x's queue
+  int m_per_wg, zc, tg, gs;
+  unsigned short qb[8];
 };
-constexpr int SQ_WG_MAXD = 32;
-struct WgGroup { WgDesc d[SQ_WG_MAXD]; int nd; };
+constexpr int SQ_WG_MAXD = 96;
+// begin[x][i]: position in XCD x's queue where block i starts (i = nd: the queue's length; beyond: INT_MAX).  Workgroup b of the
+// launch is entry b / 8 of the queue of XCD b % 8 (workgroups are handed to the XCDs round-robin).
+struct WgGroup { WgDesc d[SQ_WG_MAXD]; int begin[8][SQ_WG_MAXD + 8]; int nd; };
 struct WgradBatch {
   std::vector<WgDesc> blocks;
   bool add(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim, const int* rowmap,

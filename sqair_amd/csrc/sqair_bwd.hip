@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <climits>
+#include <vector>
 
 typedef float f32x4_b __attribute__((ext_vector_type(4)));
 
@@ -573,25 +575,47 @@ __global__ __launch_bounds__(256) void k_wgrad2(const float* __restrict__ A, int
 #include "sqair_wgrad_kernel.inc"
 #undef SQ_KWGRAD_NAME
 #undef SQ_KWGRAD_BODY
+// the same body for the workgroups of k_wgrad_group
+#ifndef SQ_WGRAD_GROUP_WAVES
+#define SQ_WGRAD_GROUP_WAVES 4
+#endif
+#define SQ_KWGRAD_BODY wgrad1_body
+#define SQ_KWGRAD_WAVES SQ_WGRAD_GROUP_WAVES
+#include "sqair_wgrad_kernel.inc"
+#undef SQ_KWGRAD_BODY
+#undef SQ_KWGRAD_WAVES
 
 // All deferred blocks of a training step in ONE launch (WgradBatch, sqair_bwd.h): the blocks of the ~50 layers are
 // independent, each is far too small to fill the chip for long (a 256 x 256 block over 6400 rows is 0.84 GFLOP = 5 us of the
 // matrix cores, measured 20 us as its own launch: ramp-up, first-load latency, the LDS meeting and the atomics' drain are
 // each as long as the MFMAs), and back to back on one stream those fixed parts added up to 1.2 ms of a 9.9 ms step.  As one
-// grid of workgroups (a 64 x 64 tile x ~m_per_wg rows each) they overlap each other's fixed parts: 0.44 ms for the same
-// 62 blocks (32 GFLOP, 73 TFLOP/s); 100 TFLOP/s at 256 sequences per GPU.  The table of blocks travels in the kernel
-// arguments (<= 32 blocks a launch); a workgroup finds its block by a scalar walk.
-__global__ __launch_bounds__(256) void k_wgrad_group(const WgGroup g SQ_TLP) {
+// grid of workgroups (a 64 x 64 tile x m_per_wg rows each) they overlap each other's fixed parts.  The table of blocks
+// travels in the kernel arguments (15 KB; 32 KB arguments were checked to work, also inside a captured graph).
+//
+// Placement.  The tiles of an M-chunk read the same operand rows, and workgroups are handed to the 8 XCDs round-robin: with
+// the tile index fastest, the 16 tiles of a 256 x 256 block's chunk sat on 8 XCDs and every L2 pulled its own copy of the rows
+// over the fabric (PMC: 1.19 GB per launch at cfg-2, 2.4 GB per step in 0.46 ms -- at the fabric's limit).  Now the host deals
+// GROUPS (a chunk's tiles, at most 32 of them) to eight per-XCD queues, always to the queue with the least work so far;
+// workgroup b runs entry b / 8 of the queue of XCD b % 8, so a group's workgroups are dispatched back to back onto one XCD and
+// walk the rows together: one of them misses, the others hit (0.37 GB per launch).
+__global__ __launch_bounds__(64 * SQ_WGRAD_GROUP_WAVES) void k_wgrad_group(const WgGroup g SQ_TLP) {
   SQ_TL_SCOPE;
   extern __shared__ __attribute__((aligned(16))) float red3[];
+  const int x = (int)blockIdx.x & 7, pos = (int)blockIdx.x >> 3;
+  // the block this queue entry belongs to: all starts of the queue in one batch of scalar loads, then a count (a serial walk
+  // was one dependent scalar load per block ahead of the workgroup's first operand request)
   int i = 0;
-  while (i + 1 < g.nd && (int)blockIdx.x >= g.d[i + 1].wg_begin) ++i;
+#pragma unroll
+  for (int j = 1; j <= SQ_WG_MAXD; ++j) i += g.begin[x][j] <= pos ? 1 : 0;
+  if (i >= g.nd) return;  // past the end of this XCD's queue
   const WgDesc& e = g.d[i];
-  const int local = (int)blockIdx.x - e.wg_begin;
-  // (Placing M-chunk z on XCD z % 8, so that an XCD pulls only its eighth of the operand rows over the fabric and the tiles'
-  // re-reads hit its L2, was measured neutral at 32 and at 256 sequences per GPU: the kernel is not fabric-bound.)
-  const int tile = local % e.n_tiles, zi = local / e.n_tiles;
-  wgrad3_body(e.A, e.lda, e.dY, e.ldy, e.dW, e.ldw, e.M, e.Kdim, e.Ndim, e.rowmap, e.alpha_ptr, e.db_a, e.db_b, e.m_per_wg, e.kt, tile, zi, red3);
+  const int rel = pos - g.begin[x][i];
+  const int m = rel / e.gs, tl = rel - m * e.gs;
+  const int q = (int)e.qb[x] + m;          // which of the block's zc * tg groups
+  const int zi = q / e.tg, r = q - zi * e.tg;
+  const int tile = r * e.gs + tl;
+  if (tile >= e.n_tiles) return;           // the last group of a chunk may be short
+  wgrad1_body(e.A, e.lda, e.dY, e.ldy, e.dW, e.ldw, e.M, e.Kdim, e.Ndim, e.rowmap, e.alpha_ptr, e.db_a, e.db_b, e.m_per_wg, e.kt, tile, zi, red3);
 }
 // what the float4 operand loads of wgrad3_body need: 16-byte aligned rows, and a width that is not a multiple of 4 padded
 // inside its row
@@ -606,6 +630,7 @@ static bool wgrad3_eligible(const float* A, int lda, const float* dY, int ldy, i
   return wgrad3_operands_ok(A, lda, dY, ldy, Kdim, Ndim) && Kdim % 4 == 0 && Ndim % 4 == 0 && Kdim >= 48 && Ndim >= 48 && M >= 256;
 }
 static const size_t WG3_LDS = (4 * 4096 + 256) * sizeof(float);
+static const size_t WG1_LDS = SQ_WGRAD_GROUP_WAVES * (4096 + 64) * sizeof(float);  // k_wgrad_group: a tile + its column sums per wave
 bool WgradBatch::add(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int Kdim, int Ndim, const int* rowmap,
                      const float* alpha_ptr, float* db_a, float* db_b) {
   static const bool grouped = SQ_KNOB_INT("SQAIR_WGRAD_GROUP", 1) != 0;
@@ -613,36 +638,76 @@ bool WgradBatch::add(const float* A, int lda, const float* dY, int ldy, float* d
   WgDesc e;
   e.A = A; e.dY = dY; e.dW = dW; e.rowmap = rowmap; e.alpha_ptr = alpha_ptr; e.db_a = db_a; e.db_b = db_b;
   e.lda = lda; e.ldy = ldy; e.ldw = ldw; e.M = M; e.Kdim = Kdim; e.Ndim = Ndim;
-  e.kt = (Kdim + 63) / 64; e.n_tiles = e.kt * ((Ndim + 63) / 64); e.wg_begin = 0;
+  e.kt = (Kdim + 63) / 64; e.n_tiles = e.kt * ((Ndim + 63) / 64);
   blocks.push_back(e);
   return true;
 }
-int WgradBatch::flush(hipStream_t s) {
-  static const int rows = SQ_KNOB_INT("SQAIR_WGRAD_ROWS", 2048);  // target rows of a workgroup
-  static const bool dump = SQ_KNOB_SET("SQAIR_WGRAD_DUMP");  // print the block table of every flush
-  if (sq_allow_big_lds((const void*)k_wgrad_group, (int)WG3_LDS) != 0) return -2;
-  for (size_t i0 = 0; i0 < blocks.size(); i0 += SQ_WG_MAXD) {
-    WgGroup g;
-    memset(&g, 0, sizeof(g));
-    g.nd = (int)std::min(blocks.size() - i0, (size_t)SQ_WG_MAXD);
-    int total = 0;
-    for (int i = 0; i < g.nd; ++i) {
-      WgDesc& e = g.d[i];
-      e = blocks[i0 + i];
-      // equal chunks of about `rows` rows, at least 8 of them for a block with many rows (4 waves x a multiple of 4 rows each;
-      // the kernel masks a partial last step)
-      e.zc = e.M >= 2048 ? 8 * std::max(1, (e.M + 4 * rows) / (8 * rows)) : (e.M + rows - 1) / rows;
-      e.m_per_wg = ((e.M + e.zc - 1) / e.zc + 15) / 16 * 16;
-      e.zc = (e.M + e.m_per_wg - 1) / e.m_per_wg;
-      e.wg_begin = total;
-      total += e.n_tiles * e.zc;
+// The launch as the host sees it: eight queues (one per XCD) of workgroups.  wg_plan() cuts every block into chunks of about
+// `rows` rows and deals the groups.  Chunk length: a workgroup's life is a fixed part (ramp, tile to LDS, sums, atomics,
+// turnover: ~8 us) plus ~0.033 us per row (tools/wgrad_floor.hip, stamped launch), so long chunks amortise the fixed part and
+// short ones fill the last round.  A list-scheduling model of that (per-XCD queues, 64 slots each) preferred 2560-3200 rows;
+// measured (A / B of the training step, chunk length 800 ... 3200) the optimum is ~1280 at cfg-2, cfg-4 and at 256 sequences
+// per GPU alike (cfg-2: 800 +22 us, 1280 0, 1600 +3, 2048 +20, 2560 +18, 3200 +29), so 1280 it is and the model is gone.
+static const double WG_FIXED_US = 8.0, WG_US_PER_ROW = 0.033;   // only the RATIO matters: the relative cost of groups when dealing
+static int wg_plan(std::vector<WgDesc>& bl, size_t i0, int nd, int rows, WgGroup* g, int* grid) {
+  double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < nd; ++i) {
+    WgDesc& e = g->d[i];
+    e = bl[i0 + i];
+    e.zc = std::max(1, (e.M + rows / 2) / rows);
+    e.m_per_wg = ((e.M + e.zc - 1) / e.zc + 15) / 16 * 16;   // 4 waves x a multiple of 4 rows; the kernel masks a partial last step
+    e.zc = (e.M + e.m_per_wg - 1) / e.m_per_wg;
+    e.tg = (e.n_tiles + 31) / 32;
+    e.gs = (e.n_tiles + e.tg - 1) / e.tg;
+  }
+  // long workgroups first (stable: blocks of one length keep the order of the backward pass)
+  std::stable_sort(g->d, g->d + nd, [](const WgDesc& a, const WgDesc& b) { return a.m_per_wg > b.m_per_wg; });
+  for (int i = 0; i < nd; ++i) {
+    WgDesc& e = g->d[i];
+    const double cost = e.gs * (WG_FIXED_US + WG_US_PER_ROW * e.m_per_wg);
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < e.zc * e.tg; ++q) {
+      int best = 0;
+      for (int x = 1; x < 8; ++x)
+        if (load[x] < load[best]) best = x;
+      ++cnt[best];
+      load[best] += cost;
     }
-    if (dump)
-      for (int i = 0; i < g.nd; ++i)
-        fprintf(stderr, "wgrad block %2d: M %6d K %4d N %4d  tiles %3d  workgroups %5d  useful %.2f\n", (int)(i0 + i), g.d[i].M, g.d[i].Kdim,
-                g.d[i].Ndim, g.d[i].n_tiles, g.d[i].n_tiles * g.d[i].zc,
-                (double)g.d[i].Kdim * g.d[i].Ndim / (4096.0 * g.d[i].n_tiles));
-    SQ_LAUNCH(k_wgrad_group, dim3(total), dim3(256), WG3_LDS, s, g);
+    int acc = 0;
+    for (int x = 0; x < 8; ++x) {
+      g->begin[x][i] = len[x];
+      e.qb[x] = (unsigned short)acc;
+      acc += cnt[x];
+      len[x] += cnt[x] * e.gs;
+    }
+    if (acc > 65535) return -1;
+  }
+  int longest = 0;
+  for (int x = 0; x < 8; ++x) {
+    for (int j = nd; j < SQ_WG_MAXD + 8; ++j) g->begin[x][j] = j == nd ? len[x] : INT_MAX;
+    longest = std::max(longest, len[x]);
+  }
+  g->nd = nd;
+  *grid = 8 * longest;
+  return 0;
+}
+int WgradBatch::flush(hipStream_t s) {
+  static const int rows = SQ_KNOB_INT("SQAIR_WGRAD_ROWS", 1280);  // target rows of a workgroup
+  static const bool dump = SQ_KNOB_SET("SQAIR_WGRAD_DUMP");  // print the block table of every flush
+  if (WG1_LDS > 65536 && sq_allow_big_lds((const void*)k_wgrad_group, (int)WG1_LDS) != 0) return -2;
+  for (size_t i0 = 0; i0 < blocks.size(); i0 += SQ_WG_MAXD) {
+    const int nd = (int)std::min(blocks.size() - i0, (size_t)SQ_WG_MAXD);
+    static thread_local WgGroup g;   // 15 KB
+    int grid = 0;
+    if (wg_plan(blocks, i0, nd, rows, &g, &grid) != 0) return -3;
+    if (dump) {
+      fprintf(stderr, "wgrad launch: %d blocks, chunk length %d, %d workgroups\n", nd, rows, grid);
+      for (int i = 0; i < nd; ++i)
+        fprintf(stderr, "wgrad block %2d: M %6d K %4d N %4d  tiles %3d  chunks %3d x %4d rows  useful %.2f\n", i, g.d[i].M, g.d[i].Kdim,
+                g.d[i].Ndim, g.d[i].n_tiles, g.d[i].zc, g.d[i].m_per_wg, (double)g.d[i].Kdim * g.d[i].Ndim / (4096.0 * g.d[i].n_tiles));
+    }
+    SQ_LAUNCH(k_wgrad_group, dim3(grid), dim3(64 * SQ_WGRAD_GROUP_WAVES), WG1_LDS, s, g);
   }
   blocks.clear();
   return 0;

@@ -16,7 +16,7 @@ python - <<PY
 import json
 j = json.load(open("$REPO/gpurun_out/${TAG}_hbm_traffic${SFX}.json"))
 for k, v in sorted(j["family_bytes_per_launch"].items()):
-    if k.split("<")[0] in ("k_crop_row", "k_insert_loglik", "k_compact", "k_logprob", "k_crop_chain_bwd", "k_insert_loglik_bwd", "k_logprob_bwd", "k_compact_bwd"):
+    if k.split("<")[0] in ("k_crop_row", "k_insert_loglik", "k_compact", "k_logprob", "k_crop_chain_bwd", "k_insert_loglik_bwd", "k_logprob_bwd", "k_compact_bwd", "k_wgrad_group", "k_linear_big", "k_linear_mt"):
         print("%-24s %10.0f bytes / launch" % (k, v))
 print("dominant", j["dominant"], j["dominant_bytes_per_launch"])
 PY

@@ -8,6 +8,16 @@
 #include <vector>
 #include "sqair_common.h"   // SQ_TLP / SQ_TL_SCOPE (nothing in the product build)
 typedef float f32x4_b __attribute__((ext_vector_type(4)));
+// the stamped variant: every wave writes the device wall clock (100 MHz) at five points of its life
+__device__ unsigned long long* g_stamps;
+#define SQ_ABL_WG_STAMP(i) if ((threadIdx.x & 63) == 0) g_stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64();
+#define SQ_KWGRAD_NAME k_stamped
+#define SQ_KWGRAD_BODY b_stamped
+#include "sqair_wgrad_kernel.inc"
+#undef SQ_KWGRAD_NAME
+#undef SQ_KWGRAD_BODY
+#undef SQ_ABL_WG_STAMP
+#define SQ_ABL_WG_STAMP(i)
 #define SQ_KWGRAD_NAME k_full
 #define SQ_KWGRAD_BODY b_full
 #include "sqair_wgrad_kernel.inc"
@@ -108,6 +118,32 @@ int main(int argc, char** argv) {
       const double us = ms * 1e3 / reps;
       printf("  %-22s %s operands: %7.2f us / launch  (%.1f TFLOP/s)\n", v.name, rot ? "rotating" : "same    ", us, 2.0 * M * K * N / us * 1e-6);
     }
+  }
+  {  // where a wave's time goes: one stamped launch (after a warm one)
+    unsigned long long* st; CK(hipMalloc(&st, (size_t)grid * 4 * 8 * 8)); CK(hipMemset(st, 0, (size_t)grid * 4 * 8 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &st, sizeof(st)));
+    CK(hipFuncSetAttribute((const void*)k_stamped, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    for (int it = 0; it < 2; ++it)
+      hipLaunchKernelGGL(k_stamped, dim3(grid), dim3(256), shm, s, A, K, dY, N, dW, N, M, K, N, nullptr, nullptr, db, nullptr, m_per_wg, kt, n_tiles);
+    CK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h((size_t)grid * 32);
+    CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    double seg[4] = {0, 0, 0, 0};
+    for (int w = 0; w < grid * 4; ++w) {
+      const unsigned long long* p = &h[(size_t)w * 8];
+      if (p[0] < t0) t0 = p[0];
+      if (p[4] > t1) t1 = p[4];
+      for (int i = 0; i < 4; ++i) seg[i] += (double)(p[i + 1] - p[i]);
+    }
+    const double nw = grid * 4.0, tick = 0.01;
+    printf("  stamped launch: span %.1f us; mean wave: entry->loads issued %.2f, loop %.2f, tile to LDS + barrier %.2f, sums + atomics %.2f us\n",
+           (t1 - t0) * tick, seg[0] / nw * tick, seg[1] / nw * tick, seg[2] / nw * tick, seg[3] / nw * tick);
+    // start times of the waves in dispatch order: when does round 2 begin?
+    std::vector<double> starts;
+    for (int w = 0; w < grid * 4; w += 4) starts.push_back((h[(size_t)w * 8] - t0) * tick);
+    printf("  workgroup start (us after the first) at workgroup 0, 1/4, 1/2, 3/4, last: %.1f %.1f %.1f %.1f %.1f\n", starts[0], starts[grid / 4],
+           starts[grid / 2], starts[3 * grid / 4], starts[grid - 1]);
   }
   return 0;
 }
