@@ -148,7 +148,7 @@ def timeline_roofline(F, Ftr, hw, P, obs, nums, algo_flops_step, ms_fwd, ms_trai
     T, B = int(obs.shape[0]), int(obs.shape[1])
     K, N = int(F.k_particles), int(F.n_steps_per_image)
     core_t, model_t = TL.make_model(F, hw, P, obs, nums, timeline=True, device="cuda:{}".format(torch.cuda.current_device()))
-    tl = TL.Timeline(core_t)
+    tl = TL.Timeline(core_t, mbytes=768 * max(1, B // 32))
     n = [0]
 
     def fwd():

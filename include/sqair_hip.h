@@ -289,7 +289,7 @@ int sqair_check_finite(SqairHandle* h, const float* x, int64_t n, const char* wh
  * _begin (sqair_timeline_available() == 0) and carries none of this in its kernels. */
 int sqair_timeline_available(void);
 int sqair_timeline_begin(SqairHandle* h, void* buf, int64_t bytes);
-int sqair_timeline_count(const SqairHandle* h);  /* records so far (recording continues) */
+int sqair_timeline_count(const SqairHandle* h);  /* records so far (recording continues); -4 once the stamp buffer has overflowed */
 int sqair_timeline_end(SqairHandle* h);
 int sqair_timeline_record(const SqairHandle* h, int i, const char** kernel, int64_t* offset_u64, int* waves, int* workgroups);
 

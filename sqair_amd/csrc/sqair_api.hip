@@ -1327,7 +1327,11 @@ extern "C" int sqair_timeline_begin(SqairHandle* h, void* buf, int64_t bytes) {
   g_tl.owner = h; g_tl.buf = (unsigned long long*)buf; g_tl.cap = bytes / 8; g_tl.on = true;
   return 0;
 }
-extern "C" int sqair_timeline_count(const SqairHandle* h) { return (h && g_tl.owner == h) ? (int)g_tl.rec.size() : -1; }
+extern "C" int sqair_timeline_count(const SqairHandle* h) {
+  if (!h || g_tl.owner != h) return -1;
+  if (g_tl.overflow) return -4;   // dispatches since the overflow carry no stamps: a partial timeline must not be read as a whole one
+  return (int)g_tl.rec.size();
+}
 extern "C" int sqair_timeline_end(SqairHandle* h) {
   if (!h) return -1;
   if (g_tl.owner != h) { sq_set_error(h, "sqair_timeline_end: this handle owns no recording"); return -6; }

@@ -36,6 +36,8 @@ class Timeline(object):
     Create it BEFORE the core captures a graph (the slot addresses are kernel arguments frozen at capture time)."""
 
     def __init__(self, core, mbytes=768):
+        """`mbytes`: the stamp buffer (16 bytes per wave of every dispatch issued while recording, eager launches included: the
+        headline configuration needs ~30 MB per training step; scale it with the batch)."""
         if core.lib.sqair_timeline_available() != 1:
             raise RuntimeError("Timeline needs a SqairCore(lib_path=_capi.TIMELINE_LIB_PATH)")
         self.core = core
@@ -50,6 +52,9 @@ class Timeline(object):
     def records(self):
         lib, h = self.core.lib, self.core.handle
         n = lib.sqair_timeline_count(h)
+        if n == -4:
+            raise RuntimeError("the timeline's stamp buffer ({} MB) overflowed: later dispatches carry no stamps; "
+                               "give Timeline(core, mbytes=...) more".format(self.buf.numel() * 8 >> 20))
         out = []
         name, off, waves, wgs = C.c_char_p(), C.c_int64(), C.c_int(), C.c_int()
         for i in range(n):

@@ -102,7 +102,7 @@ def main():
     del tr_p, model_p, core_p
 
     core_t, model_t = TL.make_model(F, hw, P, obs, nums, timeline=True)
-    tl = TL.Timeline(core_t)
+    tl = TL.Timeline(core_t, mbytes=768 * max(1, B // 32))
     tr_t = Trainer(model_t, Ftr, use_graph=True)
     for name, step_t, train in (("fwd", fwd_step(core_t), False),
                                 ("train", lambda: tr_t.step(seed=2000, global_batch=B, b0=0), True)):
