@@ -159,3 +159,74 @@ __device__ __forceinline__ void sq_canvas_band(const CanvasLds& c, int yb0, int 
     __syncthreads();
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Round 4, frames wider than a wavefront (BASELINE configs[4], 128 x 128): the ROW-WAVE formulation.  The band builder above
+// spends its time in LDS read-modify-writes of the band, a barrier per (band, slot) and ~60 VALU instructions per tap, all of
+// which re-derive quantities that depend on the pixel's COLUMN only (x tap, x weights) or on its ROW only (y tap, y weights).
+// Here a wavefront owns whole canvas rows (lane l holds columns l, l + 64, ...), so
+//   * the column half of every slot's tap -- byte offset of the left texel, its two weights -- is computed ONCE per workgroup and
+//     stays in registers (3 per slot and column),
+//   * the row half -- byte offset of the upper glimpse row, presence-scaled weights -- is a 16-byte record per (slot, row) in LDS
+//     which all lanes of the wave read at one address (a broadcast), "row inside the slot's box" is a wave-uniform branch, and so is
+//     "this 64-column half of the row meets the box",
+//   * a pixel inside a box costs two ds_read2 (texel pairs of the two glimpse rows) and nine VALU instructions, a pixel outside
+//     nothing; canvas and mask sum accumulate in registers: no band, no read-modify-write, no barrier after the prologue.
+// Both taps of an axis are taken at i, i + 1 with i clamped to [0, G - 2]; a tap that falls outside the glimpse gets weight
+// zero on the texel that stands in for it (the reference's resampler adds nothing for it either).
+// ------------------------------------------------------------------------------------------------
+struct CanvasAxisTap { int i; float wa, wb; };   // texels i, i + 1 (0 <= i <= G - 2) with weights wa, wb; both 0 outside (-1, G)
+__device__ __forceinline__ CanvasAxisTap sq_canvas_axis_tap(float g, int G) {
+  CanvasAxisTap t;
+  const float f0 = floorf(g);
+  const int i0 = (int)f0;
+  const float fr = g - f0;
+  const bool in = sq_canvas_inside(g, G);
+  // i0 == -1: only the right tap (texel 0) exists; i0 == G - 1: only the left tap (texel G - 1)
+  t.i = min(max(i0, 0), G - 2);
+  const float wl = 1.0f - fr, wr = fr;
+  t.wa = !in ? 0.0f : (i0 < 0 ? wr : (i0 > G - 2 ? 0.0f : wl));
+  t.wb = !in ? 0.0f : (i0 < 0 ? 0.0f : (i0 > G - 2 ? wl : wr));
+  return t;
+}
+__device__ __forceinline__ float sq_canvas_coord(int j, int L, float sc, float tr, int G) {   // as sq_canvas_prologue's tables
+  const float cn = -1.0f + 2.0f * (float)j / (float)(L - 1);
+  return 0.5f * (float)(G - 1) * ((cn - tr) / sc + 1.0f);
+}
+struct CanvasRowsLds {
+  float* gl;     // [N][G2]
+  float4* yrec;  // [N][H]  {byte offset of glimpse row i of slot k inside gl, pk wa, pk wb, pk (wa + wb)}; all 0 outside the box
+  float* co;     // [N][4]
+  float* pres;   // [N]
+};
+__host__ __device__ static inline size_t sq_canvas_rows_lds_floats(int N, int G, int H) {
+  return (size_t)((N * G * G + 3) & ~3) + 4 * (size_t)N * H + 4 * N + N;
+}
+__device__ __forceinline__ CanvasRowsLds sq_canvas_rows_carve(float* smem, int N, int G, int H) {
+  CanvasRowsLds c;
+  c.gl = smem;
+  c.yrec = reinterpret_cast<float4*>(smem + ((N * G * G + 3) & ~3));
+  c.co = reinterpret_cast<float*>(c.yrec + N * H);
+  c.pres = c.co + 4 * N;
+  return c;
+}
+// glimpses, coefficients, presences and the row records of one (row, frame); ends on a barrier
+__device__ __forceinline__ void sq_canvas_rows_prologue(const CanvasRowsLds& c, const float* __restrict__ glimpse, const float* __restrict__ where0,
+                                                        int where_ld, const float* __restrict__ pres0, int pres_ld, int N, int G, int H) {
+  const int tid = threadIdx.x, G2 = G * G;
+  sq_wave_stage(c.gl, glimpse, N * G2, tid & 63, tid >> 6, 4);   // (LDS-DMA: lands by the barriers below)
+  if (tid < N * 4) {
+    const int k = tid >> 2, q = tid & 3;
+    const float l = where0[(size_t)k * where_ld + q];
+    c.co[tid] = (q & 2) ? tanhf(l) : fmaxf(sq_sigmoid_geo(l), 1e-4f);
+  }
+  if (tid < N) c.pres[tid] = pres0[(size_t)tid * pres_ld];
+  __syncthreads();
+  for (int i = tid; i < N * H; i += 256) {
+    const int k = i / H, y = i - k * H;
+    const float pk = c.pres[k];
+    const CanvasAxisTap t = sq_canvas_axis_tap(sq_canvas_coord(y, H, c.co[k * 4 + 1], c.co[k * 4 + 3], G), G);
+    c.yrec[i] = make_float4(__builtin_bit_cast(float, (k * G2 + t.i * G) * 4), pk * t.wa, pk * t.wb, pk * (t.wa + t.wb));
+  }
+  __syncthreads();
+}

@@ -1064,11 +1064,131 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
   }
 }
+// The same for frames wider than a wavefront, ROW-WAVE formulation (sqair_canvas.h): wave w owns rows w, w + 4, ...; lane l the
+// columns l + 64 c, c < CPL.  NMAX bounds the slots whose column taps a thread keeps in registers (3 NMAX CPL VGPRs).
+template <int NMAX, int CPL>
+__global__ __launch_bounds__(256) void k_insert_loglik_rows(const InsertArgs a, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = d.N, G = d.G, G2 = d.G * d.G, H = d.H, W = d.W, P = d.H * d.W;
+  const CanvasRowsLds c = sq_canvas_rows_carve(smem, N, G, H);
+  __shared__ float red_s[4];
+  const int r = sq_row_of_wg(blockIdx.x, d), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = blockIdx.y;  // frame
+  const int b = sq_div(r, d.k_mul);
+  const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot of this (frame, row)
+  const float* __restrict__ img = a.img + ((size_t)fr * d.B + b) * d.P4;
+  const size_t frr = (size_t)fr * d.R + r;
+  const float qv = a.qz != nullptr ? a.qz[frr] : 0.0f, pv = a.qz != nullptr ? a.pz[frr] : 0.0f;  // requested early
+  if (a.rec) sq_canvas_rows_prologue(c, a.glimpse + fs * G2, a.rec + fs * a.rec_ld + rec::WHERE, a.rec_ld, a.rec + fs * a.rec_ld + rec::PRES, a.rec_ld, N, G, H);
+  else sq_canvas_rows_prologue(c, a.glimpse + fs * G2, a.where_plain + (size_t)r * N * 4, 4, a.pres_plain + (size_t)r * N, 1, N, G, H);
+  // column taps of this thread's CPL columns for every slot; which 64-column halves a slot's box meets (wave-uniform)
+  int xo[NMAX][CPL];
+  float wa[NMAX][CPL], wb[NMAX][CPL];
+  bool half_on[NMAX][CPL];
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k)
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      CanvasAxisTap t{0, 0.0f, 0.0f};
+      const int x = lane + 64 * q;
+      if (k < N && x < W) t = sq_canvas_axis_tap(sq_canvas_coord(x, W, c.co[k * 4 + 0], c.co[k * 4 + 2], G), G);
+      xo[k][q] = t.i * 4;
+      wa[k][q] = t.wa;
+      wb[k][q] = t.wb;
+      half_on[k][q] = __builtin_amdgcn_ballot_w64(t.wa + t.wb != 0.0f) != 0ull;
+    }
+  const bool one_sd = a.std_fg == a.std_bg;
+  const float inv_sd = 1.0f / a.std_fg, lp0 = -logf(a.std_fg) - 0.91893853320467274178f;
+  const float m_bg = sq_sigmoid(-10.0f);
+  const char* __restrict__ glb = reinterpret_cast<const char*>(c.gl);
+  const int G4 = G * 4;
+  float ll = 0.0f;
+  for (int y = wave; y < H; y += 4) {
+    float xv[CPL], mv[CPL], cv[CPL], ms[CPL];
+    bool on[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const int x = lane + 64 * q;
+      xv[q] = x < W ? img[y * W + x] : 0.0f;
+      mv[q] = x < W ? a.mean_img[y * W + x] : 0.0f;
+      cv[q] = 0.0f;
+      ms[q] = 0.0f;
+      on[q] = false;
+    }
+    float4 yrs[NMAX];   // (one address for the wave: broadcasts, all requested before the first is looked at)
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) yrs[k] = c.yrec[min(k, N - 1) * H + y];
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      if (k >= N) break;
+      const float4 yr = yrs[k];
+      if (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, yr.w)) == 0) continue;   // row outside the box / slot absent
+      const int ro = __builtin_bit_cast(int, yr.x);
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        if (!half_on[k][q]) continue;
+        const float* pa = reinterpret_cast<const float*>(glb + (xo[k][q] + ro));
+        const float* pb = reinterpret_cast<const float*>(glb + (xo[k][q] + ro + G4));
+        const float a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+        const float t0 = fmaf(wb[k][q], a1, wa[k][q] * a0), t1 = fmaf(wb[k][q], b1, wa[k][q] * b0);
+        cv[q] = fmaf(yr.y, t0, cv[q]);
+        cv[q] = fmaf(yr.z, t1, cv[q]);
+        ms[q] = fmaf(yr.w, wa[k][q] + wb[k][q], ms[q]);
+        on[q] = true;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const int x = lane + 64 * q;
+      if (x < W) {
+        const float m = on[q] ? sq_sigmoid(-10.0f + ms[q] * 20.0f) : m_bg;   // (on: wave-uniform)
+        const float cvv = cv[q] + mv[q] * m;
+        if (one_sd) {
+          const float dd = (xv[q] - cvv) * inv_sd;
+          ll += fmaf(-0.5f * dd, dd, lp0);
+        } else {
+          const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
+          ll += sq_normal_lp(xv[q], cvv, sd);
+        }
+        if (a.canvas) a.canvas[frr * P + y * W + x] = cvv;
+      }
+    }
+  }
+  ll = sq_wave_sum(ll);
+  if (lane == 0) red_s[wave] = ll;
+  __syncthreads();
+  if (tid == 0) {
+    const float dll = red_s[0] + red_s[1] + red_s[2] + red_s[3];
+    a.data_ll[frr] = dll;
+    if (a.qz != nullptr) {
+      const size_t tr = (size_t)a.t * d.R + frr;
+      const float kl = qv - pv;
+      if (a.out.data_ll_per_sample) a.out.data_ll_per_sample[tr] = dll;
+      if (a.out.kl_per_sample) a.out.kl_per_sample[tr] = kl;
+      if (a.out.log_q_z_given_x_per_sample) a.out.log_q_z_given_x_per_sample[tr] = qv;
+      if (a.out.log_p_z_per_sample) a.out.log_p_z_per_sample[tr] = pv;
+      if (a.out.log_weights_per_timestep) a.out.log_weights_per_timestep[tr] = dll - kl;
+    }
+  }
+}
+template <int NMAX, int CPL>
+static int launch_insert_rows(const InsertArgs& a, const Dims& d, dim3 grid, hipStream_t s) {
+  const size_t shm = sq_canvas_rows_lds_floats(d.N, d.G, d.H) * sizeof(float);
+  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_insert_loglik_rows<NMAX, CPL>, 150 * 1024) != 0) return -2;
+  SQ_LAUNCH((k_insert_loglik_rows<NMAX, CPL>), grid, dim3(256), shm, s, a, d);
+  return 0;
+}
 int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s) {
   const bool wide = d.W > SQ_CANVAS_WIDE;
   const int band_rows = sq_canvas_band_rows(d.H, d.W, wide ? SQ_CANVAS_PF_FWD_W : SQ_CANVAS_PF_FWD);
   const size_t shm = sq_canvas_lds_floats(d.N, d.G, d.H, d.W, band_rows) * sizeof(float);
   const dim3 grid(d.R, a.n_frames > 0 ? a.n_frames : 1);
+  // frames of 65 .. 256 columns with up to 8 slots: the row-wave kernel (cfg-5: 89 -> see DESIGN); everything else in bands
+  if (wide && d.W <= 256 && d.N <= 8 && d.G >= 2 && sq_canvas_rows_lds_floats(d.N, d.G, d.H) * sizeof(float) <= 150 * 1024) {
+    if (d.W <= 128) return d.N <= 4 ? launch_insert_rows<4, 2>(a, d, grid, s) : launch_insert_rows<8, 2>(a, d, grid, s);
+    return d.N <= 4 ? launch_insert_rows<4, 4>(a, d, grid, s) : launch_insert_rows<8, 4>(a, d, grid, s);
+  }
   if (wide) {
     if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_insert_loglik<SQ_CANVAS_PF_FWD_W, SQ_CANVAS_ROWS_FWD_W>, 150 * 1024) != 0) return -2;
     SQ_LAUNCH((k_insert_loglik<SQ_CANVAS_PF_FWD_W, SQ_CANVAS_ROWS_FWD_W>), grid, dim3(256), shm, s, a, d, band_rows);

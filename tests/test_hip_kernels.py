@@ -194,15 +194,17 @@ def test_st_crop(hw, masked):
         lib.sqair_destroy(h)
 
 
-@pytest.mark.parametrize("hw", [(50, 50), (128, 128)])
-def test_st_insert_loglik(hw):
+@pytest.mark.parametrize("hw,n_slots", [((50, 50), 4), ((128, 128), 4), ((77, 130), 4), ((40, 200), 3), ((128, 128), 7),
+                                        ((30, 250), 8), ((24, 300), 4), ((90, 65), 1)])
+def test_st_insert_loglik(hw, n_slots):
+    # 65 .. 256 columns and up to 8 slots: the row-wave kernel (sqair_canvas.h); the others the band kernel
     lib = _capi.lib()
-    F = make_flags(k_particles=2, n_steps_per_image=4)
+    F = make_flags(k_particles=2, n_steps_per_image=n_slots)
     cfg = make_config(F, hw)
     h = C.c_void_p()
     assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
     try:
-        B, K, N, G = 3, 2, 4, 20
+        B, K, N, G = 3, 2, n_slots, 20
         R = B * K
         H, W = hw
         rng = np.random.default_rng(3)
