@@ -163,18 +163,23 @@ __device__ __forceinline__ void sq_canvas_band(const CanvasLds& c, int yb0, int 
 // ------------------------------------------------------------------------------------------------
 // Round 4, frames wider than a wavefront (BASELINE configs[4], 128 x 128): the ROW-WAVE formulation.  The band builder above
 // spends its time in LDS read-modify-writes of the band, a barrier per (band, slot) and ~60 VALU instructions per tap, all of
-// which re-derive quantities that depend on the pixel's COLUMN only (x tap, x weights) or on its ROW only (y tap, y weights).
-// Here a wavefront owns whole canvas rows (lane l holds columns l, l + 64, ...), so
-//   * the column half of every slot's tap -- byte offset of the left texel, its two weights -- is computed ONCE per workgroup and
-//     stays in registers (3 per slot and column),
+// which re-derive quantities that depend on the pixel's COLUMN only (x tap, x weights) or on its ROW only (y tap, y weights) --
+// and the kernel is bound by VALU issue (a wave64 instruction occupies its SIMD16 for four cycles): 77 lane-operations per pixel
+// at 52 us.  Here a wavefront owns whole canvas rows, lane l the CPL adjacent columns CPL l .. CPL l + CPL - 1, so
+//   * the column half of every slot's tap -- byte offset of the left texel pair, its two weights -- is computed ONCE per workgroup
+//     and stays in registers (3 per slot and column),
 //   * the row half -- byte offset of the upper glimpse row, presence-scaled weights -- is a 16-byte record per (slot, row) in LDS
-//     which all lanes of the wave read at one address (a broadcast), "row inside the slot's box" is a wave-uniform branch, and so is
-//     "this 64-column half of the row meets the box",
-//   * a pixel inside a box costs two ds_read2 (texel pairs of the two glimpse rows) and nine VALU instructions, a pixel outside
-//     nothing; canvas and mask sum accumulate in registers: no band, no read-modify-write, no barrier after the prologue.
+//     which all lanes of the wave read at one address (a broadcast), and "row inside the slot's box" is a SCALAR comparison
+//     against row bounds held in SGPRs,
+//   * the glimpses lie in LDS as vertical PAIRS {g[y][x], g[y + 1][x]}: one ds_read2_b64 returns the four texels of a tap as two
+//     register pairs, which packed fp32 instructions (v_pk_mul / v_pk_fma: two lanes' worth per issue) combine,
+//   * canvas and mask sum accumulate in registers: no band, no read-modify-write, no barrier after the prologue.
 // Both taps of an axis are taken at i, i + 1 with i clamped to [0, G - 2]; a tap that falls outside the glimpse gets weight
 // zero on the texel that stands in for it (the reference's resampler adds nothing for it either).
 // ------------------------------------------------------------------------------------------------
+typedef float sq_f2 __attribute__((ext_vector_type(2)));
+typedef float sq_f4 __attribute__((ext_vector_type(4)));
+typedef float sq_f4a8 __attribute__((ext_vector_type(4), aligned(8)));   // four floats at an 8-byte boundary (ds_read2_b64)
 struct CanvasAxisTap { int i; float wa, wb; };   // texels i, i + 1 (0 <= i <= G - 2) with weights wa, wb; both 0 outside (-1, G)
 __device__ __forceinline__ CanvasAxisTap sq_canvas_axis_tap(float g, int G) {
   CanvasAxisTap t;
@@ -194,39 +199,59 @@ __device__ __forceinline__ float sq_canvas_coord(int j, int L, float sc, float t
   return 0.5f * (float)(G - 1) * ((cn - tr) / sc + 1.0f);
 }
 struct CanvasRowsLds {
-  float* gl;     // [N][G2]
-  float4* yrec;  // [N][H]  {byte offset of glimpse row i of slot k inside gl, pk wa, pk wb, pk (wa + wb)}; all 0 outside the box
-  float* co;     // [N][4]
-  float* pres;   // [N]
+  sq_f2* pr;       // [N][G - 1][G]  {g[y][x], g[y + 1][x]}
+  float4* yrec;    // [N][H]  {byte offset of pair row i of slot k inside pr, pk wa, pk wb, pk (wa + wb)}; weights 0 outside the box
+  unsigned* rmask; // [H]  bit k: row inside slot k's box (slot present, weights not both 0)
+  float* co;       // [N][4]
+  float* pres;     // [N]
 };
 __host__ __device__ static inline size_t sq_canvas_rows_lds_floats(int N, int G, int H) {
-  return (size_t)((N * G * G + 3) & ~3) + 4 * (size_t)N * H + 4 * N + N;
+  return (size_t)((2 * N * (G - 1) * G + 3) & ~3) + 4 * (size_t)N * H + H + 4 * N + N;
 }
 __device__ __forceinline__ CanvasRowsLds sq_canvas_rows_carve(float* smem, int N, int G, int H) {
   CanvasRowsLds c;
-  c.gl = smem;
-  c.yrec = reinterpret_cast<float4*>(smem + ((N * G * G + 3) & ~3));
-  c.co = reinterpret_cast<float*>(c.yrec + N * H);
+  c.pr = reinterpret_cast<sq_f2*>(smem);
+  c.yrec = reinterpret_cast<float4*>(smem + ((2 * N * (G - 1) * G + 3) & ~3));
+  c.rmask = reinterpret_cast<unsigned*>(c.yrec + N * H);
+  c.co = reinterpret_cast<float*>(c.rmask + H);
   c.pres = c.co + 4 * N;
   return c;
 }
-// glimpses, coefficients, presences and the row records of one (row, frame); ends on a barrier
+// glimpse pairs, coefficients, presences, the row records and row masks of one (row, frame); ends on a barrier.  NT threads; GL =
+// glimpse values a thread fetches (N G^2 <= NT GL); g_mul = sq_magic(G)
+template <int NT, int GL>
 __device__ __forceinline__ void sq_canvas_rows_prologue(const CanvasRowsLds& c, const float* __restrict__ glimpse, const float* __restrict__ where0,
-                                                        int where_ld, const float* __restrict__ pres0, int pres_ld, int N, int G, int H) {
-  const int tid = threadIdx.x, G2 = G * G;
-  sq_wave_stage(c.gl, glimpse, N * G2, tid & 63, tid >> 6, 4);   // (LDS-DMA: lands by the barriers below)
+                                                        int where_ld, const float* __restrict__ pres0, int pres_ld, int N, int G, int H, SqMagic g_mul) {
+  const int tid = threadIdx.x, G2 = G * G, n = N * G2;
+  float gv[GL];
+#pragma unroll
+  for (int u = 0; u < GL; ++u) gv[u] = glimpse[min(tid + NT * u, n - 1)];   // (clamped, unconditional: all in flight)
   if (tid < N * 4) {
     const int k = tid >> 2, q = tid & 3;
     const float l = where0[(size_t)k * where_ld + q];
     c.co[tid] = (q & 2) ? tanhf(l) : fmaxf(sq_sigmoid_geo(l), 1e-4f);
   }
   if (tid < N) c.pres[tid] = pres0[(size_t)tid * pres_ld];
+  for (int i = tid; i < H; i += NT) c.rmask[i] = 0u;
   __syncthreads();
-  for (int i = tid; i < N * H; i += 256) {
-    const int k = i / H, y = i - k * H;
-    const float pk = c.pres[k];
-    const CanvasAxisTap t = sq_canvas_axis_tap(sq_canvas_coord(y, H, c.co[k * 4 + 1], c.co[k * 4 + 3], G), G);
-    c.yrec[i] = make_float4(__builtin_bit_cast(float, (k * G2 + t.i * G) * 4), pk * t.wa, pk * t.wb, pk * (t.wa + t.wb));
+  for (int k = 0; k < N; ++k) {
+    const float pk = c.pres[k], sy = c.co[k * 4 + 1], ty = c.co[k * 4 + 3];
+    for (int y = tid; y < H; y += NT) {
+      const CanvasAxisTap t = sq_canvas_axis_tap(sq_canvas_coord(y, H, sy, ty, G), G);
+      const float sm = pk * (t.wa + t.wb);
+      c.yrec[k * H + y] = make_float4(__builtin_bit_cast(float, (k * (G - 1) + t.i) * G * 8), pk * t.wa, pk * t.wb, sm);
+      if (sm != 0.0f) atomicOr(&c.rmask[y], 1u << k);
+    }
+  }
+  float* prf = reinterpret_cast<float*>(c.pr);
+#pragma unroll
+  for (int u = 0; u < GL; ++u) {
+    const int i = tid + NT * u;
+    if (i < n) {
+      const int row = sq_div(i, g_mul), x = i - row * G, k = sq_div(row, g_mul), y = row - k * G;   // (no integer division)
+      if (y < G - 1) prf[((k * (G - 1) + y) * G + x) * 2] = gv[u];          // upper texel of pair row y
+      if (y > 0) prf[((k * (G - 1) + y - 1) * G + x) * 2 + 1] = gv[u];      // lower texel of pair row y - 1
+    }
   }
   __syncthreads();
 }

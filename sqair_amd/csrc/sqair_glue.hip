@@ -1065,101 +1065,190 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   }
 }
 // The same for frames wider than a wavefront, ROW-WAVE formulation (sqair_canvas.h): wave w owns rows w, w + 4, ...; lane l the
-// columns l + 64 c, c < CPL.  NMAX bounds the slots whose column taps a thread keeps in registers (3 NMAX CPL VGPRs).
-template <int NMAX, int CPL>
-__global__ __launch_bounds__(256) void k_insert_loglik_rows(const InsertArgs a, const Dims d SQ_TLP) {
+// CPL adjacent columns from CPL l.  NMAX bounds the slots whose column taps a thread keeps in registers (3 NMAX CPL VGPRs); FULLW:
+// W == 64 CPL (vector loads of the frame, no column guards).
+#ifndef SQ_ROWS_WPE
+#define SQ_ROWS_WPE(NMAX, CPL) ((NMAX) * (CPL) <= 8 ? 7 : 4)   // waves per SIMD the register allocation must leave room for
+#endif
+__device__ __forceinline__ sq_f2 sq_fma2(sq_f2 a, sq_f2 b, sq_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// sigmoid(-10 + 20 ms) for two pixels: sq_exp without its clamp and NaN select (the argument 10 - 20 ms lies in [-20 N + 10, 10]: no
+// overflow, 2^t underflows to 0 cleanly, a NaN stays a NaN), the same two-part product
+__device__ __forceinline__ sq_f2 sq_mask_sigmoid2(sq_f2 ms) {
+  const sq_f2 x = sq_fma2(ms, sq_f2{-20.0f, -20.0f}, sq_f2{10.0f, 10.0f});
+  const sq_f2 L2E = {1.44269504088896340736f, 1.44269504088896340736f};
+  const sq_f2 t = x * L2E;
+  const sq_f2 r = sq_fma2(x, L2E, -t) + x * sq_f2{1.92596299112661746e-8f, 1.92596299112661746e-8f};
+  const sq_f2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+  const sq_f2 ee = sq_fma2(e, r * sq_f2{0.69314718055994530942f, 0.69314718055994530942f}, e) + sq_f2{1.0f, 1.0f};
+  return sq_f2{__builtin_amdgcn_rcpf(ee.x), __builtin_amdgcn_rcpf(ee.y)};
+}
+template <int NMAX, int CPL, bool FULLW, bool ONE_SD, int WAVES, int PD>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SQ_ROWS_WPE(NMAX, CPL), 8))) void k_insert_loglik_rows(const InsertArgs a, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
+  static_assert(CPL == 2 || CPL == 4, "column pairs");
+  constexpr int NT = 64 * WAVES;
+  constexpr int CP = CPL / 2;   // column pairs per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.N, G = d.G, G2 = d.G * d.G, H = d.H, W = d.W, P = d.H * d.W;
   const CanvasRowsLds c = sq_canvas_rows_carve(smem, N, G, H);
-  __shared__ float red_s[4];
-  const int r = sq_row_of_wg(blockIdx.x, d), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float red_s[WAVES];
+  const int r = sq_row_of_wg(blockIdx.x, d), tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = blockIdx.y;  // frame
   const int b = sq_div(r, d.k_mul);
   const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot of this (frame, row)
-  const float* __restrict__ img = a.img + ((size_t)fr * d.B + b) * d.P4;
+  const char* __restrict__ img = reinterpret_cast<const char*>(a.img + ((size_t)fr * d.B + b) * d.P4);
+  const char* __restrict__ mean = reinterpret_cast<const char*>(a.mean_img);
   const size_t frr = (size_t)fr * d.R + r;
   const float qv = a.qz != nullptr ? a.qz[frr] : 0.0f, pv = a.qz != nullptr ? a.pz[frr] : 0.0f;  // requested early
-  if (a.rec) sq_canvas_rows_prologue(c, a.glimpse + fs * G2, a.rec + fs * a.rec_ld + rec::WHERE, a.rec_ld, a.rec + fs * a.rec_ld + rec::PRES, a.rec_ld, N, G, H);
-  else sq_canvas_rows_prologue(c, a.glimpse + fs * G2, a.where_plain + (size_t)r * N * 4, 4, a.pres_plain + (size_t)r * N, 1, N, G, H);
-  // column taps of this thread's CPL columns for every slot; which 64-column halves a slot's box meets (wave-uniform)
-  int xo[NMAX][CPL];
-  float wa[NMAX][CPL], wb[NMAX][CPL];
-  bool half_on[NMAX][CPL];
+  // frame / mean-image values of a row: one 32-bit byte offset per lane on two scalar bases; PD rows in flight -- the ring slot of a
+  // row is re-requested for the row PD trips ahead as soon as it has been read (a trip over a row no box meets is ~25 instructions:
+  // one row ahead does not cover a memory round trip)
+  sq_f2 xn[PD][CP], mn[PD][CP];
+  auto request = [&](int u, int yy) {
+    const int y = min(yy, H - 1);   // (scalar)
+    if (FULLW) {
+      const unsigned off = (unsigned)(y * W * 4) + (unsigned)lane * (CPL * 4);
+      if (CPL == 2) {
+        xn[u][0] = *reinterpret_cast<const sq_f2*>(img + off);
+        mn[u][0] = *reinterpret_cast<const sq_f2*>(mean + off);
+      } else {
+        const sq_f4 xx = *reinterpret_cast<const sq_f4*>(img + off), mm = *reinterpret_cast<const sq_f4*>(mean + off);
+        xn[u][0] = xx.xy; xn[u][CP - 1] = xx.zw; mn[u][0] = mm.xy; mn[u][CP - 1] = mm.zw;
+      }
+    } else {
 #pragma unroll
-  for (int k = 0; k < NMAX; ++k)
+      for (int q = 0; q < CP; ++q) {   // (clamped addresses, unconditional loads)
+        const unsigned o0 = (unsigned)(y * W + min(lane * CPL + 2 * q, W - 1)) * 4, o1 = (unsigned)(y * W + min(lane * CPL + 2 * q + 1, W - 1)) * 4;
+        xn[u][q] = sq_f2{*reinterpret_cast<const float*>(img + o0), *reinterpret_cast<const float*>(img + o1)};
+        mn[u][q] = sq_f2{*reinterpret_cast<const float*>(mean + o0), *reinterpret_cast<const float*>(mean + o1)};
+      }
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < PD; ++u) request(u, wave + WAVES * u);
+  if (a.rec) sq_canvas_rows_prologue<NT, (NMAX * 20 * 20 + NT - 1) / NT>(c, a.glimpse + fs * G2, a.rec + fs * a.rec_ld + rec::WHERE, a.rec_ld, a.rec + fs * a.rec_ld + rec::PRES, a.rec_ld, N, G, H, d.g_mul);
+  else sq_canvas_rows_prologue<NT, (NMAX * 20 * 20 + NT - 1) / NT>(c, a.glimpse + fs * G2, a.where_plain + (size_t)r * N * 4, 4, a.pres_plain + (size_t)r * N, 1, N, G, H, d.g_mul);
+  // column taps of this thread's CPL columns for every slot (registers)
+  int xo[NMAX][CPL];
+  sq_f2 wab[NMAX][CPL];        // {wa, wb}
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    const int kk = min(k, N - 1);
+    const float sx = c.co[kk * 4 + 0], tx = c.co[kk * 4 + 2];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
       CanvasAxisTap t{0, 0.0f, 0.0f};
-      const int x = lane + 64 * q;
-      if (k < N && x < W) t = sq_canvas_axis_tap(sq_canvas_coord(x, W, c.co[k * 4 + 0], c.co[k * 4 + 2], G), G);
-      xo[k][q] = t.i * 4;
-      wa[k][q] = t.wa;
-      wb[k][q] = t.wb;
-      half_on[k][q] = __builtin_amdgcn_ballot_w64(t.wa + t.wb != 0.0f) != 0ull;
+      const int x = lane * CPL + q;
+      if (k < N && (FULLW || x < W)) t = sq_canvas_axis_tap(sq_canvas_coord(x, W, sx, tx, G), G);
+      xo[k][q] = t.i * 8;
+      wab[k][q] = sq_f2{t.wa, t.wb};
     }
-  const bool one_sd = a.std_fg == a.std_bg;
-  const float inv_sd = 1.0f / a.std_fg, lp0 = -logf(a.std_fg) - 0.91893853320467274178f;
+  }
+  sq_f2 vw[CP];   // 1 for a column inside the frame
+#pragma unroll
+  for (int q = 0; q < CP; ++q) vw[q] = sq_f2{(FULLW || lane * CPL + 2 * q < W) ? 1.0f : 0.0f, (FULLW || lane * CPL + 2 * q + 1 < W) ? 1.0f : 0.0f};
   const float m_bg = sq_sigmoid(-10.0f);
-  const char* __restrict__ glb = reinterpret_cast<const char*>(c.gl);
-  const int G4 = G * 4;
-  float ll = 0.0f;
-  for (int y = wave; y < H; y += 4) {
-    float xv[CPL], mv[CPL], cv[CPL], ms[CPL];
-    bool on[CPL];
+  const char* __restrict__ prb = reinterpret_cast<const char*>(c.pr);
+  float ll = 0.0f;          // generic scales: the sum of the pixels' log-densities
+  sq_f2 ss = {0.0f, 0.0f};  // one scale: the sum of squared residuals
+  unsigned rm_n = c.rmask[wave];
+  for (int y0 = wave; y0 < H; y0 += WAVES * PD)
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) {
-      const int x = lane + 64 * q;
-      xv[q] = x < W ? img[y * W + x] : 0.0f;
-      mv[q] = x < W ? a.mean_img[y * W + x] : 0.0f;
-      cv[q] = 0.0f;
-      ms[q] = 0.0f;
-      on[q] = false;
+  for (int u = 0; u < PD; ++u) {
+    const int y = y0 + WAVES * u;
+    if (y >= H) break;
+    sq_f2 xv[CP], mv[CP], cvv[CP], mk[CP];
+#pragma unroll
+    for (int q = 0; q < CP; ++q) {
+      xv[q] = xn[u][q];
+      mv[q] = mn[u][q];
     }
-    float4 yrs[NMAX];   // (one address for the wave: broadcasts, all requested before the first is looked at)
+    const unsigned rm = __builtin_amdgcn_readfirstlane(rm_n);   // slots whose box meets this row (one LDS address for the wave)
+    request(u, y + WAVES * PD);
+    rm_n = c.rmask[min(y + WAVES, H - 1)];
+    if (rm == 0u) {   // (scalar branch) a row no box meets: canvas = mean image x sigmoid(-10)
 #pragma unroll
-    for (int k = 0; k < NMAX; ++k) yrs[k] = c.yrec[min(k, N - 1) * H + y];
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
-      if (k >= N) break;
-      const float4 yr = yrs[k];
-      if (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, yr.w)) == 0) continue;   // row outside the box / slot absent
-      const int ro = __builtin_bit_cast(int, yr.x);
+      for (int q = 0; q < CP; ++q) {
+        mk[q] = sq_f2{m_bg, m_bg};
+        cvv[q] = mv[q] * mk[q];
+      }
+    } else {
+      sq_f2 ms[CP];
+      float cvs[CPL];
+      sq_f2 msw[CPL];
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
-        if (!half_on[k][q]) continue;
-        const float* pa = reinterpret_cast<const float*>(glb + (xo[k][q] + ro));
-        const float* pb = reinterpret_cast<const float*>(glb + (xo[k][q] + ro + G4));
-        const float a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
-        const float t0 = fmaf(wb[k][q], a1, wa[k][q] * a0), t1 = fmaf(wb[k][q], b1, wa[k][q] * b0);
-        cv[q] = fmaf(yr.y, t0, cv[q]);
-        cv[q] = fmaf(yr.z, t1, cv[q]);
-        ms[q] = fmaf(yr.w, wa[k][q] + wb[k][q], ms[q]);
-        on[q] = true;
+        cvs[q] = 0.0f;
+        msw[q] = sq_f2{0.0f, 0.0f};
+      }
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        if (!(rm & (1u << k))) continue;   // (scalar bit test)
+        const float4 yr = c.yrec[k * H + y];   // (one address for the wave: a broadcast)
+        const int ro = __builtin_bit_cast(int, yr.x);
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          const sq_f4 tp = *reinterpret_cast<const sq_f4a8*>(prb + (xo[k][q] + ro));   // {a0, b0, a1, b1}: upper / lower texel at i, i + 1
+          // {row a, row b} x-interpolated: wa {a0, b0} + wb {a1, b1} with the weight pair {wa, wb} as it lies in its registers -- the
+          // packed instructions pick its low / high half for BOTH lanes (op_sel), where the compiler would keep {wa, wa} and {wb, wb}
+          // as two more register pairs per slot and column (16 VGPRs more: a wave fewer per SIMD)
+          sq_f2 t;
+          const sq_f2 txy = tp.xy, tzw = tp.zw;
+          asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\ts_nop 0\n\tv_pk_fma_f32 %0, %1, %3, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\ts_nop 0"
+              : "=&v"(t) : "v"(wab[k][q]), "v"(txy), "v"(tzw));
+          cvs[q] = fmaf(yr.y, t.x, cvs[q]);
+          cvs[q] = fmaf(yr.z, t.y, cvs[q]);
+        }
+        // mask sum: pk (wa_y + wb_y) (wa_x + wb_x), the x factor kept as its two terms {wa, wb} until the slots are through (their sum
+        // per slot is loop-invariant: the compiler would hoist -- and spill -- it)
+        const sq_f2 yzw = {yr.z, yr.w};
+#pragma unroll
+        for (int q = 0; q < CPL; ++q)
+          asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\ts_nop 0" : "+v"(msw[q]) : "v"(yzw), "v"(wab[k][q]));
+      }
+#pragma unroll
+      for (int q = 0; q < CP; ++q) ms[q] = sq_f2{msw[2 * q].x + msw[2 * q].y, msw[2 * q + 1].x + msw[2 * q + 1].y};
+#pragma unroll
+      for (int q = 0; q < CP; ++q) {
+        mk[q] = sq_mask_sigmoid2(ms[q]);
+        cvv[q] = sq_fma2(mv[q], mk[q], sq_f2{cvs[2 * q], cvs[2 * q + 1]});
       }
     }
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) {
-      const int x = lane + 64 * q;
-      if (x < W) {
-        const float m = on[q] ? sq_sigmoid(-10.0f + ms[q] * 20.0f) : m_bg;   // (on: wave-uniform)
-        const float cvv = cv[q] + mv[q] * m;
-        if (one_sd) {
-          const float dd = (xv[q] - cvv) * inv_sd;
-          ll += fmaf(-0.5f * dd, dd, lp0);
-        } else {
-          const float sd = m * a.std_fg + (1.0f - m) * a.std_bg;
-          ll += sq_normal_lp(xv[q], cvv, sd);
+    for (int q = 0; q < CP; ++q) {
+      if (ONE_SD) {
+        sq_f2 df = xv[q] - cvv[q];
+        if (!FULLW) df *= vw[q];
+        ss = sq_fma2(df, df, ss);
+      } else {
+        const sq_f2 sd = mk[q] * a.std_fg + (sq_f2{1.0f, 1.0f} - mk[q]) * a.std_bg;
+        ll += vw[q].x * sq_normal_lp(xv[q].x, cvv[q].x, sd.x) + vw[q].y * sq_normal_lp(xv[q].y, cvv[q].y, sd.y);
+      }
+      if (a.canvas) {
+        float* o = a.canvas + frr * P + y * W + lane * CPL + 2 * q;
+        if (FULLW) *reinterpret_cast<sq_f2*>(o) = cvv[q];
+        else {
+          if (lane * CPL + 2 * q < W) o[0] = cvv[q].x;
+          if (lane * CPL + 2 * q + 1 < W) o[1] = cvv[q].y;
         }
-        if (a.canvas) a.canvas[frr * P + y * W + x] = cvv;
       }
     }
+  }
+  if (ONE_SD) {   // sum over pixels of -0.5 ((x - c) / sd)^2 - log sd - log sqrt(2 pi)
+    const float inv_sd = 1.0f / a.std_fg, lp0 = -logf(a.std_fg) - 0.91893853320467274178f;
+    const int nrows = (H - wave + WAVES - 1) / WAVES;
+    float cnt = 0.0f;
+#pragma unroll
+    for (int q = 0; q < CP; ++q) cnt += vw[q].x + vw[q].y;
+    ll = fmaf(-0.5f * inv_sd * inv_sd, ss.x + ss.y, lp0 * cnt * (float)nrows);
   }
   ll = sq_wave_sum(ll);
   if (lane == 0) red_s[wave] = ll;
   __syncthreads();
   if (tid == 0) {
-    const float dll = red_s[0] + red_s[1] + red_s[2] + red_s[3];
+    float dll = red_s[0];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) dll += red_s[w];
     a.data_ll[frr] = dll;
     if (a.qz != nullptr) {
       const size_t tr = (size_t)a.t * d.R + frr;
@@ -1172,12 +1261,29 @@ __global__ __launch_bounds__(256) void k_insert_loglik_rows(const InsertArgs a, 
     }
   }
 }
+#ifndef SQ_ROWS_WAVES
+#define SQ_ROWS_WAVES 4   // wavefronts per workgroup
+#endif
+#ifndef SQ_ROWS_PD
+#define SQ_ROWS_PD 1      // rows of frame / mean-image values in flight per wave
+#endif
+template <int NMAX, int CPL, bool FULLW, bool ONE_SD>
+static int launch_insert_rows2(const InsertArgs& a, const Dims& d, dim3 grid, hipStream_t s) {
+  constexpr int WAVES = SQ_ROWS_WAVES, PD = SQ_ROWS_PD;
+  const size_t shm = sq_canvas_rows_lds_floats(d.N, d.G, d.H) * sizeof(float);
+  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_insert_loglik_rows<NMAX, CPL, FULLW, ONE_SD, WAVES, PD>, 150 * 1024) != 0) return -2;
+  SQ_LAUNCH((k_insert_loglik_rows<NMAX, CPL, FULLW, ONE_SD, WAVES, PD>), grid, dim3(64 * WAVES), shm, s, a, d);
+  return 0;
+}
 template <int NMAX, int CPL>
 static int launch_insert_rows(const InsertArgs& a, const Dims& d, dim3 grid, hipStream_t s) {
-  const size_t shm = sq_canvas_rows_lds_floats(d.N, d.G, d.H) * sizeof(float);
-  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_insert_loglik_rows<NMAX, CPL>, 150 * 1024) != 0) return -2;
-  SQ_LAUNCH((k_insert_loglik_rows<NMAX, CPL>), grid, dim3(256), shm, s, a, d);
-  return 0;
+  // vector loads of a row: W == 64 CPL, and rows / frames that start on the vector's alignment (the parameter buffer's mean image
+  // is only float-aligned in general)
+  const size_t al = (size_t)CPL * 4 - 1;
+  const bool fullw = d.W == 64 * CPL && (((size_t)a.img | (size_t)a.mean_img | (size_t)a.canvas) & al) == 0 && (d.P4 * 4 & al) == 0;
+  const bool one_sd = a.std_fg == a.std_bg;
+  if (fullw) return one_sd ? launch_insert_rows2<NMAX, CPL, true, true>(a, d, grid, s) : launch_insert_rows2<NMAX, CPL, true, false>(a, d, grid, s);
+  return one_sd ? launch_insert_rows2<NMAX, CPL, false, true>(a, d, grid, s) : launch_insert_rows2<NMAX, CPL, false, false>(a, d, grid, s);
 }
 int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s) {
   const bool wide = d.W > SQ_CANVAS_WIDE;
@@ -1185,7 +1291,7 @@ int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s) {
   const size_t shm = sq_canvas_lds_floats(d.N, d.G, d.H, d.W, band_rows) * sizeof(float);
   const dim3 grid(d.R, a.n_frames > 0 ? a.n_frames : 1);
   // frames of 65 .. 256 columns with up to 8 slots: the row-wave kernel (cfg-5: 89 -> see DESIGN); everything else in bands
-  if (wide && d.W <= 256 && d.N <= 8 && d.G >= 2 && sq_canvas_rows_lds_floats(d.N, d.G, d.H) * sizeof(float) <= 150 * 1024) {
+  if (wide && d.W <= 256 && d.N <= 8 && d.G >= 2 && d.G <= 20 && sq_canvas_rows_lds_floats(d.N, d.G, d.H) * sizeof(float) <= 150 * 1024) {
     if (d.W <= 128) return d.N <= 4 ? launch_insert_rows<4, 2>(a, d, grid, s) : launch_insert_rows<8, 2>(a, d, grid, s);
     return d.N <= 4 ? launch_insert_rows<4, 4>(a, d, grid, s) : launch_insert_rows<8, 4>(a, d, grid, s);
   }
