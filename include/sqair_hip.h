@@ -226,7 +226,8 @@ int sqair_lstm_cell_bwd_test(SqairHandle* h, const float* gates, const float* c_
 int sqair_st_crop_bwd(SqairHandle* h, const float* img, const float* where_logits, const float* mask,
                       const float* g_out, float* d_where_logits, float* d_mask, int B, void* stream);
 /* Adjoint of sqair_st_insert_loglik for an upstream gradient g_data_ll [R]: d_glimpse [R,N,G*G],
- * d_where_logits [R,N,4], d_mean_img [H,W] (summed over rows); scratch >= R*H*W*4 bytes. */
+ * d_where_logits [R,N,4], d_mean_img [H,W] (summed over rows; NULL: not reduced, the per-row contributions stay in
+ * scratch as [R, H*W]); scratch >= R*H*W*4 bytes. */
 int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, const float* where_logits,
                                const float* presence, const float* img, const float* mean_img,
                                const float* g_data_ll, float* d_glimpse, float* d_where_logits,

@@ -326,6 +326,385 @@ __global__ __launch_bounds__(256) void k_insert_loglik_bwd(const InsertBwdArgs a
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same adjoint for frames wider than a wavefront, ROW-WAVE formulation (sqair_canvas.h; forward: k_insert_loglik_rows): a wave
+// owns blocks of RB consecutive canvas rows (block-cyclic over the four waves), lane l the CPL adjacent columns from CPL l; column
+// taps and their derivative patterns in registers, row taps as broadcast LDS records, canvas / mask sum / pixel adjoints in
+// registers, no band, no barrier between prologue and epilogue.  Per row and slot whose box meets it:
+// (1) the taps are read once more and give d/d xg, d/d yg of the pixel's canvas value and mask term -> four running sums per slot
+//     and lane (sum gx, sum gx Xn, sum gy, sum gy Yn; d sx = -hg / sx^2 (sum gx Xn - tx sum gx), ...);
+// (2) the glimpse gradient.  Glimpse row i of a slot collects sa g_cv from the canvas rows whose upper tap is i and sb g_cv from
+//     those whose upper tap is i - 1; the tap index grows with the canvas row, so while a wave walks a block it keeps, per slot and
+//     COLUMN, just two accumulators (rows i and i + 1: two FMAs per pixel) and FLUSHES one when the index moves on: the finished
+//     row is folded over x into the slot's G texel columns -- each lane writes wa acc / wb acc of its columns to a per-wave LDS
+//     line, the G lanes that own a texel column sum their pixel run (runs found once per workgroup) -- and added to the
+//     workgroup's gradient tile with ONE ds_add_f32 per flush.  LDS float atomics cost ~85 cycles per instruction whatever the
+//     lane count (measured: a fold per canvas row through ds_add_f32, ten per row and slot, ran 600 us at 128 x 128; the band
+//     kernel 206): the formulation is chosen to need few of them, ~4.5 per slot and block of 8 rows.
+// ------------------------------------------------------------------------------------------------
+#ifndef SQ_BWD_WPE
+#define SQ_BWD_WPE 3   // waves per SIMD the register allocation must leave room for (4: 127 VGPRs with 67 scratch accesses, 169 us; 3: 155 VGPRs, none, 126 us)
+#endif
+#ifndef SQ_BWD_RB_N
+#define SQ_BWD_RB_N 16
+#endif
+constexpr int SQ_BWD_RB = SQ_BWD_RB_N;   // canvas rows per block
+template <int NMAX, int CPL, bool FULLW, bool ONE_SD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SQ_BWD_WPE, 8))) void k_insert_loglik_bwd_rows(const InsertBwdArgs a, const Dims d SQ_TLP) {
+  SQ_TL_SCOPE;
+  static_assert(CPL == 2 || CPL == 4, "column pairs");
+  constexpr int NT = 256, WAVES = 4, CP = CPL / 2, RB = SQ_BWD_RB, LW = 64 * CPL;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = d.N, G = d.G, G2 = d.G * d.G, H = d.H, W = d.W, P = d.H * d.W;
+  const CanvasRowsLds c = sq_canvas_rows_carve(smem, N, G, H, true);
+  int* runs_s = reinterpret_cast<int*>(c.end);             // [N][G]   first | last << 16 in-box column whose left tap is texel column j
+  float* acc_s = reinterpret_cast<float*>(runs_s + N * G);  // [WAVES][N][4]
+  float* un_s = acc_s + ((WAVES * N * 4 + 3) & ~3);         // union: { column records [N][W] float4 } (prologue) | { dgl [N][G2], lines [WAVES][2][LW] }
+  float4* xrec_s = reinterpret_cast<float4*>(un_s);
+  float* dgl_s = un_s;
+  float* line_s = dgl_s + ((N * G2 + 3) & ~3);
+  const int r = sq_row_of_wg(blockIdx.x, d), tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = blockIdx.y;  // frame
+  const int b = sq_div(r, d.k_mul);
+  const size_t fs = (size_t)fr * d.R * N + (size_t)r * N;  // first slot-row of this (frame, row)
+  const size_t frr = (size_t)fr * d.R + r;
+  const float gll = a.g_ll[frr];
+  const char* __restrict__ img = reinterpret_cast<const char*>(a.img + ((size_t)fr * d.B + b) * d.P4);
+  const char* __restrict__ mean = reinterpret_cast<const char*>(a.mean_img);
+  sq_f2 xn[CP], mn[CP];
+  auto request = [&](int yy) {
+    const int y = min(yy, H - 1);   // (scalar)
+    if (FULLW) {
+      const unsigned off = (unsigned)(y * W * 4) + (unsigned)lane * (CPL * 4);
+      if (CPL == 2) {
+        xn[0] = *reinterpret_cast<const sq_f2*>(img + off);
+        mn[0] = *reinterpret_cast<const sq_f2*>(mean + off);
+      } else {
+        const sq_f4 xx = *reinterpret_cast<const sq_f4*>(img + off), mm = *reinterpret_cast<const sq_f4*>(mean + off);
+        xn[0] = xx.xy; xn[CP - 1] = xx.zw; mn[0] = mm.xy; mn[CP - 1] = mm.zw;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < CP; ++q) {   // (clamped addresses, unconditional loads)
+        const unsigned o0 = (unsigned)(y * W + min(lane * CPL + 2 * q, W - 1)) * 4, o1 = (unsigned)(y * W + min(lane * CPL + 2 * q + 1, W - 1)) * 4;
+        xn[q] = sq_f2{*reinterpret_cast<const float*>(img + o0), *reinterpret_cast<const float*>(img + o1)};
+        mn[q] = sq_f2{*reinterpret_cast<const float*>(mean + o0), *reinterpret_cast<const float*>(mean + o1)};
+      }
+    }
+  };
+  // row of the wave's t-th trip: block-cyclic, RB rows per block
+  auto row_of = [&](int t) { return ((t / RB) * WAVES + wave) * RB + (t % RB); };
+  request(row_of(0));
+  if (a.rec) sq_canvas_rows_prologue<NT, (NMAX * 20 * 20 + NT - 1) / NT, true>(c, a.glimpse + fs * G2, a.rec + fs * a.rec_ld + rec::WHERE, a.rec_ld, a.rec + fs * a.rec_ld + rec::PRES, a.rec_ld, N, G, H, d.g_mul);
+  else sq_canvas_rows_prologue<NT, (NMAX * 20 * 20 + NT - 1) / NT, true>(c, a.glimpse + fs * G2, a.where + fs * 4, 4, a.pres + fs, 1, N, G, H, d.g_mul);
+  // column records of every (slot, column), computed once per workgroup: {left texel's byte offset in a pair row, wa, wb, {d wa, d wb} as two halves}
+  for (int k = 0; k < N; ++k) {
+    const float sx = c.co[k * 4 + 0], tx = c.co[k * 4 + 2];
+    for (int x = tid; x < W; x += NT) {
+      const float g = sq_canvas_coord(x, W, sx, tx, G);
+      const CanvasAxisTap t = sq_canvas_axis_tap(g, G);
+      float da, db;
+      sq_canvas_axis_tap_d(g, G, da, db);
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      const h2 dh = {(_Float16)da, (_Float16)db};
+      xrec_s[k * W + x] = make_float4(__builtin_bit_cast(float, t.i * 8), t.wa, t.wb, __builtin_bit_cast(float, dh));
+    }
+  }
+  for (int i = tid; i < N * G; i += NT) runs_s[i] = 1;   // (empty: first 1, last 0)
+  __syncthreads();
+  // runs: the in-box columns are one interval per slot and their tap index grows with the column: both ends of a run have one writer
+  for (int i = tid; i < N * W; i += NT) {
+    const int k = i / W, x = i - k * W;
+    const float4 me = xrec_s[i];
+    if (me.y + me.z != 0.0f) {
+      const int xi = __builtin_bit_cast(int, me.x) >> 3;
+      bool first = x == 0, last = x == W - 1;
+      if (!first) { const float4 l = xrec_s[i - 1]; first = (l.y + l.z == 0.0f) || (__builtin_bit_cast(int, l.x) >> 3) != xi; }
+      if (!last) { const float4 rr = xrec_s[i + 1]; last = (rr.y + rr.z == 0.0f) || (__builtin_bit_cast(int, rr.x) >> 3) != xi; }
+      short* rs = reinterpret_cast<short*>(runs_s + k * G + xi);
+      if (first) rs[0] = (short)x;
+      if (last) rs[1] = (short)x;
+    }
+  }
+  // this thread's column taps (registers)
+  int xo[NMAX][CPL];
+  sq_f2 wab[NMAX][CPL];
+  unsigned dabh[NMAX][CPL];   // {d wa, d wb} as halves (values 0, +-1)
+  float xnrm[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) xnrm[q] = -1.0f + 2.0f * (float)(lane * CPL + q) / (float)(W - 1);
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k)
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const int x = lane * CPL + q;
+      float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (k < N && (FULLW || x < W)) t = xrec_s[k * W + x];
+      xo[k][q] = __builtin_bit_cast(int, t.x);
+      wab[k][q] = sq_f2{t.y, t.z};
+      dabh[k][q] = __builtin_bit_cast(unsigned, t.w);
+    }
+  __syncthreads();   // runs complete; the column records are dead: their storage becomes the gradient tile and the lines
+  int runa[NMAX], mrl[NMAX];   // lane j: run of the columns whose left tap is texel column j; longest run (scalar)
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    const int kk = min(k, N - 1);
+    runa[k] = (lane < G - 1) ? runs_s[kk * G + lane] : 1;
+    const int len = max((runa[k] >> 16) - (runa[k] & 0xffff) + 1, 0);
+    mrl[k] = __builtin_amdgcn_readfirstlane((int)sq_wave_max((float)len));
+  }
+  for (int i = tid; i < N * G2; i += NT) dgl_s[i] = 0.0f;
+  if (lane < 32) line_s[wave * 2 * (LW + 16) + 2 * LW + lane] = 0.0f;   // the line's padding: read under a zero weight, so it must be finite
+  float sgx[NMAX], sgxx[NMAX], sgy[NMAX], sgyy[NMAX];
+  sq_f2 acc_a[NMAX][CP], acc_b[NMAX][CP];   // per column: sa g_cv summed for glimpse row cur, sb g_cv for row cur + 1
+  int cur[NMAX];                             // upper tap index the accumulators belong to, -1: none (scalar)
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    sgx[k] = sgxx[k] = sgy[k] = sgyy[k] = 0.0f;
+    cur[k] = -1;
+#pragma unroll
+    for (int q = 0; q < CP; ++q) acc_a[k][q] = acc_b[k][q] = sq_f2{0.0f, 0.0f};
+  }
+  const float gll_isd2 = gll / (a.std_fg * a.std_fg), m_bg = sq_sigmoid(-10.0f);
+  const char* __restrict__ prb = reinterpret_cast<const char*>(c.pr);
+  float* lineA = line_s + wave * 2 * (LW + 16);   // {wa acc, wb acc} per column (+ padding: a run's loop may read past the row)
+  // (lineA's padding is cleared below, once the column records that share its storage are dead)
+  // fold of a finished glimpse row over x and its addition to the gradient tile (see the header): the line holds {wa acc, wb acc} per
+  // column; lane j sums both over the run of columns whose left tap is texel column j -- the first sum belongs to texel column j,
+  // the second to j + 1 (fetched from the lane below)
+  auto flush = [&](int k, int grow, const sq_f2 (&ac)[CP], const sq_f2 (&wq)[CPL], int ra, int nmax) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const float av = (q & 1) ? ac[q / 2].y : ac[q / 2].x;
+      *reinterpret_cast<sq_f2*>(lineA + 2 * (lane * CPL + q)) = wq[q] * sq_f2{av, av};
+    }
+    const int a0 = ra & 0xffff, len = (ra >> 16) - a0;   // (the line is padded: no clamp on a0 + t)
+    const sq_f2* lp = reinterpret_cast<const sq_f2*>(lineA) + a0;
+    float sum_a = 0.0f, sum_b = 0.0f;
+    for (int t = 0; t < nmax; ++t) {
+      const sq_f2 v = lp[t];
+      const float on = t <= len ? 1.0f : 0.0f;
+      sum_a = fmaf(on, v.x, sum_a);
+      sum_b = fmaf(on, v.y, sum_b);
+    }
+    // lane j - 1's second sum: a row shift, lane 16 (first of its DPP row) fetches lane 15's by hand
+    float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum_b), 0x111, 0xf, 0xf, true));   // row_shr:1
+    const float s15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sum_b), 15));
+    if (lane == 16) up = s15;
+    if (lane < G) sq_lds_add(dgl_s + k * G2 + grow * G + lane, sum_a + up);
+  };
+  // the accumulators of slot k move on by one glimpse row: row cur is finished
+  auto advance = [&](int k) {
+    flush(k, cur[k], acc_a[k], wab[k], runa[k], mrl[k]);
+#pragma unroll
+    for (int q = 0; q < CP; ++q) {
+      acc_a[k][q] = acc_b[k][q];
+      acc_b[k][q] = sq_f2{0.0f, 0.0f};
+    }
+    cur[k] += 1;
+  };
+  const int n_trips = (H + WAVES * RB - 1) / (WAVES * RB) * RB;   // (rows past the frame are skipped inside)
+  unsigned rm_n = c.rmask[min(row_of(0), H - 1)];
+  __syncthreads();   // dgl_s cleared
+  for (int t = 0; t < n_trips; ++t) {
+    const int y = row_of(t);
+    const bool live = y < H;
+    sq_f2 xv[CP], mv[CP], cvv[CP], mk[CP], gcv[CP], gm[CP];
+#pragma unroll
+    for (int q = 0; q < CP; ++q) {
+      xv[q] = xn[q];
+      mv[q] = mn[q];
+    }
+    const unsigned rm = live ? __builtin_amdgcn_readfirstlane(rm_n) : 0u;   // slots whose box meets this row
+    request(row_of(t + 1));
+    rm_n = c.rmask[min(row_of(t + 1), H - 1)];
+    if (live) {
+      if (rm == 0u) {
+#pragma unroll
+        for (int q = 0; q < CP; ++q) {
+          mk[q] = sq_f2{m_bg, m_bg};
+          cvv[q] = mv[q] * mk[q];
+        }
+      } else {
+        float cvs[CPL];
+        sq_f2 msw[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          cvs[q] = 0.0f;
+          msw[q] = sq_f2{0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+          if (!(rm & (1u << k))) continue;   // (scalar bit test)
+          const float4 yr = c.yrec[k * H + y];
+          const int ro = __builtin_bit_cast(int, yr.x);
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            const sq_f4 tp = *reinterpret_cast<const sq_f4a8*>(prb + (xo[k][q] + ro));
+            const sq_f2 tt = sq_tap_rows(wab[k][q], tp.xy, tp.zw);
+            cvs[q] = fmaf(yr.y, tt.x, cvs[q]);
+            cvs[q] = fmaf(yr.z, tt.y, cvs[q]);
+          }
+          const sq_f2 yzw = {yr.z, yr.w};
+#pragma unroll
+          for (int q = 0; q < CPL; ++q)
+            asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\ts_nop 0" : "+v"(msw[q]) : "v"(yzw), "v"(wab[k][q]));
+        }
+#pragma unroll
+        for (int q = 0; q < CP; ++q) {
+          mk[q] = sq_mask_sigmoid2(sq_f2{msw[2 * q].x + msw[2 * q].y, msw[2 * q + 1].x + msw[2 * q + 1].y});
+          cvv[q] = sq_fma2(mv[q], mk[q], sq_f2{cvs[2 * q], cvs[2 * q + 1]});
+        }
+      }
+      // pixel adjoints: g_cv (canvas), g_m (mask) and the row's contribution to d mean_img
+#pragma unroll
+      for (int q = 0; q < CP; ++q) {
+        const sq_f2 df = xv[q] - cvv[q];
+        if (ONE_SD) {
+          gcv[q] = df * sq_f2{gll_isd2, gll_isd2};
+          gm[q] = gcv[q] * mv[q];
+        } else {
+          const sq_f2 sd = mk[q] * a.std_fg + (sq_f2{1.0f, 1.0f} - mk[q]) * a.std_bg;
+          gcv[q] = sq_f2{gll * df.x / (sd.x * sd.x), gll * df.y / (sd.y * sd.y)};
+          const sq_f2 gsd = {gll * (df.x * df.x / (sd.x * sd.x * sd.x) - 1.0f / sd.x), gll * (df.y * df.y / (sd.y * sd.y * sd.y) - 1.0f / sd.y)};
+          gm[q] = gcv[q] * mv[q] + gsd * (a.std_fg - a.std_bg);
+        }
+        const sq_f2 dm = gcv[q] * mk[q];
+        float* o = a.d_mean_rows + frr * P + y * W + lane * CPL + 2 * q;
+        if (FULLW) *reinterpret_cast<sq_f2*>(o) = dm;
+        else {
+          if (lane * CPL + 2 * q < W) o[0] = dm.x;
+          if (lane * CPL + 2 * q + 1 < W) o[1] = dm.y;
+          if (lane * CPL + 2 * q >= W) gcv[q].x = 0.0f;       // (columns past the frame: nothing flows back)
+          if (lane * CPL + 2 * q + 1 >= W) gcv[q].y = 0.0f;
+        }
+      }
+    }
+    if (rm != 0u) {
+      float gcs[CPL], gms[CPL];   // g_cv and the adjoint of the mask SUM: g_m 20 m (1 - m)
+#pragma unroll
+      for (int q = 0; q < CP; ++q) {
+        const sq_f2 g2 = gm[q] * sq_f2{20.0f, 20.0f} * mk[q] * (sq_f2{1.0f, 1.0f} - mk[q]);
+        gcs[2 * q] = gcv[q].x; gcs[2 * q + 1] = gcv[q].y;
+        gms[2 * q] = g2.x; gms[2 * q + 1] = g2.y;
+      }
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        if (!(rm & (1u << k))) continue;
+        const float4 yr = c.yrec[k * H + y], y2 = c.yrec2[k * H + y];
+        const int ro = __builtin_bit_cast(int, yr.x);
+        const int ti = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, y2.w));   // upper tap index of this row (scalar)
+        if (cur[k] != ti) {   // the index moved on: finished rows leave the registers (after two steps both accumulators are empty)
+          if (cur[k] >= 0)
+            for (int st = 0; st < 2 && cur[k] != ti; ++st) advance(k);
+          cur[k] = ti;
+        }
+        const float pdsum = y2.x + y2.y;
+        float rowgy = 0.0f;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          const h2 dh = __builtin_bit_cast(h2, dabh[k][q]);
+          const sq_f2 dab = {(float)dh.x, (float)dh.y};
+          const sq_f4 tp = *reinterpret_cast<const sq_f4a8*>(prb + (xo[k][q] + ro));
+          const sq_f2 ab = sq_tap_rows(wab[k][q], tp.xy, tp.zw);    // {A, B}: the two glimpse rows x-interpolated
+          const sq_f2 dd = sq_tap_rows(dab, tp.xy, tp.zw);          // {d A / d xg, d B / d xg}
+          const float dvdx = fmaf(yr.z, dd.y, yr.y * dd.x), dvdy = fmaf(y2.y, ab.y, y2.x * ab.x);
+          const float gx = fmaf(gcs[q], dvdx, gms[q] * (yr.w * (dab.x + dab.y)));
+          const float gy = fmaf(gcs[q], dvdy, gms[q] * (pdsum * (wab[k][q].x + wab[k][q].y)));
+          sgx[k] += gx;
+          sgxx[k] = fmaf(gx, xnrm[q], sgxx[k]);
+          rowgy += gy;
+        }
+        sgy[k] += rowgy;
+        sgyy[k] = fmaf(rowgy, y2.z, sgyy[k]);
+#pragma unroll
+        for (int q = 0; q < CP; ++q) {
+          acc_a[k][q] = sq_fma2(sq_f2{yr.y, yr.y}, gcv[q], acc_a[k][q]);
+          acc_b[k][q] = sq_fma2(sq_f2{yr.z, yr.z}, gcv[q], acc_b[k][q]);
+        }
+      }
+    }
+    if ((t % RB) == RB - 1 || t == n_trips - 1) {   // end of a block: the next block of this wave is 3 RB rows further down
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        if (cur[k] < 0) continue;
+        advance(k);
+        advance(k);
+        cur[k] = -1;
+      }
+    }
+  }
+  // coordinate gradients: wave sums -> LDS -> four values per slot
+  const float hg = 0.5f * (float)(G - 1);
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    if (k >= N) break;
+    const float sx = c.co[k * 4 + 0], sy = c.co[k * 4 + 1], tcx = c.co[k * 4 + 2], tcy = c.co[k * 4 + 3];
+    const float s0 = sq_wave_sum(sgx[k]), s1 = sq_wave_sum(sgxx[k]), s2 = sq_wave_sum(sgy[k]), s3 = sq_wave_sum(sgyy[k]);
+    if (lane == 0) {
+      float* ac = acc_s + (wave * N + k) * 4;
+      ac[0] = -hg / (sx * sx) * (s1 - tcx * s0);
+      ac[1] = -hg / (sy * sy) * (s3 - tcy * s2);
+      ac[2] = -hg / sx * s0;
+      ac[3] = -hg / sy * s2;
+    }
+  }
+  __syncthreads();   // dgl_s / acc_s complete
+  float dsc = 0.0f;
+  const float* prf = reinterpret_cast<const float*>(c.pr);
+  for (int i = tid; i < N * G2; i += NT) {
+    const float v = dgl_s[i];
+    a.d_glimpse[fs * G2 + i] = v;
+    const int row = sq_div(i, d.g_mul), x = i - row * G, k = sq_div(row, d.g_mul), yy = row - k * G;
+    const float gv = yy < G - 1 ? prf[((k * (G - 1) + yy) * G + x) * 2] : prf[((k * (G - 1) + yy - 1) * G + x) * 2 + 1];
+    dsc = fmaf(v, gv, dsc);
+  }
+  if (a.d_scale != nullptr) {
+    __shared__ float dsc_s[4];
+    dsc = sq_wave_sum(dsc);
+    if (lane == 0) dsc_s[wave] = dsc;
+    __syncthreads();
+    if (tid == 0) unsafeAtomicAdd(a.d_scale, (dsc_s[0] + dsc_s[1] + dsc_s[2] + dsc_s[3]) / a.scale[0]);
+  }
+  if (tid < N * 4) {
+    const int k = tid >> 2, q = tid & 3;
+    const float tot = acc_s[(0 * N + k) * 4 + q] + acc_s[(1 * N + k) * 4 + q] + acc_s[(2 * N + k) * 4 + q] + acc_s[(3 * N + k) * 4 + q];
+    const float l = a.rec ? a.rec[(fs + k) * a.rec_ld + rec::WHERE + q] : a.where[fs * 4 + tid];
+    const float sg = sq_sigmoid_geo(l), th = tanhf(l);
+    a.d_where[(fs + k) * a.dw_ld + q] = tot * ((q & 2) ? 1.0f - th * th : sg * (1.0f - sg));
+  }
+}
+static inline size_t insert_bwd_rows_lds_bytes(const Dims& d) {
+  const int lw = d.W <= 128 ? 128 : 256;
+  const size_t un_a = 4 * (size_t)d.N * d.W, un_b = (size_t)(((size_t)d.N * d.G * d.G + 3) & ~(size_t)3) + 4 * 2 * (size_t)(lw + 16);
+  return (sq_canvas_rows_lds_floats(d.N, d.G, d.H, true) + (size_t)d.N * d.G + ((16 * (size_t)d.N + 3) & ~(size_t)3) + (un_a > un_b ? un_a : un_b)) * sizeof(float);
+}
+// Frames of 65 .. 128 columns with up to 4 slots (BASELINE configs[4]).  The other instantiations were measured and lose to the band
+// kernel (1600 workgroups, back to back): 8 slots at 128 x 128 474 us against 396, 4 slots at 96 x 200 (four columns per lane) 419
+// against 209, 6 slots there 1120 against 376 -- the per-slot register state (taps, accumulators, running sums) no longer fits.
+static inline bool insert_bwd_use_rows(const Dims& d) {
+  return d.W > SQ_CANVAS_WIDE && d.W <= 128 && d.N <= 4 && d.G >= 2 && d.G <= 20 && insert_bwd_rows_lds_bytes(d) <= 150 * 1024;
+}
+template <int NMAX, int CPL, bool FULLW, bool ONE_SD>
+static int launch_insert_bwd_rows3(const InsertBwdArgs& a, const Dims& d, dim3 grid, hipStream_t s) {
+  const size_t shm = insert_bwd_rows_lds_bytes(d);
+  if (shm > 48 * 1024 && sq_allow_big_lds((const void*)k_insert_loglik_bwd_rows<NMAX, CPL, FULLW, ONE_SD>, 150 * 1024) != 0) return -2;
+  SQ_LAUNCH((k_insert_loglik_bwd_rows<NMAX, CPL, FULLW, ONE_SD>), grid, dim3(256), shm, s, a, d);
+  return 0;
+}
+template <int NMAX, int CPL>
+static int launch_insert_bwd_rows2(const InsertBwdArgs& a, const Dims& d, dim3 grid, hipStream_t s) {
+  const size_t al = (size_t)CPL * 4 - 1;
+  const bool fullw = d.W == 64 * CPL && (((size_t)a.img | (size_t)a.mean_img) & al) == 0 && (d.P4 * 4 & al) == 0 && ((size_t)a.d_mean_rows & 7) == 0;
+  const bool one_sd = a.std_fg == a.std_bg;
+  if (fullw) return one_sd ? launch_insert_bwd_rows3<NMAX, CPL, true, true>(a, d, grid, s) : launch_insert_bwd_rows3<NMAX, CPL, true, false>(a, d, grid, s);
+  return one_sd ? launch_insert_bwd_rows3<NMAX, CPL, false, true>(a, d, grid, s) : launch_insert_bwd_rows3<NMAX, CPL, false, false>(a, d, grid, s);
+}
+static int launch_insert_bwd_rows(const InsertBwdArgs& a, const Dims& d, dim3 grid, hipStream_t s) {
+  return launch_insert_bwd_rows2<4, 2>(a, d, grid, s);
+}
+
 // band height and dynamic LDS of k_insert_loglik_bwd
 static size_t insert_bwd_lds(const Dims& d, int& band_rows) {
   const bool wide = d.W > SQ_CANVAS_WIDE;
@@ -364,7 +743,7 @@ extern "C" int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, 
                                           const float* g_data_ll, float* d_glimpse, float* d_where_logits,
                                           float* d_mean_img, void* scratch, int64_t scratch_bytes, int B, void* stream) {
   if (!h || !glimpse || !where_logits || !presence || !img || !mean_img || !g_data_ll || !d_glimpse || !d_where_logits ||
-      !d_mean_img || !scratch || B < 1)
+      !scratch || B < 1)
     return -1;
   SqairConfig c;
   if (sqair_get_config(h, &c) != 0) return -1;
@@ -373,12 +752,17 @@ extern "C" int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, 
   if (scratch_bytes < (int64_t)d.R * P * 4) return -1;
   InsertBwdArgs a{glimpse, where_logits, presence, img, mean_img, g_data_ll, d_glimpse, d_where_logits, (float*)scratch,
                   c.output_std, c.background_std, nullptr, 0, 4};
-  int band_rows;
-  const size_t shm = insert_bwd_lds(d, band_rows);
-  if (shm == 0) return -2;
-  SQ_LAUNCH_INSERT_BWD(dim3(d.R, 1), shm, (hipStream_t)stream, a, d, band_rows);
-  SQ_LAUNCH(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch,
-                     d_mean_img, d.R, P, 0);
+  if (insert_bwd_use_rows(d)) {
+    if (launch_insert_bwd_rows(a, d, dim3(d.R, 1), (hipStream_t)stream) != 0) return -2;
+  } else {
+    int band_rows;
+    const size_t shm = insert_bwd_lds(d, band_rows);
+    if (shm == 0) return -2;
+    SQ_LAUNCH_INSERT_BWD(dim3(d.R, 1), shm, (hipStream_t)stream, a, d, band_rows);
+  }
+  if (d_mean_img)   // (NULL: the per-row contributions stay in `scratch`, [R, H * W]; what tools/time_insert.py times)
+    SQ_LAUNCH(k_reduce_rows, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch,
+                       d_mean_img, d.R, P, 0);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -749,6 +1133,7 @@ int sq_launch_insert_bwd_frames(const float* glimpse, const float* rec, int rec_
                                 float std_fg, float std_bg, int T, Dims d, hipStream_t s, const float* scale, float* d_scale) {
   InsertBwdArgs a{glimpse, nullptr, nullptr, img, mean_img, g_ll, d_glimpse, d_rec, d_mean_rows, std_fg, std_bg, rec, rec_ld,
                   d_rec_ld, scale, d_scale};
+  if (insert_bwd_use_rows(d)) return launch_insert_bwd_rows(a, d, dim3(d.R, T), s);
   int band_rows;
   const size_t shm = insert_bwd_lds(d, band_rows);
   if (shm == 0) return -2;

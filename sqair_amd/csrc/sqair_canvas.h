@@ -194,6 +194,13 @@ __device__ __forceinline__ CanvasAxisTap sq_canvas_axis_tap(float g, int G) {
   t.wb = !in ? 0.0f : (i0 < 0 ? 0.0f : (i0 > G - 2 ? wl : wr));
   return t;
 }
+// d wa / d g, d wb / d g of the same tap (the adjoint kernel): -1, +1 inside; +1, 0 at i0 == -1; 0, -1 at i0 == G - 1; 0, 0 outside
+__device__ __forceinline__ void sq_canvas_axis_tap_d(float g, int G, float& da, float& db) {
+  const int i0 = (int)floorf(g);
+  const bool in = sq_canvas_inside(g, G);
+  da = !in ? 0.0f : (i0 < 0 ? 1.0f : (i0 > G - 2 ? 0.0f : -1.0f));
+  db = !in ? 0.0f : (i0 < 0 ? 0.0f : (i0 > G - 2 ? -1.0f : 1.0f));
+}
 __device__ __forceinline__ float sq_canvas_coord(int j, int L, float sc, float tr, int G) {   // as sq_canvas_prologue's tables
   const float cn = -1.0f + 2.0f * (float)j / (float)(L - 1);
   return 0.5f * (float)(G - 1) * ((cn - tr) / sc + 1.0f);
@@ -201,25 +208,29 @@ __device__ __forceinline__ float sq_canvas_coord(int j, int L, float sc, float t
 struct CanvasRowsLds {
   sq_f2* pr;       // [N][G - 1][G]  {g[y][x], g[y + 1][x]}
   float4* yrec;    // [N][H]  {byte offset of pair row i of slot k inside pr, pk wa, pk wb, pk (wa + wb)}; weights 0 outside the box
+  float4* yrec2;   // [N][H]  adjoint kernel only: {pk d wa / d g, pk d wb / d g, normalised row coordinate Yn, glimpse row i (int)}
   unsigned* rmask; // [H]  bit k: row inside slot k's box (slot present, weights not both 0)
   float* co;       // [N][4]
   float* pres;     // [N]
+  float* end;
 };
-__host__ __device__ static inline size_t sq_canvas_rows_lds_floats(int N, int G, int H) {
-  return (size_t)((2 * N * (G - 1) * G + 3) & ~3) + 4 * (size_t)N * H + H + 4 * N + N;
+__host__ __device__ static inline size_t sq_canvas_rows_lds_floats(int N, int G, int H, bool bwd = false) {
+  return (size_t)((2 * N * (G - 1) * G + 3) & ~3) + (bwd ? 8 : 4) * (size_t)N * H + H + 4 * N + ((N + 3) & ~3);
 }
-__device__ __forceinline__ CanvasRowsLds sq_canvas_rows_carve(float* smem, int N, int G, int H) {
+__device__ __forceinline__ CanvasRowsLds sq_canvas_rows_carve(float* smem, int N, int G, int H, bool bwd = false) {
   CanvasRowsLds c;
   c.pr = reinterpret_cast<sq_f2*>(smem);
   c.yrec = reinterpret_cast<float4*>(smem + ((2 * N * (G - 1) * G + 3) & ~3));
-  c.rmask = reinterpret_cast<unsigned*>(c.yrec + N * H);
+  c.yrec2 = c.yrec + N * H;
+  c.rmask = reinterpret_cast<unsigned*>(c.yrec2 + (bwd ? N * H : 0));
   c.co = reinterpret_cast<float*>(c.rmask + H);
   c.pres = c.co + 4 * N;
+  c.end = c.pres + ((N + 3) & ~3);
   return c;
 }
 // glimpse pairs, coefficients, presences, the row records and row masks of one (row, frame); ends on a barrier.  NT threads; GL =
 // glimpse values a thread fetches (N G^2 <= NT GL); g_mul = sq_magic(G)
-template <int NT, int GL>
+template <int NT, int GL, bool BWD = false>
 __device__ __forceinline__ void sq_canvas_rows_prologue(const CanvasRowsLds& c, const float* __restrict__ glimpse, const float* __restrict__ where0,
                                                         int where_ld, const float* __restrict__ pres0, int pres_ld, int N, int G, int H, SqMagic g_mul) {
   const int tid = threadIdx.x, G2 = G * G, n = N * G2;
@@ -240,6 +251,12 @@ __device__ __forceinline__ void sq_canvas_rows_prologue(const CanvasRowsLds& c, 
       const CanvasAxisTap t = sq_canvas_axis_tap(sq_canvas_coord(y, H, sy, ty, G), G);
       const float sm = pk * (t.wa + t.wb);
       c.yrec[k * H + y] = make_float4(__builtin_bit_cast(float, (k * (G - 1) + t.i) * G * 8), pk * t.wa, pk * t.wb, sm);
+      if (BWD) {
+        float da, db;
+        const float g = sq_canvas_coord(y, H, sy, ty, G);
+        sq_canvas_axis_tap_d(g, G, da, db);
+        c.yrec2[k * H + y] = make_float4(pk * da, pk * db, -1.0f + 2.0f * (float)y / (float)(H - 1), __builtin_bit_cast(float, t.i));
+      }
       if (sm != 0.0f) atomicOr(&c.rmask[y], 1u << k);
     }
   }
@@ -254,4 +271,33 @@ __device__ __forceinline__ void sq_canvas_rows_prologue(const CanvasRowsLds& c, 
     }
   }
   __syncthreads();
+}
+#ifndef SQ_ROWS_WPE
+#define SQ_ROWS_WPE(NMAX, CPL) ((NMAX) * (CPL) <= 8 ? 7 : 4)   // waves per SIMD the register allocation must leave room for
+#endif
+__device__ __forceinline__ sq_f2 sq_fma2(sq_f2 a, sq_f2 b, sq_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// sigmoid(-10 + 20 ms) for two pixels: sq_exp without its clamp and NaN select (the argument 10 - 20 ms lies in [-20 N + 10, 10]: no
+// overflow, 2^t underflows to 0 cleanly, a NaN stays a NaN), the same two-part product
+__device__ __forceinline__ sq_f2 sq_mask_sigmoid2(sq_f2 ms) {
+  const sq_f2 x = sq_fma2(ms, sq_f2{-20.0f, -20.0f}, sq_f2{10.0f, 10.0f});
+  const sq_f2 L2E = {1.44269504088896340736f, 1.44269504088896340736f};
+  const sq_f2 t = x * L2E;
+  const sq_f2 r = sq_fma2(x, L2E, -t) + x * sq_f2{1.92596299112661746e-8f, 1.92596299112661746e-8f};
+  const sq_f2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+  const sq_f2 ee = sq_fma2(e, r * sq_f2{0.69314718055994530942f, 0.69314718055994530942f}, e) + sq_f2{1.0f, 1.0f};
+  return sq_f2{__builtin_amdgcn_rcpf(ee.x), __builtin_amdgcn_rcpf(ee.y)};
+}
+// {wa a0 + wb a1, wa b0 + wb b1} from a tap {a0, b0, a1, b1} and the weight pair {wa, wb} as it lies in its registers: the packed
+// instructions pick its low / high half for BOTH lanes (op_sel), where the compiler would keep {wa, wa} and {wb, wb} as two more
+// register pairs per slot and column (16 VGPRs more: a wave fewer per SIMD).  (s_nop: the hazard recogniser does not look inside.)
+__device__ __forceinline__ sq_f2 sq_tap_rows(sq_f2 w, sq_f2 txy, sq_f2 tzw) {
+  sq_f2 t;
+  asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\ts_nop 0\n\tv_pk_fma_f32 %0, %1, %3, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\ts_nop 0"
+      : "=&v"(t) : "v"(w), "v"(txy), "v"(tzw));
+  return t;
+}
+// fire-and-forget float add on an LDS word (ds_add_f32, no return value)
+__device__ __forceinline__ void sq_lds_add(float* p, float v) {
+  typedef __attribute__((address_space(3))) float* lds_f;
+  __builtin_amdgcn_ds_faddf((lds_f)p, v, 0, 0, false);
 }

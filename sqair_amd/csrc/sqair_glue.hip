@@ -1067,21 +1067,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 // The same for frames wider than a wavefront, ROW-WAVE formulation (sqair_canvas.h): wave w owns rows w, w + 4, ...; lane l the
 // CPL adjacent columns from CPL l.  NMAX bounds the slots whose column taps a thread keeps in registers (3 NMAX CPL VGPRs); FULLW:
 // W == 64 CPL (vector loads of the frame, no column guards).
-#ifndef SQ_ROWS_WPE
-#define SQ_ROWS_WPE(NMAX, CPL) ((NMAX) * (CPL) <= 8 ? 7 : 4)   // waves per SIMD the register allocation must leave room for
-#endif
-__device__ __forceinline__ sq_f2 sq_fma2(sq_f2 a, sq_f2 b, sq_f2 c) { return __builtin_elementwise_fma(a, b, c); }
-// sigmoid(-10 + 20 ms) for two pixels: sq_exp without its clamp and NaN select (the argument 10 - 20 ms lies in [-20 N + 10, 10]: no
-// overflow, 2^t underflows to 0 cleanly, a NaN stays a NaN), the same two-part product
-__device__ __forceinline__ sq_f2 sq_mask_sigmoid2(sq_f2 ms) {
-  const sq_f2 x = sq_fma2(ms, sq_f2{-20.0f, -20.0f}, sq_f2{10.0f, 10.0f});
-  const sq_f2 L2E = {1.44269504088896340736f, 1.44269504088896340736f};
-  const sq_f2 t = x * L2E;
-  const sq_f2 r = sq_fma2(x, L2E, -t) + x * sq_f2{1.92596299112661746e-8f, 1.92596299112661746e-8f};
-  const sq_f2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-  const sq_f2 ee = sq_fma2(e, r * sq_f2{0.69314718055994530942f, 0.69314718055994530942f}, e) + sq_f2{1.0f, 1.0f};
-  return sq_f2{__builtin_amdgcn_rcpf(ee.x), __builtin_amdgcn_rcpf(ee.y)};
-}
 template <int NMAX, int CPL, bool FULLW, bool ONE_SD, int WAVES, int PD>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SQ_ROWS_WPE(NMAX, CPL), 8))) void k_insert_loglik_rows(const InsertArgs a, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
@@ -1189,13 +1174,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SQ_R
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
           const sq_f4 tp = *reinterpret_cast<const sq_f4a8*>(prb + (xo[k][q] + ro));   // {a0, b0, a1, b1}: upper / lower texel at i, i + 1
-          // {row a, row b} x-interpolated: wa {a0, b0} + wb {a1, b1} with the weight pair {wa, wb} as it lies in its registers -- the
-          // packed instructions pick its low / high half for BOTH lanes (op_sel), where the compiler would keep {wa, wa} and {wb, wb}
-          // as two more register pairs per slot and column (16 VGPRs more: a wave fewer per SIMD)
-          sq_f2 t;
-          const sq_f2 txy = tp.xy, tzw = tp.zw;
-          asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\ts_nop 0\n\tv_pk_fma_f32 %0, %1, %3, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\ts_nop 0"
-              : "=&v"(t) : "v"(wab[k][q]), "v"(txy), "v"(tzw));
+          const sq_f2 t = sq_tap_rows(wab[k][q], tp.xy, tp.zw);   // {row a, row b} x-interpolated
           cvs[q] = fmaf(yr.y, t.x, cvs[q]);
           cvs[q] = fmaf(yr.z, t.y, cvs[q]);
         }

@@ -59,11 +59,13 @@ def test_st_crop_backward(hw, masked):
         lib.sqair_destroy(h)
 
 
-@pytest.mark.parametrize("hw", [(50, 50), (128, 128)])
-def test_st_insert_loglik_backward(hw):
-    lib, h, F = _handle(2, 4, hw)
+@pytest.mark.parametrize("hw,n_slots", [((50, 50), 4), ((128, 128), 4), ((77, 130), 4), ((40, 200), 3), ((128, 128), 7),
+                                        ((30, 250), 8), ((24, 300), 4), ((90, 65), 1)])
+def test_st_insert_loglik_backward(hw, n_slots):
+    # 65 .. 256 columns and up to 8 slots: the row-wave adjoint (k_insert_loglik_bwd_rows); the others the band kernel
+    lib, h, F = _handle(2, n_slots, hw)
     try:
-        B, K, N, G = 3, 2, 4, 20
+        B, K, N, G = 3, 2, n_slots, 20
         R = B * K
         H, W = hw
         rng = np.random.default_rng(5)

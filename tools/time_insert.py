@@ -64,10 +64,17 @@ def main():
         assert l.sqair_st_insert_loglik(h, gl.data_ptr(), where.data_ptr(), pres.data_ptr(), img.data_ptr(), mean_img.data_ptr(),
                                         None, dll.data_ptr(), B, s) == 0
 
+    needs_reduce = set()   # builds older than the NULL-d_mean_img convention: their time includes the (slow, test-only) row reduction
+
     def bwd(l, h):
-        assert l.sqair_st_insert_loglik_bwd(h, gl.data_ptr(), where.data_ptr(), pres.data_ptr(), img.data_ptr(), mean_img.data_ptr(),
-                                            g_ll.data_ptr(), d_gl.data_ptr(), d_wh.data_ptr(), d_mean.data_ptr(), scratch.data_ptr(),
-                                            scratch.numel() * 4, B, s) == 0
+        dm = d_mean.data_ptr() if id(l) in needs_reduce else None
+        rc = l.sqair_st_insert_loglik_bwd(h, gl.data_ptr(), where.data_ptr(), pres.data_ptr(), img.data_ptr(), mean_img.data_ptr(),
+                                          g_ll.data_ptr(), d_gl.data_ptr(), d_wh.data_ptr(), dm, scratch.data_ptr(),
+                                          scratch.numel() * 4, B, s)
+        if rc == -1 and dm is None:
+            needs_reduce.add(id(l))
+            return bwd(l, h)
+        assert rc == 0
 
     def timed(fn, l, h):
         fn(l, h)
@@ -90,11 +97,11 @@ def main():
         fwd(l, h)
         bwd(l, h)
         torch.cuda.synchronize()
-        out = (dll.clone(), d_gl.clone(), d_wh.clone(), d_mean.clone())
+        out = (dll.clone(), d_gl.clone(), d_wh.clone(), scratch.clone())
         if ref is None:
             ref = out
         dev_ = [float((a - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in zip(out, ref)]
-        print("{:40s} {}x{} R={} N={}: fwd {:7.1f} us (min {:7.1f})   bwd (+ row reduction) {:7.1f} us (min {:7.1f})   vs first: {}".format(
+        print("{:40s} {}x{} R={} N={}: fwd {:7.1f} us (min {:7.1f})   bwd {:7.1f} us (min {:7.1f})   vs first: {}".format(
             os.path.basename(p), H, W, R, N, float(np.median(res[p]["fwd"])), min(res[p]["fwd"]), float(np.median(res[p]["bwd"])),
             min(res[p]["bwd"]), " ".join("%.1e" % v for v in dev_)))
         l.sqair_destroy(h)
