@@ -46,7 +46,8 @@ def main():
     dom = max(dense, key=lambda k: dense[k]["launches"]) if dense else None
     fam = collections.defaultdict(lambda: [0, 0.0])
     for k, v in out.items():
-        f = k.split("<")[0].strip()
+        from sqair_amd.timeline import family as _family   # (the bench's family names, incl. the frame-size aliases)
+        f = _family(k)
         fam[f][0] += v["launches"]
         fam[f][1] += v["hbm_bytes_per_launch"] * v["launches"]
     blob = dict(build_id=build_id(),
