@@ -18,7 +18,7 @@ SHAPES = [(640, 362, 1152, 0), (640, 312, 768, 0), (640, 400, 256, 1), (6400, 56
 
 def main():
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or SHAPES
-    lib = _capi.lib(__import__('os').environ.get('SQAIR_TOOL_LIB'))  # tools may point at the -DSQAIR_KNOBS build (tools/bin/libsqair_hip_knobs.so)
+    lib = _capi.lib(__import__('os').environ.get('SQAIR_TOOL_LIB'), allow_stale=bool(__import__('os').environ.get('SQAIR_TOOL_LIB')))  # tools may point at the -DSQAIR_KNOBS build (tools/bin/libsqair_hip_knobs.so)
     h = C.c_void_p()
     cfg = make_config(make_flags(), (50, 50))
     assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
