@@ -22,10 +22,13 @@ from sqair_amd.train import Trainer
 
 over = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a)
 n_train = int(over.pop("n_train", 2048))   # n_train=16384: a training set the model cannot memorise
+hw_over = over.pop("hw", None)              # hw=128x128: BASELINE configs[4]'s frames (the row-wave canvas kernels)
 sys.argv = [a for a in sys.argv if "=" not in a]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 lr = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-5
 T, B, K, N, hw = 10, 32, 5, 4, (50, 50)
+if hw_over:
+    hw = tuple(int(v) for v in hw_over.split("x"))
 train_itr = int(sys.argv[3]) if len(sys.argv) > 3 else steps   # the piecewise-constant schedule is relative to train_itr
 seq_len = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 stage_itr = int(sys.argv[5]) if len(sys.argv) > 5 else 0
@@ -81,4 +84,4 @@ for it in range(steps + 1):
 print(json.dumps(dict(config=dict(T=T, B=B, K=K, N=N, hw=hw, steps=steps, train_itr=train_itr, learning_rate=lr, opt=str(F.opt), flag_overrides=over,
                                   schedule=F.schedule, data="%d synthetic 2-glyph sequences, 256 held out" % n_train,
                                   true_objects_per_frame=float(valid["nums"].sum(-1).mean())),
-                      upper_bound_per_frame=2500 * (-np.log(0.3) - 0.5 * np.log(2 * np.pi)), curve=log)))
+                      upper_bound_per_frame=hw[0] * hw[1] * (-np.log(0.3) - 0.5 * np.log(2 * np.pi)), curve=log)))
