@@ -1223,7 +1223,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     ia.glimpse = gl; ia.rec = rec_all; ia.rec_ld = RW; ia.img = obs; ia.mean_img = flat + po.dec_mean_img;
     ia.canvas = out.canvas; ia.data_ll = w.dll; ia.qz = w.qz; ia.pz = w.pz; ia.t = 0; ia.n_frames = T; ia.out = out;
     ia.std_fg = c.output_std; ia.std_bg = c.background_std;
-    sq_launch_insert_loglik(ia, d, s);
+    if (sq_launch_insert_loglik(ia, d, s) != 0) { sq_set_error(h, "sqair_forward: the decoder canvas launch failed (dynamic LDS limit)"); return -2; }
   }
   // final recurrent state (for state-level parity checks), in the caller's widths: [hidden | cell] halves without their padding
   const int unh = h->ucfg.n_hidden;
@@ -1494,7 +1494,7 @@ extern "C" int sqair_st_insert_loglik(SqairHandle* h, const float* glimpse, cons
   InsertArgs ia; memset(&ia, 0, sizeof(ia));
   ia.glimpse = glimpse; ia.where_plain = where_logits; ia.pres_plain = presence; ia.img = img; ia.mean_img = mean_img;
   ia.canvas = canvas; ia.data_ll = data_ll; ia.std_fg = c.output_std; ia.std_bg = c.background_std;
-  sq_launch_insert_loglik(ia, d, (hipStream_t)stream);
+  if (sq_launch_insert_loglik(ia, d, (hipStream_t)stream) != 0) { sq_set_error(h, "sqair_st_insert_loglik: launch failed (dynamic LDS limit)"); return -2; }
   SQ_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1848,8 +1848,11 @@ extern "C" int sqair_backward_decoder(SqairHandle* h, const float* flat, const v
   const float* gl = w.glimpse;  // forward wrote the decoded glimpses here unless the caller asked for the output tensor
   sq_launch_elbo_bwd(importance_weights, vimco_signal, T, B, K, g_lw, g_dl, s);
   SQ_CHECK_HIP(hipMemsetAsync(d_rec, 0, (size_t)MT * 64 * 4, s));
-  sq_launch_insert_bwd_frames(gl, rec_all, RW, obs, flat + h->po.dec_mean_img, g_lw, d_gl, d_rec + rec::WHERE, 64, d_mean_rows,
-                              c.output_std, c.background_std, T, d, s);
+  if (sq_launch_insert_bwd_frames(gl, rec_all, RW, obs, flat + h->po.dec_mean_img, g_lw, d_gl, d_rec + rec::WHERE, 64, d_mean_rows,
+                                  c.output_std, c.background_std, T, d, s) != 0) {
+    sq_set_error(h, "the decoder canvas adjoint launch failed (dynamic LDS limit)");
+    return -2;
+  }
   sq_launch_reduce_rows(d_mean_rows, flat_grad + h->po.dec_mean_img, T * R, P_, 0, s);
   // ---- DEC2: glimpse = scale * (dec_b W2 + b2)
   const float* scale = flat + h->po.dec_output_scale;

@@ -318,8 +318,8 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     float* d_rec_all = b.d_rec_m + (size_t)M * RW;
     const float* gl = w.glimpse;
     const float* scale = flat + po.dec_output_scale;
-    sq_launch_insert_bwd_frames(gl, rec_all, RW, obs, flat + po.dec_mean_img, b.g_lw, b.d_gl, d_rec_all + rec::WHERE, RW,
-                                b.d_mean_rows, c.output_std, c.background_std, T, d, s, scale, flat_grad + po.dec_output_scale);
+    CK(sq_launch_insert_bwd_frames(gl, rec_all, RW, obs, flat + po.dec_mean_img, b.g_lw, b.d_gl, d_rec_all + rec::WHERE, RW,
+                                   b.d_mean_rows, c.output_std, c.background_std, T, d, s, scale, flat_grad + po.dec_output_scale));
     sq_launch_reduce_rows_atomic(b.d_mean_rows, flat_grad + po.dec_mean_img, T * R, P_, s);
     if (!wbatch.add(w.dec_b, nh, b.d_gl, G2, flat_grad + P(h, "dec.l2.w"), G2, MT, nh, G2, nullptr, scale, flat_grad + P(h, "dec.l2.b"), nullptr))
       sq_launch_wgrad_acc(w.dec_b, nh, b.d_gl, G2, flat_grad + P(h, "dec.l2.w"), G2, MT, nh, G2, s, nullptr, scale,

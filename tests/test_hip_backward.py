@@ -529,11 +529,14 @@ def test_scalar_hyper_parameter_flags_reach_the_kernels():
 
 
 @pytest.mark.parametrize("K,N,T,B,hw", [(2, 6, 2, 2, (50, 50)), (2, 3, 2, 2, (128, 128)), (4, 2, 3, 5, (40, 56)), (3, 3, 2, 3, (37, 44)),
-                                        (2, 3, 2, 3, (51, 49)), (2, 2, 2, 2, (37, 41)), (128, 2, 2, 1, (50, 50)), (70, 3, 2, 2, (40, 40))])
+                                        (2, 3, 2, 3, (51, 49)), (2, 2, 2, 2, (37, 41)), (128, 2, 2, 1, (50, 50)), (70, 3, 2, 2, (40, 40)),
+                                        (2, 5, 2, 2, (96, 128)), (2, 4, 2, 2, (70, 150))])
 def test_full_backward_other_shapes(K, N, T, B, hw):
-    """N = 6 slots (BASELINE configs[3]), 128x128 frames (configs[4]: the frame no longer fits the default LDS window),
-    a non-square frame with B*K not a multiple of the 16-row MFMA tile, frames whose H * W is not a multiple of 4 (they
-    pass through a zero-padded copy), more particles than a wavefront has lanes (K = 70, 128: the generic ELBO kernel)."""
+    """N = 6 slots (BASELINE configs[3]), 128x128 frames (configs[4]: the frame no longer fits the default LDS window; the decoder
+    canvas and its adjoint run on the row-wave kernels), a non-square frame with B*K not a multiple of the 16-row MFMA tile, frames
+    whose H * W is not a multiple of 4 (they pass through a zero-padded copy), more particles than a wavefront has lanes (K = 70, 128:
+    the generic ELBO kernel), 5 slots on 96 x 128 (row-wave forward with 8 slot registers, band adjoint), 70 x 150 (four columns per
+    lane forward, band adjoint)."""
     report, _, _ = _full_backward_case(K, N, T, B, hw, seed=21)
     _check_report(report)
 
