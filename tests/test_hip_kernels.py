@@ -195,7 +195,7 @@ def test_st_crop(hw, masked):
 
 
 @pytest.mark.parametrize("hw,n_slots", [((50, 50), 4), ((128, 128), 4), ((77, 130), 4), ((40, 200), 3), ((128, 128), 7),
-                                        ((30, 250), 8), ((24, 300), 4), ((90, 65), 1)])
+                                        ((30, 250), 8), ((24, 300), 4), ((90, 65), 1), ((600, 100), 3)])
 def test_st_insert_loglik(hw, n_slots):
     # 65 .. 256 columns and up to 8 slots: the row-wave kernel (sqair_canvas.h); the others the band kernel
     lib = _capi.lib()
