@@ -43,6 +43,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# multi-process GPU work on this stack needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails otherwise); the boxes export it already --
+# this only covers a shell that does not.  Must be in the environment before the HIP runtime starts.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
