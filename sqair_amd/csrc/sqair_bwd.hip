@@ -478,11 +478,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SQ_BWD_WPE,
       const float av = (q & 1) ? ac[q / 2].y : ac[q / 2].x;
       *reinterpret_cast<sq_f2*>(lineA + 2 * (lane * CPL + q)) = wq[q] * sq_f2{av, av};
     }
-    const int a0 = ra & 0xffff, len = (ra >> 16) - a0;   // (the line is padded: no clamp on a0 + t)
+    const int a0 = ra & 0xffff, len = (ra >> 16) - a0;
     const sq_f2* lp = reinterpret_cast<const sq_f2*>(lineA) + a0;
     float sum_a = 0.0f, sum_b = 0.0f;
     for (int t = 0; t < nmax; ++t) {
-      const sq_f2 v = lp[t];
+      const sq_f2 v = lp[min(t, LW + 15 - a0)];   // (the padding covers the runs of the usual glimpse sizes; small glimpses have longer runs)
       const float on = t <= len ? 1.0f : 0.0f;
       sum_a = fmaf(on, v.x, sum_a);
       sum_b = fmaf(on, v.y, sum_b);

@@ -16,9 +16,9 @@ pytestmark = pytest.mark.gpu
 D = torch.float64
 
 
-def _handle(K, N, hw):
+def _handle(K, N, hw, **flags):
     lib = _capi.lib()
-    F = make_flags(k_particles=K, n_steps_per_image=N)
+    F = make_flags(k_particles=K, n_steps_per_image=N, **flags)
     cfg = make_config(F, hw)
     h = C.c_void_p()
     assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
@@ -59,13 +59,14 @@ def test_st_crop_backward(hw, masked):
         lib.sqair_destroy(h)
 
 
-@pytest.mark.parametrize("hw,n_slots", [((50, 50), 4), ((128, 128), 4), ((77, 130), 4), ((40, 200), 3), ((128, 128), 7),
-                                        ((30, 250), 8), ((24, 300), 4), ((90, 65), 1), ((600, 100), 3)])
-def test_st_insert_loglik_backward(hw, n_slots):
+@pytest.mark.parametrize("hw,n_slots,G", [((50, 50), 4, 20), ((128, 128), 4, 20), ((77, 130), 4, 20), ((40, 200), 3, 20), ((128, 128), 7, 20),
+                                          ((30, 250), 8, 20), ((24, 300), 4, 20), ((90, 65), 1, 20), ((600, 100), 3, 20),
+                                          ((128, 128), 4, 5), ((100, 128), 3, 12), ((128, 128), 2, 2)])
+def test_st_insert_loglik_backward(hw, n_slots, G):
     # 65 .. 256 columns and up to 8 slots: the row-wave adjoint (k_insert_loglik_bwd_rows); the others the band kernel
-    lib, h, F = _handle(2, n_slots, hw)
+    lib, h, F = _handle(2, n_slots, hw, glimpse_size=G)
     try:
-        B, K, N, G = 3, 2, n_slots, 20
+        B, K, N = 3, 2, n_slots
         R = B * K
         H, W = hw
         rng = np.random.default_rng(5)

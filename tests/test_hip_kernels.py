@@ -194,17 +194,18 @@ def test_st_crop(hw, masked):
         lib.sqair_destroy(h)
 
 
-@pytest.mark.parametrize("hw,n_slots", [((50, 50), 4), ((128, 128), 4), ((77, 130), 4), ((40, 200), 3), ((128, 128), 7),
-                                        ((30, 250), 8), ((24, 300), 4), ((90, 65), 1), ((600, 100), 3)])
-def test_st_insert_loglik(hw, n_slots):
+@pytest.mark.parametrize("hw,n_slots,G", [((50, 50), 4, 20), ((128, 128), 4, 20), ((77, 130), 4, 20), ((40, 200), 3, 20), ((128, 128), 7, 20),
+                                          ((30, 250), 8, 20), ((24, 300), 4, 20), ((90, 65), 1, 20), ((600, 100), 3, 20),
+                                          ((128, 128), 4, 5), ((100, 128), 3, 12), ((128, 128), 2, 2)])
+def test_st_insert_loglik(hw, n_slots, G):
     # 65 .. 256 columns and up to 8 slots: the row-wave kernel (sqair_canvas.h); the others the band kernel
     lib = _capi.lib()
-    F = make_flags(k_particles=2, n_steps_per_image=n_slots)
+    F = make_flags(k_particles=2, n_steps_per_image=n_slots, glimpse_size=G)
     cfg = make_config(F, hw)
     h = C.c_void_p()
     assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
     try:
-        B, K, N, G = 3, 2, n_slots, 20
+        B, K, N = 3, 2, n_slots
         R = B * K
         H, W = hw
         rng = np.random.default_rng(3)
