@@ -22,7 +22,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["sqair_api.hip", "sqair_linear.hip", "sqair_glue.hip", "sqair_bwd.hip", "sqair_train.hip", "sqair_linear_dx.hip"]
+SOURCES = ["sqair_api.hip", "sqair_linear.hip", "sqair_glue.hip", "sqair_bwd.hip", "sqair_train.hip", "sqair_linear_dx.hip", "sqair_chain.hip"]
 OUT = os.path.join(os.path.dirname(HERE), "libsqair_hip.so")
 OUT_TIMELINE = os.path.join(os.path.dirname(HERE), "libsqair_hip_timeline.so")
 OUT_KNOBS = os.path.join(ROOT, "tools", "bin", "libsqair_hip_knobs.so")

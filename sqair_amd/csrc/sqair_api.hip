@@ -20,6 +20,7 @@
 #include <utility>
 
 #include "sqair_internal.h"
+#include "sqair_chain.h"
 
 void sq_set_error(SqairHandle* h, const std::string& msg) {
   if (h) h->err = msg;
@@ -622,6 +623,7 @@ extern "C" int sqair_destroy(SqairHandle* h) {
     if (h->cap_exec[i]) (void)hipGraphExecDestroy(h->cap_exec[i]);
     if (h->cap_graph[i]) (void)hipGraphDestroy(h->cap_graph[i]);
   }
+  sq_chain_destroy(h);
   delete h;
   return 0;
 }
@@ -694,6 +696,7 @@ extern "C" int sqair_pack_params(SqairHandle* h, const float* flat, void* packed
 // ------------------------------------------------------------------------------------------------
 // workspace carve
 // ------------------------------------------------------------------------------------------------
+static bool sq_chain_on(const SqairHandle* h, int T, int B);
 Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) {
   const SqairConfig& c = h->cfg;
   const int64_t nh = c.n_hidden, N = c.n_steps_per_image, R = (int64_t)B * c.k_particles, M = R * N;
@@ -701,7 +704,7 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   const int64_t pre_ld = h->layers[L_PRE].nt * 16;
   Workspace w;
   memset(&w, 0, sizeof(w));
-  w.train = train; w.T = T; w.B = B; w.R = (int)R; w.M = (int)M; w.N = (int)N; w.nh = (int)nh;
+  w.train = train; w.chain = sq_chain_on(h, T, B) && h->opt_slot_chain_mode == 1; w.tape = train || sq_chain_on(h, T, B); w.T = T; w.B = B; w.R = (int)R; w.M = (int)M; w.N = (int)N; w.nh = (int)nh;
   const int64_t snh = c.time_cell == CELL_LSTM ? 2 * nh : nh;  // temporal state of a slot: [hidden | cell] for the LSTM
   w.snh = (int)snh;
   const int64_t psnh = c.prior_cell == CELL_LSTM ? 2 * nh : nh;
@@ -712,15 +715,16 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
     o += align64(n);
     return p;
   };
-  const int64_t F = train ? T : 1;          // per-frame multiplicity
-  const int64_t S = train ? 2 * T * N : 1;  // per-slot multiplicity (x R rows)
+  const bool tape = w.tape;
+  const int64_t F = tape ? T : 1;          // per-frame multiplicity
+  const int64_t S = tape ? 2 * T * N : 1;  // per-slot multiplicity (x R rows)
   w.ienc_a = take((int64_t)T * B * nh);
   w.ienc_b = take((int64_t)T * B * nh);
   const int64_t rw = sq_rnn_width(c);  // slot-RNN pre-activation width (LSTM: the four gates)
   w.pre_disc = take((int64_t)T * B * rw);
   w.rec_m_all = take((int64_t)(T + 1) * M * rec::W);
-  w.temporal_m = take((train ? T + 1 : 2) * M * snh);
-  w.prior_m = take((train ? T + 1 : 2) * M * psnh);
+  w.temporal_m = take((tape ? T + 1 : 2) * M * snh);
+  w.prior_m = take((tape ? T + 1 : 2) * M * psnh);
   w.last_id[0] = take(R);
   w.last_id[1] = take(R);
   w.rec_p_all = take((int64_t)T * M * rec::W);
@@ -753,9 +757,9 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.leb = take(F * M * nh);
   w.c = take(F * R * nh);
   w.pre_d = take(R * rw);
-  w.r = take((train ? S : 2) * R * nh);
-  w.rc = take(c.rnn_cell == RNN_LSTM ? (train ? S : 2) * R * nh : 64);       // LSTM slot RNN: cell states, laid out like r
-  w.rgates = take(c.rnn_cell != RNN_VANILLA ? (train ? S : 1) * R * rw : 64);  // kept: LSTM gate pre-activations / GRU [z | r | candidate]
+  w.r = take((tape ? S : 2) * R * nh);
+  w.rc = take(c.rnn_cell == RNN_LSTM ? (tape ? S : 2) * R * nh : 64);       // LSTM slot RNN: cell states, laid out like r
+  w.rgates = take(c.rnn_cell != RNN_VANILLA ? (tape ? S : 1) * R * rw : 64);  // kept: LSTM gate pre-activations / GRU [z | r | candidate]
   w.t1 = take(S * R * T1_LD);
   w.t2 = take(S * R * nh);
   w.tp = take(S * R * TP_LD);
@@ -768,11 +772,11 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
   w.gz = take(S * R * nh);
   w.gr = take(S * R * nh);
   w.ghc = take(S * R * nh);
-  w.grh = take(R * nh);
-  w.gxh = take(R * nh);
+  w.grh = take((w.chain ? S : 1) * R * nh);   // (the chain hands every slot's GRU internals over in its own buffer)
+  w.gxh = take((w.chain ? S : 1) * R * nh);
   // LSTM: recurrent gate pre-activations of all slots of a frame, and the kept gate pre-activations per slot
   w.lpre = take(c.time_cell == CELL_LSTM ? M * 4 * nh : 64);
-  w.lgates = take(c.time_cell == CELL_LSTM ? (train ? (int64_t)T * N : 1) * R * 4 * nh : 64);
+  w.lgates = take(c.time_cell == CELL_LSTM ? (tape ? (int64_t)T * N : 1) * R * 4 * nh : 64);
   w.src = (int*)take(train ? (int64_t)T * M : 64);
   w.qz = take((int64_t)T * R);
   w.pz = take((int64_t)T * R);
@@ -787,6 +791,7 @@ Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train) 
     w.obs_p = take(P4 != P_ ? (int64_t)T * B * P4 + 16 : 64);   // (+16: the last K chunk of the input encoder may read past the row)
   }
   w.prof_ts = (unsigned long long*)take(5 * PROF_MAX * 2);
+  w.chain_ctl = (unsigned*)take(w.chain ? (int64_t)SQ_CHAIN_MAX_LAUNCHES * SQ_CHAIN_CTL_WORDS : 64);
   w.total = o;
   return w;
 }
@@ -821,6 +826,7 @@ int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipSt
   l.a.bias = packed + pl.b + L.b_off;
   l.a.M = M;
   l.a.N = L.N;
+  if (sq_chain_active(h)) return sq_chain_add_dense(h, l.a, L.kc, L.nt);   // collected into the chain launch (sqair_chain.h)
   const int rc = sq_launch_linear(l.a, L, s);
   if (rc != 0) sq_set_error(h, "internal: A-operand contract (16-byte aligned, ld % 4 == 0) violated in layer " + std::to_string((int)id));
   return rc;
@@ -838,6 +844,12 @@ static int run_rnn_tail(SqairHandle* h, const TailArgs& ta, Dims d, LayerId id, 
                         float* out, int out_ld, const float* packed, hipStream_t s) {
   const PackedLayer& L = h->layers[id];
   const PackedLayout pl = packed_layout(h);
+  if (sq_chain_active(h)) {
+    ChainRnn r; memset(&r, 0, sizeof(r));
+    r.ta = ta; r.hid = hid; r.hid_ld = hid_ld; r.wp = packed + pl.w + L.w_off; r.bias = packed + pl.b + L.b_off; r.add = add; r.add_ld = add_ld;
+    r.out = out; r.out_ld = out_ld; r.n_out = L.N;
+    return sq_chain_add_rnn_tail(h, r);
+  }
   const int rc = sq_launch_rnn_tail(ta, d, hid, hid_ld, packed + pl.w + L.w_off, packed + pl.b + L.b_off, add, add_ld, out, out_ld, L.N, s, nullptr);
   if (rc != 0) sq_set_error(h, "internal: k_rnn_tail launch rejected");
   return rc;
@@ -852,8 +864,27 @@ static int run_rnn_tail(SqairHandle* h, const TailArgs& ta, Dims d, LayerId id, 
     RUN(l2, id2, M);                              \
   } while (0)
 
-static int emit_crop(SqairHandle* h, const CropArgs& ca, POff po, Dims d, int nslots, hipStream_t s) { (void)h; return sq_launch_crop(ca, po, d, nslots, s); }
-static int emit_tail(SqairHandle* h, const TailArgs& ta, Dims d, hipStream_t s) { (void)h; return sq_launch_slot_tail(ta, d, s); }
+static int emit_crop(SqairHandle* h, const CropArgs& ca, POff po, Dims d, int nslots, hipStream_t s) {
+  if (sq_chain_active(h)) return sq_chain_add_crop(h, ca);
+  return sq_launch_crop(ca, po, d, nslots, s);
+}
+static int emit_tail(SqairHandle* h, const TailArgs& ta, Dims d, hipStream_t s) {
+  if (sq_chain_active(h)) return sq_chain_add_tail(h, ta);
+  return sq_launch_slot_tail(ta, d, s);
+}
+// The in-launch slot chain (sqair_chain.h) serves the shipped cell configuration -- VanillaRNN slot cell with the tail fused into
+// the next slot's layer, GRU temporal cell -- at the row counts where the pass is latency-bound; everything else keeps one launch
+// per op.  The workspace is then laid out like the training tape (every slot's activations in their own buffer).
+static bool sq_chain_on(const SqairHandle* h, int T, int B) {
+#ifdef SQAIR_WIDE
+  (void)h; (void)T; (void)B;
+  return false;
+#else
+  const SqairConfig& c = h->cfg;
+  return h->opt_slot_chain && c.rnn_cell == RNN_VANILLA && c.time_cell == CELL_GRU && !c.sample_from_prior &&
+         c.n_hidden == 256 && can_fuse_tail(h, L_PROP_RNN) && can_fuse_tail(h, L_DISC_RNN) && B * c.k_particles <= 320 && 2 * T <= SQ_CHAIN_MAX_LAUNCHES;
+#endif
+}
 static int emit_latsum(SqairHandle* h, const float* f, const float* rec_p, float* c, Dims d, hipStream_t s) { (void)h; return sq_launch_latent_sum(f, rec_p, c, d, s); }
 static int emit_compact(SqairHandle* h, const CompactArgs& ka, POff po, Dims d, hipStream_t s) { (void)h; return sq_launch_compact(ka, po, d, s); }
 
@@ -922,6 +953,31 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     sq_launch_init_state(w.rec_m_all, w.state(w.temporal_m, 0, w.snh), w.state(w.prior_m, 0, w.psnh), w.last_id[0], w.disc_init_rec,
                          w.prop_rnn_init, w.disc_rnn_init, w.rn_init_state, w.w3_prop, w.w3_disc,
                          (int)P(h, "prop.transform.l2.w"), (int)P(h, "disc.transform.l2.w"), flat, po, d, s);
+    if (w.chain) {
+      // hand-off words of the chain launches of this pass -> sentinel; their control blocks -> zero (one launch)
+      ChainPoisonList pl; memset(&pl, 0, sizeof(pl));
+      const int64_t SR = (int64_t)T * R * N;   // rows of one phase of a slot buffer
+      auto slotbuf = [&](float* base, int ld, int width, bool disc_too) {
+        pl.r[pl.n++] = ChainPoison{base, disc_too ? 2 * SR : SR, ld, width, 0};
+      };
+      slotbuf(w.r, nh, nh, true);
+      slotbuf(w.t1, T1_LD, h->layers[L_PROP_T1].N, true);
+      slotbuf(w.t2, nh, nh, true);
+      slotbuf(w.g2, G2, G2, true);
+      slotbuf(w.e1, nh, nh, true);
+      slotbuf(w.e2, nh, nh, true);
+      slotbuf(w.enc, ENC_LD, 2 * nw, true);
+      slotbuf(w.hraw, HRAW_LD, h->layers[L_PROP_HEADS].N, false);
+      slotbuf(w.gz, nh, nh, false);
+      slotbuf(w.grh, nh, nh, false);
+      slotbuf(w.gxh, nh, nh, false);
+      pl.r[pl.n++] = ChainPoison{w.temporal_p, (int64_t)T * M, w.snh, nh, 0};
+      pl.r[pl.n++] = ChainPoison{w.rec_p_all + rec::WHERE, (int64_t)T * M, rec::W, 4, 0};
+      pl.r[pl.n++] = ChainPoison{w.rec_d_all + rec::WHERE, (int64_t)T * M, rec::W, 4, 0};
+      pl.r[pl.n++] = ChainPoison{w.rec_d_all + rec::PRES, (int64_t)T * M, rec::W, 1, 0};
+      if (h->layers[L_DISC_T1].N != h->layers[L_PROP_T1].N) { sq_set_error(h, "slot chain: T1 widths differ"); return -3; }
+      sq_chain_poison(pl, w.chain_ctl, SQ_CHAIN_MAX_LAUNCHES * SQ_CHAIN_CTL_WORDS, s);
+    }
     if (obs != obs_user) SQ_LAUNCH(k_pad_rows, dim3(T * B), dim3(256), 0, s, obs_user, w.obs_p, P_, PL);
     // input encoder for every frame of every sequence at once (core.py:165, modules.py:100-112)
     Lin a; a.seg(obs, PL, P_).out(w.ienc_a, nh).act(ACT_ELU); RUN(a, L_IENC0, T * B);
@@ -933,6 +989,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   // latency-bound (-0.2 ms at 160 rows), even at 320 rows, a loss from 640 on -- 20.5 us against 5.9 + 5.5 us at 1280 rows)
   static const int tail_rows = SQ_KNOB_INT("SQAIR_TAIL_FUSION_ROWS", 320);
   const bool fuse_prop = d.R <= tail_rows && can_fuse_tail(h, L_PROP_RNN), fuse_disc = d.R <= tail_rows && can_fuse_tail(h, L_DISC_RNN);
+  if (w.chain && !(fuse_prop && fuse_disc)) { sq_set_error(h, "slot chain: tail fusion off"); return -3; }
   TailArgs pending_tail; memset(&pending_tail, 0, sizeof(pending_tail));
   for (int t = 0; (parts & 2) && t < T; ++t) {
     const int pp = t & 1, pn = pp ^ 1;
@@ -1006,6 +1063,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
       }
     }
     // ---- E. propagation slots (propagate.py:168-184 static_rnn over PropagationCore) ----
+    if (w.chain) sq_chain_begin(h, d, po, wsbase, ws_bytes);
     for (int k = 0; k < N; ++k) {
       const float* pre_k = w.pre + (size_t)k * pre_ld;
       const int pre_rld = N * pre_ld;
@@ -1057,7 +1115,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
       {
         CropArgs ca; memset(&ca, 0, sizeof(ca));
         ca.mode = CROP_PROP2; ca.img = img; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N;
-        ca.mask_row_add = k; ca.out = g2; ca.out_row_mul = train ? N : 1; ca.rec_prev = rec_prev; ca.rec_new = rec_p_t;
+        ca.mask_row_add = k; ca.out = g2; ca.out_row_mul = w.tape ? N : 1; ca.rec_prev = rec_prev; ca.rec_new = rec_p_t;
         ca.t2 = t2; ca.t2_ld = rl; ca.w3 = w.w3_prop; ca.noise = nz; ca.flat = flat; ca.slot = k;
         if (train) { ca.tp_out = w.slot(w.tp, TP_LD, t, 0, k); ca.tp_out_ld = w.sld(TP_LD); }
         emit_crop(h, ca, po, d, 1, s);
@@ -1083,12 +1141,15 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         Lin hd; hd.seg(temporal_p + (size_t)k * nh, N * nh, nh).out(hraw, hl); RUN(hd, L_PROP_HEADS, R);
       } else {
         const float* tau_k = temporal_prev + (size_t)k * nh;
+        float* grh_k = w.chain ? w.slot(w.grh, nh, t, 0, k) : w.grh;   // (the chain: every slot's hand-offs in their own buffers)
+        float* gxh_k = w.chain ? w.slot(w.gxh, nh, t, 0, k) : w.gxh;
+        const int grl = w.chain ? rl : nh;
         Lin g1l; g1l.seg(r_k, rl, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(enc, el, 2 * nw)
                    .add(pre_k + rw + nh + nh / 2, pre_rld, 2 * nh).out(gz, rl)
-                   .gru1(tau_k, N * nh, w.grh, nh, w.gxh, nh, nh);
+                   .gru1(tau_k, N * nh, grh_k, grl, gxh_k, grl, nh);
         if (train) { g1l.a.o3 = w.slot(w.gr, nh, t, 0, k); g1l.a.o3_ld = rl; }
         RUN(g1l, L_PROP_GRU1, R);
-        Lin g2l; g2l.seg(w.grh, nh, nh).add(w.gxh, nh, nh).out(temporal_p + (size_t)k * nh, N * nh)
+        Lin g2l; g2l.seg(grh_k, grl, nh).add(gxh_k, grl, nh).out(temporal_p + (size_t)k * nh, N * nh)
                    .gru2(tau_k, N * nh, gz, rl, nh);
         if (train) { g2l.a.o1 = w.slot(w.ghc, nh, t, 0, k); g2l.a.o1_ld = rl; }
         RUN(g2l, L_PROP_GRU2, R);
@@ -1104,6 +1165,10 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         if (fuse_prop && k + 1 < N) pending_tail = ta;  // computed inside the next slot's RNN launch
         else emit_tail(h, ta, d, s);
       }
+    }
+    if (w.chain) {
+      const int rc = sq_chain_flush(h, w.chain_ctl + (size_t)(2 * t) * SQ_CHAIN_CTL_WORDS, 2 * t, s);
+      if (rc != 0) return rc;
     }
     // ---- generation modes: prior samples of the propagated objects (sqair_modules.py:294-302) ----
     const bool do_generate = c.sample_from_prior && c.generate_after > 0 && (t_offset + t) > c.generate_after;  // seq.py:198-200
@@ -1125,6 +1190,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
       }
     }
     // ---- G. discovery steps (sqair_modules.py:129-147 static_rnn over DiscoveryCore) ----
+    if (w.chain) sq_chain_begin(h, d, po, wsbase, ws_bytes);
     for (int j = 0; j < N; ++j) {
       float* r_j = w.rslot(t, 1, j);
       const int rl = w.sld(nh), t1l = w.sld(T1_LD), gl2 = w.sld(G2), el = w.sld(ENC_LD);
@@ -1167,7 +1233,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
       }
       {
         CropArgs ca; memset(&ca, 0, sizeof(ca));
-        ca.mode = CROP_DISC; ca.img = img; ca.out = g2; ca.out_row_mul = train ? N : 1; ca.rec_new = rec_d_t; ca.t2 = t2;
+        ca.mode = CROP_DISC; ca.img = img; ca.out = g2; ca.out_row_mul = w.tape ? N : 1; ca.rec_new = rec_d_t; ca.t2 = t2;
         ca.t2_ld = rl; ca.w3 = w.w3_disc; ca.noise = nz; ca.flat = flat; ca.slot = j;
         if (train) { ca.tp_out = w.slot(w.tp, TP_LD, t, 1, j); ca.tp_out_ld = w.sld(TP_LD); }
         emit_crop(h, ca, po, d, 1, s);
@@ -1186,6 +1252,10 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         if (fuse_disc && j + 1 < N) pending_tail = ta;
         else emit_tail(h, ta, d, s);
       }
+    }
+    if (w.chain) {
+      const int rc = sq_chain_flush(h, w.chain_ctl + (size_t)(2 * t + 1) * SQ_CHAIN_CTL_WORDS, 2 * t + 1, s);
+      if (rc != 0) return rc;
     }
     if (do_generate) sq_launch_generate_disc(ga, po, d, s);  // sqair_modules.py:157-170
     // ---- I. merge / compaction (the log-probabilities H and the decoder J are off the recurrence's critical path:
@@ -1367,7 +1437,15 @@ extern "C" int sqair_set_option(SqairHandle* h, const char* name, int value) {
   if (!h || !name) return -1;
   const std::string n(name);
   if (n == "tail_fusion") { h->opt_tail_fusion = value != 0; return 0; }
-  sq_set_error(h, "sqair_set_option: unknown option '" + n + "' (known: tail_fusion)");
+  if (n == "slot_chain") {
+#ifdef SQAIR_WIDE
+    if (value != 0) { sq_set_error(h, "sqair_set_option: slot_chain is not available in the wide build"); return -2; }
+#endif
+    h->opt_slot_chain = value != 0;
+    h->opt_slot_chain_mode = value;   // (2: the chain's workspace layout with one launch per op -- a debugging aid)
+    return 0;
+  }
+  sq_set_error(h, "sqair_set_option: unknown option '" + n + "' (known: tail_fusion, slot_chain)");
   return -2;
 }
 
@@ -1421,6 +1499,11 @@ extern "C" int sqair_graph_capture(SqairHandle* h, const float* flat_params, con
   hipStream_t s = (hipStream_t)stream;
   if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
   if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+  if (h->opt_slot_chain) {  // one eager pass: the chain launches' op tables are uploaded outside the capture (sqair_chain.hip)
+    const int rc0 = forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace, workspace_bytes, s);
+    if (rc0 != 0) return rc0;
+    SQ_CHECK_HIP(hipStreamSynchronize(s));
+  }
   SQ_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   int rc = forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
                         workspace_bytes, s);
@@ -1439,6 +1522,27 @@ extern "C" int sqair_graph_capture(SqairHandle* h, const float* flat_params, con
   SQ_CHECK_HIP(hipGraphGetNodes(g, nullptr, &nn));
   h->graph_nodes = (int)nn;
   SQ_CHECK_HIP(hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0));
+  return 0;
+}
+
+// Status of the in-launch slot chain's launches of the last pass on this workspace (synchronises the stream): 0 = every launch
+// completed; otherwise the first non-zero status word (1 = a consumer gave up polling for an operand, 3 = the census of the
+// workgroups never completed, 4 = more row tiles per XCD than the kernel is laid out for) -- the pass's results are then not valid.
+// Returns 0 as well when the chain is off for this shape.
+extern "C" int sqair_chain_status(SqairHandle* h, void* workspace, int T, int B, int train, void* stream) {
+  if (!h || !workspace || T < 1 || B < 1) return -1;
+  const Workspace w = sq_carve(h, T, B, (float*)workspace, train != 0);
+  if (!w.chain) return 0;
+  std::vector<unsigned> ctl((size_t)SQ_CHAIN_MAX_LAUNCHES * SQ_CHAIN_CTL_WORDS);
+  SQ_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  SQ_CHECK_HIP(hipMemcpy(ctl.data(), w.chain_ctl, ctl.size() * 4, hipMemcpyDeviceToHost));
+  for (int l = 0; l < 2 * T; ++l) {
+    const unsigned st = ctl[(size_t)l * SQ_CHAIN_CTL_WORDS + 9 * 32];
+    if (st != 0) {
+      sq_set_error(h, "slot chain: launch " + std::to_string(l) + " ended with status " + std::to_string(st));
+      return (int)st;
+    }
+  }
   return 0;
 }
 

@@ -178,7 +178,20 @@ struct SqTlScope {
 #else
 #define SQ_TLP
 #define SQ_TL_SCOPE
+#ifdef SQAIR_KNOBS
+// knob build: SQAIR_SYNC_LAUNCHES=1 names every kernel on stderr before it is launched and waits for it (which launch faults)
+#include <cstdio>
+#include <cstdlib>
+#define SQ_LAUNCH(kern, grid, block, lds, s, ...)                                              \
+  do {                                                                                         \
+    static const bool sq_sync_ = getenv("SQAIR_SYNC_LAUNCHES") != nullptr;                     \
+    if (sq_sync_) { fprintf(stderr, "launch %s\n", #kern); fflush(stderr); }                   \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__);                                \
+    if (sq_sync_) (void)hipStreamSynchronize(s);                                               \
+  } while (0)
+#else
 #define SQ_LAUNCH(kern, grid, block, lds, s, ...) hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__)
+#endif
 #endif
 
 // Measurement knobs (tile shapes, fusion switches, dump files) are read from the environment ONLY in a library built with
@@ -246,6 +259,13 @@ __device__ __forceinline__ float sq_act(float v, int act) {
     default: return v;
   }
 }
+// Sums of two / three products, association fixed with explicit fused multiply-adds: left to the compiler, `a x + b y` is
+// contracted into fma(a, x, b y) or fma(b, y, a x) depending on the surrounding code, and two kernels that compute the same
+// quantity (launch-per-op path | in-launch slot chain) would differ in the last bit.
+__device__ __forceinline__ float sq_mix2(float a, float x, float b, float y) { return fmaf(b, y, a * x); }
+__device__ __forceinline__ float sq_mix3(float a, float x, float b, float y, float c, float z) { return fmaf(c, z, fmaf(b, y, a * x)); }
+// GRU state update h' = (1 - z) h + z hc
+__device__ __forceinline__ float sq_gru_blend(float z, float h, float hc) { return sq_mix2(1.0f - z, h, z, hc); }
 __device__ __forceinline__ float sq_normal_lp(float x, float loc, float scale) {
   const float d = (x - loc) / scale;
   return -0.5f * d * d - logf(scale) - 0.91893853320467274178f;

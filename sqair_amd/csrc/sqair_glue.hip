@@ -144,8 +144,8 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
       const float fg = sq_sigmoid(hr[2 * nw + c]) * 0.9999f;
       const float ig = sq_sigmoid(hr[3 * nw + c]) * 0.9999f;
       const float tg = sq_sigmoid(hr[4 * nw + c]) * 0.9999f;
-      const float l2 = fg * tm1 + (1.0f - ig) * loc + (1.0f - tg) * t_loc;
-      sc = (1.0f - ig) * sc + (1.0f - tg) * t_scale;
+      const float l2 = sq_mix3(fg, tm1, 1.0f - ig, loc, 1.0f - tg, t_loc);
+      sc = sq_mix2(1.0f - ig, sc, 1.0f - tg, t_scale);
       loc = l2;
     }
     const float what = loc + sc * eps;
@@ -282,8 +282,8 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
         const float fg = sq_sigmoid(v_h[q][2]) * 0.9999f;
         const float ig = sq_sigmoid(v_h[q][3]) * 0.9999f;
         const float tg = sq_sigmoid(v_h[q][4]) * 0.9999f;
-        loc = fg * v_tm1[q] + (1.0f - ig) * v_loc[q] + (1.0f - tg) * t_loc;
-        sc = (1.0f - ig) * v_sc[q] + (1.0f - tg) * t_scale;
+        loc = sq_mix3(fg, v_tm1[q], 1.0f - ig, v_loc[q], 1.0f - tg, t_loc);
+        sc = sq_mix2(1.0f - ig, v_sc[q], 1.0f - tg, t_scale);
       }
       const float what = loc + sc * v_eps[q];
       zt[rr * ZLD + rec::WHAT + c] = what;

@@ -59,6 +59,10 @@ struct SqairHandle {
   int debug_reps = 0;       // sqair_debug_linear_time
   float debug_us = 0.0f;
   bool opt_tail_fusion = true;  // sqair_set_option("tail_fusion"): the tail of slot k inside slot k + 1's RNN launch (bit-identical either way)
+  bool opt_slot_chain = false;  // sqair_set_option("slot_chain"): the slot launches of a frame's propagation / discovery loop as one
+                                // persistent launch each (sqair_chain.h; bit-identical; set BEFORE sizing / clearing workspaces)
+  int opt_slot_chain_mode = 0;
+  void* chain = nullptr;        // ChainState (sqair_chain.hip)
   bool clear_each_pass = true;  // zero the caller's workspace at the start of every pass (sqair_set_workspace_clearing)
   const float* gen_noise = nullptr;  // sqair_set_generation_noise
   // generic capture slots (sqair_capture_begin / _end / _launch): any sequence of C-ABI calls as one HIP graph
@@ -137,6 +141,9 @@ constexpr int PS_LD = 112, ENC_LD = 112, M1_LD = 64, HRAW_LD = 256, WB_LD = 4, T
 
 struct Workspace {
   bool train;
+  bool tape;    // per-frame / per-slot buffers are kept apart ([T] / [2 phases][T][B'][N]): training, or the in-launch slot chain
+  bool chain;   // the slot loops run as chain launches (sqair_chain.h)
+  unsigned* chain_ctl;   // control blocks of the pass's chain launches
   int T, B, R, M, N, nh, snh, psnh;
   float *ienc_a, *ienc_b, *pre_disc;
   float *rec_m_all, *rec_p_all, *rec_d_all;
@@ -157,16 +164,16 @@ struct Workspace {
   unsigned long long* prof_ts;
   int64_t total;  // floats
 
-  float* frame(float* base, int64_t per_frame, int t) const { return base + (train ? (size_t)t * per_frame : 0); }
-  float* state(float* base, int t, int width) const { return base + (size_t)(train ? t : (t & 1)) * M * width; }
+  float* frame(float* base, int64_t per_frame, int t) const { return base + (tape ? (size_t)t * per_frame : 0); }
+  float* state(float* base, int t, int width) const { return base + (size_t)(tape ? t : (t & 1)) * M * width; }
   // slot buffer of width W: pointer of (frame t, phase ph, slot k) and its row stride
   float* slot(float* base, int W, int t, int ph, int k) const {
-    return base + (train ? (((size_t)(ph * T + t) * R * N) + k) * W : 0);  // [phase][T][B'][N][W]
+    return base + (tape ? (((size_t)(ph * T + t) * R * N) + k) * W : 0);  // [phase][T][B'][N][W]
   }
-  int sld(int W) const { return train ? N * W : W; }
-  float* cslot(int t, int ph, int k) const { return train ? slot(rc, nh, t, ph, k) : rc + (size_t)(k & 1) * R * nh; }
+  int sld(int W) const { return tape ? N * W : W; }
+  float* cslot(int t, int ph, int k) const { return tape ? slot(rc, nh, t, ph, k) : rc + (size_t)(k & 1) * R * nh; }
   float* rslot(int t, int ph, int k) const {  // RNN hidden state: ping-pong over slots when no tape is kept
-    return train ? slot(r, nh, t, ph, k) : r + (size_t)(k & 1) * R * nh;
+    return tape ? slot(r, nh, t, ph, k) : r + (size_t)(k & 1) * R * nh;
   }
 };
 Workspace sq_carve(const SqairHandle* h, int T, int B, float* base, bool train);

@@ -46,7 +46,7 @@ __device__ __forceinline__ void x_epilogue(const LinArgs& a, int m, int n, float
     } else a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
   } else {
     const float hc = sq_tanh(v);
-    a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1) * p_e0 + p_e1 * hc;
+    a.out[(size_t)m * a.out_ld + n] = sq_gru_blend(p_e1, p_e0, hc);
     if (a.o1 != nullptr) a.o1[(size_t)m * a.o1_ld + n] = hc;
   }
 }
@@ -111,7 +111,8 @@ __device__ __forceinline__ void x_epilogue4(const LinArgs& a, int m, int n0, sq_
     const sq_f32x4 h = *reinterpret_cast<const sq_f32x4*>(a.e0 + (size_t)m * a.e0_ld + n0);
     const sq_f32x4 z = *reinterpret_cast<const sq_f32x4*>(a.e1 + (size_t)m * a.e1_ld + n0);
     const sq_f32x4 hc = sq_f32x4{sq_tanh(x[0]), sq_tanh(x[1]), sq_tanh(x[2]), sq_tanh(x[3])};
-    *reinterpret_cast<sq_f32x4*>(a.out + (size_t)m * a.out_ld + n0) = (1.0f - z) * h + z * hc;
+    *reinterpret_cast<sq_f32x4*>(a.out + (size_t)m * a.out_ld + n0) =
+        sq_f32x4{sq_gru_blend(z.x, h.x, hc.x), sq_gru_blend(z.y, h.y, hc.y), sq_gru_blend(z.z, h.z, hc.z), sq_gru_blend(z.w, h.w, hc.w)};
     if (a.o1 != nullptr) *reinterpret_cast<sq_f32x4*>(a.o1 + (size_t)m * a.o1_ld + n0) = hc;
   }
 }

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_linear_rows(const LinArgs a, const int 
         else a.o2[(size_t)m * a.o2_ld + (n - 2 * nh)] = v;
       } else {
         const float hc = sq_tanh(v);
-        a.out[(size_t)m * a.out_ld + n] = (1.0f - p_e1[i]) * p_e0[i] + p_e1[i] * hc;
+        a.out[(size_t)m * a.out_ld + n] = sq_gru_blend(p_e1[i], p_e0[i], hc);
         if (a.o1 != nullptr) a.o1[(size_t)m * a.o1_ld + n] = hc;
       }
     }

@@ -59,7 +59,7 @@ class SqairCore(object):
     """Thin owner of a library handle + the device buffers it needs (parameters, packed parameters,
     workspace, noise, outputs) for one (T, B) shape on one device / stream."""
 
-    def __init__(self, F, img_hw, device="cuda:0", lib_path=None, stream_priority=0):
+    def __init__(self, F, img_hw, device="cuda:0", lib_path=None, stream_priority=0, options=None):
         if not torch.cuda.is_available():
             raise RuntimeError("sqair_amd needs a HIP device (no CPU fallback)")
         self.F = F
@@ -74,6 +74,10 @@ class SqairCore(object):
             raise ValueError("sqair_create rejected the configuration (rc={}): limits n_what <= {n_what}, n_steps_per_image <= "
                              "{n_steps_per_image} (<= 14 with the wide record), n_units <= 16, k_particles <= 256".format(
                                  rc, **_capi.WIDE_LIMITS))
+        # documented run-time options of the library (include/sqair_hip.h: sqair_set_option), set before any workspace is sized
+        self.options = dict(options or {})
+        for name, value in self.options.items():
+            self.check(self.lib.sqair_set_option(self.handle, name.encode(), int(value)), "sqair_set_option")
         self.spec = param_spec(F, img_hw)
         self.offsets, self.n_params = param_offsets(self.spec)
         assert self.n_params == self.lib.sqair_param_count(self.handle), "parameter inventory mismatch"
