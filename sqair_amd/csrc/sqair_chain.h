@@ -19,7 +19,7 @@ enum { COP_DENSE = 0, COP_CROP = 1, COP_RNN_TAIL = 2, COP_TAIL = 3 };
 constexpr int SQ_CHAIN_MAX_OPS = 160;
 constexpr int SQ_CHAIN_CTL_WORDS = 512;       // control block of one chain launch (zeroed once per pass)
 constexpr int SQ_CHAIN_MAX_LAUNCHES = 128;    // control blocks per pass (2 per frame)
-constexpr int SQ_CHAIN_SPIN_LIMIT = 1 << 17;  // polls before a consumer gives up and flags the launch (never hang the device)
+constexpr int SQ_CHAIN_SPIN_LIMIT = 1 << 14;  // polls before a consumer gives up and flags the launch (never hang the device)
 
 // the VanillaRNN layer of a slot with the previous slot's tail computed in front of it (k_rnn_tail's arguments)
 struct ChainRnn {
@@ -32,26 +32,25 @@ struct ChainRnn {
 // A dense layer as the chain's body wants it: everything the launch path derives per launch from LinArgs is derived once on the
 // host, every operand inside the workspace is a 32-bit byte offset from its base (one buffer resource, no 64-bit address
 // arithmetic on the device), and the virtually concatenated A operand is a table of K chunks.
-struct ChChunk { unsigned base, ldb, lim, pad; };   // chunk g of a row: bytes [base + row * ldb + min(16 kq, lim), +16)
+struct alignas(16) ChChunk { unsigned base, ldb, lim, pad; };   // chunk g of a row: bytes [base + row * ldb + min(16 kq, lim), +16)
 constexpr int SQ_CHAIN_MAX_KC = 28;
 constexpr unsigned SQ_CHAIN_NONE = 0xFFFFFFFFu;
-struct ChDense {
-  unsigned wp_lo, wp_hi, wz_lo, wz_hi, bias_lo, bias_hi;   // packed weights / zero block / packed bias (parameter buffer)
-  int M, N, kc_total, nch;
+struct alignas(16) ChDense {     // (16-byte groups: the body fetches the descriptor from LDS with a handful of 128-bit reads)
+  int kc_total, nch, M, N;
   int epi, act_a, act_b, act_split;
-  float scale; int nh;
-  unsigned out_off; int out_ld;
-  unsigned add_off; int add_ld, add_n;     // add_off = SQ_CHAIN_NONE: no addend
+  int nh, add_n; unsigned add_off; int add_ld;     // add_off = SQ_CHAIN_NONE: no addend
+  unsigned wp_lo, wp_hi, wz_lo, wz_hi;             // packed weights / zero block (parameter buffer)
+  unsigned bias_lo, bias_hi, out_off; int out_ld;  // packed bias
   unsigned e0_off; int e0_ld; unsigned e1_off; int e1_ld;
-  unsigned o1_off; int o1_ld; unsigned o2_off; int o2_ld; unsigned o3_off; int o3_ld;   // (SQ_CHAIN_NONE: not kept)
-  int pad[3];
+  unsigned o1_off; int o1_ld; unsigned o2_off; int o2_ld;   // (SQ_CHAIN_NONE: not kept)
+  unsigned o3_off; int o3_ld; float scale; int pad;
   ChChunk chunk[SQ_CHAIN_MAX_KC];
 };
-struct ChainOp {
+struct alignas(16) ChainOp {
   int kind;      // COP_*
-  int items;     // dense: column tiles (an item = one column tile of up to two row tiles); RNN + tail: column tiles of one row
-                 // tile; crop: the 16 rows of a row tile; tail: 1
-  int pad0, pad1;
+  int items;     // dense: column tiles; RNN + tail: column tiles; crop: the 16 rows of a row tile; tail: 1
+  int nch;       // dense: K chunks per wave (which instantiation)
+  int pad1;
   union {
     ChDense dense;
     CropArgs crop;
@@ -59,15 +58,16 @@ struct ChainOp {
     TailArgs tail;
   } u;
 };
-struct ChainTable {
+struct alignas(16) ChainTable {
   int n_ops, n_row_tiles;
   int launch_id;            // ordinal of the chain launch inside its pass (2 t + phase)
   int pad0;
   int staged;               // crop: frame staged in LDS
   int lds_scratch_floats;   // LDS floats ahead of the table's copy (the ops' scratch)
+  int pad1, pad2;
   Dims d;
   POff po;
-  ChainOp ops[SQ_CHAIN_MAX_OPS];
+  alignas(16) ChainOp ops[SQ_CHAIN_MAX_OPS];
 };
 
 // a strided range of hand-off words to fill with the sentinel before a pass

@@ -43,10 +43,22 @@ constexpr int CH_LDS_TR = 16 * 68 + 64 + 3072;   // eight stamps of the current 
 #define CH_TRACE_T(i)
 #endif
 #define CH_TRACE_POLLS(n)
+// A pointer read from the LDS copy of the table is a generic pointer to the compiler: it is dereferenced with FLAT instructions,
+// which count on lgkmcnt as well -- every later wait for an LDS read then also waits for the weight / operand loads in flight
+// (measured: the A-operand polls of a dense item went out a memory round trip late).  Round-tripping the pointer through the
+// global address space lets the address-space inference turn those accesses into global_load / global_store.
+typedef __attribute__((address_space(1))) float ch_gf;
+typedef const __attribute__((address_space(1))) float ch_gcf;
+typedef const __attribute__((address_space(1))) f32x4_t ch_gcf4;
+typedef const __attribute__((address_space(1))) float4 ch_gcfloat4;
+#define CH_GLB(T, p) ((T*)(p))
 #define CH_POLL_BEGIN { int ch_spins = 0; bool ch_ok; do { ch_ok = true; unsigned ch_bad = 0;
 #define CH_POLL_END(status)                                                                         \
     ch_ok = __all(ch_ok && ch_bad == 0);                                                            \
-    if (!ch_ok) __builtin_amdgcn_s_sleep(1);                                                        \
+    if (!ch_ok) {                                                                                   \
+      __builtin_amdgcn_s_sleep(1);                                                                  \
+      if ((ch_spins & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break; \
+    }                                                                                               \
   } while (!ch_ok && ++ch_spins < SQ_CHAIN_SPIN_LIMIT);                                             \
   CH_TRACE_POLLS(ch_spins + 1);                                                                     \
   if (!ch_ok && (threadIdx.x & 63) == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -68,19 +80,23 @@ __device__ __forceinline__ void chain_dense(const ChDense& a, CH_RSRC rs, const 
   const unsigned out_off = a.out_off, o2_off = a.o2_off, e0_off = a.e0_off, e1_off = a.e1_off;
   const int out_ld = a.out_ld, o1_ld = a.o1_ld, o2_ld = a.o2_ld, o3_ld = a.o3_ld, add_ld = a.add_ld, e0_ld = a.e0_ld, e1_ld = a.e1_ld;
   const float scale = a.scale;
-  const f32x4_t* __restrict__ wp0 = reinterpret_cast<const f32x4_t*>(((unsigned long long)CH_UNI(a.wp_hi) << 32) | CH_UNI(a.wp_lo)) + lane;
-  const f32x4_t* __restrict__ wz = reinterpret_cast<const f32x4_t*>(((unsigned long long)CH_UNI(a.wz_hi) << 32) | CH_UNI(a.wz_lo)) + lane;
-  const float* __restrict__ biasp = reinterpret_cast<const float*>(((unsigned long long)CH_UNI(a.bias_hi) << 32) | CH_UNI(a.bias_lo));
+  ch_gcf4* __restrict__ wp0 = CH_GLB(ch_gcf4, ((unsigned long long)CH_UNI(a.wp_hi) << 32) | CH_UNI(a.wp_lo)) + lane;
+  ch_gcf4* __restrict__ wz = CH_GLB(ch_gcf4, ((unsigned long long)CH_UNI(a.wz_hi) << 32) | CH_UNI(a.wz_lo)) + lane;
+  ch_gcf* __restrict__ biasp = CH_GLB(ch_gcf, ((unsigned long long)CH_UNI(a.bias_hi) << 32) | CH_UNI(a.bias_lo));
   const int nmine = (kc_total - wave + 3) >> 2;
   f32x4_t bv[TN][NCH];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
-    const f32x4_t* wp = wp0 + (size_t)(min(tile_n0 + tn, n_tiles - 1) * kc_total) * 64;
+    ch_gcf4* wp = wp0 + (size_t)(min(tile_n0 + tn, n_tiles - 1) * kc_total) * 64;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const bool valid = j < nmine;
       const int g = valid ? wave + 4 * j : wave;
+#ifdef SQAIR_CHAIN_ABL_NOW
+      bv[tn][j] = *wz;          // ablation (timing only): every weight chunk = the (cache-resident) zero block
+#else
       bv[tn][j] = *(valid ? wp + (size_t)g * 64 : wz);
+#endif
     }
   }
   CH_TRACE_T(1);
@@ -192,8 +208,16 @@ __device__ __forceinline__ void chain_crop(const CropArgs& a, const POff& po, co
   const int slot = CH_UNI(a.slot), mode = CH_UNI(a.mode);
   const int mrow_add = a.mask_row_add;
   const int orow_add = a.out_row_add;
-  const float* __restrict__ img = a.img + (size_t)b * d.P4;
+  ch_gcf* __restrict__ img = CH_GLB(ch_gcf, a.img) + (size_t)b * d.P4;
   const bool has_mask = a.mask != nullptr;
+  ch_gcf* __restrict__ a_mask = CH_GLB(ch_gcf, a.mask);
+  ch_gcf* __restrict__ a_noise = CH_GLB(ch_gcf, a.noise);
+  ch_gcf* __restrict__ a_flat = CH_GLB(ch_gcf, a.flat);
+  ch_gcf* __restrict__ a_rec_prev = CH_GLB(ch_gcf, a.rec_prev);
+  ch_gcf* __restrict__ a_w3 = CH_GLB(ch_gcf, a.w3);
+  ch_gf* __restrict__ a_out = CH_GLB(ch_gf, a.out);
+  ch_gf* __restrict__ a_rec_new = CH_GLB(ch_gf, a.rec_new);
+  ch_gf* __restrict__ a_tp_out = CH_GLB(ch_gf, a.tp_out);
   constexpr int IPT = 10;
   float v0[IPT];
   constexpr int MPT = 2;
@@ -205,20 +229,23 @@ __device__ __forceinline__ void chain_crop(const CropArgs& a, const POff& po, co
   constexpr int QM = 2;
   const int nq = per / 4;
   f32x4_t xv[QM];
-  float4 wv[QM][4][2];
+  f32x4_t wv[QM][4][2];
   if (tid < 32) {
-    const float* eps = a.noise + (((size_t)r * 2 + (mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
+    ch_gcf* eps = a_noise + (((size_t)r * 2 + (mode == CROP_DISC ? 1 : 0)) * d.N + slot) * d.nzw;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) e[jj] = eps[jj];
     if (mode == CROP_DISC) {
-      off = a.flat[po.disc_scale_offset];
+      off = a_flat[po.disc_scale_offset];
     } else {
-      off = a.flat[po.prop_scale_offset];
-      zp = a.rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHERE + ci];
+      off = a_flat[po.prop_scale_offset];
+      zp = a_rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHERE + ci];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) chv[jj] = tril4(a.flat + po.cholesky, ci, min(jj, ci));
+      for (int jj = 0; jj < 4; ++jj) {   // tril4 (sqair_common.h) on the global pointer
+        const int tq = ci * 4 + min(jj, ci);
+        chv[jj] = (a_flat + po.cholesky)[tq < 6 ? 4 + tq : 15 - tq];
+      }
     }
-    const float4* w4 = reinterpret_cast<const float4*>(a.w3) + (size_t)per * hl * 2;
+    ch_gcf4* w4 = (ch_gcf4*)(a_w3) + (size_t)per * hl * 2;
 #pragma unroll
     for (int q = 0; q < QM; ++q) {
       const int qc = min(q, nq - 1);
@@ -233,7 +260,7 @@ __device__ __forceinline__ void chain_crop(const CropArgs& a, const POff& po, co
   }
 #pragma unroll
   for (int q = 0; q < MPT; ++q)
-    mk0[q] = has_mask ? a.mask[((size_t)r * a.mask_row_mul + mrow_add) * G2 + min(tid + 256 * q, G2 - 1)] : 1.0f;
+    mk0[q] = has_mask ? a_mask[((size_t)r * a.mask_row_mul + mrow_add) * G2 + min(tid + 256 * q, G2 - 1)] : 1.0f;
   __builtin_amdgcn_sched_barrier(0);
   if (tid < 32) {
     const unsigned xoff = ch_off(wsb, a.t2) + (unsigned)(r * a.t2_ld + per * hl) * 4u;
@@ -253,19 +280,19 @@ __device__ __forceinline__ void chain_crop(const CropArgs& a, const POff& po, co
         const float xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
-          const float4 wa = wv[q][ii][0], wb2 = wv[q][ii][1];
+          const f32x4_t wa = wv[q][ii][0], wb2 = wv[q][ii][1];
           part[0] += xs[ii] * wa.x; part[1] += xs[ii] * wa.y; part[2] += xs[ii] * wa.z; part[3] += xs[ii] * wa.w;
           part[4] += xs[ii] * wb2.x; part[5] += xs[ii] * wb2.y; part[6] += xs[ii] * wb2.z; part[7] += xs[ii] * wb2.w;
         }
       }
     }
 #pragma unroll
-    for (int o = 0; o < 8; ++o) part[o] = sq_half_sum(part[o]) + a.w3[d.nh * 8 + o];
+    for (int o = 0; o < 8; ++o) part[o] = sq_half_sum(part[o]) + a_w3[d.nh * 8 + o];
     tp_loc = ci == 0 ? part[0] : (ci == 1 ? part[1] : (ci == 2 ? part[2] : part[3]));
     tp_raw = ci == 0 ? part[4] : (ci == 1 ? part[5] : (ci == 2 ? part[6] : part[7]));
     if (a.tp_out != nullptr && hl < 4) {
-      a.tp_out[(size_t)r * a.tp_out_ld + ci] = tp_loc;
-      a.tp_out[(size_t)r * a.tp_out_ld + 4 + ci] = tp_raw;
+      a_tp_out[(size_t)r * a.tp_out_ld + ci] = tp_loc;
+      a_tp_out[(size_t)r * a.tp_out_ld + 4 + ci] = tp_raw;
     }
     float wl, loc, sc;
     if (mode == CROP_DISC) {
@@ -282,7 +309,7 @@ __device__ __forceinline__ void chain_crop(const CropArgs& a, const POff& po, co
       wl = loc + acc;
     }
     if (hl < 4) {
-      float* rn = a.rec_new + ((size_t)r * d.N + slot) * rec::W;
+      ch_gf* rn = a_rec_new + ((size_t)r * d.N + slot) * rec::W;
       rn[rec::WHERE + ci] = wl;
       rn[rec::WHERE_LOC + ci] = loc;
       rn[rec::WHERE_SCALE + ci] = sc;
@@ -298,7 +325,7 @@ __device__ __forceinline__ void chain_crop(const CropArgs& a, const POff& po, co
     for (int idx = 256 * IPT + tid; idx < P; idx += 256) img_s[idx] = img[idx];
   }
   __syncthreads();
-  const float* __restrict__ src = stage_img ? img_s : img;
+  const float* __restrict__ src = img_s;   // (read only when stage_img)
   for (int i = tid; i < 2 * G; i += 256) {
     const bool is_y = i >= G;
     const int j = is_y ? i - G : i;
@@ -318,7 +345,7 @@ __device__ __forceinline__ void chain_crop(const CropArgs& a, const POff& po, co
 #pragma unroll
       for (int u = 0; u < PX; ++u) {
         const int pix = min(p0 + 256 * u, G2 - 1);
-        mk[u] = has_mask ? a.mask[((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix] : 1.0f;
+        mk[u] = has_mask ? a_mask[((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix] : 1.0f;
         const int i = sq_div(pix, d.g_mul), j = pix - i * G;
         const float x0f = tab_s[j * 2], wx1 = tab_s[j * 2 + 1];
         const float y0f = tab_s[(G + i) * 2], wy1 = tab_s[(G + i) * 2 + 1];
@@ -339,12 +366,12 @@ __device__ __forceinline__ void chain_crop(const CropArgs& a, const POff& po, co
           float v = 0.0f;
 #pragma unroll
           for (int q = 0; q < 4; ++q) v += tw[u][q] * tv[u][q];
-          a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + p0 + 256 * u] = has_mask ? v * mk[u] : v;
+          a_out[((size_t)r * a.out_row_mul + orow_add) * G2 + p0 + 256 * u] = has_mask ? v * mk[u] : v;
         }
     }
   } else
   for (int pix = tid, q = 0; pix < G2; pix += 256, ++q) {
-    const float mk = q < MPT ? mk0[q < MPT ? q : 0] : (has_mask ? a.mask[((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix] : 1.0f);
+    const float mk = q < MPT ? mk0[q < MPT ? q : 0] : (has_mask ? a_mask[((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix] : 1.0f);
     const int i = sq_div(pix, d.g_mul), j = pix - i * G;
     const float x0f = tab_s[j * 2], wx1 = tab_s[j * 2 + 1];
     const float y0f = tab_s[(G + i) * 2], wy1 = tab_s[(G + i) * 2 + 1];
@@ -363,7 +390,7 @@ __device__ __forceinline__ void chain_crop(const CropArgs& a, const POff& po, co
         v += wy * wx * src[yy * d.W + xx];
       }
     }
-    a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + pix] = has_mask ? v * mk : v;
+    a_out[((size_t)r * a.out_row_mul + orow_add) * G2 + pix] = has_mask ? v * mk : v;
   }
 }
 
@@ -379,7 +406,12 @@ __device__ __forceinline__ void chain_tail(const TailArgs& a, const Dims& d, CH_
   const int n_tiles = nsp / 16;
   const bool is_disc = CH_UNI(a.is_disc) != 0;
   const int slot = CH_UNI(a.slot);
-  const f32x4_t* wp4 = reinterpret_cast<const f32x4_t*>(a.wp);
+  ch_gcf4* wp4 = CH_GLB(ch_gcf4, a.wp);
+  ch_gcf* __restrict__ a_flat = CH_GLB(ch_gcf, a.flat);
+  ch_gcf* __restrict__ a_noise = CH_GLB(ch_gcf, a.noise);
+  ch_gcf* __restrict__ a_rec_prev = CH_GLB(ch_gcf, a.rec_prev);
+  ch_gf* __restrict__ a_rec_new = CH_GLB(ch_gf, a.rec_new);
+  ch_gf* __restrict__ a_s1h_out = CH_GLB(ch_gf, a.s1h_out);
   f32x4_t bv[2][4];
   float sp[2][4], w2v[2];
   unsigned sp_off[2][4];
@@ -391,14 +423,14 @@ __device__ __forceinline__ void chain_tail(const TailArgs& a, const Dims& d, CH_
     for (int c = 0; c < 4; ++c) bv[t][c] = wp4[(size_t)(tile * 4 + c) * 64 + lane];
 #pragma unroll
     for (int i = 0; i < 4; ++i) sp_off[t][i] = ch_off(wsb, a.s1p) + (unsigned)(min(row0 + 4 * kq + i, d.R - 1) * a.s1p_ld + col) * 4u;
-    w2v[t] = a.flat[a.w2_off + col];
+    w2v[t] = a_flat[a.w2_off + col];
   }
   const int pr = min(row0 + (tid & 15), d.R - 1);
-  const float b2 = a.flat[a.b2_off];
-  const float u = a.noise[(((size_t)pr * 2 + (is_disc ? 1 : 0)) * d.N + slot) * d.nzw + 4 + nw];
+  const float b2 = a_flat[a.b2_off];
+  const float u = a_noise[(((size_t)pr * 2 + (is_disc ? 1 : 0)) * d.N + slot) * d.nzw + 4 + nw];
   const bool prev_dep = is_disc && slot > 0;   // the previous discovery step's presence: written by an earlier op of this chain
   float prev = 1.0f;
-  if (!is_disc) prev = a.rec_prev[((size_t)pr * d.N + slot) * rec::W + rec::PRES];
+  if (!is_disc) prev = a_rec_prev[((size_t)pr * d.N + slot) * rec::W + rec::PRES];
   const unsigned wh_off = ch_off(wsb, a.rec_new) + (unsigned)((pr * d.N + slot) * rec::W + rec::WHERE) * 4u;
   const unsigned prev_off = prev_dep ? ch_off(wsb, a.rec_new) + (unsigned)((pr * d.N + slot - 1) * rec::W + rec::PRES) * 4u : wh_off;
   float whv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -413,8 +445,8 @@ __device__ __forceinline__ void chain_tail(const TailArgs& a, const Dims& d, CH_
     const int r = min(row0 + rr, d.R - 1);
     enc_off[q] = ch_off(wsb, a.enc) + (unsigned)(r * a.enc_ld + c) * 4u;
     h_off[q] = is_disc ? enc_off[q] : ch_off(wsb, a.hraw) + (unsigned)(r * a.h_ld + c) * 4u;
-    v_eps[q] = a.noise[(((size_t)r * 2 + (is_disc ? 1 : 0)) * d.N + slot) * d.nzw + 4 + c];
-    v_tm1[q] = is_disc ? 0.0f : a.rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHAT + c];
+    v_eps[q] = a_noise[(((size_t)r * 2 + (is_disc ? 1 : 0)) * d.N + slot) * d.nzw + 4 + c];
+    v_tm1[q] = is_disc ? 0.0f : a_rec_prev[((size_t)r * d.N + slot) * rec::W + rec::WHAT + c];
   }
   __builtin_amdgcn_sched_barrier(0);
   const unsigned nwb = (unsigned)nw * 4u;
@@ -476,7 +508,7 @@ __device__ __forceinline__ void chain_tail(const TailArgs& a, const Dims& d, CH_
       const float what = loc + sc * v_eps[q];
       zt[rr * CH_ZLD + rec::WHAT + c] = what;
       if (STORE && row0 + rr < d.R) {
-        float* rn = a.rec_new + ((size_t)(row0 + rr) * d.N + slot) * rec::W;
+        ch_gf* rn = a_rec_new + ((size_t)(row0 + rr) * d.N + slot) * rec::W;
         rn[rec::WHAT + c] = what;
         rn[rec::WHAT_LOC + c] = loc;
         rn[rec::WHAT_SCALE + c] = sc;
@@ -506,7 +538,7 @@ __device__ __forceinline__ void chain_tail(const TailArgs& a, const Dims& d, CH_
         const float hv = sq_elu(acc[t][i] + sp[t][i]);
         v += hv * w2v[t];
         if (STORE && a.s1h_out != nullptr && row0 + 4 * kq + i < d.R)
-          a.s1h_out[(size_t)(row0 + 4 * kq + i) * a.s1h_ld + (wave + 4 * t) * 16 + (lane & 15)] = hv;
+          a_s1h_out[(size_t)(row0 + 4 * kq + i) * a.s1h_ld + (wave + 4 * t) * 16 + (lane & 15)] = hv;
       }
     part[i] = sq_row_sum(v);
   }
@@ -521,7 +553,7 @@ __device__ __forceinline__ void chain_tail(const TailArgs& a, const Dims& d, CH_
     const float prob = sq_sigmoid(logit);
     const float pres = (u < prob ? 1.0f : 0.0f) * prev;
     if (STORE && row0 + tid < d.R) {
-      float* rn = a.rec_new + ((size_t)(row0 + tid) * d.N + slot) * rec::W;
+      ch_gf* rn = a_rec_new + ((size_t)(row0 + tid) * d.N + slot) * rec::W;
       rn[rec::PRES] = pres;
       rn[rec::LOGIT] = logit;
       rn[rec::PROB] = prob;
@@ -542,14 +574,14 @@ __device__ __forceinline__ void chain_rnn(const ChainRnn& c, const Dims& d, CH_R
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
   const int row0 = tile_m * 16;
   constexpr int KC = 4 + 4 * NH;
-  const f32x4_t* __restrict__ wp = reinterpret_cast<const f32x4_t*>(c.wp) + ((size_t)tile_n * KC) * 64 + lane;
+  ch_gcf4* __restrict__ wp = CH_GLB(ch_gcf4, c.wp) + ((size_t)tile_n * KC) * 64 + lane;
   const unsigned hoff = ch_off(wsb, c.hid) + (unsigned)(min(row0 + l15, d.R - 1) * c.hid_ld) * 4u;
   f32x4_t bz = wp[(size_t)wave * 64], bh[NH], ah[NH];
 #pragma unroll
   for (int i = 0; i < NH; ++i) bh[i] = wp[(size_t)(wave + 4 * (i + 1)) * 64];
   const int m = row0 + (tid >> 4), n = tile_n * 16 + (tid & 15);
   const int mc = min(m, d.R - 1), nc = min(n, c.n_out - 1);
-  const float p_bias = c.bias[nc];
+  const float p_bias = CH_GLB(ch_gcf, c.bias)[nc];
   const unsigned add_off = ch_off(wsb, c.add) + (unsigned)(mc * c.add_ld + nc) * 4u;
   float p_add;
   CH_POLL_BEGIN
@@ -584,7 +616,7 @@ __device__ __forceinline__ void chain_rnn(const ChainRnn& c, const Dims& d, CH_R
   r[(4 * kq + 2) * 16 + l15] = acc0.z + acc1.z;
   r[(4 * kq + 3) * 16 + l15] = acc0.w + acc1.w;
   __syncthreads();
-  if (m < d.R && n < c.n_out) c.out[(size_t)m * c.out_ld + n] = sq_tanh(red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + p_bias + p_add);
+  if (m < d.R && n < c.n_out) CH_GLB(ch_gf, c.out)[(size_t)m * c.out_ld + n] = sq_tanh(red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + p_bias + p_add);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -608,13 +640,19 @@ __global__ __launch_bounds__(256) void k_slot_chain(const ChainTable* __restrict
   CH_RSRC rs = __builtin_amdgcn_make_buffer_rsrc((void*)ws_base, 0, (int)ws_bytes, 0x00020000);
   const char* wsb = (const char*)ws_base;
   const int n_row_tiles = tab->n_row_tiles, n_ops = tab->n_ops;
+  // a failed launch fails the rest of the pass at once (its results are garbage anyway; nobody spins on them)
+  const unsigned* pass_status = ctl - (size_t)tab->launch_id * SQ_CHAIN_CTL_WORDS + 9 * 32;
+  if (tab->launch_id > 0 && __hip_atomic_load(pass_status + (size_t)(tab->launch_id - 1) * SQ_CHAIN_CTL_WORDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    if (tid == 0) __hip_atomic_store(status, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   if (n_ops < 1 || n_ops > SQ_CHAIN_MAX_OPS || tab->lds_scratch_floats < CH_LDS_FLOATS || tab->lds_scratch_floats > 40000) {
     if (tid == 0) __hip_atomic_store(status, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // not a table
     return;
   }
   // the table's LDS copy (behind the ops' scratch): requested while the census atomics travel
   const int scratch_floats = tab->lds_scratch_floats;
-  const ChainTable* lt = reinterpret_cast<const ChainTable*>(smem + scratch_floats);
+  const ChainTable* lt = reinterpret_cast<const ChainTable*>(__builtin_assume_aligned(smem + (scratch_floats & ~3), 16));
   {
     const int words4 = ((int)offsetof(ChainTable, ops) + n_ops * (int)sizeof(ChainOp) + 15) / 16;
     const u32x4_t* src = reinterpret_cast<const u32x4_t*>(tab);
@@ -691,7 +729,7 @@ __global__ __launch_bounds__(256) void k_slot_chain(const ChainTable* __restrict
       while (sub >= groups) { sub -= groups; ++grp; }
       const int tile = idx_x + grp * n_act;
       if (kind == COP_DENSE) {
-        const int nch = CH_UNI(op.u.dense.nch);
+        const int nch = CH_UNI(op.nch);
         if (nch <= 4) {
           if (tn == 1) chain_dense<4, 1>(op.u.dense, rs, tile, sub, items, red, status);
           else if (tn == 2) chain_dense<4, 2>(op.u.dense, rs, tile, 2 * sub, items, red, status);
@@ -785,6 +823,7 @@ struct ChainState {
   std::vector<ChainCacheEntry> cache;
   void* arena = nullptr;
   size_t arena_used = 0;
+  int grid = 0, occupancy = 0;
 };
 static ChainState* cs_of(SqairHandle* h) {
   if (!h->chain) h->chain = new ChainState();
@@ -840,6 +879,7 @@ int sq_chain_add_dense(SqairHandle* h, const LinArgs& a, int kc_total, int n_til
   chain_split(a.wzero, &dn.wz_lo, &dn.wz_hi);
   chain_split(a.bias, &dn.bias_lo, &dn.bias_hi);
   dn.M = a.M; dn.N = a.N; dn.kc_total = kc_total; dn.nch = (kc_total + 3) / 4;
+  op->nch = dn.nch;
   dn.epi = a.epi; dn.act_a = a.act_a; dn.act_b = a.act_b; dn.act_split = a.act_split; dn.scale = a.scale; dn.nh = a.nh;
   dn.add_off = dn.o1_off = dn.o2_off = dn.o3_off = SQ_CHAIN_NONE;
   bool ok = chain_off(h, a.out, &dn.out_off);
@@ -938,7 +978,22 @@ int sq_chain_flush(SqairHandle* h, unsigned* ctl, int launch_id, hipStream_t s) 
   if (lds > 64 * 1024) {
     if (lds > 150 * 1024 || sq_allow_big_lds((const void*)k_slot_chain, lds) != 0) { sq_set_error(h, "slot chain: LDS"); return -3; }
   }
-  SQ_LAUNCH(k_slot_chain, dim3(256), dim3(256), lds, s, (const ChainTable*)dev, ctl, (const float*)c->ws_base, (unsigned)c->ws_bytes);
+  // The census needs the whole grid co-resident: one workgroup per CU, or two where the occupancy query says two fit (one
+  // polls while the other computes).
+  if (c->grid == 0) {
+    int dev_id = 0, cus = 0, occ = 0;
+    SQ_CHECK_HIP(hipGetDevice(&dev_id));
+    SQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id));
+    SQ_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_slot_chain, 256, (size_t)lds));
+    static const int per_cu = SQ_KNOB_INT("SQAIR_CHAIN_WGS_PER_CU", 1);
+    c->occupancy = occ;
+    c->grid = cus * (occ >= per_cu ? per_cu : 1);
+    if (occ < 1 || cus < 1) { sq_set_error(h, "slot chain: the kernel does not fit a CU"); return -3; }
+#ifdef SQAIR_KNOBS
+    fprintf(stderr, "slot chain: %d CUs, occupancy query %d workgroups per CU at %d bytes of LDS, grid %d\n", cus, occ, lds, c->grid);
+#endif
+  }
+  SQ_LAUNCH(k_slot_chain, dim3(c->grid), dim3(256), lds, s, (const ChainTable*)dev, ctl, (const float*)c->ws_base, (unsigned)c->ws_bytes);
   return 0;
 #endif
 }

@@ -29,7 +29,7 @@ def main():
     noise[..., -1] = rng.uniform(size=noise.shape[:-1])
     res = {}
     for name, opts in (("launches", {}), ("chain", {"slot_chain": 1})):
-        core = SqairCore(F, hw, options=opts)
+        core = SqairCore(F, hw, options=opts, lib_path=(os.path.join(ROOT, "tools", "bin", os.environ["KNOBS"] if os.environ.get("KNOBS", "1") != "1" else "libsqair_hip_knobs.so") if os.environ.get("KNOBS") else None))
         core.set_params(P)
         m = Model(obs, None, core, K, presence=d["nums"])
         for use_graph in (False, True):
