@@ -74,7 +74,9 @@ const char* sqair_build_flags(void);
  * same C-ABI, slower per-row kernels -- takes n_what <= 128, n_steps_per_image <= 16 (15, 16 only while the log-probability
  * adjoint's LDS staging fits: not with its 416-float slot record), n_hidden <= 512.  Both: n_hidden = 32 * n_units any multiple
  * of 16 (the kernels run on the next of 128 / 256 / 512 with inert padding units; parameters, gradients and final states cross
- * this ABI in the reference's shapes), k_particles <= 256, any H x W.  The reference's flags take any value
+ * this ABI in the reference's shapes), k_particles <= 256, any H x W for inference; TRAINING (sqair_forward_train /
+ * sqair_backward) takes frames up to 38 400 pixels (150 KB: the crop adjoint stages the frame in LDS) and says so at entry.
+ * The reference's flags take any value
  * (sqair/common_model_flags.py:32-56, sqair/configs/mlp_mnist_model.py:42-52); a host picks the library by the flags
  * (sqair_amd/_capi.py: lib_path_for). */
 int sqair_create(const SqairConfig* cfg, SqairHandle** out);
@@ -270,13 +272,32 @@ int sqair_clear_workspace(SqairHandle* h, void* workspace, int64_t workspace_byt
  *   "tail_fusion" (default 1): compute the tail of slot k inside slot k + 1's VanillaRNN launch; 0 = one launch per
  *                 operation.  Results are bit-identical either way (tests/test_hip_forward.py); affects the following passes
  *                 and captures.
+ *   "vi_target" (default 0): the learning signal sqair_elbo writes (and sqair_backward consumes) and the proxy loss in
+ *                 scalars_out[2]: 0 = VIMCO, log w - control variate (sqair/targets.py:62-75: what the reference's make_target
+ *                 uses); 1 = plain REINFORCE, log w (sqair/targets.py:78-89, advertised in Model.VI_TARGETS).
+ *   "slot_chain" (default 0): run the strictly sequential slot launches of a frame's propagation loop, and of its discovery
+ *                 loop, as ONE persistent launch each (csrc/sqair_chain.h: hand-offs through the XCD's L2, polled word by word).
+ *                 Bit-identical results.  Serves the shipped cell configuration (VanillaRNN slot cell, GRU temporal cell,
+ *                 n_hidden 256) up to 320 particle rows; other shapes keep one launch per op.  Set it BEFORE sizing / clearing
+ *                 workspaces (the per-slot buffers are then kept apart like the training tape), and use it on a device this
+ *                 process has to itself: the launch needs its 256 workgroups co-resident (another kernel occupying the CUs
+ *                 makes it give up after ~20 ms with a status instead of results: sqair_chain_status).  Faster than the
+ *                 launches up to ~128 particle rows (one 16-row tile per XCD), about equal at 160.
  * Returns -2 for an unknown name. */
 int sqair_set_option(SqairHandle* h, const char* name, int value);
+/* Status of the slot chain's launches of the last pass on `workspace` (synchronises `stream`): 0 = all completed (or the chain is
+ * off for this shape), else the first non-zero status (1 = an operand never arrived, 3 = the workgroups were not co-resident,
+ * 6 = an earlier launch of the pass had failed); the text is in sqair_last_error. */
+int sqair_chain_status(SqairHandle* h, void* workspace, int T, int B, int train, void* stream);
 /* Debug mode of the reference (`debug=True` -> validate_args / allow_nan_stats=False on its distributions,
  * sqair/core.py:226, :261, sqair/modules.py:318-320; a TF runtime error inside sess.run): checks x[0:n] for NaN / Inf on
  * `stream`, SYNCHRONISES it, and returns -5 with "non-finite values in <what>: count, first index" in sqair_last_error.
  * flag_dev: caller-owned device int32[2] scratch. */
 int sqair_check_finite(SqairHandle* h, const float* x, int64_t n, const char* what, int32_t* flag_dev, void* stream);
+/* The same mode's argument validation of the Normal distributions: the posterior scales of `what` and `where` of EVERY propagation
+ * and discovery slot of the last pass on `workspace` must be positive and finite -- also of slots the presence mask later removes
+ * from the log-weights (which sqair_check_finite on the log-weights cannot see).  Synchronises; -5 + text on failure. */
+int sqair_check_scales(SqairHandle* h, void* workspace, int T, int B, int train, int32_t* flag_dev, void* stream);
 
 /* ---- per-dispatch timeline (measurement; bench.py's roofline, tools/timeline.py) -----------------------------------------
  * libsqair_hip_timeline.so is THIS library compiled with -DSQAIR_TIMELINE: every kernel takes one more argument and every

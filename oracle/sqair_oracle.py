@@ -303,6 +303,15 @@ def vimco(log_w, log_probs, elbo_iwae=None):
     return (-elbo_iwae[..., None] - signal * log_probs).mean()
 
 
+def reinforce(log_w, log_probs, elbo_iwae=None):
+    """targets.py:78-89 (learning signal = stop_gradient(log_w): no control variate)."""
+    signal = log_w.detach()
+    log_probs = log_probs.reshape(log_w.shape)
+    if elbo_iwae is None:
+        elbo_iwae = iwae(log_w)
+    return (-elbo_iwae[..., None] - signal * log_probs).mean()
+
+
 def ess(w):
     """ops.py:52-59 with average=True."""
     return (w.sum(-1) ** 2 / (w ** 2).sum(-1)).mean()
@@ -832,10 +841,11 @@ class SqairOracle(object):
         m.n_timesteps = T
         return m
 
-    def make_target(self, m, l2_reg=0.0):
-        """Model.make_target (model.py:150-168): VIMCO / T (+ l2)."""
+    def make_target(self, m, l2_reg=0.0, vi_target="vimco"):
+        """Model.make_target (model.py:150-168): VIMCO / T (+ l2); `reinforce` = the other entry of Model.VI_TARGETS (model.py:36)."""
         log_probs = m.discrete_log_prob.sum(0)
-        target = vimco(m.log_weights, log_probs, m.elbo_iwae_per_example) / float(m.n_timesteps)
+        fn = {"vimco": vimco, "reinforce": reinforce}[vi_target]
+        target = fn(m.log_weights, log_probs, m.elbo_iwae_per_example) / float(m.n_timesteps)
         if l2_reg != 0.0:
             target = target + l2_reg * sum(0.5 * (p ** 2).sum() for p in self.P.values())
         return target

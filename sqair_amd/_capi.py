@@ -78,6 +78,8 @@ _PROTOS = {
     "sqair_set_workspace_clearing": (C.c_int, [C.c_void_p, C.c_int]),
     "sqair_clear_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sqair_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "sqair_chain_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sqair_check_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sqair_check_finite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_void_p, C.c_void_p]),
     "sqair_timeline_available": (C.c_int, []),
     "sqair_timeline_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -177,8 +179,16 @@ def lib(path=None, allow_stale=False):
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        got, want = l.sqair_build_id().decode(), source_id()
-        if got != want and not allow_stale:
+        got = l.sqair_build_id().decode()
+        try:
+            want = source_id()
+        except OSError:     # a binary-only deployment (no csrc/ or include/ beside the package): nothing to compare with
+            want = None
+            if not allow_stale:
+                import warnings
+                warnings.warn("{}: the kernel sources are not beside the package, the staleness check of the binary "
+                              "(build id {}) is skipped".format(os.path.basename(path), got))
+        if want is not None and got != want and not allow_stale:
             raise StaleLibraryError(
                 "{} was compiled from sources {} but the sources on disk are {}: rebuild (python sqair_amd/csrc/build.py "
                 "--force [--timeline] [--knobs]); numbers measured on a stale binary would be attributed to the wrong "

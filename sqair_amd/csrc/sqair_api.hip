@@ -1277,7 +1277,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     la.rec_p = w.rec_p_all; la.rec_d = w.rec_d_all; la.rec_prev = w.rec_m_all; la.pstats = w.pstats; la.ps_ld = PS_LD;
     la.spre = w.spre; la.flat = flat; la.t_global = t_offset; la.t = 0; la.n_frames = T; la.qz = w.qz; la.pz = w.pz;
     la.disc_lp = w.dlp; la.out = out; la.cfg = c; la.gen = c.sample_from_prior ? w.gen : nullptr;
-    sq_launch_logprob(la, po, d, s);
+    if (sq_launch_logprob(la, po, d, s) != 0) { sq_set_error(h, "sqair_forward: the log-probability launch failed (dynamic LDS limit)"); return -2; }
   }
   // ---- J. decoder of all T frames as three M = T*B'*N row GEMMs + one insert / log-likelihood launch
   //      (modules.py:435-467, seq.py:271-276) ----
@@ -1318,10 +1318,21 @@ static int forward_impl(SqairHandle* h, const float* flat, const float* packed, 
 
 // Training-mode forward pass: identical launch sequence and results, but every intermediate the backward pass needs
 // is kept in the (larger) workspace; sqair_backward consumes it.
+// The crop adjoint stages the whole frame in LDS (k_crop_chain_bwd, sqair_bwd.hip): frames beyond SQ_TRAIN_MAX_FRAME_BYTES can be
+// evaluated (sqair_forward) but not trained.  Said here, at the entry points, instead of by a failed launch deep in the sweep.
+bool sq_trainable_frame(SqairHandle* h) {
+  const int64_t bytes = ((int64_t)h->cfg.img_h * h->cfg.img_w + 3) / 4 * 4 * 4;
+  if (bytes <= SQ_TRAIN_MAX_FRAME_BYTES) return true;
+  sq_set_error(h, "training is limited to frames of at most " + std::to_string(SQ_TRAIN_MAX_FRAME_BYTES / 4) + " pixels (" +
+                      std::to_string(h->cfg.img_h) + " x " + std::to_string(h->cfg.img_w) +
+                      " given): the crop adjoint stages the frame in LDS; inference (sqair_forward) has no such limit");
+  return false;
+}
 extern "C" int sqair_forward_train(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
                                    const float* noise, int T, int B, int t_offset, const SqairOutputs* out,
                                    void* workspace, int64_t workspace_bytes, void* stream) {
   if (!h) return -1;
+  if (!sq_trainable_frame(h)) return -1;
   return sq_forward_impl(h, flat_params, (const float*)packed, obs, noise, T, B, t_offset, out, (float*)workspace,
                          workspace_bytes, (hipStream_t)stream, true, 7);
 }
@@ -1437,6 +1448,11 @@ extern "C" int sqair_set_option(SqairHandle* h, const char* name, int value) {
   if (!h || !name) return -1;
   const std::string n(name);
   if (n == "tail_fusion") { h->opt_tail_fusion = value != 0; return 0; }
+  if (n == "vi_target") {   // 0 = vimco (the reference's make_target), 1 = reinforce (targets.py:78-89)
+    if (value != 0 && value != 1) { sq_set_error(h, "sqair_set_option: vi_target is 0 (vimco) or 1 (reinforce)"); return -2; }
+    h->opt_vi_target = value;
+    return 0;
+  }
   if (n == "slot_chain") {
 #ifdef SQAIR_WIDE
     if (value != 0) { sq_set_error(h, "sqair_set_option: slot_chain is not available in the wide build"); return -2; }
@@ -1445,7 +1461,7 @@ extern "C" int sqair_set_option(SqairHandle* h, const char* name, int value) {
     h->opt_slot_chain_mode = value;   // (2: the chain's workspace layout with one launch per op -- a debugging aid)
     return 0;
   }
-  sq_set_error(h, "sqair_set_option: unknown option '" + n + "' (known: tail_fusion, slot_chain)");
+  sq_set_error(h, "sqair_set_option: unknown option '" + n + "' (known: tail_fusion, slot_chain, vi_target)");
   return -2;
 }
 
@@ -1482,6 +1498,53 @@ extern "C" int sqair_check_finite(SqairHandle* h, const float* x, int64_t n, con
            (long long)n, got[1]);
   sq_set_error(h, msg);
   return -5;
+}
+
+// validate_args of the reference's Normal distributions (sqair/core.py:226, :261, sqair/modules.py:318-320: every scale must be
+// positive -- of EVERY slot, also of the slots the presence mask later removes from the log-weights): the posterior scales of
+// `what` and `where` of all propagation and discovery slots of the last pass on this workspace.
+__global__ __launch_bounds__(256) void k_scale_check(const float* __restrict__ rec, int64_t n_rec, int nw, int* __restrict__ flag SQ_TLP) {
+  SQ_TL_SCOPE;
+  const int per = 4 + nw;
+  int bad = 0;
+  int64_t first = n_rec * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_rec * per; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / per;
+    const int j = (int)(i - r * per);
+    const float v = rec[r * rec::W + (j < 4 ? rec::WHERE_SCALE + j : rec::WHAT_SCALE + (j - 4))];
+    if (!(v > 0.0f && v <= 3.4028234664e38f)) { ++bad; if (i < first) first = i; }
+  }
+  if (bad) {
+    atomicAdd(&flag[0], bad);
+    atomicMin(&flag[1], (int)(first < 0x7fffffff ? first : 0x7fffffff));
+  }
+}
+extern "C" int sqair_check_scales(SqairHandle* h, void* workspace, int T, int B, int train, int32_t* flag_dev, void* stream) {
+  if (!h || !workspace || !flag_dev || T < 1 || B < 1) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const Workspace w = sq_carve(h, T, B, (float*)workspace, train != 0);
+  const int64_t n_rec = (int64_t)T * w.M;
+  const char* names[2] = {"propagation", "discovery"};
+  const float* recs[2] = {w.rec_p_all, w.rec_d_all};
+  for (int ph = 0; ph < 2; ++ph) {
+    const int init[2] = {0, 0x7fffffff};
+    int got[2] = {0, 0};
+    SQ_CHECK_HIP(hipMemcpyAsync(flag_dev, init, sizeof(init), hipMemcpyHostToDevice, s));
+    SQ_LAUNCH(k_scale_check, dim3((int)std::min<int64_t>((n_rec * (4 + h->cfg.n_what) + 255) / 256, 1024)), dim3(256), 0, s, recs[ph], n_rec,
+              h->cfg.n_what, (int*)flag_dev);
+    SQ_CHECK_HIP(hipMemcpyAsync(got, flag_dev, sizeof(got), hipMemcpyDeviceToHost, s));
+    SQ_CHECK_HIP(hipStreamSynchronize(s));
+    if (got[0] != 0) {
+      const int per = 4 + h->cfg.n_what, rec_i = got[1] / per, j = got[1] % per;
+      char msg[320];
+      snprintf(msg, sizeof(msg), "scale not positive / not finite in the %s posterior: %d values, first at frame %d, row %d, slot %d, %s[%d] "
+               "(validate_args: every slot's scale is checked, also slots the presence mask removes)", names[ph], got[0],
+               rec_i / w.M, (rec_i % w.M) / w.N, rec_i % w.N, j < 4 ? "where_scale" : "what_scale", j < 4 ? j : j - 4);
+      sq_set_error(h, msg);
+      return -5;
+    }
+  }
+  return 0;
 }
 
 extern "C" int sqair_forward(SqairHandle* h, const float* flat_params, const void* packed, const float* obs,
@@ -1568,7 +1631,7 @@ extern "C" int sqair_elbo(SqairHandle* h, const float* log_w_t, const float* dis
                           void* stream) {
   if (!h || !log_w_t || T < 1 || B < 1 || n_means < 0 || n_means > 8) return -1;
   sq_launch_elbo(log_w_t, disc_lp_t, T, B, h->cfg.k_particles, log_weights, elbo_iwae_per_example, importance_weights,
-                 vimco_signal, scalars_out, iw_means_in, n_means, iw_means_out, (hipStream_t)stream);
+                 vimco_signal, scalars_out, iw_means_in, n_means, iw_means_out, (hipStream_t)stream, h->opt_vi_target);
   SQ_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1925,6 +1988,7 @@ extern "C" int sqair_backward_decoder(SqairHandle* h, const float* flat, const v
     sq_set_error(h, "sqair_backward_decoder: workspace / scratch too small");
     return -1;
   }
+  if (!sq_unit_frame_ok(h) || !sq_trainable_frame(h)) return -1;
   if (h->padded || rec::ZWP != 64) {
     sq_set_error(h, "sqair_backward_decoder (a partial adjoint kept for unit tests) writes in the product build's own shapes: use sqair_backward in the wide build or with an n_hidden that is padded");
     return -1;

@@ -205,4 +205,4 @@ int sq_launch_insert_loglik(const InsertArgs& a, Dims d, hipStream_t s);
 
 int sq_launch_elbo(const float* log_w_t, const float* disc_lp_t, int T, int B, int K, float* log_weights,
                    float* elbo_per_ex, float* iw, float* signal, float* scalars, const float* const* means_in,
-                   int n_means, float* means_out, hipStream_t s);
+                   int n_means, float* means_out, hipStream_t s, int reinforce = 0);

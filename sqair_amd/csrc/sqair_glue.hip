@@ -1293,7 +1293,7 @@ struct ElboMeans { const float* p[8]; };
 
 __global__ __launch_bounds__(1024) void k_elbo(const float* __restrict__ log_w_t, const float* __restrict__ disc_lp_t,
                                               int T, int B, int K, float* log_weights, float* elbo_per_ex, float* iw_out,
-                                              float* signal_out, float* scalars, ElboMeans means, int n_means,
+                                              float* signal_out, float* scalars, ElboMeans means, int n_means, const int reinforce,
                                               float* means_out SQ_TLP) {
   SQ_TL_SCOPE;
   __shared__ float acc_s[16][4 + 8];
@@ -1382,7 +1382,8 @@ __global__ __launch_bounds__(1024) void k_elbo(const float* __restrict__ log_w_t
         }
         cv = m2 + logf(rest + expf(abo - m2)) - logf((float)K);
       }
-      const float sig = act ? lw - cv : 0.0f;
+      // learning signal: VIMCO's log w - control variate (targets.py:62-75), or plain REINFORCE's log w (targets.py:78-89)
+      const float sig = act ? (reinforce ? lw : lw - cv) : 0.0f;
       const float loss = act ? (-elbo - sig * dl) : 0.0f;
       a_vae += sq_wave_sum(act ? lw : 0.0f);
       a_vimco += sq_wave_sum(loss);
@@ -1423,7 +1424,7 @@ __global__ __launch_bounds__(1024) void k_elbo(const float* __restrict__ log_w_t
 // k_elbo term by term (model.py:88-103, :150-158, :202-205; targets.py:38-75; ops.py:52-59).
 __global__ __launch_bounds__(1024) void k_elbo_wide(const float* __restrict__ log_w_t, const float* __restrict__ disc_lp_t,
                                                    int T, int B, int K, float* log_weights, float* elbo_per_ex, float* iw_out,
-                                                   float* signal_out, float* scalars, ElboMeans means, int n_means,
+                                                   float* signal_out, float* scalars, ElboMeans means, int n_means, const int reinforce,
                                                    float* means_out SQ_TLP) {
   SQ_TL_SCOPE;
   __shared__ float lw_s[1024], red_s[1024];
@@ -1461,7 +1462,7 @@ __global__ __launch_bounds__(1024) void k_elbo_wide(const float* __restrict__ lo
         if (j != k) rest += expf(lw_s[j] - m2);
       cv = m2 + logf(rest + expf(abo - m2)) - logf((float)K);
     }
-    const float sig = act ? lw - cv : 0.0f;
+    const float sig = act ? (reinforce ? lw : lw - cv) : 0.0f;
     const float loss = act ? (-elbo - sig * dl) : 0.0f;
     a_vae += sum_lw;
     a_vimco += bsum(loss);
@@ -1489,15 +1490,15 @@ __global__ __launch_bounds__(1024) void k_elbo_wide(const float* __restrict__ lo
 
 int sq_launch_elbo(const float* log_w_t, const float* disc_lp_t, int T, int B, int K, float* log_weights,
                    float* elbo_per_ex, float* iw, float* signal, float* scalars, const float* const* means_in,
-                   int n_means, float* means_out, hipStream_t s) {
+                   int n_means, float* means_out, hipStream_t s, int reinforce) {
   ElboMeans m;
   for (int i = 0; i < 8; ++i) m.p[i] = (means_in != nullptr && i < n_means) ? means_in[i] : nullptr;
   if (K > 64) {
     SQ_LAUNCH(k_elbo_wide, dim3(1), dim3(1024), 0, s, log_w_t, disc_lp_t, T, B, K, log_weights, elbo_per_ex, iw, signal, scalars, m,
-              n_means, means_out);
+              n_means, reinforce, means_out);
     return 0;
   }
   SQ_LAUNCH(k_elbo, dim3(1), dim3(1024), 0, s, log_w_t, disc_lp_t, T, B, K, log_weights, elbo_per_ex, iw,
-                     signal, scalars, m, n_means, means_out);
+                     signal, scalars, m, n_means, reinforce, means_out);
   return 0;
 }

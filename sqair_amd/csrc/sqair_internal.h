@@ -62,6 +62,7 @@ struct SqairHandle {
   bool opt_slot_chain = false;  // sqair_set_option("slot_chain"): the slot launches of a frame's propagation / discovery loop as one
                                 // persistent launch each (sqair_chain.h; bit-identical; set BEFORE sizing / clearing workspaces)
   int opt_slot_chain_mode = 0;
+  int opt_vi_target = 0;        // sqair_set_option("vi_target"): learning signal of sqair_elbo, 0 = VIMCO, 1 = plain REINFORCE
   void* chain = nullptr;        // ChainState (sqair_chain.hip)
   bool clear_each_pass = true;  // zero the caller's workspace at the start of every pass (sqair_set_workspace_clearing)
   const float* gen_noise = nullptr;  // sqair_set_generation_noise
@@ -72,6 +73,16 @@ struct SqairHandle {
 
 
 inline int64_t align64(int64_t x) { return (x + 63) / 64 * 64; }
+constexpr int64_t SQ_TRAIN_MAX_FRAME_BYTES = 150 * 1024;   // dynamic LDS the crop adjoint may ask for (sq_allow_big_lds)
+bool sq_trainable_frame(SqairHandle* h);                   // false + error text when the handle's frames cannot be trained
+// The partial adjoints kept for unit tests (sqair_st_*_bwd, sqair_backward_decoder) take the caller's frames as they are; the
+// adjoint kernels stage frames in 16-byte units, so these entry points want H * W to be a multiple of 4 (the full passes stage
+// other frames through a padded copy).
+inline bool sq_unit_frame_ok(SqairHandle* h) {
+  if (((h->cfg.img_h * h->cfg.img_w) & 3) == 0) return true;
+  sq_set_error(h, "this unit entry point needs H * W to be a multiple of 4 (use sqair_forward_train / sqair_backward for other frame sizes)");
+  return false;
+}
 int64_t P(const SqairHandle* h, const std::string& name);  // flat offset of a parameter (aborts on unknown names)
 int PC(const SqairHandle* h, const std::string& name);      // its number of columns
 

@@ -216,6 +216,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     sq_set_error(h, "sqair_backward: workspace / scratch too small");
     return -1;
   }
+  if (!sq_trainable_frame(h)) return -1;
   hipStream_t s = (hipStream_t)stream;
   const float* packed = (const float*)packedv;
   const SqairConfig& c = h->cfg;
@@ -339,7 +340,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     la.spre = w.spre; la.g_lw = b.g_lw; la.g_dl = b.g_dl; la.d_rec_p = b.d_rec_p; la.d_rec_d = b.d_rec_d;
     la.d_rec_m = b.d_rec_m; la.d_pstats = b.d_pstats; la.d_spre = b.d_spre; la.flat = flat; la.flat_grad = flat_grad;
     la.t_global0 = t_offset; la.cfg = c;
-    sq_launch_logprob_bwd(la, po, d, T, s);
+    CK(sq_launch_logprob_bwd(la, po, d, T, s));
   }
 
   // the adjoint of the transform's 8-wide output layer rides in the crop adjoint that produces its input (80 launches fewer)
@@ -394,7 +395,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         ta.noise = nz; ta.d_s1pre = d_t1 + nh; ta.ds_ld = t1l; ta.d_enc = d_enc3; ta.de_ld = el; ta.enc_pre = 1; ta.d_raw_out = slotp(b.d_raw, 1, t, 1, j); ta.dr_ld = N; ta.flat = flat;
         ta.flat_grad = flat_grad; ta.w2_off = po.disc_steps_l1_w; ta.b2_off = po.disc_steps_l1_b;
         ta.wwhat_off = (int)P(h, "disc.steps.l0.w") + nh * nsp;
-        sq_launch_slot_tail_bwd(ta, d, s);
+        CK(sq_launch_slot_tail_bwd(ta, d, s));
       }
       { Dx x(d_enc3, el); x.to(0, nh, d_e2, rl).dact(e2, rl, ACT_ELU); CK(rundx(L_WHAT_HEAD, x, R)); }
       { Dx x(d_e2, rl); x.to(0, nh, d_e1, rl).dact(e1, rl, ACT_ELU); CK(rundx(L_GENC1, x, R)); }
@@ -405,7 +406,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         ca.d_rec_new = d_rec_d_t; ca.g_out = b.d_g; ca.g_row_mul = 1; ca.tp = cslotp(w.tp, TP_LD, t, 1, j); ca.tp_ld = tpl;
         ca.d_tp = d_tp; ca.dtp_ld = tpl; ca.noise = nz; ca.flat = flat; ca.flat_grad = flat_grad;
         if (fuse_t3) { ca.w3 = w.w3_disc; ca.t2 = t2; ca.t2_ld = rl; ca.d_t2 = d_t2; ca.dt2_ld = rl; }
-        sq_launch_crop_chain_bwd(ca, po, d, 1, s);
+        CK(sq_launch_crop_chain_bwd(ca, po, d, 1, s));
       }
       if (!fuse_t3) { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_DISC_T3, x, R)); }
       { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU); CK(rundx(L_DISC_T2, x, R)); }
@@ -500,7 +501,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         ta.d_enc = b.d_enc; ta.de_ld = ENC_LD; ta.d_hraw = d_hraw; ta.dh_ld = hl; ta.d_raw_out = slotp(b.d_raw, 1, t, 0, k); ta.dr_ld = N;
         ta.flat = flat; ta.flat_grad = flat_grad; ta.w2_off = po.prop_steps_l1_w; ta.b2_off = po.prop_steps_l1_b;
         ta.wwhat_off = (int)P(h, "prop.steps.l0.w") + 2 * nh * nsp;
-        sq_launch_slot_tail_bwd(ta, d, s);
+        CK(sq_launch_slot_tail_bwd(ta, d, s));
       }
       // heads -> d tau'_k (the new HIDDEN state), + what the compaction sent back for this slot's new temporal state
       if (c.time_cell == CELL_VANILLA) {  // tanh' folded into the same launch; second copy: the hoisted recurrent block of d_pre
@@ -547,7 +548,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
         ca.d_mask = d_mask_t; ca.g_out = b.d_g; ca.g_row_mul = 1; ca.tp = cslotp(w.tp, TP_LD, t, 0, k); ca.tp_ld = tpl;
         ca.d_tp = d_tp; ca.dtp_ld = tpl; ca.noise = nz; ca.flat = flat; ca.flat_grad = flat_grad;
         if (fuse_t3) { ca.w3 = w.w3_prop; ca.t2 = t2; ca.t2_ld = rl; ca.d_t2 = d_t2; ca.dt2_ld = rl; }
-        sq_launch_crop_chain_bwd(ca, po, d, 1, s);
+        CK(sq_launch_crop_chain_bwd(ca, po, d, 1, s));
       }
       if (!fuse_t3) { Dx x(d_tp, tpl); x.to(0, nh, d_t2, rl).dact(t2, rl, ACT_ELU); CK(rundx(L_PROP_T3, x, R)); }
       { Dx x(d_t2, rl); x.to(0, nh, d_t1, t1l).dact(t1, t1l, ACT_ELU).dup(d_pre_k + rw, pre_rld); CK(rundx(L_PROP_T2, x, R)); }
@@ -614,7 +615,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
       ca.wb_ld = WB_LD; ca.d_wb = b.d_wb + (size_t)t * M * WB_LD; ca.mask = c.masked_glimpse ? mask : nullptr; ca.mask_row_mul = N;
       ca.d_mask = d_mask_t; ca.g_out = b.d_g1; ca.g_row_mul = N; ca.flat = flat; ca.flat_grad = flat_grad;
       ca.mask_dact = 1;  // the frame's last contribution to d mask: the sigmoid's adjoint rides on its write (d_mask_t IS d_maskpre)
-      sq_launch_crop_chain_bwd(ca, po, d, N, s);
+      CK(sq_launch_crop_chain_bwd(ca, po, d, N, s));
     }
     // ---- B^T. mask MLP and where-bias MLP
     {
@@ -684,7 +685,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     cs.add(b.d_raw, 1, (int)ph1, 1, flat_grad + po.prop_steps_l1_b, s);
     cs.add(w.s1h + ph1 * S1_LD, S1_LD, (int)ph1, nsp, flat_grad + po.disc_steps_l1_w, s, b.d_raw + ph1, 1);
     cs.add(b.d_raw + ph1, 1, (int)ph1, 1, flat_grad + po.disc_steps_l1_b, s);
-    cs.flush(s);
+    CK(cs.flush(s));
   }
   {
     const int TB = T * B;
@@ -760,7 +761,7 @@ extern "C" int sqair_backward(SqairHandle* h, const float* flat, const void* pac
     wgrad(L_DISC_S1, {{w.rec_d_all, RW}}, b.d_t1 + ph1 * T1_LD + nh, T1_LD, MT);
     sq_launch_where_param_grads(b.d_tp, TP_LD, b.d_rec_p, w.rec_p_all, noise, T, d, flat_grad, po, s);
   }
-  wbatch.flush(s);
+  CK(wbatch.flush(s));
   if (h->padded) sq_flat_gather(h, flat_grad, user_grad, packedv, s);
   SQ_CHECK_HIP(hipGetLastError());
   return 0;

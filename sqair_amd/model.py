@@ -380,9 +380,39 @@ class SqairCore(object):
     def graph_nodes(self):
         return self.lib.sqair_graph_nodes(self.handle)
 
+    def set_vi_target(self, name):
+        """The learning signal of the fused ELBO kernel: "vimco" (what the reference's make_target uses, targets.py:62-75) or
+        "reinforce" (targets.py:78-89, the other entry of Model.VI_TARGETS).  Captured graphs are dropped: the signal is part of
+        what they replay."""
+        code = {"vimco": 0, "iwae": 0, "reinforce": 1}[name]
+        self.check(self.lib.sqair_set_option(self.handle, b"vi_target", code), "sqair_set_option")
+        self.vi_target = "reinforce" if code else "vimco"
+        self._graph_ready = False
+        self._train_graph_ready = False
+
     def check(self, rc, what):
         """Raises RuntimeError with this handle's error text, read through the library the handle came from."""
         _capi.check(self.handle, rc, what, library=self.lib)
+
+    def check_scales(self, train=False):
+        """Debug mode, the validate_args half: the posterior scales of `what` / `where` of every propagation and discovery slot of
+        the last pass -- masked slots included -- are positive and finite (sqair/core.py:226, :261, sqair/modules.py:318-320)."""
+        if getattr(self, "_finite_flag", None) is None:
+            self._finite_flag = torch.zeros(2, dtype=torch.int32, device=self.device)
+        ws = self.train_ws if train else self.workspace
+        with torch.cuda.device(self.device):
+            self._join_in()
+            self.check(self.lib.sqair_check_scales(self.handle, ws.data_ptr(), self.T, self.B, int(train), self._finite_flag.data_ptr(),
+                                                   self._stream()), "sqair_check_scales")
+
+    def check_chain(self, train=False):
+        """Raises when a launch of the in-launch slot chain (option slot_chain) did not complete in the last pass."""
+        ws = self.train_ws if train else self.workspace
+        if ws is None:
+            return
+        with torch.cuda.device(self.device):
+            self.check(self.lib.sqair_chain_status(self.handle, ws.data_ptr(), self.T, self.B, int(train), self._stream()),
+                       "sqair_chain_status")
 
     def check_finite(self, tensor, what):
         """Debug mode (reference: `debug` -> validate_args / allow_nan_stats=False, sqair/core.py:226, :261,
@@ -476,6 +506,8 @@ class Model(object):
         (sqair/core.py:226, :261, sqair/modules.py:318-320) — a failed check aborts `sess.run`.  Here: the per-frame
         log-weights (every log-probability of the pass ends up in them) and the sequence log-weights must be finite."""
         core = self.core
+        core.check_chain()       # (in-launch slot chain, when switched on: every launch of the pass completed)
+        core.check_scales()      # validate_args: every slot's what / where scale > 0 and finite -- the specific message first
         core.check_finite(core.out["log_weights_per_timestep"], "log_weights_per_timestep [T, B*K]")
         core.check_finite(core.log_weights, "log_weights [B, K]")
 
@@ -548,7 +580,7 @@ class Model(object):
                for a in args]
         return res[0] if len(res) == 1 else res
 
-    def make_target(self, opt=None, n_train_itr=None, l2_reg=0.0):
+    def make_target(self, opt=None, n_train_itr=None, l2_reg=0.0, vi_target=None):
         """reference: sqair/model.py:150-168.  Returns (target, grads_and_vars): the VIMCO target (already divided
         by T, plus the l2 term) from the fused ELBO kernel and, when an optimiser is given, the gradients of every
         trainable variable from the HIP backward pass as a list of (gradient tensor, variable name) — the
@@ -556,6 +588,9 @@ class Model(object):
         ``opt.apply_gradients(gvs)`` (sqair_amd.train.Optimizer; learning rate from the flags' schedule unless given)
         performs the update."""
         core = self.core
+        if vi_target is not None and vi_target != getattr(core, "vi_target", "vimco"):
+            core.set_vi_target(vi_target)   # (`reinforce`: targets.py:78-89; the reference's own make_target always takes vimco)
+            self._ran = False
         if opt is None:
             if not self._ran:
                 self.run()

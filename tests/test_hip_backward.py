@@ -134,6 +134,41 @@ def test_elbo_backward(B, K, T):
         lib.sqair_destroy(h)
 
 
+@pytest.mark.parametrize("K", [5, 70])
+def test_elbo_reinforce_signal(K):
+    """sqair_set_option("vi_target", 1): the plain REINFORCE target of sqair/targets.py:78-89 (stop_gradient(log w) as the learning
+    signal, no control variate) -- signal, proxy loss and the gradients of both inputs against the oracle's restatement."""
+    B, T = 6, 4
+    lib, h, F = _handle(K, 3, (50, 50))
+    try:
+        assert lib.sqair_set_option(h, b"vi_target", 1) == 0
+        rng = np.random.default_rng(K)
+        lw_t = (rng.standard_normal((T, B * K)) * 20.0 + 300.0).astype(np.float32)
+        dl_t = (rng.standard_normal((T, B * K)) * 2.0 - 3.0).astype(np.float32)
+        d_lw, d_dl = dev(lw_t), dev(dl_t)
+        lw = torch.zeros(B, K, device="cuda"); el = torch.zeros(B, device="cuda"); iw = torch.zeros(B, K, device="cuda")
+        sig = torch.zeros(B, K, device="cuda"); sc = torch.zeros(16, device="cuda"); mo = torch.zeros(8, device="cuda")
+        means = (C.c_void_p * 8)(*([None] * 8))
+        assert lib.sqair_elbo(h, d_lw.data_ptr(), d_dl.data_ptr(), T, B, lw.data_ptr(), el.data_ptr(), iw.data_ptr(),
+                              sig.data_ptr(), sc.data_ptr(), means, 0, mo.data_ptr(), stream()) == 0
+        g_lw = torch.zeros(T, B * K, device="cuda"); g_dl = torch.zeros(T, B * K, device="cuda")
+        assert lib.sqair_elbo_bwd(h, iw.data_ptr(), sig.data_ptr(), T, B, g_lw.data_ptr(), g_dl.data_ptr(), stream()) == 0
+        torch.cuda.synchronize()
+        a = torch.tensor(lw_t, dtype=D, requires_grad=True)
+        b = torch.tensor(dl_t, dtype=D, requires_grad=True)
+        LW = a.sum(0).reshape(B, K)
+        tgt = O.reinforce(LW, b.sum(0).reshape(B, K), O.iwae(LW)) / T
+        tgt.backward()
+        assert np.array_equal(sig.cpu().numpy(), lw_t.sum(0, dtype=np.float32).reshape(B, K)) or \
+            rel_err(sig.cpu().numpy(), LW.detach().numpy()) < 1e-6
+        assert abs(float(sc[2]) - float(tgt)) <= 1e-5 * abs(float(tgt))
+        assert np.abs(g_lw.cpu().numpy() - a.grad.numpy()).max() < 5e-3 * np.abs(a.grad.numpy()).max()
+        assert np.abs(g_dl.cpu().numpy() - b.grad.numpy()).max() < 5e-3 * np.abs(b.grad.numpy()).max()
+        assert lib.sqair_set_option(h, b"vi_target", 2) != 0   # only 0 / 1
+    finally:
+        lib.sqair_destroy(h)
+
+
 @pytest.mark.parametrize("M,K,N,act", [(160, 256, 256, 1), (640, 400, 256, 1), (6400, 56, 256, 1), (160, 311, 128, 2),
                                        (37, 54, 109, 0), (160, 256, 100, 4), (33, 128, 400, 3)])
 def test_linear_backward_mfma(M, K, N, act):

@@ -19,6 +19,24 @@ from tests.hip_util import (GOLDEN, MARGIN, MAX_DRAWS, draw_noise, params32, pre
 pytestmark = pytest.mark.gpu
 
 REL = 1e-4  # tolerance stated by north_star
+GOLDEN_TOL = 2e-5   # per-output gate of the committed fixtures (scaled absolute error; measured worst ~2e-6: profiles/r05_parity.json).
+                    # The live-oracle cases with fp32 compounding over many steps (LSTM cells, T = 30) keep 5e-4.
+
+
+def _record_parity(case, worst):
+    """Appends the worst scaled error per output of a fixture case to gpurun_out/r05_parity.json (copied to profiles/ by hand:
+    the margin between what is measured and what the gate accepts, for the next reader)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "gpurun_out", "r05_parity.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[case] = dict(gate=GOLDEN_TOL, build_id=_capi.build_id(), worst_scaled_abs_err=max(worst.values()),
+                          worst_output=max(worst, key=worst.get), per_output={k: float("%.3g" % v) for k, v in sorted(worst.items())})
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
 
 
 def _check_against(m, ref_out, ref_model, names, T, tol=5e-4):
@@ -53,8 +71,9 @@ def test_forward_matches_golden_fixture(name):
     ref_model = {k[6:]: z[k] for k in z.files if k.startswith("model_")}
     m = run_hip(F, (H, W), P, z["obs"], z["noise"], nums=z["nums"], resample_u=z["resample_u"])
     names = [k for k in ref_out if k in m.outputs]
-    worst = _check_against(m, ref_out, ref_model, names, T)
+    worst = _check_against(m, ref_out, ref_model, names, T, tol=GOLDEN_TOL)
     print(name, "worst scaled abs err:", max(worst.values()), max(worst, key=worst.get))
+    _record_parity(name, worst)
     if K > 1:
         assert abs(float(m.vimco_target) - float(ref_model["vimco_target"])) <= 1e-3 * abs(float(ref_model["vimco_target"]))
         assert np.array_equal(m.iw_resampling_idx.cpu().numpy(), ref_model["iw_resampling_idx"].astype(np.int64))
@@ -458,14 +477,24 @@ def test_debug_mode_raises_on_non_finite_log_weights():
         bad = dict(P)
         bad[name] = np.full_like(P[name], np.nan)
         core.set_params(bad)
-        with pytest.raises(RuntimeError, match="non-finite values in log_weights"):
+        with pytest.raises(RuntimeError, match="non-finite values in log_weights|scale not positive / not finite"):
             m.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))
     core.set_params(P)
     m.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))   # healthy again
+    # validate_args: a scale that is not positive / finite is named (which posterior, frame, row, slot, entry) ahead of the
+    # log-weights check -- the presence mask is a multiplication (here as in the reference), so such a scale reaches the log-weights
+    # as NaN too, but "non-finite log-weights" does not say where it came from
+    bad = dict(P)
+    bad["prop.transform.scale_offset"] = np.full_like(P["prop.transform.scale_offset"], np.nan)
+    core.set_params(bad)
+    with pytest.raises(RuntimeError, match="scale not positive / not finite in the propagation posterior.*where_scale"):
+        m.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))
+    core.set_params(P)
+    m.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))
     obs_bad = obs.copy()
     obs_bad[1, 0, 20, 20] = np.nan
     mb = Model(obs_bad, None, core, K, presence=d["nums"], debug=True)
-    with pytest.raises(RuntimeError, match="non-finite values in log_weights"):
+    with pytest.raises(RuntimeError, match="non-finite values in log_weights|scale not positive / not finite"):
         mb.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))
 
 
