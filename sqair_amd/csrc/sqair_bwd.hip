@@ -102,10 +102,6 @@ extern "C" int sqair_st_crop_bwd(SqairHandle* h, const float* img, const float* 
   if (!h || !img || !where_logits || !g_out || !d_where_logits || B < 1) return -1;
   SqairConfig c;
   if (sqair_get_config(h, &c) != 0) return -1;
-  if (((c.img_h * c.img_w) & 3) != 0) {   // (the adjoint kernels stage frames in 16-byte units; the full passes pad such frames)
-    sq_set_error(h, "this unit entry point needs H * W to be a multiple of 4 (use sqair_forward_train / sqair_backward for other frame sizes)");
-    return -1;
-  }
   Dims d = make_dims(c, B);
   CropBwdArgs a{img, where_logits, mask, g_out, d_where_logits, d_mask};
   const size_t shm = (size_t)d.H * d.W * sizeof(float);
@@ -751,10 +747,6 @@ extern "C" int sqair_st_insert_loglik_bwd(SqairHandle* h, const float* glimpse, 
     return -1;
   SqairConfig c;
   if (sqair_get_config(h, &c) != 0) return -1;
-  if (((c.img_h * c.img_w) & 3) != 0) {   // (the adjoint kernels stage frames in 16-byte units; the full passes pad such frames)
-    sq_set_error(h, "this unit entry point needs H * W to be a multiple of 4 (use sqair_forward_train / sqair_backward for other frame sizes)");
-    return -1;
-  }
   Dims d = make_dims(c, B);
   const int P = d.H * d.W;
   if (scratch_bytes < (int64_t)d.R * P * 4) return -1;

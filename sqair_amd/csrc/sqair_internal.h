@@ -75,9 +75,9 @@ struct SqairHandle {
 inline int64_t align64(int64_t x) { return (x + 63) / 64 * 64; }
 constexpr int64_t SQ_TRAIN_MAX_FRAME_BYTES = 150 * 1024;   // dynamic LDS the crop adjoint may ask for (sq_allow_big_lds)
 bool sq_trainable_frame(SqairHandle* h);                   // false + error text when the handle's frames cannot be trained
-// The partial adjoints kept for unit tests (sqair_st_*_bwd, sqair_backward_decoder) take the caller's frames as they are; the
-// adjoint kernels stage frames in 16-byte units, so these entry points want H * W to be a multiple of 4 (the full passes stage
-// other frames through a padded copy).
+// The partial adjoint kept for unit tests (sqair_backward_decoder) takes the caller's frames as they are, and the full adjoint
+// kernels stage frames in 16-byte units: it wants H * W to be a multiple of 4 (the full passes stage other frames through a
+// padded copy; the per-kernel entry points sqair_st_*_bwd read frames word by word and take any size).
 inline bool sq_unit_frame_ok(SqairHandle* h) {
   if (((h->cfg.img_h * h->cfg.img_w) & 3) == 0) return true;
   sq_set_error(h, "this unit entry point needs H * W to be a multiple of 4 (use sqair_forward_train / sqair_backward for other frame sizes)");

@@ -161,7 +161,7 @@ def test_elbo_reinforce_signal(K):
         tgt.backward()
         assert np.array_equal(sig.cpu().numpy(), lw_t.sum(0, dtype=np.float32).reshape(B, K)) or \
             rel_err(sig.cpu().numpy(), LW.detach().numpy()) < 1e-6
-        assert abs(float(sc[2]) - float(tgt)) <= 1e-5 * abs(float(tgt))
+        assert abs(float(sc[2]) - float(tgt.detach())) <= 1e-5 * abs(float(tgt.detach()))
         assert np.abs(g_lw.cpu().numpy() - a.grad.numpy()).max() < 5e-3 * np.abs(a.grad.numpy()).max()
         assert np.abs(g_dl.cpu().numpy() - b.grad.numpy()).max() < 5e-3 * np.abs(b.grad.numpy()).max()
         assert lib.sqair_set_option(h, b"vi_target", 2) != 0   # only 0 / 1
