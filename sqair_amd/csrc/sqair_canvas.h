@@ -273,7 +273,10 @@ __device__ __forceinline__ void sq_canvas_rows_prologue(const CanvasRowsLds& c, 
   __syncthreads();
 }
 #ifndef SQ_ROWS_WPE
-#define SQ_ROWS_WPE(NMAX, CPL) ((NMAX) * (CPL) <= 8 ? 7 : 4)   // waves per SIMD the register allocation must leave room for
+// waves per SIMD the register allocation must leave room for.  8 slots x 4 columns per lane keep 96 VGPRs of column taps alone: at
+// 4 waves per SIMD (128 VGPRs) that instantiation spilled 27-32 registers to scratch; with room for 2 it takes 158-166 VGPRs, no
+// scratch, and is faster (back to back, 1600 rows: 30 x 250 x 8 slots 74 -> 53 us, 100 x 200 x 6 slots 151 -> 96 us)
+#define SQ_ROWS_WPE(NMAX, CPL) ((NMAX) * (CPL) <= 8 ? 7 : ((NMAX) * (CPL) >= 32 ? 2 : 4))
 #endif
 __device__ __forceinline__ sq_f2 sq_fma2(sq_f2 a, sq_f2 b, sq_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 // sigmoid(-10 + 20 ms) for two pixels: sq_exp without its clamp and NaN select (the argument 10 - 20 ms lies in [-20 N + 10, 10]: no

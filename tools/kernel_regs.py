@@ -1,4 +1,6 @@
-"""VGPRs / SGPRs / scratch / LDS / code size of the kernels of a libsqair_hip*.so (from the AMDGPU metadata notes)."""
+"""VGPRs / AGPRs / SGPRs / scratch / LDS / spill counts of the kernels of a libsqair_hip*.so (from the AMDGPU metadata notes).
+    python tools/kernel_regs.py [substring of the demangled name] [library.so]
+`kernel_table(path)` returns the same as a list of dicts (tests/test_kernel_resources.py: no kernel of a shipped library spills)."""
 import os
 import re
 import struct
@@ -6,30 +8,54 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "sqair_amd", "libsqair_hip.so")
-pat = sys.argv[1] if len(sys.argv) > 1 else ""
-so = open(path, "rb").read()
-for k, i in enumerate([m.start() for m in re.finditer(b"\x7fELF", so)][1:]):
-    if struct.unpack_from("<H", so, i + 18)[0] != 224:
-        continue
-    co = "/tmp/_sq_regs%d.co" % k
-    open(co, "wb").write(so[i:])
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
-    cur = {}
-    for line in out.splitlines():
-        m = re.match(r"\s+[-.]?\s*\.?(\w+):\s+(.*)", line)
-        if not m:
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+KEYS = ("vgpr_count", "agpr_count", "sgpr_count", "private_segment_fixed_size", "group_segment_fixed_size", "vgpr_spill_count",
+        "sgpr_spill_count")
+
+
+def kernel_table(path):
+    so = open(path, "rb").read()
+    rows = []
+    for k, i in enumerate([m.start() for m in re.finditer(b"\x7fELF", so)][1:]):
+        if struct.unpack_from("<H", so, i + 18)[0] != 224:   # EM_AMDGPU
             continue
-        key, val = m.group(1), m.group(2).strip()
-        if key == "name" and not val.endswith(".kd"):
-            cur = {"name": val}
-        elif key in ("vgpr_count", "sgpr_count", "private_segment_fixed_size", "group_segment_fixed_size", "vgpr_spill_count", "agpr_count"):
-            cur[key] = val
-        elif key == "symbol" and cur:
-            name = subprocess.run(["c++filt", cur.get("name", "")], capture_output=True, text=True).stdout.strip()
-            name = re.sub(r"\(.*", "", name)
-            if pat in name:
-                print("%-60s vgpr %4s agpr %3s sgpr %4s scratch %5s lds %6s spill %s" % (
-                    name[:60], cur.get("vgpr_count"), cur.get("agpr_count", "0"), cur.get("sgpr_count"), cur.get("private_segment_fixed_size"),
-                    cur.get("group_segment_fixed_size"), cur.get("vgpr_spill_count", "0")))
-            cur = {}
+        co = "/tmp/_sq_regs_%d_%d.co" % (os.getpid(), k)
+        open(co, "wb").write(so[i:])
+        out = subprocess.run([READELF, "--notes", co], capture_output=True, text=True).stdout
+        os.remove(co)
+        cur = None
+        for line in out.splitlines():
+            m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)", line)
+            if not m:
+                continue
+            key, val = m.group(1), m.group(2).strip()
+            if key == "name" and val.startswith("_Z") or key == "name" and re.match(r"^[A-Za-z_]\w*$", val) and not val.endswith(".kd"):
+                if cur and "vgpr_count" in cur:
+                    rows.append(cur)
+                cur = {"mangled": val}
+            elif cur is not None and key in KEYS:
+                cur[key] = int(val)
+        if cur and "vgpr_count" in cur:
+            rows.append(cur)
+    names = subprocess.run(["c++filt"], input="\n".join(r["mangled"] for r in rows), capture_output=True, text=True).stdout.splitlines()
+    seen, uniq = set(), []
+    for r, n in zip(rows, names):
+        r["name"] = re.sub(r"\(.*", "", n)
+        if r["mangled"] not in seen:
+            seen.add(r["mangled"])
+            uniq.append(r)
+    return uniq
+
+
+def main():
+    pat = sys.argv[1] if len(sys.argv) > 1 else ""
+    path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "sqair_amd", "libsqair_hip.so")
+    for r in kernel_table(path):
+        if pat in r["name"]:
+            print("%-64s vgpr %4d agpr %3d sgpr %4d scratch %5d lds %6d vgpr-spill %3d sgpr-spill %3d" % (
+                r["name"][:64], r["vgpr_count"], r.get("agpr_count", 0), r.get("sgpr_count", 0), r.get("private_segment_fixed_size", 0),
+                r.get("group_segment_fixed_size", 0), r.get("vgpr_spill_count", 0), r.get("sgpr_spill_count", 0)))
+
+
+if __name__ == "__main__":
+    main()
