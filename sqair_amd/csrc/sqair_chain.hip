@@ -696,6 +696,16 @@ __global__ __launch_bounds__(256) void k_slot_chain(const ChainTable* __restrict
   // row tiles of this XCD: idx_x, idx_x + n_act, ...
   const int ntl = idx_x < n_row_tiles ? (n_row_tiles - idx_x + n_act - 1) / n_act : 0;
   if (ntl == 0) return;
+  // With two workgroups per CU in the grid (sq_chain_flush: where the occupancy allows), an XCD serving ONE row tile keeps
+  // one workgroup per CU -- its ops have at most as many items as that, and the workgroups not needed would only add pollers --
+  // while an XCD serving several tiles uses both: consecutive ops then run on alternating halves there too.
+  {
+    const int cus_x = max((int)gridDim.x >> 4, 1);   // workgroups per XCD at one per CU (8 XCDs, 2 per CU in the grid)
+    if ((int)gridDim.x >= 512 && ntl == 1 && n_x > cus_x) {
+      if (rank >= cus_x) return;
+      n_x = cus_x;
+    }
+  }
   if (ntl > CH_MAX_TILES_PER_XCD) {
     if (tid == 0) __hip_atomic_store(status, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
@@ -985,7 +995,7 @@ int sq_chain_flush(SqairHandle* h, unsigned* ctl, int launch_id, hipStream_t s) 
     SQ_CHECK_HIP(hipGetDevice(&dev_id));
     SQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id));
     SQ_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_slot_chain, 256, (size_t)lds));
-    static const int per_cu = SQ_KNOB_INT("SQAIR_CHAIN_WGS_PER_CU", 1);
+    static const int per_cu = SQ_KNOB_INT("SQAIR_CHAIN_WGS_PER_CU", 1);   // (2 measured: 3.3 -> 7.3 ms at cfg-2)
     c->occupancy = occ;
     c->grid = cus * (occ >= per_cu ? per_cu : 1);
     if (occ < 1 || cus < 1) { sq_set_error(h, "slot chain: the kernel does not fit a CU"); return -3; }
