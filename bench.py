@@ -19,7 +19,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
                  (135.4 MFLOP/frame at cfg-2, as the reference graph computes them, / dense
                  launches per step) / average SLOT of a dense launch (its busy time + the dependent-launch gap up to
                  the next dispatch: the slots of all dispatches sum to the step); frac_busy_only and
-                 frac_whole_step beside it; peak = 157.3 TFLOP/s.  The committed profiles/r04_timeline_*.csv
+                 frac_whole_step beside it; peak = 157.3 TFLOP/s.  The committed profiles/r05_timeline_*.csv
                  are the same measurement (tools/timeline.py; `--recompute` recomputes the fractions from them).
   roofline_hbm — the gather / scatter / reduce class (k_crop_row, k_insert_loglik, k_compact, k_logprob): busy time
                  from the same timeline, algorithmic bytes from the shapes (sqair_amd/timeline.py), PMC traffic
@@ -55,7 +55,7 @@ MACS_PER_FRAME_PARTICLE = {1: 10166288, 2: 13543744, 3: 13543744, 4: 20298656, 5
 # ... and what the path EXECUTES per frame (the loop-invariant input encoder hoisted out of the N slot steps, the
 # mask MLP evaluated once): MFLOP per frame, all K particles included.  `roofline.frac_executed` is quoted on this figure.
 EXECUTED_MFLOP_PER_FRAME = {1: 17.5, 2: 114.3, 3: 114.3, 4: 167.7, 5: 149.8}
-PROFILE_TAG = "r04"                    # profiles/<tag>_*.json|csv: the committed files of this round (tools/profile_round.sh)
+PROFILE_TAG = "r05"                    # profiles/<tag>_*.json|csv: the committed files of this round (tools/profile_round.sh)
 
 
 def cpu_baseline(F, hw, P, obs, noise, hip_ref, budget_s=25.0):
@@ -547,6 +547,47 @@ def main():
             torch.cuda.set_stream(core.stream)
         except Exception as e:  # never take the bench line down
             all_out = dict(error="{}: {}".format(type(e).__name__, e))
+    # ---- the in-launch slot chain (extra object "slot_chain"; option `slot_chain` of the library, off by default and NOT part of
+    # `value`): the same forward step with the slot launches of every frame's propagation / discovery loop run as one persistent
+    # launch each (sqair_amd/csrc/sqair_chain.h; bit-identical results: tests/test_slot_chain.py) -- at this workload and at half
+    # the sequences, where every XCD serves a single 16-row tile.
+    chain = None
+    if rank == 0 and world == 1 and use_graph and args.transition == "VanillaRNN" and args.time_transition == "GRU":
+        try:
+            from sqair_amd.timeline import time_steps
+            chain = {}
+            for tag, nb in (("this_workload", B), ("half_the_sequences", max(B // 2, 1))):
+                ob, nu = (obs, nums) if nb == B else (obs[:, :nb], nums[:, :nb])
+                res = {}
+                for name, opts in (("launches", None), ("chain", {"slot_chain": 1})):
+                    if name == "launches" and nb == B:
+                        res[name] = dict(ms_per_step=ms_per_step, graph_nodes=core.graph_nodes())
+                        continue
+                    c_c = SqairCore(F, hw, device=device, options=opts)
+                    with c_c.on_stream():
+                        c_c.set_params(P)
+                        m_c = Model(ob, None, c_c, K, presence=nu, outputs="minimal")
+                        kc = [0]
+
+                        def cstep():
+                            c_c.draw_noise(seed=1000, step=kc[0], global_batch=nb, b0=0)
+                            kc[0] += 1
+                            c_c.forward(use_graph=True)
+                        ms_c = time_steps(c_c, cstep, steps=max(10, args.steps // 2), warm=3)
+                        if opts:
+                            c_c.check_chain()
+                        m_c._collect()
+                        res[name] = dict(ms_per_step=ms_c, graph_nodes=c_c.graph_nodes(), elbo_iwae=float(m_c.elbo_iwae))
+                    del m_c, c_c
+                    torch.cuda.empty_cache()
+                chain[tag] = dict(sequences=nb, particle_rows=nb * K, launches=res["launches"], chain=res["chain"],
+                                  chain_over_launches=res["chain"]["ms_per_step"] / res["launches"]["ms_per_step"],
+                                  value=nb * T / (res["chain"]["ms_per_step"] * 1e-3), unit="frames/s")
+            chain["what"] = ("option slot_chain (default off): noise draw + graph replay + ELBO, the slot loops as two persistent launches "
+                             "per frame; needs the device to itself (its 256 workgroups must be co-resident)")
+            torch.cuda.set_stream(core.stream)
+        except Exception as e:  # never take the bench line down
+            chain = dict(error="{}: {}".format(type(e).__name__, e))
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -609,7 +650,7 @@ def main():
         "elbo_iwae_nats_per_seq": elbo, "elbo_vae_nats_per_seq": elbo_vae,
         "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu, "train": train,
         "forward_all_outputs": all_out, "forward_all_outputs_ms": (all_out or {}).get("ms_per_step"),
-        "single_gpu_at_global_batch": single, "streams": streams, "build_id": bid,
+        "single_gpu_at_global_batch": single, "streams": streams, "slot_chain": chain, "build_id": bid,
     }
     if cpu is not None:
         line["speedup_vs_cpu_baseline"] = value / world / cpu["value"]
