@@ -36,7 +36,7 @@ __device__ unsigned long long* g_chain_trace = nullptr;
 __device__ unsigned g_chain_trace_cap = 0;
 __device__ unsigned g_chain_trace_n = 0;
 __device__ __forceinline__ unsigned long long ch_clock() { return __builtin_amdgcn_s_memrealtime(); }
-constexpr int CH_LDS_TR = 16 * 68 + 64 + 3072;   // eight stamps of the current item behind the ops' scratch
+constexpr int CH_LDS_TR = 16 * 68 + 64 + 2 * 3072;   // eight stamps of the current item behind the ops' scratch
 #define CH_TRACE_T(i) do { extern __shared__ __attribute__((aligned(16))) float ch_smem_[]; \
     if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(ch_smem_ + CH_LDS_TR)[i] = ch_clock(); } while (0)
 #else
@@ -63,6 +63,19 @@ typedef const __attribute__((address_space(1))) float4 ch_gcfloat4;
   CH_TRACE_POLLS(ch_spins + 1);                                                                     \
   if (!ch_ok && (threadIdx.x & 63) == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Poll loops written out (polls issued once AHEAD of the item's other preparations, which then run in the shadow of the polls' round
+// trip): CH_RETRY(bad, status, REISSUE) at the bottom of `for (int spins = 0;;) { check -> bad; CH_RETRY(...) }`.
+#define CH_RETRY(bad, status, REISSUE)                                                                                       \
+  if (__all((bad) == 0)) break;                                                                                              \
+  if (++spins >= SQ_CHAIN_SPIN_LIMIT ||                                                                                      \
+      ((spins & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {               \
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                 \
+    break;                                                                                                                   \
+  }                                                                                                                          \
+  __builtin_amdgcn_s_sleep(1);                                                                                               \
+  REISSUE;                                                                                                                   \
+  __builtin_amdgcn_sched_barrier(0);
+
 // ------------------------------------------------------------------------------------------------
 // dense layer: TN (1..3) consecutive column tiles of ONE row tile -- the A operand is fetched (polled) once for all of them.
 // k_linear's arithmetic per 16 x 16 output tile: waves split the K chunks g = wave + 4 j, two accumulators, LDS reduce in wave
@@ -70,11 +83,26 @@ typedef const __attribute__((address_space(1))) float4 ch_gcfloat4;
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ch_st(CH_RSRC rs, unsigned off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)off, 0, 0); }
 template <int NCH, int TN>
-__device__ __forceinline__ void chain_dense(const ChDense& a, CH_RSRC rs, const int tile_m, const int tile_n0, const int n_tiles, float* red,
-                                            unsigned* status) {
+__device__ __forceinline__ void chain_dense(const ChDense& a, CH_RSRC rs, const int tile_m, const int tile_n0, const int n_tiles, const int M,
+                                            float* red, unsigned* status) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
-  // every field of the descriptor up front (LDS reads in one batch; the control fields go back to SGPRs)
-  const int M = CH_UNI(a.M), kc_total = CH_UNI(a.kc_total), epi = CH_UNI(a.epi), N = CH_UNI(a.N), nh = CH_UNI(a.nh);
+  // The A-operand polls go out FIRST: their addresses need nothing but the chunk table (padded to SQ_CHAIN_MAX_KC entries, so the
+  // slots past this layer's K meet a valid chunk -- against zero weights), and everything else an item has to prepare (the
+  // descriptor's fields, the weight requests, the epilogue's operands) then runs in the shadow of the polls' round trip.  One
+  // wave per SIMD hides nothing by itself: with the preparation ahead of the polls an item took 0.4 us longer.
+  const unsigned arow = (unsigned)min(tile_m * 16 + l15, M - 1);
+  unsigned aoff[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const ChChunk c = a.chunk[wave + 4 * j];
+    aoff[j] = c.base + min((unsigned)kq * 16u, c.lim) + arow * c.ldb;
+  }
+  u32x4_t ar[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) ar[j] = ch_l4(rs, aoff[j]);
+  __builtin_amdgcn_sched_barrier(0);
+  CH_TRACE_T(1);
+  const int kc_total = CH_UNI(a.kc_total), epi = CH_UNI(a.epi), N = CH_UNI(a.N), nh = CH_UNI(a.nh);
   const int act_a = CH_UNI(a.act_a), act_b = CH_UNI(a.act_b), act_split = CH_UNI(a.act_split), add_n = CH_UNI(a.add_n);
   const unsigned add_base = CH_UNI(a.add_off), o3_off = CH_UNI(a.o3_off), o1_off = CH_UNI(a.o1_off);
   const unsigned out_off = a.out_off, o2_off = a.o2_off, e0_off = a.e0_off, e1_off = a.e1_off;
@@ -99,15 +127,6 @@ __device__ __forceinline__ void chain_dense(const ChDense& a, CH_RSRC rs, const 
 #endif
     }
   }
-  CH_TRACE_T(1);
-  const unsigned arow = (unsigned)min(tile_m * 16 + l15, M - 1);
-  unsigned aoff[NCH];
-#pragma unroll
-  for (int j = 0; j < NCH; ++j) {
-    const int g = j < nmine ? wave + 4 * j : wave;   // invalid slots re-read A chunk `wave` against zero weights
-    const ChChunk c = a.chunk[g];
-    aoff[j] = c.base + min((unsigned)kq * 16u, c.lim) + arow * c.ldb;
-  }
   // epilogue operands
   const int m = tile_m * 16 + (tid >> 4);
   const int mc = min(m, M - 1);
@@ -130,22 +149,35 @@ __device__ __forceinline__ void chain_dense(const ChDense& a, CH_RSRC rs, const 
   f32x4_t av[NCH];
   float p_add[TN], p_e0[TN], p_e1[TN];
   CH_TRACE_T(2);
-  CH_POLL_BEGIN
-    u32x4_t ar[NCH];
+  {
     unsigned xa[TN], x0[TN], x1[TN];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) ar[j] = ch_l4(rs, aoff[j]);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) { xa[tn] = ch_l1(rs, off_add[tn]); x0[tn] = ch_l1(rs, off_e0[tn]); x1[tn] = ch_l1(rs, off_e1[tn]); }
     __builtin_amdgcn_sched_barrier(0);
+    int spins = 0;
+    for (;;) {
+      unsigned bad = 0;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) { ch_bad |= ch_bad4(ar[j]); av[j] = ch_f4(ar[j]); }
+      for (int j = 0; j < NCH; ++j) { bad |= ch_bad4(ar[j]); av[j] = ch_f4(ar[j]); }
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      ch_bad |= (unsigned)(xa[tn] == SQ_SENT) | (unsigned)(x0[tn] == SQ_SENT) | (unsigned)(x1[tn] == SQ_SENT);
-      p_add[tn] = __uint_as_float(xa[tn]); p_e0[tn] = __uint_as_float(x0[tn]); p_e1[tn] = __uint_as_float(x1[tn]);
+      for (int tn = 0; tn < TN; ++tn) {
+        bad |= (unsigned)(xa[tn] == SQ_SENT) | (unsigned)(x0[tn] == SQ_SENT) | (unsigned)(x1[tn] == SQ_SENT);
+        p_add[tn] = __uint_as_float(xa[tn]); p_e0[tn] = __uint_as_float(x0[tn]); p_e1[tn] = __uint_as_float(x1[tn]);
+      }
+      if (__all(bad == 0)) break;
+      if (++spins >= SQ_CHAIN_SPIN_LIMIT ||
+          ((spins & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        if ((tid & 63) == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) ar[j] = ch_l4(rs, aoff[j]);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) { xa[tn] = ch_l1(rs, off_add[tn]); x0[tn] = ch_l1(rs, off_e0[tn]); x1[tn] = ch_l1(rs, off_e1[tn]); }
+      __builtin_amdgcn_sched_barrier(0);
     }
-  CH_POLL_END(status)
+  }
   CH_TRACE_T(3);
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -623,7 +655,7 @@ __device__ __forceinline__ void chain_rnn(const ChainRnn& c, const Dims& d, CH_R
 // the persistent kernel.  Control block of a launch (zero at launch): word 0 of line x (32 words) = workgroups counted on XCD x;
 // line 9 word 0 = status (1 = a consumer gave up polling, 3 = the census never completed).
 // ------------------------------------------------------------------------------------------------
-constexpr int CH_LDS_ZT = 0, CH_LDS_RS = 16 * CH_ZLD, CH_LDS_RED = CH_LDS_RS + 64, CH_LDS_FLOATS = CH_LDS_RED + 3072 + 16;
+constexpr int CH_LDS_ZT = 0, CH_LDS_RS = 16 * CH_ZLD, CH_LDS_RED = CH_LDS_RS + 64, CH_LDS_FLOATS = CH_LDS_RED + 2 * 3072 + 16;
 constexpr int CH_MAX_TILES_PER_XCD = 8;
 
 __global__ __launch_bounds__(256) void k_slot_chain(const ChainTable* __restrict__ tab, unsigned* __restrict__ ctl, const float* ws_base,
@@ -712,9 +744,12 @@ __global__ __launch_bounds__(256) void k_slot_chain(const ChainTable* __restrict
   }
   float* zt = smem + CH_LDS_ZT;
   float (*rsum)[16] = reinterpret_cast<float (*)[16]>(smem + CH_LDS_RS);
-  float* red = smem + CH_LDS_RED;
   const int R = CH_UNI(lt->d.R);
   const bool staged = CH_UNI(lt->staged) != 0;
+  // dense items alternate between two LDS meeting areas and end without a barrier (the barrier inside the NEXT dense item
+  // orders this item's reads ahead of the one after next's writes); any other item starts behind one when a dense item preceded it
+  int red_par = 0;
+  bool pending_sync = false;
 #ifdef SQAIR_KNOBS
   unsigned tr_items = 0;
 #endif
@@ -739,17 +774,22 @@ __global__ __launch_bounds__(256) void k_slot_chain(const ChainTable* __restrict
       while (sub >= groups) { sub -= groups; ++grp; }
       const int tile = idx_x + grp * n_act;
       if (kind == COP_DENSE) {
+        float* red = smem + CH_LDS_RED + red_par * 3072;
+        red_par ^= 1;
+        pending_sync = true;
         const int nch = CH_UNI(op.nch);
         if (nch <= 4) {
-          if (tn == 1) chain_dense<4, 1>(op.u.dense, rs, tile, sub, items, red, status);
-          else if (tn == 2) chain_dense<4, 2>(op.u.dense, rs, tile, 2 * sub, items, red, status);
-          else chain_dense<4, 3>(op.u.dense, rs, tile, 3 * sub, items, red, status);
+          if (tn == 1) chain_dense<4, 1>(op.u.dense, rs, tile, sub, items, R, red, status);
+          else if (tn == 2) chain_dense<4, 2>(op.u.dense, rs, tile, 2 * sub, items, R, red, status);
+          else chain_dense<4, 3>(op.u.dense, rs, tile, 3 * sub, items, R, red, status);
         } else {
-          if (tn == 1) chain_dense<7, 1>(op.u.dense, rs, tile, sub, items, red, status);
-          else if (tn == 2) chain_dense<7, 2>(op.u.dense, rs, tile, 2 * sub, items, red, status);
-          else chain_dense<7, 3>(op.u.dense, rs, tile, 3 * sub, items, red, status);
+          if (tn == 1) chain_dense<7, 1>(op.u.dense, rs, tile, sub, items, R, red, status);
+          else if (tn == 2) chain_dense<7, 2>(op.u.dense, rs, tile, 2 * sub, items, R, red, status);
+          else chain_dense<7, 3>(op.u.dense, rs, tile, 3 * sub, items, R, red, status);
         }
       } else {
+        if (pending_sync) { __syncthreads(); pending_sync = false; }
+        float* red = smem + CH_LDS_RED;
         if (kind == COP_CROP) {
           const int r = tile * 16 + sub;
           if (r < R) {
@@ -775,7 +815,7 @@ __global__ __launch_bounds__(256) void k_slot_chain(const ChainTable* __restrict
         }
       }
 #endif
-      __syncthreads();
+      if (kind != COP_DENSE) __syncthreads();
     }
   }
 }
@@ -888,6 +928,7 @@ int sq_chain_add_dense(SqairHandle* h, const LinArgs& a, int kc_total, int n_til
   chain_split(a.wp, &dn.wp_lo, &dn.wp_hi);
   chain_split(a.wzero, &dn.wz_lo, &dn.wz_hi);
   chain_split(a.bias, &dn.bias_lo, &dn.bias_hi);
+  if (a.M != cs_of(h)->tab.d.R) { sq_set_error(h, "slot chain: a dense op over other rows than the particle rows"); return -3; }
   dn.M = a.M; dn.N = a.N; dn.kc_total = kc_total; dn.nch = (kc_total + 3) / 4;
   op->nch = dn.nch;
   dn.epi = a.epi; dn.act_a = a.act_a; dn.act_b = a.act_b; dn.act_split = a.act_split; dn.scale = a.scale; dn.nh = a.nh;
