@@ -615,19 +615,27 @@ __device__ __forceinline__ void chain_rnn(const ChainRnn& c, const Dims& d, CH_R
   const int mc = min(m, d.R - 1), nc = min(n, c.n_out - 1);
   const float p_bias = CH_GLB(ch_gcf, c.bias)[nc];
   const unsigned add_off = ch_off(wsb, c.add) + (unsigned)(mc * c.add_ld + nc) * 4u;
+  // The layer's own dependent operands (the previous slot's hidden state, produced ~8 ops ago; the hoisted pre-activation) are
+  // requested here and CHECKED after the tail: the tail's poll waits a round trip for operands the op just before this one wrote,
+  // and by then these have long arrived -- one round trip for the item instead of two.
   float p_add;
-  CH_POLL_BEGIN
-    u32x4_t hr[NH];
-#pragma unroll
-    for (int i = 0; i < NH; ++i) hr[i] = ch_l4(rs, hoff + (unsigned)((wave + 4 * i) * 16 + kq * 4) * 4u);
-    const unsigned xa = ch_l1(rs, add_off);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NH; ++i) { ch_bad |= ch_bad4(hr[i]); ah[i] = ch_f4(hr[i]); }
-    ch_bad |= (unsigned)(xa == SQ_SENT);
-    p_add = __uint_as_float(xa);
-  CH_POLL_END(status)
+  u32x4_t hr[NH];
+  unsigned xa;
+#define CH_RNN_ISSUE()                                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < NH; ++i) hr[i] = ch_l4(rs, hoff + (unsigned)((wave + 4 * i) * 16 + kq * 4) * 4u); \
+  xa = ch_l1(rs, add_off);
+  CH_RNN_ISSUE()
+  __builtin_amdgcn_sched_barrier(0);
   chain_tail<true>(c.ta, d, rs, wsb, row0, tile_n == 0, zt, rsum, status);
+  for (int spins = 0;;) {
+    unsigned bad = 0;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) { bad |= ch_bad4(hr[i]); ah[i] = ch_f4(hr[i]); }
+    bad |= (unsigned)(xa == SQ_SENT);
+    p_add = __uint_as_float(xa);
+    CH_RETRY(bad, status, CH_RNN_ISSUE())
+  }
+#undef CH_RNN_ISSUE
   __syncthreads();
   const f32x4_t az = *reinterpret_cast<const f32x4_t*>(&zt[l15 * CH_ZLD + 16 * wave + 4 * kq]);
   f32x4_t acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
