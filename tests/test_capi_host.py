@@ -155,3 +155,48 @@ def test_limits_of_both_builds():
             assert (rc == 0) == ok, (flags, l.sqair_build_flags(), rc)
             if rc == 0:
                 l.sqair_destroy(h)
+
+
+def test_run_time_options_host_side():
+    """sqair_set_option without a GPU: the in-launch slot chain lays the inference workspace out like the training tape for the
+    configurations it serves (shipped cells, n_hidden 256, up to 320 particle rows) and leaves the others alone; the wide build
+    refuses it; vi_target takes 0 / 1."""
+    lib = _capi.lib()
+
+    def handle(library, **flags):
+        F = make_flags(k_particles=5, n_steps_per_image=4, **flags)
+        cfg = make_config(F, (50, 50))
+        h = C.c_void_p()
+        assert library.sqair_create(C.byref(cfg), C.byref(h)) == 0
+        return h
+    h = handle(lib)
+    base = lib.sqair_workspace_bytes(h, 10, 32)
+    train = lib.sqair_train_workspace_bytes(h, 10, 32)
+    assert lib.sqair_set_option(h, b"slot_chain", 1) == 0
+    on = lib.sqair_workspace_bytes(h, 10, 32)
+    assert on > 5 * base and on >= train          # per-slot buffers kept apart + the launches' control blocks
+    assert lib.sqair_workspace_bytes(h, 10, 256) == _fresh_bytes(lib, 10, 256)   # 1280 rows: the chain keeps out
+    assert lib.sqair_set_option(h, b"slot_chain", 0) == 0
+    assert lib.sqair_workspace_bytes(h, 10, 32) == base
+    assert lib.sqair_set_option(h, b"vi_target", 1) == 0 and lib.sqair_set_option(h, b"vi_target", 0) == 0
+    assert lib.sqair_set_option(h, b"vi_target", 7) == -2 and b"vi_target" in lib.sqair_last_error(h)
+    lib.sqair_destroy(h)
+    h = handle(lib, time_transition="LSTM")
+    base = lib.sqair_workspace_bytes(h, 10, 32)
+    assert lib.sqair_set_option(h, b"slot_chain", 1) == 0
+    assert lib.sqair_workspace_bytes(h, 10, 32) == base      # LSTM temporal cell: one launch per op
+    lib.sqair_destroy(h)
+    wide = _capi.lib(_capi.WIDE_LIB_PATH)
+    h = handle(wide)
+    assert wide.sqair_set_option(h, b"slot_chain", 1) == -2 and b"wide build" in wide.sqair_last_error(h)
+    wide.sqair_destroy(h)
+
+
+def _fresh_bytes(lib, T, B):
+    F = make_flags(k_particles=5, n_steps_per_image=4)
+    cfg = make_config(F, (50, 50))
+    h = C.c_void_p()
+    assert lib.sqair_create(C.byref(cfg), C.byref(h)) == 0
+    n = lib.sqair_workspace_bytes(h, T, B)
+    lib.sqair_destroy(h)
+    return n
