@@ -25,16 +25,15 @@ __device__ __forceinline__ unsigned ch_uni(unsigned x) { return (unsigned)__buil
 __device__ __forceinline__ unsigned ch_off(const char* wsb, const void* p) { return (unsigned)((const char*)p - wsb); }
 __device__ __forceinline__ u32x4_t ch_l4(CH_RSRC rs, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16); }
 __device__ __forceinline__ unsigned ch_l1(CH_RSRC rs, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 16); }
-__device__ __forceinline__ bool ch_ok4(u32x4_t v) { return ((unsigned)(v.x == SQ_SENT) | (unsigned)(v.y == SQ_SENT) | (unsigned)(v.z == SQ_SENT) | (unsigned)(v.w == SQ_SENT)) == 0; }
 __device__ __forceinline__ unsigned ch_bad4(u32x4_t v) { return (unsigned)(v.x == SQ_SENT) | (unsigned)(v.y == SQ_SENT) | (unsigned)(v.z == SQ_SENT) | (unsigned)(v.w == SQ_SENT); }
 __device__ __forceinline__ f32x4_t ch_f4(u32x4_t v) {
   return f32x4_t{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 }
 #ifdef SQAIR_KNOBS
-// per-item trace of the knob build (tools/chain_trace.py): {op, tile, sub | xcc << 16, polls} + four stamps of the 100 MHz clock
+// per-item trace of the knob build (tools/chain_trace.py): 8 x u64 per item -- {op, tile, sub, xcc, rank, kind} + seven stamps of the
+// 100 MHz clock -- in the item's own slot (launch, workgroup, item ordinal): no atomics in the loop
 __device__ unsigned long long* g_chain_trace = nullptr;
 __device__ unsigned g_chain_trace_cap = 0;
-__device__ unsigned g_chain_trace_n = 0;
 __device__ __forceinline__ unsigned long long ch_clock() { return __builtin_amdgcn_s_memrealtime(); }
 constexpr int CH_LDS_TR = 16 * 68 + 64 + 2 * 3072;   // eight stamps of the current item behind the ops' scratch
 #define CH_TRACE_T(i) do { extern __shared__ __attribute__((aligned(16))) float ch_smem_[]; \
@@ -42,15 +41,14 @@ constexpr int CH_LDS_TR = 16 * 68 + 64 + 2 * 3072;   // eight stamps of the curr
 #else
 #define CH_TRACE_T(i)
 #endif
-#define CH_TRACE_POLLS(n)
 // A pointer read from the LDS copy of the table is a generic pointer to the compiler: it is dereferenced with FLAT instructions,
 // which count on lgkmcnt as well -- every later wait for an LDS read then also waits for the weight / operand loads in flight
-// (measured: the A-operand polls of a dense item went out a memory round trip late).  Round-tripping the pointer through the
-// global address space lets the address-space inference turn those accesses into global_load / global_store.
+// (measured: the A-operand polls of a dense item went out a memory round trip late).  The bodies therefore cast every such
+// pointer to the global address space ONCE (typed pointers: a cast through a generic pointer is folded away again) and all
+// accesses through it are global_load / global_store.
 typedef __attribute__((address_space(1))) float ch_gf;
 typedef const __attribute__((address_space(1))) float ch_gcf;
 typedef const __attribute__((address_space(1))) f32x4_t ch_gcf4;
-typedef const __attribute__((address_space(1))) float4 ch_gcfloat4;
 #define CH_GLB(T, p) ((T*)(p))
 #define CH_POLL_BEGIN { int ch_spins = 0; bool ch_ok; do { ch_ok = true; unsigned ch_bad = 0;
 #define CH_POLL_END(status)                                                                         \
@@ -60,7 +58,6 @@ typedef const __attribute__((address_space(1))) float4 ch_gcfloat4;
       if ((ch_spins & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break; \
     }                                                                                               \
   } while (!ch_ok && ++ch_spins < SQ_CHAIN_SPIN_LIMIT);                                             \
-  CH_TRACE_POLLS(ch_spins + 1);                                                                     \
   if (!ch_ok && (threadIdx.x & 63) == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Poll loops written out (polls issued once AHEAD of the item's other preparations, which then run in the shadow of the polls' round
@@ -1058,25 +1055,15 @@ int sq_chain_flush(SqairHandle* h, unsigned* ctl, int launch_id, hipStream_t s) 
 }
 
 #ifdef SQAIR_KNOBS
-// knob build only: per-item trace buffer of the chain kernel (6 x u64 per record); cap = 0 switches it off
+// knob build only: per-item trace buffer of the chain kernel (8 x u64 per record, (launch * 256 + workgroup) * 96 + item ordinal);
+// a null buffer / cap 0 switches it off
 extern "C" int sqair_chain_trace(void* buf, unsigned cap_records) {
 #ifndef SQAIR_WIDE
-  unsigned zero = 0;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace), &buf, sizeof(buf)) != hipSuccess) return -2;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace_cap), &cap_records, 4) != hipSuccess) return -2;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace_n), &zero, 4) != hipSuccess) return -2;
   return 0;
 #else
   (void)buf; (void)cap_records;
-  return -1;
-#endif
-}
-extern "C" int sqair_chain_trace_count(void) {
-#ifndef SQAIR_WIDE
-  unsigned n = 0;
-  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_chain_trace_n), 4) != hipSuccess) return -2;
-  return (int)n;
-#else
   return -1;
 #endif
 }

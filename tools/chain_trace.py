@@ -1,8 +1,11 @@
 """Per-item trace of the in-launch slot chain (knob build): where a hop's time goes.
     python tools/chain_trace.py [B] [K] [N] [T]      (on the GPU box)
-Each record: op, row tile, sub item, XCD, workgroup, polls, t0 (ticket read), t1 (decoded), t2 (last poll done), t3 (item end).
-Printed per op of ONE chain launch: when its last item ended relative to the previous op's last end (= the hop), how long the
-item bodies took (t3 - t1), decode (t1 - t0), time from poll success to end (t3 - t2), polls per item."""
+One record per item (its own slot per launch, workgroup and item ordinal: no atomics in the loop): op, row tile, sub item, XCD,
+rank, kind and seven stamps of the 100 MHz device clock -- t0 item start, t1 operand polls issued, t2 descriptor / weights /
+epilogue operands prepared, t3 polls succeeded, t4 MFMAs done and partial sums in LDS, t5 past the barrier, t6 item end (the
+stamps 1-5 exist for dense items).  Printed per op of the propagation and the discovery launch of frame 1: the hop (last end of
+the op minus last end of the previous op on the same XCD) and the item time for XCDs serving one / two row tiles, and the mean
+phase lengths of the dense items."""
 import ctypes as C
 import os
 import sys
