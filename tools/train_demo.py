@@ -23,6 +23,7 @@ from sqair_amd.train import Trainer
 over = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a)
 n_train = int(over.pop("n_train", 2048))   # n_train=16384: a training set the model cannot memorise
 hw_over = over.pop("hw", None)              # hw=128x128: BASELINE configs[4]'s frames (the row-wave canvas kernels)
+slot_chain = int(over.pop("slot_chain", 0))  # slot_chain=1: the library's in-launch slot chain (sqair_set_option) for every pass
 sys.argv = [a for a in sys.argv if "=" not in a]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 lr = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-5
@@ -40,7 +41,7 @@ feed = MinibatchFeed(dict(imgs=to_float(train["imgs"]), nums=train["nums"], coor
                      seq_len=seq_len, stage_itr=stage_itr)
 vfeed = MinibatchFeed(dict(imgs=to_float(valid["imgs"]), nums=valid["nums"], coords=valid["coords"]), B, shuffle=False)
 mean_img = to_float(train["imgs"]).mean((0, 1))
-core = SqairCore(F, hw)
+core = SqairCore(F, hw, options={"slot_chain": 1} if slot_chain else None)
 core.set_params({k: np.asarray(v, dtype=np.float32) for k, v in init_params(F, hw, seed=0, mean_img=mean_img).items()})
 model = Model(to_float(train["imgs"][:(seq_len if seq_len and stage_itr else T), :B]), None, core, K, outputs="minimal")
 trainer = Trainer(model, F)
@@ -81,7 +82,10 @@ for it in range(steps + 1):
         with core.on_stream():
             e = float(core.scalars[1]) / core.T
         run = e if it == 0 else 0.9 * run + 0.1 * e
-print(json.dumps(dict(config=dict(T=T, B=B, K=K, N=N, hw=hw, steps=steps, train_itr=train_itr, learning_rate=lr, opt=str(F.opt), flag_overrides=over,
+if slot_chain:   # every chain launch of the last training and validation passes completed
+    core.check_chain(train=True)
+    core.check_chain(train=False)
+print(json.dumps(dict(config=dict(slot_chain=slot_chain, T=T, B=B, K=K, N=N, hw=hw, steps=steps, train_itr=train_itr, learning_rate=lr, opt=str(F.opt), flag_overrides=over,
                                   schedule=F.schedule, data="%d synthetic 2-glyph sequences, 256 held out" % n_train,
                                   true_objects_per_frame=float(valid["nums"].sum(-1).mean())),
                       upper_bound_per_frame=hw[0] * hw[1] * (-np.log(0.3) - 0.5 * np.log(2 * np.pi)), curve=log)))
