@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims 
 // ~1 us of redundant work inside the layer.  The RNN part is k_linear's arithmetic (4 waves split the K chunks g = wave + 4 i in
 // order, two accumulators, LDS reduce), so the layer's result does not depend on whether the tail was fused.
 // ------------------------------------------------------------------------------------------------
-template <int NH>  // hidden-state chunks per wave = nh / 64
+template <int NH, int TN>  // hidden-state chunks per wave = nh / 64; TN column tiles per workgroup (the tail is derived once for them)
 __global__ __launch_bounds__(256) void k_rnn_tail(const TailArgs ta, const Dims d, const float* __restrict__ hid, const int hid_ld,
                                                   const float* __restrict__ wp0, const float* __restrict__ bias,
                                                   const float* __restrict__ add, const int add_ld, float* __restrict__ out,
@@ -376,51 +376,69 @@ __global__ __launch_bounds__(256) void k_rnn_tail(const TailArgs ta, const Dims 
   SQ_TL_SCOPE;
   __shared__ __attribute__((aligned(16))) float zt[16 * ZLD];
   __shared__ float rs[4][16];
-  __shared__ float red[4 * 256];
+  __shared__ float red[TN * 4 * 256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
-  const int tile_n = blockIdx.x, row0 = blockIdx.y * 16;
+  const int tile_n0 = blockIdx.x * TN, row0 = blockIdx.y * 16;
+  const int n_tiles = (n_out + 15) >> 4;
   constexpr int KC = 4 + 4 * NH;
   unsigned long long t_start = 0;
   if (prof_ts != nullptr && tid == 0) t_start = wall_clock64();
   // operands of the layer that do not depend on the tail: weights of my chunks, the hidden-state segment, the epilogue operands
-  const f32x4_t* __restrict__ wp = reinterpret_cast<const f32x4_t*>(wp0) + ((size_t)tile_n * KC) * 64 + lane;
   const float* hrow = hid + (size_t)min(row0 + l15, d.R - 1) * hid_ld;
-  f32x4_t bz = wp[(size_t)wave * 64], bh[NH], ah[NH];
+  f32x4_t bz[TN], bh[TN][NH], ah[NH];
 #pragma unroll
-  for (int i = 0; i < NH; ++i) {
-    const int g = wave + 4 * (i + 1);
-    bh[i] = wp[(size_t)g * 64];
-    ah[i] = *reinterpret_cast<const f32x4_t*>(hrow + (g - 4) * 16 + kq * 4);
+  for (int t = 0; t < TN; ++t) {
+    const f32x4_t* __restrict__ wp = reinterpret_cast<const f32x4_t*>(wp0) + ((size_t)min(tile_n0 + t, n_tiles - 1) * KC) * 64 + lane;
+    bz[t] = wp[(size_t)wave * 64];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) bh[t][i] = wp[(size_t)(wave + 4 * (i + 1)) * 64];
   }
+#pragma unroll
+  for (int i = 0; i < NH; ++i) ah[i] = *reinterpret_cast<const f32x4_t*>(hrow + (wave + 4 * i) * 16 + kq * 4);
   // (fences: hipcc otherwise computes the addresses of ALL ~70 loads of the kernel -- 180 instructions of 64-bit address
   // arithmetic -- before it issues the first one; each group of requests goes out as soon as its own addresses are known)
   __builtin_amdgcn_sched_barrier(0);
-  const int m = row0 + (tid >> 4), n = tile_n * 16 + (tid & 15);
-  const int mc = min(m, d.R - 1), nc = min(n, n_out - 1);
-  const float p_bias = bias[nc], p_add = add[(size_t)mc * add_ld + nc];
+  const int m = row0 + (tid >> 4);
+  const int mc = min(m, d.R - 1);
+  float p_bias[TN], p_add[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int nc = min((tile_n0 + t) * 16 + (tid & 15), n_out - 1);
+    p_bias[t] = bias[nc];
+    p_add[t] = add[(size_t)mc * add_ld + nc];
+  }
   __builtin_amdgcn_sched_barrier(0);
-  tail_body<true>(ta, d, row0, tile_n == 0, zt, rs);
+  tail_body<true>(ta, d, row0, blockIdx.x == 0, zt, rs);
   __syncthreads();
   const f32x4_t az = *reinterpret_cast<const f32x4_t*>(&zt[l15 * ZLD + 16 * wave + 4 * kq]);
-  f32x4_t acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(az.x, bz.x, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(az.y, bz.y, acc1, 0, 0, 0);
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(az.z, bz.z, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(az.w, bz.w, acc1, 0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < NH; ++i) {
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i].x, bh[i].x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i].y, bh[i].y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i].z, bh[i].z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i].w, bh[i].w, acc1, 0, 0, 0);
+  for (int t = 0; t < TN; ++t) {
+    f32x4_t acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(az.x, bz[t].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(az.y, bz[t].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(az.z, bz[t].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(az.w, bz[t].w, acc1, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i].x, bh[t][i].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i].y, bh[t][i].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i].z, bh[t][i].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i].w, bh[t][i].w, acc1, 0, 0, 0);
+    }
+    float* r = red + t * 1024 + wave * 256;
+    r[(4 * kq + 0) * 16 + l15] = acc0.x + acc1.x;
+    r[(4 * kq + 1) * 16 + l15] = acc0.y + acc1.y;
+    r[(4 * kq + 2) * 16 + l15] = acc0.z + acc1.z;
+    r[(4 * kq + 3) * 16 + l15] = acc0.w + acc1.w;
   }
-  float* r = red + wave * 256;
-  r[(4 * kq + 0) * 16 + l15] = acc0.x + acc1.x;
-  r[(4 * kq + 1) * 16 + l15] = acc0.y + acc1.y;
-  r[(4 * kq + 2) * 16 + l15] = acc0.z + acc1.z;
-  r[(4 * kq + 3) * 16 + l15] = acc0.w + acc1.w;
   __syncthreads();
-  if (m < d.R && n < n_out) out[(size_t)m * out_ld + n] = sq_tanh(red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + p_bias + p_add);
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int n = (tile_n0 + t) * 16 + (tid & 15);
+    const float* rt = red + t * 1024;
+    if (m < d.R && n < n_out && tile_n0 + t < n_tiles)
+      out[(size_t)m * out_ld + n] = sq_tanh(rt[tid] + rt[256 + tid] + rt[512 + tid] + rt[768 + tid] + p_bias[t] + p_add[t]);
+  }
   if (prof_ts != nullptr) {
     __syncthreads();
     // (stamped by the last column-tile workgroup of every row tile and by workgroup (0, 0) only: one atomic pair per workgroup
@@ -446,9 +464,21 @@ int sq_launch_rnn_tail(const TailArgs& ta, Dims d, const float* hid, int hid_ld,
   (void)ta; (void)d; (void)hid; (void)hid_ld; (void)wp; (void)bias; (void)add; (void)add_ld; (void)out; (void)out_ld; (void)n_out; (void)s; (void)prof_ts;
   return -1;   // (the wide build never fuses the tail: can_fuse_tail, sqair_api.hip)
 #else
-  const dim3 g((n_out + 15) / 16, (d.R + 15) / 16);
-  if (d.nh == 256) SQ_LAUNCH(k_rnn_tail<4>, g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
-  else if (d.nh == 128) SQ_LAUNCH(k_rnn_tail<2>, g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
+  const int nt = (n_out + 15) / 16, mt = (d.R + 15) / 16;
+  // More 16 x 16 tiles than CUs (from 272 particle rows on at n_hidden 256: cfg-4's 320): the launch would run in two rounds of
+  // workgroups, each re-deriving the tail of its rows.  Two column tiles per workgroup then halve both the workgroups and the
+  // tail work (same sums per tile: bit-identical).
+  static const int two_from = SQ_KNOB_INT("SQAIR_RNN_TAIL_TN2_TILES", 257);
+  if (nt * mt >= two_from && nt >= 2) {
+    const dim3 g((nt + 1) / 2, mt);
+    if (d.nh == 256) SQ_LAUNCH((k_rnn_tail<4, 2>), g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
+    else if (d.nh == 128) SQ_LAUNCH((k_rnn_tail<2, 2>), g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
+    else return -1;
+    return 0;
+  }
+  const dim3 g(nt, mt);
+  if (d.nh == 256) SQ_LAUNCH((k_rnn_tail<4, 1>), g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
+  else if (d.nh == 128) SQ_LAUNCH((k_rnn_tail<2, 1>), g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
   else return -1;
   return 0;
 #endif

@@ -592,12 +592,13 @@ __device__ unsigned long long sq_big_phase[8];   // knob builds: phase stamps of
 #else
 #define SQ_BIG_STAMP(i)
 #endif
-template <int TNW>
+template <int TMW, int TNW>   // wave tile 16 TMW rows x 16 TNW columns; workgroup tile twice that each way
 __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int kc_total, const int n_tiles, const int n_colblk,
                                                     const int n_tiles_total, const int vec_ok SQ_TLP) {
   SQ_TL_SCOPE;
   SQ_BIG_STAMP(0)
-  constexpr int A_BYTES = 128 * 16 * 4, B_BYTES = 2 * TNW * 1024, STAGE = A_BYTES + B_BYTES;
+  constexpr int ROWS = 32 * TMW, A_BYTES = ROWS * 16 * 4, B_BYTES = 2 * TNW * 1024, STAGE = A_BYTES + B_BYTES;
+  constexpr int NPA = (2 * TMW + 3) / 4;       // 16-row activation pieces a wave stages per chunk (pieces wave, wave + 4, ...)
   constexpr int PARK = 4 * (2 * TNW) * 1024;   // epilogue: per wave 2 TNW parked accumulators, 16 bytes per lane each
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE > PARK ? 2 * STAGE : PARK];
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
   if (j >= qn + (xcd < rn ? 1 : 0)) return;
   const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + j;
   const int rowblk = tile / n_colblk, colblk = tile - rowblk * n_colblk;
-  const int row0 = rowblk * 128;
+  const int row0 = rowblk * ROWS;
   const int tile_n0 = colblk * (2 * TNW);
   // segment table in named locals (see k_linear_mt)
   const float* sp0 = a.seg[0].p; const float* sp1 = a.seg[1].p; const float* sp2 = a.seg[2].p; const float* sp3 = a.seg[3].p;
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
   const int c3 = c2 + (a.nseg > 2 ? (w2 + 15) >> 4 : 0);
   const int cum1 = a.nseg > 1 ? c1 : 0x7fffffff, cum2 = a.nseg > 2 ? c2 : 0x7fffffff, cum3 = a.nseg > 3 ? c3 : 0x7fffffff;
   const int lim0 = ((w0 + 3) & ~3) - 4, lim1 = ((w1 + 3) & ~3) - 4, lim2 = ((w2 + 3) & ~3) - 4, lim3 = ((w3 + 3) & ~3) - 4;
-  // staging map of the activations: wave w issues the two 16-row pieces 2 w and 2 w + 1 of a chunk; lane -> row (lane >> 2) of
+  // staging map of the activations: wave w issues the 16-row pieces w, w + 4, .. of a chunk; lane -> row (lane >> 2) of
   // the piece, LDS slot lane & 3, which holds the 16-byte unit q = slot ^ ((row >> 1) & 3) of the row's 64 bytes.
   // The per-chunk address work is kept to a handful of instructions (one wave per SIMD issues an instruction every ~4-5 cycles:
   // ~70 instructions of segment selection and 64-bit arithmetic per chunk were 0.3 us of every 1.2 us chunk): the row pointers
@@ -629,8 +630,12 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
   // the weight pointers advance by one fragment block.
   const int srow = lane >> 2;
   const int sq4 = ((lane & 3) ^ ((srow >> 1) & 3)) * 4;
-  const int arow_a = min(row0 + 32 * wave + srow, a.M - 1), arow_b = min(row0 + 32 * wave + 16 + srow, a.M - 1);
-  const float *pa = nullptr, *pb = nullptr;   // row pointers into the current segment
+  int arow[NPA];
+#pragma unroll
+  for (int q = 0; q < NPA; ++q) arow[q] = min(row0 + 16 * (wave + 4 * q) + srow, a.M - 1);
+  const float* pa[NPA];                       // row pointers into the current segment
+#pragma unroll
+  for (int q = 0; q < NPA; ++q) pa[q] = nullptr;
   int seg_c0 = 0, seg_end = 0, seg_lim = 0, seg_i = -1;     // its first chunk, one past its last chunk, clamp of the k offset
   const float* wpt[(2 * TNW + 3) / 4];        // this wave's weight tiles t = wave, wave + 4, ...: pointer to the block of the NEXT chunk
 #pragma unroll
@@ -646,13 +651,14 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
       const unsigned sm = seg_i == 0 ? sm0 : (seg_i == 1 ? sm1 : (seg_i == 2 ? sm2 : sm3));                           \
       const int sw = seg_i == 0 ? w0 : (seg_i == 1 ? w1 : (seg_i == 2 ? w2 : w3));                                    \
       seg_c0 = seg_end; seg_end += (sw + 15) >> 4; seg_lim = ((sw + 3) & ~3) - 4;                                     \
-      pa = sp + (size_t)(sm ? (int)__umulhi((unsigned)arow_a, sm) : arow_a) * sl;                                     \
-      pb = sp + (size_t)(sm ? (int)__umulhi((unsigned)arow_b, sm) : arow_b) * sl;                                     \
+      _Pragma("unroll") for (int q = 0; q < NPA; ++q)                                                                 \
+        pa[q] = sp + (size_t)(sm ? (int)__umulhi((unsigned)arow[q], sm) : arow[q]) * sl;                              \
     }                                                                                                                \
     const int kk = min((g - seg_c0) * 16 + sq4, seg_lim);                                                            \
     char* st = lds + (BUF) * STAGE;                                                                                   \
-    __builtin_amdgcn_global_load_lds((glb_ptr)(pa + kk), (lds_ptr)(st + (2 * wave) * 1024), 16, 0, 0);               \
-    __builtin_amdgcn_global_load_lds((glb_ptr)(pb + kk), (lds_ptr)(st + (2 * wave + 1) * 1024), 16, 0, 0);           \
+    _Pragma("unroll") for (int q = 0; q < NPA; ++q)                                                                   \
+      if (wave + 4 * q < 2 * TMW)                                                                                     \
+        __builtin_amdgcn_global_load_lds((glb_ptr)(pa[q] + kk), (lds_ptr)(st + (wave + 4 * q) * 1024), 16, 0, 0);     \
     _Pragma("unroll") for (int q = 0; q < (2 * TNW + 3) / 4; ++q)                                                     \
       if (wave + 4 * q < 2 * TNW) {                                                                                   \
         __builtin_amdgcn_global_load_lds((glb_ptr)wpt[q], (lds_ptr)(st + A_BYTES + (wave + 4 * q) * 1024), 16, 0, 0); \
@@ -660,13 +666,13 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
       }                                                                                                               \
   }
 
-  f32x4 acc[4][TNW];
+  f32x4 acc[TMW][TNW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TMW; ++i)
 #pragma unroll
     for (int t = 0; t < TNW; ++t) acc[i][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  // fragment read offsets (bytes inside a stage): activation row (64 wave_m + 16 i + l15), slot kq ^ ((l15 >> 1) & 3)
-  const int a_off = (64 * wave_m + l15) * 64 + ((kq ^ ((l15 >> 1) & 3)) * 16);
+  // fragment read offsets (bytes inside a stage): activation row (16 TMW wave_m + 16 i + l15), slot kq ^ ((l15 >> 1) & 3)
+  const int a_off = (16 * TMW * wave_m + l15) * 64 + ((kq ^ ((l15 >> 1) & 3)) * 16);
   const int b_off = A_BYTES + wave_n * TNW * 1024 + lane * 16;
   SQ_BIG_STAMP(1)
   SQ_BIG_STAGE(0, 0)
@@ -677,25 +683,25 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
     const int buf = c & 1;
     if (c + 1 < kc_total) SQ_BIG_STAGE(c + 1, buf ^ 1)
     const char* st = lds + buf * STAGE;
-    f32x4 af[4], bv[TNW];
+    f32x4 af[TMW], bv[TNW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + a_off + i * 1024);
+    for (int i = 0; i < TMW; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + a_off + i * 1024);
 #pragma unroll
     for (int t = 0; t < TNW; ++t) bv[t] = *reinterpret_cast<const f32x4*>(st + b_off + t * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
       for (int t = 0; t < TNW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].x, af[i].x, acc[i][t], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
       for (int t = 0; t < TNW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].y, af[i].y, acc[i][t], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
       for (int t = 0; t < TNW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].z, af[i].z, acc[i][t], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
       for (int t = 0; t < TNW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].w, af[i].w, acc[i][t], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise hoists the barrier into the middle of the chunk's MFMAs: half the time for the loads)
@@ -725,18 +731,21 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
   const float sc = a.scale * p_scale;
   const int act = a.act_a;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < (TMW + 1) / 2; ++half) {
+    constexpr int LAST = TMW - 2 * ((TMW - 1) / 2);    // row tiles of the last group (an odd TMW ends on a single one)
+    const int n_ii = half == (TMW - 1) / 2 ? LAST : 2;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int t = 0; t < TNW; ++t) park[(ii * TNW + t) * 64] = acc[2 * half + ii][t];
+      for (int t = 0; t < TNW; ++t)
+        if (2 * half + ii < TMW) park[(ii * TNW + t) * 64] = acc[2 * half + ii][t];
     if (half == 0) { SQ_BIG_STAMP(5) }
     if (half == 1) { SQ_BIG_STAMP(6) }
-    const int mh = row0 + wave_m * 64 + half * 32 + l15;
+    const int mh = row0 + wave_m * (16 * TMW) + half * 32 + l15;
     // (TNW accumulators per trip: a lone wave stalls on every LDS / address / store latency of a one-accumulator body --
     // measured 0.23 us per accumulator with an identity activation -- so the trip carries TNW independent chains)
 #pragma unroll 1
-    for (int ii = 0; ii < 2; ++ii) {
+    for (int ii = 0; ii < n_ii; ++ii) {
       const int m = mh + ii * 16;
       sq_f32x4 v[TNW];
 #pragma unroll
@@ -776,9 +785,33 @@ extern "C" int sqair_debug_big_phases(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sq_big_phase), sizeof(unsigned long long) * 8);
 }
 #endif
-template <int TNW>
+// Tile shape of k_linear_big.  The layer shapes of the pass put between 60 and a few hundred 128 x 64 tiles on 256 CUs, so the
+// number of ROUNDS of workgroups decides more than the efficiency of a tile: 270 tiles (cfg-4's 1920 x 362 x 1152) leave 14
+// CUs with two tiles while 242 wait (33.2 us; 240 tiles of 96 x 96: 24.5), 80 tiles (2560 x 256 x 256) leave two thirds of the
+// chip idle (16.9 us; 160 tiles of 64 x 64: 11.1).  Every shape accumulates a given output in the same order (bit-identical).
+// The choice minimises a cost model fitted to tools/big_shapes.sh (14 layer shapes x 9 tile shapes, back to back, MI355X; rms
+// 0.4 us on the single-round launches): one round of a wave tile of u = TMW TNW MFMA tiles over kc K chunks takes
+//   T1 = 1.39 + 0.33 kc + 0.0677 kc u + 0.101 u (+ 0.162 u with a non-linear activation)   [us]
+// and r = ceil(tiles / 256) rounds take T1 (1 + (0.338 + 0.0357 u)(r - 1)) -- a second workgroup on a CU hides part of the
+// first one's stalls, less so the larger the tile.  With the four shapes kept, the model's picks sum to 368 us over the 14
+// shapes against 355 for the best of all nine shapes per layer and 408 for 128 x 64 everywhere.
+static int pick_big_shape(int M, int n_tiles, int kc, bool nonlinear) {
+  static const int cand[4][2] = {{4, 2}, {3, 3}, {3, 2}, {2, 2}};
+  int best = 42;
+  float best_t = 1e30f;
+  for (int i = 0; i < 4; ++i) {
+    const int tm = cand[i][0], tn = cand[i][1], u = tm * tn;
+    const int tiles = ((M + 32 * tm - 1) / (32 * tm)) * ((n_tiles + 2 * tn - 1) / (2 * tn));
+    const float t1 = 1.39f + 0.33f * kc + 0.0677f * kc * u + 0.101f * u + (nonlinear ? 0.162f * u : 0.0f);
+    const float t = t1 * (1.0f + (0.338f + 0.0357f * u) * (float)((tiles + 255) / 256 - 1));
+    if (t < best_t) { best_t = t; best = 10 * tm + tn; }
+  }
+  return best;
+}
+
+template <int TMW, int TNW>
 static void launch_big(const LinArgs& a, const PackedLayer& L, hipStream_t s) {
-  const int n_colblk = (L.nt + 2 * TNW - 1) / (2 * TNW), n_rowblk = (a.M + 127) / 128;
+  const int n_colblk = (L.nt + 2 * TNW - 1) / (2 * TNW), n_rowblk = (a.M + 32 * TMW - 1) / (32 * TMW);
   const int total = n_colblk * n_rowblk;
   // 16-byte epilogue accesses need 16-byte aligned rows in every tensor the epilogue touches
   auto al = [](const void* p, int ld) { return p == nullptr || (((uintptr_t)p & 15) == 0 && (ld & 3) == 0); };
@@ -793,7 +826,7 @@ static void launch_big(const LinArgs& a, const PackedLayer& L, hipStream_t s) {
   // (measured and dropped: starting the workgroups in odd hardware wave slots half a CU-load of matrix work late, so that their
   // K loops cover the others' epilogues -- 51200 x 256 x 256: 91 -> 84 us at half the computed delay with the 128 x 64 tile,
   // slower in every other combination tried)
-  SQ_LAUNCH((k_linear_big<TNW>), dim3(8 * ((total + 7) / 8)), dim3(256), 0, s, a, L.kc, L.nt, n_colblk, total, vec);
+  SQ_LAUNCH((k_linear_big<TMW, TNW>), dim3(8 * ((total + 7) / 8)), dim3(256), 0, s, a, L.kc, L.nt, n_colblk, total, vec);
 }
 
 // Tile shape of the throughput variants, from measurements of the layer shapes of the pass (tools/time_linear.py, MI355X):
@@ -863,13 +896,21 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
     const LinSeg& sg = a.seg[i];
     if ((reinterpret_cast<uintptr_t>(sg.p) & 15) != 0 || (sg.ld & 3) != 0 || sg.width < 1 || sg.rdiv < 1) return -5;
   }
-  // Launches with thousands of rows: the throughput variants.  Below that the split-K kernel (one 16 x 16 tile per workgroup,
-  // 4 waves on the K range) is the faster one IN THE PASS on every configuration measured -- its time barely moves between 160
-  // and 1920 rows (4.7 -> 5.0 us), while the macro-tile kernels, ahead of it in back-to-back timing of one shape, lost 1 % of
-  // the forward pass at 32 sequences per GPU, 11 % at 64 and at cfg-4 (they were used from 256 rows up until round 2).
+  // Launches with many thousands of rows: the throughput variants.  Below that the split-K kernel (one 16 x 16 tile per
+  // workgroup, 4 waves on the K range) is the faster one IN THE PASS on every configuration measured -- its time barely moves
+  // between 160 and 1920 rows (4.7 -> 5.0 us), while the macro-tile kernels, ahead of it in back-to-back timing of one shape,
+  // lost 1 % of the forward pass at 32 sequences per GPU, 11 % at 64 and at cfg-4 (they were used from 256 rows up until round 2).
+  // The boundary was 2048 rows until round 5 and is 6000 now (tools/ab_libs.py on product builds with the boundary at 2048 /
+  // 4096 / 5200 / 7000 / 20000 / never): 128 sequences per GPU (2560-row layers) forward 5.85 -> 5.43 ms, training 14.00 ->
+  // 13.60; 256 sequences (5120 rows) 8.33 -> 8.10 / 21.63 -> 21.37; from 6400 rows on the LDS-tiled kernel is ahead (cfg-2's and
+  // cfg-4's once-per-pass layers: 20000 costs cfg-4 0.05 ms, cfg-2 0.007).  Back to back the split-K kernel does
+  // 2560 x 256 x 256 in 8.4 us (the LDS-tiled kernel's best tile 11.1), 5120 x 256 x 256 in 15.2 (15.1).
   // Also tried for the 2048+ row launches and dropped: the split-K structure with a 32 x 32 and with a 64 x 64 workgroup tile
   // (half / a quarter of the operand bytes per output tile): 22 - 25 us against 16 - 17 us on 5120 x 256 x 256, back to back.
-  static const int mt_rows = SQ_KNOB_INT("SQAIR_MT_ROWS", 2048);  // measurement knob
+#ifndef SQAIR_MT_ROWS_DEFAULT
+#define SQAIR_MT_ROWS_DEFAULT 6000
+#endif
+  static const int mt_rows = SQ_KNOB_INT("SQAIR_MT_ROWS", SQAIR_MT_ROWS_DEFAULT);  // measurement knob (tools/build_rev.sh WT <name> -D...)
   // just below 2048 rows only the WIDE layers go to the LDS-tiled kernel (its 128 x 64 tiles then still number ~200):
   // tools/time_linear.py, back to back, 1920 x 362 x 1152 35.7 -> 33.2 us, 1920 x 312 x 768 21.2 -> 19.2 (every 256 / 400-column
   // layer would be twice as slow; at 1280 rows 362 x 1152 gains back to back, 24.3 -> 21.1, but not in the pass, and
@@ -888,12 +929,23 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
     // tiles (tools/time_linear.py, back to back: 5120 x 362 x 1152 70 -> 52 us, 51200 x 256 x 256 113 -> 88, 6400 x 256 x 400
     // 28 -> 25, 5120 x 256 x 256 18 -> 17.4); the 128 x 64 tile (TNW = 2) beats 128 x 128 wherever the tile count is what
     // limits (all of these shapes: 80 - 1600 tiles on 256 CUs)
-    static const int big = SQ_KNOB_INT("SQAIR_BIG", 2);  // measurement knob: 0 = off, 2 / 4 = forced TNW
+    static const int big = SQ_KNOB_INT("SQAIR_BIG", 2);  // measurement knob: 0 = off
     if (big > 0 && prof_ts == nullptr && L.nt >= 4) {
 #ifdef SQAIR_KNOBS
-      if (big == 4) { launch_big<4>(a, L, s); return 0; }   // (the 128 x 128 tile exists in the knob build only)
+      if (const char* e = SQ_KNOB_STR("SQAIR_BIG_SHAPE")) {   // "TMW,TNW": forced tile (measurement)
+        const int tm = e[0] - '0', tn = e[2] - '0';
+#define SQ_BIG_CASE(A, B) if (tm == A && tn == B) { launch_big<A, B>(a, L, s); return 0; }
+        SQ_BIG_CASE(2, 2) SQ_BIG_CASE(2, 3) SQ_BIG_CASE(2, 4) SQ_BIG_CASE(3, 2) SQ_BIG_CASE(3, 3) SQ_BIG_CASE(3, 4)
+        SQ_BIG_CASE(4, 2) SQ_BIG_CASE(4, 3) SQ_BIG_CASE(4, 4)
+#undef SQ_BIG_CASE
+      }
 #endif
-      launch_big<2>(a, L, s);
+      switch (pick_big_shape(a.M, L.nt, L.kc, a.act_a != ACT_NONE)) {
+        case 22: launch_big<2, 2>(a, L, s); break;
+        case 32: launch_big<3, 2>(a, L, s); break;
+        case 33: launch_big<3, 3>(a, L, s); break;
+        default: launch_big<4, 2>(a, L, s); break;
+      }
       return 0;
     }
     static const int lds_wgs = SQ_KNOB_INT("SQAIR_LDS_WGS", 512);  // measurement knob

@@ -28,10 +28,18 @@ def handle():
 @pytest.mark.parametrize("M,K,N,act", [(160, 256, 256, 1), (37, 54, 109, 0), (640, 400, 256, 1), (5, 2500, 256, 1),
                                        (160, 311, 256, 2), (160, 256, 8, 0), (33, 128, 400, 3), (160, 256, 100, 4),
                                        (16, 16, 16, 0), (1, 3, 1, 0),
-                                       # thousands of rows: the 64 x 64 split-K kernel (ragged last row tile, column tiles past N,
-                                       # K that is not a multiple of 16, fewer chunks than waves, more than two blocks of chunks)
+                                       # thousands of rows on the split-K kernel (below 6000 rows since round 5: ragged last row
+                                       # tile, column tiles past N, K that is not a multiple of 16, more than two blocks of chunks)
                                        (2048, 256, 256, 1), (5120, 400, 256, 1), (2100, 311, 109, 2), (2049, 72, 8, 0),
-                                       (3000, 1100, 200, 4), (2048, 40, 64, 3)])
+                                       (3000, 1100, 200, 4), (2048, 40, 64, 3),
+                                       # from 6000 rows: the throughput kernels -- k_linear_big with its four tile shapes
+                                       # (128 x 64, 64 x 64, 128 x 64 deep K, 96 x 64), one column tile (macro-tile kernel), K <= 64
+                                       # (k_linear_rows)
+                                       (6400, 256, 256, 1), (6100, 311, 109, 2), (7000, 1100, 200, 4), (6400, 256, 400, 0),
+                                       (6001, 72, 8, 0), (6400, 40, 64, 3),
+                                       # the wide layers from 1792 rows: a few more 128 x 64 tiles than CUs (270) -> 96 x 96 tiles
+                                       # (cfg-4's widest once-per-frame layer; ragged last row block and column block), 96 x 64
+                                       (1920, 362, 1152, 0), (1900, 311, 1100, 1), (1920, 312, 768, 0)])
 def test_linear_mfma_matches_fp64(handle, M, K, N, act):
     lib, h, _ = handle
     rng = np.random.default_rng(M * 7 + K)
@@ -63,7 +71,7 @@ def test_linear_identity_asymmetric(handle):
     assert np.array_equal(y.cpu().numpy(), w)
 
 
-@pytest.mark.parametrize("M", [16, 2048])  # split-K kernel / macro-tile kernel (rolled epilogue)
+@pytest.mark.parametrize("M", [16, 6400])  # split-K kernel / row-slab kernel of the K <= 64 layers (rolled epilogue)
 def test_activations_saturate_cleanly(handle, M):
     """Large finite pre-activations must saturate (tanh -> +-1, sigmoid -> 0 / 1, softplus -> x / 0.01, ELU -> x / -1) and never
     produce NaN: the hardware-exp2 based exponential overflowed to inf * r = NaN beyond |x| ~ 88 (round-2 advisor finding)."""
@@ -96,7 +104,7 @@ def test_activations_saturate_cleanly(handle, M):
             assert (got[0, pre <= -89.0] <= 1e-38).all()
 
 
-@pytest.mark.parametrize("M,Kx", [(160, 360), (640, 54), (7, 17), (2304, 360), (2050, 54)])
+@pytest.mark.parametrize("M,Kx", [(160, 360), (640, 54), (7, 17), (2304, 360), (2050, 54), (6400, 360), (6050, 54)])
 def test_gru_step(handle, M, Kx):
     lib, h, _ = handle
     nh = 256
@@ -111,7 +119,7 @@ def test_gru_step(handle, M, Kx):
     x = rng.standard_normal((M, Kx)).astype(np.float32)
     hs = rng.standard_normal((M, nh)).astype(np.float32)
     out = torch.zeros(M, nh, device="cuda")
-    scratch = torch.empty(1 << 22, dtype=torch.float32, device="cuda")
+    scratch = torch.empty(1 << 24, dtype=torch.float32, device="cuda")
     dx, dh, df = dev(x), dev(hs), dev(np.concatenate(flat))
     rc = lib.sqair_gru_test(h, dx.data_ptr(), dh.data_ptr(), df.data_ptr(),
                             out.data_ptr(), M, Kx, scratch.data_ptr(), scratch.numel() * 4, stream())

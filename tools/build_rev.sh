@@ -16,7 +16,7 @@ else
 fi
 mkdir -p $REPO/tools/bin
 cd $TMP/sqair_amd/csrc
-for f in sqair_api sqair_linear sqair_glue sqair_bwd sqair_train sqair_linear_dx; do
+for f in $(ls *.hip | sed "s/\.hip$//"); do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-mfma-vgpr-form=1 $EXTRA \
     -DSQAIR_BUILD_ID="\"rev$(git -C $REPO rev-parse --short=13 $REV)\"" -DSQAIR_BUILD_VARIANT='"product"' -c $f.hip -o $f.o &
 done

@@ -23,19 +23,33 @@ def kernel_table(path):
         open(co, "wb").write(so[i:])
         out = subprocess.run([READELF, "--notes", co], capture_output=True, text=True).stdout
         os.remove(co)
-        cur = None
+        # one YAML list item per kernel ("  - .agpr_count: ..." opens it; its keys are in alphabetical order, so some of them
+        # come BEFORE .name); nested items (.args) are indented deeper
+        cur, ind = None, None
+        in_kernels = False
         for line in out.splitlines():
-            m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)", line)
+            if re.match(r"\s*amdhsa\.kernels:", line):
+                in_kernels = True
+                continue
+            if not in_kernels:
+                continue
+            m = re.match(r"(\s*)(- )?\.(\w+):\s*(.*)", line)
             if not m:
                 continue
-            key, val = m.group(1), m.group(2).strip()
-            if key == "name" and val.startswith("_Z") or key == "name" and re.match(r"^[A-Za-z_]\w*$", val) and not val.endswith(".kd"):
-                if cur and "vgpr_count" in cur:
+            lead, dash, key, val = len(m.group(1)), m.group(2), m.group(3), m.group(4).strip()
+            if dash and (ind is None or lead == ind) and key != "address_space" and key != "offset" and key != "actual_access":
+                if ind is None:
+                    ind = lead
+                if cur and "vgpr_count" in cur and "mangled" in cur:
                     rows.append(cur)
-                cur = {"mangled": val}
-            elif cur is not None and key in KEYS:
+                cur = {}
+            if cur is None or lead != ind + 2 and not (dash and lead == ind):
+                continue
+            if key == "name":
+                cur["mangled"] = val
+            elif key in KEYS:
                 cur[key] = int(val)
-        if cur and "vgpr_count" in cur:
+        if cur and "vgpr_count" in cur and "mangled" in cur:
             rows.append(cur)
     names = subprocess.run(["c++filt"], input="\n".join(r["mangled"] for r in rows), capture_output=True, text=True).stdout.splitlines()
     seen, uniq = set(), []
