@@ -987,7 +987,10 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
 
   // (the fused launch recomputes a slot's tail in each of the layer's nh / 16 column-tile workgroups: free while the pass is
   // latency-bound (-0.2 ms at 160 rows), even at 320 rows, a loss from 640 on -- 20.5 us against 5.9 + 5.5 us at 1280 rows)
-  static const int tail_rows = SQ_KNOB_INT("SQAIR_TAIL_FUSION_ROWS", 320);
+#ifndef SQAIR_TAIL_FUSION_ROWS_DEFAULT
+#define SQAIR_TAIL_FUSION_ROWS_DEFAULT 560
+#endif
+  static const int tail_rows = SQ_KNOB_INT("SQAIR_TAIL_FUSION_ROWS", SQAIR_TAIL_FUSION_ROWS_DEFAULT);
   const bool fuse_prop = d.R <= tail_rows && can_fuse_tail(h, L_PROP_RNN), fuse_disc = d.R <= tail_rows && can_fuse_tail(h, L_DISC_RNN);
   if (w.chain && !(fuse_prop && fuse_disc)) { sq_set_error(h, "slot chain: tail fusion off"); return -3; }
   TailArgs pending_tail; memset(&pending_tail, 0, sizeof(pending_tail));

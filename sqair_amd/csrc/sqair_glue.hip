@@ -468,7 +468,10 @@ int sq_launch_rnn_tail(const TailArgs& ta, Dims d, const float* hid, int hid_ld,
   // More 16 x 16 tiles than CUs (from 272 particle rows on at n_hidden 256: cfg-4's 320): the launch would run in two rounds of
   // workgroups, each re-deriving the tail of its rows.  Two column tiles per workgroup then halve both the workgroups and the
   // tail work (same sums per tile: bit-identical).
-  static const int two_from = SQ_KNOB_INT("SQAIR_RNN_TAIL_TN2_TILES", 257);
+#ifndef SQAIR_RNN_TAIL_TN2_TILES_DEFAULT
+#define SQAIR_RNN_TAIL_TN2_TILES_DEFAULT 257
+#endif
+  static const int two_from = SQ_KNOB_INT("SQAIR_RNN_TAIL_TN2_TILES", SQAIR_RNN_TAIL_TN2_TILES_DEFAULT);
   if (nt * mt >= two_from && nt >= 2) {
     const dim3 g((nt + 1) / 2, mt);
     if (d.nh == 256) SQ_LAUNCH((k_rnn_tail<4, 2>), g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);

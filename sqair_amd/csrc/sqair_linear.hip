@@ -19,6 +19,7 @@
 //     weights, always lands on the same XCD (block b runs on XCD b % 8) and stays in that L2;
 //   * epilogue fuses bias, a precomputed partial sum (loop-invariant part of the pre-activation),
 //     the activation, and the GRU gate arithmetic.
+#include <type_traits>
 #include "sqair_common.h"
 #include "sqair_lin_device.h"
 #include <stdio.h>
@@ -576,8 +577,8 @@ static void launch_t2_any(const LinArgs& a, const PackedLayer& L, hipStream_t s)
 //     fragment block of the packed buffer IS lane order; an activation block (16 rows x 64 bytes) is fetched with 4 lanes on
 //     each row's 64 contiguous bytes and the 16-byte unit q of row r goes to slot q ^ ((r >> 1) & 3) -- the swizzle is applied
 //     to the SOURCE address -- so that the fragment read (16 rows, same q) spreads over all banks;
-//   * two LDS stages: the loads of chunk c + 1 are issued before the MFMAs of chunk c and retired by the barrier that ends it
-//     (one chunk = ~0.9 us of matrix-core work per wave hides an L2 / MALL round trip);
+//   * NST LDS stages: the loads of chunk c + NST are issued during chunk c, and a wave waits only until ITS loads of chunk
+//     c + 1 have landed (s_waitcnt vmcnt(loads of the later chunks), then the workgroup barrier);
 //   * blockIdx -> tile is XCD-aware: XCD x (= blockIdx % 8) owns a contiguous run of tiles in row-block-major order, i.e. a few
 //     row blocks with ALL their column blocks: every activation row is pulled into ONE L2 (the weights, small, into all 8);
 //     with the column block fastest across XCDs every L2 would fetch the whole activation matrix;
@@ -589,18 +590,37 @@ static void launch_t2_any(const LinArgs& a, const PackedLayer& L, hipStream_t s)
 #ifdef SQAIR_KNOBS
 __device__ unsigned long long sq_big_phase[8];   // knob builds: phase stamps of workgroup 0 / wave 0 (tools/time_linear.py prints them)
 #define SQ_BIG_STAMP(i) if (blockIdx.x == 8 && threadIdx.x == 0) sq_big_phase[i] = wall_clock64();
+// shader-clock cycles of the K loop (s_memtime), next to its wall time: the clock the loop ran at
+#define SQ_BIG_CYC0() const unsigned long long cyc0 = __builtin_readcyclecounter();
+#define SQ_BIG_CYC1() if (blockIdx.x == 8 && threadIdx.x == 0) sq_big_phase[7] = __builtin_readcyclecounter() - cyc0;
 #else
 #define SQ_BIG_STAMP(i)
+#define SQ_BIG_CYC0()
+#define SQ_BIG_CYC1()
 #endif
+#ifndef SQ_BIG_NST
+#define SQ_BIG_NST 4
+#endif
+// s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt = bits 15:14 | 3:0, expcnt 6:4 and lgkmcnt 11:8 left at "no wait"); n is wave-uniform
+#define SQ_VMCNT_IMM(n) (((n) & 15) | (((n) >> 4) << 14) | 0x0F70)
+template <int I, int N, class F>
+__device__ __forceinline__ void sq_static_for(F&& f) {   // f(integral_constant<int, I>) ... f(integral_constant<int, N - 1>), in order
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sq_static_for<I + 1, N>(f);
+  }
+}
 template <int TMW, int TNW>   // wave tile 16 TMW rows x 16 TNW columns; workgroup tile twice that each way
 __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int kc_total, const int n_tiles, const int n_colblk,
                                                     const int n_tiles_total, const int vec_ok SQ_TLP) {
   SQ_TL_SCOPE;
   SQ_BIG_STAMP(0)
   constexpr int ROWS = 32 * TMW, A_BYTES = ROWS * 16 * 4, B_BYTES = 2 * TNW * 1024, STAGE = A_BYTES + B_BYTES;
+  constexpr int NST = SQ_BIG_NST, AHEAD = NST - 2;   // chunks whose loads may still be in flight while chunk c is multiplied
   constexpr int NPA = (2 * TMW + 3) / 4;       // 16-row activation pieces a wave stages per chunk (pieces wave, wave + 4, ...)
+  constexpr int NPB = (2 * TNW + 3) / 4;       // weight tiles a wave stages per chunk
   constexpr int PARK = 4 * (2 * TNW) * 1024;   // epilogue: per wave 2 TNW parked accumulators, 16 bytes per lane each
-  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE > PARK ? 2 * STAGE : PARK];
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE > PARK ? NST * STAGE : PARK];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
@@ -641,7 +661,12 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
 #pragma unroll
   for (int q = 0; q < (2 * TNW + 3) / 4; ++q)
     wpt[q] = a.wp + ((size_t)min(tile_n0 + wave + 4 * q, n_tiles - 1) * kc_total) * 256 + (size_t)lane * 4;
-#define SQ_BIG_STAGE(G, BUF)                                                                                         \
+  // issuing the loads of one chunk, in steps the K loop places between its MFMAs:
+  //   SEG   -- (rarely) move the row pointers to the next segment of the virtually concatenated operand
+  //   A(q)  -- this wave's q-th 16-row activation piece;  B(q) -- its q-th weight tile
+  int ld_kk = 0;
+  char* ld_st = lds;
+#define SQ_BIG_SEG(G, BUF)                                                                                           \
   {                                                                                                                  \
     const int g = (G);                                                                                               \
     if (g >= seg_end) { /* next segment (wave-uniform) */                                                            \
@@ -654,16 +679,23 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
       _Pragma("unroll") for (int q = 0; q < NPA; ++q)                                                                 \
         pa[q] = sp + (size_t)(sm ? (int)__umulhi((unsigned)arow[q], sm) : arow[q]) * sl;                              \
     }                                                                                                                \
-    const int kk = min((g - seg_c0) * 16 + sq4, seg_lim);                                                            \
-    char* st = lds + (BUF) * STAGE;                                                                                   \
-    _Pragma("unroll") for (int q = 0; q < NPA; ++q)                                                                   \
-      if (wave + 4 * q < 2 * TMW)                                                                                     \
-        __builtin_amdgcn_global_load_lds((glb_ptr)(pa[q] + kk), (lds_ptr)(st + (wave + 4 * q) * 1024), 16, 0, 0);     \
-    _Pragma("unroll") for (int q = 0; q < (2 * TNW + 3) / 4; ++q)                                                     \
-      if (wave + 4 * q < 2 * TNW) {                                                                                   \
-        __builtin_amdgcn_global_load_lds((glb_ptr)wpt[q], (lds_ptr)(st + A_BYTES + (wave + 4 * q) * 1024), 16, 0, 0); \
-        wpt[q] += 256;                                                                                                \
-      }                                                                                                               \
+    ld_kk = min((g - seg_c0) * 16 + sq4, seg_lim);                                                                    \
+    ld_st = lds + (BUF) * STAGE;                                                                                      \
+  }
+  // (a piece index every wave has is not tested: the test would cost an exec-mask save / restore around the load)
+#define SQ_BIG_LOAD_A(q)                                                                                              \
+  if (4 * (q) + 3 < 2 * TMW || wave + 4 * (q) < 2 * TMW)                                                              \
+    __builtin_amdgcn_global_load_lds((glb_ptr)(pa[q] + ld_kk), (lds_ptr)(ld_st + (wave + 4 * (q)) * 1024), 16, 0, 0);
+#define SQ_BIG_LOAD_B(q)                                                                                              \
+  if (4 * (q) + 3 < 2 * TNW || wave + 4 * (q) < 2 * TNW) {                                                            \
+    __builtin_amdgcn_global_load_lds((glb_ptr)wpt[q], (lds_ptr)(ld_st + A_BYTES + (wave + 4 * (q)) * 1024), 16, 0, 0); \
+    wpt[q] += 256;                                                                                                    \
+  }
+#define SQ_BIG_STAGE(G, BUF)                                                                                          \
+  {                                                                                                                  \
+    SQ_BIG_SEG(G, BUF)                                                                                                \
+    _Pragma("unroll") for (int q = 0; q < NPA; ++q) { SQ_BIG_LOAD_A(q) }                                              \
+    _Pragma("unroll") for (int q = 0; q < NPB; ++q) { SQ_BIG_LOAD_B(q) }                                              \
   }
 
   f32x4 acc[TMW][TNW];
@@ -675,40 +707,87 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a, const int k
   const int a_off = (16 * TMW * wave_m + l15) * 64 + ((kq ^ ((l15 >> 1) & 3)) * 16);
   const int b_off = A_BYTES + wave_n * TNW * 1024 + lane * 16;
   SQ_BIG_STAMP(1)
-  SQ_BIG_STAGE(0, 0)
-  __syncthreads();
+  // vector-memory instructions this wave issues per chunk (wave-uniform): NL_MAX for the waves that have a piece / tile of every
+  // round q, NL_MIN for the others
+  constexpr int NL_MAX = NPA + NPB, NL_MIN = (2 * TMW) / 4 + (2 * TNW) / 4;
+  const bool ld_max = __builtin_amdgcn_readfirstlane((2 * TMW - wave + 3) / 4 + (2 * TNW - wave + 3) / 4) == NL_MAX;
+#pragma unroll
+  for (int g0 = 0; g0 < NST; ++g0)
+    if (g0 < kc_total) SQ_BIG_STAGE(g0, g0)
   SQ_BIG_STAMP(2)
+  SQ_BIG_CYC0()
+  // Software pipeline inside the wave: the fragments of chunk c + 1 are read from LDS into a second register set, and the loads
+  // of chunk c + NST are issued, BETWEEN the MFMAs of chunk c (which depend on registers only).  With one wave per SIMD --
+  // what a launch of <= 256 workgroups gives -- nothing else fills the matrix pipe during the ~45 instructions of address work,
+  // the fragment reads and their latency: issued ahead of the MFMAs they were 0.2 - 0.3 us of every chunk (0.33 us per chunk
+  // on top of the MFMAs in the fit of tools/big_shapes.sh, for every tile shape; deeper prefetch alone changed nothing).
+  // The placement is by hand (the loads sit behind wave-uniform branches, and hipcc does not move MFMAs across basic blocks):
+  // an MFMA occupies the pipe for 32 cycles, a step below issues in about as many.
+  f32x4 af0[TMW], bv0[TNW], af1[TMW], bv1[TNW];
+  constexpr int NM = 4 * TMW * TNW;                 // MFMAs of a chunk, in sweeps over the accumulators (x, y, z, w)
+  constexpr int GAP = NM >= 32 ? 2 : 1;             // MFMAs between two steps
+#define SQ_BIG_MF(FA, FB, k)                                                                                          \
+  {                                                                                                                  \
+    const int comp = (k) / (TMW * TNW), i_ = ((k) % (TMW * TNW)) / TNW, t_ = (k) % TNW;                               \
+    acc[i_][t_] = __builtin_amdgcn_mfma_f32_16x16x4f32(FB[t_][comp], FA[i_][comp], acc[i_][t_], 0, 0, 0);             \
+  }
+  // one chunk: (my loads of chunk c + 1 have landed, my reads of chunk c are in registers) -> barrier (everybody's) -> MFMAs of
+  // chunk c with, between them, the reads of chunk c + 1 and the loads of chunk c + NST (into the stage chunk c was read from)
+  // (k is a constant in every copy of the unrolled loop: the step tests fold)
+#define SQ_BIG_CHUNK(FA, FB, GA, GB)                                                                                  \
+  {                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    if (c + NST <= kc_total) {                                                                                        \
+      if (ld_max) __builtin_amdgcn_s_waitcnt(SQ_VMCNT_IMM(NL_MAX * (NST - 2)));                                       \
+      else __builtin_amdgcn_s_waitcnt(SQ_VMCNT_IMM(NL_MIN * (NST - 2)));                                              \
+    } else __builtin_amdgcn_s_waitcnt(SQ_VMCNT_IMM(0));   /* the last NST - 1 chunks: everything */                   \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    const int nb = bc + 1 == NST ? 0 : bc + 1;                                                                        \
+    const bool rd = c + 1 < kc_total, ld = c + NST < kc_total;                                                        \
+    const char* rst = lds + nb * STAGE;                                                                               \
+    _Pragma("unroll") for (int k = 0; k < NM; ++k) {                                                                  \
+      SQ_BIG_MF(FA, FB, k)                                                                                            \
+      const int step = (k % GAP == GAP - 1) ? k / GAP : -1;                                                           \
+      if (step >= 0 && step < TMW) { if (rd) GA[step] = *reinterpret_cast<const f32x4*>(rst + a_off + step * 1024); }  \
+      else if (step >= TMW && step < TMW + TNW) { if (rd) GB[step - TMW] = *reinterpret_cast<const f32x4*>(rst + b_off + (step - TMW) * 1024); } \
+      else if (step == TMW + TNW) { if (ld) SQ_BIG_SEG(c + NST, bc) }                                                 \
+      else if (step > TMW + TNW && step <= TMW + TNW + NPA) { if (ld) { SQ_BIG_LOAD_A(step - TMW - TNW - 1) } }       \
+      else if (step > TMW + TNW + NPA && step <= TMW + TNW + NPA + NPB) { if (ld) { SQ_BIG_LOAD_B(step - TMW - TNW - NPA - 1) } } \
+      if (step >= 0 && step <= TMW + TNW + NPA + NPB) __builtin_amdgcn_sched_barrier(0);                              \
+    }                                                                                                                 \
+    bc = nb;                                                                                                          \
+  }
+  static_assert((NM + GAP - 1) / GAP > TMW + TNW + NPA + NPB, "not enough MFMAs of a chunk to place the steps between");
+  if (kc_total <= NST) __builtin_amdgcn_s_waitcnt(SQ_VMCNT_IMM(0));   // chunk 0 (all of them if there are that few)
+  else if (ld_max) __builtin_amdgcn_s_waitcnt(SQ_VMCNT_IMM(NL_MAX * (NST - 1)));
+  else __builtin_amdgcn_s_waitcnt(SQ_VMCNT_IMM(NL_MIN * (NST - 1)));
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const char* st = lds;
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) af0[i] = *reinterpret_cast<const f32x4*>(st + a_off + i * 1024);
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) bv0[t] = *reinterpret_cast<const f32x4*>(st + b_off + t * 1024);
+  }
+  int bc = 0;   // stage of chunk c
 #pragma unroll 1
   for (int c = 0; c < kc_total; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < kc_total) SQ_BIG_STAGE(c + 1, buf ^ 1)
-    const char* st = lds + buf * STAGE;
-    f32x4 af[TMW], bv[TNW];
-#pragma unroll
-    for (int i = 0; i < TMW; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + a_off + i * 1024);
-#pragma unroll
-    for (int t = 0; t < TNW; ++t) bv[t] = *reinterpret_cast<const f32x4*>(st + b_off + t * 1024);
-#pragma unroll
-    for (int i = 0; i < TMW; ++i)
-#pragma unroll
-      for (int t = 0; t < TNW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].x, af[i].x, acc[i][t], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < TMW; ++i)
-#pragma unroll
-      for (int t = 0; t < TNW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].y, af[i].y, acc[i][t], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < TMW; ++i)
-#pragma unroll
-      for (int t = 0; t < TNW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].z, af[i].z, acc[i][t], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < TMW; ++i)
-#pragma unroll
-      for (int t = 0; t < TNW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].w, af[i].w, acc[i][t], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise hoists the barrier into the middle of the chunk's MFMAs: half the time for the loads)
-    __syncthreads();   // retires the loads of chunk c + 1 (vmcnt(0) precedes the barrier) and the reads of chunk c
+    SQ_BIG_CHUNK(af0, bv0, af1, bv1)
+    if (++c >= kc_total) break;
+    SQ_BIG_CHUNK(af1, bv1, af0, bv0)
   }
+#undef SQ_BIG_CHUNK
+#undef SQ_BIG_MF
 #undef SQ_BIG_STAGE
+#undef SQ_BIG_SEG
+#undef SQ_BIG_LOAD_A
+#undef SQ_BIG_LOAD_B
+  __syncthreads();   // the last chunk's fragments have been read by every wave: the stages become the epilogue's parking space
   SQ_BIG_STAMP(3)
+  SQ_BIG_CYC1()
   // Epilogue.  The MFMAs above take the WEIGHT fragment as their first operand and the activation fragment as the second, i.e.
   // they compute the transposed tile: lane (kq, l15) of accumulator (i, t) holds C[row 16 i + l15][columns 16 t + 4 kq .. + 3]
   // -- four CONSECUTIVE COLUMNS of one row (the products commute and k is summed in the same order: bit-identical sums).  So
@@ -789,12 +868,12 @@ extern "C" int sqair_debug_big_phases(unsigned long long* out) {
 // number of ROUNDS of workgroups decides more than the efficiency of a tile: 270 tiles (cfg-4's 1920 x 362 x 1152) leave 14
 // CUs with two tiles while 242 wait (33.2 us; 240 tiles of 96 x 96: 24.5), 80 tiles (2560 x 256 x 256) leave two thirds of the
 // chip idle (16.9 us; 160 tiles of 64 x 64: 11.1).  Every shape accumulates a given output in the same order (bit-identical).
-// The choice minimises a cost model fitted to tools/big_shapes.sh (14 layer shapes x 9 tile shapes, back to back, MI355X; rms
-// 0.4 us on the single-round launches): one round of a wave tile of u = TMW TNW MFMA tiles over kc K chunks takes
-//   T1 = 1.39 + 0.33 kc + 0.0677 kc u + 0.101 u (+ 0.162 u with a non-linear activation)   [us]
-// and r = ceil(tiles / 256) rounds take T1 (1 + (0.338 + 0.0357 u)(r - 1)) -- a second workgroup on a CU hides part of the
-// first one's stalls, less so the larger the tile.  With the four shapes kept, the model's picks sum to 368 us over the 14
-// shapes against 355 for the best of all nine shapes per layer and 408 for 128 x 64 everywhere.
+// The choice minimises a cost model fitted to tools/big_shapes.sh (14 layer shapes x 8 tile shapes, back to back, MI355X; rms
+// 0.5 us on the single-round launches): one round of a wave tile of u = TMW TNW MFMA tiles over kc K chunks takes
+//   T1 = 1.92 + 0.297 kc + 0.0736 kc u - 0.069 u (+ 0.175 u with a non-linear activation)   [us]
+// and r = ceil(tiles / 256) rounds take T1 (1 + (0.335 + 0.0342 u)(r - 1)) -- a second workgroup on a CU hides part of the
+// first one's stalls, less so the larger the tile.  With the four shapes kept, the model's picks sum to 361 us over the 14
+// shapes against 353 for the best of all shapes per layer and 388 for 128 x 64 everywhere.
 static int pick_big_shape(int M, int n_tiles, int kc, bool nonlinear) {
   static const int cand[4][2] = {{4, 2}, {3, 3}, {3, 2}, {2, 2}};
   int best = 42;
@@ -802,8 +881,8 @@ static int pick_big_shape(int M, int n_tiles, int kc, bool nonlinear) {
   for (int i = 0; i < 4; ++i) {
     const int tm = cand[i][0], tn = cand[i][1], u = tm * tn;
     const int tiles = ((M + 32 * tm - 1) / (32 * tm)) * ((n_tiles + 2 * tn - 1) / (2 * tn));
-    const float t1 = 1.39f + 0.33f * kc + 0.0677f * kc * u + 0.101f * u + (nonlinear ? 0.162f * u : 0.0f);
-    const float t = t1 * (1.0f + (0.338f + 0.0357f * u) * (float)((tiles + 255) / 256 - 1));
+    const float t1 = 1.92f + 0.297f * kc + 0.0736f * kc * u - 0.069f * u + (nonlinear ? 0.175f * u : 0.0f);
+    const float t = t1 * (1.0f + (0.335f + 0.0342f * u) * (float)((tiles + 255) / 256 - 1));
     if (t < best_t) { best_t = t; best = 10 * tm + tn; }
   }
   return best;

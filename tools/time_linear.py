@@ -48,6 +48,9 @@ def main():
                 t = [ph[i] - ph[0] for i in range(5)]
                 print("   k_linear_big phases of one workgroup [us]: setup %.2f | first loads %.2f | K loop %.2f | epilogue %.2f (park tile 0 at +%.2f, tile 1 at +%.2f)" % (
                     t[1] * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (ph[5] - ph[3]) * 0.01, (ph[6] - ph[3]) * 0.01))
+                kc = (K + 15) // 16
+                print("   K loop: %d shader cycles = %.0f per chunk (%d chunks, first-load wait included); clock %.2f GHz" % (
+                    ph[7], ph[7] / kc, kc, ph[7] / max(1, t[3] - t[2]) * 0.1))
     lib.sqair_destroy(h)
 
 
