@@ -318,6 +318,14 @@ def test_full_backward_single_frame_discovery_only():
     _check_report(report)
 
 
+@pytest.mark.parametrize("K,N,T,B", [(2, 1, 2, 1), (2, 2, 2, 9), (3, 1, 3, 6)])
+def test_full_backward_degenerate_sizes(K, N, T, B):
+    """One slot, one sequence, and row counts that leave a last 16-row tile of 2 rows (18 rows): every parameter's gradient
+    against autograd through the fp64 oracle."""
+    report, _, _ = _full_backward_case(K, N, T, B, (50, 50), seed=7)
+    _check_report(report)
+
+
 @pytest.mark.parametrize("K,N,T,B,hw", [(3, 3, 3, 3, (50, 50)), (5, 4, 4, 2, (50, 50))])
 def test_full_backward_matches_autograd(K, N, T, B, hw):
     """Gradient of the VIMCO target w.r.t. EVERY parameter through the whole recurrence (propagation + discovery +
