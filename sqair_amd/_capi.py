@@ -127,7 +127,7 @@ TIMELINE_LIB_PATH = os.path.join(_HERE, "libsqair_hip_timeline.so")
 WIDE_LIB_PATH = os.path.join(_HERE, "libsqair_hip_wide.so")
 # what the product library is laid out for (csrc/sqair_glue.h: SQ_MAXN, SQ_MAX_NWHAT, SQ_MAX_NHIDDEN)
 PRODUCT_LIMITS = dict(n_what=50, n_steps_per_image=8, n_hidden=256)
-WIDE_LIMITS = dict(n_what=128, n_steps_per_image=16, n_hidden=512)
+WIDE_LIMITS = dict(n_what=128, n_steps_per_image=14, n_hidden=512)   # (15, 16 slots: the log-probability adjoint's LDS staging does not fit the wide record)
 
 
 def lib_path_for(n_what, n_steps_per_image, n_hidden):

@@ -72,7 +72,7 @@ class SqairCore(object):
         rc = self.lib.sqair_create(C.byref(self.cfg), C.byref(self.handle))
         if rc != 0:
             raise ValueError("sqair_create rejected the configuration (rc={}): limits n_what <= {n_what}, n_steps_per_image <= "
-                             "{n_steps_per_image} (<= 14 with the wide record), n_units <= 16, k_particles <= 256".format(
+                             "{n_steps_per_image}, n_units <= 16, k_particles <= 256".format(
                                  rc, **_capi.WIDE_LIMITS))
         # documented run-time options of the library (include/sqair_hip.h: sqair_set_option), set before any workspace is sized
         self.options = dict(options or {})

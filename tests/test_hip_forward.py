@@ -112,6 +112,14 @@ def test_degenerate_sizes_vs_live_oracle(K, N, T, B):
     _live_oracle_case(F, hw=(32, 40), T=T, B=B)
 
 
+@pytest.mark.parametrize("K,N,T,B", [(256, 2, 2, 1), (2, 14, 2, 1), (64, 8, 2, 1)])
+def test_maximum_sizes_vs_live_oracle(K, N, T, B):
+    """The largest particle and slot counts `sqair_create` accepts (256 particles; 14 slots, on the wide build; 8 slots x 64
+    particles on the product build) against the live oracle, every output."""
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    _live_oracle_case(F, hw=(32, 40), T=T, B=B)
+
+
 def test_empty_frames_vs_live_oracle():
     """Sequences without any object (all-zero frames, presence labels 0): nothing to propagate, discovery must come up empty or
     agree with the oracle on whatever it proposes; every output against the live oracle."""
