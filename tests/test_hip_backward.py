@@ -259,7 +259,7 @@ def _full_backward_case(K, N, T, B, hw, seed, flags=None, lib_path=None):
     from sqair_amd.model import Model, SqairCore
     from tests.hip_util import draw_noise, params32
     F = make_flags(k_particles=K, n_steps_per_image=N, **(flags or {}))
-    d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=min(28, hw[0] // 2), seed=seed)
+    d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=max(2, min(28, min(hw) // 2)), seed=seed)
     obs = to_float(d["imgs"])
     P = params32(F, hw, 4, 0.05, obs.mean((0, 1)))
     core = SqairCore(F, hw, lib_path=lib_path)
@@ -583,6 +583,33 @@ def test_full_backward_other_shapes(K, N, T, B, hw):
     lane forward, band adjoint)."""
     report, _, _ = _full_backward_case(K, N, T, B, hw, seed=21)
     _check_report(report)
+
+
+@pytest.mark.parametrize("hw", [(12, 14), (3, 250), (257, 5), (150, 256)])
+def test_full_backward_extreme_frame_shapes(hw):
+    """Frames smaller than the glimpse, degenerate aspect ratios, and the largest frame training takes (38 400 pixels: the crop
+    adjoint stages the frame in LDS): every parameter's gradient against autograd through the fp64 oracle."""
+    report, _, _ = _full_backward_case(2, 2, 2, 2, hw, seed=21)
+    _check_report(report)
+
+
+def test_training_refuses_frames_it_cannot_stage():
+    """One pixel row beyond 38 400 pixels: inference runs, the training entry points say why they do not."""
+    from sqair_amd.model import Model, SqairCore
+    from tests.hip_util import draw_noise, params32
+    from sqair_amd.data import make_sequences, to_float
+    hw, T, B, K, N = (151, 256), 2, 1, 2, 2
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    d = make_sequences(B, T=T, canvas=hw, seed=1)
+    obs = to_float(d["imgs"])
+    core = SqairCore(F, hw)
+    core.set_params(params32(F, hw, 0, 0.05, obs.mean((0, 1))))
+    m = Model(obs, None, core, K, presence=d["nums"])
+    m.run(noise=draw_noise(np.random.default_rng(0), T, B * K, N, 55))
+    assert np.isfinite(float(m.elbo_iwae))
+    with pytest.raises(Exception, match="38 ?400|pixels|frame"):
+        with core.on_stream():
+            core.forward(train=True)
 
 
 def test_full_size_gradient_is_the_mean_of_shard_gradients():

@@ -120,6 +120,14 @@ def test_maximum_sizes_vs_live_oracle(K, N, T, B):
     _live_oracle_case(F, hw=(32, 40), T=T, B=B)
 
 
+@pytest.mark.parametrize("hw", [(12, 14), (200, 300), (3, 250), (257, 5)])
+def test_extreme_frame_shapes_vs_live_oracle(hw):
+    """Frames smaller than the 20 x 20 glimpse, much larger than the LDS-staged crop takes (60 000 pixels), and degenerate
+    aspect ratios (row-wave canvas kernels: 250 columns; 5 columns) -- inference takes any H x W -- against the live oracle."""
+    F = make_flags(k_particles=2, n_steps_per_image=3)
+    _live_oracle_case(F, hw=hw, T=2, B=2)
+
+
 def test_empty_frames_vs_live_oracle():
     """Sequences without any object (all-zero frames, presence labels 0): nothing to propagate, discovery must come up empty or
     agree with the oracle on whatever it proposes; every output against the live oracle."""
