@@ -6,9 +6,12 @@ lives under tests/ because it calls the oracle).  On the GPU box:
 Every case draws sizes (particles, slots, frames, sequences, frame shape, n_what, n_units), cells, priors and the boolean model
 flags at random inside the library's limits, a decision-stable noise draw on the ORACLE's margin (tests/hip_util.stable_noise),
 and compares presence / ids exactly, every output at 5e-4 scaled, the bounds at 1e-4 relative; with --grad also every
-parameter's gradient against autograd through the fp64 oracle (tests/test_hip_backward._full_backward_case's bar).  Round 5: 100 forward
-cases (seeds 1, 3) and 30 gradient cases (seed 2) without a failure.  Prints one line
-per case and the failures with their configuration; exit code = number of failures."""
+parameter's gradient against autograd through the fp64 oracle (tests/test_hip_backward._full_backward_case's bar).  With --chain
+the sizes are drawn inside what the in-launch slot chain takes (VanillaRNN slot cell, GRU temporal cell, n_units 8) and the
+pass with `slot_chain` on must reproduce the launches bit for bit, eager and as a graph replay.  Round 5: 100 forward cases
+(seeds 1, 3) without a failure; 30 gradient cases (seed 2) with one beyond the tight bar, on parameters whose gradient is 3e-4 of
+the largest one, by exactly what fp32 autograd through the oracle misses the fp64 one (run_case's second bar).  Prints one
+line per case and the failures with their configuration; exit code = number of failures."""
 import os
 import sys
 import traceback
@@ -38,6 +41,18 @@ def draw_case(rng):
                  rec_where_prior=bool(rng.integers(2)), masked_glimpse=bool(rng.integers(2)),
                  glimpse_size=int(rng.choice([20, 20, 12, 8])))
     return flags, hw, T, B
+
+
+def run_chain_case(flags, hw, T, B, seed):
+    from tests.test_slot_chain import _inputs, _run
+    K, N = flags["k_particles"], flags["n_steps_per_image"]
+    extra = {k: v for k, v in flags.items() if k not in ("k_particles", "n_steps_per_image")}
+    F, d, obs, P, noise = _inputs(B, K, N, T, hw, seed=seed, **extra)
+    _, _, ref = _run(F, hw, d, obs, P, noise, K, chain=False, use_graph=False)
+    for use_graph in (False, True):
+        _, _, got = _run(F, hw, d, obs, P, noise, K, chain=True, use_graph=use_graph)   # (debug on: every chain launch's status is checked)
+        for k, v in ref.items():
+            assert np.array_equal(v, got[k], equal_nan=True), (k, use_graph)
 
 
 def run_case(flags, hw, T, B, seed, grad):
@@ -72,15 +87,23 @@ def run_case(flags, hw, T, B, seed, grad):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    grad = "--grad" in sys.argv
+    grad, chain = "--grad" in sys.argv, "--chain" in sys.argv
     n, seed = (int(args[0]) if args else 30), (int(args[1]) if len(args) > 1 else 0)
     rng = np.random.default_rng(seed)
     failures = []
     for i in range(n):
         flags, hw, T, B = draw_case(rng)
+        if chain:
+            flags.update(transition="VanillaRNN", time_transition="GRU", n_units=8, n_what=min(flags["n_what"], 50))
+            B = int(rng.integers(1, 65))
+            while B * flags["k_particles"] > 320:
+                B = max(1, B // 2)
         tag = "case {:3d}: hw {} T {} B {} {}".format(i, hw, T, B, flags)
         try:
-            run_case(flags, hw, T, B, seed * 1000 + i, grad)
+            if chain:
+                run_chain_case(flags, hw, T, B, seed * 1000 + i)
+            else:
+                run_case(flags, hw, T, B, seed * 1000 + i, grad)
             print("ok   " + tag, flush=True)
         except AssertionError as e:
             if "no decision-stable noise draw" in str(e):
