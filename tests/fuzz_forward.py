@@ -1,14 +1,17 @@
 """Randomised configuration sweep of the forward pass against the live oracle (a checker script, not collected by pytest: it
 lives under tests/ because it calls the oracle).  On the GPU box:
 
-    python tests/fuzz_forward.py [n_cases] [seed] [--grad]
+    python tests/fuzz_forward.py [n_cases] [seed] [--grad | --chain | --gen]
 
 Every case draws sizes (particles, slots, frames, sequences, frame shape, n_what, n_units), cells, priors and the boolean model
 flags at random inside the library's limits, a decision-stable noise draw on the ORACLE's margin (tests/hip_util.stable_noise),
 and compares presence / ids exactly, every output at 5e-4 scaled, the bounds at 1e-4 relative; with --grad also every
 parameter's gradient against autograd through the fp64 oracle (tests/test_hip_backward._full_backward_case's bar).  With --chain
 the sizes are drawn inside what the in-launch slot chain takes (VanillaRNN slot cell, GRU temporal cell, n_units 8) and the
-pass with `slot_chain` on must reproduce the launches bit for bit, eager and as a graph replay.  Round 5: 100 forward cases
+pass with `slot_chain` on must reproduce the launches bit for bit, eager and as a graph replay.  With --gen the generation
+modes (`sample_from_prior`, frames after a random `generate_after` drawn from the priors: seq.py:198-200,
+sqair_modules.py:157-170, 294-302) with a second noise tensor, the draw chosen on the oracle's posterior AND prior margins.
+Round 5: 100 forward cases
 (seeds 1, 3) without a failure; 30 gradient cases (seed 2) with one beyond the tight bar, on parameters whose gradient is 3e-4 of
 the largest one, by exactly what fp32 autograd through the oracle misses the fp64 one (run_case's second bar).  Prints one
 line per case and the failures with their configuration; exit code = number of failures."""
@@ -55,6 +58,47 @@ def run_chain_case(flags, hw, T, B, seed):
             assert np.array_equal(v, got[k], equal_nan=True), (k, use_graph)
 
 
+def run_gen_case(flags, hw, T, B, seed, rng):
+    import torch
+    from oracle import sqair_oracle as O
+    from sqair_amd.model import Model, SqairCore
+    from tests.hip_util import MARGIN, MAX_DRAWS, draw_noise, presence_margins, prior_presence_margins
+    T = max(T, 2)
+    flags = dict(flags, sample_from_prior=True, generate_after=int(rng.integers(-1, T)))
+    if flags["prop_prior_type"] == "rw":
+        flags["rec_where_prior"] = False
+    F = make_flags(**flags)
+    K, N, nzw = int(F.k_particles), int(F.n_steps_per_image), 4 + int(F.n_what) + 1
+    d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=max(2, min(20, min(hw) // 2)), seed=seed)
+    obs = to_float(d["imgs"])
+    P = params32(F, hw, seed, 0.05, obs.mean((0, 1)))
+    orc = O.SqairOracle(P, O.make_cfg(F, hw), torch.float64)
+    for attempt in range(MAX_DRAWS):
+        r2 = np.random.default_rng(seed * 7 + attempt)
+        noise, gen_noise = draw_noise(r2, T, B * K, N, nzw), draw_noise(r2, T, B * K, N, nzw)
+        with torch.no_grad():
+            ref = orc.model(obs, noise, num=d["nums"], gen_noise=gen_noise)
+        mg = min(float(presence_margins(ref.outputs, noise).min()), float(prior_presence_margins(ref.outputs, gen_noise).min()))
+        if mg >= MARGIN:
+            break
+    else:
+        raise AssertionError("no decision-stable noise draw")
+    core = SqairCore(F, hw)
+    core.set_params(P)
+    m = Model(obs, None, core, K, presence=d["nums"])
+    m.run(noise=noise, gen_noise=gen_noise)
+    for k in ("prop_pres", "disc_pres", "presence", "obj_id"):
+        assert np.array_equal(getattr(m, k).cpu().numpy(), getattr(ref, k).numpy().astype(np.float32)), (k, flags["generate_after"])
+    for k, v in core.out.items():
+        name = "_" + k if k.startswith("final_") else k
+        if name not in ref.outputs:
+            continue
+        want = ref.outputs[name].numpy()
+        err = np.abs(v.cpu().numpy().reshape(want.shape) - want).max() / max(np.abs(want).max(), 1.0)
+        assert err <= 5e-4, (k, err, flags["generate_after"])
+    assert abs(float(m.elbo_iwae) - float(ref.elbo_iwae)) <= 1e-4 * max(1.0, abs(float(ref.elbo_iwae)))
+
+
 def run_case(flags, hw, T, B, seed, grad):
     F = make_flags(**flags)
     K, N = int(F.k_particles), int(F.n_steps_per_image)
@@ -87,7 +131,7 @@ def run_case(flags, hw, T, B, seed, grad):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    grad, chain = "--grad" in sys.argv, "--chain" in sys.argv
+    grad, chain, gen = "--grad" in sys.argv, "--chain" in sys.argv, "--gen" in sys.argv
     n, seed = (int(args[0]) if args else 30), (int(args[1]) if len(args) > 1 else 0)
     rng = np.random.default_rng(seed)
     failures = []
@@ -102,6 +146,8 @@ def main():
         try:
             if chain:
                 run_chain_case(flags, hw, T, B, seed * 1000 + i)
+            elif gen:
+                run_gen_case(flags, hw, T, B, seed * 1000 + i, rng)
             else:
                 run_case(flags, hw, T, B, seed * 1000 + i, grad)
             print("ok   " + tag, flush=True)
