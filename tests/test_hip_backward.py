@@ -633,16 +633,19 @@ def test_training_refuses_frames_it_cannot_stage():
             core.forward(train=True)
 
 
-def test_full_size_gradient_is_the_mean_of_shard_gradients():
+@pytest.mark.parametrize("batch", [0, 128])
+def test_full_size_gradient_is_the_mean_of_shard_gradients(batch):
     """BASELINE configs[1] / configs[2] shape (T10, 50x50, B32, K5, N4): the gradient of the full batch equals the mean
     of the gradients of its two 16-sequence shards run as separate problems on the same noise rows — the identity the
     data-parallel training step relies on (all-reduce(sum) / world == reduce_mean over the global batch,
-    sqair/model.py:91-93, sqair/targets.py:75)."""
+    sqair/model.py:91-93, sqair/targets.py:75).  With 128 sequences the full batch and its 64-sequence shards run on DIFFERENT
+    kernel variants (640 against 320 particle rows: slot tail as its own launch / fused with two column tiles per workgroup;
+    25 600 against 12 800 decoder rows: other tiles of the LDS-tiled kernel): the identity must hold across them."""
     from sqair_amd.data import config_inputs
     from sqair_amd.dist import shard_batch, shard_noise
     from sqair_amd.model import Model, SqairCore
     from tests.hip_util import draw_noise, params32
-    ov, obs, _, _ = config_inputs(2)
+    ov, obs, _, _ = config_inputs(2, B=batch) if batch else config_inputs(2)
     F = make_flags(**ov)
     K, N = int(F.k_particles), int(F.n_steps_per_image)
     hw = obs.shape[2:4]
