@@ -24,10 +24,11 @@ over = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a)
 n_train = int(over.pop("n_train", 2048))   # n_train=16384: a training set the model cannot memorise
 hw_over = over.pop("hw", None)              # hw=128x128: BASELINE configs[4]'s frames (the row-wave canvas kernels)
 slot_chain = int(over.pop("slot_chain", 0))  # slot_chain=1: the library's in-launch slot chain (sqair_set_option) for every pass
+batch_over = int(over.pop("batch", 0))       # batch=128: sequences per step (the large-row dense kernels; default 32)
 sys.argv = [a for a in sys.argv if "=" not in a]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 lr = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-5
-T, B, K, N, hw = 10, 32, 5, 4, (50, 50)
+T, B, K, N, hw = 10, batch_over or 32, 5, 4, (50, 50)
 if hw_over:
     hw = tuple(int(v) for v in hw_over.split("x"))
 train_itr = int(sys.argv[3]) if len(sys.argv) > 3 else steps   # the piecewise-constant schedule is relative to train_itr
