@@ -283,6 +283,11 @@ int sqair_clear_workspace(SqairHandle* h, void* workspace, int64_t workspace_byt
  *                 process has to itself: the launch needs its 256 workgroups co-resident (another kernel occupying the CUs
  *                 makes it give up after ~20 ms with a status instead of results: sqair_chain_status).  Faster than the
  *                 launches up to ~128 particle rows (one 16-row tile per XCD), about equal at 160.
+ *                 A launch reads a table of its ops that holds the operand ADDRESSES (frames, noise, parameters, workspace);
+ *                 tables are cached by content in device arenas of the handle.  Passes on the same buffers reuse them; passes
+ *                 on fresh buffers make new ones, and a full arena is recycled (after a stream synchronise) unless a captured
+ *                 graph refers to it -- memory grows with the number of captured graphs, not with the number of passes.
+ *   "slot_chain_arena_kb" (default 32768): size of one such arena; set before the first pass with the chain on.
  * Returns -2 for an unknown name. */
 int sqair_set_option(SqairHandle* h, const char* name, int value);
 /* Status of the slot chain's launches of the last pass on `workspace` (synchronises `stream`): 0 = all completed (or the chain is

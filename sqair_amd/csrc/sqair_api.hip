@@ -1464,7 +1464,11 @@ extern "C" int sqair_set_option(SqairHandle* h, const char* name, int value) {
     h->opt_slot_chain_mode = value;   // (2: the chain's workspace layout with one launch per op -- a debugging aid)
     return 0;
   }
-  sq_set_error(h, "sqair_set_option: unknown option '" + n + "' (known: tail_fusion, slot_chain, vi_target)");
+  if (n == "slot_chain_arena_kb") {   // size of one device arena of chain tables (default 32768): before the first chain launch
+    if (sq_chain_set_arena_kb(h, value) != 0) { sq_set_error(h, "sqair_set_option: slot_chain_arena_kb is 64 .. 1048576, set before the first pass"); return -2; }
+    return 0;
+  }
+  sq_set_error(h, "sqair_set_option: unknown option '" + n + "' (known: tail_fusion, slot_chain, slot_chain_arena_kb, vi_target)");
   return -2;
 }
 

@@ -87,3 +87,4 @@ int sq_chain_add_tail(SqairHandle* h, const TailArgs& a);
 int sq_chain_flush(SqairHandle* h, unsigned* ctl, int launch_id, hipStream_t s);
 int sq_chain_poison(const ChainPoisonList& pl, unsigned* ctl_all, int ctl_words, hipStream_t s);
 void sq_chain_destroy(SqairHandle* h);
+int sq_chain_set_arena_kb(SqairHandle* h, int kb);

@@ -6,6 +6,8 @@
 #include "sqair_internal.h"
 
 #include <cstring>
+#include <list>
+#include <vector>
 
 #ifndef SQAIR_WIDE
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -867,28 +869,43 @@ int sq_chain_poison(const ChainPoisonList& pl, unsigned* ctl_all, int ctl_words,
 // ------------------------------------------------------------------------------------------------
 // host recorder + table cache
 // ------------------------------------------------------------------------------------------------
-struct ChainCacheEntry { std::vector<char> host; void* dev; };
+// A cached table is keyed by its CONTENT, which includes the addresses of the caller's frame / noise / parameter buffers: a
+// caller that streams batches through fresh buffers makes new tables every pass.  Tables live in device arenas of the handle;
+// a table a stream capture has referenced is pinned (a graph holds its address), so is its arena.  When the current arena is
+// full the stream is synchronised and the arena recycled if nothing in it is pinned, else a new one is opened -- growth is
+// bounded by the number of captured graphs, not by the number of passes.
+struct ChainCacheEntry { std::vector<char> host; void* dev; int arena; bool pinned; };
 constexpr size_t CH_ARENA_BYTES = 32u << 20;
+constexpr int CH_MAX_ARENAS = 64;
+struct ChainArena { void* mem = nullptr; size_t used = 0; bool pinned = false; };
 struct ChainState {
   bool active = false;
   bool failed = false;
   const char* ws_base = nullptr;
   int64_t ws_bytes = 0;
   ChainTable tab;
-  std::vector<ChainCacheEntry> cache;
-  void* arena = nullptr;
-  size_t arena_used = 0;
+  std::list<ChainCacheEntry> cache;   // (a list: the host copies are the sources of asynchronous uploads and must not move)
+  std::vector<ChainArena> arenas;
+  size_t arena_bytes = CH_ARENA_BYTES;
+  int cur_arena = -1;
   int grid = 0, occupancy = 0;
 };
 static ChainState* cs_of(SqairHandle* h) {
   if (!h->chain) h->chain = new ChainState();
   return (ChainState*)h->chain;
 }
+int sq_chain_set_arena_kb(SqairHandle* h, int kb) {   // before the first chain launch of the handle only
+  ChainState* c = cs_of(h);
+  if (kb < 64 || kb > (1 << 20) || !c->arenas.empty()) return -2;
+  c->arena_bytes = (size_t)kb << 10;
+  return 0;
+}
 bool sq_chain_active(const SqairHandle* h) { return h->chain && ((const ChainState*)h->chain)->active; }
 void sq_chain_destroy(SqairHandle* h) {
   if (!h->chain) return;
   ChainState* c = (ChainState*)h->chain;
-  if (c->arena) (void)hipFree(c->arena);
+  for (auto& a : c->arenas)
+    if (a.mem) (void)hipFree(a.mem);
   delete c;
   h->chain = nullptr;
 }
@@ -1000,35 +1017,54 @@ int sq_chain_flush(SqairHandle* h, unsigned* ctl, int launch_id, hipStream_t s) 
   }
   const size_t bytes = (offsetof(ChainTable, ops) + (size_t)t.n_ops * sizeof(ChainOp) + 15) / 16 * 16;
   void* dev = nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  SQ_CHECK_HIP(hipStreamIsCapturing(s, &cap));
   for (auto& e : c->cache)
-    if (e.host.size() == bytes && memcmp(e.host.data(), &t, bytes) == 0) { dev = e.dev; break; }
+    if (e.host.size() == bytes && memcmp(e.host.data(), &t, bytes) == 0) {
+      dev = e.dev;
+      if (cap != hipStreamCaptureStatusNone) { e.pinned = true; c->arenas[e.arena].pinned = true; }   // a graph now holds this address
+      break;
+    }
   if (!dev) {
-    c->cache.reserve(4096);   // (entries' host copies are the sources of asynchronous uploads: they must not move)
-    if (c->cache.size() >= 4096) { sq_set_error(h, "slot chain: table cache full"); return -3; }
     // Tables are uploaded outside stream captures only (an allocation + copy issued while a capture is open on this thread
     // produced a graph that read a garbage table): the capturing entry points run one eager pass first, which leaves every
     // table of the pass resident here.
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    SQ_CHECK_HIP(hipStreamIsCapturing(s, &cap));
     if (cap != hipStreamCaptureStatusNone) {
       sq_set_error(h, "slot chain: a table of this pass is not resident -- run the same pass once eagerly before capturing it");
       return -3;
     }
-    // (a plain hipMemcpy from pageable memory returns once the bytes are in the staging buffer, not once they are on the device:
-    // the chain launch behind it read a half-written table.  Own stream + synchronize.)
-    // The table goes into a device arena of the handle (allocated once), IN the stream of the launch that reads it.
-    if (!c->arena) {
-      SQ_CHECK_HIP(hipMalloc(&c->arena, CH_ARENA_BYTES));
-      c->arena_used = 0;
+    if (bytes > c->arena_bytes) { sq_set_error(h, "slot chain: table larger than an arena"); return -3; }
+    if (c->cur_arena < 0 || c->arenas[c->cur_arena].used + bytes > c->arena_bytes) {
+      // the current arena is full: every launch that reads its tables is in stream order behind us -- wait for them, then
+      // recycle the first arena no graph refers to (its entries leave the cache), else open another one
+      if (c->cur_arena >= 0) SQ_CHECK_HIP(hipStreamSynchronize(s));
+      int pick = -1;
+      for (int i = 0; i < (int)c->arenas.size() && pick < 0; ++i)
+        if (!c->arenas[i].pinned) pick = i;
+      if (pick >= 0) {
+        c->cache.remove_if([pick](const ChainCacheEntry& e) { return e.arena == pick; });
+        c->arenas[pick].used = 0;
+      } else {
+        if ((int)c->arenas.size() >= CH_MAX_ARENAS) { sq_set_error(h, "slot chain: table arenas exhausted (too many captured graphs on this handle)"); return -3; }
+        ChainArena a;
+        SQ_CHECK_HIP(hipMalloc(&a.mem, c->arena_bytes));
+        c->arenas.push_back(a);
+        pick = (int)c->arenas.size() - 1;
+      }
+      c->cur_arena = pick;
     }
-    if (c->arena_used + bytes > CH_ARENA_BYTES) { sq_set_error(h, "slot chain: table arena full"); return -3; }
-    dev = (char*)c->arena + c->arena_used;
-    c->arena_used += (bytes + 255) / 256 * 256;
-    ChainCacheEntry ce;
+    // The table goes IN the stream of the launch that reads it (a plain hipMemcpy from pageable memory returns once the bytes
+    // are in the staging buffer, not once they are on the device: the chain launch behind it read a half-written table).
+    ChainArena& ar = c->arenas[c->cur_arena];
+    dev = (char*)ar.mem + ar.used;
+    ar.used += (bytes + 255) / 256 * 256;
+    c->cache.emplace_back();
+    ChainCacheEntry& ce = c->cache.back();
     ce.host.assign((const char*)&t, (const char*)&t + bytes);
     ce.dev = dev;
-    c->cache.push_back(std::move(ce));
-    SQ_CHECK_HIP(hipMemcpyAsync(dev, c->cache.back().host.data(), bytes, hipMemcpyHostToDevice, s));
+    ce.arena = c->cur_arena;
+    ce.pinned = false;
+    SQ_CHECK_HIP(hipMemcpyAsync(dev, ce.host.data(), bytes, hipMemcpyHostToDevice, s));
   }
   const int lds = t.lds_scratch_floats * 4 + (int)bytes;
   if (lds > 64 * 1024) {

@@ -94,3 +94,41 @@ def test_chain_keeps_out_of_configurations_it_does_not_serve():
     plain.set_params(P)
     Model(obs, None, plain, K, presence=d["nums"]).run(noise=noise, use_graph=True)
     assert core.lib.sqair_graph_nodes(core.handle) == plain.lib.sqair_graph_nodes(plain.handle)
+
+
+def test_chain_tables_survive_fresh_operand_buffers_and_a_capture():
+    """A chain launch reads a table holding operand addresses; tables are cached in device arenas of the handle.  A caller that
+    streams batches through FRESH frame / noise buffers makes new tables every pass: with a small arena the passes below fill it
+    many times over (recycled after a synchronise), a capture in between pins the arena its graph refers to (the later passes
+    open another one), and every pass -- eager on fresh buffers, and the replay of the pinned graph at the end -- stays
+    bit-identical to the launch-per-op path."""
+    B, K, N, T, hw = 4, 2, 3, 3, (50, 50)
+    F, d, obs, P, noise = _inputs(B, K, N, T, hw)
+    _, _, ref = _run(F, hw, d, obs, P, noise, K, chain=False, use_graph=False)
+    core = SqairCore(F, hw, options={"slot_chain": 1, "slot_chain_arena_kb": 256})
+    core.set_params(P)
+    m = Model(obs, None, core, K, presence=d["nums"], debug=True)
+    keep = []   # old buffers stay alive: every pass gets addresses no earlier pass had
+
+    def fresh():
+        keep.append((core.obs, core.noise))
+        core.obs, core.noise = core.obs.clone(), torch.empty_like(core.noise)
+
+    def check(use_graph):
+        m.run(noise=noise, use_graph=use_graph)
+        torch.cuda.synchronize()
+        for k, v in core.out.items():
+            assert np.array_equal(ref[k], v.detach().cpu().numpy(), equal_nan=True), (k, use_graph)
+        assert np.array_equal(ref["log_weights"], core.log_weights.cpu().numpy())
+
+    for _ in range(8):
+        fresh()
+        check(False)
+    check(True)            # capture on the current buffers: their tables are pinned
+    pinned = (core.obs, core.noise)
+    for _ in range(8):
+        fresh()
+        check(False)
+    core.obs, core.noise = pinned
+    check(True)            # the graph's tables are still where it expects them
+    assert core.lib.sqair_set_option(core.handle, b"slot_chain_arena_kb", 512) == -2   # only before the first pass
