@@ -262,6 +262,9 @@ def main():
     ap.add_argument("--time-transition", default="GRU", choices=["GRU", "LSTM"],
                     help="propagation temporal cell (the shipped config and BASELINE's metric use GRU)")
     ap.add_argument("--prior-transition", default="GRU", choices=["GRU", "LSTM"], help="propagation prior cell (shipped: GRU)")
+    ap.add_argument("--require-native-comm", action="store_true",
+                    help="with a device per rank: exit with status 3 if the native RCCL communicator (sqair_amd/rccl.py) cannot be "
+                         "built, instead of sending the gradient all-reduce through torch.distributed's nccl group (reported)")
     ap.add_argument("--transition", default="VanillaRNN", choices=["VanillaRNN", "GRU", "LSTM"],
                     help="slot RNN of both cores (shipped: VanillaRNN)")
     args = ap.parse_args()
@@ -304,6 +307,7 @@ def main():
         dist.init_process_group(backend=backend, **kw)  # "nccl" = RCCL on ROCm
     # the training step's gradient all-reduce goes through RCCL's C API on the library's own launch stream
     comm = None
+    native_comm_error = None
     if dist is not None and backend == "nccl":
         from sqair_amd.rccl import RcclComm
         comm_error = None
@@ -314,13 +318,22 @@ def main():
         ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
-            print("bench: rank {}: the native RCCL communicator could not be built ({}); refusing to fall back".format(
-                rank, comm_error or "failed on another rank"), file=sys.stderr, flush=True)
+            # Never silently: the failure goes to stderr on every rank and into the JSON line (`native_comm_error`,
+            # `allreduce_on_launch_stream` false).  With --require-native-comm the run ends here (status 3); otherwise the step's
+            # all-reduce goes through torch.distributed's "nccl" group -- RCCL over xGMI all the same, but issued from torch's
+            # collective stream instead of the library's launch stream.
+            native_comm_error = comm_error or "failed on another rank"
+            print("bench: rank {}: the native RCCL communicator could not be built ({}); {}".format(
+                rank, native_comm_error, "refusing to fall back" if args.require_native_comm else
+                "the gradient all-reduce goes through torch.distributed (nccl = RCCL) instead"), file=sys.stderr, flush=True)
             if comm is not None:
                 comm.destroy()
-            dist.destroy_process_group()
-            raise SystemExit(3)
-        assert comm.n_ranks == world
+                comm = None
+            if args.require_native_comm:
+                dist.destroy_process_group()
+                raise SystemExit(3)
+        else:
+            assert comm.n_ranks == world
 
     from sqair_amd._capi import build_id
     from sqair_amd.data import config_inputs, make_sequences, to_float
@@ -413,14 +426,17 @@ def main():
                 allreduce_ms = e0.elapsed_time(e1) / 20
         train = dict(value=frames_per_step / (el / n_train), unit="frames/s", ms_per_step=el / n_train * 1e3, steps=n_train,
                      scaling="weak", graph_nodes=getattr(core, "train_graph_nodes", None),
-                     rccl_ranks=comm.n_ranks if comm is not None else 0,
+                     rccl_ranks=comm.n_ranks if comm is not None else (world if (dist is not None and backend == "nccl") else 0),
                      allreduce_on_launch_stream=bool(comm is not None) if world > 1 else None,
+                     native_comm_error=native_comm_error,
                      allreduce_ms=allreduce_ms,
                      collective="all-reduce(sum) of {} fp32 gradients ({:.1f} MB) per step, {}; 1/world folded into the fused "
                                 "RMSProp kernel".format(core.n_params, core.n_params * 4 / 1e6,
                                                         "ncclAllReduce (RCCL C API) on the launch stream" if comm is not None
-                                                        else "torch.distributed " + backend + " (ranks share devices: functional "
-                                                        "check only)") if world > 1 else "none (1 rank)",
+                                                        else ("torch.distributed nccl (= RCCL) on torch's collective stream: the native "
+                                                              "communicator could not be built" if native_comm_error else
+                                                              "torch.distributed " + backend + " (ranks share devices: functional "
+                                                              "check only)")) if world > 1 else "none (1 rank)",
                      what="draw noise + forward(train) + VIMCO target + backward (one HIP-graph replay) + all-reduce + "
                           "RMSProp + re-pack; finite={}".format(bool(torch.isfinite(core.flat).all())))
         core.set_params(P)  # back to the benchmark parameters for the parity / roofline legs below
@@ -643,7 +659,8 @@ def main():
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "rccl_ranks": comm.n_ranks if comm is not None else 0, "dist_backend": (backend if dist is not None else None),
+        "rccl_ranks": comm.n_ranks if comm is not None else (world if (dist is not None and backend == "nccl") else 0),
+        "native_comm_error": native_comm_error, "dist_backend": (backend if dist is not None else None),
         "config": {"workload": "cfg{}: T={} HxW={}x{} B={}/GPU K={} N={} cells {}/{}/{} forward (elbo_iwae), HIP-graph replay={}".format(
             args.cfg, T, hw[0], hw[1], B, K, N, args.transition, args.time_transition, args.prior_transition, use_graph), "global_batch": B * world, "seq_len": T,
             "parallelism": "dp{}".format(world), "graph_nodes": core.graph_nodes()},

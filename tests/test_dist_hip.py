@@ -127,24 +127,36 @@ def test_two_ranks_on_two_devices_all_reduce_over_rccl(tmp_path):
     assert np.isfinite(z["g0"]).all() and np.isfinite(z["flat"]).all()
 
 
-def test_bench_refuses_a_silent_fallback_when_rccl_is_required(tmp_path):
-    """With one device per rank the native communicator is required: `bench.py` must exit non-zero rather than fall back to
-    another collective.  Simulated at one rank with `--force-dist` and an unloadable RCCL (the ctypes loader is pointed at a
-    missing library through the module attribute, not through the environment)."""
-    code = ("import sys, runpy; sys.argv = ['bench.py', '--force-dist', '--steps', '1', '--warmup', '1', '--train-steps', '0', "
-            "'--no-cpu-baseline', '--no-timeline', '--streams', '0', '--cfg', '1']\n"
+def _bench_with_broken_rccl(extra):
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--force-dist', '--steps', '1', '--warmup', '1', '--train-steps', '1', "
+            "'--no-cpu-baseline', '--no-timeline', '--streams', '0', '--cfg', '1'] + {extra!r}\n"
             "sys.path.insert(0, {root!r})\n"
             "import sqair_amd.rccl as R\n"
             "def broken(*a, **k): raise OSError('librccl.so deliberately unavailable')\n"
             "R.RcclComm.from_process_group = classmethod(broken)\n"
-            "runpy.run_path({bench!r}, run_name='__main__')\n").format(root=ROOT, bench=os.path.join(ROOT, "bench.py"))
+            "runpy.run_path({bench!r}, run_name='__main__')\n").format(root=ROOT, bench=os.path.join(ROOT, "bench.py"), extra=extra)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_never_falls_back_silently_when_the_native_communicator_fails(tmp_path):
+    """With one device per rank the native communicator (RCCL's C API on the launch stream) is what the step's all-reduce uses.
+    If it cannot be built the run says so -- on stderr and in the JSON line -- and goes through torch.distributed's nccl group;
+    with `--require-native-comm` it exits with status 3 and prints no bench line.  Simulated at one rank with `--force-dist`
+    and an unloadable RCCL (the ctypes loader is broken through the module attribute, not through the environment)."""
+    p = _bench_with_broken_rccl(["--require-native-comm"])
     assert p.returncode == 3, (p.returncode, p.stderr[-1500:])
     assert "refusing to fall back" in p.stderr
     assert not [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    p = _bench_with_broken_rccl([])
+    assert p.returncode == 0, (p.returncode, p.stderr[-1500:])
+    assert "could not be built" in p.stderr and "torch.distributed" in p.stderr
+    import json
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert "deliberately unavailable" in line["native_comm_error"]
+    assert line["train"]["native_comm_error"] == line["native_comm_error"] and line["dist_backend"] == "nccl"
 
 
 def test_native_rccl_all_reduce_on_the_launch_stream_single_rank():
