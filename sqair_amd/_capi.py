@@ -150,8 +150,10 @@ class StaleLibraryError(ImportError):
 def source_id():
     """Hash of the kernel sources ON DISK (sqair_amd/csrc/ + include/sqair_hip.h + compiler flags): what a fresh build of any
     variant would report as its `sqair_build_id()`."""
-    from .csrc.build import source_id as _sid
-    return _sid()
+    from .csrc import build as _b
+    if not any(f.endswith(".hip") for f in os.listdir(_b.HERE)):
+        raise OSError("no kernel sources in {}".format(_b.HERE))   # (build.py alone does not make a source tree)
+    return _b.source_id()
 
 
 def lib(path=None, allow_stale=False):
@@ -182,7 +184,8 @@ def lib(path=None, allow_stale=False):
         got = l.sqair_build_id().decode()
         try:
             want = source_id()
-        except OSError:     # a binary-only deployment (no csrc/ or include/ beside the package): nothing to compare with
+        except (OSError, ImportError):   # a binary-only deployment (no csrc/ -- ModuleNotFoundError --, its .hip files stripped, or no
+            # include/ beside the package): nothing to compare with
             want = None
             if not allow_stale:
                 import warnings

@@ -923,6 +923,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
     return -1;
   }
   flat = sq_flat(h, flat, packed);   // (padded configurations: the copy sqair_pack_params keeps in the packed buffer)
+  sq_chain_reset(h);                 // (a pass that ended early between sq_chain_begin and sq_chain_flush left the recorder open)
   const SqairOutputs out = *outp;
   const int nh = c.n_hidden, nw = c.n_what, N = c.n_steps_per_image, K = c.k_particles;
   const int R = B * K, M = R * N, G2 = c.glimpse_size * c.glimpse_size, P_ = c.img_h * c.img_w;

@@ -78,6 +78,7 @@ struct ChainPoisonList { int n; int pad; ChainPoison r[SQ_CHAIN_MAX_POISON]; };
 struct SqairHandle;
 // host recorder (sqair_chain.hip): between sq_chain_begin and sq_chain_flush the slot loop's launches are collected
 bool sq_chain_active(const SqairHandle* h);
+void sq_chain_reset(SqairHandle* h);   // closes a recorder an earlier pass left open (early return between begin and flush)
 void sq_chain_begin(SqairHandle* h, const Dims& d, const POff& po, const float* ws_base, int64_t ws_bytes);
 int sq_chain_add_dense(SqairHandle* h, const LinArgs& a, int kc_total, int n_tiles);
 int sq_chain_add_crop(SqairHandle* h, const CropArgs& a);

@@ -900,6 +900,12 @@ int sq_chain_set_arena_kb(SqairHandle* h, int kb) {   // before the first chain 
   c->arena_bytes = (size_t)kb << 10;
   return 0;
 }
+void sq_chain_reset(SqairHandle* h) {
+  if (!h->chain) return;
+  ChainState* c = (ChainState*)h->chain;
+  c->active = false;
+  c->failed = false;
+}
 bool sq_chain_active(const SqairHandle* h) { return h->chain && ((const ChainState*)h->chain)->active; }
 void sq_chain_destroy(SqairHandle* h) {
   if (!h->chain) return;
@@ -946,11 +952,12 @@ int sq_chain_add_dense(SqairHandle* h, const LinArgs& a, int kc_total, int n_til
   ChainOp* op = chain_new_op(h, COP_DENSE, n_tiles);
   if (!op) return -3;
   ChDense& dn = op->u.dense;
-  if (kc_total > SQ_CHAIN_MAX_KC || a.scale_ptr != nullptr || a.add_rdiv > 1) { sq_set_error(h, "slot chain: layer outside the chain's dense body"); return -3; }
+  ChainState* cst = cs_of(h);
+  if (kc_total > SQ_CHAIN_MAX_KC || a.scale_ptr != nullptr || a.add_rdiv > 1) { sq_set_error(h, "slot chain: layer outside the chain's dense body"); cst->failed = true; return -3; }
   chain_split(a.wp, &dn.wp_lo, &dn.wp_hi);
   chain_split(a.wzero, &dn.wz_lo, &dn.wz_hi);
   chain_split(a.bias, &dn.bias_lo, &dn.bias_hi);
-  if (a.M != cs_of(h)->tab.d.R) { sq_set_error(h, "slot chain: a dense op over other rows than the particle rows"); return -3; }
+  if (a.M != cst->tab.d.R) { sq_set_error(h, "slot chain: a dense op over other rows than the particle rows"); cst->failed = true; return -3; }
   dn.M = a.M; dn.N = a.N; dn.kc_total = kc_total; dn.nch = (kc_total + 3) / 4;
   op->nch = dn.nch;
   dn.epi = a.epi; dn.act_a = a.act_a; dn.act_b = a.act_b; dn.act_split = a.act_split; dn.scale = a.scale; dn.nh = a.nh;
@@ -966,19 +973,19 @@ int sq_chain_add_dense(SqairHandle* h, const LinArgs& a, int kc_total, int n_til
   int g = 0;
   for (int i = 0; i < a.nseg && ok; ++i) {
     const LinSeg& sg = a.seg[i];
-    if (sg.rdiv > 1) { sq_set_error(h, "slot chain: row divisors are not supported"); return -3; }
+    if (sg.rdiv > 1) { sq_set_error(h, "slot chain: row divisors are not supported"); cst->failed = true; return -3; }
     unsigned base = 0;
     ok = chain_off(h, sg.p, &base);
     const int lim = ((sg.width + 3) & ~3) - 4;
     for (int q = 0; q < (sg.width + 15) / 16; ++q, ++g) dn.chunk[g] = ChChunk{base + 64u * q, (unsigned)sg.ld * 4u, (unsigned)(lim * 4 - 64 * q), 0u};
   }
   if (!ok) return -3;
-  if (g != kc_total) { sq_set_error(h, "slot chain: chunk count mismatch"); return -3; }
+  if (g != kc_total) { sq_set_error(h, "slot chain: chunk count mismatch"); cst->failed = true; return -3; }
   for (; g < SQ_CHAIN_MAX_KC; ++g) dn.chunk[g] = dn.chunk[kc_total - 1];
   return 0;
 }
 int sq_chain_add_crop(SqairHandle* h, const CropArgs& a) {
-  if (!(a.mode == CROP_PROP2 || a.mode == CROP_DISC) || a.t2 == nullptr) { sq_set_error(h, "slot chain: unsupported crop mode"); return -3; }
+  if (!(a.mode == CROP_PROP2 || a.mode == CROP_DISC) || a.t2 == nullptr) { sq_set_error(h, "slot chain: unsupported crop mode"); cs_of(h)->failed = true; return -3; }
   ChainOp* op = chain_new_op(h, COP_CROP, 16);
   if (!op) return -3;
   op->u.crop = a;

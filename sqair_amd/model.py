@@ -501,13 +501,14 @@ class Model(object):
         self._ran = True
         return self
 
-    def _debug_checks(self):
+    def _debug_checks(self, train=False):
         """`debug=True` of the reference turns on argument validation / NaN checks of every distribution inside the graph
         (sqair/core.py:226, :261, sqair/modules.py:318-320) — a failed check aborts `sess.run`.  Here: the per-frame
         log-weights (every log-probability of the pass ends up in them) and the sequence log-weights must be finite."""
         core = self.core
-        core.check_chain()       # (in-launch slot chain, when switched on: every launch of the pass completed)
-        core.check_scales()      # validate_args: every slot's what / where scale > 0 and finite -- the specific message first
+        # (train: the pass just run wrote the TRAINING workspace -- the tape --, not the inference one)
+        core.check_chain(train=train)    # in-launch slot chain, when switched on: every launch of the pass completed
+        core.check_scales(train=train)   # validate_args: every slot's what / where scale > 0 and finite -- the specific message first
         core.check_finite(core.out["log_weights_per_timestep"], "log_weights_per_timestep [T, B*K]")
         core.check_finite(core.log_weights, "log_weights [B, K]")
 
@@ -588,6 +589,10 @@ class Model(object):
         ``opt.apply_gradients(gvs)`` (sqair_amd.train.Optimizer; learning rate from the flags' schedule unless given)
         performs the update."""
         core = self.core
+        if vi_target is not None:
+            if vi_target not in ("vimco", "iwae", "reinforce"):
+                raise ValueError("vi_target is 'vimco' (alias 'iwae', the reference's Model.VI_TARGETS name for it) or 'reinforce'")
+            vi_target = "vimco" if vi_target == "iwae" else vi_target   # canonical name first: the checks below compare with it
         if self.k_particles == 1 and (vi_target or getattr(core, "vi_target", "vimco")) == "vimco":
             # targets.py:55 divides by k_particles - 1: the reference's target (and this library's) is NaN with one particle
             raise ValueError("the VIMCO control variate needs k_particles >= 2 (sqair/targets.py:55 divides by k_particles - 1); "
@@ -607,7 +612,7 @@ class Model(object):
                 core.draw_noise()
             core.grad_step(use_graph=self._use_graph)
             if self.debug:
-                self._debug_checks()
+                self._debug_checks(train=True)
                 core.check_finite(core.flat_grad, "flat gradient of the VIMCO target")
             if l2_reg != 0.0:
                 core.check(core.lib.sqair_add_l2_grad(

@@ -98,3 +98,37 @@ def test_load_through_global_flags_then_one_training_step_matches_the_oracle(glo
     # the next pass runs on the updated (re-packed) parameters
     m.run(noise=noise)
     assert np.isfinite(float(m.elbo_iwae)) and float(m.elbo_iwae) != float(ref.elbo_iwae.detach())
+
+
+@pytest.mark.gpu
+def test_make_target_with_debug_checks_the_training_pass_and_takes_the_iwae_alias(global_flags):
+    """`make_target(opt)` with debug=True and NO earlier `run()`: the debug checks must look at the workspace the gradient pass
+    wrote (the tape), not at the never-written inference workspace (whose zero scales used to raise a false 'scale not positive').
+    `vi_target='iwae'` is the reference's name for the VIMCO target (Model.VI_TARGETS): an alias, not a change of target -- it
+    must neither drop the captured graphs on every call nor slip past the one-particle guard."""
+    F = global_flags
+    F.update(k_particles=2, n_steps_per_image=2, learning_rate=1e-4, train_itr=100, opt="rmsprop")
+    T, B, hw = 2, 3, (50, 50)
+    d = make_sequences(B, T=T, canvas=hw, n_objects=(1, 2), obj_size=24, seed=5)
+    img = to_float(d["imgs"])
+    for chain in (0, 1):
+        if not chain:
+            m = MD.load(img, d["coords"], d["nums"], img.mean((0, 1)), debug=True)
+        else:   # (the in-launch slot chain on: its status words live in the training workspace too)
+            core = MD.SqairCore(F, hw, options={"slot_chain": 1})
+            core.set_params(init_params(F, hw, seed=0, mean_img=img.mean((0, 1))))
+            m = MD.Model(img, d["coords"], core, 2, presence=d["nums"], debug=True)
+        opt = Optimizer(m.core, F.opt)
+        m._use_graph = True
+        target, gvs = m.make_target(opt)            # first pass of this model: the training pass, debug checks on the tape
+        assert np.isfinite(float(target)) and len(gvs) == len(m.core.spec)
+        assert m.core._train_graph_ready
+        t2, _ = m.make_target(opt, vi_target="iwae")
+        assert getattr(m.core, "vi_target", "vimco") == "vimco" and m.core._train_graph_ready, "the alias must not drop the captured graph"
+        assert np.isfinite(float(t2))
+    with pytest.raises(ValueError, match="vi_target"):
+        m.make_target(opt, vi_target="elbo")
+    F.update(k_particles=1)
+    m1 = MD.load(img, d["coords"], d["nums"], img.mean((0, 1)))
+    with pytest.raises(ValueError, match="k_particles >= 2"):
+        m1.make_target(None, vi_target="iwae")

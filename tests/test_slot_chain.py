@@ -57,6 +57,38 @@ def test_chain_is_bit_identical_to_the_launches(B, K, N, T, hw):
             assert n_chain < (n_plain // 2 if N > 1 else n_plain), (n_chain, n_plain)   # (one slot: little to replace)
 
 
+def test_chain_passes_with_fresh_noise_and_frames_on_one_workspace():
+    """Consecutive passes on ONE workspace and ONE captured graph with different noise and frames: a hand-off buffer missing from
+    the pass's sentinel fill would let a consumer read the previous pass's (different) value instead of waiting -- with the same
+    inputs every pass (the other tests) a stale value equals the right one."""
+    B, K, N, T, hw = 32, 5, 4, 2, (50, 50)
+    F, d, obs, P, noise = _inputs(B, K, N, T, hw)
+    rng = np.random.default_rng(11)
+    cores = []
+    for chain in (False, True):
+        core = SqairCore(F, hw, options={"slot_chain": 1} if chain else None)
+        core.set_params(P)
+        cores.append((core, Model(obs, None, core, K, presence=d["nums"], debug=chain)))
+    prev = None
+    for it in range(4):
+        nz = draw_noise(rng, T, B * K, N, 4 + int(F.n_what) + 1)
+        ob = np.roll(obs, it, axis=1) if it else obs
+        outs = []
+        for core, m in cores:
+            with core.on_stream():
+                core.obs.copy_(torch.as_tensor(ob).reshape(core.obs.shape))
+            m.run(noise=nz, use_graph=it > 0)
+            torch.cuda.synchronize()
+            o = {k: v.detach().cpu().numpy().copy() for k, v in core.out.items()}
+            o["log_weights"] = core.log_weights.cpu().numpy().copy()
+            outs.append(o)
+        for k, v in outs[0].items():
+            assert np.array_equal(v, outs[1][k], equal_nan=True), (k, it)
+        if prev is not None:
+            assert not np.array_equal(outs[0]["log_weights"], prev), "the passes were meant to differ"
+        prev = outs[0]["log_weights"]
+
+
 def test_chain_gradients_match_the_launches():
     """The backward pass consumes the tape the chain's forward pass wrote -- bit-identical to the launches' tape -- so the gradients
     agree to the run-to-run reproducibility of the backward pass itself (its weight-gradient launches accumulate with float
