@@ -55,7 +55,8 @@ MACS_PER_FRAME_PARTICLE = {1: 10166288, 2: 13543744, 3: 13543744, 4: 20298656, 5
 # ... and what the path EXECUTES per frame (the loop-invariant input encoder hoisted out of the N slot steps, the
 # mask MLP evaluated once): MFLOP per frame, all K particles included.  `roofline.frac_executed` is quoted on this figure.
 EXECUTED_MFLOP_PER_FRAME = {1: 17.5, 2: 114.3, 3: 114.3, 4: 167.7, 5: 149.8}
-PROFILE_TAG = "r05"                    # profiles/<tag>_*.json|csv: the committed files of this round (tools/profile_round.sh)
+MIN_HBM_BYTES_PER_FRAME = {2: 101060, 3: 101060}   # minimum HBM bytes per frame (all K particles), cfg-2 shapes
+PROFILE_TAG = "r06"                    # profiles/<tag>_*.json|csv: the committed files of this round (tools/profile_round.sh)
 
 
 def cpu_baseline(F, hw, P, obs, noise, hip_ref, budget_s=25.0):
@@ -165,7 +166,7 @@ def timeline_roofline(F, Ftr, hw, P, obs, nums, algo_flops_step, ms_fwd, ms_trai
     alg = TL.algorithmic_hbm_bytes(T, B, K, N, hw[0], hw[1], G=int(F.glimpse_size), nh=core_t.nh, nw=core_t.nw, snh=core_t.snh,
                                    psnh=core_t.psnh, masked=bool(F.masked_glimpse), train=False)
     # PMC traffic measured by rocprofv3 on this build, if committed (tools/profile_round.sh)
-    traffic, traffic_note, fam_traffic = None, None, None
+    traffic, traffic_note, fam_traffic, dense_fam_traffic = None, None, None, None
     tname = PROFILE_TAG + "_hbm_traffic" + ("" if cfg_id in (2, 3) else "_cfg{}".format(cfg_id)) + ".json"
     tpath = os.path.join(ROOT, "profiles", tname)
     if os.path.exists(tpath) and not batch_override:
@@ -174,6 +175,7 @@ def timeline_roofline(F, Ftr, hw, P, obs, nums, algo_flops_step, ms_fwd, ms_trai
             if tj.get("build_id") == bid:
                 traffic = tj.get("dominant_bytes_per_launch")
                 fam_traffic = tj.get("family_bytes_per_launch")
+                dense_fam_traffic = tj.get("dense_family_bytes_per_launch")
                 traffic_note = "PMC FETCH_SIZE / WRITE_SIZE of {} on this build (profiles/{}, two separate --pmc passes)".format(tj.get("dominant"), tname)
             else:
                 traffic_note = "profiles/{} was measured on build {} != this build {}: not quoted".format(tname, tj.get("build_id"), bid)
@@ -195,10 +197,41 @@ def timeline_roofline(F, Ftr, hw, P, obs, nums, algo_flops_step, ms_fwd, ms_trai
                              recompute="python tools/timeline.py --recompute profiles/{}_timeline_fwd.csv".format(PROFILE_TAG))
         except Exception as e:
             committed = dict(error=str(e))
+    # PMC traffic against what the launches NEED: the dominant instantiation's unique operands (rows x K in, K x N weights, rows x N
+    # out of the 160 x 256 x 256 slot layer), and the dense family's bytes per step against SURVEY 8(d)'s minimum for the whole
+    # step (activations that must cross HBM + every weight once)
+    traffic_ratio = None
+    if traffic is not None:
+        R_ = B * K
+        uniq = 4.0 * (R_ * core_t.nh + core_t.nh * core_t.nh + R_ * core_t.nh)
+        traffic_ratio = dict(dominant_over_unique_operands=traffic / uniq, dominant_unique_operand_bytes=uniq)
+        if dense_fam_traffic is not None and cfg_id in MIN_HBM_BYTES_PER_FRAME:
+            need = MIN_HBM_BYTES_PER_FRAME[cfg_id] * float(B * T) + 4.0 * core_t.n_params
+            traffic_ratio.update(dense_family_bytes_per_launch=dense_fam_traffic, dense_family_bytes_per_step=dense_fam_traffic * d["launches"],
+                                 algorithmic_min_bytes_per_step=need,
+                                 dense_family_over_algorithmic_min=dense_fam_traffic * d["launches"] / need,
+                                 why="each of the 8 XCD L2s pulls a layer's weights again on every launch (8 x 256 KB for the dominant one); "
+                                     "not the bound: with the weight loads removed the step is 3 % faster (DESIGN.md section 3)")
+    # third leg (profiles/<tag>_dense_b2b.json, tools/dense_graph_time.py): per-node time of 1000-node HIP graphs of every dense shape
+    # of the step, PRODUCT library, plain HIP events -- a figure for the same fraction that the stamped build did not produce
+    third = None
+    bpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_dense_b2b.json")
+    if os.path.exists(bpath) and cfg_id == 2 and not batch_override:
+        try:
+            bj = json.load(open(bpath))
+            third = dict(file="profiles/{}_dense_b2b.json".format(PROFILE_TAG), same_build_as_this_run=bj.get("build_id") == bid,
+                         build_id=bj.get("build_id"), frac_dense_family=bj.get("frac_dense_family"),
+                         k_linear_avg_node_us=bj.get("k_linear_avg_node_us"),
+                         graph_nodes_over_timeline_slots_k_linear=bj.get("graph_nodes_over_timeline_slots_k_linear"),
+                         how="census of the step's dense launches x microseconds per node of a 1000-node HIP graph of each shape "
+                             "(every launch reading what the previous one wrote), product library, HIP events")
+        except Exception as e:
+            third = dict(error=str(e))
     roofline = dict(
         kernel="fp32-MFMA dense layers (k_linear*, k_rnn_tail; {} launches/step)".format(d["launches"]),
         bound="mfma", achieved=per / (d["avg_slot_us"] * 1e-6) / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-        frac=frac(d["avg_slot_us"]), traffic=traffic, traffic_note=traffic_note,
+        frac=frac(d["avg_slot_us"]), traffic=traffic, traffic_note=traffic_note, traffic_over_algorithmic=traffic_ratio,
+        third_leg=third,
         frac_is="frac_slot: algorithmic FLOPs per dense launch / average slot of a dense launch (first-wave start to the next "
                 "dispatch's first-wave start = busy + dependent-launch gap), from the per-dispatch timeline of one step stamped "
                 "by the kernels themselves (no profiler)",
@@ -335,6 +368,17 @@ def main():
         else:
             assert comm.n_ranks == world
 
+    # which communicator carries the training step's gradient all-reduce -- said once, unambiguously
+    if dist is None:
+        collective_path = None            # one rank, no process group: no collective
+    elif comm is not None:
+        collective_path = "native"        # ncclAllReduce through RCCL's C API on the library's launch stream (sqair_amd/rccl.py)
+    elif backend == "nccl":
+        collective_path = "torch-nccl"    # torch.distributed's nccl group (= RCCL) on torch's collective stream
+    else:
+        collective_path = "gloo"          # ranks share devices: functional check only
+    rccl_ranks = comm.n_ranks if collective_path == "native" else (world if collective_path == "torch-nccl" else 0)
+
     from sqair_amd._capi import build_id
     from sqair_amd.data import config_inputs, make_sequences, to_float
     from sqair_amd.flags import make_flags
@@ -426,7 +470,7 @@ def main():
                 allreduce_ms = e0.elapsed_time(e1) / 20
         train = dict(value=frames_per_step / (el / n_train), unit="frames/s", ms_per_step=el / n_train * 1e3, steps=n_train,
                      scaling="weak", graph_nodes=getattr(core, "train_graph_nodes", None),
-                     rccl_ranks=comm.n_ranks if comm is not None else (world if (dist is not None and backend == "nccl") else 0),
+                     rccl_ranks=rccl_ranks, collective_path=collective_path,
                      allreduce_on_launch_stream=bool(comm is not None) if world > 1 else None,
                      native_comm_error=native_comm_error,
                      allreduce_ms=allreduce_ms,
@@ -659,7 +703,8 @@ def main():
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "rccl_ranks": comm.n_ranks if comm is not None else (world if (dist is not None and backend == "nccl") else 0),
+        # ranks of the RCCL communicator that carried the gradient all-reduce of the `train` leg (0: none did -- one rank, or gloo)
+        "rccl_ranks": rccl_ranks, "collective_path": collective_path,
         "native_comm_error": native_comm_error, "dist_backend": (backend if dist is not None else None),
         "config": {"workload": "cfg{}: T={} HxW={}x{} B={}/GPU K={} N={} cells {}/{}/{} forward (elbo_iwae), HIP-graph replay={}".format(
             args.cfg, T, hw[0], hw[1], B, K, N, args.transition, args.time_transition, args.prior_transition, use_graph), "global_batch": B * world, "seq_len": T,

@@ -111,6 +111,10 @@ _PROTOS = {
     "sqair_linear_bwd_test": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_int64, C.c_void_p]),
     "sqair_debug_linear_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "sqair_debug_linear_graph_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "sqair_debug_dense_log": (C.c_int, [C.c_void_p, C.c_int]),
+    "sqair_debug_dense_log_entry": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "sqair_debug_layers": (C.c_int, [C.c_void_p]),
     "sqair_debug_padded_count": (C.c_int64, [C.c_void_p, C.POINTER(C.c_int)]),
     "sqair_debug_layer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),

@@ -826,6 +826,7 @@ int sq_run(SqairHandle* h, Lin& l, LayerId id, int M, const float* packed, hipSt
   l.a.bias = packed + pl.b + L.b_off;
   l.a.M = M;
   l.a.N = L.N;
+  if (h->dense_log_on) { const int e[4] = {(int)id, M, L.kc * 16, L.N}; h->dense_log.insert(h->dense_log.end(), e, e + 4); }
   if (sq_chain_active(h)) return sq_chain_add_dense(h, l.a, L.kc, L.nt);   // collected into the chain launch (sqair_chain.h)
   const int rc = sq_launch_linear(l.a, L, s);
   if (rc != 0) sq_set_error(h, "internal: A-operand contract (16-byte aligned, ld % 4 == 0) violated in layer " + std::to_string((int)id));
@@ -844,6 +845,7 @@ static int run_rnn_tail(SqairHandle* h, const TailArgs& ta, Dims d, LayerId id, 
                         float* out, int out_ld, const float* packed, hipStream_t s) {
   const PackedLayer& L = h->layers[id];
   const PackedLayout pl = packed_layout(h);
+  if (h->dense_log_on) { const int e[4] = {-1 - (int)id, d.R, L.kc * 16, L.N}; h->dense_log.insert(h->dense_log.end(), e, e + 4); }   // (id < 0: with the tail in front)
   if (sq_chain_active(h)) {
     ChainRnn r; memset(&r, 0, sizeof(r));
     r.ta = ta; r.hid = hid; r.hid_ld = hid_ld; r.wp = packed + pl.w + L.w_off; r.bias = packed + pl.b + L.b_off; r.add = add; r.add_ld = add_ld;
@@ -1731,7 +1733,47 @@ extern "C" int sqair_linear_test(SqairHandle* h, const float* x, const float* wm
   if (sq_launch_linear(l.a, L, s) != 0) { sq_set_error(h, "sqair_linear_test: A-operand contract violated"); return -5; }
   SQ_CHECK_HIP(hipGetLastError());
   SQ_CHECK_HIP(hipStreamSynchronize(s));
-  if (h->debug_reps > 0) {  // sqair_debug_linear_time: the same launch `reps` times back to back between two events
+  if (h->debug_reps > 0 && h->debug_graph_nodes > 0) {
+    // sqair_debug_linear_graph_time: `nodes` launches of this layer captured as ONE HIP graph -- the same launch over and over
+    // (no data dependence), or (dependent) every launch reading what the previous one wrote -- and the graph replayed
+    // `reps` times between two HIP events: time per graph NODE (kernel + the dependent-dispatch boundary), on whatever build
+    // of the library this is.  The figure bench.py's timeline calls the SLOT of a dense launch, measured without the stamps.
+    // dependent: every launch reads what the previous one wrote -- IN PLACE, input columns [0, K) and output columns [0, N) of
+    // one buffer of pitch max(K, N) behind the other scratch (a race between the workgroups of a row tile: the values mean
+    // nothing, tanh keeps them finite; what is timed is a launch whose operand comes out of the previous launch's stores)
+    Lin l2;
+    const bool dep = h->debug_graph_dependent;
+    if (dep) {
+      const int ldz = (std::max(kpad, Ndim) + 3) & ~3;
+      float* d_z = d_x + (size_t)M * kpad;
+      if (scratch_bytes < (2 * nel + 2 * nb + 256 + (int64_t)M * kpad + (int64_t)M * ldz + 16) * 4) { sq_set_error(h, "sqair_debug_linear_graph_time: scratch too small"); return -1; }
+      SQ_CHECK_HIP(hipMemsetAsync(d_z, 0, ((size_t)M * ldz + 16) * 4, s));
+      SQ_CHECK_HIP(hipMemcpy2DAsync(d_z, (size_t)ldz * 4, x, (size_t)Kdim * 4, (size_t)Kdim * 4, M, hipMemcpyDeviceToDevice, s));
+      l2.seg(d_z, ldz, Kdim).out(d_z, ldz).act(act);
+      l2.a.wp = d_w; l2.a.wzero = d_zero; l2.a.bias = d_b; l2.a.M = M; l2.a.N = Ndim;
+    }
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    SQ_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < h->debug_graph_nodes; ++i) sq_launch_linear(dep ? l2.a : l.a, L, s);
+    SQ_CHECK_HIP(hipStreamEndCapture(s, &g));
+    SQ_CHECK_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipEvent_t ea, eb;
+    SQ_CHECK_HIP(hipEventCreate(&ea));
+    SQ_CHECK_HIP(hipEventCreate(&eb));
+    for (int i = 0; i < 2; ++i) SQ_CHECK_HIP(hipGraphLaunch(ge, s));
+    (void)hipEventRecord(ea, s);
+    for (int i = 0; i < h->debug_reps; ++i) SQ_CHECK_HIP(hipGraphLaunch(ge, s));
+    (void)hipEventRecord(eb, s);
+    SQ_CHECK_HIP(hipStreamSynchronize(s));
+    float ms = 0.0f;
+    SQ_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb));
+    h->debug_us = ms * 1e3f / ((float)h->debug_reps * (float)h->debug_graph_nodes);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    (void)hipGraphExecDestroy(ge);
+    (void)hipGraphDestroy(g);
+  } else if (h->debug_reps > 0) {  // sqair_debug_linear_time: the same launch `reps` times back to back between two events
     hipEvent_t ea, eb;
     SQ_CHECK_HIP(hipEventCreate(&ea));
     SQ_CHECK_HIP(hipEventCreate(&eb));
@@ -1755,6 +1797,32 @@ extern "C" int sqair_debug_linear_time(SqairHandle* h, const float* x, const flo
   h->debug_reps = reps;
   const int rc = sqair_linear_test(h, x, wmat, b, y, M, Kdim, Ndim, act, scratch, scratch_bytes, stream);
   h->debug_reps = 0;
+  *us_out = h->debug_us;
+  return rc;
+}
+
+// measurement helper (tools/dense_graph_time.py): the dense launches of the passes issued between (on = 1) and the read-out.
+// entry i -> {layer id (-1 - id: the VanillaRNN layer with the slot tail fused in front), rows, K padded, N}; returns the count.
+extern "C" int sqair_debug_dense_log(SqairHandle* h, int on) {
+  if (!h) return -1;
+  if (on) h->dense_log.clear();
+  h->dense_log_on = on != 0;
+  return (int)(h->dense_log.size() / 4);
+}
+extern "C" int sqair_debug_dense_log_entry(const SqairHandle* h, int i, int* out4) {
+  if (!h || !out4 || i < 0 || (size_t)i * 4 + 3 >= h->dense_log.size()) return -1;
+  for (int q = 0; q < 4; ++q) out4[q] = h->dense_log[(size_t)i * 4 + q];
+  return 0;
+}
+// measurement helper (tools/dense_graph_time.py): time per NODE of a HIP graph of `nodes` launches of one dense layer -- the same
+// launch again and again, or (dependent != 0) each reading what the previous one wrote -- replayed `replays` times between HIP events
+extern "C" int sqair_debug_linear_graph_time(SqairHandle* h, const float* x, const float* wmat, const float* b, float* y, int M, int Kdim,
+                                             int Ndim, int act, void* scratch, int64_t scratch_bytes, int nodes, int replays,
+                                             int dependent, float* us_out, void* stream) {
+  if (!h || !us_out || nodes < 1 || replays < 1) return -1;
+  h->debug_reps = replays; h->debug_graph_nodes = nodes; h->debug_graph_dependent = dependent != 0;
+  const int rc = sqair_linear_test(h, x, wmat, b, y, M, Kdim, Ndim, act, scratch, scratch_bytes, stream);
+  h->debug_reps = 0; h->debug_graph_nodes = 0;
   *us_out = h->debug_us;
   return rc;
 }

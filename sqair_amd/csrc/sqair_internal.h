@@ -57,6 +57,10 @@ struct SqairHandle {
   hipGraphExec_t graph_exec = nullptr;
   int graph_nodes = 0;
   int debug_reps = 0;       // sqair_debug_linear_time
+  int debug_graph_nodes = 0;           // sqair_debug_linear_graph_time: launches per captured graph
+  bool debug_graph_dependent = false;  // ... chained through two buffers (K == N) instead of repeated
+  bool dense_log_on = false;           // sqair_debug_dense_log: {layer id, rows, K (padded to 16 per segment), N} of every dense launch
+  std::vector<int> dense_log;          // of the passes issued while it was on (host side only: nothing changes on the device)
   float debug_us = 0.0f;
   bool opt_tail_fusion = true;  // sqair_set_option("tail_fusion"): the tail of slot k inside slot k + 1's RNN launch (bit-identical either way)
   bool opt_slot_chain = false;  // sqair_set_option("slot_chain"): the slot launches of a frame's propagation / discovery loop as one

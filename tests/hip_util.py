@@ -33,12 +33,14 @@ def draw_noise(rng, T, R, N, nzw):
     return nz
 
 
-def run_hip(F, hw, P, obs, noise, nums=None, resample_u=None, use_graph=False, outputs="all"):
-    core = SqairCore(F, hw)
+def run_hip(F, hw, P, obs, noise, nums=None, resample_u=None, use_graph=False, outputs="all", options=None):
+    core = SqairCore(F, hw, options=options)
     core.set_params(P)
     m = Model(obs, None, core, int(F.k_particles), presence=nums, outputs=outputs)
     m.run(noise=noise, resample_u=resample_u, use_graph=use_graph)
     torch.cuda.synchronize()
+    if options and options.get("slot_chain"):
+        core.check_chain()   # (every launch of the in-launch slot chain completed: otherwise the outputs mean nothing)
     return m
 
 

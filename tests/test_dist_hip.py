@@ -157,6 +157,20 @@ def test_bench_never_falls_back_silently_when_the_native_communicator_fails(tmp_
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
     assert "deliberately unavailable" in line["native_comm_error"]
     assert line["train"]["native_comm_error"] == line["native_comm_error"] and line["dist_backend"] == "nccl"
+    # which communicator carried the all-reduce is said in one field (and rccl_ranks counts THAT communicator's ranks)
+    assert line["collective_path"] == "torch-nccl" and line["train"]["collective_path"] == "torch-nccl" and line["rccl_ranks"] == 1
+    # ... and the healthy branch: the native communicator on the launch stream
+    code_ok = ("import sys, runpy; sys.argv = ['bench.py', '--force-dist', '--steps', '1', '--warmup', '1', '--train-steps', '1', "
+               "'--no-cpu-baseline', '--no-timeline', '--streams', '0', '--cfg', '1']\n"
+               "runpy.run_path({bench!r}, run_name='__main__')\n").format(bench=os.path.join(ROOT, "bench.py"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", code_ok], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.returncode, p.stderr[-1500:])
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert line["collective_path"] == "native" and line["train"]["collective_path"] == "native" and line["native_comm_error"] is None
+    assert line["rccl_ranks"] == 1
 
 
 def test_native_rccl_all_reduce_on_the_launch_stream_single_rank():
@@ -210,8 +224,10 @@ def test_bench_launches_its_own_ranks():
     assert line["train"]["allreduce_ms"] > 0
     if torch.cuda.device_count() >= 2:
         assert line["rccl_ranks"] == 2 and line["train"]["rccl_ranks"] == 2 and line["train"]["allreduce_on_launch_stream"] is True
+        assert line["collective_path"] == "native"
     else:
         assert line["dist_backend"] == "gloo" and line["rccl_ranks"] == 0 and line["train"]["allreduce_on_launch_stream"] is False
+        assert line["collective_path"] == "gloo" and line["train"]["collective_path"] == "gloo"
 
 
 def test_bench_eight_ranks_functional_check_on_one_node():
@@ -244,6 +260,7 @@ def test_bench_eight_ranks_functional_check_on_one_node():
     assert sg["sequences"] == 8 * B and sg["forward_value"] > 0 and sg["train_value"] > 0
     assert line["forward_all_outputs_ms"] > 0
     if torch.cuda.device_count() >= 8:
-        assert line["rccl_ranks"] == 8 and tr["allreduce_on_launch_stream"] is True
+        assert line["rccl_ranks"] == 8 and tr["allreduce_on_launch_stream"] is True and line["collective_path"] == "native"
     else:
         assert line["dist_backend"] == "gloo" and line["rccl_ranks"] == 0 and tr["allreduce_on_launch_stream"] is False
+        assert line["collective_path"] == "gloo"

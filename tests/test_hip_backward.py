@@ -752,8 +752,10 @@ def test_rccl_all_reduce_on_the_gradient_buffer_single_rank():
         dist.destroy_process_group()
 
 
-def test_gradients_match_the_golden_fixture():
-    """tests/golden/k5_iwae_vimco_grads.npz (autograd through the fp64 oracle on the k5_iwae_vimco fixture; digest per
+@pytest.mark.parametrize("options", [None, {"slot_chain": 1}], ids=["launches", "slot_chain"])
+def test_gradients_match_the_golden_fixture(options):
+    """(also with the forward pass of the gradient evaluation on the in-launch slot chain: the tape the adjoint reads is then the
+    chain's)  tests/golden/k5_iwae_vimco_grads.npz (autograd through the fp64 oracle on the k5_iwae_vimco fixture; digest per
     parameter: sampled elements + sum / sum|.| / L2 / max|.|): the HIP backward pass on the same frames, parameters, noise."""
     import os
     from sqair_amd.model import Model, SqairCore
@@ -764,7 +766,7 @@ def test_gradients_match_the_golden_fixture():
     T, B, K, N, H, W, _, _ = [int(v) for v in z["meta"]]
     F = make_flags(k_particles=K, n_steps_per_image=N)
     P = fixture_params(z, F, (H, W))
-    core = SqairCore(F, (H, W))
+    core = SqairCore(F, (H, W), options=options)
     core.set_params(P)
     m = Model(z["obs"], None, core, K, presence=z["nums"], outputs=["log_weights_per_timestep", "discrete_log_prob", "presence"])
     with core.on_stream():
@@ -772,6 +774,8 @@ def test_gradients_match_the_golden_fixture():
         core.forward(train=True)
         core.backward()
     core.stream.synchronize()
+    if options:
+        core.check_chain(train=True)
     assert np.array_equal(core.out["presence"].cpu().numpy(), z["out_presence"].astype(np.float32))
     assert abs(float(core.scalars[2]) - float(g["vimco_target"])) <= 1e-4 * abs(float(g["vimco_target"]))
     report = []

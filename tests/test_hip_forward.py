@@ -24,11 +24,11 @@ GOLDEN_TOL = 2e-5   # per-output gate of the committed fixtures (scaled absolute
 
 
 def _record_parity(case, worst):
-    """Appends the worst scaled error per output of a fixture case to gpurun_out/r05_parity.json (copied to profiles/ by hand:
+    """Appends the worst scaled error per output of a fixture case to gpurun_out/r06_parity.json (copied to profiles/ by hand:
     the margin between what is measured and what the gate accepts, for the next reader)."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "gpurun_out", "r05_parity.json")
+    path = os.path.join(root, "gpurun_out", "r06_parity.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         data = json.load(open(path)) if os.path.exists(path) else {}
@@ -65,19 +65,23 @@ def _check_against(m, ref_out, ref_model, names, T, tol=5e-4):
     return worst
 
 
+CHAIN = {"slot_chain": 1}   # option of the library: the slot loops as one persistent launch per frame and phase (sqair_chain.h)
+
+
+@pytest.mark.parametrize("options", [None, CHAIN], ids=["launches", "slot_chain"])
 @pytest.mark.parametrize("name", ["cfg1_plumbing", "k5_iwae_vimco", "hw128_small"])
-def test_forward_matches_golden_fixture(name):
+def test_forward_matches_golden_fixture(name, options):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     T, B, K, N, H, W, pseed, _ = [int(v) for v in z["meta"]]
     F = make_flags(k_particles=K, n_steps_per_image=N)
     P = fixture_params(z, F, (H, W))   # regenerated from (seed, jitter); asserts the stored params_sha256
     ref_out = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
     ref_model = {k[6:]: z[k] for k in z.files if k.startswith("model_")}
-    m = run_hip(F, (H, W), P, z["obs"], z["noise"], nums=z["nums"], resample_u=z["resample_u"])
+    m = run_hip(F, (H, W), P, z["obs"], z["noise"], nums=z["nums"], resample_u=z["resample_u"], options=options)
     names = [k for k in ref_out if k in m.outputs]
     worst = _check_against(m, ref_out, ref_model, names, T, tol=GOLDEN_TOL)
     print(name, "worst scaled abs err:", max(worst.values()), max(worst, key=worst.get))
-    _record_parity(name, worst)
+    _record_parity(name + ("" if options is None else "+slot_chain"), worst)
     if K > 1:
         assert abs(float(m.vimco_target) - float(ref_model["vimco_target"])) <= 1e-3 * abs(float(ref_model["vimco_target"]))
         assert np.array_equal(m.iw_resampling_idx.cpu().numpy(), ref_model["iw_resampling_idx"].astype(np.int64))
@@ -440,7 +444,8 @@ def test_tail_fused_into_the_next_rnn_layer_is_bitwise_identical(K, N, T, B, n_u
     assert float(plain["presence"].sum()) > 0
 
 
-def test_cfg2_full_batch_against_the_fp32_oracle():
+@pytest.mark.parametrize("options", [None, CHAIN], ids=["launches", "slot_chain"])
+def test_cfg2_full_batch_against_the_fp32_oracle(options):
     """BASELINE configs[1] at FULL size (all 32 sequences x 5 particles x 10 frames) against the oracle in fp32 — the
     comparison bench.py's cpu_baseline leg prints, as a test: every particle row whose Bernoullis are decision-stable on the
     oracle's margin must decide identically, and the sequence log-weights / ELBO agree to the north-star 1e-4 relative."""
@@ -451,7 +456,8 @@ def test_cfg2_full_batch_against_the_fp32_oracle():
     P = params32(F, hw, 0, 0.02, obs.mean((0, 1)))
     noise = draw_noise(np.random.default_rng(4242), T, B * K, N, 55)
     ref = run_oracle(F, hw, P, obs, noise, nums=nums, dtype=torch.float32)
-    m = run_hip(F, hw, P, obs, noise, nums=nums, outputs=["log_weights_per_timestep", "discrete_log_prob", "presence"])
+    m = run_hip(F, hw, P, obs, noise, nums=nums, outputs=["log_weights_per_timestep", "discrete_log_prob", "presence"], options=options,
+                use_graph=options is not None)
     stable = presence_margins(ref.outputs, noise) >= MARGIN
     agree = (m.presence.cpu().numpy() == ref.presence.numpy()).all((0, 2))
     print("cfg-2 full batch: {} of {} rows decision-stable, {} agree".format(int(stable.sum()), stable.size, int(agree.sum())))
@@ -459,6 +465,31 @@ def test_cfg2_full_batch_against_the_fp32_oracle():
     a = m.log_weights.cpu().numpy().astype(np.float64).reshape(-1)[stable]
     b = ref.log_weights.numpy().astype(np.float64).reshape(-1)[stable]
     # fp32 oracle vs fp32 kernels: both carry ~1e-6 of rounding through a 10-frame recurrence
+    assert np.abs(a - b).max() <= REL * np.abs(b).max()
+    if agree.all():
+        assert abs(float(m.elbo_iwae) - float(ref.elbo_iwae)) <= REL * abs(float(ref.elbo_iwae))
+
+
+@pytest.mark.parametrize("cfg_id,T", [(4, 3), (5, 3)])
+def test_cfg4_cfg5_full_batch_against_the_fp32_oracle(cfg_id, T):
+    """BASELINE configs[3] (64 sequences x 5 particles, 6 slots) and configs[4] (128 x 128 frames, 32 x 5) at their FULL batch,
+    first T frames, against the oracle in fp32 -- the evidence test_cfg2_full_batch_against_the_fp32_oracle gives for configs[1]:
+    every decision-stable particle row decides identically, the sequence log-weights agree to 1e-4 relative."""
+    ov, obs, nums, _ = config_inputs(cfg_id)
+    F = make_flags(**ov)
+    hw = tuple(obs.shape[2:])
+    obs, nums = obs[:T], nums[:T]
+    B, K, N = obs.shape[1], int(F.k_particles), int(F.n_steps_per_image)
+    P = params32(F, hw, 0, 0.02, obs.mean((0, 1)))
+    noise = draw_noise(np.random.default_rng(4242 + cfg_id), T, B * K, N, 55)
+    ref = run_oracle(F, hw, P, obs, noise, nums=nums, dtype=torch.float32)
+    m = run_hip(F, hw, P, obs, noise, nums=nums, outputs=["log_weights_per_timestep", "discrete_log_prob", "presence"])
+    stable = presence_margins(ref.outputs, noise) >= MARGIN
+    agree = (m.presence.cpu().numpy() == ref.presence.numpy()).all((0, 2))
+    print("cfg-{} full batch ({} rows, {} frames): {} rows decision-stable, {} agree".format(cfg_id, stable.size, T, int(stable.sum()), int(agree.sum())))
+    assert stable.mean() > 0.95 and agree[stable].all()
+    a = m.log_weights.cpu().numpy().astype(np.float64).reshape(-1)[stable]
+    b = ref.log_weights.numpy().astype(np.float64).reshape(-1)[stable]
     assert np.abs(a - b).max() <= REL * np.abs(b).max()
     if agree.all():
         assert abs(float(m.elbo_iwae) - float(ref.elbo_iwae)) <= REL * abs(float(ref.elbo_iwae))
