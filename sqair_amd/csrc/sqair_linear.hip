@@ -1014,6 +1014,7 @@ int sq_launch_linear(const LinArgs& a_in, const PackedLayer& L, hipStream_t s, u
       if (const char* e = SQ_KNOB_STR("SQAIR_BIG_SHAPE")) {   // "TMW,TNW": forced tile (measurement)
         const int tm = e[0] - '0', tn = e[2] - '0';
 #define SQ_BIG_CASE(A, B) if (tm == A && tn == B) { launch_big<A, B>(a, L, s); return 0; }
+        SQ_BIG_CASE(1, 2) SQ_BIG_CASE(1, 3) SQ_BIG_CASE(1, 4)
         SQ_BIG_CASE(2, 2) SQ_BIG_CASE(2, 3) SQ_BIG_CASE(2, 4) SQ_BIG_CASE(3, 2) SQ_BIG_CASE(3, 3) SQ_BIG_CASE(3, 4)
         SQ_BIG_CASE(4, 2) SQ_BIG_CASE(4, 3) SQ_BIG_CASE(4, 4)
 #undef SQ_BIG_CASE
