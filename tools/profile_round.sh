@@ -12,8 +12,8 @@
 #                          segfaults inside rocprofv3 when the step is a 2000-node graph replay)
 #   rNN_profile_meta.json  build_id of the library the profiles were taken on + the commands
 #   rNN_bench.json, rNN_bench_cfg{4,5}.json   bench lines of the same build WITH cpu_baseline
-# usage: gpurun --timeout 1800 -- 'bash tools/profile_round.sh r05'
-R=${1:-r05}
+# usage: gpurun --timeout 1800 -- 'bash tools/profile_round.sh r06'
+R=${1:-r06}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$R
 mkdir -p $OUT
