@@ -317,3 +317,47 @@ def test_device_noise_is_standard_and_shard_invariant():
     shard.draw_noise(seed=7, step=3, global_batch=32, b0=16)
     torch.cuda.synchronize()
     assert torch.equal(shard.noise, full[:, 16 * 5:24 * 5])
+
+
+def test_dense_launch_census_and_graph_node_time():
+    """The measurement helpers behind profiles/r06_dense_b2b.json (tools/dense_graph_time.py): the host-side launch log reports the
+    746 dense launches bench.py's roofline divides the step's FLOPs by (60 of them the VanillaRNN layer with the slot tail in
+    front), and a HIP graph of one dense shape times a node in the low microseconds, a dependent chain not faster than a repeated one
+    by more than noise."""
+    from sqair_amd.data import config_inputs
+    from sqair_amd.model import Model, SqairCore
+    from tests.hip_util import params32
+    ov, obs, nums, _ = config_inputs(2)
+    F = make_flags(**ov)
+    hw = tuple(int(v) for v in obs.shape[2:])
+    core = SqairCore(F, hw)
+    core.set_params(params32(F, hw, 0, 0.02, obs.mean((0, 1))))
+    m = Model(obs, None, core, int(F.k_particles), presence=nums, outputs="minimal")
+    lib, h = core.lib, core.handle
+    m.run(use_graph=False)
+    assert lib.sqair_debug_dense_log(h, 1) == 0
+    m.run(use_graph=False)
+    n = lib.sqair_debug_dense_log(h, 0)
+    e = (C.c_int * 4)()
+    fused = 0
+    for i in range(n):
+        assert lib.sqair_debug_dense_log_entry(h, i, e) == 0
+        fused += e[0] < 0
+        assert e[1] >= 160 and e[2] % 16 == 0 and e[3] >= 4
+    assert (n, fused) == (746, 60)
+    m.run(use_graph=False)
+    assert lib.sqair_debug_dense_log(h, 0) == 746, "the log is off: a further pass adds nothing"
+    torch.cuda.set_stream(core.stream)
+    s = C.c_void_p(core.stream.cuda_stream)
+    M, K, N = 160, 256, 256
+    x, w, b = torch.randn(M, K, device="cuda") * 0.1, torch.randn(K, N, device="cuda") / 16, torch.zeros(N, device="cuda")
+    y = torch.zeros(M, N, device="cuda")
+    scratch = torch.zeros(2 * 16 * 16 * 256 + 2 * 16 * 16 + 256 + 2 * M * (K + 4) + 128, device="cuda")
+    us = {}
+    for dep in (0, 1):
+        out = C.c_float()
+        assert lib.sqair_debug_linear_graph_time(h, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, K, N, 2, scratch.data_ptr(),
+                                                 scratch.numel() * 4, 200, 5, dep, C.byref(out), s) == 0, lib.sqair_last_error(h)
+        us[dep] = float(out.value)
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    assert 1.0 < us[0] < 6.0 and 1.0 < us[1] < 6.0 and us[1] > us[0] - 0.2, us
