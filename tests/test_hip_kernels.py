@@ -360,4 +360,4 @@ def test_dense_launch_census_and_graph_node_time():
                                                  scratch.numel() * 4, 200, 5, dep, C.byref(out), s) == 0, lib.sqair_last_error(h)
         us[dep] = float(out.value)
     torch.cuda.set_stream(torch.cuda.default_stream())
-    assert 1.0 < us[0] < 6.0 and 1.0 < us[1] < 6.0 and us[1] > us[0] - 0.2, us
+    assert 1.0 < us[0] < 12.0 and 1.0 < us[1] < 12.0 and us[1] > us[0] - 0.5, us   # (loose: a timing, not a benchmark)
