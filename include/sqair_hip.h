@@ -272,6 +272,11 @@ int sqair_clear_workspace(SqairHandle* h, void* workspace, int64_t workspace_byt
  *   "tail_fusion" (default 1): compute the tail of slot k inside slot k + 1's VanillaRNN launch; 0 = one launch per
  *                 operation.  Results are bit-identical either way (tests/test_hip_forward.py); affects the following passes
  *                 and captures.
+ *   "what_fusion" (default 1): inference passes on the launch path compute a slot's what sample (what, what_loc, what_scale:
+ *                 sqair/core.py:226-229, :336-359) in the epilogue of the dense layer that produces its operands -- the glimpse
+ *                 encoder's Gaussian head of a discovery slot, the temporal cell's heads of a propagation slot -- instead of in
+ *                 the slot tail (csrc/sqair_glue.h: WhatArgs).  Results are bit-identical either way; re-capture graphs after
+ *                 changing it.  (Training passes and the slot chain always derive the sample in the tail.)
  *   "vi_target" (default 0): the learning signal sqair_elbo writes (and sqair_backward consumes) and the proxy loss in
  *                 scalars_out[2]: 0 = VIMCO, log w - control variate (sqair/targets.py:62-75: what the reference's make_target
  *                 uses); 1 = plain REINFORCE, log w (sqair/targets.py:78-89, advertised in Model.VI_TARGETS).

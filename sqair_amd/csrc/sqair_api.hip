@@ -397,6 +397,18 @@ static void build_plan(SqairHandle* h) {
   simple(L_GENC1, "enc.glimpse.l1", nh, nh);
   build_layer(h, L_WHAT_LOC, {nh}, {cb1(nw, 0, "enc.what_head.w", rm_range(0, nh), "enc.what_head.b")});
   simple(L_WHAT_HEAD, "enc.what_head", nh, 2 * nw);
+  {
+    // the same layer with its output columns INTERLEAVED (loc_c, scale_c adjacent): a discovery slot's what sample
+    // loc + scale * eps is then one lane pair of the layer's epilogue (k_linear_what, sqair_glue.hip) instead of 16 rows x nw
+    // elements re-derived in every column-tile workgroup of the next slot's fused RNN + tail launch.  Forward-only (inference):
+    // the training pass keeps L_WHAT_HEAD and its tape layout.
+    std::vector<ColBlock> bl;
+    for (int cc = 0; cc < nw; ++cc) {
+      bl.push_back(cb1(1, cc, "enc.what_head.w", rm_range(0, nh), "enc.what_head.b"));
+      bl.push_back(cb1(1, nw + cc, "enc.what_head.w", rm_range(0, nh), "enc.what_head.b"));
+    }
+    build_layer(h, L_WHAT_HEAD_I, {nh}, bl);
+  }
   // loop-invariant pre-activations of a propagation slot, segments [m1 (nw) | z_{t-1} record | temporal state]
   {
     const int tm1 = nw + (nw + 5);  // rnn input: [loc1 nw | what,where,pres (k-1) | what,where,pres (t-1) | temporal]
@@ -476,6 +488,26 @@ static void build_plan(SqairHandle* h) {
   build_layer(h, L_PROP_HEADS, {nh},
               {cb1(2 * nw, 0, "prop.what_head.w", rm_range(0, nh), "prop.what_head.b"),
                cb1(3 * nw, 0, "prop.gates.w", rm_range(0, nh), "prop.gates.b")});
+  {
+    // ... and the heads of a propagation slot with the FIVE pre-activations of a `what` element (temporal loc, temporal scale,
+    // forget / input / temporal gate: hraw columns c, nw + c, 2 nw + c, 3 nw + c, 4 nw + c) in five adjacent columns, three
+    // elements per 16-column tile (column 15 of a tile is empty): the gated what sample (sqair/core.py:336-359) is then computed by
+    // the lanes of the layer's epilogue.  Forward-only as well.
+    std::vector<ColBlock> bl;
+    auto empty = [&]() { ColBlock b; b.ncols = 1; b.col0 = 0; b.seg = {{"", RowMap()}}; return b; };
+    for (int t = 0; t < (nw + 2) / 3; ++t) {
+      for (int el = 0; el < 3; ++el) {
+        const int cc = 3 * t + el;
+        for (int g = 0; g < 5; ++g) {
+          if (cc >= nw) { bl.push_back(empty()); continue; }
+          if (g < 2) bl.push_back(cb1(1, g * nw + cc, "prop.what_head.w", rm_range(0, nh), "prop.what_head.b"));
+          else bl.push_back(cb1(1, (g - 2) * nw + cc, "prop.gates.w", rm_range(0, nh), "prop.gates.b"));
+        }
+      }
+      bl.push_back(empty());
+    }
+    build_layer(h, L_PROP_HEADS_I, {nh}, bl);
+  }
   {
     ColBlock b;
     b.ncols = nsp; b.col0 = 0;
@@ -857,6 +889,34 @@ static int run_rnn_tail(SqairHandle* h, const TailArgs& ta, Dims d, LayerId id, 
   return rc;
 }
 
+// A slot's what sample in the epilogue of the layer that produces its operands (WhatArgs, sqair_glue.h): the glimpse encoder's
+// Gaussian head of a discovery slot (mode 0, pack L_WHAT_HEAD_I) / the temporal cell's heads of a propagation slot (mode 1, pack
+// L_PROP_HEADS_I).  Inference passes of the product build on the launch path; the slot's tail then runs with `what_done`.
+static bool sq_what_fusion(const SqairHandle* h, bool train, bool chain) {
+#ifdef SQAIR_WIDE
+  (void)h; (void)train; (void)chain;
+  return false;
+#else
+  // (not in training passes: the layer would also have to write its own output to the tape for the adjoint -- scattered 4-byte stores
+  //  in the reference column order -- and the step was slower with it, 7.38 against 7.35 ms)
+  return h->opt_what_fusion && !train && !chain && (h->cfg.n_hidden == 128 || h->cfg.n_hidden == 256);
+#endif
+}
+static int run_what(SqairHandle* h, int mode, const float* x, int x_ld, int M, int slot, const float* noise, const float* enc, int enc_ld,
+                    const float* rec_prev, float* rec_new, const float* packed, hipStream_t s) {
+  const LayerId id = mode == 0 ? L_WHAT_HEAD_I : L_PROP_HEADS_I;
+  const PackedLayer& L = h->layers[id];
+  const PackedLayout pl = packed_layout(h);
+  WhatArgs a; memset(&a, 0, sizeof(a));
+  a.mode = mode; a.x = x; a.x_ld = x_ld; a.wp = packed + pl.w + L.w_off; a.wzero = packed + pl.w; a.bias = packed + pl.b + L.b_off;
+  a.M = M; a.kc = L.kc; a.n_tiles = L.nt; a.nw = h->cfg.n_what; a.N = h->cfg.n_steps_per_image; a.slot = slot; a.nzw = 4 + h->cfg.n_what + 1;
+  a.noise = noise; a.enc = enc; a.enc_ld = enc_ld; a.rec_prev = rec_prev; a.rec_new = rec_new; a.layer_id = (int)id;
+  if (h->dense_log_on) { const int e[4] = {(int)id, M, L.kc * 16, L.N}; h->dense_log.insert(h->dense_log.end(), e, e + 4); }
+  const int rc = sq_launch_linear_what(a, s);
+  if (rc != 0) sq_set_error(h, "internal: k_linear_what launch rejected (layer " + std::to_string((int)id) + ")");
+  return rc;
+}
+
 // three dependent slot layers: one launch each (a single multi-layer launch with in-launch hand-offs was built and
 // measured slower twice in round 1 -- tools/xcd_team.hip, DESIGN.md section 8 -- and left the library)
 #define RUN_CHAIN3(l0, id0, l1, id1, l2, id2, M) \
@@ -996,6 +1056,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
   static const int tail_rows = SQ_KNOB_INT("SQAIR_TAIL_FUSION_ROWS", SQAIR_TAIL_FUSION_ROWS_DEFAULT);
   const bool fuse_prop = d.R <= tail_rows && can_fuse_tail(h, L_PROP_RNN), fuse_disc = d.R <= tail_rows && can_fuse_tail(h, L_DISC_RNN);
   if (w.chain && !(fuse_prop && fuse_disc)) { sq_set_error(h, "slot chain: tail fusion off"); return -3; }
+  const bool fw = sq_what_fusion(h, train, w.chain);   // the what sample in the producing layer's epilogue (sqair_glue.h: WhatArgs)
   TailArgs pending_tail; memset(&pending_tail, 0, sizeof(pending_tail));
   for (int t = 0; (parts & 2) && t < T; ++t) {
     const int pp = t & 1, pn = pp ^ 1;
@@ -1139,12 +1200,14 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
                   .add(w.lpre + (size_t)k * 4 * nh, N * 4 * nh, 4 * nh).out(gates, gld);
         RUN(gl, L_PROP_GRU1, R);
         sq_launch_lstm_cell(gates, gld, tau_prev + (size_t)k * snh, N * snh, temporal_p + (size_t)k * snh, N * snh, R, nh, s);
-        Lin hd; hd.seg(temporal_p + (size_t)k * snh, N * snh, nh).out(hraw, hl); RUN(hd, L_PROP_HEADS, R);
+        if (fw) { const int rc = run_what(h, 1, temporal_p + (size_t)k * snh, N * snh, R, k, nz, enc, el, rec_prev, rec_p_t, packed, s); if (rc != 0) return rc; }
+        else { Lin hd; hd.seg(temporal_p + (size_t)k * snh, N * snh, nh).out(hraw, hl); RUN(hd, L_PROP_HEADS, R); }
       } else if (c.time_cell == CELL_VANILLA) {  // tau' = tanh(x W_i + [tau W_h + b, hoisted into `pre`]) in one launch
         Lin g; g.seg(r_k, rl, nh).seg(rec_p_t + (size_t)k * RW + rec::WHERE, N * RW, 4).seg(enc, el, 2 * nw)
                  .add(pre_k + rw + nh + nh / 2, pre_rld, nh).out(temporal_p + (size_t)k * nh, N * nh).act(ACT_TANH);
         RUN(g, L_PROP_GRU1, R);
-        Lin hd; hd.seg(temporal_p + (size_t)k * nh, N * nh, nh).out(hraw, hl); RUN(hd, L_PROP_HEADS, R);
+        if (fw) { const int rc = run_what(h, 1, temporal_p + (size_t)k * nh, N * nh, R, k, nz, enc, el, rec_prev, rec_p_t, packed, s); if (rc != 0) return rc; }
+        else { Lin hd; hd.seg(temporal_p + (size_t)k * nh, N * nh, nh).out(hraw, hl); RUN(hd, L_PROP_HEADS, R); }
       } else {
         const float* tau_k = temporal_prev + (size_t)k * nh;
         float* grh_k = w.chain ? w.slot(w.grh, nh, t, 0, k) : w.grh;   // (the chain: every slot's hand-offs in their own buffers)
@@ -1159,7 +1222,8 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
                    .gru2(tau_k, N * nh, gz, rl, nh);
         if (train) { g2l.a.o1 = w.slot(w.ghc, nh, t, 0, k); g2l.a.o1_ld = rl; }
         RUN(g2l, L_PROP_GRU2, R);
-        Lin hd; hd.seg(temporal_p + (size_t)k * nh, N * nh, nh).out(hraw, hl); RUN(hd, L_PROP_HEADS, R);
+        if (fw) { const int rc = run_what(h, 1, temporal_p + (size_t)k * nh, N * nh, R, k, nz, enc, el, rec_prev, rec_p_t, packed, s); if (rc != 0) return rc; }
+        else { Lin hd; hd.seg(temporal_p + (size_t)k * nh, N * nh, nh).out(hraw, hl); RUN(hd, L_PROP_HEADS, R); }
       }
       {
         TailArgs ta; memset(&ta, 0, sizeof(ta));
@@ -1168,6 +1232,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         ta.wp = packed + pl.w + h->layers[L_PROP_S1].w_off; ta.flat = flat;
         ta.w2_off = po.prop_steps_l1_w; ta.b2_off = po.prop_steps_l1_b;
         if (train) { ta.s1h_out = w.slot(w.s1h, S1_LD, t, 0, k); ta.s1h_ld = w.sld(S1_LD); }
+        ta.what_done = fw ? 1 : 0;
         if (fuse_prop && k + 1 < N) pending_tail = ta;  // computed inside the next slot's RNN launch
         else emit_tail(h, ta, d, s);
       }
@@ -1246,7 +1311,15 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         Lin a; a.seg(g2, gl2, G2).out(e1, rl).act(ACT_ELU);
         Lin b; b.seg(e1, rl, nh).out(e2, rl).act(ACT_ELU);
         Lin e; e.seg(e2, rl, nh).out(enc, el).act2(ACT_NONE, ACT_SOFTPLUS_MIN, nw);
-        RUN_CHAIN3(a, L_GENC0, b, L_GENC1, e, L_WHAT_HEAD, R);
+        if (fw) {   // the Gaussian head writes the slot's what sample itself (`enc` has no other reader in a discovery slot)
+          RUN(a, L_GENC0, R);
+          RUN(b, L_GENC1, R);
+          const int rc = run_what(h, 0, e2, rl, R, j, nz, nullptr, 0, nullptr, rec_d_t, packed, s);
+          if (rc != 0) return rc;
+
+        } else {
+          RUN_CHAIN3(a, L_GENC0, b, L_GENC1, e, L_WHAT_HEAD, R);
+        }
       }
       {
         TailArgs ta; memset(&ta, 0, sizeof(ta));
@@ -1255,6 +1328,7 @@ int sq_forward_impl(SqairHandle* h, const float* flat, const float* packed, cons
         ta.wp = packed + pl.w + h->layers[L_DISC_S1].w_off; ta.flat = flat;
         ta.w2_off = po.disc_steps_l1_w; ta.b2_off = po.disc_steps_l1_b;
         if (train) { ta.s1h_out = w.slot(w.s1h, S1_LD, t, 1, j); ta.s1h_ld = w.sld(S1_LD); }
+        ta.what_done = fw ? 1 : 0;
         if (fuse_disc && j + 1 < N) pending_tail = ta;
         else emit_tail(h, ta, d, s);
       }
@@ -1454,6 +1528,7 @@ extern "C" int sqair_set_option(SqairHandle* h, const char* name, int value) {
   if (!h || !name) return -1;
   const std::string n(name);
   if (n == "tail_fusion") { h->opt_tail_fusion = value != 0; return 0; }
+  if (n == "what_fusion") { h->opt_what_fusion = value != 0; return 0; }   // (results do not depend on it; drop captured graphs after changing it)
   if (n == "vi_target") {   // 0 = vimco (the reference's make_target), 1 = reinforce (targets.py:78-89)
     if (value != 0 && value != 1) { sq_set_error(h, "sqair_set_option: vi_target is 0 (vimco) or 1 (reinforce)"); return -2; }
     h->opt_vi_target = value;
@@ -1471,7 +1546,7 @@ extern "C" int sqair_set_option(SqairHandle* h, const char* name, int value) {
     if (sq_chain_set_arena_kb(h, value) != 0) { sq_set_error(h, "sqair_set_option: slot_chain_arena_kb is 64 .. 1048576, set before the first pass"); return -2; }
     return 0;
   }
-  sq_set_error(h, "sqair_set_option: unknown option '" + n + "' (known: tail_fusion, slot_chain, slot_chain_arena_kb, vi_target)");
+  sq_set_error(h, "sqair_set_option: unknown option '" + n + "' (known: tail_fusion, what_fusion, slot_chain, slot_chain_arena_kb, vi_target)");
   return -2;
 }
 

@@ -530,11 +530,10 @@ __device__ __forceinline__ void chain_tail(const TailArgs& a, const Dims& d, CH_
       } else {
         const float t_loc = v_h[q][0];
         const float t_scale = sq_softplus(v_h[q][1]) + 1e-2f;
-        const float fg = sq_sigmoid(v_h[q][2]) * 0.9999f;
-        const float ig = sq_sigmoid(v_h[q][3]) * 0.9999f;
-        const float tg = sq_sigmoid(v_h[q][4]) * 0.9999f;
-        loc = sq_mix3(fg, v_tm1[q], 1.0f - ig, v_loc[q], 1.0f - tg, t_loc);
-        sc = sq_mix2(1.0f - ig, v_sc[q], 1.0f - tg, t_scale);
+        const float fg = sq_gate(v_h[q][2]);
+        const float om_ig = sq_gate_compl(v_h[q][3]), om_tg = sq_gate_compl(v_h[q][4]);   // 1 - input gate, 1 - temporal gate
+        loc = sq_mix3(fg, v_tm1[q], om_ig, v_loc[q], om_tg, t_loc);
+        sc = sq_mix2(om_ig, v_sc[q], om_tg, t_scale);
       }
       const float what = loc + sc * v_eps[q];
       zt[rr * CH_ZLD + rec::WHAT + c] = what;

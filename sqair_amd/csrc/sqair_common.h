@@ -266,6 +266,12 @@ __device__ __forceinline__ float sq_mix2(float a, float x, float b, float y) { r
 __device__ __forceinline__ float sq_mix3(float a, float x, float b, float y, float c, float z) { return fmaf(c, z, fmaf(b, y, a * x)); }
 // GRU state update h' = (1 - z) h + z hc
 __device__ __forceinline__ float sq_gru_blend(float z, float h, float hc) { return sq_mix2(1.0f - z, h, z, hc); }
+// Gates of the propagated what sample (sqair/core.py:336-359): g = 0.9999 sigmoid(.), and 1 - g with ONE rounding, written out
+// as an explicit fused multiply-add: left to the compiler, `1.0f - sigmoid(x) * 0.9999f` is one fma where the product is not
+// needed elsewhere and two roundings where it is (e.g. when the gate itself travels through a wave shuffle) -- the slot tail, its
+// in-launch restatement and the layer epilogue that can take its place (k_linear_what) must agree to the last bit.
+__device__ __forceinline__ float sq_gate(float x) { return sq_sigmoid(x) * 0.9999f; }
+__device__ __forceinline__ float sq_gate_compl(float x) { return fmaf(-sq_sigmoid(x), 0.9999f, 1.0f); }
 __device__ __forceinline__ float sq_normal_lp(float x, float loc, float scale) {
   const float d = (x - loc) / scale;
   return -0.5f * d * d - logf(scale) - 0.91893853320467274178f;

@@ -131,7 +131,30 @@ struct TailArgs {
   const float* wp;                  // packed [nh/32 ... ] weights of the `what` rows of steps.l0 (layer *_S1)
   const float* flat; int w2_off, b2_off;
   float* s1h_out; int s1h_ld;       // optional (training): the hidden activations elu(.) [R, nh/2]
+  int what_done;                    // 1: the slot's what sample (what, what_loc, what_scale of rec_new) has been written by the layer that
+                                    // produces its operands (k_linear_what below): the tail reads `what` instead of deriving it
 };
+// "What fusion" (round 6; INFERENCE passes only -- in a training pass the layer would also have to write its own output to the tape for
+// the adjoint, in the reference column order: measured, 7.34 -> 7.38 ms per training step, against 7.35 without the fusion there): the what sample of a slot computed in the epilogue of the dense layer that
+// produces its last operands -- a discovery slot's in the glimpse encoder's Gaussian head (what = loc + scale eps,
+// sqair/core.py:226-229), a propagation slot's in the temporal cell's heads (the gated mixture of sqair/core.py:336-359) --
+// through packs whose output columns put the two / five pre-activations of one `what` element into adjacent lanes
+// (L_WHAT_HEAD_I, L_PROP_HEADS_I).  The element-wise work is then done ONCE per element by the lanes of one launch instead of
+// by every one of the 16 column-tile workgroups of the next slot's fused RNN + tail launch, whose per-workgroup instruction
+// stream is what that launch waits for (timing ablation: -2.8 % of the cfg-2 forward step).  Same arithmetic on the same
+// operands: results are bit-identical to the tail deriving the sample (tests/test_hip_forward.py).
+struct WhatArgs {
+  int mode;                          // 0: discovery (pairs loc, scale); 1: propagation (t_loc, t_scale, forget, input, temporal gate)
+  const float* x; int x_ld;          // A operand [M][K = 16 kc] (one segment, 16-byte aligned rows)
+  const float* wp; const float* wzero; const float* bias;   // interleaved pack of the layer, the packed buffer's zero block, packed bias
+  int M, kc, n_tiles, nw, N, slot, nzw;
+  const float* noise;                // noise of frame t [R][2][N][nzw]
+  const float* enc; int enc_ld;      // mode 1: glimpse-encoder Gaussian of the slot [R][loc nw | scale nw]
+  const float* rec_prev;             // mode 1: merged records of t - 1 [R][N][rec::W]
+  float* rec_new;                    // rec_p / rec_d of this frame: what, what_loc, what_scale of (row, slot) are written
+  int layer_id;                      // (for the host-side launch log)
+};
+int sq_launch_linear_what(const WhatArgs& a, hipStream_t s);
 int sq_launch_slot_tail(const TailArgs& a, Dims d, hipStream_t s);
 int sq_launch_rnn_tail(const TailArgs& ta, Dims d, const float* hid, int hid_ld, const float* wp, const float* bias, const float* add,
                        int add_ld, float* out, int out_ld, int n_out, hipStream_t s, unsigned long long* prof_ts);

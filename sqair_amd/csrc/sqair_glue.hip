@@ -141,11 +141,10 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
       const float tm1 = a.rec_prev[((size_t)r * d.N + a.slot) * rec::W + rec::WHAT + c];
       const float t_loc = hr[c];
       const float t_scale = sq_softplus(hr[nw + c]) + 1e-2f;
-      const float fg = sq_sigmoid(hr[2 * nw + c]) * 0.9999f;
-      const float ig = sq_sigmoid(hr[3 * nw + c]) * 0.9999f;
-      const float tg = sq_sigmoid(hr[4 * nw + c]) * 0.9999f;
-      const float l2 = sq_mix3(fg, tm1, 1.0f - ig, loc, 1.0f - tg, t_loc);
-      sc = sq_mix2(1.0f - ig, sc, 1.0f - tg, t_scale);
+      const float fg = sq_gate(hr[2 * nw + c]);
+      const float om_ig = sq_gate_compl(hr[3 * nw + c]), om_tg = sq_gate_compl(hr[4 * nw + c]);
+      const float l2 = sq_mix3(fg, tm1, om_ig, loc, om_tg, t_loc);
+      sc = sq_mix2(om_ig, sc, om_tg, t_scale);
       loc = l2;
     }
     const float what = loc + sc * eps;
@@ -204,7 +203,10 @@ constexpr int ZLD = 68;
 // Body shared by k_slot_tail (one workgroup per 16 rows, results to memory) and k_rnn_tail (every workgroup of the NEXT slot's RNN
 // layer re-derives the tail of its 16 rows and keeps the z-record in LDS as the layer's first A segment).  FULL_Z: also place
 // where / presence / logit into the LDS tile `zt` (the what columns are always there); STORE: write the results to memory.
-template <bool FULL_Z>
+// WD ("what done"): the slot's what sample was written by the layer that produced its operands (k_linear_what below) -- the tail
+// reads it instead of deriving it.  A TEMPLATE parameter: with both variants in one kernel the training pass, which never takes
+// the short one, ran 1 % slower (the slot loop's kernels are sensitive to their code size).
+template <bool FULL_Z, bool WD>
 __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, const int row0, const bool STORE, float* zt, float (*rs)[16]) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
   const int nw = d.nw, nsp = d.nh / 2;
@@ -244,6 +246,21 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
   constexpr int EPT = 4;
   const int nel = 16 * nw;
   float v_loc[EPT], v_sc[EPT], v_eps[EPT], v_h[EPT][5], v_tm1[EPT];
+  constexpr bool what_done = WD;
+  if (what_done) {
+    // the sample was written by the layer that produced its operands (k_linear_what): one load per element
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = min(tid + 256 * q, nel - 1);
+      const int rr = sq_div(e, d.nw_mul), c = e - rr * nw;
+      const int r = min(row0 + rr, d.R - 1);
+      v_loc[q] = a.rec_new[((size_t)r * d.N + a.slot) * rec::W + rec::WHAT + c];
+      v_sc[q] = 0.0f; v_eps[q] = 0.0f; v_tm1[q] = 0.0f;
+#pragma unroll
+      for (int g = 0; g < 5; ++g) v_h[q][g] = 0.0f;
+    }
+  }
+  if (!what_done) {
 #pragma unroll
   for (int q = 0; q < EPT; ++q) {
     const int e = min(tid + 256 * q, nel - 1);
@@ -263,10 +280,22 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
       v_tm1[q] = 0.0f;
     }
   }
+  }
   for (int i = tid; i < 16 * ZLD; i += 256) {  // everything but the `what` columns of the tile is zero
     const int c = i % ZLD;
     if (c < rec::WHAT || c >= rec::WHAT + nw) zt[i] = 0.0f;
   }
+  if (what_done) {
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = tid + 256 * q;
+      if (e < nel) {
+        const int rr = sq_div(e, d.nw_mul), c = e - rr * nw;
+        zt[rr * ZLD + rec::WHAT + c] = v_loc[q];
+      }
+    }
+  }
+  if (!what_done) {
 #pragma unroll
   for (int q = 0; q < EPT; ++q) {
     const int e = tid + 256 * q;
@@ -279,11 +308,10 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
       } else {
         const float t_loc = v_h[q][0];
         const float t_scale = sq_softplus(v_h[q][1]) + 1e-2f;
-        const float fg = sq_sigmoid(v_h[q][2]) * 0.9999f;
-        const float ig = sq_sigmoid(v_h[q][3]) * 0.9999f;
-        const float tg = sq_sigmoid(v_h[q][4]) * 0.9999f;
-        loc = sq_mix3(fg, v_tm1[q], 1.0f - ig, v_loc[q], 1.0f - tg, t_loc);
-        sc = sq_mix2(1.0f - ig, v_sc[q], 1.0f - tg, t_scale);
+        const float fg = sq_gate(v_h[q][2]);
+        const float om_ig = sq_gate_compl(v_h[q][3]), om_tg = sq_gate_compl(v_h[q][4]);   // 1 - input gate, 1 - temporal gate
+        loc = sq_mix3(fg, v_tm1[q], om_ig, v_loc[q], om_tg, t_loc);
+        sc = sq_mix2(om_ig, v_sc[q], om_tg, t_scale);
       }
       const float what = loc + sc * v_eps[q];
       zt[rr * ZLD + rec::WHAT + c] = what;
@@ -294,6 +322,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
         rn[rec::WHAT_SCALE + c] = sc;
       }
     }
+  }
   }
   __syncthreads();
   // ---- hidden layer: acc = what W_what  (K = 56 padded to 64)
@@ -351,11 +380,16 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const Dims& d, cons
 
 #endif
 
+template <bool WD>
 __global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims d SQ_TLP) {
   SQ_TL_SCOPE;
   __shared__ __attribute__((aligned(16))) float zt[16 * ZLD];
   __shared__ float rs[4][16];
-  tail_body<false>(a, d, blockIdx.x * 16, true, zt, rs);
+#ifdef SQAIR_WIDE
+  tail_body<false>(a, d, blockIdx.x * 16, true, zt, rs);   // (the wide build has no what fusion: WD is always false there)
+#else
+  tail_body<false, WD>(a, d, blockIdx.x * 16, true, zt, rs);
+#endif
 }
 
 #ifndef SQAIR_WIDE
@@ -368,7 +402,7 @@ __global__ __launch_bounds__(256) void k_slot_tail(const TailArgs a, const Dims 
 // ~1 us of redundant work inside the layer.  The RNN part is k_linear's arithmetic (4 waves split the K chunks g = wave + 4 i in
 // order, two accumulators, LDS reduce), so the layer's result does not depend on whether the tail was fused.
 // ------------------------------------------------------------------------------------------------
-template <int NH, int TN>  // hidden-state chunks per wave = nh / 64; TN column tiles per workgroup (the tail is derived once for them)
+template <int NH, int TN, bool WD>  // hidden-state chunks per wave = nh / 64; TN column tiles per workgroup (the tail is derived once for them); WD: tail_body
 __global__ __launch_bounds__(256) void k_rnn_tail(const TailArgs ta, const Dims d, const float* __restrict__ hid, const int hid_ld,
                                                   const float* __restrict__ wp0, const float* __restrict__ bias,
                                                   const float* __restrict__ add, const int add_ld, float* __restrict__ out,
@@ -408,7 +442,7 @@ __global__ __launch_bounds__(256) void k_rnn_tail(const TailArgs ta, const Dims 
     p_add[t] = add[(size_t)mc * add_ld + nc];
   }
   __builtin_amdgcn_sched_barrier(0);
-  tail_body<true>(ta, d, row0, blockIdx.x == 0, zt, rs);
+  tail_body<true, WD>(ta, d, row0, blockIdx.x == 0, zt, rs);
   __syncthreads();
   const f32x4_t az = *reinterpret_cast<const f32x4_t*>(&zt[l15 * ZLD + 16 * wave + 4 * kq]);
 #pragma unroll
@@ -452,8 +486,116 @@ __global__ __launch_bounds__(256) void k_rnn_tail(const TailArgs ta, const Dims 
 
 #endif
 
+#ifndef SQAIR_WIDE
+// ------------------------------------------------------------------------------------------------
+// A slot's what sample in the epilogue of the dense layer that produces its operands (WhatArgs, sqair_glue.h).  The GEMM part is
+// k_linear's (sqair_linear_kernel.inc: one 16 x 16 tile per workgroup, four waves on the K chunks g = wave + 4 j, two accumulators,
+// LDS reduce in wave order), so a column's sum is the same number the plain layer writes; the packs put the 2 (discovery) / 5
+// (propagation) pre-activations of one `what` element into adjacent lanes of a row, which exchange them with wave shuffles.
+//   MODE 0  glimpse-encoder head of a DISCOVERY slot (sqair/core.py:226-229): columns (loc_c, raw scale_c), 8 elements per tile;
+//           scale = softplus(.) + 1e-2, what = loc + scale eps -> rec_d.{what, what_loc, what_scale}
+//   MODE 1  heads of a PROPAGATION slot (sqair/core.py:336-359): columns (t_loc, t_scale, forget, input, temporal gate) of element
+//           c, 3 elements per tile; the gated mixture with the glimpse encoder's Gaussian and what_{t-1} -> rec_p.{...}
+// Arithmetic = tail_body's, expression by expression.
+// ------------------------------------------------------------------------------------------------
+template <int NCH, int MODE>
+__global__ __launch_bounds__(256) void k_linear_what(const WhatArgs a SQ_TLP) {
+  SQ_TL_SCOPE;
+  __shared__ float red[4 * 256];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
+  const int tile_n = blockIdx.x, tile_m = blockIdx.y;
+  const int arow = min(tile_m * 16 + l15, a.M - 1);
+  const f32x4_t* __restrict__ wp = reinterpret_cast<const f32x4_t*>(a.wp) + ((size_t)tile_n * a.kc) * 64 + lane;
+  const f32x4_t* __restrict__ wz = reinterpret_cast<const f32x4_t*>(a.wzero) + lane;
+  const int nmine = (a.kc - wave + 3) >> 2;
+  const float* __restrict__ rp = a.x + (size_t)arow * a.x_ld + kq * 4;
+  f32x4_t av[NCH], bv[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const bool valid = j < nmine;
+    const int g = valid ? wave + 4 * j : wave;
+    av[j] = *reinterpret_cast<const f32x4_t*>(rp + g * 16);
+    bv[j] = *(valid ? wp + (size_t)g * 64 : wz);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // epilogue operands, requested behind the operand loads and ahead of the MFMAs (clamped addresses, every lane)
+  const int m = tile_m * 16 + (tid >> 4), col = tid & 15, mc = min(m, a.M - 1);
+  const float p_bias = a.bias[tile_n * 16 + col];
+  const int c = MODE == 0 ? tile_n * 8 + (col >> 1) : tile_n * 3 + col / 5;
+  const int g5 = MODE == 0 ? (col & 1) : col % 5;
+  const bool valid = c < a.nw && (MODE == 0 || col < 15) && m < a.M;
+  const int cc = min(c, a.nw - 1);
+  const float eps = a.noise[(((size_t)mc * 2 + (MODE == 0 ? 1 : 0)) * a.N + a.slot) * a.nzw + 4 + cc];
+  float e_loc = 0.0f, e_sc = 0.0f, tm1 = 0.0f;
+  if (MODE == 1) {
+    e_loc = a.enc[(size_t)mc * a.enc_ld + cc];
+    e_sc = a.enc[(size_t)mc * a.enc_ld + a.nw + cc];
+    tm1 = a.rec_prev[((size_t)mc * a.N + a.slot) * rec::W + rec::WHAT + cc];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4_t acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
+  }
+  float* r = red + wave * 256;
+  r[(4 * kq + 0) * 16 + l15] = acc0.x + acc1.x;
+  r[(4 * kq + 1) * 16 + l15] = acc0.y + acc1.y;
+  r[(4 * kq + 2) * 16 + l15] = acc0.z + acc1.z;
+  r[(4 * kq + 3) * 16 + l15] = acc0.w + acc1.w;
+  __syncthreads();
+  const float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid] + p_bias;
+  float* rn = a.rec_new + ((size_t)mc * a.N + a.slot) * rec::W;
+  if (MODE == 0) {
+    const float t = g5 ? sq_softplus(v) + 1e-2f : v;
+    const float sc = sq_dpp<0x101>(t);   // row_shl:1 -- lane i takes lane i + 1 of its row of 16 (an exact copy; no LDS round trip)
+    if (g5 == 0 && valid) {
+      const float loc = t;
+      const float what = loc + sc * eps;
+      rn[rec::WHAT + c] = what;
+      rn[rec::WHAT_LOC + c] = loc;
+      rn[rec::WHAT_SCALE + c] = sc;
+    }
+  } else {
+    // lane g of an element: temporal loc | temporal scale | forget gate | 1 - input gate | 1 - temporal gate
+    const float t = g5 == 0 ? v : (g5 == 1 ? sq_softplus(v) + 1e-2f : (g5 == 2 ? sq_gate(v) : sq_gate_compl(v)));
+    const float t_scale = sq_dpp<0x101>(t), fg = sq_dpp<0x102>(t), om_ig = sq_dpp<0x103>(t), om_tg = sq_dpp<0x104>(t);   // row_shl:1..4
+    if (g5 == 0 && valid) {
+      const float t_loc = t;
+      const float loc = sq_mix3(fg, tm1, om_ig, e_loc, om_tg, t_loc);
+      const float sc = sq_mix2(om_ig, e_sc, om_tg, t_scale);
+      const float what = loc + sc * eps;
+      rn[rec::WHAT + c] = what;
+      rn[rec::WHAT_LOC + c] = loc;
+      rn[rec::WHAT_SCALE + c] = sc;
+    }
+  }
+}
+#endif
+int sq_launch_linear_what(const WhatArgs& a, hipStream_t s) {
+#ifdef SQAIR_WIDE
+  (void)a; (void)s;
+  return -1;
+#else
+  if ((reinterpret_cast<uintptr_t>(a.x) & 15) != 0 || (a.x_ld & 3) != 0 || a.M < 1 || (a.kc != 16 && a.kc != 8)) return -5;
+  const dim3 g(a.n_tiles, (a.M + 15) / 16);
+  if (a.kc == 16) {
+    if (a.mode == 0) SQ_LAUNCH((k_linear_what<4, 0>), g, dim3(256), 0, s, a);
+    else SQ_LAUNCH((k_linear_what<4, 1>), g, dim3(256), 0, s, a);
+  } else {
+    if (a.mode == 0) SQ_LAUNCH((k_linear_what<2, 0>), g, dim3(256), 0, s, a);
+    else SQ_LAUNCH((k_linear_what<2, 1>), g, dim3(256), 0, s, a);
+  }
+  return 0;
+#endif
+}
+
 int sq_launch_slot_tail(const TailArgs& a, Dims d, hipStream_t s) {
-  SQ_LAUNCH(k_slot_tail, dim3((d.R + 15) / 16), dim3(256), 0, s, a, d);
+  if (a.what_done) SQ_LAUNCH(k_slot_tail<true>, dim3((d.R + 15) / 16), dim3(256), 0, s, a, d);
+  else SQ_LAUNCH(k_slot_tail<false>, dim3((d.R + 15) / 16), dim3(256), 0, s, a, d);
   return 0;
 }
 // tail of slot `ta.slot` + the VanillaRNN layer of the next slot: out = tanh([z-record | hid] W + bias + add); wp / bias point at
@@ -474,15 +616,21 @@ int sq_launch_rnn_tail(const TailArgs& ta, Dims d, const float* hid, int hid_ld,
   static const int two_from = SQ_KNOB_INT("SQAIR_RNN_TAIL_TN2_TILES", SQAIR_RNN_TAIL_TN2_TILES_DEFAULT);
   if (nt * mt >= two_from && nt >= 2) {
     const dim3 g((nt + 1) / 2, mt);
-    if (d.nh == 256) SQ_LAUNCH((k_rnn_tail<4, 2>), g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
-    else if (d.nh == 128) SQ_LAUNCH((k_rnn_tail<2, 2>), g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
+#define SQ_RT(NH, TN)                                                                                                              \
+    do {                                                                                                                             \
+      if (ta.what_done) SQ_LAUNCH((k_rnn_tail<NH, TN, true>), g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts); \
+      else SQ_LAUNCH((k_rnn_tail<NH, TN, false>), g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts); \
+    } while (0)
+    if (d.nh == 256) SQ_RT(4, 2);
+    else if (d.nh == 128) SQ_RT(2, 2);
     else return -1;
     return 0;
   }
   const dim3 g(nt, mt);
-  if (d.nh == 256) SQ_LAUNCH((k_rnn_tail<4, 1>), g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
-  else if (d.nh == 128) SQ_LAUNCH((k_rnn_tail<2, 1>), g, dim3(256), 0, s, ta, d, hid, hid_ld, wp, bias, add, add_ld, out, out_ld, n_out, prof_ts);
+  if (d.nh == 256) SQ_RT(4, 1);
+  else if (d.nh == 128) SQ_RT(2, 1);
   else return -1;
+#undef SQ_RT
   return 0;
 #endif
 }

@@ -16,7 +16,9 @@ enum LayerId {
   L_IENC0, L_IENC1, L_PREDISC, L_PRIOR_GRU1, L_PRIOR_GRU2, L_PRIOR_LIN, L_TAU1, L_WB2, L_MASK2, L_GENC0, L_GENC1,
   L_WHAT_LOC, L_WHAT_HEAD, L_PRE, L_PROP_RNN, L_PROP_T1, L_PROP_T2, L_PROP_T3, L_PROP_GRU1, L_PROP_GRU2,
   L_PROP_HEADS, L_PROP_S1, L_LAT0, L_LAT1, L_PRED, L_RNCOND, L_DISC_RNN, L_DISC_T1, L_DISC_T2, L_DISC_T3,
-  L_DISC_S1, L_DEC0, L_DEC1, L_DEC2, L_PROP_RNN2, L_DISC_RNN2, L_COUNT
+  L_DISC_S1, L_DEC0, L_DEC1, L_DEC2, L_PROP_RNN2, L_DISC_RNN2,
+  L_WHAT_HEAD_I, L_PROP_HEADS_I,   // forward-only packs with interleaved output columns (what fusion, sqair_glue.h: WhatArgs)
+  L_COUNT
 };
 
 struct SqairHandle {
@@ -62,6 +64,7 @@ struct SqairHandle {
   bool dense_log_on = false;           // sqair_debug_dense_log: {layer id, rows, K (padded to 16 per segment), N} of every dense launch
   std::vector<int> dense_log;          // of the passes issued while it was on (host side only: nothing changes on the device)
   float debug_us = 0.0f;
+  bool opt_what_fusion = true;  // sqair_set_option("what_fusion"): the what sample of a slot inside the layer that produces its operands (bit-identical)
   bool opt_tail_fusion = true;  // sqair_set_option("tail_fusion"): the tail of slot k inside slot k + 1's RNN launch (bit-identical either way)
   bool opt_slot_chain = false;  // sqair_set_option("slot_chain"): the slot launches of a frame's propagation / discovery loop as one
                                 // persistent launch each (sqair_chain.h; bit-identical; set BEFORE sizing / clearing workspaces)

@@ -50,7 +50,7 @@ def run_chain_case(flags, hw, T, B, seed):
     from tests.test_slot_chain import _inputs, _run
     K, N = flags["k_particles"], flags["n_steps_per_image"]
     extra = {k: v for k, v in flags.items() if k not in ("k_particles", "n_steps_per_image")}
-    F, d, obs, P, noise = _inputs(B, K, N, T, hw, seed=seed, **extra)
+    F, d, obs, P, noise = _inputs(B, K, N, T, hw, seed=seed, obj_size=max(2, min(20, min(hw) // 2)), **extra)
     _, _, ref = _run(F, hw, d, obs, P, noise, K, chain=False, use_graph=False)
     for use_graph in (False, True):
         _, _, got = _run(F, hw, d, obs, P, noise, K, chain=True, use_graph=use_graph)   # (debug on: every chain launch's status is checked)

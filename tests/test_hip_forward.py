@@ -444,6 +444,61 @@ def test_tail_fused_into_the_next_rnn_layer_is_bitwise_identical(K, N, T, B, n_u
     assert float(plain["presence"].sum()) > 0
 
 
+@pytest.mark.parametrize("B,K,N,T,hw,flags", [
+    (32, 5, 4, 3, (50, 50), {}),                                           # BASELINE configs[1] rows
+    (7, 3, 5, 2, (37, 41), {}),                                            # ragged rows, a frame that is not a multiple of 4 floats
+    (3, 2, 1, 2, (50, 50), {}),                                            # one slot: only the un-fused final tails
+    (5, 2, 3, 2, (50, 50), dict(n_what=10)),                               # 10 elements: one heads tile short of full, ragged pairs
+    (4, 3, 3, 2, (50, 50), dict(n_what=33, n_units=4)),                    # n_hidden 128 (two chunks per wave), 33 = 11 x 3 elements
+    (4, 2, 2, 3, (50, 50), dict(time_transition="LSTM")),                  # LSTM temporal cell: heads on the hidden half of [h | c]
+    (4, 2, 2, 2, (50, 50), dict(time_transition="VanillaRNN", transition="GRU")),   # un-fused tails after a GRU slot cell
+    (6, 2, 3, 3, (50, 50), dict(sample_from_prior=True, generate_after=1)),         # generation modes read the same records
+    (5, 3, 8, 2, (72, 64), dict(masked_glimpse=False, prop_prior_type="rw"))])      # eight slots, a frame beyond the staged crop
+def test_what_fusion_is_bit_identical(B, K, N, T, hw, flags):
+    """The what sample of a slot computed in the epilogue of the layer that produces its operands (option what_fusion, default
+    on for inference passes: sqair_glue.h WhatArgs, packs L_WHAT_HEAD_I / L_PROP_HEADS_I) against the slot tail deriving it:
+    the same arithmetic on the same operands -- every output bit for bit, eager and as a graph replay."""
+    from sqair_amd.model import Model, SqairCore
+    F = make_flags(k_particles=K, n_steps_per_image=N, **flags)
+    d = make_sequences(B, T=T, canvas=hw, seed=13)
+    obs = to_float(d["imgs"])
+    P = params32(F, hw, 3, 0.05, obs.mean((0, 1)))
+    rng = np.random.default_rng(7)
+    nzw = 4 + int(F.n_what) + 1
+    noise, gen_noise = draw_noise(rng, T, B * K, N, nzw), draw_noise(rng, T, B * K, N, nzw)
+
+    def run(fusion, use_graph):
+        core = SqairCore(F, hw, options={"what_fusion": int(fusion)})
+        core.set_params(P)
+        m = Model(obs, None, core, K, presence=d["nums"])
+        m.run(noise=noise, use_graph=use_graph, gen_noise=gen_noise if flags.get("sample_from_prior") else None)
+        torch.cuda.synchronize()
+        out = {k: v.detach().cpu().numpy().copy() for k, v in core.out.items()}
+        out["log_weights"] = core.log_weights.cpu().numpy().copy()
+        return out, core.lib.sqair_graph_nodes(core.handle) if use_graph else 0
+
+    ref, _ = run(False, False)
+    assert float(ref["presence"].sum()) > 0
+    for use_graph in (False, True):
+        got, nodes = run(True, use_graph)
+        for k, v in ref.items():
+            assert np.array_equal(v, got[k], equal_nan=True), (k, use_graph)
+    _, nodes_off = run(False, True)
+    assert nodes == nodes_off, "the fusion replaces launches one for one"
+    # (a training pass does not take the fusion: its results equal the inference pass's all the same)
+    core = SqairCore(F, hw)
+    core.set_params(P)
+    Model(obs, None, core, K, presence=d["nums"])
+    with core.on_stream():
+        core.noise.copy_(torch.as_tensor(noise).reshape(core.noise.shape))
+        if not flags.get("sample_from_prior"):
+            core.forward(train=True)
+            core.stream.synchronize()
+            for k, v in ref.items():
+                if k in core.out:
+                    assert np.array_equal(v, core.out[k].detach().cpu().numpy(), equal_nan=True), (k, "train")
+
+
 @pytest.mark.parametrize("options", [None, CHAIN], ids=["launches", "slot_chain"])
 def test_cfg2_full_batch_against_the_fp32_oracle(options):
     """BASELINE configs[1] at FULL size (all 32 sequences x 5 particles x 10 frames) against the oracle in fp32 — the

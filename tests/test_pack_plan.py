@@ -14,7 +14,7 @@ from sqair_amd.params import flatten_params, init_params, param_spec
 
 LAYERS = ("IENC0 IENC1 PREDISC PRIOR_GRU1 PRIOR_GRU2 PRIOR_LIN TAU1 WB2 MASK2 GENC0 GENC1 WHAT_LOC WHAT_HEAD PRE PROP_RNN "
           "PROP_T1 PROP_T2 PROP_T3 PROP_GRU1 PROP_GRU2 PROP_HEADS PROP_S1 LAT0 LAT1 PRED RNCOND DISC_RNN DISC_T1 DISC_T2 "
-          "DISC_T3 DISC_S1 DEC0 DEC1 DEC2 PROP_RNN2 DISC_RNN2").split()
+          "DISC_T3 DISC_S1 DEC0 DEC1 DEC2 PROP_RNN2 DISC_RNN2 WHAT_HEAD_I PROP_HEADS_I").split()
 NW, NH = 50, 256
 
 
@@ -197,3 +197,27 @@ def test_cell_variant_composites(rnn):
         assert np.allclose(pg, np.concatenate([xp, hid], -1) @ P["prop.prior_lstm.w"] + P["prop.prior_lstm.b"], atol=1e-9)
     finally:
         plan.lib.sqair_destroy(plan.h)
+
+
+def test_interleaved_forward_packs_hold_the_same_columns(plan):
+    """The forward-only packs of the what fusion (sqair_glue.h: WhatArgs) are column permutations of the layers they stand in for:
+    WHAT_HEAD_I column 2 c / 2 c + 1 = WHAT_HEAD column c / nw + c (loc, scale of element c); PROP_HEADS_I column 16 t + 5 e + g =
+    PROP_HEADS column g nw + 3 t + e (the five pre-activations of element 3 t + e), every other column of a tile empty."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, NH))
+    ref, got = plan.apply("WHAT_HEAD", x), plan.apply("WHAT_HEAD_I", x)
+    assert got.shape[-1] == 2 * NW
+    for c in range(NW):
+        assert np.array_equal(got[:, 2 * c], ref[:, c]) and np.array_equal(got[:, 2 * c + 1], ref[:, NW + c])
+    ref = plan.apply("PROP_HEADS", x)
+    W, bias, widths, n = plan.layer("PROP_HEADS_I")
+    full = x @ W[:NH] + bias
+    nt = (NW + 2) // 3
+    assert n == 16 * nt and W.shape[1] == 16 * nt
+    for t in range(nt):
+        for e in range(3):
+            c = 3 * t + e
+            for g in range(5):
+                col = full[:, 16 * t + 5 * e + g]
+                assert np.array_equal(col, ref[:, g * NW + c]) if c < NW else not col.any()
+        assert not full[:, 16 * t + 15].any()

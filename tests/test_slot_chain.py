@@ -14,9 +14,11 @@ from tests.hip_util import draw_noise, params32
 pytestmark = pytest.mark.gpu
 
 
-def _inputs(B, K, N, T, hw, seed=3, **flags):
+def _inputs(B, K, N, T, hw, seed=3, obj_size=None, **flags):
     F = make_flags(k_particles=K, n_steps_per_image=N, **flags)
-    d = make_sequences(B, T=T, canvas=hw, seed=seed)
+    # (obj_size: tests/fuzz_forward.py draws canvases down to 8 x 8 -- the generator, like the reference's, re-draws a sample until
+    #  its objects fit without overlap, i.e. for ever when they cannot)
+    d = make_sequences(B, T=T, canvas=hw, seed=seed, **({"obj_size": obj_size} if obj_size else {}))
     obs = to_float(d["imgs"])
     P = params32(F, hw, 0, 0.05, obs.mean((0, 1)))
     noise = draw_noise(np.random.default_rng(seed), T, B * K, N, 4 + int(F.n_what) + 1)

@@ -41,7 +41,7 @@ def main():
             continue
         out[k] = dict(launches=max(nf, nw, 1), fetch_kb_raw=f / max(nf, 1), write_kb=w / max(nw, 1),
                       hbm_bytes_per_launch=(2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0)
-    dense = {k: v for k, v in out.items() if k.startswith(("k_linear<", "k_linear_rows", "k_linear_mt"))}
+    dense = {k: v for k, v in out.items() if k.startswith(("k_linear<", "k_linear_what<", "k_linear_rows", "k_linear_mt"))}
     tot_n = sum(v["launches"] for v in dense.values())
     dom = max(dense, key=lambda k: dense[k]["launches"]) if dense else None
     fam = collections.defaultdict(lambda: [0, 0.0])

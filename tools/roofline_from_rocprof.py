@@ -15,7 +15,7 @@ def dense_average_ns(path):
     per = {}
     for r in csv.DictReader(open(path)):
         name = r["Name"].replace("void ", "")
-        if name.startswith(("k_linear<", "k_linear_rows", "k_linear_mt")):
+        if name.startswith(("k_linear<", "k_linear_what<", "k_linear_rows", "k_linear_mt")):
             tot += float(r["TotalDurationNs"])
             calls += float(r["Calls"])
             per[name.split("(")[0]] = (int(r["Calls"]), float(r["AverageNs"]))
