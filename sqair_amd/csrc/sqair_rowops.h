@@ -215,28 +215,41 @@ __device__ void x_crop_row(const CropArgs& a, const POff& po, const Dims& d, int
           a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + p0 + 256 * u] = has_mask ? v * mk[u] : v;
         }
     }
-  } else
-  for (int pix = tid, q = 0; pix < G2; pix += 256, ++q) {
-    const float mk = q < MPT ? mk0[q < MPT ? q : 0] : (has_mask ? LD::f(a.mask + ((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix) : 1.0f);
-    const int i = sq_div(pix, d.g_mul), j = pix - i * G;
-    const float x0f = tab_s[j * 2], wx1 = tab_s[j * 2 + 1];
-    const float y0f = tab_s[(G + i) * 2], wy1 = tab_s[(G + i) * 2 + 1];
-    const int x0 = (int)x0f, y0 = (int)y0f;
-    float v = 0.0f;
+  } else {
+    // Frame staged in LDS: the same four taps per glimpse pixel out of `img_s`, TWO pixels of a thread at once and without branches
+    // (unconditional reads from clamped positions, taps outside the frame get weight zero): a 20 x 20 glimpse is two rounds of 256
+    // threads, each a dependent chain table read -> tap reads -> sum -> store that used to run one after the other.  Same products
+    // in the same order: a tap outside the frame adds fma(0, x, v) = v where the branchy form skipped it.
+    constexpr int PX = MPT;
+    for (int p0 = tid, it = 0; p0 < G2; p0 += 256 * PX, ++it) {
+      float tv[PX][4], tw[PX][4], mk[PX];
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-      const int yy = y0 + dy;
-      const float wy = dy ? wy1 : 1.0f - wy1;
-      if (yy < 0 || yy >= d.H) continue;
+      for (int u = 0; u < PX; ++u) {
+        const int pix = min(p0 + 256 * u, G2 - 1);
+        mk[u] = it == 0 ? mk0[u] : (has_mask ? LD::f(a.mask + ((size_t)r * a.mask_row_mul + mrow_add) * G2 + pix) : 1.0f);
+        const int i = sq_div(pix, d.g_mul), j = pix - i * G;
+        const float x0f = tab_s[j * 2], wx1 = tab_s[j * 2 + 1];
+        const float y0f = tab_s[(G + i) * 2], wy1 = tab_s[(G + i) * 2 + 1];
+        const int x0 = (int)x0f, y0 = (int)y0f;
 #pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        const int xx = x0 + dx;
-        const float wx = dx ? wx1 : 1.0f - wx1;
-        if (xx < 0 || xx >= d.W) continue;
-        v += wy * wx * src[yy * d.W + xx];
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int yy = y0 + dy, xx = x0 + dx;
+            const bool ok = yy >= 0 && yy < d.H && xx >= 0 && xx < d.W;
+            tv[u][dy * 2 + dx] = src[min(max(yy, 0), d.H - 1) * d.W + min(max(xx, 0), d.W - 1)];
+            tw[u][dy * 2 + dx] = ok ? (dy ? wy1 : 1.0f - wy1) * (dx ? wx1 : 1.0f - wx1) : 0.0f;
+          }
       }
+#pragma unroll
+      for (int u = 0; u < PX; ++u)
+        if (p0 + 256 * u < G2) {
+          float v = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v += tw[u][q] * tv[u][q];
+          a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + p0 + 256 * u] = has_mask ? v * mk[u] : v;
+        }
     }
-    a.out[((size_t)r * a.out_row_mul + orow_add) * G2 + pix] = has_mask ? v * mk : v;
   }
   __syncthreads();
 }
